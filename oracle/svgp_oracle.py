@@ -1,0 +1,515 @@
+"""CPU oracle for the SVGP ELBO / posterior path of ApproximateGPs.jl v0.4.6.
+
+TEST INFRASTRUCTURE ONLY.  Nothing under ``approximategps.jl_amd/`` (the product)
+may import this module; only ``tests/``, ``__graft_entry__.smoke()`` and the
+``cpu_baseline`` leg of ``bench.py`` do, and there only as the checker / the
+timed CPU baseline -- never as the thing shipped.
+
+PARITY UNPINNED (numerically): the reference is pure Julia, Julia is not
+installed in the build container, and the reference's own tests hold no golden
+numbers for this path (test/SparseVariationalApproximationModule.jl is made of
+equivalences and bounds only).  This restatement is therefore pinned by
+  * every input-independent assertion of the reference's test file, re-stated
+    over seeded inputs in tests/test_oracle_*.py (Centered == NonCentered,
+    elbo <= logpdf, FiniteGP call == LatentGP+Gaussian call, z = x + optimal q
+    == exact GPR, heteroscedastic noise -> error), and
+  * derived known-answer tests (Titsias collapsed bound, GH == analytic for a
+    Gaussian likelihood, K_uf' alpha == A' m, 50-digit mpmath restatement in
+    oracle/svgp_oracle_mp.py),
+not by reference outputs.
+
+Every function cites the reference lines it follows.  Paths are relative to
+/root/reference; ``SVA`` = src/SparseVariationalApproximationModule.jl.
+Behaviour that lives in un-vendored Julia dependencies (AbstractGPs,
+KernelFunctions, GPLikelihoods, PDMats, Distributions, FastGaussQuadrature) is
+restated from their published semantics and marked [dep].
+
+The operation order is the reference's: materialise Kuf, trsm, trmm, elementwise
+reductions (SVA:215-219, 246-253).  numpy / scipy-OpenBLAS, fp64 unless a dtype
+is passed.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+from typing import Optional, Tuple
+
+import numpy as np
+import scipy.linalg as sla
+from scipy.special import gammaln
+
+# ----------------------------------------------------------------------------
+# constants of the dependency layer
+# ----------------------------------------------------------------------------
+DEFAULT_SIGMA2 = 1e-18  # [dep] AbstractGPs.default_σ² used by f_post(x) (SVA:354)
+DEFAULT_GH_POINTS = 20  # [dep] GPLikelihoods.DefaultExpectationMethod -> GaussHermiteExpectation(20)
+
+KERNEL_SE = 0
+KERNEL_MATERN32 = 1
+KERNEL_MATERN52 = 2
+
+LIK_GAUSSIAN = 0
+LIK_BERNOULLI_LOGISTIC = 1
+LIK_POISSON_EXP = 2
+
+_SQRT3 = math.sqrt(3.0)
+_SQRT5 = math.sqrt(5.0)
+
+
+# ----------------------------------------------------------------------------
+# kernels  [dep KernelFunctions]; call sites SVA:211,216,227,234,251, src/utils.jl:17
+# ----------------------------------------------------------------------------
+@dataclass
+class Kernel:
+    """variance * (Base ∘ ARDTransform(inv_lengthscale)).
+
+    ``inv_lengthscale`` has d entries (all equal for an isotropic ScaleTransform).
+    test/test_utils.jl:2 builds ``softplus(k1) * (SE ∘ ScaleTransform(softplus(k2)))``,
+    i.e. the *inverse* lengthscale is the parameter; examples/a-regression/script.jl:55-59
+    uses ``with_lengthscale`` (inverse = 1/l).
+    """
+
+    family: int
+    variance: float
+    inv_lengthscale: np.ndarray
+
+    def __post_init__(self):
+        self.inv_lengthscale = np.atleast_1d(np.asarray(self.inv_lengthscale, dtype=np.float64))
+
+    @property
+    def d(self) -> int:
+        return int(self.inv_lengthscale.shape[0])
+
+
+def _as_dn(x: np.ndarray) -> np.ndarray:
+    """Inputs are ColVecs: a (d, n) array, each point one column; a 1-D array is d = 1."""
+    x = np.asarray(x)
+    if x.ndim == 1:
+        return x[None, :]
+    return x
+
+
+def _scaled_sqdist(kernel: Kernel, a: np.ndarray, b: np.ndarray) -> np.ndarray:
+    """r2[i, j] = sum_k ((a[k,i] - b[k,j]) * inv_l[k])**2 by direct differences.
+
+    The reference reaches Distances.jl, which uses |a|^2+|b|^2-2a.b clamped at 0 for d > 1
+    [dep]; direct differences are at least as accurate.
+    """
+    a = _as_dn(a)
+    b = _as_dn(b)
+    dt = np.result_type(a.dtype, b.dtype)
+    il = kernel.inv_lengthscale.astype(dt)
+    r2 = np.zeros((a.shape[1], b.shape[1]), dtype=dt)
+    for k in range(a.shape[0]):
+        diff = (a[k][:, None] - b[k][None, :]) * il[k]
+        r2 += diff * diff
+    return r2
+
+
+def _kappa(kernel: Kernel, r2: np.ndarray) -> np.ndarray:
+    var = r2.dtype.type(kernel.variance)
+    if kernel.family == KERNEL_SE:
+        return var * np.exp(-0.5 * r2)
+    r = np.sqrt(r2)
+    if kernel.family == KERNEL_MATERN32:
+        return var * (1.0 + _SQRT3 * r) * np.exp(-_SQRT3 * r)
+    if kernel.family == KERNEL_MATERN52:
+        return var * (1.0 + _SQRT5 * r + (5.0 / 3.0) * r2) * np.exp(-_SQRT5 * r)
+    raise ValueError("unknown kernel family")
+
+
+def kernelmatrix(kernel: Kernel, a: np.ndarray, b: Optional[np.ndarray] = None) -> np.ndarray:
+    """[dep] KernelFunctions.kernelmatrix(k, a[, b]) -> (len(a), len(b))."""
+    if b is None:
+        b = a
+    return _kappa(kernel, _scaled_sqdist(kernel, a, b))
+
+
+def kernelmatrix_diag(kernel: Kernel, a: np.ndarray) -> np.ndarray:
+    """[dep] KernelFunctions.kernelmatrix_diag: k(x, x) = variance for stationary kernels."""
+    a = _as_dn(a)
+    return np.full(a.shape[1], kernel.variance, dtype=a.dtype if a.dtype.kind == "f" else np.float64)
+
+
+# ----------------------------------------------------------------------------
+# model containers mirroring the reference's types
+# ----------------------------------------------------------------------------
+@dataclass
+class SVA:
+    """SparseVariationalApproximation{P}(fz, q)  (SVA:59-62, 76-95).
+
+    fz = f(z, jitter) with f = GP(mean_const, kernel); q = MvNormal(m, S), S = Lq Lq'.
+    ``Lq`` is the lower Cholesky factor of cov(q) (src/utils.jl:15,18); only its lower
+    triangle is read.
+    """
+
+    kernel: Kernel
+    z: np.ndarray  # (d, M)
+    m: np.ndarray  # (M,)
+    Lq: np.ndarray  # (M, M) lower
+    jitter: float = DEFAULT_SIGMA2
+    mean_const: float = 0.0
+    centered: bool = False  # default ctor is NonCentered (SVA:93-95)
+
+    def __post_init__(self):
+        self.z = _as_dn(np.asarray(self.z))
+        self.m = np.asarray(self.m)
+        self.Lq = np.tril(np.asarray(self.Lq))
+
+    @property
+    def M(self) -> int:
+        return int(self.m.shape[0])
+
+
+@dataclass
+class Posterior:
+    """ApproxPosteriorGP(sva, prior, (Kuu::Cholesky, B, α))  (SVA:134-135, 185-186)."""
+
+    sva: SVA
+    Lk: np.ndarray
+    B: np.ndarray
+    alpha: np.ndarray
+
+
+class PosDefException(Exception):
+    def __init__(self, info: int):
+        super().__init__(f"matrix is not positive definite; Cholesky factorization failed (info={info})")
+        self.info = info
+
+
+def _chol_lower_checked(K: np.ndarray) -> np.ndarray:
+    """cholesky(Symmetric(K)).L with LAPACK's info -> PosDefException(info) [dep LinearAlgebra]."""
+    potrf = sla.get_lapack_funcs("potrf", (K,))
+    c, info = potrf(K, lower=True, clean=True)
+    if info > 0:
+        raise PosDefException(int(info))
+    if info < 0:
+        raise ValueError(f"potrf illegal argument {-info}")
+    return c
+
+
+def kuu(sva: SVA) -> np.ndarray:
+    """cov(fz) = kernelmatrix(k, z) + jitter * I  (src/utils.jl:17 ∘ [dep] cov(::FiniteGP)).
+
+    The jitter is part of Kuu."""
+    K = kernelmatrix(sva.kernel, sva.z)
+    K[np.diag_indices_from(K)] += K.dtype.type(sva.jitter)
+    return K
+
+
+def posterior(sva: SVA) -> Posterior:
+    """posterior(sva)  — NonCentered SVA:160-187, Centered SVA:115-136."""
+    Lk = _chol_lower_checked(kuu(sva))  # SVA:181 / :132
+    if not sva.centered:
+        alpha = sla.solve_triangular(Lk, sva.m, lower=True, trans="T")  # SVA:182  α = Lk' \ m
+        B = sva.Lq  # SVA:183-184
+    else:
+        B = sla.solve_triangular(Lk, sva.Lq, lower=True)  # SVA:133  B = Lk \ Lq
+        rhs = sva.m - sva.mean_const  # SVA:134  m - mean(fz)
+        alpha = sla.cho_solve((Lk, True), rhs)  # α = Kuu \ (m - mean(fz))
+    return Posterior(sva, Lk, B, alpha)
+
+
+def A_and_Kuf(post: Posterior, x: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
+    """_A_and_Kuf (SVA:215-219): Kuf = k(z, x) (M×n), A = Lk \\ Kuf (trsm)."""
+    Kuf = kernelmatrix(post.sva.kernel, post.sva.z, x)
+    A = sla.solve_triangular(post.Lk, Kuf, lower=True)
+    return A, Kuf
+
+
+def _Bt_A(B: np.ndarray, A: np.ndarray) -> np.ndarray:
+    """B' * A with B LowerTriangular -> BLAS trmm (SVA:227,234,242,251)."""
+    trmm = sla.get_blas_funcs("trmm", (B, A))
+    return trmm(1.0, B, A, side=0, lower=1, trans_a=1, diag=0)
+
+
+def mean(post: Posterior, x: np.ndarray) -> np.ndarray:
+    """mean(f, x) = mean(prior, x) + cov(prior, x, z) * α  (SVA:208-212)."""
+    Kfu = kernelmatrix(post.sva.kernel, x, post.sva.z)
+    return post.sva.mean_const + Kfu @ post.alpha
+
+
+def var(post: Posterior, x: np.ndarray) -> np.ndarray:
+    """var(f, x) = var(prior,x) - diag_At_A(A) + diag_At_A(B'A)  (SVA:230-235)."""
+    A, _ = A_and_Kuf(post, x)
+    BtA = _Bt_A(post.B, A)
+    return kernelmatrix_diag(post.sva.kernel, x) - np.sum(A * A, axis=0) + np.sum(BtA * BtA, axis=0)
+
+
+def cov(post: Posterior, x: np.ndarray, y: Optional[np.ndarray] = None) -> np.ndarray:
+    """cov(f, x) (SVA:223-228) and cross-cov(f, x, y) (SVA:255-264)."""
+    k = post.sva.kernel
+    if y is None:
+        A, _ = A_and_Kuf(post, x)
+        BtA = _Bt_A(post.B, A)
+        return kernelmatrix(k, x) - A.T @ A + BtA.T @ BtA
+    Ax, _ = A_and_Kuf(post, x)
+    Ay, _ = A_and_Kuf(post, y)
+    return kernelmatrix(k, x, y) - Ax.T @ Ay + (Ax.T @ post.B) @ (post.B.T @ Ay)
+
+
+def mean_and_var(post: Posterior, x: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
+    """StatsBase.mean_and_var (SVA:246-253): one Kuf/A shared by μ and Σ_diag."""
+    A, Kuf = A_and_Kuf(post, x)
+    mu = post.sva.mean_const + Kuf.T @ post.alpha  # SVA:250
+    BtA = _Bt_A(post.B, A)
+    v = kernelmatrix_diag(post.sva.kernel, x) - np.sum(A * A, axis=0) + np.sum(BtA * BtA, axis=0)  # SVA:251
+    return mu, v
+
+
+def mean_and_cov(post: Posterior, x: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
+    """StatsBase.mean_and_cov (SVA:237-244)."""
+    A, Kuf = A_and_Kuf(post, x)
+    mu = post.sva.mean_const + Kuf.T @ post.alpha
+    BtA = _Bt_A(post.B, A)
+    return mu, kernelmatrix(post.sva.kernel, x) - A.T @ A + BtA.T @ BtA
+
+
+class DomainError(Exception):
+    """[dep] sqrt of a negative variance inside marginals."""
+
+
+def marginals(post: Posterior, x: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
+    """marginals(f_post(x)) (SVA:354): f_post(x) = FiniteGP(f_post, x, 1e-18) [dep];
+    returns (μ, σ) of Normal.(μ, sqrt.(v + 1e-18)); a negative variance is a DomainError."""
+    mu, v = mean_and_var(post, x)
+    v = v + v.dtype.type(DEFAULT_SIGMA2)
+    if np.any(v < 0):
+        raise DomainError(f"sqrt of negative variance (min {v.min()})")
+    return mu, np.sqrt(v)
+
+
+# ----------------------------------------------------------------------------
+# expected log-likelihood  [dep GPLikelihoods 0.4]; call site SVA:355
+# ----------------------------------------------------------------------------
+def gausshermite(n: int) -> Tuple[np.ndarray, np.ndarray]:
+    """[dep] FastGaussQuadrature.gausshermite(n): physicists' weight exp(-x^2)."""
+    return np.polynomial.hermite.hermgauss(n)
+
+
+def loglik(lik: int, f: np.ndarray, y: np.ndarray, sigma2: float = 1.0) -> np.ndarray:
+    """log p(y | f) per likelihood [dep GPLikelihoods]."""
+    if lik == LIK_GAUSSIAN:
+        return -0.5 * (math.log(2.0 * math.pi) + math.log(sigma2) + (y - f) ** 2 / sigma2)
+    if lik == LIK_BERNOULLI_LOGISTIC:
+        # y log σ(f) + (1-y) log(1-σ(f)) written as -softplus(∓f):
+        # identical to rounding wherever the reference's log(logistic(f)) is finite.
+        s = np.where(y > 0.5, -f, f)
+        return -np.logaddexp(0.0, s)
+    if lik == LIK_POISSON_EXP:
+        return y * f - np.exp(f) - gammaln(y + 1.0)
+    raise ValueError("unknown likelihood")
+
+
+def expected_loglik(
+    lik: int,
+    mu: np.ndarray,
+    sigma: np.ndarray,
+    y: np.ndarray,
+    sigma2: float = 1.0,
+    quadrature_n: int = 0,
+) -> float:
+    """expected_loglikelihood(quadrature, lik, q_f, y) -> scalar (SVA:355).
+
+    quadrature_n == 0 is DefaultExpectationMethod: analytic for Gaussian (and Poisson with
+    exp link), otherwise Gauss–Hermite with 20 points.  quadrature_n > 0 forces GH-n:
+    E[g(f)] ≈ π^{-1/2} Σ_j w_j g(√2 σ x_j + μ).
+    """
+    if quadrature_n == 0:
+        if lik == LIK_GAUSSIAN:
+            v = sigma * sigma
+            return float(np.sum(-0.5 * (math.log(2.0 * math.pi) + math.log(sigma2) + ((y - mu) ** 2 + v) / sigma2)))
+        if lik == LIK_POISSON_EXP:
+            v = sigma * sigma
+            return float(np.sum(y * mu - np.exp(mu + 0.5 * v) - gammaln(y + 1.0)))
+        quadrature_n = DEFAULT_GH_POINTS
+    xs, ws = gausshermite(quadrature_n)
+    acc = np.zeros_like(mu, dtype=np.float64)
+    sq2 = math.sqrt(2.0)
+    for xj, wj in zip(xs, ws):
+        acc += wj * loglik(lik, sq2 * sigma * xj + mu, y, sigma2)
+    return float(np.sum(acc) / math.sqrt(math.pi))
+
+
+# ----------------------------------------------------------------------------
+# KL and ELBO
+# ----------------------------------------------------------------------------
+def prior_kl(sva: SVA) -> float:
+    """_prior_kl — NonCentered SVA:364-373: ½(Σ Lq² + m'm − M − logdet S), logdet S = 2 Σ log diag Lq;
+    Centered SVA:362: Distributions.kldivergence(q, fz) between MvNormals [dep]."""
+    M = sva.M
+    Lq = np.asarray(sva.Lq, dtype=np.float64)
+    m = np.asarray(sva.m, dtype=np.float64)
+    logdet_S = 2.0 * float(np.sum(np.log(np.diag(Lq))))
+    if not sva.centered:
+        trace_term = float(np.sum(Lq * Lq))  # SVA:369-370 (sum(L .^ 2), AD work-around)
+        return 0.5 * (trace_term + float(m @ m) - M - logdet_S)
+    # ½[tr(Σp⁻¹Σq) + (μp−μq)'Σp⁻¹(μp−μq) − M + logdetΣp − logdetΣq],  p = fz, q = q
+    Lk = _chol_lower_checked(np.asarray(kuu(sva), dtype=np.float64))
+    X = sla.solve_triangular(Lk, Lq, lower=True)
+    tr = float(np.sum(X * X))
+    dm = sla.solve_triangular(Lk, m - sva.mean_const, lower=True)
+    logdet_K = 2.0 * float(np.sum(np.log(np.diag(Lk))))
+    return 0.5 * (tr + float(dm @ dm) - M + logdet_K - logdet_S)
+
+
+@dataclass
+class ElboTerms:
+    elbo: float
+    expectation: float  # Σ_i E_q[log p(y_i|f_i)] before scaling
+    kl: float
+    scale: float
+    mu: np.ndarray = field(repr=False, default=None)
+    v: np.ndarray = field(repr=False, default=None)
+
+
+def elbo_terms(
+    sva: SVA,
+    x: np.ndarray,
+    y: np.ndarray,
+    lik: int = LIK_GAUSSIAN,
+    sigma2: float = 1.0,
+    num_data: Optional[float] = None,
+    quadrature_n: int = 0,
+) -> ElboTerms:
+    """elbo(sva, lfx, y; num_data, quadrature)  (SVA:340-360).
+
+    The FiniteGP method (SVA:307-317) is this with lik = Gaussian(σ² = fx.Σy[1])."""
+    post = posterior(sva)  # SVA:353
+    mu, sd = marginals(post, x)  # SVA:354
+    E = expected_loglik(lik, mu, sd, np.asarray(y), sigma2, quadrature_n)  # SVA:355
+    n_batch = len(y)
+    scale = (float(num_data) if num_data is not None else float(n_batch)) / n_batch  # SVA:357-358
+    kl = prior_kl(sva)
+    return ElboTerms(E * scale - kl, E, kl, scale, mu, sd * sd)  # SVA:359
+
+
+def elbo(sva: SVA, x, y, **kw) -> float:
+    return elbo_terms(sva, x, y, **kw).elbo
+
+
+def elbo_finite_gp(sva: SVA, x, y, Sigma_y, **kw) -> float:
+    """elbo(sva, fx::FiniteGP, y) (SVA:307-327): isotropic noise only, else ErrorException."""
+    Sigma_y = np.asarray(Sigma_y, dtype=np.float64)
+    if Sigma_y.ndim == 0:
+        s2 = float(Sigma_y)
+    else:
+        raise RuntimeError(
+            "The observation noise fx.Σy must be homoscedastic.\n"
+            "To avoid this error, construct fx using: f = GP(kernel); fx = f(x, σ²), where σ² is a positive Real."
+        )
+    return elbo(sva, x, y, lik=LIK_GAUSSIAN, sigma2=s2, **kw)
+
+
+# ----------------------------------------------------------------------------
+# fixtures used by the reference's tests (test/test_utils.jl) and derived known answers
+# ----------------------------------------------------------------------------
+def softplus(t: float) -> float:
+    return math.log1p(math.exp(-abs(t))) + max(t, 0.0)
+
+
+def make_kernel(k) -> Kernel:
+    """test/test_utils.jl:2 — softplus(k1) * (SE ∘ ScaleTransform(softplus(k2)))."""
+    return Kernel(KERNEL_SE, softplus(k[0]), [softplus(k[1])])
+
+
+def optimal_variational_posterior(kernel: Kernel, z, jitter: float, x, sigma2: float, y):
+    """test/test_utils.jl:7-17 (Titsias closed form; ZeroMean): returns (m, S) of q(u)."""
+    z = _as_dn(np.asarray(z, dtype=np.float64))
+    x = _as_dn(np.asarray(x, dtype=np.float64))
+    Kuf = kernelmatrix(kernel, z, x)
+    Kuu = kernelmatrix(kernel, z) + jitter * np.eye(z.shape[1])
+    Sigma = Kuu + Kuf @ Kuf.T / sigma2
+    Sigma = 0.5 * (Sigma + Sigma.T)
+    m = (Kuu @ np.linalg.solve(Sigma, Kuf)) @ np.asarray(y, dtype=np.float64) / sigma2
+    S = Kuu @ np.linalg.solve(Sigma, Kuu)
+    return m, 0.5 * (S + S.T)
+
+
+def whiten(kernel: Kernel, z, jitter: float, m, S, mean_const: float = 0.0):
+    """test/SparseVariationalApproximationModule.jl:39-43: q_ε = N(Lk⁻¹(m−μz), Lk⁻¹ S Lk⁻ᵀ)."""
+    z = _as_dn(np.asarray(z, dtype=np.float64))
+    Kuu = kernelmatrix(kernel, z) + jitter * np.eye(z.shape[1])
+    Lk = np.linalg.cholesky(Kuu)
+    me = sla.solve_triangular(Lk, m - mean_const, lower=True)
+    X = sla.solve_triangular(Lk, S, lower=True)
+    Se = sla.solve_triangular(Lk, X.T, lower=True).T
+    return me, 0.5 * (Se + Se.T)
+
+
+def exact_gp_logpdf(kernel: Kernel, x, sigma2: float, y) -> float:
+    """logpdf(fx, y) for fx = GP(kernel)(x, σ²) [dep AbstractGPs]."""
+    x = _as_dn(np.asarray(x, dtype=np.float64))
+    y = np.asarray(y, dtype=np.float64)
+    n = len(y)
+    L = np.linalg.cholesky(kernelmatrix(kernel, x) + sigma2 * np.eye(n))
+    w = sla.solve_triangular(L, y, lower=True)
+    return float(-0.5 * (w @ w) - np.sum(np.log(np.diag(L))) - 0.5 * n * math.log(2 * math.pi))
+
+
+def exact_gp_posterior(kernel: Kernel, x, sigma2: float, y, xs):
+    """posterior(fx, y): exact GPR mean/cov at xs [dep AbstractGPs]."""
+    x = _as_dn(np.asarray(x, dtype=np.float64))
+    xs = _as_dn(np.asarray(xs, dtype=np.float64))
+    n = x.shape[1]
+    L = np.linalg.cholesky(kernelmatrix(kernel, x) + sigma2 * np.eye(n))
+    Ks = kernelmatrix(kernel, x, xs)
+    V = sla.solve_triangular(L, Ks, lower=True)
+    w = sla.solve_triangular(L, np.asarray(y, dtype=np.float64), lower=True)
+    return V.T @ w, kernelmatrix(kernel, xs) - V.T @ V
+
+
+def titsias_bound(kernel: Kernel, z, jitter: float, x, sigma2: float, y) -> float:
+    """Collapsed bound log N(y|0, Qff+σ²I) − tr(Kff−Qff)/(2σ²), Qff = Kfu Kuu⁻¹ Kuf with the
+    same jittered Kuu (known answer K1)."""
+    z = _as_dn(np.asarray(z, dtype=np.float64))
+    x = _as_dn(np.asarray(x, dtype=np.float64))
+    y = np.asarray(y, dtype=np.float64)
+    n = len(y)
+    Kuu = kernelmatrix(kernel, z) + jitter * np.eye(z.shape[1])
+    Lk = np.linalg.cholesky(Kuu)
+    A = sla.solve_triangular(Lk, kernelmatrix(kernel, z, x), lower=True)
+    Qff = A.T @ A
+    L = np.linalg.cholesky(Qff + sigma2 * np.eye(n))
+    w = sla.solve_triangular(L, y, lower=True)
+    ll = -0.5 * (w @ w) - np.sum(np.log(np.diag(L))) - 0.5 * n * math.log(2 * math.pi)
+    return float(ll - (n * kernel.variance - np.trace(Qff)) / (2 * sigma2))
+
+
+# ----------------------------------------------------------------------------
+# synthetic workloads shared by tests, golden fixtures, smoke and bench
+# ----------------------------------------------------------------------------
+def synth_problem(
+    config_id: int,
+    N: int,
+    M: int,
+    d: int,
+    family: int = KERNEL_SE,
+    lik: int = LIK_GAUSSIAN,
+    dtype=np.float64,
+    jitter: Optional[float] = None,
+):
+    """Seeded synthetic (x, y, sva, lik params) per SURVEY §8d.  Returned arrays are fp64
+    rounded through ``dtype`` so fp32 runs and the fp64 oracle see identical inputs."""
+    rng = np.random.default_rng(20260313 + config_id)
+    x = rng.standard_normal((d, N))
+    z = x[:, :M] + 1e-3 * rng.standard_normal((d, M))
+    ell = math.sqrt(d) * (0.75 + 0.5 * np.arange(d) / d)
+    kernel = Kernel(family, 1.3, 1.0 / ell)
+    m = 0.1 * rng.standard_normal(M)
+    Lq = np.eye(M) + 0.05 * np.tril(rng.standard_normal((M, M))) / math.sqrt(M)
+    Lq[np.diag_indices(M)] = np.abs(np.diag(Lq))
+    s = x.sum(axis=0) / math.sqrt(d)
+    sigma2 = 0.3
+    if lik == LIK_GAUSSIAN:
+        y = np.sin(s) + math.sqrt(sigma2) * rng.standard_normal(N)
+    elif lik == LIK_BERNOULLI_LOGISTIC:
+        p = 1.0 / (1.0 + np.exp(-2.0 * np.sin(s)))
+        y = (rng.random(N) < p).astype(np.float64)
+    else:
+        y = rng.poisson(np.exp(np.sin(s))).astype(np.float64)
+    if jitter is None:
+        jitter = 1e-5 if np.dtype(dtype) == np.float64 else 1e-3
+    rt = lambda a: np.asarray(a, dtype=dtype).astype(np.float64)
+    sva = SVA(kernel, rt(z), rt(m), rt(Lq), jitter=jitter)
+    return rt(x), rt(y), sva, sigma2

@@ -1,0 +1,13 @@
+"""pytest configuration: registers the ``gpu`` marker and puts the product package
+(``approximategps.jl_amd/`` holds the importable ``approxgp`` package) and the oracle on sys.path."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "approximategps.jl_amd"), os.path.join(ROOT, "oracle")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run on the GPU box via gpurun)")
