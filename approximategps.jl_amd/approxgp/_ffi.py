@@ -1,0 +1,355 @@
+"""ctypes binding of libsvgp_mi355x.so (include/svgp_mi355x.h) — the same symbols the Julia shim
+`ccall`s.  There is no CPU fallback: a missing library or a missing GPU raises."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "csrc", "libsvgp_mi355x.so")
+
+OK, INVALID_ARG, NOT_POSDEF, NEG_VARIANCE, UNSUPPORTED, HIP_ERROR, RCCL_ERROR, OOM = range(8)
+F64, F32 = 0, 1
+COLVECS, ROWVECS, VEC = 0, 1, 2
+KERNEL_SE, KERNEL_MATERN32, KERNEL_MATERN52 = 0, 1, 2
+LIK_GAUSSIAN, LIK_BERNOULLI_LOGISTIC, LIK_POISSON_EXP = 0, 1, 2
+NONCENTERED, CENTERED = 0, 1
+NEGVAR_ERROR, NEGVAR_CLAMP = 0, 1
+
+
+class ModelDesc(C.Structure):
+    _fields_ = [
+        ("dtype", C.c_int32), ("kernel", C.c_int32), ("parametrization", C.c_int32), ("likelihood", C.c_int32),
+        ("quadrature_n", C.c_int32), ("layout_z", C.c_int32), ("neg_var_policy", C.c_int32), ("d", C.c_int32),
+        ("M", C.c_int64), ("variance", C.c_double), ("inv_lengthscale", C.POINTER(C.c_double)),
+        ("mean_const", C.c_double), ("jitter", C.c_double), ("lik_sigma2", C.c_double),
+        ("z", C.c_void_p), ("m", C.c_void_p), ("Lq", C.c_void_p),
+    ]
+
+
+class Terms(C.Structure):
+    _fields_ = [
+        ("elbo", C.c_double), ("expectation", C.c_double), ("kl", C.c_double), ("scale", C.c_double),
+        ("logdet_kuu", C.c_double), ("n_points", C.c_int64), ("n_neg_var", C.c_int64),
+        ("chol_info", C.c_int32), ("reserved", C.c_int32),
+    ]
+
+
+class Timing(C.Structure):
+    _fields_ = [("ms_total", C.c_double), ("ms_prep", C.c_double), ("ms_strip", C.c_double), ("ms_kuf", C.c_double),
+                ("strip_launches", C.c_int64)]
+
+
+# every symbol include/svgp_mi355x.h declares: (restype, argtypes)
+_P = C.c_void_p
+SYMBOLS = {
+    "svgp_version": (C.c_int32, []),
+    "svgp_device_count": (C.c_int32, []),
+    "svgp_ctx_create": (C.c_int32, [C.c_int32, _P, C.POINTER(_P)]),
+    "svgp_ctx_destroy": (C.c_int32, [_P]),
+    "svgp_last_error": (C.c_char_p, [_P]),
+    "svgp_last_timing": (C.c_int32, [_P, C.POINTER(Timing)]),
+    "svgp_data_upload": (C.c_int32, [_P, C.c_int32, C.c_int32, C.c_int32, C.c_int64, _P, _P, C.POINTER(_P)]),
+    "svgp_data_wrap_device": (C.c_int32, [_P, C.c_int32, C.c_int32, C.c_int64, C.c_int64, _P, _P, C.POINTER(_P)]),
+    "svgp_data_free": (C.c_int32, [_P, _P]),
+    "svgp_model_create": (C.c_int32, [_P, C.POINTER(ModelDesc), C.POINTER(_P)]),
+    "svgp_model_update": (C.c_int32, [_P, _P, C.POINTER(ModelDesc)]),
+    "svgp_model_free": (C.c_int32, [_P, _P]),
+    "svgp_elbo": (C.c_int32, [_P, _P, _P, C.c_int64, C.c_int64, C.c_double, C.POINTER(C.c_double), C.POINTER(Terms)]),
+    "svgp_elbo_partial": (C.c_int32, [_P, _P, _P, C.c_int64, C.c_int64, C.POINTER(C.c_double)]),
+    "svgp_prior_kl": (C.c_int32, [_P, _P, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "svgp_elbo_host": (C.c_int32, [_P, C.POINTER(ModelDesc), C.c_int32, C.c_int64, _P, _P, C.c_double,
+                                   C.POINTER(C.c_double), C.POINTER(Terms)]),
+    "svgp_posterior": (C.c_int32, [_P, _P, _P, _P, _P]),
+    "svgp_predict": (C.c_int32, [_P, _P, C.c_int32, C.c_int64, _P, _P, _P, _P]),
+    "svgp_predict_cross_cov": (C.c_int32, [_P, _P, C.c_int32, C.c_int64, _P, C.c_int64, _P, _P]),
+    "svgp_kuf": (C.c_int32, [_P, _P, _P, C.c_int64, C.c_int64, _P]),
+    "svgp_gausshermite": (C.c_int32, [C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+}
+
+_lib = None
+
+
+def load_library():
+    """dlopen the in-tree library and type every symbol.  Raises (never falls back) when it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: build it with ./build.sh (hipcc --offload-arch=gfx950). "
+            "This package has no CPU implementation."
+        )
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+# ---- exceptions mirroring the Julia ones the shim raises --------------------------
+class SvgpError(RuntimeError):
+    pass
+
+
+class PosDefException(SvgpError):
+    def __init__(self, info, msg=""):
+        super().__init__(msg or f"matrix is not positive definite; Cholesky factorization failed (info={info})")
+        self.info = info
+
+
+class DomainError(SvgpError):
+    pass
+
+
+class UnsupportedError(SvgpError):
+    pass
+
+
+def np_dtype(dtype: int):
+    return np.float64 if dtype == F64 else np.float32
+
+
+def dtype_code(dt) -> int:
+    dt = np.dtype(dt)
+    if dt == np.float64:
+        return F64
+    if dt == np.float32:
+        return F32
+    raise UnsupportedError(f"unsupported element type {dt}; use float64 or float32")
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class Context:
+    """One GPU + one HIP stream.  `stream` may be a raw hipStream_t (e.g. torch.cuda.current_stream().cuda_stream)."""
+
+    def __init__(self, device: int = 0, stream: int | None = None):
+        self.lib = load_library()
+        if self.lib.svgp_device_count() < 1:
+            raise SvgpError("no HIP device visible: libsvgp_mi355x has no CPU path")
+        h = C.c_void_p()
+        rc = self.lib.svgp_ctx_create(device, C.c_void_p(stream) if stream else None, C.byref(h))
+        if rc != OK:
+            raise SvgpError(f"svgp_ctx_create failed with status {rc}")
+        self.h = h
+        self.device = device
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.svgp_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def check(self, rc: int, terms: Terms | None = None):
+        if rc == OK:
+            return
+        msg = (self.lib.svgp_last_error(self.h) or b"").decode()
+        if rc == INVALID_ARG:
+            raise ValueError(msg)  # Julia ArgumentError
+        if rc == NOT_POSDEF:
+            raise PosDefException(terms.chol_info if terms is not None else -1, msg)
+        if rc == NEG_VARIANCE:
+            raise DomainError(msg)
+        if rc == UNSUPPORTED:
+            raise UnsupportedError(msg)
+        if rc == OOM:
+            raise MemoryError(msg)
+        raise SvgpError(f"status {rc}: {msg}")
+
+    def timing(self) -> Timing:
+        t = Timing()
+        self.lib.svgp_last_timing(self.h, C.byref(t))
+        return t
+
+
+_default_ctx: Context | None = None
+
+
+def default_context() -> Context:
+    global _default_ctx
+    if _default_ctx is None:
+        _default_ctx = Context(0)
+    return _default_ctx
+
+
+class DeviceData:
+    """x = lfx.fx.x and y resident in HBM (svgp_data)."""
+
+    def __init__(self, ctx: Context, x: np.ndarray, y: np.ndarray | None, dtype, layout: int = COLVECS):
+        self.ctx = ctx
+        dt = np_dtype(dtype_code(dtype))
+        x = np.asarray(x, dtype=dt)
+        if x.ndim == 1:
+            layout, d, n = VEC, 1, x.shape[0]
+            xbuf = np.ascontiguousarray(x)
+        elif layout == COLVECS:
+            d, n = x.shape  # (d, n) numpy view of Julia's d×n column-major matrix: point-contiguous
+            xbuf = np.asfortranarray(x)
+        else:
+            n, d = x.shape  # RowVecs: n×d column-major, feature-contiguous
+            xbuf = np.asfortranarray(x)
+        self._x = xbuf
+        self._y = None if y is None else np.ascontiguousarray(np.asarray(y, dtype=dt))
+        if self._y is not None and self._y.shape[0] != n:
+            raise ValueError("x and y lengths differ")
+        self.n, self.d, self.dtype = n, d, dtype_code(dt)
+        h = C.c_void_p()
+        ctx.check(ctx.lib.svgp_data_upload(ctx.h, self.dtype, layout, d, n, _ptr(self._x), _ptr(self._y), C.byref(h)))
+        self.h = h
+
+    @classmethod
+    def wrap(cls, ctx: Context, dtype, d: int, n: int, ldx: int, x_ptr: int, y_ptr: int | None):
+        self = cls.__new__(cls)
+        self.ctx, self.n, self.d, self.dtype = ctx, n, d, dtype_code(dtype)
+        h = C.c_void_p()
+        ctx.check(ctx.lib.svgp_data_wrap_device(ctx.h, self.dtype, d, n, ldx, C.c_void_p(x_ptr),
+                                                C.c_void_p(y_ptr) if y_ptr else None, C.byref(h)))
+        self.h = h
+        return self
+
+    def free(self):
+        if getattr(self, "h", None):
+            self.ctx.lib.svgp_data_free(self.ctx.h, self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def make_desc(dtype, kernel, variance, inv_lengthscale, z, m, Lq, jitter, *, parametrization=NONCENTERED,
+              likelihood=LIK_GAUSSIAN, lik_sigma2=1.0, quadrature_n=0, mean_const=0.0, neg_var_policy=NEGVAR_ERROR,
+              layout_z=COLVECS):
+    """Builds a svgp_model_desc plus the numpy buffers it borrows (keep the returned tuple alive)."""
+    code = dtype_code(dtype)
+    dt = np_dtype(code)
+    z = np.asarray(z, dtype=dt)
+    if z.ndim == 1:
+        layout_z, d, M = VEC, 1, z.shape[0]
+        zbuf = np.ascontiguousarray(z)
+    elif layout_z == COLVECS:
+        d, M = z.shape
+        zbuf = np.asfortranarray(z)
+    else:
+        M, d = z.shape
+        zbuf = np.asfortranarray(z)
+    il = np.ascontiguousarray(np.broadcast_to(np.asarray(inv_lengthscale, dtype=np.float64), (d,)))
+    mbuf = np.ascontiguousarray(np.asarray(m, dtype=dt))
+    Lbuf = np.asfortranarray(np.asarray(Lq, dtype=dt))
+    if mbuf.shape != (M,) or Lbuf.shape != (M, M):
+        raise ValueError("m must have M entries and Lq must be M×M")
+    desc = ModelDesc(code, kernel, parametrization, likelihood, quadrature_n, layout_z, neg_var_policy, d, M,
+                     float(variance), il.ctypes.data_as(C.POINTER(C.c_double)), float(mean_const), float(jitter),
+                     float(lik_sigma2), _ptr(zbuf), _ptr(mbuf), _ptr(Lbuf))
+    return desc, (il, zbuf, mbuf, Lbuf)
+
+
+class DeviceModel:
+    """SparseVariationalApproximation(fz, q) + likelihood resident in HBM (svgp_model)."""
+
+    def __init__(self, ctx: Context, desc: ModelDesc, keep):
+        self.ctx = ctx
+        self.M, self.d, self.dtype = desc.M, desc.d, desc.dtype
+        h = C.c_void_p()
+        ctx.check(ctx.lib.svgp_model_create(ctx.h, C.byref(desc), C.byref(h)))
+        self.h = h
+        del keep
+
+    def update(self, desc: ModelDesc, keep):
+        self.ctx.check(self.ctx.lib.svgp_model_update(self.ctx.h, self.h, C.byref(desc)))
+        del keep
+
+    def elbo(self, data: DeviceData, off=0, length=None, num_data=0.0):
+        length = data.n - off if length is None else length
+        out, terms = C.c_double(), Terms()
+        rc = self.ctx.lib.svgp_elbo(self.ctx.h, self.h, data.h, off, length, float(num_data), C.byref(out), C.byref(terms))
+        self.ctx.check(rc, terms)
+        return out.value, terms
+
+    def elbo_partial(self, data: DeviceData, off=0, length=None):
+        length = data.n - off if length is None else length
+        buf = (C.c_double * 4)()
+        self.ctx.check(self.ctx.lib.svgp_elbo_partial(self.ctx.h, self.h, data.h, off, length, buf))
+        return np.array(buf[:], dtype=np.float64)
+
+    def prior_kl(self):
+        kl, ld = C.c_double(), C.c_double()
+        self.ctx.check(self.ctx.lib.svgp_prior_kl(self.ctx.h, self.h, C.byref(kl), C.byref(ld)))
+        return kl.value, ld.value
+
+    def posterior(self):
+        dt = np_dtype(self.dtype)
+        Lk = np.zeros((self.M, self.M), dtype=dt, order="F")
+        alpha = np.zeros(self.M, dtype=dt)
+        B = np.zeros((self.M, self.M), dtype=dt, order="F")
+        self.ctx.check(self.ctx.lib.svgp_posterior(self.ctx.h, self.h, _ptr(Lk), _ptr(alpha), _ptr(B)))
+        return Lk, alpha, B
+
+    def predict(self, x, want_mean=True, want_var=True, want_cov=False, layout=COLVECS):
+        dt = np_dtype(self.dtype)
+        x = np.asarray(x, dtype=dt)
+        if x.ndim == 1:
+            layout, n, xb = VEC, x.shape[0], np.ascontiguousarray(x)
+        else:
+            n = x.shape[1] if layout == COLVECS else x.shape[0]
+            xb = np.asfortranarray(x)
+        mean = np.zeros(n, dtype=dt) if want_mean else None
+        var = np.zeros(n, dtype=dt) if want_var else None
+        cov = np.zeros((n, n), dtype=dt, order="F") if want_cov else None
+        self.ctx.check(self.ctx.lib.svgp_predict(self.ctx.h, self.h, layout, n, _ptr(xb), _ptr(mean), _ptr(var), _ptr(cov)))
+        return mean, var, cov
+
+    def cross_cov(self, x, y, layout=COLVECS):
+        dt = np_dtype(self.dtype)
+        x, y = np.asarray(x, dtype=dt), np.asarray(y, dtype=dt)
+        if x.ndim == 1:
+            layout, nx, ny = VEC, x.shape[0], y.shape[0]
+            xb, yb = np.ascontiguousarray(x), np.ascontiguousarray(y)
+        else:
+            nx = x.shape[1] if layout == COLVECS else x.shape[0]
+            ny = y.shape[1] if layout == COLVECS else y.shape[0]
+            xb, yb = np.asfortranarray(x), np.asfortranarray(y)
+        cov = np.zeros((nx, ny), dtype=dt, order="F")
+        self.ctx.check(self.ctx.lib.svgp_predict_cross_cov(self.ctx.h, self.h, layout, nx, _ptr(xb), ny, _ptr(yb), _ptr(cov)))
+        return cov
+
+    def kuf(self, data: DeviceData, off=0, length=None, fetch=True):
+        length = data.n - off if length is None else length
+        out = np.zeros((self.M, length), dtype=np_dtype(self.dtype), order="F") if fetch else None
+        self.ctx.check(self.ctx.lib.svgp_kuf(self.ctx.h, self.h, data.h, off, length, _ptr(out)))
+        return out
+
+    def free(self):
+        if getattr(self, "h", None):
+            self.ctx.lib.svgp_model_free(self.ctx.h, self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def gausshermite(n: int):
+    lib = load_library()
+    xs = np.zeros(n)
+    ws = np.zeros(n)
+    rc = lib.svgp_gausshermite(n, xs.ctypes.data_as(C.POINTER(C.c_double)), ws.ctypes.data_as(C.POINTER(C.c_double)))
+    if rc != OK:
+        raise ValueError(f"svgp_gausshermite({n}) failed with status {rc}")
+    return xs, ws

@@ -1,0 +1,54 @@
+"""Data-parallel ELBO: the expectation term Σ_i E_q[log p(y_i|f_i)] is a plain sum over points
+(SVA:355-359), so each rank evaluates its own shard / minibatch with the HIP library and ONE
+all-reduce (RCCL over xGMI on GPUs; gloo in the CPU tests) combines {ΣE, n, n_neg, chol_info};
+the M-sized work (Kuu, Cholesky, KL) is replicated and the KL is subtracted once after the reduce.
+Pure host logic: nothing here computes a partial sum itself."""
+from __future__ import annotations
+
+import numpy as np
+
+
+def shard_range(n: int, rank: int, world: int):
+    """Contiguous shard [lo, hi) of n points for `rank` (first n % world ranks get one more point)."""
+    if not (0 <= rank < world):
+        raise ValueError("rank outside world")
+    base, rem = divmod(n, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def allreduce_partials(partial, group=None, device=None):
+    """Sum the 4-vector {ΣE, n_points, n_neg_var, chol_info_flag} over ranks with one collective.
+    chol_info is combined as a max (any rank failing fails the step) by packing it in its own slot."""
+    import torch
+    import torch.distributed as dist
+
+    t = torch.tensor([partial[0], partial[1], partial[2], 1.0 if partial[3] != 0 else 0.0], dtype=torch.float64,
+                     device=device if device is not None else "cpu")
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    return t.cpu().numpy()
+
+
+def combine(total, kl: float, num_data: float):
+    """ELBO = ΣE · num_data / n_global − KL  (SVA:357-359) from the all-reduced vector."""
+    sum_e, n_global, n_neg, bad_chol = (float(v) for v in total)
+    if bad_chol > 0:
+        raise ArithmeticError("Kuu was not positive definite on at least one rank")
+    if n_global <= 0:
+        raise ValueError("empty global batch")
+    return sum_e * (float(num_data) / n_global) - kl
+
+
+class ShardedELBO:
+    """One rank's view of a minibatched, data-parallel ELBO (config C5): holds this rank's shard of the
+    data on its GPU and evaluates `batch` points per step starting at a rotating offset."""
+
+    def __init__(self, model, data, num_data: float, group=None, device=None):
+        self.model, self.data, self.num_data, self.group, self.device = model, data, float(num_data), group, device
+
+    def step(self, off: int, length: int):
+        partial = self.model.elbo_partial(self.data, off, length)
+        kl, _ = self.model.prior_kl()
+        total = allreduce_partials(partial, self.group, self.device)
+        return combine(total, kl, self.num_data)

@@ -1,0 +1,195 @@
+"""Python host mirror of ApproximateGPs.jl's SparseVariationalApproximation API — same names, argument
+meaning and error behaviour as /root/reference/src/SparseVariationalApproximationModule.jl (SVA) —
+over the C-ABI of libsvgp_mi355x.so.  This file only packs parameters and maps status codes to
+exceptions; the numbers come from the HIP library (there is no CPU path)."""
+from __future__ import annotations
+
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import _ffi
+from .gp import (BernoulliLikelihood, DefaultExpectationMethod, FiniteGP, GaussHermiteExpectation,
+                 GaussianLikelihood, LatentFiniteGP, MvNormal, PoissonLikelihood, _as_dn)
+from .kernels import unpack_kernel
+
+
+class Centered:  # SVA:41
+    pass
+
+
+class NonCentered:  # SVA:57
+    pass
+
+
+@dataclass(eq=False)
+class SparseVariationalApproximation:
+    """SparseVariationalApproximation([Centered()|NonCentered(),] fz::FiniteGP, q::MvNormal)  (SVA:59-95).
+    The two-argument form is NonCentered (SVA:93-95)."""
+
+    parametrization: object
+    fz: FiniteGP
+    q: MvNormal
+
+    def __init__(self, *args):
+        if len(args) == 2:
+            self.parametrization, (self.fz, self.q) = NonCentered(), args
+        elif len(args) == 3:
+            self.parametrization, self.fz, self.q = args
+            if isinstance(self.parametrization, type):
+                self.parametrization = self.parametrization()
+        else:
+            raise TypeError("SparseVariationalApproximation([parametrization,] fz, q)")
+        if not isinstance(self.fz, FiniteGP) or not isinstance(self.q, MvNormal):
+            raise TypeError("fz must be a FiniteGP and q an MvNormal")
+
+    @property
+    def is_centered(self):
+        return isinstance(self.parametrization, Centered)
+
+
+def SVGP(*args):
+    """src/deprecations.jl:1 — SVGP(args...) = SparseVariationalApproximation(Centered(), args...)."""
+    return SparseVariationalApproximation(Centered(), *args)
+
+
+_LIK = {GaussianLikelihood: _ffi.LIK_GAUSSIAN, BernoulliLikelihood: _ffi.LIK_BERNOULLI_LOGISTIC,
+        PoissonLikelihood: _ffi.LIK_POISSON_EXP}
+
+
+def _desc(sva: SparseVariationalApproximation, lik=None, quadrature=None, dtype=None, neg_var_policy=_ffi.NEGVAR_ERROR):
+    fz = sva.fz
+    z = np.asarray(fz.x)
+    if not fz.is_isotropic():
+        raise _ffi.UnsupportedError("fz.Σy must be isotropic jitter")
+    dtype = np.dtype(dtype if dtype is not None else (np.float32 if z.dtype == np.float32 else np.float64))
+    d = 1 if z.ndim == 1 else z.shape[0]
+    family, variance, il = unpack_kernel(fz.f.kernel, d)
+    lik_code, s2 = _ffi.LIK_GAUSSIAN, 1.0
+    if lik is not None:
+        if type(lik) not in _LIK:
+            raise _ffi.UnsupportedError(f"unsupported likelihood {lik!r}")
+        lik_code = _LIK[type(lik)]
+        if isinstance(lik, GaussianLikelihood):
+            s2 = float(lik.sigma2)
+    qn = 0
+    if isinstance(quadrature, GaussHermiteExpectation):
+        qn = int(quadrature.n)
+    elif quadrature is not None and not isinstance(quadrature, DefaultExpectationMethod):
+        raise _ffi.UnsupportedError(f"unsupported quadrature {quadrature!r}")
+    return _ffi.make_desc(dtype, family, variance, il, z, sva.q.m, sva.q.chol_lower, float(fz.Sigma_y),
+                          parametrization=_ffi.CENTERED if sva.is_centered else _ffi.NONCENTERED,
+                          likelihood=lik_code, lik_sigma2=s2, quadrature_n=qn, mean_const=fz.f.mean_const,
+                          neg_var_policy=neg_var_policy)
+
+
+# ------------------------------------------------------------------------------------------------
+# elbo / approx_lml
+# ------------------------------------------------------------------------------------------------
+def elbo(sva: SparseVariationalApproximation, fx, y, *, num_data=None, quadrature=None, ctx=None, dtype=None,
+         return_terms=False):
+    """elbo(sva, fx::FiniteGP | lfx::LatentFiniteGP, y; num_data=length(y), quadrature=DefaultExpectationMethod())
+
+    FiniteGP method (SVA:307-317): Gaussian likelihood with σ² = fx.Σy[1]; non-isotropic noise raises the
+    reference's ErrorException text (SVA:319-327).  LatentFiniteGP method: SVA:340-360."""
+    if isinstance(fx, FiniteGP):
+        if not fx.is_isotropic():
+            raise RuntimeError(
+                "The observation noise fx.Σy must be homoscedastic.\n"
+                "To avoid this error, construct fx using: f = GP(kernel); fx = f(x, σ²), where σ² is a positive Real."
+            )
+        lfx = LatentFiniteGP(fx, GaussianLikelihood(float(fx.Sigma_y)))
+    elif isinstance(fx, LatentFiniteGP):
+        lfx = fx
+    else:
+        raise TypeError("elbo expects a FiniteGP or a LatentFiniteGP")
+    if sva.fz.f is not lfx.fx.f:  # SVA:347-351
+        raise ValueError("(Latent)FiniteGP prior is not consistent with SparseVariationalApproximation's")
+    ctx = ctx or _ffi.default_context()
+    desc, keep = _desc(sva, lfx.lik, quadrature, dtype)
+    y = np.asarray(y)
+    n = y.shape[0]
+    data = _ffi.DeviceData(ctx, lfx.fx.x, y, _ffi.np_dtype(desc.dtype))
+    model = _ffi.DeviceModel(ctx, desc, keep)
+    try:
+        val, terms = model.elbo(data, 0, n, float(num_data) if num_data is not None else 0.0)
+    finally:
+        model.free()
+        data.free()
+    return (val, terms) if return_terms else val
+
+
+def approx_lml(sva, l_fx, ys, **kwargs):
+    """API.approx_lml (SVA:276-280): forwards to elbo."""
+    return elbo(sva, l_fx, ys, **kwargs)
+
+
+# ------------------------------------------------------------------------------------------------
+# posterior and the prediction API on ApproxPosteriorGP{<:SparseVariationalApproximation}
+# ------------------------------------------------------------------------------------------------
+class ApproxPosteriorGP:
+    """ApproxPosteriorGP(sva, prior, (Kuu = Cholesky(Lk), B, α))  (SVA:134-135, :185-186), with the model
+    kept resident on the GPU for the prediction methods."""
+
+    def __init__(self, approx: SparseVariationalApproximation, ctx=None, dtype=None):
+        self.approx = approx
+        self.prior = approx.fz.f
+        self.ctx = ctx or _ffi.default_context()
+        desc, keep = _desc(approx, None, None, dtype)
+        self._model = _ffi.DeviceModel(self.ctx, desc, keep)
+        Lk, alpha, B = self._model.posterior()
+        self.data = {"Kuu": Lk, "B": B, "α": alpha, "alpha": alpha}
+
+    def inducing_points(self):  # SVA:270
+        return self.approx.fz.x
+
+    def mean(self, x):  # SVA:208-212
+        return self._model.predict(x, True, False, False)[0]
+
+    def var(self, x):  # SVA:230-235
+        return self._model.predict(x, False, True, False)[1]
+
+    def mean_and_var(self, x):  # SVA:246-253
+        m, v, _ = self._model.predict(x, True, True, False)
+        return m, v
+
+    def cov(self, x, y=None):  # SVA:223-228 and :255-264
+        if y is None:
+            return self._model.predict(x, False, False, True)[2]
+        return self._model.cross_cov(x, y)
+
+    def mean_and_cov(self, x):  # SVA:237-244
+        m, _, c = self._model.predict(x, True, False, True)
+        return m, c
+
+    def marginals(self, x):
+        """marginals(f_post(x)) (SVA:354): (μ, σ) of Normal.(μ, sqrt.(v + 1e-18))."""
+        m, v = self.mean_and_var(x)
+        v = v + 1e-18
+        if np.any(v < 0):
+            raise _ffi.DomainError("sqrt of a negative variance")
+        return m, np.sqrt(v)
+
+
+def posterior(sva: SparseVariationalApproximation, fx=None, y=None, *, ctx=None, dtype=None):
+    """posterior(sva) (SVA:115-136 / :160-187); the 3-argument forms assert the same prior and ignore the
+    data (SVA:189-201)."""
+    if fx is not None:
+        prior = fx.f if isinstance(fx, FiniteGP) else fx.fx.f
+        assert sva.fz.f is prior  # SVA:192,199
+    return ApproxPosteriorGP(sva, ctx=ctx, dtype=dtype)
+
+
+def inducing_points(f: ApproxPosteriorGP):
+    return f.inducing_points()
+
+
+def prior_kl(sva: SparseVariationalApproximation, *, ctx=None, dtype=None):
+    """_prior_kl(sva) (SVA:362-373)."""
+    ctx = ctx or _ffi.default_context()
+    desc, keep = _desc(sva, None, None, dtype)
+    model = _ffi.DeviceModel(ctx, desc, keep)
+    try:
+        return model.prior_kl()[0]
+    finally:
+        model.free()

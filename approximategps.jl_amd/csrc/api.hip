@@ -1,0 +1,830 @@
+// api.hip — the C-ABI of libsvgp_mi355x.so (include/svgp_mi355x.h).  Host orchestration only: every
+// number is produced by the HIP kernels in prep.hip / strip.hip; there is no CPU compute path.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/svgp_mi355x.h"
+#include "kernels.hpp"
+
+using namespace svgp;
+
+// ------------------------------------------------------------------------------------------------
+struct svgp_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  int num_cus = 256;
+  std::string err;
+  svgp_timing timing{};
+  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  // growable scratch
+  void* work = nullptr;       size_t work_bytes = 0;
+  double* partial = nullptr;  unsigned* negcnt = nullptr;  // [1024] per-block sums of the expectation kernel
+  double* mom = nullptr;      size_t mom_cap = 0;           // [2][mom_cap] per-point mean / variance
+  double* d_res = nullptr;    // [8] device results
+  void* kuf_buf = nullptr;    size_t kuf_bytes = 0;
+};
+
+struct svgp_data {
+  int dtype = 0, d = 0;
+  int64_t n = 0, ldx = 0;
+  void* x = nullptr;  // feature-major [d][ldx]
+  void* y = nullptr;
+  bool own = true;
+};
+
+struct svgp_model {
+  svgp_model_desc desc{};
+  std::vector<double> invl_host;
+  int64_t M = 0, Mp = 0;
+  int dtype = 0, d = 0;
+  size_t es = 8;
+  void *z_raw = nullptr, *m_raw = nullptr, *Lq_raw = nullptr;  // user layout
+  void *invl = nullptr, *zs = nullptr, *L = nullptr, *T = nullptr, *U = nullptr, *mp = nullptr, *B = nullptr;
+  double* scal = nullptr;  // [8 + Mp]
+  int* info = nullptr;
+  double *gh_x = nullptr, *gh_w = nullptr;
+  int gh_n = 0;
+  bool prepared = false;
+  // host copies of the last prep's scalars
+  double kl = 0, logdet_kuu = 0;
+  int chol_info = 0;
+};
+
+namespace {
+
+#define HIPC(ctx, call)                                                                            \
+  do {                                                                                             \
+    hipError_t e_ = (call);                                                                        \
+    if (e_ != hipSuccess) {                                                                        \
+      (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e_);                              \
+      return (e_ == hipErrorOutOfMemory) ? SVGP_OOM : SVGP_HIP_ERROR;                              \
+    }                                                                                              \
+  } while (0)
+
+// SVGP_DEBUG_SYNC=1: synchronise and check after every kernel launch, naming the offender.
+bool debug_sync() {
+  static const bool on = [] { const char* e = getenv("SVGP_DEBUG_SYNC"); return e && e[0] == '1'; }();
+  return on;
+}
+#define KCHECK(ctx, name)                                                                          \
+  do {                                                                                             \
+    hipError_t e_ = hipGetLastError();                                                             \
+    if (e_ == hipSuccess && debug_sync()) e_ = hipStreamSynchronize((ctx)->stream);                \
+    if (e_ != hipSuccess) {                                                                        \
+      (ctx)->err = std::string("kernel ") + name + ": " + hipGetErrorString(e_);                   \
+      return SVGP_HIP_ERROR;                                                                       \
+    }                                                                                              \
+  } while (0)
+
+int fail(svgp_ctx* ctx, int code, const std::string& msg) {
+  if (ctx) ctx->err = msg;
+  return code;
+}
+
+size_t esize(int dtype) { return dtype == SVGP_F64 ? 8 : 4; }
+
+// Golub–Welsch: nodes/weights of the n-point Gauss–Hermite rule (weight exp(-x²)), as
+// FastGaussQuadrature.gausshermite(n).  Symmetric tridiagonal QL with implicit shifts on the Jacobi matrix.
+int gauss_hermite(int n, double* xs, double* ws) {
+  if (n < 1 || n > 512) return SVGP_INVALID_ARG;
+  std::vector<double> d(n, 0.0), e(n, 0.0), z(n, 0.0);
+  for (int i = 1; i < n; ++i) e[i - 1] = std::sqrt(0.5 * i);
+  z[0] = 1.0;  // first row of the eigenvector matrix
+  for (int l = 0; l < n; ++l) {
+    int iter = 0, m;
+    do {
+      for (m = l; m < n - 1; ++m) {
+        const double dd = std::fabs(d[m]) + std::fabs(d[m + 1]);
+        if (std::fabs(e[m]) <= 2.3e-16 * dd) break;
+      }
+      if (m != l) {
+        if (++iter > 200) return SVGP_INVALID_ARG;
+        double g = (d[l + 1] - d[l]) / (2.0 * e[l]);
+        double r = std::hypot(g, 1.0);
+        g = d[m] - d[l] + e[l] / (g + (g >= 0 ? std::fabs(r) : -std::fabs(r)));
+        double s = 1.0, c = 1.0, p = 0.0;
+        int i;
+        for (i = m - 1; i >= l; --i) {
+          double f = s * e[i], b = c * e[i];
+          r = std::hypot(f, g);
+          e[i + 1] = r;
+          if (r == 0.0) {
+            d[i + 1] -= p;
+            e[m] = 0.0;
+            break;
+          }
+          s = f / r;
+          c = g / r;
+          g = d[i + 1] - p;
+          r = (d[i] - g) * s + 2.0 * c * b;
+          p = s * r;
+          d[i + 1] = g + p;
+          g = c * r - b;
+          f = z[i + 1];
+          z[i + 1] = s * z[i] + c * f;
+          z[i] = c * z[i] - s * f;
+        }
+        if (r == 0.0 && i >= l) continue;
+        d[l] -= p;
+        e[l] = g;
+        e[m] = 0.0;
+      }
+    } while (m != l);
+  }
+  // sort ascending
+  std::vector<int> idx(n);
+  for (int i = 0; i < n; ++i) idx[i] = i;
+  for (int i = 1; i < n; ++i) {
+    int k = idx[i], j = i - 1;
+    while (j >= 0 && d[idx[j]] > d[k]) {
+      idx[j + 1] = idx[j];
+      --j;
+    }
+    idx[j + 1] = k;
+  }
+  const double mu0 = 1.7724538509055160273;  // sqrt(pi)
+  for (int i = 0; i < n; ++i) {
+    xs[i] = d[idx[i]];
+    ws[i] = mu0 * z[idx[i]] * z[idx[i]];
+  }
+  // symmetrise (the rule is exactly symmetric)
+  for (int i = 0; i < n / 2; ++i) {
+    const double a = 0.5 * (xs[n - 1 - i] - xs[i]);
+    xs[i] = -a;
+    xs[n - 1 - i] = a;
+    const double w = 0.5 * (ws[i] + ws[n - 1 - i]);
+    ws[i] = ws[n - 1 - i] = w;
+  }
+  if (n % 2) xs[n / 2] = 0.0;
+  return SVGP_OK;
+}
+
+int validate_desc(svgp_ctx* ctx, const svgp_model_desc* d) {
+  if (!d) return fail(ctx, SVGP_INVALID_ARG, "null model descriptor");
+  if (d->dtype != SVGP_F64 && d->dtype != SVGP_F32) return fail(ctx, SVGP_INVALID_ARG, "dtype must be SVGP_F64 or SVGP_F32");
+  if (d->kernel < 0 || d->kernel > SVGP_KERNEL_MATERN52) return fail(ctx, SVGP_UNSUPPORTED, "unsupported kernel family");
+  if (d->likelihood < 0 || d->likelihood > SVGP_LIK_POISSON_EXP) return fail(ctx, SVGP_UNSUPPORTED, "unsupported likelihood");
+  if (d->parametrization != SVGP_NONCENTERED && d->parametrization != SVGP_CENTERED)
+    return fail(ctx, SVGP_INVALID_ARG, "parametrization must be SVGP_NONCENTERED or SVGP_CENTERED");
+  if (d->d < 1 || d->d > 32) return fail(ctx, SVGP_UNSUPPORTED, "input dimension must be in 1..32");
+  if (d->M < 1) return fail(ctx, SVGP_INVALID_ARG, "M must be >= 1");
+  if (d->layout_z < 0 || d->layout_z > SVGP_VEC) return fail(ctx, SVGP_INVALID_ARG, "bad layout_z");
+  if (d->layout_z == SVGP_VEC && d->d != 1) return fail(ctx, SVGP_INVALID_ARG, "SVGP_VEC layout requires d == 1");
+  if (d->quadrature_n < 0 || d->quadrature_n > 512) return fail(ctx, SVGP_INVALID_ARG, "quadrature_n must be in 0..512");
+  if (!d->inv_lengthscale || !d->z || !d->m || !d->Lq) return fail(ctx, SVGP_INVALID_ARG, "null parameter array");
+  if (!(d->variance > 0)) return fail(ctx, SVGP_INVALID_ARG, "kernel variance must be positive");
+  if (d->likelihood == SVGP_LIK_GAUSSIAN && !(d->lik_sigma2 > 0)) return fail(ctx, SVGP_INVALID_ARG, "Gaussian likelihood needs sigma2 > 0");
+  return SVGP_OK;
+}
+
+int effective_gh(const svgp_model_desc& d) {
+  if (d.quadrature_n > 0) return d.quadrature_n;
+  if (d.likelihood == SVGP_LIK_GAUSSIAN || d.likelihood == SVGP_LIK_POISSON_EXP) return 0;  // closed forms
+  return 20;  // DefaultExpectationMethod -> GaussHermiteExpectation(20)  [GPLikelihoods]
+}
+
+int upload_params(svgp_ctx* ctx, svgp_model* m, const svgp_model_desc* d) {
+  const size_t es = m->es;
+  m->desc = *d;
+  m->invl_host.assign(d->inv_lengthscale, d->inv_lengthscale + d->d);
+  m->desc.inv_lengthscale = m->invl_host.data();
+  m->desc.z = m->desc.m = m->desc.Lq = nullptr;  // host pointers are borrowed for the call only
+  HIPC(ctx, hipMemcpyAsync(m->z_raw, d->z, size_t(m->M) * m->d * es, hipMemcpyHostToDevice, ctx->stream));
+  HIPC(ctx, hipMemcpyAsync(m->m_raw, d->m, size_t(m->M) * es, hipMemcpyHostToDevice, ctx->stream));
+  HIPC(ctx, hipMemcpyAsync(m->Lq_raw, d->Lq, size_t(m->M) * m->M * es, hipMemcpyHostToDevice, ctx->stream));
+  if (m->dtype == SVGP_F64) {
+    HIPC(ctx, hipMemcpyAsync(m->invl, m->invl_host.data(), m->d * 8, hipMemcpyHostToDevice, ctx->stream));
+  } else {
+    std::vector<float> f(m->invl_host.begin(), m->invl_host.end());
+    HIPC(ctx, hipMemcpyAsync(m->invl, f.data(), m->d * 4, hipMemcpyHostToDevice, ctx->stream));
+    HIPC(ctx, hipStreamSynchronize(ctx->stream));
+  }
+  const int gh = effective_gh(*d);
+  if (gh != m->gh_n) {
+    if (m->gh_x) hipFree(m->gh_x);
+    if (m->gh_w) hipFree(m->gh_w);
+    m->gh_x = m->gh_w = nullptr;
+    m->gh_n = gh;
+    if (gh > 0) {
+      std::vector<double> xs(gh), ws(gh);
+      if (gauss_hermite(gh, xs.data(), ws.data()) != SVGP_OK) return fail(ctx, SVGP_INVALID_ARG, "Gauss-Hermite rule failed to converge");
+      for (auto& w : ws) w /= 1.7724538509055160273;
+      HIPC(ctx, hipMalloc(&m->gh_x, gh * 8));
+      HIPC(ctx, hipMalloc(&m->gh_w, gh * 8));
+      HIPC(ctx, hipMemcpy(m->gh_x, xs.data(), gh * 8, hipMemcpyHostToDevice));
+      HIPC(ctx, hipMemcpy(m->gh_w, ws.data(), gh * 8, hipMemcpyHostToDevice));
+    }
+  }
+  HIPC(ctx, hipStreamSynchronize(ctx->stream));  // host buffers may be released by the caller
+  m->prepared = false;
+  return SVGP_OK;
+}
+
+KernelParams kparams(const svgp_model* m) {
+  KernelParams kp;
+  kp.family = m->desc.kernel;
+  kp.d = m->d;
+  kp.variance = m->desc.variance;
+  kp.invl = m->invl;
+  return kp;
+}
+
+// The M-sized work of posterior(sva): enqueue only, no sync.
+int enqueue_prep(svgp_ctx* ctx, svgp_model* m) {
+  hipStream_t s = ctx->stream;
+  const KernelParams kp = kparams(m);
+  HIPC(ctx, hipMemsetAsync(m->info, 0, sizeof(int), s));
+  launch_scale_inputs(m->dtype, s, m->z_raw, m->desc.layout_z, m->d, m->M, m->Mp, m->invl, m->zs);
+  KCHECK(ctx, "scale_inputs");
+  launch_kuu(m->dtype, s, kp, m->zs, m->M, m->Mp, m->desc.jitter, m->L);
+  KCHECK(ctx, "kuu");
+  launch_potrf(m->dtype, s, m->L, m->T, m->Mp, m->info);
+  KCHECK(ctx, "potrf");
+  launch_tpanels(m->dtype, s, m->L, m->T, m->Mp);
+  KCHECK(ctx, "tpanels");
+  if (m->desc.parametrization == SVGP_NONCENTERED) {
+    launch_pack_q(m->dtype, s, m->Lq_raw, m->m_raw, m->M, m->Mp, m->U, m->mp);          // B = Lq      SVA:183-184
+    launch_kl_terms(m->dtype, s, m->Lq_raw, m->m_raw, m->L, m->M, m->Mp, m->scal);        // SVA:364-373
+  } else {
+    // Centered (SVA:115-136): B = Lk \ Lq, whitened mean m~ = Lk \ (m - mean(fz)); then α = Lk' \ m~ = Kuu \ (m - μ)
+    // and KL(q || p(u)) = ½(ΣB² + m~'m~ − M − logdet(BB')) — the NonCentered expression evaluated at (m~, B).
+    launch_pad_lower(m->dtype, s, m->Lq_raw, m->M, m->Mp, m->B);
+    launch_trsm_mat(m->dtype, s, m->T, m->Mp, m->B);
+    launch_shift_vec(m->dtype, s, m->m_raw, -m->desc.mean_const, m->M, m->Mp, m->mp);
+    launch_trsv2(m->dtype, s, m->L, m->T, m->Mp, 0, m->mp);
+    launch_pack_q_ld(m->dtype, s, m->B, m->Mp, nullptr, m->Mp, m->Mp, m->U, nullptr);
+    launch_kl_terms_ld(m->dtype, s, m->B, m->Mp, m->mp, m->L, m->M, m->Mp, m->scal);
+  }
+  KCHECK(ctx, "pack_q/kl");
+  return SVGP_OK;
+}
+
+// scalars of the last prep -> host (requires a stream sync by the caller before use)
+struct PrepScalars { double scal[4]; int info; };
+
+void finish_prep(svgp_model* m, const PrepScalars& ps) {
+  m->chol_info = ps.info;
+  m->kl = 0.5 * (ps.scal[0] + ps.scal[1] - double(m->M) - 2.0 * ps.scal[2]);
+  m->logdet_kuu = 2.0 * ps.scal[3];
+  m->prepared = (ps.info == 0);
+}
+
+int ensure_scratch(svgp_ctx* ctx, size_t work_bytes, size_t npoints) {
+  if (work_bytes > ctx->work_bytes) {
+    if (ctx->work) hipFree(ctx->work);
+    ctx->work = nullptr;
+    ctx->work_bytes = 0;
+    HIPC(ctx, hipMalloc(&ctx->work, work_bytes));
+    ctx->work_bytes = work_bytes;
+  }
+  if (npoints > ctx->mom_cap) {
+    if (ctx->mom) hipFree(ctx->mom);
+    ctx->mom = nullptr;
+    ctx->mom_cap = 0;
+    HIPC(ctx, hipMalloc(&ctx->mom, 2 * npoints * sizeof(double)));
+    ctx->mom_cap = npoints;
+  }
+  return SVGP_OK;
+}
+
+struct StripOuts {
+  void* mu = nullptr;
+  void* var = nullptr;
+  void* A = nullptr;
+  void* C = nullptr;
+  int64_t lda = 0;
+};
+
+// enqueue the fused strip kernel + final reduce over points [off, off+len) of (x, y)
+int enqueue_strips(svgp_ctx* ctx, svgp_model* m, const void* x, int64_t ldx, const void* y, int64_t off, int64_t len,
+                   const StripOuts& o) {
+  const int nt = strip_nt(m->dtype, m->Mp, len);
+  const int64_t nstrips = (len + nt - 1) / nt;
+  const int grid = strip_grid(m->dtype, nt, nstrips, ctx->num_cus);
+  int rc = ensure_scratch(ctx, strip_work_bytes(m->dtype, m->Mp, nt, grid), size_t(len));
+  if (rc) return rc;
+  StripArgs a{};
+  a.T = m->T;
+  a.U = m->U;
+  a.zs = m->zs;
+  a.mp = m->mp;
+  a.x = x;
+  a.work = ctx->work;
+  a.mom_mu = ctx->mom;
+  a.mom_var = ctx->mom + ctx->mom_cap;
+  a.A_out = o.A;
+  a.C_out = o.C;
+  a.lda = o.lda;
+  a.ldx = ldx;
+  a.off = off;
+  a.len = len;
+  a.Mp = m->Mp;
+  a.M = m->M;
+  a.kp = kparams(m);
+  a.mean_const = m->desc.mean_const;
+  LikParams lp{};
+  lp.lik = m->desc.likelihood;
+  lp.gh_n = m->gh_n;
+  lp.sigma2 = m->desc.likelihood == SVGP_LIK_GAUSSIAN ? m->desc.lik_sigma2 : 1.0;
+  lp.gh_x = m->gh_x;
+  lp.gh_w = m->gh_w;
+  lp.clamp_neg_var = (m->desc.neg_var_policy == SVGP_NEGVAR_CLAMP);
+  lp.mean_const = m->desc.mean_const;
+  launch_strip(m->dtype, ctx->stream, a, nt, grid, nstrips);
+  KCHECK(ctx, "strip");
+  launch_expect(m->dtype, ctx->stream, lp, a.mom_mu, a.mom_var, y, off, len, ctx->partial, ctx->negcnt, o.mu, o.var);
+  KCHECK(ctx, "expect");
+  launch_final_reduce(ctx->stream, ctx->partial, ctx->negcnt, expect_blocks(len), ctx->d_res);
+  KCHECK(ctx, "final_reduce");
+  ctx->timing.strip_launches = 1;
+  HIPC(ctx, hipGetLastError());
+  return SVGP_OK;
+}
+
+int check_batch(svgp_ctx* ctx, const svgp_model* m, const svgp_data* data, int64_t off, int64_t len, bool need_y) {
+  if (!ctx) return SVGP_INVALID_ARG;
+  if (!m || !data) return fail(ctx, SVGP_INVALID_ARG, "null model or data");
+  if (data->dtype != m->dtype) return fail(ctx, SVGP_INVALID_ARG, "data and model dtypes differ");
+  if (data->d != m->d) return fail(ctx, SVGP_INVALID_ARG, "data and model input dimensions differ");
+  if (off < 0 || len < 1 || off + len > data->n) return fail(ctx, SVGP_INVALID_ARG, "batch range outside the data");
+  if (need_y && !data->y) return fail(ctx, SVGP_INVALID_ARG, "data has no observations y");
+  return SVGP_OK;
+}
+
+// prep + strips + readback; returns E, n_neg, and refreshes the model's prep scalars
+int run_elbo(svgp_ctx* ctx, svgp_model* m, const svgp_data* data, int64_t off, int64_t len, double* E, double* nneg) {
+  hipStream_t s = ctx->stream;
+  HIPC(ctx, hipSetDevice(ctx->device));
+  HIPC(ctx, hipEventRecord(ctx->ev[0], s));
+  int rc = enqueue_prep(ctx, m);
+  if (rc) return rc;
+  HIPC(ctx, hipEventRecord(ctx->ev[1], s));
+  rc = enqueue_strips(ctx, m, data->x, data->ldx, data->y, off, len, StripOuts{});
+  if (rc) return rc;
+  HIPC(ctx, hipEventRecord(ctx->ev[2], s));
+  double res[2];
+  PrepScalars ps;
+  HIPC(ctx, hipMemcpyAsync(res, ctx->d_res, sizeof(res), hipMemcpyDeviceToHost, s));
+  HIPC(ctx, hipMemcpyAsync(ps.scal, m->scal, sizeof(ps.scal), hipMemcpyDeviceToHost, s));
+  HIPC(ctx, hipMemcpyAsync(&ps.info, m->info, sizeof(int), hipMemcpyDeviceToHost, s));
+  HIPC(ctx, hipStreamSynchronize(s));
+  finish_prep(m, ps);
+  float t01 = 0, t12 = 0;
+  hipEventElapsedTime(&t01, ctx->ev[0], ctx->ev[1]);
+  hipEventElapsedTime(&t12, ctx->ev[1], ctx->ev[2]);
+  ctx->timing.ms_prep = t01;
+  ctx->timing.ms_strip = t12;
+  ctx->timing.ms_total = t01 + t12;
+  ctx->timing.ms_kuf = 0;
+  *E = res[0];
+  *nneg = res[1];
+  return SVGP_OK;
+}
+
+int status_of(svgp_ctx* ctx, const svgp_model* m, double nneg) {
+  if (m->chol_info != 0) {
+    char buf[160];
+    snprintf(buf, sizeof buf, "Kuu is not positive definite: leading minor of order %d (PosDefException)", m->chol_info);
+    return fail(ctx, SVGP_NOT_POSDEF, buf);
+  }
+  if (nneg > 0 && m->desc.neg_var_policy == SVGP_NEGVAR_ERROR) {
+    char buf[160];
+    snprintf(buf, sizeof buf, "%lld predictive variances were negative (DomainError in sqrt)", (long long)nneg);
+    return fail(ctx, SVGP_NEG_VARIANCE, buf);
+  }
+  return SVGP_OK;
+}
+
+int ensure_prepared(svgp_ctx* ctx, svgp_model* m) {
+  if (m->prepared) return SVGP_OK;
+  int rc = enqueue_prep(ctx, m);
+  if (rc) return rc;
+  PrepScalars ps;
+  HIPC(ctx, hipMemcpyAsync(ps.scal, m->scal, sizeof(ps.scal), hipMemcpyDeviceToHost, ctx->stream));
+  HIPC(ctx, hipMemcpyAsync(&ps.info, m->info, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+  HIPC(ctx, hipStreamSynchronize(ctx->stream));
+  finish_prep(m, ps);
+  return status_of(ctx, m, 0);
+}
+
+int make_data(svgp_ctx* ctx, int dtype, int layout, int d, int64_t n, const void* x_host, const void* y_host,
+              svgp_data** out) {
+  if (!out) return fail(ctx, SVGP_INVALID_ARG, "null out pointer");
+  if (dtype != SVGP_F64 && dtype != SVGP_F32) return fail(ctx, SVGP_INVALID_ARG, "bad dtype");
+  if (d < 1 || d > 32 || n < 1 || !x_host) return fail(ctx, SVGP_INVALID_ARG, "bad data shape");
+  if (layout < 0 || layout > SVGP_VEC || (layout == SVGP_VEC && d != 1)) return fail(ctx, SVGP_INVALID_ARG, "bad layout");
+  const size_t es = esize(dtype);
+  svgp_data* D = new (std::nothrow) svgp_data();
+  if (!D) return SVGP_OOM;
+  D->dtype = dtype;
+  D->d = d;
+  D->n = n;
+  D->ldx = n;
+  hipStream_t s = ctx->stream;
+  hipError_t e = hipMalloc(&D->x, size_t(n) * d * es);
+  if (e == hipSuccess && y_host) e = hipMalloc(&D->y, size_t(n) * es);
+  if (e != hipSuccess) {
+    if (D->x) hipFree(D->x);
+    delete D;
+    return fail(ctx, SVGP_OOM, "hipMalloc failed for data");
+  }
+  if (layout == SVGP_COLVECS && d > 1) {
+    void* tmp = nullptr;
+    HIPC(ctx, hipMalloc(&tmp, size_t(n) * d * es));
+    HIPC(ctx, hipMemcpyAsync(tmp, x_host, size_t(n) * d * es, hipMemcpyHostToDevice, s));
+    launch_transpose_colvecs(dtype, s, tmp, d, n, D->ldx, D->x);
+    HIPC(ctx, hipStreamSynchronize(s));
+    hipFree(tmp);
+  } else {
+    HIPC(ctx, hipMemcpyAsync(D->x, x_host, size_t(n) * d * es, hipMemcpyHostToDevice, s));
+  }
+  if (y_host) HIPC(ctx, hipMemcpyAsync(D->y, y_host, size_t(n) * es, hipMemcpyHostToDevice, s));
+  HIPC(ctx, hipStreamSynchronize(s));
+  *out = D;
+  return SVGP_OK;
+}
+
+}  // namespace
+
+// ================================================================================================
+extern "C" {
+
+int32_t svgp_version(void) { return SVGP_ABI_VERSION; }
+
+int32_t svgp_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+int32_t svgp_gausshermite(int32_t n, double* nodes_out, double* weights_out) {
+  if (!nodes_out || !weights_out) return SVGP_INVALID_ARG;
+  return gauss_hermite(n, nodes_out, weights_out);
+}
+
+int32_t svgp_ctx_create(int32_t device_id, void* stream, svgp_ctx** out) {
+  if (!out) return SVGP_INVALID_ARG;
+  *out = nullptr;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n < 1) return SVGP_HIP_ERROR;  // no GPU: the library has no CPU path
+  if (device_id < 0 || device_id >= n) return SVGP_INVALID_ARG;
+  svgp_ctx* c = new (std::nothrow) svgp_ctx();
+  if (!c) return SVGP_OOM;
+  c->device = device_id;
+  if (hipSetDevice(device_id) != hipSuccess) { delete c; return SVGP_HIP_ERROR; }
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device_id) == hipSuccess) c->num_cus = prop.multiProcessorCount;
+  if (stream) {
+    c->stream = static_cast<hipStream_t>(stream);
+  } else {
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return SVGP_HIP_ERROR; }
+    c->own_stream = true;
+  }
+  for (auto& e : c->ev)
+    if (hipEventCreate(&e) != hipSuccess) { delete c; return SVGP_HIP_ERROR; }
+  if (hipMalloc(&c->d_res, 8 * sizeof(double)) != hipSuccess || hipMalloc(&c->partial, 1024 * sizeof(double)) != hipSuccess ||
+      hipMalloc(&c->negcnt, 1024 * sizeof(unsigned)) != hipSuccess) { delete c; return SVGP_OOM; }
+  *out = c;
+  return SVGP_OK;
+}
+
+int32_t svgp_ctx_destroy(svgp_ctx* c) {
+  if (!c) return SVGP_OK;
+  hipSetDevice(c->device);
+  hipStreamSynchronize(c->stream);
+  if (c->work) hipFree(c->work);
+  if (c->partial) hipFree(c->partial);
+  if (c->negcnt) hipFree(c->negcnt);
+  if (c->mom) hipFree(c->mom);
+  if (c->d_res) hipFree(c->d_res);
+  if (c->kuf_buf) hipFree(c->kuf_buf);
+  for (auto& e : c->ev)
+    if (e) hipEventDestroy(e);
+  if (c->own_stream) hipStreamDestroy(c->stream);
+  delete c;
+  return SVGP_OK;
+}
+
+const char* svgp_last_error(const svgp_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+int32_t svgp_last_timing(const svgp_ctx* ctx, svgp_timing* out) {
+  if (!ctx || !out) return SVGP_INVALID_ARG;
+  *out = ctx->timing;
+  return SVGP_OK;
+}
+
+int32_t svgp_data_upload(svgp_ctx* ctx, int32_t dtype, int32_t layout, int32_t d, int64_t n, const void* x_host,
+                         const void* y_host, svgp_data** out) {
+  if (!ctx) return SVGP_INVALID_ARG;
+  HIPC(ctx, hipSetDevice(ctx->device));
+  return make_data(ctx, dtype, layout, d, n, x_host, y_host, out);
+}
+
+int32_t svgp_data_wrap_device(svgp_ctx* ctx, int32_t dtype, int32_t d, int64_t n, int64_t ldx, const void* x_dev,
+                              const void* y_dev, svgp_data** out) {
+  if (!ctx) return SVGP_INVALID_ARG;
+  if (!out || !x_dev || d < 1 || d > 32 || n < 1 || ldx < n) return fail(ctx, SVGP_INVALID_ARG, "bad wrap arguments");
+  if (dtype != SVGP_F64 && dtype != SVGP_F32) return fail(ctx, SVGP_INVALID_ARG, "bad dtype");
+  svgp_data* D = new (std::nothrow) svgp_data();
+  if (!D) return SVGP_OOM;
+  D->dtype = dtype;
+  D->d = d;
+  D->n = n;
+  D->ldx = ldx;
+  D->x = const_cast<void*>(x_dev);
+  D->y = const_cast<void*>(y_dev);
+  D->own = false;
+  *out = D;
+  return SVGP_OK;
+}
+
+int32_t svgp_data_free(svgp_ctx* ctx, svgp_data* D) {
+  if (!D) return SVGP_OK;
+  if (ctx) hipSetDevice(ctx->device);
+  if (D->own) {
+    if (D->x) hipFree(D->x);
+    if (D->y) hipFree(D->y);
+  }
+  delete D;
+  return SVGP_OK;
+}
+
+int32_t svgp_model_free(svgp_ctx* ctx, svgp_model* m) {
+  if (!m) return SVGP_OK;
+  if (ctx) hipSetDevice(ctx->device);
+  void* bufs[] = {m->z_raw, m->m_raw, m->Lq_raw, m->invl, m->zs, m->L, m->T, m->U, m->mp, m->B, m->scal, m->info, m->gh_x, m->gh_w};
+  for (void* b : bufs)
+    if (b) hipFree(b);
+  delete m;
+  return SVGP_OK;
+}
+
+int32_t svgp_model_create(svgp_ctx* ctx, const svgp_model_desc* desc, svgp_model** out) {
+  if (!ctx) return SVGP_INVALID_ARG;
+  if (!out) return fail(ctx, SVGP_INVALID_ARG, "null out pointer");
+  *out = nullptr;
+  int rc = validate_desc(ctx, desc);
+  if (rc) return rc;
+  HIPC(ctx, hipSetDevice(ctx->device));
+  svgp_model* m = new (std::nothrow) svgp_model();
+  if (!m) return SVGP_OOM;
+  m->M = desc->M;
+  m->Mp = (desc->M + 127) / 128 * 128;
+  m->dtype = desc->dtype;
+  m->d = desc->d;
+  m->es = esize(desc->dtype);
+  const size_t es = m->es, M = size_t(m->M), Mp = size_t(m->Mp);
+  struct { void** p; size_t bytes; } allocs[] = {
+      {&m->z_raw, M * m->d * es}, {&m->m_raw, M * es},     {&m->Lq_raw, M * M * es}, {&m->invl, size_t(m->d) * es},
+      {&m->zs, Mp * m->d * es},   {&m->L, Mp * Mp * es},   {&m->T, Mp * Mp * es},    {&m->U, Mp * Mp * es},
+      {&m->mp, Mp * es},          {(void**)&m->scal, (8 + Mp) * sizeof(double)},     {(void**)&m->info, sizeof(int)},
+  };
+  for (auto& a : allocs)
+    if (hipMalloc(a.p, a.bytes) != hipSuccess) {
+      svgp_model_free(ctx, m);
+      return fail(ctx, SVGP_OOM, "hipMalloc failed for model buffers");
+    }
+  if (desc->parametrization == SVGP_CENTERED && hipMalloc(&m->B, Mp * Mp * es) != hipSuccess) {
+    svgp_model_free(ctx, m);
+    return fail(ctx, SVGP_OOM, "hipMalloc failed for model buffers");
+  }
+  HIPC(ctx, hipMemsetAsync(m->T, 0, Mp * Mp * es, ctx->stream));
+  rc = upload_params(ctx, m, desc);
+  if (rc) {
+    svgp_model_free(ctx, m);
+    return rc;
+  }
+  *out = m;
+  return SVGP_OK;
+}
+
+int32_t svgp_model_update(svgp_ctx* ctx, svgp_model* m, const svgp_model_desc* desc) {
+  if (!ctx) return SVGP_INVALID_ARG;
+  if (!m) return fail(ctx, SVGP_INVALID_ARG, "null model");
+  int rc = validate_desc(ctx, desc);
+  if (rc) return rc;
+  if (desc->M != m->M || desc->d != m->d || desc->dtype != m->dtype || desc->parametrization != m->desc.parametrization)
+    return fail(ctx, SVGP_INVALID_ARG, "svgp_model_update: M, d, dtype and parametrization must not change");
+  HIPC(ctx, hipSetDevice(ctx->device));
+  return upload_params(ctx, m, desc);
+}
+
+int32_t svgp_elbo_partial(svgp_ctx* ctx, svgp_model* m, const svgp_data* data, int64_t off, int64_t len,
+                          double partial_out[4]) {
+  int rc = check_batch(ctx, m, data, off, len, true);
+  if (rc) return rc;
+  if (!partial_out) return fail(ctx, SVGP_INVALID_ARG, "null output");
+  double E = 0, nneg = 0;
+  rc = run_elbo(ctx, m, data, off, len, &E, &nneg);
+  if (rc) return rc;
+  partial_out[0] = E;
+  partial_out[1] = double(len);
+  partial_out[2] = nneg;
+  partial_out[3] = double(m->chol_info);
+  return status_of(ctx, m, nneg);
+}
+
+int32_t svgp_elbo(svgp_ctx* ctx, svgp_model* m, const svgp_data* data, int64_t off, int64_t len, double num_data,
+                  double* elbo_out, svgp_terms* terms_out) {
+  int rc = check_batch(ctx, m, data, off, len, true);
+  if (rc) return rc;
+  double E = 0, nneg = 0;
+  rc = run_elbo(ctx, m, data, off, len, &E, &nneg);
+  if (rc) return rc;
+  const double scale = (num_data > 0 ? num_data : double(len)) / double(len);  // SVA:357-358
+  const double elbo = E * scale - m->kl;                                        // SVA:359
+  if (terms_out) {
+    terms_out->elbo = elbo;
+    terms_out->expectation = E;
+    terms_out->kl = m->kl;
+    terms_out->scale = scale;
+    terms_out->logdet_kuu = m->logdet_kuu;
+    terms_out->n_points = len;
+    terms_out->n_neg_var = (int64_t)nneg;
+    terms_out->chol_info = m->chol_info;
+    terms_out->reserved = 0;
+  }
+  rc = status_of(ctx, m, nneg);
+  if (elbo_out) *elbo_out = (rc == SVGP_OK) ? elbo : NAN;
+  return rc;
+}
+
+int32_t svgp_prior_kl(svgp_ctx* ctx, svgp_model* m, double* kl_out, double* logdet_out) {
+  if (!ctx) return SVGP_INVALID_ARG;
+  if (!m) return fail(ctx, SVGP_INVALID_ARG, "null model");
+  HIPC(ctx, hipSetDevice(ctx->device));
+  int rc = ensure_prepared(ctx, m);
+  if (rc) return rc;
+  if (kl_out) *kl_out = m->kl;
+  if (logdet_out) *logdet_out = m->logdet_kuu;
+  return SVGP_OK;
+}
+
+int32_t svgp_elbo_host(svgp_ctx* ctx, const svgp_model_desc* desc, int32_t layout_x, int64_t n, const void* x_host,
+                       const void* y_host, double num_data, double* elbo_out, svgp_terms* terms_out) {
+  if (!ctx) return SVGP_INVALID_ARG;
+  if (!desc || !y_host) return fail(ctx, SVGP_INVALID_ARG, "null descriptor or observations");
+  svgp_model* m = nullptr;
+  svgp_data* D = nullptr;
+  int rc = svgp_model_create(ctx, desc, &m);
+  if (rc) return rc;
+  rc = svgp_data_upload(ctx, desc->dtype, layout_x, desc->d, n, x_host, y_host, &D);
+  if (rc == SVGP_OK) rc = svgp_elbo(ctx, m, D, 0, n, num_data, elbo_out, terms_out);
+  svgp_data_free(ctx, D);
+  svgp_model_free(ctx, m);
+  return rc;
+}
+
+int32_t svgp_kuf(svgp_ctx* ctx, svgp_model* m, const svgp_data* data, int64_t off, int64_t len, void* Kuf_out_host) {
+  int rc = check_batch(ctx, m, data, off, len, false);
+  if (rc) return rc;
+  HIPC(ctx, hipSetDevice(ctx->device));
+  hipStream_t s = ctx->stream;
+  const size_t bytes = size_t(m->M) * size_t(len) * m->es;
+  if (bytes > ctx->kuf_bytes) {
+    if (ctx->kuf_buf) hipFree(ctx->kuf_buf);
+    ctx->kuf_buf = nullptr;
+    ctx->kuf_bytes = 0;
+    HIPC(ctx, hipMalloc(&ctx->kuf_buf, bytes));
+    ctx->kuf_bytes = bytes;
+  }
+  launch_scale_inputs(m->dtype, s, m->z_raw, m->desc.layout_z, m->d, m->M, m->Mp, m->invl, m->zs);
+  HIPC(ctx, hipEventRecord(ctx->ev[0], s));
+  launch_kuf(m->dtype, s, kparams(m), m->zs, m->M, m->Mp, data->x, data->ldx, off, len, ctx->kuf_buf);
+  HIPC(ctx, hipEventRecord(ctx->ev[1], s));
+  HIPC(ctx, hipGetLastError());
+  if (Kuf_out_host) HIPC(ctx, hipMemcpyAsync(Kuf_out_host, ctx->kuf_buf, bytes, hipMemcpyDeviceToHost, s));
+  HIPC(ctx, hipStreamSynchronize(s));
+  float t = 0;
+  hipEventElapsedTime(&t, ctx->ev[0], ctx->ev[1]);
+  ctx->timing = svgp_timing{};
+  ctx->timing.ms_kuf = t;
+  ctx->timing.ms_total = t;
+  return SVGP_OK;
+}
+
+int32_t svgp_posterior(svgp_ctx* ctx, svgp_model* m, void* Lk_out, void* alpha_out, void* B_out) {
+  if (!ctx) return SVGP_INVALID_ARG;
+  if (!m) return fail(ctx, SVGP_INVALID_ARG, "null model");
+  HIPC(ctx, hipSetDevice(ctx->device));
+  int rc = ensure_prepared(ctx, m);
+  if (rc) return rc;
+  hipStream_t s = ctx->stream;
+  const size_t es = m->es, M = size_t(m->M), Mp = size_t(m->Mp);
+  void* tmp = nullptr;
+  HIPC(ctx, hipMalloc(&tmp, (M * M + Mp) * es));
+  void* vec = static_cast<char*>(tmp) + M * M * es;
+  if (Lk_out) {
+    launch_extract_lower(m->dtype, s, m->L, m->Mp, m->M, tmp);
+    HIPC(ctx, hipMemcpyAsync(Lk_out, tmp, M * M * es, hipMemcpyDeviceToHost, s));
+    HIPC(ctx, hipStreamSynchronize(s));
+  }
+  if (alpha_out) {
+    // α = Lk' \ m~ (SVA:182; for Centered m~ = Lk \ (m − μ) so α = Kuu \ (m − μ), SVA:134)
+    HIPC(ctx, hipMemcpyAsync(vec, m->mp, Mp * es, hipMemcpyDeviceToDevice, s));
+    launch_trsv2(m->dtype, s, m->L, m->T, m->Mp, 1, vec);
+    HIPC(ctx, hipMemcpyAsync(alpha_out, vec, M * es, hipMemcpyDeviceToHost, s));
+    HIPC(ctx, hipStreamSynchronize(s));
+  }
+  if (B_out) {
+    if (m->desc.parametrization == SVGP_CENTERED) {
+      launch_extract_lower(m->dtype, s, m->B, m->Mp, m->M, tmp);
+    } else {
+      launch_extract_lower(m->dtype, s, m->Lq_raw, m->M, m->M, tmp);
+    }
+    HIPC(ctx, hipMemcpyAsync(B_out, tmp, M * M * es, hipMemcpyDeviceToHost, s));
+    HIPC(ctx, hipStreamSynchronize(s));
+  }
+  HIPC(ctx, hipGetLastError());
+  hipFree(tmp);
+  return SVGP_OK;
+}
+
+static int32_t predict_impl(svgp_ctx* ctx, svgp_model* m, int32_t layout, int64_t nx, const void* x_host, int64_t ny,
+                            const void* y_host, void* mean_out, void* var_out, void* cov_out, bool cross) {
+  if (!ctx) return SVGP_INVALID_ARG;
+  if (!m || !x_host || nx < 1) return fail(ctx, SVGP_INVALID_ARG, "bad predict arguments");
+  HIPC(ctx, hipSetDevice(ctx->device));
+  int rc = ensure_prepared(ctx, m);
+  if (rc) return rc;
+  hipStream_t s = ctx->stream;
+  const size_t es = m->es;
+  svgp_data* X = nullptr;
+  svgp_data* Y = nullptr;
+  rc = make_data(ctx, m->dtype, layout, m->d, nx, x_host, nullptr, &X);
+  if (rc) return rc;
+  if (cross) {
+    rc = make_data(ctx, m->dtype, layout, m->d, ny, y_host, nullptr, &Y);
+    if (rc) { svgp_data_free(ctx, X); return rc; }
+  }
+  auto pad = [](int64_t n) { return (n + 127) / 128 * 128; };
+  const int64_t ldax = pad(nx), lday = cross ? pad(ny) : 0;
+  void *mu = nullptr, *var = nullptr, *Ax = nullptr, *Cx = nullptr, *Ay = nullptr, *Cy = nullptr, *cov = nullptr;
+  const bool want_cov = cov_out != nullptr;
+  hipError_t e = hipSuccess;
+  if (e == hipSuccess) e = hipMalloc(&mu, size_t(nx) * es);
+  if (e == hipSuccess) e = hipMalloc(&var, size_t(nx) * es);
+  if (want_cov) {
+    if (e == hipSuccess) e = hipMalloc(&Ax, size_t(m->Mp) * ldax * es);
+    if (e == hipSuccess) e = hipMalloc(&Cx, size_t(m->Mp) * ldax * es);
+    if (cross) {
+      if (e == hipSuccess) e = hipMalloc(&Ay, size_t(m->Mp) * lday * es);
+      if (e == hipSuccess) e = hipMalloc(&Cy, size_t(m->Mp) * lday * es);
+    }
+    if (e == hipSuccess) e = hipMalloc(&cov, size_t(nx) * size_t(cross ? ny : nx) * es);
+  }
+  auto cleanup = [&]() {
+    for (void* p : {mu, var, Ax, Cx, Ay, Cy, cov})
+      if (p) hipFree(p);
+    svgp_data_free(ctx, X);
+    svgp_data_free(ctx, Y);
+  };
+  if (e != hipSuccess) { cleanup(); return fail(ctx, SVGP_OOM, "hipMalloc failed in predict"); }
+  StripOuts o;
+  o.mu = mu; o.var = var; o.A = Ax; o.C = Cx; o.lda = ldax;
+  rc = enqueue_strips(ctx, m, X->x, X->ldx, nullptr, 0, nx, o);
+  if (rc == SVGP_OK && cross && want_cov) {
+    StripOuts oy;
+    oy.A = Ay; oy.C = Cy; oy.lda = lday;
+    rc = enqueue_strips(ctx, m, Y->x, Y->ldx, nullptr, 0, ny, oy);
+  }
+  if (rc == SVGP_OK && want_cov) {
+    if (cross)
+      launch_cov_assemble(m->dtype, s, kparams(m), X->x, X->ldx, nx, Y->x, Y->ldx, ny, Ax, Cx, ldax, Ay, Cy, lday, m->Mp, cov);
+    else
+      launch_cov_assemble(m->dtype, s, kparams(m), X->x, X->ldx, nx, X->x, X->ldx, nx, Ax, Cx, ldax, Ax, Cx, ldax, m->Mp, cov);
+  }
+  hipError_t le = hipGetLastError();
+  if (rc == SVGP_OK && le != hipSuccess) rc = fail(ctx, SVGP_HIP_ERROR, hipGetErrorString(le));
+  if (rc == SVGP_OK) {
+    if (mean_out) hipMemcpyAsync(mean_out, mu, size_t(nx) * es, hipMemcpyDeviceToHost, s);
+    if (var_out) hipMemcpyAsync(var_out, var, size_t(nx) * es, hipMemcpyDeviceToHost, s);
+    if (want_cov) hipMemcpyAsync(cov_out, cov, size_t(nx) * size_t(cross ? ny : nx) * es, hipMemcpyDeviceToHost, s);
+    if (hipStreamSynchronize(s) != hipSuccess) rc = fail(ctx, SVGP_HIP_ERROR, "stream sync failed in predict");
+  } else {
+    hipStreamSynchronize(s);
+  }
+  cleanup();
+  return rc;
+}
+
+int32_t svgp_predict(svgp_ctx* ctx, svgp_model* m, int32_t layout_x, int64_t n, const void* x_host, void* mean_out,
+                     void* var_out, void* cov_out) {
+  return predict_impl(ctx, m, layout_x, n, x_host, 0, nullptr, mean_out, var_out, cov_out, false);
+}
+
+int32_t svgp_predict_cross_cov(svgp_ctx* ctx, svgp_model* m, int32_t layout, int64_t nx, const void* x_host, int64_t ny,
+                               const void* y_host, void* cov_out) {
+  if (ctx && (!y_host || ny < 1 || !cov_out)) return fail(ctx, SVGP_INVALID_ARG, "bad cross-cov arguments");
+  return predict_impl(ctx, m, layout, nx, x_host, ny, y_host, nullptr, nullptr, cov_out, true);
+}
+
+}  // extern "C"

@@ -1,0 +1,97 @@
+// Host-visible launch interface of the HIP kernels (implemented in prep.hip / strip.hip).
+// dtype: 0 = f64, 1 = f32 (SVGP_F64 / SVGP_F32).  All pointers are device pointers.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace svgp {
+
+struct KernelParams {
+  int family;        // SVGP_KERNEL_*
+  int d;
+  double variance;
+  const void* invl;  // [d] inverse lengthscales, compute dtype
+};
+
+struct LikParams {
+  int lik;            // SVGP_LIK_*
+  int gh_n;           // 0 = closed form
+  double sigma2;
+  const double* gh_x; // [gh_n] nodes (device)
+  const double* gh_w; // [gh_n] weights / sqrt(pi) (device)
+  int clamp_neg_var;
+  double mean_const;
+};
+
+// ---- prep.hip --------------------------------------------------------------------------------
+// zs[k][i] = z_k,i * invl[k] for i < M, 0 for M <= i < Mp.  z given per `layout` (SVGP_COLVECS...).
+void launch_scale_inputs(int dtype, hipStream_t s, const void* z, int layout, int d, int64_t M, int64_t Mp,
+                         const void* invl, void* zs);
+// host ColVecs (d x n, point-contiguous) -> feature-major [d][ldx]
+void launch_transpose_colvecs(int dtype, hipStream_t s, const void* x_dn, int d, int64_t n, int64_t ldx, void* x_fm);
+// Kuu (Mp x Mp col-major): k(z_i, z_j) + jitter*[i==j] on the M x M block, identity on the padding.
+void launch_kuu(int dtype, hipStream_t s, const KernelParams& kp, const void* zs, int64_t M, int64_t Mp,
+                double jitter, void* Kuu);
+// Blocked Cholesky in place (lower); T receives the inverted 128x128 diagonal blocks; info = 0 or the
+// 1-based order of the first non-positive pivot.
+void launch_potrf(int dtype, hipStream_t s, void* A, void* T, int64_t Mp, int* info);
+// T[I, <I] = -inv(L_II) * L[I, <I]   (diagonal blocks of T already hold inv(L_II))
+void launch_tpanels(int dtype, hipStream_t s, const void* L, void* T, int64_t Mp);
+// U = Lq' (upper triangular, Mp x Mp col-major, zero padding); also mp[i] = m[i] padded with zeros.
+void launch_pack_q(int dtype, hipStream_t s, const void* Lq, const void* m, int64_t M, int64_t Mp, void* U, void* mp);
+// scal[0] = sum(Lq.^2 lower), scal[1] = m'm, scal[2] = sum log diag Lq, scal[3] = sum log diag Lk (first M)
+void launch_kl_terms(int dtype, hipStream_t s, const void* Lq, const void* m, const void* Lk, int64_t M, int64_t Mp,
+                     double* scal);
+void launch_pack_q_ld(int dtype, hipStream_t s, const void* Lq, int64_t ldq, const void* m, int64_t M, int64_t Mp, void* U,
+                       void* mp);
+void launch_kl_terms_ld(int dtype, hipStream_t s, const void* Lq, int64_t ldq, const void* m, const void* Lk, int64_t M,
+                        int64_t Mp, double* scal);
+// x := L \ x (trans = 0) or L' \ x (trans = 1) for one vector of length Mp, using the inverted diagonal blocks in T
+void launch_trsv2(int dtype, hipStream_t s, const void* L, const void* Tm, int64_t Mp, int trans, void* x);
+// X := Lk \ X in place for a lower-triangular Mp x Mp column-major X (Centered B = Lk \ Lq, SVA:133)
+void launch_trsm_mat(int dtype, hipStream_t s, const void* Tm, int64_t Mp, void* X);
+// out (Mp x Mp, ld Mp) = lower triangle of Lq (M x M, ld M), zero elsewhere
+void launch_pad_lower(int dtype, hipStream_t s, const void* Lq, int64_t M, int64_t Mp, void* out);
+// out[i] = m[i] + shift for i < M, 0 for M <= i < Mp
+void launch_shift_vec(int dtype, hipStream_t s, const void* m, double shift, int64_t M, int64_t Mp, void* out);
+// copy the lower triangle of the leading M x M block of A (ld Mp) into out (ld M), zero the upper part
+void launch_extract_lower(int dtype, hipStream_t s, const void* A, int64_t Mp, int64_t M, void* out);
+
+// ---- strip.hip -------------------------------------------------------------------------------
+struct StripArgs {
+  const void* T;     // Mp x Mp col-major: block rows of inv(L_II) * [-L_I,<I | I]
+  const void* U;     // Mp x Mp col-major: B' (upper triangular)
+  const void* zs;    // [d][Mp] scaled inducing inputs
+  const void* mp;    // [Mp] padded mean of q
+  const void* x;     // [d][ldx] feature-major inputs
+  void* work;        // grid * Mp * NT elements: per-workgroup A strip
+  double* mom_mu;    // [len] posterior mean of every point of the batch      (SVA:250)
+  double* mom_var;   // [len] posterior variance, before the 1e-18 of f_post(x) (SVA:251)
+  void* A_out;       // nullable: A  = Lk \ Kuf as a k-major [Mp][lda] matrix (predict-cov path)
+  void* C_out;       // nullable: B'A
+  int64_t lda;
+  int64_t ldx, off, len;
+  int64_t Mp, M;
+  KernelParams kp;
+  double mean_const;
+};
+int strip_nt(int dtype, int64_t Mp, int64_t len);                 // column-strip width chosen for a problem
+size_t strip_work_bytes(int dtype, int64_t Mp, int nt, int grid);  // workspace bytes
+int strip_grid(int dtype, int nt, int64_t nstrips, int num_cus);
+void launch_strip(int dtype, hipStream_t s, const StripArgs& a, int nt, int grid, int64_t nstrips);
+// marginals + expected log-likelihood of every point (SVA:354-355): per-block sums into partial/negcnt
+int expect_blocks(int64_t len);
+void launch_expect(int dtype, hipStream_t s, const LikParams& lp, const double* mom_mu, const double* mom_var,
+                   const void* y, int64_t off, int64_t len, double* partial, unsigned* negcnt, void* mu_out,
+                   void* var_out);
+// out[0] = sum(partial[0..n)), out[1] = sum(negcnt) in fixed order (deterministic)
+void launch_final_reduce(hipStream_t s, const double* partial, const unsigned* negcnt, int64_t n, double* out);
+// standalone Kuf (M x len col-major, ld = M)
+void launch_kuf(int dtype, hipStream_t s, const KernelParams& kp, const void* zs, int64_t M, int64_t Mp,
+                const void* x, int64_t ldx, int64_t off, int64_t len, void* Kuf);
+// out(n x n col-major) = kxx - A'A + C'C  from k-major A, C ([Mp][lda]); prior block computed from x.
+void launch_cov_assemble(int dtype, hipStream_t s, const KernelParams& kp, const void* xa, int64_t ldxa, int64_t na,
+                         const void* xb, int64_t ldxb, int64_t nb, const void* Aa, const void* Ca, int64_t lda,
+                         const void* Ab, const void* Cb, int64_t ldb, int64_t Mp, void* out);
+
+}  // namespace svgp

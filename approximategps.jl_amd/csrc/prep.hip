@@ -1,0 +1,576 @@
+// prep.hip — the M-sized, data-independent part of posterior(sva) (reference
+// src/SparseVariationalApproximationModule.jl:160-187 and src/utils.jl:15-18) and of _prior_kl (:364-373):
+//   Kuu = k(z, z) + jitter I            (src/utils.jl:17 ∘ cov(::FiniteGP))
+//   Lk  = cholesky(Kuu).L               blocked right-looking: LDS-resident 128x128 POTF2 + MFMA TRSM/SYRK tiles
+//   T   = blkdiag(inv(L_II)) * [-L_strict | I]   so that the data-sized trsm (SVA:217) becomes pure GEMM panels
+//   U   = Lq'                           (SVA:183-184, B = Lq for NonCentered)
+//   KL scalars                          (SVA:364-373)
+// Everything is padded to Mp = ceil(M/128)*128 with an identity block so no kernel needs edge tiles.
+#include "device_common.hpp"
+#include "kernels.hpp"
+
+#include <cstdio>
+#include <cstdlib>
+
+namespace svgp {
+namespace {
+
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void scale_inputs_kernel(const T* __restrict__ z, int layout, int d, int64_t M, int64_t Mp,
+                                    const T* __restrict__ invl, T* __restrict__ zs) {
+  const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  const int f = blockIdx.y;
+  if (i >= Mp) return;
+  T v = T(0);
+  if (i < M) v = (layout == 1 ? z[int64_t(f) * M + i] : z[i * d + f]) * invl[f];  // RowVecs : ColVecs/Vec
+  zs[int64_t(f) * Mp + i] = v;
+}
+
+template <typename T>
+__global__ void transpose_colvecs_kernel(const T* __restrict__ x, int d, int64_t n, int64_t ldx, T* __restrict__ out) {
+  const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  for (int f = 0; f < d; ++f) out[int64_t(f) * ldx + i] = x[i * d + f];
+}
+
+template <typename T>
+__global__ void kuu_kernel(KernelParams kp, const T* __restrict__ zs, int64_t M, int64_t Mp, T jitter,
+                           T* __restrict__ K) {
+  const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  const int64_t j = blockIdx.y;
+  if (i >= Mp) return;
+  T v;
+  if (i < M && j < M) {
+    T r2 = T(0);
+    for (int f = 0; f < kp.d; ++f) {
+      const T df = zs[int64_t(f) * Mp + i] - zs[int64_t(f) * Mp + j];
+      r2 = fma(df, df, r2);
+    }
+    v = kappa<T>(kp.family, r2, T(kp.variance));
+    if (i == j) v += jitter;
+  } else {
+    v = (i == j) ? T(1) : T(0);
+  }
+  K[i + j * Mp] = v;
+}
+
+// ------------------------------------------------------------------------------------------------
+// POTF2 of one 128x128 diagonal block held in LDS, followed by its triangular inverse.
+// L overwrites the lower triangle of the block in A; inv(L) goes to the same block of Tm (upper = 0).
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(k256) potf2_kernel(T* __restrict__ A, T* __restrict__ Tm, int64_t ld,
+                                                          int* __restrict__ info, int pbase) {
+  constexpr int NB = kNB, LD = NB + 1;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  T* sm = reinterpret_cast<T*>(smem_raw);
+  __shared__ int failed;
+  const int tid = threadIdx.x;
+  if (tid == 0) failed = (*info != 0);
+  for (int e = tid; e < NB * NB; e += k256) {
+    const int i = e % NB, j = e / NB;
+    sm[i * LD + j] = A[i + int64_t(j) * ld];
+  }
+  __syncthreads();
+  if (failed) return;  // an earlier panel already reported the first bad pivot
+
+  const int i = tid % NB, h = tid / NB;
+  for (int j = 0; j < NB; ++j) {
+    const T djj = sm[j * LD + j];
+    if (!(djj > T(0))) {  // uniform: every thread reads the same LDS word
+      if (tid == 0) *info = pbase + j + 1;
+      return;
+    }
+    const T dj = ksqrt(djj);
+    if (h == 0) {
+      if (i == j) sm[j * LD + j] = dj;
+      else if (i > j) sm[i * LD + j] /= dj;
+    }
+    __syncthreads();
+    const T lij = sm[i * LD + j];
+    for (int k = j + 1 + h; k <= i; k += 2) sm[i * LD + k] -= lij * sm[k * LD + j];
+    __syncthreads();
+  }
+
+  // X = inv(L), column c by thread c; X' is kept in the strictly upper triangle of the LDS block.
+  T xcc = T(0);
+  if (tid < NB) xcc = T(1) / sm[tid * LD + tid];
+  for (int r = 1; r < NB; ++r) {
+    if (tid < r) {
+      const int c = tid;
+      T s = sm[r * LD + c] * xcc;
+      for (int k = c + 1; k < r; ++k) s = fma(sm[r * LD + k], sm[c * LD + k], s);
+      sm[c * LD + r] = -s / sm[r * LD + r];
+    }
+    // a thread only ever reads X entries it wrote itself, and L entries nobody writes: no barrier needed
+  }
+  __syncthreads();
+  for (int e = tid; e < NB * NB; e += k256) {
+    const int r = e % NB, c = e / NB;
+    if (r >= c) A[r + int64_t(c) * ld] = sm[r * LD + c];
+    T x = T(0);
+    if (r > c) x = sm[c * LD + r];
+    else if (r == c) x = T(1) / sm[r * LD + r];
+    Tm[r + int64_t(c) * ld] = x;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// 128x128 MFMA tile kernels used by the blocked Cholesky and the T panels.
+// ------------------------------------------------------------------------------------------------
+enum : int { MODE_TRSM = 0, MODE_SYRK = 1, MODE_TPANEL = 2 };
+
+__device__ __forceinline__ void tri_index(int b, int& i, int& j) {  // b -> (i >= j) in row-major triangle order
+  i = 0;
+  while (b >= i + 1) {
+    b -= i + 1;
+    ++i;
+  }
+  j = b;
+}
+
+template <typename T, int MODE>
+__global__ void __launch_bounds__(kThreads, 2) tile128_kernel(T* __restrict__ A, T* __restrict__ Tm, int64_t ld, int p) {
+  using G = TileGemm<T, kNB, 16>;
+  using QRegs = typename G::QRegs;
+  constexpr int NB = kNB;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  T* smem = reinterpret_cast<T*>(smem_raw);
+  typename G::Acc acc;
+  acc.zero();
+  if (MODE == MODE_TRSM) {
+    // X' = inv(L_pp) * A[i, p]'  ->  L[i, p] = A[i, p] inv(L_pp)'   (row block i = p + 1 + blockIdx.x)
+    const int i = p + 1 + blockIdx.x;
+    const T* P = Tm + int64_t(p) * NB + int64_t(p) * NB * ld;
+    const T* Q = A + int64_t(i) * NB + int64_t(p) * NB * ld;
+    auto qload = [&](int t, QRegs& r) { G::load_q(r, Q + int64_t(t) * 16 * ld, ld); };
+    G::loop(acc, P, ld, NB / 16, qload, smem);
+    T* C = A + int64_t(i) * NB + int64_t(p) * NB * ld;
+#pragma unroll
+    for (int a = 0; a < G::MI; ++a)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int b = 0; b < G::NJ; ++b) C[G::acc_col(b) + int64_t(G::acc_row(a, r)) * ld] = acc.v[a][b][r];
+  } else if (MODE == MODE_SYRK) {
+    // A[i, j] -= L[i, p] L[j, p]'  for p < j <= i, computed transposed so stores run along columns of A
+    int ti, tj;
+    tri_index(blockIdx.x, ti, tj);
+    const int i = p + 1 + ti, j = p + 1 + tj;
+    const T* P = A + int64_t(j) * NB + int64_t(p) * NB * ld;
+    const T* Q = A + int64_t(i) * NB + int64_t(p) * NB * ld;
+    auto qload = [&](int t, QRegs& r) { G::load_q(r, Q + int64_t(t) * 16 * ld, ld); };
+    G::loop(acc, P, ld, NB / 16, qload, smem);
+    T* C = A + int64_t(i) * NB + int64_t(j) * NB * ld;
+#pragma unroll
+    for (int a = 0; a < G::MI; ++a)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int b = 0; b < G::NJ; ++b) C[G::acc_col(b) + int64_t(G::acc_row(a, r)) * ld] -= acc.v[a][b][r];
+  } else {
+    // T[I, J] = -inv(L_II) L[I, J],  J < I
+    int ti, tj;
+    tri_index(blockIdx.x, ti, tj);
+    const int I = ti + 1, J = tj;
+    const T* P = Tm + int64_t(I) * NB + int64_t(I) * NB * ld;
+    const T* Q = A + int64_t(I) * NB + int64_t(J) * NB * ld;  // element (k, c) at Q[k + c*ld]
+    auto qload = [&](int t, QRegs& r) { G::load_q_trans(r, Q + int64_t(t) * 16, ld); };
+    G::loop(acc, P, ld, NB / 16, qload, smem);
+    T* C = Tm + int64_t(I) * NB + int64_t(J) * NB * ld;
+#pragma unroll
+    for (int a = 0; a < G::MI; ++a)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int b = 0; b < G::NJ; ++b) C[G::acc_row(a, r) + int64_t(G::acc_col(b)) * ld] = -acc.v[a][b][r];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void pack_q_kernel(const T* __restrict__ Lq, int64_t ldq, const T* __restrict__ m, int64_t M, int64_t Mp,
+                              T* __restrict__ U, T* __restrict__ mp) {
+  // U[j, k] = Lq[k, j] for k >= j (both < M), else 0.  32x32 LDS transpose keeps both sides coalesced.
+  __shared__ T tile[32][33];
+  const int64_t bj = int64_t(blockIdx.x) * 32, bk = int64_t(blockIdx.y) * 32;
+  for (int r = threadIdx.y; r < 32; r += blockDim.y) {
+    const int64_t k = bk + threadIdx.x, j = bj + r;  // read Lq[k + j*M]: consecutive threads -> consecutive k
+    tile[r][threadIdx.x] = (k < M && j < M && k >= j) ? Lq[k + j * ldq] : T(0);
+  }
+  __syncthreads();
+  for (int r = threadIdx.y; r < 32; r += blockDim.y) {
+    const int64_t j = bj + threadIdx.x, k = bk + r;  // write U[j + k*Mp]: consecutive threads -> consecutive j
+    U[j + k * Mp] = tile[threadIdx.x][r];
+  }
+  if (mp && blockIdx.y == 0 && threadIdx.y == 0) {
+    const int64_t i = bj + threadIdx.x;
+    mp[i] = (i < M) ? m[i] : T(0);
+  }
+}
+
+template <typename T>
+__global__ void kl_colsq_kernel(const T* __restrict__ Lq, int64_t ldq, int64_t M, double* __restrict__ colsq) {
+  __shared__ double sh[k256];
+  const int64_t j = blockIdx.x;
+  double s = 0.0;
+  for (int64_t i = j + threadIdx.x; i < M; i += k256) {
+    const double v = double(Lq[i + j * ldq]);
+    s = fma(v, v, s);
+  }
+  sh[threadIdx.x] = s;
+  __syncthreads();
+  for (int w = k256 / 2; w > 0; w >>= 1) {
+    if (int(threadIdx.x) < w) sh[threadIdx.x] += sh[threadIdx.x + w];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) colsq[j] = sh[0];
+}
+
+template <typename T>
+__global__ void kl_final_kernel(const T* __restrict__ Lq, int64_t ldq, const T* __restrict__ m, const T* __restrict__ Lk, int64_t M,
+                                int64_t Mp, const double* __restrict__ colsq, double* __restrict__ scal) {
+  __shared__ double sh[4][k256];
+  double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+  for (int64_t i = threadIdx.x; i < M; i += k256) {
+    s0 += colsq[i];
+    const double mi = double(m[i]);
+    s1 = fma(mi, mi, s1);
+    s2 += log(double(Lq[i + i * ldq]));
+    s3 += log(double(Lk[i + i * Mp]));
+  }
+  sh[0][threadIdx.x] = s0;
+  sh[1][threadIdx.x] = s1;
+  sh[2][threadIdx.x] = s2;
+  sh[3][threadIdx.x] = s3;
+  __syncthreads();
+  for (int w = k256 / 2; w > 0; w >>= 1) {
+    if (int(threadIdx.x) < w)
+      for (int q = 0; q < 4; ++q) sh[q][threadIdx.x] += sh[q][threadIdx.x + w];
+    __syncthreads();
+  }
+  if (threadIdx.x < 4) scal[threadIdx.x] = sh[threadIdx.x][0];
+}
+
+template <typename T>
+__global__ void extract_lower_kernel(const T* __restrict__ A, int64_t Mp, int64_t M, T* __restrict__ out) {
+  const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  const int64_t j = blockIdx.y;
+  if (i >= M) return;
+  out[i + j * M] = (i >= j) ? A[i + j * Mp] : T(0);
+}
+
+// ------------------------------------------------------------------------------------------------
+// x := L \ x (trans = 0) or L' \ x (trans = 1), blocked with the inverted diagonal blocks in Tm.
+// One workgroup; x (length Mp) lives in LDS.  Used by posterior(sva) for α (SVA:182), not by the ELBO.
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(k256) trsv_kernel(const T* __restrict__ L, const T* __restrict__ Tm, int64_t Mp,
+                                                         int trans, T* __restrict__ x) {
+  constexpr int NB = kNB;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  T* xs = reinterpret_cast<T*>(smem_raw);  // [Mp]
+  T* rs = xs + Mp;                          // [NB] right-hand side of the current block
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nP = int(Mp / NB);
+  for (int64_t i = tid; i < Mp; i += k256) xs[i] = x[i];
+  __syncthreads();
+  for (int step = 0; step < nP; ++step) {
+    const int I = trans ? nP - 1 - step : step;
+    if (!trans) {
+      // r_i = x_i - sum_{k < I*NB} L[i, k] x_k ; thread pair (i, h) strides k by 2 -> coalesced along i
+      const int i = tid % NB, h = tid / NB;
+      double s = 0.0;
+      for (int64_t k = h; k < int64_t(I) * NB; k += 2) s = fma(double(L[int64_t(I) * NB + i + k * Mp]), double(xs[k]), s);
+      __shared__ double part[2][NB];
+      part[h][i] = s;
+      __syncthreads();
+      if (tid < NB) rs[tid] = T(double(xs[I * NB + tid]) - part[0][tid] - part[1][tid]);
+      __syncthreads();
+      // x_I = inv(L_II) r : thread pair per row, coalesced along rows
+      double t = 0.0;
+      for (int k = h; k <= i; k += 2) t = fma(double(Tm[int64_t(I) * NB + i + (int64_t(I) * NB + k) * Mp]), double(rs[k]), t);
+      part[h][i] = t;
+      __syncthreads();
+      if (tid < NB) xs[I * NB + tid] = T(part[0][tid] + part[1][tid]);
+      __syncthreads();
+    } else {
+      // r_i = x_i - sum_{k >= (I+1)*NB} L[k, i] x_k : one wave per row i, lanes along k (contiguous)
+      for (int i = wave; i < NB; i += 4) {
+        double s = 0.0;
+        const T* col = L + (int64_t(I) * NB + i) * Mp;
+        for (int64_t k = int64_t(I + 1) * NB + lane; k < Mp; k += 64) s = fma(double(col[k]), double(xs[k]), s);
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        if (lane == 0) rs[i] = T(double(xs[I * NB + i]) - s);
+      }
+      __syncthreads();
+      // x_I = inv(L_II)' r : x_c = sum_{r >= c} Winv[r, c] r_r ; wave per column, lanes along r
+      for (int c = wave; c < NB; c += 4) {
+        double s = 0.0;
+        const T* col = Tm + int64_t(I) * NB + (int64_t(I) * NB + c) * Mp;
+        for (int r = c + lane; r < NB; r += 64) s = fma(double(col[r]), double(rs[r]), s);
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        if (lane == 0) xs[I * NB + c] = T(s);
+      }
+      __syncthreads();
+    }
+  }
+  for (int64_t i = tid; i < Mp; i += k256) x[i] = xs[i];
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// X := Lk \ X in place, X lower-triangular Mp x Mp column-major (Centered: B = Lk \ Lq, SVA:133).
+// One workgroup per 128-column tile; row panels sequentially, X_I = T[I, 0:(I+1)128] * [X_<I ; X_I].
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(kThreads, 2) trsm_mat_kernel(const T* __restrict__ Tm, T* __restrict__ X, int64_t Mp) {
+  using G = TileGemm<T, kNB, 16>;
+  using QRegs = typename G::QRegs;
+  constexpr int NB = kNB;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  T* smem = reinterpret_cast<T*>(smem_raw);
+  const int ct = blockIdx.x, nP = int(Mp / NB);
+  T* Xc = X + int64_t(ct) * NB * Mp;  // element (k, c) at Xc[k + c*Mp]
+  for (int I = ct; I < nP; ++I) {     // rows above the diagonal tile are zero
+    typename G::Acc acc;
+    acc.zero();
+    const int t0 = ct * (NB / 16);    // X[k, cols] = 0 for k < ct*128
+    auto qload = [&](int t, QRegs& r) { G::load_q_trans(r, Xc + int64_t(t0 + t) * 16, Mp); };
+    G::loop(acc, Tm + int64_t(I) * NB + int64_t(t0) * 16 * Mp, Mp, (I + 1) * (NB / 16) - t0, qload, smem);
+#pragma unroll
+    for (int a = 0; a < G::MI; ++a)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int b = 0; b < G::NJ; ++b) Xc[int64_t(I) * NB + G::acc_row(a, r) + int64_t(G::acc_col(b)) * Mp] = acc.v[a][b][r];
+    __syncthreads();
+  }
+}
+
+template <typename T>
+__global__ void pad_lower_kernel(const T* __restrict__ Lq, int64_t M, int64_t Mp, T* __restrict__ out) {
+  const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  const int64_t j = blockIdx.y;
+  if (i >= Mp) return;
+  out[i + j * Mp] = (i < M && j < M && i >= j) ? Lq[i + j * M] : T(0);
+}
+
+template <typename T>
+__global__ void shift_vec_kernel(const T* __restrict__ m, T shift, int64_t M, int64_t Mp, T* __restrict__ out) {
+  const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i < Mp) out[i] = (i < M) ? m[i] + shift : T(0);
+}
+
+// ------------------------------------------------------------------------------------------------
+// cov(f, xa, xb) = k(xa, xb) - Aa'Ab + Ca'Cb  (SVA:223-228, :255-264) from the k-major factors the strip
+// kernel wrote.  Tile (j-block of xb) x (i-block of xa) so that stores run along columns of the output.
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(kThreads, 2) cov_assemble_kernel(KernelParams kp, const T* __restrict__ xa, int64_t ldxa,
+                                                                    int64_t na, const T* __restrict__ xb, int64_t ldxb,
+                                                                    int64_t nb, const T* __restrict__ Aa,
+                                                                    const T* __restrict__ Ca, int64_t lda,
+                                                                    const T* __restrict__ Ab, const T* __restrict__ Cb,
+                                                                    int64_t ldb, int64_t Mp, T* __restrict__ out) {
+  using G = TileGemm<T, kNB, 16>;
+  using QRegs = typename G::QRegs;
+  constexpr int NB = kNB;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  T* smem = reinterpret_cast<T*>(smem_raw);
+  const int64_t i0 = int64_t(blockIdx.x) * NB, j0 = int64_t(blockIdx.y) * NB;
+  typename G::Acc acc;
+  acc.zero();
+  const int nsteps = int(Mp / 16);
+  {
+    auto qload = [&](int t, QRegs& r) { G::load_q(r, Aa + int64_t(t) * 16 * lda + i0, lda); };
+    G::loop(acc, Ab + j0, ldb, nsteps, qload, smem);
+  }
+#pragma unroll
+  for (int a = 0; a < G::MI; ++a)
+#pragma unroll
+    for (int b = 0; b < G::NJ; ++b) acc.v[a][b] = -acc.v[a][b];
+  {
+    auto qload = [&](int t, QRegs& r) { G::load_q(r, Ca + int64_t(t) * 16 * lda + i0, lda); };
+    G::loop(acc, Cb + j0, ldb, nsteps, qload, smem);
+  }
+  const T* __restrict__ invl = static_cast<const T*>(kp.invl);
+#pragma unroll
+  for (int a = 0; a < G::MI; ++a)
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int b = 0; b < G::NJ; ++b) {
+        const int64_t j = j0 + G::acc_row(a, r), i = i0 + G::acc_col(b);
+        if (i < na && j < nb) {
+          T r2 = T(0);
+          for (int f = 0; f < kp.d; ++f) {
+            const T df = (xa[int64_t(f) * ldxa + i] - xb[int64_t(f) * ldxb + j]) * invl[f];
+            r2 = fma(df, df, r2);
+          }
+          out[i + j * na] = kappa<T>(kp.family, r2, T(kp.variance)) + acc.v[a][b][r];
+        }
+      }
+}
+
+void dbg(const char* name, hipStream_t s) {
+  static const bool on = [] { const char* e = getenv("SVGP_DEBUG_SYNC"); return e && e[0] == '1'; }();
+  if (!on) return;
+  hipError_t e = hipPeekAtLastError();
+  if (e == hipSuccess) e = hipStreamSynchronize(s);
+  if (e != hipSuccess) fprintf(stderr, "[svgp debug] %s: %s\n", name, hipGetErrorString(e));
+}
+
+template <typename T>
+void potrf_t(hipStream_t s, T* A, T* Tm, int64_t Mp, int* info) {
+  using G = TileGemm<T, kNB, 16>;
+  const int nP = int(Mp / kNB);
+  const size_t lds_potf2 = size_t(kNB) * (kNB + 1) * sizeof(T);
+  set_max_lds(reinterpret_cast<const void*>(potf2_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds_potf2));
+  set_max_lds(reinterpret_cast<const void*>(tile128_kernel<T, MODE_TRSM>), hipFuncAttributeMaxDynamicSharedMemorySize, int(G::LDS_BYTES));
+  set_max_lds(reinterpret_cast<const void*>(tile128_kernel<T, MODE_SYRK>), hipFuncAttributeMaxDynamicSharedMemorySize, int(G::LDS_BYTES));
+  for (int p = 0; p < nP; ++p) {
+    T* diagA = A + int64_t(p) * kNB * (Mp + 1);
+    T* diagT = Tm + int64_t(p) * kNB * (Mp + 1);
+    hipLaunchKernelGGL(potf2_kernel<T>, dim3(1), dim3(k256), lds_potf2, s, diagA, diagT, Mp, info, p * kNB);
+    dbg("potf2", s);
+    const int n = nP - p - 1;
+    if (n > 0) {
+      hipLaunchKernelGGL((tile128_kernel<T, MODE_TRSM>), dim3(n), dim3(kThreads), G::LDS_BYTES, s, A, Tm, Mp, p);
+      dbg("tile128 trsm", s);
+      hipLaunchKernelGGL((tile128_kernel<T, MODE_SYRK>), dim3(n * (n + 1) / 2), dim3(kThreads), G::LDS_BYTES, s, A, Tm, Mp, p);
+    }
+  }
+}
+
+template <typename T>
+void tpanels_t(hipStream_t s, const T* L, T* Tm, int64_t Mp) {
+  using G = TileGemm<T, kNB, 16>;
+  const int nP = int(Mp / kNB);
+  set_max_lds(reinterpret_cast<const void*>(tile128_kernel<T, MODE_TPANEL>), hipFuncAttributeMaxDynamicSharedMemorySize, int(G::LDS_BYTES));
+  if (nP > 1)
+    hipLaunchKernelGGL((tile128_kernel<T, MODE_TPANEL>), dim3(nP * (nP - 1) / 2), dim3(kThreads), G::LDS_BYTES, s,
+                       const_cast<T*>(L), Tm, Mp, 0);
+}
+
+}  // namespace
+
+#define SVGP_DISPATCH(dtype, expr_d, expr_f) \
+  do {                                       \
+    if ((dtype) == 0) { expr_d; } else { expr_f; } \
+  } while (0)
+
+void launch_scale_inputs(int dtype, hipStream_t s, const void* z, int layout, int d, int64_t M, int64_t Mp,
+                         const void* invl, void* zs) {
+  dim3 grid((unsigned)((Mp + 255) / 256), (unsigned)d);
+  SVGP_DISPATCH(dtype,
+                hipLaunchKernelGGL(scale_inputs_kernel<double>, grid, dim3(256), 0, s, (const double*)z, layout, d, M, Mp, (const double*)invl, (double*)zs),
+                hipLaunchKernelGGL(scale_inputs_kernel<float>, grid, dim3(256), 0, s, (const float*)z, layout, d, M, Mp, (const float*)invl, (float*)zs));
+}
+
+void launch_transpose_colvecs(int dtype, hipStream_t s, const void* x, int d, int64_t n, int64_t ldx, void* out) {
+  dim3 grid((unsigned)((n + 255) / 256));
+  SVGP_DISPATCH(dtype,
+                hipLaunchKernelGGL(transpose_colvecs_kernel<double>, grid, dim3(256), 0, s, (const double*)x, d, n, ldx, (double*)out),
+                hipLaunchKernelGGL(transpose_colvecs_kernel<float>, grid, dim3(256), 0, s, (const float*)x, d, n, ldx, (float*)out));
+}
+
+void launch_kuu(int dtype, hipStream_t s, const KernelParams& kp, const void* zs, int64_t M, int64_t Mp, double jitter,
+                void* Kuu) {
+  dim3 grid((unsigned)((Mp + 255) / 256), (unsigned)Mp);
+  SVGP_DISPATCH(dtype,
+                hipLaunchKernelGGL(kuu_kernel<double>, grid, dim3(256), 0, s, kp, (const double*)zs, M, Mp, jitter, (double*)Kuu),
+                hipLaunchKernelGGL(kuu_kernel<float>, grid, dim3(256), 0, s, kp, (const float*)zs, M, Mp, float(jitter), (float*)Kuu));
+}
+
+void launch_potrf(int dtype, hipStream_t s, void* A, void* T, int64_t Mp, int* info) {
+  SVGP_DISPATCH(dtype, potrf_t<double>(s, (double*)A, (double*)T, Mp, info), potrf_t<float>(s, (float*)A, (float*)T, Mp, info));
+}
+
+void launch_tpanels(int dtype, hipStream_t s, const void* L, void* T, int64_t Mp) {
+  SVGP_DISPATCH(dtype, tpanels_t<double>(s, (const double*)L, (double*)T, Mp), tpanels_t<float>(s, (const float*)L, (float*)T, Mp));
+}
+
+void launch_pack_q_ld(int dtype, hipStream_t s, const void* Lq, int64_t ldq, const void* m, int64_t M, int64_t Mp, void* U,
+                       void* mp) {
+  dim3 grid((unsigned)(Mp / 32), (unsigned)(Mp / 32)), block(32, 8);
+  SVGP_DISPATCH(dtype,
+                hipLaunchKernelGGL(pack_q_kernel<double>, grid, block, 0, s, (const double*)Lq, ldq, (const double*)m, M, Mp, (double*)U, (double*)mp),
+                hipLaunchKernelGGL(pack_q_kernel<float>, grid, block, 0, s, (const float*)Lq, ldq, (const float*)m, M, Mp, (float*)U, (float*)mp));
+}
+
+void launch_pack_q(int dtype, hipStream_t s, const void* Lq, const void* m, int64_t M, int64_t Mp, void* U, void* mp) {
+  launch_pack_q_ld(dtype, s, Lq, M, m, M, Mp, U, mp);
+}
+
+void launch_kl_terms_ld(int dtype, hipStream_t s, const void* Lq, int64_t ldq, const void* m, const void* Lk, int64_t M,
+                        int64_t Mp, double* scal) {
+  double* colsq = scal + 8;  // caller provides 8 + M doubles
+  if (dtype == 0) {
+    hipLaunchKernelGGL(kl_colsq_kernel<double>, dim3((unsigned)M), dim3(k256), 0, s, (const double*)Lq, ldq, M, colsq);
+    hipLaunchKernelGGL(kl_final_kernel<double>, dim3(1), dim3(k256), 0, s, (const double*)Lq, ldq, (const double*)m, (const double*)Lk, M, Mp, colsq, scal);
+  } else {
+    hipLaunchKernelGGL(kl_colsq_kernel<float>, dim3((unsigned)M), dim3(k256), 0, s, (const float*)Lq, ldq, M, colsq);
+    hipLaunchKernelGGL(kl_final_kernel<float>, dim3(1), dim3(k256), 0, s, (const float*)Lq, ldq, (const float*)m, (const float*)Lk, M, Mp, colsq, scal);
+  }
+}
+
+void launch_kl_terms(int dtype, hipStream_t s, const void* Lq, const void* m, const void* Lk, int64_t M, int64_t Mp,
+                     double* scal) {
+  launch_kl_terms_ld(dtype, s, Lq, M, m, Lk, M, Mp, scal);
+}
+
+void launch_extract_lower(int dtype, hipStream_t s, const void* A, int64_t Mp, int64_t M, void* out) {
+  dim3 grid((unsigned)((M + 255) / 256), (unsigned)M);
+  SVGP_DISPATCH(dtype,
+                hipLaunchKernelGGL(extract_lower_kernel<double>, grid, dim3(256), 0, s, (const double*)A, Mp, M, (double*)out),
+                hipLaunchKernelGGL(extract_lower_kernel<float>, grid, dim3(256), 0, s, (const float*)A, Mp, M, (float*)out));
+}
+
+void launch_trsv2(int dtype, hipStream_t s, const void* L, const void* Tm, int64_t Mp, int trans, void* x) {
+  const size_t lds = size_t(Mp + kNB) * (dtype == 0 ? 8 : 4);
+  SVGP_DISPATCH(dtype,
+                hipLaunchKernelGGL(trsv_kernel<double>, dim3(1), dim3(k256), lds, s, (const double*)L, (const double*)Tm, Mp, trans, (double*)x),
+                hipLaunchKernelGGL(trsv_kernel<float>, dim3(1), dim3(k256), lds, s, (const float*)L, (const float*)Tm, Mp, trans, (float*)x));
+}
+
+void launch_trsm_mat(int dtype, hipStream_t s, const void* Tm, int64_t Mp, void* X) {
+  using Gd = TileGemm<double, kNB, 16>;
+  using Gf = TileGemm<float, kNB, 16>;
+  set_max_lds(reinterpret_cast<const void*>(trsm_mat_kernel<double>), hipFuncAttributeMaxDynamicSharedMemorySize, int(Gd::LDS_BYTES));
+  set_max_lds(reinterpret_cast<const void*>(trsm_mat_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, int(Gf::LDS_BYTES));
+  dim3 grid((unsigned)(Mp / kNB));
+  SVGP_DISPATCH(dtype,
+                hipLaunchKernelGGL(trsm_mat_kernel<double>, grid, dim3(kThreads), Gd::LDS_BYTES, s, (const double*)Tm, (double*)X, Mp),
+                hipLaunchKernelGGL(trsm_mat_kernel<float>, grid, dim3(kThreads), Gf::LDS_BYTES, s, (const float*)Tm, (float*)X, Mp));
+}
+
+void launch_pad_lower(int dtype, hipStream_t s, const void* Lq, int64_t M, int64_t Mp, void* out) {
+  dim3 grid((unsigned)((Mp + 255) / 256), (unsigned)Mp);
+  SVGP_DISPATCH(dtype,
+                hipLaunchKernelGGL(pad_lower_kernel<double>, grid, dim3(256), 0, s, (const double*)Lq, M, Mp, (double*)out),
+                hipLaunchKernelGGL(pad_lower_kernel<float>, grid, dim3(256), 0, s, (const float*)Lq, M, Mp, (float*)out));
+}
+
+void launch_shift_vec(int dtype, hipStream_t s, const void* m, double shift, int64_t M, int64_t Mp, void* out) {
+  dim3 grid((unsigned)((Mp + 255) / 256));
+  SVGP_DISPATCH(dtype,
+                hipLaunchKernelGGL(shift_vec_kernel<double>, grid, dim3(256), 0, s, (const double*)m, shift, M, Mp, (double*)out),
+                hipLaunchKernelGGL(shift_vec_kernel<float>, grid, dim3(256), 0, s, (const float*)m, float(shift), M, Mp, (float*)out));
+}
+
+void launch_cov_assemble(int dtype, hipStream_t s, const KernelParams& kp, const void* xa, int64_t ldxa, int64_t na,
+                         const void* xb, int64_t ldxb, int64_t nb, const void* Aa, const void* Ca, int64_t lda,
+                         const void* Ab, const void* Cb, int64_t ldb, int64_t Mp, void* out) {
+  using Gd = TileGemm<double, kNB, 16>;
+  using Gf = TileGemm<float, kNB, 16>;
+  set_max_lds(reinterpret_cast<const void*>(cov_assemble_kernel<double>), hipFuncAttributeMaxDynamicSharedMemorySize, int(Gd::LDS_BYTES));
+  set_max_lds(reinterpret_cast<const void*>(cov_assemble_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, int(Gf::LDS_BYTES));
+  dim3 grid((unsigned)((na + kNB - 1) / kNB), (unsigned)((nb + kNB - 1) / kNB));
+  SVGP_DISPATCH(dtype,
+                hipLaunchKernelGGL(cov_assemble_kernel<double>, grid, dim3(kThreads), Gd::LDS_BYTES, s, kp, (const double*)xa, ldxa, na, (const double*)xb, ldxb, nb, (const double*)Aa, (const double*)Ca, lda, (const double*)Ab, (const double*)Cb, ldb, Mp, (double*)out),
+                hipLaunchKernelGGL(cov_assemble_kernel<float>, grid, dim3(kThreads), Gf::LDS_BYTES, s, kp, (const float*)xa, ldxa, na, (const float*)xb, ldxb, nb, (const float*)Aa, (const float*)Ca, lda, (const float*)Ab, (const float*)Cb, ldb, Mp, (float*)out));
+}
+
+}  // namespace svgp

@@ -1,0 +1,396 @@
+// strip.hip — the data-parallel hot path of elbo(sva, lfx, y) (reference
+// src/SparseVariationalApproximationModule.jl:340-360 -> :246-253 -> :215-219) as ONE fused kernel.
+//
+// One 256-thread workgroup owns a strip of NT data points (columns) at a time and never lets the
+// M x NT blocks Kuf, A = Lk \ Kuf and B'A reach HBM as whole matrices:
+//   phase 1 (trsm, SVA:217):  for each 128-row panel I
+//        A_I = inv(L_II) K_I - (inv(L_II) L_I,<I) A_<I  =  T[I, 0:(I+1)128] * [A_<I ; K_I]
+//      one MFMA GEMM whose last 128 k-rows are GENERATED from x and z (Kuf assembly, SVA:216) straight
+//      into LDS; A_I goes to a per-workgroup scratch strip (L2/MALL resident), and
+//      colsumsq(A), A'm (= Kuf'α, SVA:250) accumulate in registers.
+//   phase 2 (trmm, SVA:251):  C_J = U[J, J*128:Mp] * A_>=J with U = B' ; colsumsq(C) in registers.
+//   epilogue: v = k(x,x) - Σ A² + Σ C² + 1e-18 (SVA:251, :354), expected log-likelihood per point
+//      (GPLikelihoods), deterministic per-strip sum.
+// Roofline: MFMA-bound (2 Mp² flops per point); algorithmic HBM bytes are only x, y.
+#include "device_common.hpp"
+#include "kernels.hpp"
+
+namespace svgp {
+
+namespace {
+
+constexpr double kDefaultSigma2 = 1e-18;  // AbstractGPs.default_σ² added by f_post(x) (SVA:354)
+
+__device__ __forceinline__ double softplus_d(double s) { return fmax(s, 0.0) + log1p(exp(-fabs(s))); }
+
+// log p(y | f)  [GPLikelihoods]
+__device__ __forceinline__ double loglik_point(int lik, double f, double y, double sigma2, double log_sigma2) {
+  if (lik == 0) {
+    const double r = y - f;
+    return -0.5 * (1.8378770664093453 + log_sigma2 + r * r / sigma2);
+  }
+  if (lik == 1) return -softplus_d(y > 0.5 ? -f : f);
+  return y * f - exp(f) - lgamma(y + 1.0);
+}
+
+// E_{N(mu, v)}[log p(y|f)]: closed form (gh_n == 0) or Gauss-Hermite  [GPLikelihoods.expected_loglikelihood]
+__device__ __forceinline__ double expected_loglik_point(const LikParams& lp, double mu, double v, double y,
+                                                        double log_sigma2) {
+  if (lp.gh_n == 0) {
+    if (lp.lik == 0) {
+      const double r = y - mu;
+      return -0.5 * (1.8378770664093453 + log_sigma2 + (r * r + v) / lp.sigma2);
+    }
+    return y * mu - exp(mu + 0.5 * v) - lgamma(y + 1.0);  // Poisson, exp link
+  }
+  const double s = 1.4142135623730951 * sqrt(v);
+  double acc = 0.0;
+  for (int q = 0; q < lp.gh_n; ++q) acc += lp.gh_w[q] * loglik_point(lp.lik, s * lp.gh_x[q] + mu, y, lp.sigma2, log_sigma2);
+  return acc;  // weights are pre-divided by sqrt(pi)
+}
+
+template <typename T, int NT, int BK>
+__global__ void __launch_bounds__(kThreads, 2) strip_kernel(StripArgs a, int64_t nstrips) {
+  using G = TileGemm<T, NT, BK>;
+  using Acc = typename G::Acc;
+  using QRegs = typename G::QRegs;
+  constexpr int NB = G::NB, MI = G::MI, NJ = G::NJ, VEC = G::VEC;
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  T* smem = reinterpret_cast<T*>(smem_raw);                 // staging (2 buffers), reused as reduction scratch
+  T* xs = smem + 2 * G::STAGE;                              // [d][NT] inputs of the strip, scaled by 1/l
+
+  const T* __restrict__ Tm = static_cast<const T*>(a.T);
+  const T* __restrict__ U = static_cast<const T*>(a.U);
+  const T* __restrict__ zs = static_cast<const T*>(a.zs);
+  const T* __restrict__ mp = static_cast<const T*>(a.mp);
+  const T* __restrict__ x = static_cast<const T*>(a.x);
+  const T* __restrict__ invl = static_cast<const T*>(a.kp.invl);
+  const int64_t Mp = a.Mp, M = a.M;
+  const int d = a.kp.d, family = a.kp.family;
+  const T variance = T(a.kp.variance);
+  const int nP = int(Mp / NB);
+  T* __restrict__ work = static_cast<T*>(a.work) + int64_t(blockIdx.x) * Mp * NT;
+  const int tid = threadIdx.x, lane = tid & 63;
+
+  for (int64_t strip = blockIdx.x; strip < nstrips; strip += gridDim.x) {
+    const int64_t c0 = strip * NT;                          // first column of the strip inside the batch
+    const int64_t last = a.off + a.len - 1;
+    // scaled inputs of the strip -> LDS (columns past the batch end replicate the last point; masked later)
+    for (int e = tid; e < d * NT; e += kThreads) {
+      const int f = e / NT, c = e % NT;
+      int64_t g = a.off + c0 + c;
+      g = g > last ? last : g;
+      xs[e] = x[int64_t(f) * a.ldx + g] * invl[f];
+    }
+    __syncthreads();
+
+    double sA[NJ], sM[NJ], sC[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) sA[j] = sM[j] = sC[j] = 0.0;
+
+    // ---------------- phase 1: A = Lk \ Kuf, panel by panel ----------------
+    for (int I = 0; I < nP; ++I) {
+      Acc acc;
+      acc.zero();
+      const int gen_from = I * (NB / BK);
+      auto qload = [&](int t, QRegs& r) {
+        if (t < gen_from) {
+          G::load_q(r, work + int64_t(t) * BK * NT, NT);
+        } else {
+#pragma unroll
+          for (int p = 0; p < G::Q_PASSES; ++p) {
+            int kk, c;
+            G::q_coord(p, kk, c);
+            const int64_t k = int64_t(t) * BK + kk;         // inducing index (row of Kuf)
+            T r2[VEC];
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) r2[e] = T(0);
+            for (int f = 0; f < d; ++f) {
+              const T zf = zs[int64_t(f) * Mp + k];
+#pragma unroll
+              for (int e = 0; e < VEC; ++e) {
+                const T df = xs[f * NT + c + e] - zf;
+                r2[e] = fma(df, df, r2[e]);
+              }
+            }
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) r.v[p][e] = (k < M) ? kappa<T>(family, r2[e], variance) : T(0);
+          }
+        }
+      };
+      G::loop(acc, Tm + int64_t(I) * NB, Mp, (I + 1) * (NB / BK), qload, smem);
+
+      // epilogue: A_I -> scratch strip, column sums in fp64
+#pragma unroll
+      for (int i = 0; i < MI; ++i) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = I * NB + G::acc_row(i, r);
+          const double mr = double(mp[row]);
+#pragma unroll
+          for (int j = 0; j < NJ; ++j) {
+            const T val = acc.v[i][j][r];
+            const int col = G::acc_col(j);
+            work[int64_t(row) * NT + col] = val;
+            if (a.A_out) static_cast<T*>(a.A_out)[int64_t(row) * a.lda + c0 + col] = val;
+            const double dv = double(val);
+            sA[j] = fma(dv, dv, sA[j]);
+            sM[j] = fma(dv, mr, sM[j]);
+          }
+        }
+      }
+      __syncthreads();  // scratch rows of panel I visible to the whole workgroup
+    }
+
+    // ---------------- phase 2: C = B' A ----------------
+    for (int J = 0; J < nP; ++J) {
+      Acc acc;
+      acc.zero();
+      const T* wq = work + int64_t(J) * NB * NT;
+      auto qload = [&](int t, QRegs& r) { G::load_q(r, wq + int64_t(t) * BK * NT, NT); };
+      G::loop(acc, U + int64_t(J) * NB + int64_t(J) * NB * Mp, Mp, (nP - J) * (NB / BK), qload, smem);
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int j = 0; j < NJ; ++j) {
+            const T val = acc.v[i][j][r];
+            if (a.C_out) static_cast<T*>(a.C_out)[int64_t(J * NB + G::acc_row(i, r)) * a.lda + c0 + G::acc_col(j)] = val;
+            const double dv = double(val);
+            sC[j] = fma(dv, dv, sC[j]);
+          }
+    }
+
+    // ---------------- per-point moments: mu = mean + A'm (SVA:250), v = k(x,x) - ΣA² + ΣC² (SVA:251) ----------------
+    double* red = reinterpret_cast<double*>(smem_raw);       // [3][WR][NT]; staging is idle here
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      double va = sA[j], vm = sM[j], vc = sC[j];
+      va += __shfl_xor(va, 16); va += __shfl_xor(va, 32);
+      vm += __shfl_xor(vm, 16); vm += __shfl_xor(vm, 32);
+      vc += __shfl_xor(vc, 16); vc += __shfl_xor(vc, 32);
+      if ((lane >> 4) == 0) {
+        const int wr = (tid >> 6) / G::WC;
+        const int col = G::acc_col(j);
+        red[(0 * G::WR + wr) * NT + col] = va;
+        red[(1 * G::WR + wr) * NT + col] = vm;
+        red[(2 * G::WR + wr) * NT + col] = vc;
+      }
+    }
+    __syncthreads();
+    if (tid < NT && c0 + tid < a.len) {
+      double qa = 0, qm = 0, qc = 0;
+#pragma unroll
+      for (int w = 0; w < G::WR; ++w) {
+        qa += red[(0 * G::WR + w) * NT + tid];
+        qm += red[(1 * G::WR + w) * NT + tid];
+        qc += red[(2 * G::WR + w) * NT + tid];
+      }
+      a.mom_mu[c0 + tid] = a.mean_const + qm;
+      a.mom_var[c0 + tid] = a.kp.variance - qa + qc;
+    }
+    __syncthreads();
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// marginals + expected_loglikelihood (SVA:354-355): one point per thread, fixed-order block sums.
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(k256) expect_kernel(LikParams lp, const double* __restrict__ mom_mu,
+                                                      const double* __restrict__ mom_var, const T* __restrict__ y,
+                                                      int64_t off, int64_t len, double* __restrict__ partial,
+                                                      unsigned* __restrict__ negcnt, T* __restrict__ mu_out,
+                                                      T* __restrict__ var_out) {
+  __shared__ double sh[k256];
+  __shared__ unsigned sn[k256];
+  const double log_sigma2 = log(lp.sigma2);
+  double e = 0.0;
+  unsigned neg = 0;
+  for (int64_t i = int64_t(blockIdx.x) * k256 + threadIdx.x; i < len; i += int64_t(gridDim.x) * k256) {
+    const double mu = mom_mu[i];
+    const double vraw = mom_var[i];
+    double v = vraw + kDefaultSigma2;                     // FiniteGP(f_post, x, 1e-18) -> marginals
+    bool bad = v < 0.0;
+    if (bad) {
+      ++neg;
+      if (lp.clamp_neg_var) { v = 0.0; bad = false; }
+    }
+    if (mu_out) mu_out[i] = T(mu);
+    if (var_out) var_out[i] = T(vraw);
+    if (y && !bad) e += expected_loglik_point(lp, mu, v, double(y[off + i]), log_sigma2);
+  }
+  sh[threadIdx.x] = e;
+  sn[threadIdx.x] = neg;
+  __syncthreads();
+  for (int w = k256 / 2; w > 0; w >>= 1) {
+    if (int(threadIdx.x) < w) {
+      sh[threadIdx.x] += sh[threadIdx.x + w];
+      sn[threadIdx.x] += sn[threadIdx.x + w];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    partial[blockIdx.x] = sh[0];
+    negcnt[blockIdx.x] = sn[0];
+  }
+}
+
+__global__ void final_reduce_kernel(const double* __restrict__ partial, const unsigned* __restrict__ negcnt, int64_t n,
+                                    double* __restrict__ out) {
+  // fixed-order tree: thread t sums elements t, t+256, ... then a fixed LDS tree -> bitwise reproducible
+  __shared__ double sh[k256];
+  __shared__ double sn[k256];
+  double s = 0.0, c = 0.0;
+  for (int64_t i = threadIdx.x; i < n; i += k256) {
+    s += partial[i];
+    c += double(negcnt[i]);
+  }
+  sh[threadIdx.x] = s;
+  sn[threadIdx.x] = c;
+  __syncthreads();
+  for (int w = k256 / 2; w > 0; w >>= 1) {
+    if (int(threadIdx.x) < w) {
+      sh[threadIdx.x] += sh[threadIdx.x + w];
+      sn[threadIdx.x] += sn[threadIdx.x + w];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    out[0] = sh[0];
+    out[1] = sn[0];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// standalone Kuf assembly (SVA:216): M x len column-major, HBM-write bound.
+// A workgroup writes a 128(i) x TJ(j) tile; each thread owns VEC consecutive rows (one 16-byte store
+// per column) so a wave's store instruction covers whole 128-byte lines of one column.
+// ---------------------------------------------------------------------------------------------
+template <typename T, int TJ>
+__global__ void __launch_bounds__(k256) kuf_kernel(KernelParams kp, const T* __restrict__ zs, int64_t M, int64_t Mp,
+                                                        const T* __restrict__ x, int64_t ldx, int64_t off, int64_t len,
+                                                        T* __restrict__ K) {
+  constexpr int VEC = Vec16<T>::N;
+  using V = typename Vec16<T>::type;
+  constexpr int TI = 128;
+  constexpr int IG = TI / VEC;          // row groups
+  constexpr int JG = k256 / IG;     // column groups
+  constexpr int RJ = TJ / JG;           // columns per thread
+  constexpr int DMAX = 32;
+  __shared__ T xt[DMAX][TJ];
+  const int d = kp.d;
+  const T* __restrict__ invl = static_cast<const T*>(kp.invl);
+  const int64_t j0 = int64_t(blockIdx.x) * TJ;
+  const int64_t i0 = int64_t(blockIdx.y) * TI;
+  for (int e = threadIdx.x; e < d * TJ; e += k256) {
+    const int f = e / TJ, c = e % TJ;
+    int64_t g = j0 + c;
+    g = g < len ? g : len - 1;
+    xt[f][c] = x[int64_t(f) * ldx + off + g] * invl[f];
+  }
+  __syncthreads();
+  const int ig = threadIdx.x % IG, jg = threadIdx.x / IG;
+  const int64_t i = i0 + int64_t(ig) * VEC;
+  T r2[RJ][VEC];
+#pragma unroll
+  for (int q = 0; q < RJ; ++q)
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) r2[q][e] = T(0);
+  for (int f = 0; f < d; ++f) {
+    const V zv = *reinterpret_cast<const V*>(zs + int64_t(f) * Mp + i);   // Mp is a multiple of 128: in bounds, aligned
+#pragma unroll
+    for (int q = 0; q < RJ; ++q) {
+      const T xv = xt[f][jg * RJ + q];
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) {
+        const T df = xv - zv[e];
+        r2[q][e] = fma(df, df, r2[q][e]);
+      }
+    }
+  }
+  const T variance = T(kp.variance);
+  const bool vec_ok = (M % VEC == 0) && (i + VEC <= M);
+#pragma unroll
+  for (int q = 0; q < RJ; ++q) {
+    const int64_t j = j0 + jg * RJ + q;
+    if (j >= len) continue;
+    V out;
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) out[e] = kappa<T>(kp.family, r2[q][e], variance);
+    if (vec_ok) {
+      *reinterpret_cast<V*>(K + j * M + i) = out;
+    } else {
+#pragma unroll
+      for (int e = 0; e < VEC; ++e)
+        if (i + e < M) K[j * M + i + e] = out[e];
+    }
+  }
+}
+
+template <typename T, int NT, int BK>
+void launch_strip_t(hipStream_t s, const StripArgs& a, int grid, int64_t nstrips) {
+  using G = TileGemm<T, NT, BK>;
+  const size_t lds = G::LDS_BYTES + size_t(a.kp.d) * NT * sizeof(T);
+  auto kern = strip_kernel<T, NT, BK>;
+  set_max_lds(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), lds, s, a, nstrips);
+}
+
+}  // namespace
+
+int strip_nt(int /*dtype*/, int64_t /*Mp*/, int64_t /*len*/) { return 128; }
+
+size_t strip_work_bytes(int dtype, int64_t Mp, int nt, int grid) {
+  return size_t(grid) * size_t(Mp) * size_t(nt) * (dtype == 0 ? 8 : 4);
+}
+
+int strip_grid(int /*dtype*/, int /*nt*/, int64_t nstrips, int num_cus) {
+  const int64_t cap = int64_t(num_cus) * 2;
+  return int(nstrips < cap ? nstrips : cap);
+}
+
+void launch_strip(int dtype, hipStream_t s, const StripArgs& a, int nt, int grid, int64_t nstrips) {
+  (void)nt;
+  if (dtype == 0)
+    launch_strip_t<double, 128, 16>(s, a, grid, nstrips);
+  else
+    launch_strip_t<float, 128, 16>(s, a, grid, nstrips);
+}
+
+int expect_blocks(int64_t len) {
+  const int64_t b = (len + k256 - 1) / k256;
+  return int(b < 1024 ? b : 1024);
+}
+
+void launch_expect(int dtype, hipStream_t s, const LikParams& lp, const double* mom_mu, const double* mom_var,
+                   const void* y, int64_t off, int64_t len, double* partial, unsigned* negcnt, void* mu_out,
+                   void* var_out) {
+  const int nb = expect_blocks(len);
+  if (dtype == 0)
+    hipLaunchKernelGGL(expect_kernel<double>, dim3(nb), dim3(k256), 0, s, lp, mom_mu, mom_var, (const double*)y, off, len,
+                       partial, negcnt, (double*)mu_out, (double*)var_out);
+  else
+    hipLaunchKernelGGL(expect_kernel<float>, dim3(nb), dim3(k256), 0, s, lp, mom_mu, mom_var, (const float*)y, off, len,
+                       partial, negcnt, (float*)mu_out, (float*)var_out);
+}
+
+void launch_final_reduce(hipStream_t s, const double* partial, const unsigned* negcnt, int64_t n, double* out) {
+  hipLaunchKernelGGL(final_reduce_kernel, dim3(1), dim3(k256), 0, s, partial, negcnt, n, out);
+}
+
+void launch_kuf(int dtype, hipStream_t s, const KernelParams& kp, const void* zs, int64_t M, int64_t Mp, const void* x,
+                int64_t ldx, int64_t off, int64_t len, void* Kuf) {
+  constexpr int TJ = 32;
+  dim3 grid((unsigned)((len + TJ - 1) / TJ), (unsigned)(Mp / 128));
+  if (dtype == 0)
+    hipLaunchKernelGGL((kuf_kernel<double, TJ>), grid, dim3(k256), 0, s, kp, static_cast<const double*>(zs), M, Mp,
+                       static_cast<const double*>(x), ldx, off, len, static_cast<double*>(Kuf));
+  else
+    hipLaunchKernelGGL((kuf_kernel<float, TJ>), grid, dim3(k256), 0, s, kp, static_cast<const float*>(zs), M, Mp,
+                       static_cast<const float*>(x), ldx, off, len, static_cast<float*>(Kuf));
+}
+
+}  // namespace svgp

@@ -1,0 +1,175 @@
+/*
+ * svgp_mi355x.h — C-ABI of libsvgp_mi355x.so: the MI355X-native (gfx950) sparse-variational-GP
+ * ELBO / posterior path that drops in under ApproximateGPs.jl's
+ * SparseVariationalApproximation / elbo / approx_lml / posterior API.
+ *
+ * The reference has NO FFI boundary today (pure Julia, multiple dispatch on AbstractGPs generics).
+ * Each entry point below therefore cites the reference METHOD BODY it replaces
+ * (paths relative to the reference repo; SVA = src/SparseVariationalApproximationModule.jl),
+ * and INTEGRATION.md shows the Julia `ccall` binding a maintainer would add.
+ *
+ * Conventions
+ *   - plain C, no C++/torch types; every function returns an int32 status (SVGP_OK == 0) and
+ *     never throws, aborts, prints or calls back into the host language.
+ *   - all matrices are column-major (Julia layout).  Host pointers are borrowed for the call only.
+ *   - array elements are in the compute dtype of the object (SVGP_F64 -> double, SVGP_F32 -> float);
+ *     scalars are always double.
+ *   - one svgp_ctx is bound to one GPU and one HIP stream; distinct contexts may be used
+ *     concurrently from different threads, one context is not re-entrant.  Calls block until
+ *     their host-visible results are written.
+ */
+#ifndef SVGP_MI355X_H
+#define SVGP_MI355X_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SVGP_ABI_VERSION 1
+
+/* status codes -> Julia exceptions raised by the shim */
+enum {
+  SVGP_OK = 0,
+  SVGP_INVALID_ARG = 1,  /* ArgumentError        (SVA:347-351 prior mismatch is checked Julia-side) */
+  SVGP_NOT_POSDEF = 2,   /* PosDefException(info) from cholesky(Kuu)  [LinearAlgebra]; info in svgp_terms */
+  SVGP_NEG_VARIANCE = 3, /* DomainError from sqrt(v < 0) inside marginals (SVA:354) */
+  SVGP_UNSUPPORTED = 4,  /* shim falls back to the pure-Julia method */
+  SVGP_HIP_ERROR = 5,
+  SVGP_RCCL_ERROR = 6,
+  SVGP_OOM = 7
+};
+
+enum { SVGP_F64 = 0, SVGP_F32 = 1 };
+
+/* input layouts [KernelFunctions]: ColVecs(X) X is d×n (a point is contiguous); RowVecs(X) X is n×d
+ * (a feature is contiguous); a plain Vector is d = 1. */
+enum { SVGP_COLVECS = 0, SVGP_ROWVECS = 1, SVGP_VEC = 2 };
+
+/* kernel families [KernelFunctions]: variance * (Base ∘ ARDTransform(inv_lengthscale)) */
+enum { SVGP_KERNEL_SE = 0, SVGP_KERNEL_MATERN32 = 1, SVGP_KERNEL_MATERN52 = 2 };
+
+/* likelihoods [GPLikelihoods]; SVA:307-317 wraps FiniteGP noise as GAUSSIAN(σ² = fx.Σy[1]) */
+enum { SVGP_LIK_GAUSSIAN = 0, SVGP_LIK_BERNOULLI_LOGISTIC = 1, SVGP_LIK_POISSON_EXP = 2 };
+
+/* SVA:41 Centered, SVA:57 NonCentered (the 2-arg constructor's default, SVA:93-95) */
+enum { SVGP_NONCENTERED = 0, SVGP_CENTERED = 1 };
+
+/* what to do when a predictive variance (+1e-18) is negative: the reference throws DomainError */
+enum { SVGP_NEGVAR_ERROR = 0, SVGP_NEGVAR_CLAMP = 1 };
+
+typedef struct svgp_ctx svgp_ctx;
+typedef struct svgp_data svgp_data;
+typedef struct svgp_model svgp_model;
+
+/* Everything a SparseVariationalApproximation + likelihood holds (SVA:59-62):
+ *   fz = GP(mean_const, variance * (Base ∘ ARD(inv_lengthscale)))(z, jitter),  q = MvNormal(m, Lq Lq'). */
+typedef struct svgp_model_desc {
+  int32_t dtype;           /* SVGP_F64 | SVGP_F32: compute dtype AND element type of z, m, Lq */
+  int32_t kernel;          /* SVGP_KERNEL_* */
+  int32_t parametrization; /* SVGP_NONCENTERED | SVGP_CENTERED */
+  int32_t likelihood;      /* SVGP_LIK_* */
+  int32_t quadrature_n;    /* 0 = DefaultExpectationMethod (analytic where closed form exists, else GH-20);
+                              n > 0 = GaussHermiteExpectation(n) */
+  int32_t layout_z;        /* layout of z: SVGP_COLVECS (d×M) | SVGP_ROWVECS (M×d) | SVGP_VEC */
+  int32_t neg_var_policy;  /* SVGP_NEGVAR_* */
+  int32_t d;               /* input dimension */
+  int64_t M;               /* number of inducing points */
+  double variance;         /* kernel variance σ_k² */
+  const double* inv_lengthscale; /* d entries; isotropic = all equal */
+  double mean_const;       /* ConstMean value, 0 for ZeroMean */
+  double jitter;           /* fz.Σy (isotropic), part of Kuu (src/utils.jl:17) */
+  double lik_sigma2;       /* GaussianLikelihood σ² */
+  const void* z;           /* inducing inputs */
+  const void* m;           /* mean(q), M */
+  const void* Lq;          /* _chol_lower(_chol_cov(q)) (src/utils.jl:15,18), M×M, upper triangle ignored */
+} svgp_model_desc;
+
+/* Optional breakdown of one ELBO evaluation (SVA:355-359). */
+typedef struct svgp_terms {
+  double elbo;        /* expectation * scale - kl */
+  double expectation; /* Σ_i E_{q(f_i)}[log p(y_i | f_i)], unscaled */
+  double kl;          /* _prior_kl(sva)  SVA:362-373 */
+  double scale;       /* num_data / n_batch  SVA:357-358 */
+  double logdet_kuu;  /* 2 Σ log diag chol(Kuu) */
+  int64_t n_points;
+  int64_t n_neg_var;  /* points whose variance + 1e-18 was negative */
+  int32_t chol_info;  /* 0, or the order of the first non-positive leading minor of Kuu (LAPACK info) */
+  int32_t reserved;
+} svgp_terms;
+
+/* Device timings of the last call on the context, measured with HIP events on the context's stream. */
+typedef struct svgp_timing {
+  double ms_total;
+  double ms_prep;  /* Kuu, cholesky, diagonal-block inverses, panel products, KL */
+  double ms_strip; /* fused Kuf -> trsm -> trmm -> expectation kernel (+ final reduce) */
+  double ms_kuf;   /* standalone Kuf assembly (svgp_kuf only) */
+  int64_t strip_launches;
+} svgp_timing;
+
+/* ---- library / context ------------------------------------------------------------------- */
+int32_t svgp_version(void);
+int32_t svgp_device_count(void);
+/* `stream` is a hipStream_t to run on (e.g. torch's current stream) or NULL to create a private one. */
+int32_t svgp_ctx_create(int32_t device_id, void* stream, svgp_ctx** out);
+int32_t svgp_ctx_destroy(svgp_ctx* ctx);
+/* text of the last error on ctx (owned by the library, valid until the next call on ctx) */
+const char* svgp_last_error(const svgp_ctx* ctx);
+int32_t svgp_last_timing(const svgp_ctx* ctx, svgp_timing* out);
+
+/* ---- data: x = lfx.fx.x, y (SVA:340-343) kept resident in HBM ------------------------------ */
+int32_t svgp_data_upload(svgp_ctx* ctx, int32_t dtype, int32_t layout, int32_t d, int64_t n,
+                         const void* x_host, const void* y_host, svgp_data** out);
+/* wrap device memory without copying: x_dev is feature-major [d][ldx] (RowVecs storage), y_dev may be NULL */
+int32_t svgp_data_wrap_device(svgp_ctx* ctx, int32_t dtype, int32_t d, int64_t n, int64_t ldx,
+                              const void* x_dev, const void* y_dev, svgp_data** out);
+int32_t svgp_data_free(svgp_ctx* ctx, svgp_data* data);
+
+/* ---- model: SparseVariationalApproximation(fz, q) + likelihood, resident in HBM -------------- */
+int32_t svgp_model_create(svgp_ctx* ctx, const svgp_model_desc* desc, svgp_model** out);
+/* new parameter values, same M / d / dtype (a training step) */
+int32_t svgp_model_update(svgp_ctx* ctx, svgp_model* model, const svgp_model_desc* desc);
+int32_t svgp_model_free(svgp_ctx* ctx, svgp_model* model);
+
+/* ---- elbo(sva, lfx, y; num_data, quadrature)  replaces SVA:340-360 (and :307-317, :276-280) --- */
+/* evaluates points [batch_off, batch_off + batch_len) of `data`; num_data <= 0 means batch_len. */
+int32_t svgp_elbo(svgp_ctx* ctx, svgp_model* model, const svgp_data* data, int64_t batch_off,
+                  int64_t batch_len, double num_data, double* elbo_out, svgp_terms* terms_out);
+/* data-parallel shard: only Σ_i E[log p(y_i|f_i)] over the shard's points (no scale, no KL), so that
+ * ranks sum partials with ONE all-reduce and subtract the KL once (SVA:355-359).
+ * partial_out[4] = {sum_expectation, n_points, n_neg_var, chol_info}. */
+int32_t svgp_elbo_partial(svgp_ctx* ctx, svgp_model* model, const svgp_data* data, int64_t batch_off,
+                          int64_t batch_len, double partial_out[4]);
+/* KL(q || p) and logdet(Kuu) of the model alone: _prior_kl  SVA:362-373 */
+int32_t svgp_prior_kl(svgp_ctx* ctx, svgp_model* model, double* kl_out, double* logdet_kuu_out);
+/* one-shot variant taking host x, y (the literal drop-in for an ad-hoc elbo(sva, fx, y) call) */
+int32_t svgp_elbo_host(svgp_ctx* ctx, const svgp_model_desc* desc, int32_t layout_x, int64_t n,
+                       const void* x_host, const void* y_host, double num_data, double* elbo_out,
+                       svgp_terms* terms_out);
+
+/* ---- posterior(sva)  replaces SVA:115-136 (Centered) / SVA:160-187 (NonCentered) -------------
+ * fills ApproxPosteriorGP.data = (Kuu = Cholesky(Lk), B, α): Lk_out M×M lower (upper zeroed),
+ * alpha_out M, B_out M×M (NULL to skip; NonCentered B is the caller's Lq). */
+int32_t svgp_posterior(svgp_ctx* ctx, svgp_model* model, void* Lk_out, void* alpha_out, void* B_out);
+
+/* ---- mean / var / mean_and_var / cov / mean_and_cov  replaces SVA:208-253 ---------------------
+ * mean_out, var_out: n (either may be NULL); cov_out: n×n or NULL (SVA:223-228). */
+int32_t svgp_predict(svgp_ctx* ctx, svgp_model* model, int32_t layout_x, int64_t n, const void* x_host,
+                     void* mean_out, void* var_out, void* cov_out);
+/* cross-covariance cov(f, x, y)  replaces SVA:255-264; cov_out is nx×ny */
+int32_t svgp_predict_cross_cov(svgp_ctx* ctx, svgp_model* model, int32_t layout, int64_t nx,
+                               const void* x_host, int64_t ny, const void* y_host, void* cov_out);
+
+/* ---- Kuf = cov(prior, z, x) alone  (SVA:216), for the "Kuf-assembly HBM GB/s" metric ----------
+ * Kuf_out_host: M×batch_len column-major or NULL (result stays in HBM; timing only). */
+int32_t svgp_kuf(svgp_ctx* ctx, svgp_model* model, const svgp_data* data, int64_t batch_off,
+                 int64_t batch_len, void* Kuf_out_host);
+
+/* ---- Gauss–Hermite rule used by GH-n (FastGaussQuadrature.gausshermite) ---------------------- */
+int32_t svgp_gausshermite(int32_t n, double* nodes_out, double* weights_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SVGP_MI355X_H */

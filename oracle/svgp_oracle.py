@@ -493,7 +493,8 @@ def synth_problem(
     rounded through ``dtype`` so fp32 runs and the fp64 oracle see identical inputs."""
     rng = np.random.default_rng(20260313 + config_id)
     x = rng.standard_normal((d, N))
-    z = x[:, :M] + 1e-3 * rng.standard_normal((d, M))
+    zbase = x[:, :M] if M <= N else rng.standard_normal((d, M))  # more inducing points than data: fresh draws
+    z = zbase + 1e-3 * rng.standard_normal((d, M))
     ell = math.sqrt(d) * (0.75 + 0.5 * np.arange(d) / d)
     kernel = Kernel(family, 1.3, 1.0 / ell)
     m = 0.1 * rng.standard_normal(M)

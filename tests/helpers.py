@@ -1,0 +1,22 @@
+"""Shared helpers for the parity tests: turn an oracle SVA (oracle/svgp_oracle.py) into the C-ABI objects."""
+import numpy as np
+
+import svgp_oracle as o
+from approxgp import _ffi
+
+
+def desc_from_oracle(sva: o.SVA, dtype=np.float64, lik=o.LIK_GAUSSIAN, sigma2=1.0, quadrature_n=0,
+                     neg_var_policy=_ffi.NEGVAR_ERROR):
+    return _ffi.make_desc(
+        dtype, sva.kernel.family, sva.kernel.variance, sva.kernel.inv_lengthscale, sva.z, sva.m, sva.Lq, sva.jitter,
+        parametrization=_ffi.CENTERED if sva.centered else _ffi.NONCENTERED, likelihood=lik, lik_sigma2=sigma2,
+        quadrature_n=quadrature_n, mean_const=sva.mean_const, neg_var_policy=neg_var_policy)
+
+
+def device_model(ctx, sva, **kw):
+    desc, keep = desc_from_oracle(sva, **kw)
+    return _ffi.DeviceModel(ctx, desc, keep)
+
+
+def rel(a, b):
+    return abs(a - b) / max(abs(b), 1e-300)

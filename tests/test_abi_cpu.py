@@ -1,0 +1,100 @@
+"""CPU-side checks (no GPU): the C-ABI library loads and exports every symbol include/svgp_mi355x.h
+declares, the host-only entry points work, the product refuses to run without a GPU, and the Python
+host mirror reproduces the reference's argument checks."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import approxgp
+from approxgp import _ffi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _has_gpu():
+    return _ffi.load_library().svgp_device_count() > 0
+
+
+def test_library_exports_every_declared_symbol():
+    header = open(os.path.join(ROOT, "include", "svgp_mi355x.h")).read()
+    declared = set(re.findall(r"\b(svgp_[a-z_0-9]+)\s*\(", header))
+    assert declared, "no declarations parsed"
+    lib = _ffi.load_library()
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"{name} declared in the header but not exported"
+    assert declared == set(_ffi.SYMBOLS), "ctypes table and header disagree"
+    assert lib.svgp_version() == 1
+
+
+def test_gausshermite_matches_numpy():
+    for n in (1, 2, 5, 20, 33):
+        xs, ws = approxgp.gausshermite(n)
+        x2, w2 = np.polynomial.hermite.hermgauss(n)
+        np.testing.assert_allclose(xs, x2, atol=1e-13)
+        np.testing.assert_allclose(ws, w2, rtol=1e-11)
+    with pytest.raises(ValueError):
+        approxgp.gausshermite(0)
+
+
+@pytest.mark.skipif(_has_gpu(), reason="checks the no-GPU failure mode")
+def test_no_cpu_fallback_without_gpu():
+    lib = _ffi.load_library()
+    h = C.c_void_p()
+    assert lib.svgp_ctx_create(0, None, C.byref(h)) == _ffi.HIP_ERROR
+    with pytest.raises(_ffi.SvgpError):
+        _ffi.Context(0)
+    f = approxgp.GP(approxgp.SqExponentialKernel())
+    sva = approxgp.SparseVariationalApproximation(f(np.linspace(0, 1, 4), 1e-6), approxgp.MvNormal(np.zeros(4), np.eye(4)))
+    with pytest.raises(_ffi.SvgpError):
+        approxgp.elbo(sva, f(np.linspace(0, 1, 9), 0.1), np.zeros(9))
+
+
+def test_kernel_unpacking():
+    from approxgp.kernels import unpack_kernel
+
+    k = 1.3 * approxgp.with_lengthscale(approxgp.SqExponentialKernel(), 0.3)
+    fam, var, il = unpack_kernel(k, 1)
+    assert (fam, var) == (_ffi.KERNEL_SE, 1.3) and il[0] == pytest.approx(1 / 0.3)
+    k = 0.7 * (approxgp.Matern52Kernel() @ approxgp.ARDTransform([1.0, 2.0, 4.0]))
+    fam, var, il = unpack_kernel(k, 3)
+    assert fam == _ffi.KERNEL_MATERN52 and list(il) == [1.0, 2.0, 4.0]
+    fam, var, il = unpack_kernel(approxgp.Matern32Kernel(), 2)  # test file's GP(Matern32Kernel())
+    assert (fam, var, list(il)) == (_ffi.KERNEL_MATERN32, 1.0, [1.0, 1.0])
+    with pytest.raises(ValueError):
+        unpack_kernel(k, 2)
+
+
+def test_reference_argument_checks_happen_before_the_gpu():
+    f, g = approxgp.GP(approxgp.SqExponentialKernel()), approxgp.GP(approxgp.SqExponentialKernel())
+    z, x, y = np.linspace(0, 1, 4), np.linspace(0, 1, 9), np.zeros(9)
+    sva = approxgp.SparseVariationalApproximation(f(z, 1e-6), approxgp.MvNormal(np.zeros(4), np.eye(4)))
+    assert isinstance(sva.parametrization, approxgp.NonCentered)  # SVA:93-95
+    assert approxgp.SVGP(f(z, 1e-6), approxgp.MvNormal(np.zeros(4), np.eye(4))).is_centered  # deprecations.jl:1
+    with pytest.raises(RuntimeError, match="homoscedastic"):  # SVA:319-327
+        approxgp.elbo(sva, f(x, np.full(9, 0.1)), y)
+    with pytest.raises(ValueError, match="not consistent"):  # SVA:347-351
+        approxgp.elbo(sva, g(x, 0.1), y)
+    with pytest.raises(AssertionError):  # SVA:192
+        approxgp.posterior(sva, g(x, 0.1), y)
+
+
+def test_mvnormal_factor_is_free_or_one_potrf():
+    A = np.tril(np.random.default_rng(0).standard_normal((5, 5))) + 5 * np.eye(5)
+    q = approxgp.MvNormal.from_cholesky(np.zeros(5), A)
+    assert q.chol_lower is q._L
+    q2 = approxgp.MvNormal(np.zeros(5), A @ A.T)
+    np.testing.assert_allclose(np.abs(q2.chol_lower), np.abs(A), atol=1e-12)
+
+
+def test_make_desc_layouts():
+    z = np.arange(6, dtype=np.float64).reshape(2, 3)  # d=2, M=3 ColVecs
+    desc, keep = _ffi.make_desc(np.float64, 0, 1.0, [1.0, 2.0], z, np.zeros(3), np.eye(3), 1e-6)
+    assert (desc.d, desc.M, desc.layout_z) == (2, 3, _ffi.COLVECS)
+    assert keep[1].flags.f_contiguous and list(keep[1].ravel(order="K")) == [0, 3, 1, 4, 2, 5]  # point-contiguous
+    desc, keep = _ffi.make_desc(np.float32, 0, 1.0, 2.0, np.zeros(7), np.zeros(7), np.eye(7), 1e-6)
+    assert (desc.d, desc.M, desc.layout_z, desc.dtype) == (1, 7, _ffi.VEC, _ffi.F32)
+    with pytest.raises(ValueError):
+        _ffi.make_desc(np.float64, 0, 1.0, 1.0, np.zeros(7), np.zeros(6), np.eye(7), 1e-6)

@@ -1,0 +1,62 @@
+"""world_size-2 gloo test of the data-parallel ELBO host logic (approxgp/distributed.py): shard ranges,
+ONE all-reduce of {ΣE, n, n_neg, chol}, KL subtracted once.  The per-shard partial sums come from the
+CPU oracle here (test infrastructure); on the GPU ranks they come from svgp_elbo_partial."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch.multiprocessing as mp
+
+from approxgp.distributed import combine, shard_range
+
+
+def test_shard_ranges_cover_everything():
+    for n in (1, 7, 100, 262144 * 8 + 3):
+        for world in (1, 2, 3, 8):
+            spans = [shard_range(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1
+    with pytest.raises(ValueError):
+        shard_range(10, 2, 2)
+
+
+def test_combine():
+    assert combine([10.0, 5, 0, 0], 1.5, 50) == pytest.approx(10.0 * 10 - 1.5)
+    with pytest.raises(ArithmeticError):
+        combine([10.0, 5, 0, 1], 1.5, 50)
+
+
+def _worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for p in (os.path.join(root, "approximategps.jl_amd"), os.path.join(root, "oracle")):
+        sys.path.insert(0, p)
+    import torch.distributed as dist
+
+    import svgp_oracle as o
+    from approxgp.distributed import allreduce_partials, combine, shard_range
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    x, y, sva, s2 = o.synth_problem(21, 301, 12, 3)
+    lo, hi = shard_range(301, rank, world)
+    t = o.elbo_terms(sva, x[:, lo:hi], y[lo:hi], sigma2=s2)
+    total = allreduce_partials([t.expectation, hi - lo, 0, 0])
+    val = combine(total, t.kl, 1e4)
+    if rank == 0:
+        full = o.elbo(sva, x, y, sigma2=s2, num_data=1e4)
+        np.save(out, np.array([val, full]))
+    dist.destroy_process_group()
+
+
+def test_two_rank_gloo_elbo_equals_single_process(tmp_path):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = str(tmp_path / "res.npy")
+    mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
+    val, full = np.load(out)
+    assert val == pytest.approx(full, rel=1e-12)

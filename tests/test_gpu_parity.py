@@ -1,0 +1,251 @@
+"""GPU parity: the HIP path through the C-ABI vs the CPU oracle on identical seeded inputs.
+Tolerances: fp64 rel 1e-8 on the ELBO (north star; observed ~1e-12), fp32 rel 1e-4 vs the fp64 oracle
+evaluated on the fp32-rounded inputs."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+import svgp_oracle as o
+from approxgp import _ffi
+from helpers import device_model, rel
+
+pytestmark = pytest.mark.gpu
+
+F64_RTOL = 1e-8
+F32_RTOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = _ffi.Context(0)
+    yield c
+    c.close()
+
+
+def _run(ctx, sva, x, y, dtype=np.float64, lik=o.LIK_GAUSSIAN, sigma2=1.0, qn=0, num_data=None, off=0, length=None):
+    model = device_model(ctx, sva, dtype=dtype, lik=lik, sigma2=sigma2, quadrature_n=qn)
+    data = _ffi.DeviceData(ctx, x, y, dtype)
+    try:
+        return model.elbo(data, off, length, 0.0 if num_data is None else num_data)
+    finally:
+        model.free()
+        data.free()
+
+
+CASES = [
+    # N, M, d, family, lik, qn
+    (1000, 32, 1, o.KERNEL_SE, o.LIK_GAUSSIAN, 0),            # C1 shape
+    (777, 200, 3, o.KERNEL_MATERN32, o.LIK_GAUSSIAN, 0),      # ragged M and N
+    (1500, 256, 8, o.KERNEL_SE, o.LIK_GAUSSIAN, 0),           # two row panels
+    (900, 300, 16, o.KERNEL_MATERN52, o.LIK_BERNOULLI_LOGISTIC, 0),  # C3 kernel/lik, GH-20
+    (640, 129, 2, o.KERNEL_SE, o.LIK_POISSON_EXP, 0),
+    (513, 64, 5, o.KERNEL_MATERN52, o.LIK_GAUSSIAN, 9),       # GH on a Gaussian (K2)
+    (130, 140, 2, o.KERNEL_SE, o.LIK_GAUSSIAN, 0),            # M > N
+    (1, 5, 1, o.KERNEL_SE, o.LIK_GAUSSIAN, 0),                # a single point
+]
+
+
+@pytest.mark.parametrize("N,M,d,family,lik,qn", CASES)
+def test_elbo_fp64_matches_oracle(ctx, N, M, d, family, lik, qn):
+    x, y, sva, s2 = o.synth_problem(100 + N, N, M, d, family=family, lik=lik)
+    ref = o.elbo_terms(sva, x, y, lik=lik, sigma2=s2, num_data=3.5 * N, quadrature_n=qn)
+    val, t = _run(ctx, sva, x, y, lik=lik, sigma2=s2, qn=qn, num_data=3.5 * N)
+    assert rel(val, ref.elbo) < F64_RTOL
+    assert rel(t.expectation, ref.expectation) < F64_RTOL
+    assert rel(t.kl, ref.kl) < 1e-10
+    assert t.scale == pytest.approx(3.5)
+    Lk = o.posterior(sva).Lk
+    assert t.logdet_kuu == pytest.approx(2 * np.log(np.diag(Lk)).sum(), rel=1e-10, abs=1e-9)
+    assert (t.n_points, t.n_neg_var, t.chol_info) == (N, 0, 0)
+
+
+@pytest.mark.parametrize("N,M,d,family,lik,qn", CASES[:6])
+def test_elbo_fp32_matches_oracle(ctx, N, M, d, family, lik, qn):
+    x, y, sva, s2 = o.synth_problem(100 + N, N, M, d, family=family, lik=lik, dtype=np.float32)
+    ref = o.elbo_terms(sva, x, y, lik=lik, sigma2=s2, quadrature_n=qn)
+    val, t = _run(ctx, sva, x, y, dtype=np.float32, lik=lik, sigma2=s2, qn=qn)
+    assert rel(val, ref.elbo) < F32_RTOL
+    assert rel(t.kl, ref.kl) < 1e-5
+
+
+def test_hard_conditioning_optimal_q(ctx):
+    """Titsias-optimal q (test/test_utils.jl:7-17) whitened: large cancellation in v, small jitter.  K1 on the GPU."""
+    rng = np.random.default_rng(5)
+    N, M = 400, 150
+    x = rng.random(N) * 10
+    y = np.sin(x) + 0.9 * np.cos(1.6 * x) + 0.4 * rng.random(N)
+    z = np.sort(rng.random(M) * 10)
+    kernel = o.make_kernel([0.2, 0.6])
+    jitter, s2 = 1e-6, 0.1
+    m, S = o.optimal_variational_posterior(kernel, z, jitter, x, s2, y)
+    me, Se = o.whiten(kernel, z, jitter, m, S)
+    sva = o.SVA(kernel, z, me, np.linalg.cholesky(Se + 1e-14 * np.eye(M)), jitter=jitter)
+    ref = o.elbo_terms(sva, x, y, sigma2=s2)
+    val, t = _run(ctx, sva, x, y, sigma2=s2)
+    assert rel(val, ref.elbo) < 1e-7   # cond(Kuu) ~ 1e7 here: both sides carry ~1e-9 of rounding
+    assert val <= o.exact_gp_logpdf(kernel, x, s2, y) + 1e-6           # ref test :88
+    assert val == pytest.approx(o.titsias_bound(kernel, z, jitter, x, s2, y), rel=1e-6)
+
+
+def test_minibatch_offsets_and_additivity(ctx):
+    x, y, sva, s2 = o.synth_problem(7, 1000, 96, 4)
+    model = device_model(ctx, sva, sigma2=s2)
+    data = _ffi.DeviceData(ctx, x, y, np.float64)
+    full = model.elbo_partial(data)
+    parts = [model.elbo_partial(data, a, b - a) for a, b in ((0, 129), (129, 640), (640, 1000))]
+    assert sum(p[0] for p in parts) == pytest.approx(full[0], rel=1e-12)
+    assert sum(p[1] for p in parts) == 1000
+    ref = o.elbo_terms(sva, x[:, 129:640], y[129:640], sigma2=s2, num_data=1e6)
+    val, _ = model.elbo(data, 129, 511, 1e6)
+    assert rel(val, ref.elbo) < F64_RTOL
+    # bitwise repeatability (fixed-order reductions)
+    assert model.elbo(data, 129, 511, 1e6)[0] == val
+    model.free()
+    data.free()
+
+
+def test_layouts_rowvecs_equals_colvecs(ctx):
+    x, y, sva, s2 = o.synth_problem(8, 300, 40, 3)
+    model = device_model(ctx, sva, sigma2=s2)
+    a = _ffi.DeviceData(ctx, x, y, np.float64, _ffi.COLVECS)
+    b = _ffi.DeviceData(ctx, np.ascontiguousarray(x.T), y, np.float64, _ffi.ROWVECS)
+    assert model.elbo(a)[0] == model.elbo(b)[0]
+    desc, keep = _ffi.make_desc(np.float64, sva.kernel.family, sva.kernel.variance, sva.kernel.inv_lengthscale,
+                                np.ascontiguousarray(sva.z.T), sva.m, sva.Lq, sva.jitter, lik_sigma2=s2,
+                                layout_z=_ffi.ROWVECS)
+    m2 = _ffi.DeviceModel(ctx, desc, keep)
+    assert m2.elbo(a)[0] == model.elbo(a)[0]
+    for h in (model, m2, a, b):
+        h.free()
+
+
+def test_centered_equals_noncentered(ctx):
+    # ref test :60-70
+    kernel = o.Kernel(o.KERNEL_MATERN32, 1.0, [1.0])
+    rng = np.random.default_rng(3)
+    x = np.linspace(-1, 1, 50)
+    z = np.linspace(-1, 1, 12)
+    y = np.sin(3 * x) + 0.03 * rng.standard_normal(50)
+    m, S = o.optimal_variational_posterior(kernel, z, 1e-6, x, 1e-3, y)
+    me, Se = o.whiten(kernel, z, 1e-6, m, S)
+    c = o.SVA(kernel, z, m, np.linalg.cholesky(S), jitter=1e-6, centered=True)
+    nc = o.SVA(kernel, z, me, np.linalg.cholesky(Se), jitter=1e-6, centered=False)
+    vc, tc = _run(ctx, c, x, y, sigma2=1e-3)
+    vn, tn = _run(ctx, nc, x, y, sigma2=1e-3)
+    assert tc.kl == pytest.approx(tn.kl, rel=1e-5)
+    assert vc == pytest.approx(vn, rel=1e-6)
+    assert rel(vc, o.elbo(c, x, y, sigma2=1e-3)) < 1e-7
+    assert rel(tc.kl, o.prior_kl(c)) < 1e-8
+
+
+@pytest.mark.parametrize("centered", [False, True])
+def test_posterior_and_predict(ctx, centered):
+    x, y, sva, s2 = o.synth_problem(9, 200, 150, 3, family=o.KERNEL_MATERN52)
+    if centered:
+        sva = o.SVA(sva.kernel, sva.z, sva.m + 0.3, sva.Lq * 0.5, jitter=sva.jitter, mean_const=0.3, centered=True)
+    post = o.posterior(sva)
+    model = device_model(ctx, sva)
+    Lk, alpha, B = model.posterior()
+    np.testing.assert_allclose(Lk, post.Lk, rtol=1e-9, atol=1e-11)
+    np.testing.assert_allclose(alpha, post.alpha, rtol=1e-6, atol=1e-7)   # α = Lk' \ m amplifies by cond(Lk)
+    np.testing.assert_allclose(B, post.B, rtol=1e-8, atol=1e-10)
+    xs = x[:, :131]
+    xt = x[:, 131:200]
+    mean, var, cov = model.predict(xs, True, True, True)
+    mu_ref, v_ref = o.mean_and_var(post, xs)
+    np.testing.assert_allclose(mean, mu_ref, rtol=1e-9, atol=1e-10)
+    np.testing.assert_allclose(var, v_ref, rtol=1e-9, atol=1e-10)
+    np.testing.assert_allclose(cov, o.cov(post, xs), rtol=1e-9, atol=1e-10)
+    np.testing.assert_allclose(np.diag(cov), var, atol=1e-10)
+    np.testing.assert_allclose(model.cross_cov(xs, xt), o.cov(post, xs, xt), rtol=1e-9, atol=1e-10)
+    model.free()
+
+
+def test_kuf_matches_kernelmatrix(ctx):
+    for dtype, tol in ((np.float64, 1e-13), (np.float32, 2e-6)):
+        for family in (o.KERNEL_SE, o.KERNEL_MATERN32, o.KERNEL_MATERN52):
+            x, y, sva, s2 = o.synth_problem(10, 333, 70, 5, family=family, dtype=dtype)
+            model = device_model(ctx, sva, dtype=dtype)
+            data = _ffi.DeviceData(ctx, x, None, dtype)
+            K = model.kuf(data, 3, 300)
+            np.testing.assert_allclose(K, o.kernelmatrix(sva.kernel, sva.z, x[:, 3:303]), rtol=tol * 10, atol=tol)
+            model.free()
+            data.free()
+
+
+def test_error_statuses(ctx):
+    x, y, sva, s2 = o.synth_problem(12, 100, 20, 2)
+    # not positive definite: a negative jitter larger than the smallest eigenvalue
+    bad = o.SVA(sva.kernel, sva.z, sva.m, sva.Lq, jitter=-1.0)
+    with pytest.raises(o.PosDefException) as ref:
+        o.posterior(bad)
+    with pytest.raises(_ffi.PosDefException) as got:
+        _run(ctx, bad, x, y, sigma2=s2)
+    assert got.value.info == ref.value.info
+    # negative predictive variance -> DomainError (policy ERROR) or clamp
+    z = np.linspace(-2, 2, 8)[None, :]
+    k = o.Kernel(o.KERNEL_SE, 1.0, [5.0])   # nearly diagonal Kuu: stays PD with a small negative jitter
+    neg = o.SVA(k, z, np.zeros(8), 1e-3 * np.eye(8), jitter=-1e-3)
+    with pytest.raises(o.DomainError):
+        o.elbo(neg, z, np.zeros(8))
+    with pytest.raises(_ffi.DomainError):
+        _run(ctx, neg, z, np.zeros(8))
+    model = device_model(ctx, neg, neg_var_policy=_ffi.NEGVAR_CLAMP)
+    data = _ffi.DeviceData(ctx, z, np.zeros(8), np.float64)
+    val, t = model.elbo(data)
+    assert np.isfinite(val) and t.n_neg_var > 0
+    with pytest.raises(ValueError):
+        model.elbo(data, 4, 100)
+    model.free()
+    data.free()
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz"))))
+def test_golden_fixtures(ctx, path):
+    g = np.load(path)
+    kernel = o.Kernel(int(g["family"]), float(g["variance"]), g["inv_lengthscale"])
+    sva = o.SVA(kernel, g["z"], g["m"], g["Lq"], jitter=float(g["jitter"]))
+    nd = float(g["num_data"])
+    model = device_model(ctx, sva, lik=int(g["lik"]), sigma2=float(g["sigma2"]), quadrature_n=int(g["quadrature_n"]))
+    data = _ffi.DeviceData(ctx, g["x"], g["y"], np.float64)
+    val, t = model.elbo(data, 0, None, nd if nd > 0 else 0.0)
+    assert rel(val, float(g["elbo"])) < F64_RTOL
+    assert rel(t.expectation, float(g["expectation"])) < F64_RTOL
+    assert rel(t.kl, float(g["kl"])) < 1e-10
+    mean, var, cov = model.predict(g["x"][:, :9], True, True, True)
+    np.testing.assert_allclose(mean, g["mu"][:9], rtol=1e-9, atol=1e-10)
+    np.testing.assert_allclose(var, g["v"][:9], rtol=1e-9, atol=1e-10)
+    np.testing.assert_allclose(cov, g["cov9"], rtol=1e-9, atol=1e-10)
+    Lk, alpha, _ = model.posterior()
+    np.testing.assert_allclose(Lk, g["Lk"], rtol=1e-9, atol=1e-11)
+    np.testing.assert_allclose(model.kuf(data, 0, 9), g["kuf9"], rtol=1e-12, atol=1e-14)
+    model.free()
+    data.free()
+
+
+def test_python_mirror_end_to_end(ctx):
+    """The reference-shaped call sequence of examples/a-regression/script.jl through the host mirror."""
+    import approxgp as ag
+
+    rng = np.random.default_rng(0)
+    N, M = 600, 20
+    x = rng.uniform(-1, 1, N)
+    y = np.sin(3 * x) + np.sqrt(0.3) * rng.standard_normal(N)
+    z = x[:M].copy()
+    A = np.eye(M) + 0.01 * np.tril(rng.standard_normal((M, M)))
+    mvec = 0.1 * rng.standard_normal(M)
+    f = ag.GP(1.3 * ag.with_lengthscale(ag.SqExponentialKernel(), 0.3))
+    sva = ag.SparseVariationalApproximation(f(z, 1e-5), ag.MvNormal.from_cholesky(mvec, A))
+    osva = o.SVA(o.Kernel(o.KERNEL_SE, 1.3, [1 / 0.3]), z, mvec, A, jitter=1e-5)
+    got = ag.elbo(sva, f(x[:100], 0.3), y[:100], num_data=N, ctx=ctx)
+    assert rel(got, o.elbo(osva, x[:100], y[:100], sigma2=0.3, num_data=N)) < F64_RTOL
+    lfx = ag.LatentGP(f, ag.GaussianLikelihood(0.3), 1e-18)(x[:100])
+    assert ag.approx_lml(sva, lfx, y[:100], num_data=N, ctx=ctx) == pytest.approx(got, abs=1e-10)  # ref test :93-96
+    post = ag.posterior(sva, ctx=ctx)
+    mu, v = post.mean_and_var(x[:50])
+    mu_ref, v_ref = o.mean_and_var(o.posterior(osva), x[:50])
+    np.testing.assert_allclose(mu, mu_ref, rtol=1e-9, atol=1e-10)
+    np.testing.assert_allclose(v, v_ref, rtol=1e-9, atol=1e-10)
+    assert ag.prior_kl(sva, ctx=ctx) == pytest.approx(o.prior_kl(osva), rel=1e-10)
