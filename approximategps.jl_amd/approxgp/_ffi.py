@@ -38,7 +38,8 @@ class Terms(C.Structure):
 
 
 class Timing(C.Structure):
-    _fields_ = [("ms_total", C.c_double), ("ms_prep", C.c_double), ("ms_strip", C.c_double), ("ms_kuf", C.c_double),
+    _fields_ = [("ms_total", C.c_double), ("ms_prep", C.c_double), ("ms_strip", C.c_double), ("ms_expect", C.c_double),
+                ("ms_kuf", C.c_double),
                 ("strip_launches", C.c_int64)]
 
 

@@ -23,7 +23,7 @@ struct svgp_ctx {
   int num_cus = 256;
   std::string err;
   svgp_timing timing{};
-  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};  // start, prep done, strip done, all done
   // growable scratch
   void* work = nullptr;       size_t work_bytes = 0;
   double* partial = nullptr;  unsigned* negcnt = nullptr;  // [1024] per-block sums of the expectation kernel
@@ -340,6 +340,7 @@ int enqueue_strips(svgp_ctx* ctx, svgp_model* m, const void* x, int64_t ldx, con
   lp.mean_const = m->desc.mean_const;
   launch_strip(m->dtype, ctx->stream, a, nt, grid, nstrips);
   KCHECK(ctx, "strip");
+  HIPC(ctx, hipEventRecord(ctx->ev[2], ctx->stream));
   launch_expect(m->dtype, ctx->stream, lp, a.mom_mu, a.mom_var, y, off, len, ctx->partial, ctx->negcnt, o.mu, o.var);
   KCHECK(ctx, "expect");
   launch_final_reduce(ctx->stream, ctx->partial, ctx->negcnt, expect_blocks(len), ctx->d_res);
@@ -369,7 +370,7 @@ int run_elbo(svgp_ctx* ctx, svgp_model* m, const svgp_data* data, int64_t off, i
   HIPC(ctx, hipEventRecord(ctx->ev[1], s));
   rc = enqueue_strips(ctx, m, data->x, data->ldx, data->y, off, len, StripOuts{});
   if (rc) return rc;
-  HIPC(ctx, hipEventRecord(ctx->ev[2], s));
+  HIPC(ctx, hipEventRecord(ctx->ev[3], s));
   double res[2];
   PrepScalars ps;
   HIPC(ctx, hipMemcpyAsync(res, ctx->d_res, sizeof(res), hipMemcpyDeviceToHost, s));
@@ -377,12 +378,14 @@ int run_elbo(svgp_ctx* ctx, svgp_model* m, const svgp_data* data, int64_t off, i
   HIPC(ctx, hipMemcpyAsync(&ps.info, m->info, sizeof(int), hipMemcpyDeviceToHost, s));
   HIPC(ctx, hipStreamSynchronize(s));
   finish_prep(m, ps);
-  float t01 = 0, t12 = 0;
+  float t01 = 0, t12 = 0, t23 = 0;
   hipEventElapsedTime(&t01, ctx->ev[0], ctx->ev[1]);
   hipEventElapsedTime(&t12, ctx->ev[1], ctx->ev[2]);
+  hipEventElapsedTime(&t23, ctx->ev[2], ctx->ev[3]);
   ctx->timing.ms_prep = t01;
   ctx->timing.ms_strip = t12;
-  ctx->timing.ms_total = t01 + t12;
+  ctx->timing.ms_expect = t23;
+  ctx->timing.ms_total = t01 + t12 + t23;
   ctx->timing.ms_kuf = 0;
   *E = res[0];
   *nneg = res[1];

@@ -103,8 +103,9 @@ typedef struct svgp_terms {
 typedef struct svgp_timing {
   double ms_total;
   double ms_prep;  /* Kuu, cholesky, diagonal-block inverses, panel products, KL */
-  double ms_strip; /* fused Kuf -> trsm -> trmm -> expectation kernel (+ final reduce) */
-  double ms_kuf;   /* standalone Kuf assembly (svgp_kuf only) */
+  double ms_strip; /* the fused Kuf -> trsm -> trmm strip kernel alone (one launch) */
+  double ms_expect;/* marginals + expected log-likelihood + final reduce */
+  double ms_kuf;   /* standalone Kuf assembly kernel (svgp_kuf only) */
   int64_t strip_launches;
 } svgp_timing;
 
