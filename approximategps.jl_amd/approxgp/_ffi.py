@@ -8,7 +8,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "csrc", "libsvgp_mi355x.so")
+LIB_PATH = os.environ.get("SVGP_MI355X_LIB") or os.path.join(os.path.dirname(_HERE), "csrc", "libsvgp_mi355x.so")
 
 OK, INVALID_ARG, NOT_POSDEF, NEG_VARIANCE, UNSUPPORTED, HIP_ERROR, RCCL_ERROR, OOM = range(8)
 F64, F32 = 0, 1

@@ -1,6 +1,6 @@
 // Device-side building blocks shared by every kernel of libsvgp_mi355x (gfx950 only).
 //   * Mfma16<T>: the 16x16x4 MFMA (f64 / f32-in-f32-acc) with its C/D lane map
-//   * TileGemm<T, NT, BK>: a 128 x NT output tile per 256-thread workgroup, K streamed through
+//   * TileGemm<T, NT, BK, NTHR>: a 128 x NT output tile per NTHR-thread workgroup, K streamed through
 //     double-buffered LDS tiles, operands given as "k-major" matrices (element (k, i) at k*ld + i),
 //     which is exactly a column-major Julia matrix read along its columns.
 //   * the stationary kernel functions of KernelFunctions.jl (SE, Matern-3/2, Matern-5/2).
@@ -74,14 +74,14 @@ __device__ __forceinline__ T kappa(int family, T r2, T variance) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// TileGemm: acc(128 x NT) += P(128 x K) * Q(K x NT)
+// TileGemm: acc(128 x NT) += P(128 x K) * Q(K x NT) on an NTHR-thread workgroup
 // ---------------------------------------------------------------------------------------------
-template <typename T, int NT, int BK>
+template <typename T, int NT, int BK, int NTHR = kThreads>
 struct TileGemm {
   static constexpr int NB = kNB;
-  static constexpr int WR = 2, WC = 4;           // wave grid: a wave owns 64 rows x NT/4 columns
+  static constexpr int WR = 2, WC = NTHR / 128;  // wave grid: a wave owns 64 rows x NT/WC columns
   static constexpr int MI = NB / WR / 16;        // 16-row tiles per wave (4)
-  static constexpr int NJ = NT / WC / 16;        // 16-col tiles per wave (2 @ NT=128, 1 @ NT=64)
+  static constexpr int NJ = NT / WC / 16;        // 16-col tiles per wave (2 for 128 cols x 8 waves or 64 cols x 4 waves)
   static constexpr int PLD = NB + 16;            // LDS leading dims: +16 elements makes the 4 k-rows a
   static constexpr int QLD = NT + 16;            // 64-lane fragment read touches land on disjoint banks
   static constexpr int VEC = Vec16<T>::N;
@@ -89,10 +89,10 @@ struct TileGemm {
   using acc_t = typename Mfma16<T>::acc_t;
 
   static constexpr int P_TPR = NB / VEC;                 // threads per k-row of the P tile
-  static constexpr int P_RPP = kThreads / P_TPR;         // k-rows per pass
+  static constexpr int P_RPP = NTHR / P_TPR;             // k-rows per pass
   static constexpr int P_PASSES = BK / P_RPP;
   static constexpr int Q_TPR = NT / VEC;
-  static constexpr int Q_RPP = kThreads / Q_TPR;
+  static constexpr int Q_RPP = NTHR / Q_TPR;
   static constexpr int Q_PASSES = (BK / Q_RPP) > 0 ? (BK / Q_RPP) : 1;
   static_assert(BK % P_RPP == 0, "BK must be a multiple of the P rows per pass");
   static_assert(BK % Q_RPP == 0, "BK must be a multiple of the Q rows per pass");
@@ -116,12 +116,34 @@ struct TileGemm {
   struct QRegs { V v[Q_PASSES]; };
 
   // --- global -> registers, k-major source: element (k, i) at src[k*ld + i] -------------------
-  static __device__ __forceinline__ void load_p(PRegs& r, const T* __restrict__ src, int64_t ld) {
+  // `src` must be wave-uniform: the per-thread part of the address is a fixed 32-bit byte offset (POff/QOff),
+  // so a step costs scalar pointer arithmetic only (f64 MFMA does not co-execute with VALU work).
+  struct POff { uint32_t o[P_PASSES]; };
+  struct QOff { uint32_t o[Q_PASSES]; };
+  static __device__ __forceinline__ POff p_offsets(int64_t ld) {
+    POff r;
     const int t = threadIdx.x;
     const int kk0 = t / P_TPR, c = (t % P_TPR) * VEC;
 #pragma unroll
-    for (int p = 0; p < P_PASSES; ++p)
-      r.v[p] = *reinterpret_cast<const V*>(src + int64_t(kk0 + p * P_RPP) * ld + c);
+    for (int p = 0; p < P_PASSES; ++p) r.o[p] = uint32_t((int64_t(kk0 + p * P_RPP) * ld + c) * sizeof(T));
+    return r;
+  }
+  static __device__ __forceinline__ QOff q_offsets(int64_t ld) {
+    QOff r;
+    const int t = threadIdx.x;
+    const int kk0 = t / Q_TPR, c = (t % Q_TPR) * VEC;
+#pragma unroll
+    for (int p = 0; p < Q_PASSES; ++p) r.o[p] = uint32_t((int64_t(kk0 + p * Q_RPP) * ld + c) * sizeof(T));
+    return r;
+  }
+  static __device__ __forceinline__ void load_p(PRegs& r, const T* __restrict__ src, const POff& off) {
+#if defined(SVGP_ABLATE) && (SVGP_ABLATE & 1)
+    (void)src; (void)off; asm volatile("" : "+v"(r.v[0]));  // diagnostic build: skip the P-tile loads
+    return;
+#endif
+    const char* base = reinterpret_cast<const char*>(src);
+#pragma unroll
+    for (int p = 0; p < P_PASSES; ++p) r.v[p] = *reinterpret_cast<const V*>(base + off.o[p]);
   }
   static __device__ __forceinline__ void store_p(const PRegs& r, T* __restrict__ Ps) {
     const int t = threadIdx.x;
@@ -129,12 +151,14 @@ struct TileGemm {
 #pragma unroll
     for (int p = 0; p < P_PASSES; ++p) *reinterpret_cast<V*>(Ps + (kk0 + p * P_RPP) * PLD + c) = r.v[p];
   }
-  static __device__ __forceinline__ void load_q(QRegs& r, const T* __restrict__ src, int64_t ld) {
-    const int t = threadIdx.x;
-    const int kk0 = t / Q_TPR, c = (t % Q_TPR) * VEC;
+  static __device__ __forceinline__ void load_q(QRegs& r, const T* __restrict__ src, const QOff& off) {
+#if defined(SVGP_ABLATE) && (SVGP_ABLATE & 2)
+    (void)src; (void)off; asm volatile("" : "+v"(r.v[0]));  // diagnostic build: skip the Q-tile loads
+    return;
+#endif
+    const char* base = reinterpret_cast<const char*>(src);
 #pragma unroll
-    for (int p = 0; p < Q_PASSES; ++p)
-      r.v[p] = *reinterpret_cast<const V*>(src + int64_t(kk0 + p * Q_RPP) * ld + c);
+    for (int p = 0; p < Q_PASSES; ++p) r.v[p] = *reinterpret_cast<const V*>(base + off.o[p]);
   }
   // transposed source: element (k, j) at src[j*ld + k] (contiguous along k).  Prep kernels only.
   static __device__ __forceinline__ void load_q_trans(QRegs& r, const T* __restrict__ src, int64_t ld) {
@@ -158,25 +182,32 @@ struct TileGemm {
     c = (t % Q_TPR) * VEC;
   }
 
-  // --- one BK-deep slab of MFMAs out of LDS ---------------------------------------------------
-  static __device__ __forceinline__ void compute(Acc& acc, const T* __restrict__ Ps, const T* __restrict__ Qs) {
+  // --- MFMA fragments: one k-slab (4 k's) of the tile pair in LDS --------------------------------
+  struct Frag {
+    T a[MI], b[NJ];
+  };
+  // per-thread element offsets of its fragment inside a P / Q tile (slab 0)
+  static __device__ __forceinline__ int frag_a_off() {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int wr = wave / WC, wc = wave % WC;
-    const int l15 = lane & 15, lk = lane >> 4;
-    const T* pa = Ps + lk * PLD + wr * (MI * 16) + l15;
-    const T* pb = Qs + lk * QLD + wc * (NJ * 16) + l15;
+    return (lane >> 4) * PLD + (wave / WC) * (MI * 16) + (lane & 15);
+  }
+  static __device__ __forceinline__ int frag_b_off() {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    return (lane >> 4) * QLD + (wave % WC) * (NJ * 16) + (lane & 15);
+  }
+  // fa / fb already point at this thread's fragment of slab 0 of buffer 0; BUF and KSLAB are immediates
+  template <int BUF, int KSLAB>
+  static __device__ __forceinline__ void load_frag(Frag& f, const T* __restrict__ fa, const T* __restrict__ fb) {
 #pragma unroll
-    for (int ks = 0; ks < BK / 4; ++ks) {
-      T a[MI], b[NJ];
+    for (int i = 0; i < MI; ++i) f.a[i] = fa[BUF * STAGE + KSLAB * 4 * PLD + i * 16];
 #pragma unroll
-      for (int i = 0; i < MI; ++i) a[i] = pa[ks * 4 * PLD + i * 16];
+    for (int j = 0; j < NJ; ++j) f.b[j] = fb[BUF * STAGE + KSLAB * 4 * QLD + j * 16];
+  }
+  static __device__ __forceinline__ void mma_frag(Acc& acc, const Frag& f) {
 #pragma unroll
-      for (int j = 0; j < NJ; ++j) b[j] = pb[ks * 4 * QLD + j * 16];
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
-      for (int i = 0; i < MI; ++i)
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) acc.v[i][j] = Mfma16<T>::mma(a[i], b[j], acc.v[i][j]);
-    }
+      for (int j = 0; j < NJ; ++j) acc.v[i][j] = Mfma16<T>::mma(f.a[i], f.b[j], acc.v[i][j]);
   }
 
   // element (row, col) of acc.v[i][j][r] inside the 128 x NT tile
@@ -189,34 +220,81 @@ struct TileGemm {
     return (wave % WC) * (NJ * 16) + j * 16 + (lane & 15);
   }
 
-  // --- the K loop: QLoad::operator()(step, QRegs&) produces the Q tile of a step ---------------
-  // P tile of step t is Pbase + t*BK*ldp.  Ends with all waves past their last LDS read.
+  // --- the K loop -----------------------------------------------------------------------------------
+  // P tile of step t is Pbase + t*BK*ldp (Pbase wave-uniform); QLoad::operator()(step, QRegs&) produces the
+  // Q tile of a step.  Software pipeline, written so that the steady state issues (almost) nothing but
+  // MFMA, LDS and global-memory instructions (measured: f64 MFMA never co-executes with VALU work,
+  // SQ_VALU_MFMA_COEXEC_CYCLES = 0, so every VALU instruction in the loop is stolen MFMA time):
+  //   * fragments ping-pong between two register sets (no copies); the step loop is unrolled by two so the
+  //     LDS buffer of a step is a compile-time immediate;
+  //   * fragments of slab ks+1 are read from LDS while the MFMAs of slab ks execute;
+  //   * the MFMAs of the LAST slab of step t are issued AFTER the barrier that ends the step, behind the first
+  //     fragment reads of step t+1, so the write -> barrier -> read latency hides under them;
+  //   * global loads of tile t+2 are in flight during step t+1 and land in LDS just before its barrier.
+  // Ends with all waves past their last LDS read.
+  template <int BUF, typename QLoad>
+  static __device__ __forceinline__ void step(Acc& acc, Frag (&f)[2], PRegs& pr, QRegs& qr, const T* __restrict__ Pbase,
+                                              int64_t pstride, const POff& poff, int t, int nsteps, QLoad& qload,
+                                              T* __restrict__ smem, const T* __restrict__ fa, const T* __restrict__ fb) {
+    constexpr int KS = BK / 4;
+    static_assert(KS % 2 == 0, "the fragment ping-pong needs an even number of k-slabs per step");
+    const bool more = (t + 1 < nsteps);
+#pragma unroll
+    for (int ks = 0; ks + 1 < KS; ++ks) {
+      if (ks == 0) load_frag<BUF, 1>(f[1], fa, fb);
+      if (ks == 1) load_frag<BUF, 2>(f[0], fa, fb);
+      if (ks == 2) load_frag<BUF, 3>(f[1], fa, fb);
+      if (ks == 3) load_frag<BUF, 4 < KS ? 4 : 0>(f[0], fa, fb);
+      if (ks == 4) load_frag<BUF, 5 < KS ? 5 : 0>(f[1], fa, fb);
+      if (ks == 5) load_frag<BUF, 6 < KS ? 6 : 0>(f[0], fa, fb);
+      if (ks == 6) load_frag<BUF, 7 < KS ? 7 : 0>(f[1], fa, fb);
+      mma_frag(acc, f[ks & 1]);
+    }
+    if (more) {
+      T* Pn = smem + (BUF ^ 1) * STAGE;
+      store_p(pr, Pn);
+      store_q(qr, Pn + P_TILE);
+    }
+    __syncthreads();
+    if (more) {
+      load_frag<BUF ^ 1, 0>(f[0], fa, fb);
+      if (t + 2 < nsteps) {
+        load_p(pr, Pbase + int64_t(t + 2) * pstride, poff);
+        qload(t + 2, qr);
+      }
+    }
+    mma_frag(acc, f[(KS - 1) & 1]);
+  }
+
   template <typename QLoad>
   static __device__ __forceinline__ void loop(Acc& acc, const T* __restrict__ Pbase, int64_t ldp, int nsteps,
                                               QLoad&& qload, T* __restrict__ smem) {
     if (nsteps <= 0) return;
+    static_assert(BK <= 32, "step() enumerates at most 8 k-slabs");
+    const POff poff = p_offsets(ldp);
+    const int64_t pstride = int64_t(BK) * ldp;
+    const T* fa = smem + frag_a_off();
+    const T* fb = smem + P_TILE + frag_b_off();
     PRegs pr;
     QRegs qr;
-    load_p(pr, Pbase, ldp);
+    load_p(pr, Pbase, poff);
     qload(0, qr);
     store_p(pr, smem);
     store_q(qr, smem + P_TILE);
     __syncthreads();
-    for (int t = 0; t < nsteps; ++t) {
-      T* cur = smem + (t & 1) * STAGE;
-      T* nxt = smem + ((t + 1) & 1) * STAGE;
-      const bool more = (t + 1 < nsteps);
-      if (more) {
-        load_p(pr, Pbase + int64_t(t + 1) * BK * ldp, ldp);
-        qload(t + 1, qr);
-      }
-      compute(acc, cur, cur + P_TILE);
-      if (more) {
-        store_p(pr, nxt);
-        store_q(qr, nxt + P_TILE);
-      }
-      __syncthreads();
+    if (nsteps > 1) {
+      load_p(pr, Pbase + pstride, poff);
+      qload(1, qr);
     }
+    Frag f[2];
+    load_frag<0, 0>(f[0], fa, fb);
+    int t = 0;
+    for (; t + 1 < nsteps; t += 2) {
+      step<0>(acc, f, pr, qr, Pbase, pstride, poff, t, nsteps, qload, smem, fa, fb);
+      step<1>(acc, f, pr, qr, Pbase, pstride, poff, t + 1, nsteps, qload, smem, fa, fb);
+    }
+    if (t < nsteps) step<0>(acc, f, pr, qr, Pbase, pstride, poff, t, nsteps, qload, smem, fa, fb);
+    __syncthreads();  // the tail MFMAs read no LDS, but callers reuse the staging buffers right away
   }
 };
 

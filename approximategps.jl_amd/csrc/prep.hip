@@ -75,6 +75,9 @@ __global__ void __launch_bounds__(k256) potf2_kernel(T* __restrict__ A, T* __res
   __syncthreads();
   if (failed) return;  // an earlier panel already reported the first bad pivot
 
+  // Right-looking column sweep.  Thread pair (i, h) owns row i and the columns of parity h.  The scaled
+  // column j is broadcast through its own LDS array so the row update is a stream of independent FMAs.
+  __shared__ T colj[2][NB];
   const int i = tid % NB, h = tid / NB;
   for (int j = 0; j < NB; ++j) {
     const T djj = sm[j * LD + j];
@@ -83,27 +86,48 @@ __global__ void __launch_bounds__(k256) potf2_kernel(T* __restrict__ A, T* __res
       return;
     }
     const T dj = ksqrt(djj);
-    if (h == 0) {
-      if (i == j) sm[j * LD + j] = dj;
-      else if (i > j) sm[i * LD + j] /= dj;
+    T* cj = colj[j & 1];
+    if (h == 0 && i >= j) {
+      const T l = (i == j) ? dj : sm[i * LD + j] / dj;
+      sm[i * LD + j] = l;
+      cj[i] = l;
     }
     __syncthreads();
-    const T lij = sm[i * LD + j];
-    for (int k = j + 1 + h; k <= i; k += 2) sm[i * LD + k] -= lij * sm[k * LD + j];
+    if (i > j) {
+      const T nl = -cj[i];
+      T* row = sm + i * LD;
+      int k = j + 1;                            // first column > j whose parity is h
+      if ((k & 1) != h) ++k;
+#pragma unroll 4
+      for (; k <= i; k += 2) row[k] = fma(nl, cj[k], row[k]);
+    }
     __syncthreads();
   }
 
-  // X = inv(L), column c by thread c; X' is kept in the strictly upper triangle of the LDS block.
-  T xcc = T(0);
-  if (tid < NB) xcc = T(1) / sm[tid * LD + tid];
-  for (int r = 1; r < NB; ++r) {
-    if (tid < r) {
-      const int c = tid;
-      T s = sm[r * LD + c] * xcc;
-      for (int k = c + 1; k < r; ++k) s = fma(sm[r * LD + k], sm[c * LD + k], s);
-      sm[c * LD + r] = -s / sm[r * LD + r];
+  // X = inv(L) from X L = I, one ROW per thread: X[r][c] = (δ_rc - Σ_{c<k<=r} X[r][k] L[k][c]) / L[c][c], c = r..0.
+  // X' is kept in the strictly upper triangle of the LDS block (X[r][k] at sm[k*LD + r]: stride-1 across threads),
+  // L[k][c] is the same word for every lane (broadcast); both loops are wave-uniform so the reads pipeline.
+  if (tid < NB) {
+    const int r = tid;
+    const T xrr = T(1) / sm[r * LD + r];
+    for (int c = NB - 2; c >= 0; --c) {
+      T s0 = T(0), s1 = T(0);
+      int k = c + 1;
+      // k == r term uses the diagonal X[r][r] held in a register
+#pragma unroll 4
+      for (; k + 1 < NB; k += 2) {
+        const T l0 = sm[k * LD + c], l1 = sm[(k + 1) * LD + c];
+        const T x0 = (k < r) ? sm[k * LD + r] : (k == r ? xrr : T(0));
+        const T x1 = (k + 1 < r) ? sm[(k + 1) * LD + r] : (k + 1 == r ? xrr : T(0));
+        s0 = fma(x0, l0, s0);
+        s1 = fma(x1, l1, s1);
+      }
+      if (k < NB) {
+        const T x0 = (k < r) ? sm[k * LD + r] : (k == r ? xrr : T(0));
+        s0 = fma(x0, sm[k * LD + c], s0);
+      }
+      if (c < r) sm[c * LD + r] = -(s0 + s1) / sm[c * LD + c];
     }
-    // a thread only ever reads X entries it wrote itself, and L entries nobody writes: no barrier needed
   }
   __syncthreads();
   for (int e = tid; e < NB * NB; e += k256) {
@@ -144,7 +168,8 @@ __global__ void __launch_bounds__(kThreads, 2) tile128_kernel(T* __restrict__ A,
     const int i = p + 1 + blockIdx.x;
     const T* P = Tm + int64_t(p) * NB + int64_t(p) * NB * ld;
     const T* Q = A + int64_t(i) * NB + int64_t(p) * NB * ld;
-    auto qload = [&](int t, QRegs& r) { G::load_q(r, Q + int64_t(t) * 16 * ld, ld); };
+    const typename G::QOff qoff = G::q_offsets(ld);
+    auto qload = [&](int t, QRegs& r) { G::load_q(r, Q + int64_t(t) * 16 * ld, qoff); };
     G::loop(acc, P, ld, NB / 16, qload, smem);
     T* C = A + int64_t(i) * NB + int64_t(p) * NB * ld;
 #pragma unroll
@@ -160,7 +185,8 @@ __global__ void __launch_bounds__(kThreads, 2) tile128_kernel(T* __restrict__ A,
     const int i = p + 1 + ti, j = p + 1 + tj;
     const T* P = A + int64_t(j) * NB + int64_t(p) * NB * ld;
     const T* Q = A + int64_t(i) * NB + int64_t(p) * NB * ld;
-    auto qload = [&](int t, QRegs& r) { G::load_q(r, Q + int64_t(t) * 16 * ld, ld); };
+    const typename G::QOff qoff = G::q_offsets(ld);
+    auto qload = [&](int t, QRegs& r) { G::load_q(r, Q + int64_t(t) * 16 * ld, qoff); };
     G::loop(acc, P, ld, NB / 16, qload, smem);
     T* C = A + int64_t(i) * NB + int64_t(j) * NB * ld;
 #pragma unroll
@@ -384,7 +410,8 @@ __global__ void __launch_bounds__(kThreads, 2) cov_assemble_kernel(KernelParams 
   acc.zero();
   const int nsteps = int(Mp / 16);
   {
-    auto qload = [&](int t, QRegs& r) { G::load_q(r, Aa + int64_t(t) * 16 * lda + i0, lda); };
+    const typename G::QOff qoff = G::q_offsets(lda);
+    auto qload = [&](int t, QRegs& r) { G::load_q(r, Aa + int64_t(t) * 16 * lda + i0, qoff); };
     G::loop(acc, Ab + j0, ldb, nsteps, qload, smem);
   }
 #pragma unroll
@@ -392,7 +419,8 @@ __global__ void __launch_bounds__(kThreads, 2) cov_assemble_kernel(KernelParams 
 #pragma unroll
     for (int b = 0; b < G::NJ; ++b) acc.v[a][b] = -acc.v[a][b];
   {
-    auto qload = [&](int t, QRegs& r) { G::load_q(r, Ca + int64_t(t) * 16 * lda + i0, lda); };
+    const typename G::QOff qoff = G::q_offsets(lda);
+    auto qload = [&](int t, QRegs& r) { G::load_q(r, Ca + int64_t(t) * 16 * lda + i0, qoff); };
     G::loop(acc, Cb + j0, ldb, nsteps, qload, smem);
   }
   const T* __restrict__ invl = static_cast<const T*>(kp.invl);

@@ -15,6 +15,8 @@
 #include "device_common.hpp"
 #include "kernels.hpp"
 
+#include <cstdlib>
+
 namespace svgp {
 
 namespace {
@@ -49,9 +51,9 @@ __device__ __forceinline__ double expected_loglik_point(const LikParams& lp, dou
   return acc;  // weights are pre-divided by sqrt(pi)
 }
 
-template <typename T, int NT, int BK>
-__global__ void __launch_bounds__(kThreads, 2) strip_kernel(StripArgs a, int64_t nstrips) {
-  using G = TileGemm<T, NT, BK>;
+template <typename T, int NT, int BK, int NTHR>
+__global__ void __launch_bounds__(NTHR, 2) strip_kernel(StripArgs a, int64_t nstrips) {
+  using G = TileGemm<T, NT, BK, NTHR>;
   using Acc = typename G::Acc;
   using QRegs = typename G::QRegs;
   constexpr int NB = G::NB, MI = G::MI, NJ = G::NJ, VEC = G::VEC;
@@ -72,12 +74,13 @@ __global__ void __launch_bounds__(kThreads, 2) strip_kernel(StripArgs a, int64_t
   const int nP = int(Mp / NB);
   T* __restrict__ work = static_cast<T*>(a.work) + int64_t(blockIdx.x) * Mp * NT;
   const int tid = threadIdx.x, lane = tid & 63;
+  const typename G::QOff qoff = G::q_offsets(NT);           // per-thread byte offsets inside a scratch-strip tile
 
   for (int64_t strip = blockIdx.x; strip < nstrips; strip += gridDim.x) {
     const int64_t c0 = strip * NT;                          // first column of the strip inside the batch
     const int64_t last = a.off + a.len - 1;
     // scaled inputs of the strip -> LDS (columns past the batch end replicate the last point; masked later)
-    for (int e = tid; e < d * NT; e += kThreads) {
+    for (int e = tid; e < d * NT; e += NTHR) {
       const int f = e / NT, c = e % NT;
       int64_t g = a.off + c0 + c;
       g = g > last ? last : g;
@@ -96,7 +99,7 @@ __global__ void __launch_bounds__(kThreads, 2) strip_kernel(StripArgs a, int64_t
       const int gen_from = I * (NB / BK);
       auto qload = [&](int t, QRegs& r) {
         if (t < gen_from) {
-          G::load_q(r, work + int64_t(t) * BK * NT, NT);
+          G::load_q(r, work + int64_t(t) * BK * NT, qoff);
         } else {
 #pragma unroll
           for (int p = 0; p < G::Q_PASSES; ++p) {
@@ -115,7 +118,11 @@ __global__ void __launch_bounds__(kThreads, 2) strip_kernel(StripArgs a, int64_t
               }
             }
 #pragma unroll
+#if defined(SVGP_ABLATE) && (SVGP_ABLATE & 8)
+            for (int e = 0; e < VEC; ++e) r.v[p][e] = (k < M) ? r2[e] * variance : T(0);   // diagnostic: no exp
+#else
             for (int e = 0; e < VEC; ++e) r.v[p][e] = (k < M) ? kappa<T>(family, r2[e], variance) : T(0);
+#endif
           }
         }
       };
@@ -132,11 +139,17 @@ __global__ void __launch_bounds__(kThreads, 2) strip_kernel(StripArgs a, int64_t
           for (int j = 0; j < NJ; ++j) {
             const T val = acc.v[i][j][r];
             const int col = G::acc_col(j);
+#if !(defined(SVGP_ABLATE) && (SVGP_ABLATE & 4))
             work[int64_t(row) * NT + col] = val;
+#endif
             if (a.A_out) static_cast<T*>(a.A_out)[int64_t(row) * a.lda + c0 + col] = val;
+#if !(defined(SVGP_ABLATE) && (SVGP_ABLATE & 16))
             const double dv = double(val);
             sA[j] = fma(dv, dv, sA[j]);
             sM[j] = fma(dv, mr, sM[j]);
+#else
+            sA[j] += double(val) + mr;
+#endif
           }
         }
       }
@@ -148,7 +161,7 @@ __global__ void __launch_bounds__(kThreads, 2) strip_kernel(StripArgs a, int64_t
       Acc acc;
       acc.zero();
       const T* wq = work + int64_t(J) * NB * NT;
-      auto qload = [&](int t, QRegs& r) { G::load_q(r, wq + int64_t(t) * BK * NT, NT); };
+      auto qload = [&](int t, QRegs& r) { G::load_q(r, wq + int64_t(t) * BK * NT, qoff); };
       G::loop(acc, U + int64_t(J) * NB + int64_t(J) * NB * Mp, Mp, (nP - J) * (NB / BK), qload, smem);
 #pragma unroll
       for (int i = 0; i < MI; ++i)
@@ -330,34 +343,51 @@ __global__ void __launch_bounds__(k256) kuf_kernel(KernelParams kp, const T* __r
   }
 }
 
-template <typename T, int NT, int BK>
+template <typename T, int NT, int BK, int NTHR>
 void launch_strip_t(hipStream_t s, const StripArgs& a, int grid, int64_t nstrips) {
-  using G = TileGemm<T, NT, BK>;
+  using G = TileGemm<T, NT, BK, NTHR>;
   const size_t lds = G::LDS_BYTES + size_t(a.kp.d) * NT * sizeof(T);
-  auto kern = strip_kernel<T, NT, BK>;
+  auto kern = strip_kernel<T, NT, BK, NTHR>;
   set_max_lds(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), lds, s, a, nstrips);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(NTHR), lds, s, a, nstrips);
 }
 
 }  // namespace
 
-int strip_nt(int /*dtype*/, int64_t /*Mp*/, int64_t /*len*/) { return 128; }
+// Strip geometry.  Default: 64-point strips on 256-thread workgroups, two workgroups per CU, so the two
+// waves on a SIMD belong to different workgroups and do not park at the same barrier.
+// SVGP_STRIP_NT=128 selects the 128-point / 512-thread build, SVGP_STRIP_BK=32 the 32-deep k-step (tuning knobs).
+static int env_int(const char* name, int dflt) {
+  const char* e = getenv(name);
+  return e ? atoi(e) : dflt;
+}
+
+int strip_nt(int /*dtype*/, int64_t /*Mp*/, int64_t /*len*/) {
+  static const int nt = env_int("SVGP_STRIP_NT", 64) == 128 ? 128 : 64;
+  return nt;
+}
 
 size_t strip_work_bytes(int dtype, int64_t Mp, int nt, int grid) {
   return size_t(grid) * size_t(Mp) * size_t(nt) * (dtype == 0 ? 8 : 4);
 }
 
-int strip_grid(int /*dtype*/, int /*nt*/, int64_t nstrips, int num_cus) {
-  const int64_t cap = int64_t(num_cus) * 2;
+int strip_grid(int /*dtype*/, int nt, int64_t nstrips, int num_cus) {
+  const int64_t cap = int64_t(num_cus) * (nt == 64 ? 2 : 1);
   return int(nstrips < cap ? nstrips : cap);
 }
 
 void launch_strip(int dtype, hipStream_t s, const StripArgs& a, int nt, int grid, int64_t nstrips) {
-  (void)nt;
-  if (dtype == 0)
-    launch_strip_t<double, 128, 16>(s, a, grid, nstrips);
-  else
-    launch_strip_t<float, 128, 16>(s, a, grid, nstrips);
+  static const bool bk32 = env_int("SVGP_STRIP_BK", 16) == 32;
+  if (nt == 64) {
+    if (dtype == 0) launch_strip_t<double, 64, 16, 256>(s, a, grid, nstrips);
+    else launch_strip_t<float, 64, 16, 256>(s, a, grid, nstrips);
+  } else if (dtype == 0) {
+    if (bk32 && a.kp.d <= 8) launch_strip_t<double, 128, 32, 512>(s, a, grid, nstrips);
+    else launch_strip_t<double, 128, 16, 512>(s, a, grid, nstrips);
+  } else {
+    if (bk32 && a.kp.d <= 8) launch_strip_t<float, 128, 32, 512>(s, a, grid, nstrips);
+    else launch_strip_t<float, 128, 16, 512>(s, a, grid, nstrips);
+  }
 }
 
 int expect_blocks(int64_t len) {
