@@ -56,18 +56,39 @@ __global__ void kuu_kernel(KernelParams kp, const T* __restrict__ zs, int64_t M,
 }
 
 // ------------------------------------------------------------------------------------------------
-// POTF2 of one 128x128 diagonal block held in LDS, followed by its triangular inverse.
+// POTF2 + TRTRI of one 128x128 diagonal block, LDS resident, MFMA blocked (16-wide panels).
+//   per panel p:  wave 0 factors the 16x16 diagonal block D in registers (lane i owns row i; pivots and
+//                 columns travel by v_readlane) and forms inv(D) row-parallel from X D = I;
+//                 all waves: L[t,p] = A[t,p] inv(D)'  and  A[ti,tj] -= L[ti,p] L[tj,p]'  as 16x16x4 MFMAs.
+//   inverse:      X = inv(L) by 16-blocks, one wave per block column (no barriers):
+//                 X[ti,tj] = -inv(D_ti) * sum_{tj<=s<ti} L[ti,s] X[s,tj]; the accumulator of the sum is fed
+//                 straight back as the B operand of the second product (register r of a 16x16 result is
+//                 k-slab r of a B fragment when A is read with k = Mfma16::row(lane, r)).
 // L overwrites the lower triangle of the block in A; inv(L) goes to the same block of Tm (upper = 0).
+// info: LAPACK semantics, order of the first non-positive pivot (kept if an earlier panel already failed).
 // ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double readlane_t(double v, int srclane) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), srclane);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), srclane);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ float readlane_t(float v, int srclane) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), srclane));
+}
+
 template <typename T>
 __global__ void __launch_bounds__(k256) potf2_kernel(T* __restrict__ A, T* __restrict__ Tm, int64_t ld,
-                                                          int* __restrict__ info, int pbase) {
-  constexpr int NB = kNB, LD = NB + 1;
+                                                      int* __restrict__ info, int pbase) {
+  constexpr int NB = kNB, LD = NB + 1, NBLK = NB / 16, DL = 17;
+  using M16 = Mfma16<T>;
+  using acc_t = typename M16::acc_t;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  T* sm = reinterpret_cast<T*>(smem_raw);
+  T* sm = reinterpret_cast<T*>(smem_raw);   // [128][129] row-major block; strictly-upper 16-blocks later hold X'
+  T* dinv = sm + NB * LD;                   // [8][16][17]  inverses of the 16x16 diagonal blocks
   __shared__ int failed;
-  const int tid = threadIdx.x;
-  if (tid == 0) failed = (*info != 0);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l15 = lane & 15, g = lane >> 4;
+  if (tid == 0) failed = (*info != 0) ? -1 : 0;
   for (int e = tid; e < NB * NB; e += k256) {
     const int i = e % NB, j = e / NB;
     sm[i * LD + j] = A[i + int64_t(j) * ld];
@@ -75,58 +96,100 @@ __global__ void __launch_bounds__(k256) potf2_kernel(T* __restrict__ A, T* __res
   __syncthreads();
   if (failed) return;  // an earlier panel already reported the first bad pivot
 
-  // Right-looking column sweep.  Thread pair (i, h) owns row i and the columns of parity h.  The scaled
-  // column j is broadcast through its own LDS array so the row update is a stream of independent FMAs.
-  __shared__ T colj[2][NB];
-  const int i = tid % NB, h = tid / NB;
-  for (int j = 0; j < NB; ++j) {
-    const T djj = sm[j * LD + j];
-    if (!(djj > T(0))) {  // uniform: every thread reads the same LDS word
-      if (tid == 0) *info = pbase + j + 1;
-      return;
-    }
-    const T dj = ksqrt(djj);
-    T* cj = colj[j & 1];
-    if (h == 0 && i >= j) {
-      const T l = (i == j) ? dj : sm[i * LD + j] / dj;
-      sm[i * LD + j] = l;
-      cj[i] = l;
+  for (int p = 0; p < NBLK; ++p) {
+    const int o = 16 * p;
+    if (wave == 0) {
+      // ---- 16x16 Cholesky in registers: every 16-lane group redundantly holds row l15 ----
+      T row[16];
+#pragma unroll
+      for (int c = 0; c < 16; ++c) row[c] = sm[(o + l15) * LD + o + c];
+      int bad = 0;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const T d = readlane_t(row[j], j);
+        if (!(d > T(0)) && !bad) bad = j + 1;
+        const T dj = ksqrt(d);
+        const T lij = (l15 == j) ? dj : row[j] / dj;
+        row[j] = lij;
+#pragma unroll
+        for (int k = j + 1; k < 16; ++k) row[k] = fma(-lij, readlane_t(lij, k), row[k]);
+      }
+      // ---- X = inv(D): X D = I, row l15 per lane, D[k][c] fetched from lane k ----
+      T x[16];
+#pragma unroll
+      for (int c = 15; c >= 0; --c) {
+        T s = (l15 == c) ? T(1) : T(0);
+#pragma unroll
+        for (int k = c + 1; k < 16; ++k) s = fma(-x[k], readlane_t(row[c], k), s);
+        x[c] = (c <= l15) ? s / readlane_t(row[c], c) : T(0);
+      }
+      if (lane < 16) {
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+          if (c <= l15) sm[(o + l15) * LD + o + c] = row[c];
+          dinv[(p * 16 + l15) * DL + c] = x[c];
+        }
+        if (bad && lane == 0) failed = pbase + o + bad;
+      }
     }
     __syncthreads();
-    if (i > j) {
-      const T nl = -cj[i];
-      T* row = sm + i * LD;
-      int k = j + 1;                            // first column > j whose parity is h
-      if ((k & 1) != h) ++k;
-#pragma unroll 4
-      for (; k <= i; k += 2) row[k] = fma(nl, cj[k], row[k]);
+    if (failed) {
+      if (tid == 0) *info = failed;
+      return;
+    }
+    // ---- panel: L[t, p] = A[t, p] inv(D)' ----
+    for (int t = p + 1 + wave; t < NBLK; t += 4) {
+      acc_t acc = {0, 0, 0, 0};
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const int k = 4 * s + g;
+        acc = M16::mma(sm[(16 * t + l15) * LD + o + k], dinv[(p * 16 + l15) * DL + k], acc);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) sm[(16 * t + M16::row(lane, r)) * LD + o + l15] = acc[r];
+    }
+    __syncthreads();
+    // ---- trailing update: A[ti, tj] -= L[ti, p] L[tj, p]'  for p < tj <= ti ----
+    {
+      const int n = NBLK - p - 1;
+      int ti = 0, tj = 0;  // walk the lower triangle of n x n tiles in row-major order
+      for (int idx = 0; idx < n * (n + 1) / 2; ++idx) {
+        if ((idx & 3) == wave) {
+          const int bi = 16 * (p + 1 + ti), bj = 16 * (p + 1 + tj);
+          acc_t acc = {0, 0, 0, 0};
+#pragma unroll
+          for (int s = 0; s < 4; ++s) {
+            const int k = 4 * s + g;
+            acc = M16::mma(sm[(bi + l15) * LD + o + k], sm[(bj + l15) * LD + o + k], acc);
+          }
+#pragma unroll
+          for (int r = 0; r < 4; ++r) sm[(bi + M16::row(lane, r)) * LD + bj + l15] -= acc[r];
+        }
+        if (++tj > ti) { tj = 0; ++ti; }
+      }
     }
     __syncthreads();
   }
 
-  // X = inv(L) from X L = I, one ROW per thread: X[r][c] = (δ_rc - Σ_{c<k<=r} X[r][k] L[k][c]) / L[c][c], c = r..0.
-  // X' is kept in the strictly upper triangle of the LDS block (X[r][k] at sm[k*LD + r]: stride-1 across threads),
-  // L[k][c] is the same word for every lane (broadcast); both loops are wave-uniform so the reads pipeline.
-  if (tid < NB) {
-    const int r = tid;
-    const T xrr = T(1) / sm[r * LD + r];
-    for (int c = NB - 2; c >= 0; --c) {
-      T s0 = T(0), s1 = T(0);
-      int k = c + 1;
-      // k == r term uses the diagonal X[r][r] held in a register
-#pragma unroll 4
-      for (; k + 1 < NB; k += 2) {
-        const T l0 = sm[k * LD + c], l1 = sm[(k + 1) * LD + c];
-        const T x0 = (k < r) ? sm[k * LD + r] : (k == r ? xrr : T(0));
-        const T x1 = (k + 1 < r) ? sm[(k + 1) * LD + r] : (k + 1 == r ? xrr : T(0));
-        s0 = fma(x0, l0, s0);
-        s1 = fma(x1, l1, s1);
+  // ---- X = inv(L) by 16-blocks; wave w owns block columns w and 7-w; X[ti,tj]' lives at block (tj,ti) ----
+  for (int pass = 0; pass < 2; ++pass) {
+    const int tj = pass == 0 ? wave : NBLK - 1 - wave;
+    for (int ti = tj + 1; ti < NBLK; ++ti) {
+      acc_t acc = {0, 0, 0, 0};
+      for (int sb = tj; sb < ti; ++sb) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          const int k = 4 * s + g;
+          const T a = sm[(16 * ti + l15) * LD + 16 * sb + k];
+          const T b = (sb == tj) ? dinv[(tj * 16 + k) * DL + l15] : sm[(16 * tj + l15) * LD + 16 * sb + k];
+          acc = M16::mma(a, b, acc);
+        }
       }
-      if (k < NB) {
-        const T x0 = (k < r) ? sm[k * LD + r] : (k == r ? xrr : T(0));
-        s0 = fma(x0, sm[k * LD + c], s0);
-      }
-      if (c < r) sm[c * LD + r] = -(s0 + s1) / sm[c * LD + c];
+      acc_t x = {0, 0, 0, 0};
+#pragma unroll
+      for (int s = 0; s < 4; ++s) x = M16::mma(dinv[(ti * 16 + l15) * DL + M16::row(lane, s)], acc[s], x);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) sm[(16 * tj + l15) * LD + 16 * ti + M16::row(lane, r)] = -x[r];
     }
   }
   __syncthreads();
@@ -134,8 +197,7 @@ __global__ void __launch_bounds__(k256) potf2_kernel(T* __restrict__ A, T* __res
     const int r = e % NB, c = e / NB;
     if (r >= c) A[r + int64_t(c) * ld] = sm[r * LD + c];
     T x = T(0);
-    if (r > c) x = sm[c * LD + r];
-    else if (r == c) x = T(1) / sm[r * LD + r];
+    if (r >= c) x = ((r >> 4) == (c >> 4)) ? dinv[((r >> 4) * 16 + (r & 15)) * DL + (c & 15)] : sm[c * LD + r];
     Tm[r + int64_t(c) * ld] = x;
   }
 }
@@ -454,7 +516,7 @@ template <typename T>
 void potrf_t(hipStream_t s, T* A, T* Tm, int64_t Mp, int* info) {
   using G = TileGemm<T, kNB, 16>;
   const int nP = int(Mp / kNB);
-  const size_t lds_potf2 = size_t(kNB) * (kNB + 1) * sizeof(T);
+  const size_t lds_potf2 = (size_t(kNB) * (kNB + 1) + 8 * 16 * 17) * sizeof(T);
   set_max_lds(reinterpret_cast<const void*>(potf2_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds_potf2));
   set_max_lds(reinterpret_cast<const void*>(tile128_kernel<T, MODE_TRSM>), hipFuncAttributeMaxDynamicSharedMemorySize, int(G::LDS_BYTES));
   set_max_lds(reinterpret_cast<const void*>(tile128_kernel<T, MODE_SYRK>), hipFuncAttributeMaxDynamicSharedMemorySize, int(G::LDS_BYTES));
