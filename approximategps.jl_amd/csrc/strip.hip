@@ -371,8 +371,11 @@ size_t strip_work_bytes(int dtype, int64_t Mp, int nt, int grid) {
   return size_t(grid) * size_t(Mp) * size_t(nt) * (dtype == 0 ? 8 : 4);
 }
 
-int strip_grid(int /*dtype*/, int nt, int64_t nstrips, int num_cus) {
-  const int64_t cap = int64_t(num_cus) * (nt == 64 ? 2 : 1);
+int strip_grid(int dtype, int nt, int64_t nstrips, int num_cus) {
+  // two workgroups per CU (measured: a third f32 workgroup fits but is 7 % slower; SVGP_WG_PER_CU overrides)
+  (void)dtype;
+  const int per_cu = env_int("SVGP_WG_PER_CU", nt == 64 ? 2 : 1);
+  const int64_t cap = int64_t(num_cus) * per_cu;
   return int(nstrips < cap ? nstrips : cap);
 }
 
@@ -380,7 +383,7 @@ void launch_strip(int dtype, hipStream_t s, const StripArgs& a, int nt, int grid
   static const bool bk32 = env_int("SVGP_STRIP_BK", 16) == 32;
   if (nt == 64) {
     if (dtype == 0) launch_strip_t<double, 64, 16, 256>(s, a, grid, nstrips);
-    else launch_strip_t<float, 64, 16, 256>(s, a, grid, nstrips);
+    else launch_strip_t<float, 64, 16, 256>(s, a, grid, nstrips);   // BK = 32 measured identical
   } else if (dtype == 0) {
     if (bk32 && a.kp.d <= 8) launch_strip_t<double, 128, 32, 512>(s, a, grid, nstrips);
     else launch_strip_t<double, 128, 16, 512>(s, a, grid, nstrips);
