@@ -25,7 +25,7 @@ def allreduce_partials(partial, group=None, device=None):
 
     t = torch.tensor([partial[0], partial[1], partial[2], 1.0 if partial[3] != 0 else 0.0], dtype=torch.float64,
                      device=device if device is not None else "cpu")
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+    if dist.is_available() and dist.is_initialized():
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
     return t.cpu().numpy()
 

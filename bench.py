@@ -120,8 +120,10 @@ def main():
         raise SystemExit("bench.py needs a GPU: the library has no CPU path")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or os.environ.get("BENCH_FORCE_DIST") == "1"   # the env knob exercises the RCCL path on one GPU
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     n, M, d, family, lik, dtype = CONFIGS[args.config]
@@ -140,14 +142,14 @@ def main():
     def step():
         part = model.elbo_partial(data, 0, n)              # prep + fused strips + read-back (HIP library)
         kl, _ = model.prior_kl()                           # cached scalars of the same prep
-        if world > 1:
+        if use_dist:
             part = allreduce_partials(part, device=dev)    # ONE RCCL all-reduce of 4 doubles
         else:
             part = np.array([part[0], part[1], part[2], 1.0 if part[3] else 0.0])
         return combine(part, kl, num_data)
 
     def fence():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -164,7 +166,7 @@ def main():
         expect_ms.append(t.ms_expect)
     fence()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
@@ -216,7 +218,7 @@ def main():
     model.free()
     data.free()
     ctx.close()
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -1,0 +1,77 @@
+"""GPU parity at BASELINE.json's full sizes.  The oracle cannot evaluate 1e6 x 2048 in seconds, so at full
+size the checks are (i) the oracle on random contiguous sub-batches at the FULL M (exactly the code path of a
+minibatch), (ii) size-independent properties: additivity of the expectation over shards, invariance under a
+permutation of the points, bitwise repeatability, KL independent of the data."""
+import numpy as np
+import pytest
+
+import svgp_oracle as o
+from approxgp import _ffi
+from helpers import device_model, rel
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = _ffi.Context(0)
+    yield c
+    c.close()
+
+
+FULL = [
+    # name, N, M, d, family, lik, dtype, rtol, sub-batch
+    ("C2", 100_000, 512, 8, o.KERNEL_SE, o.LIK_GAUSSIAN, np.float64, 1e-8, 4000),
+    ("H", 1_000_000, 1024, 8, o.KERNEL_SE, o.LIK_GAUSSIAN, np.float64, 1e-8, 3000),
+    ("C3", 1_000_000, 2048, 16, o.KERNEL_MATERN52, o.LIK_BERNOULLI_LOGISTIC, np.float32, 1e-4, 1500),
+    ("C5", 262_144, 1024, 8, o.KERNEL_SE, o.LIK_GAUSSIAN, np.float32, 1e-4, 3000),
+]
+
+
+@pytest.mark.parametrize("name,N,M,d,family,lik,dtype,rtol,nb", FULL)
+def test_full_size_subbatches_and_properties(ctx, name, N, M, d, family, lik, dtype, rtol, nb):
+    x, y, sva, s2 = o.synth_problem(2, N, M, d, family=family, lik=lik, dtype=dtype)
+    model = device_model(ctx, sva, dtype=dtype, lik=lik, sigma2=s2)
+    data = _ffi.DeviceData(ctx, x, y, dtype)
+    full = model.elbo_partial(data)
+    assert full[1] == N and full[2] == 0 and full[3] == 0
+    # (i) oracle on sub-batches at the full M
+    rng = np.random.default_rng(0)
+    for off in (0, int(rng.integers(1, N - nb - 1)), N - nb):
+        ref = o.elbo_terms(sva, x[:, off:off + nb], y[off:off + nb], lik=lik, sigma2=s2, num_data=N)
+        val, t = model.elbo(data, off, nb, float(N))
+        assert rel(val, ref.elbo) < rtol, (name, off)
+        assert rel(t.kl, ref.kl) < (1e-9 if dtype == np.float64 else 1e-5)
+    # (ii) additivity over three uneven shards, bitwise repeatability
+    cuts = [0, N // 3 + 17, (2 * N) // 3 - 5, N]
+    parts = [model.elbo_partial(data, a, b - a)[0] for a, b in zip(cuts, cuts[1:])]
+    assert rel(sum(parts), full[0]) < 1e-11
+    assert model.elbo_partial(data)[0] == full[0]
+    # permutation invariance of the expectation
+    perm = rng.permutation(N)
+    pdata = _ffi.DeviceData(ctx, x[:, perm], y[perm], dtype)
+    assert rel(model.elbo_partial(pdata)[0], full[0]) < (1e-11 if dtype == np.float64 else 1e-9)
+    # KL does not depend on the data
+    kl0, _ = model.prior_kl()
+    assert kl0 == model.elbo(pdata, 0, 1000, 1000.0)[1].kl
+    for h in (model, data, pdata):
+        h.free()
+
+
+def test_c4_large_m_cholesky_dominated(ctx):
+    """C4: M = 8192, fp32.  Cholesky/T panels of a 268 MB Kuu; sub-batch against the oracle, logdet against LAPACK."""
+    N, M, d = 20_000, 8192, 8
+    x, y, sva, s2 = o.synth_problem(4, N, M, d, dtype=np.float32)
+    model = device_model(ctx, sva, dtype=np.float32, sigma2=s2)
+    data = _ffi.DeviceData(ctx, x, y, np.float32)
+    nb = 1000
+    ref = o.elbo_terms(sva, x[:, :nb], y[:nb], sigma2=s2, num_data=N)
+    val, t = model.elbo(data, 0, nb, float(N))
+    assert rel(val, ref.elbo) < 1e-4
+    Lk = o.posterior(sva).Lk
+    assert t.logdet_kuu == pytest.approx(2 * np.log(np.diag(Lk)).sum(), rel=1e-5)
+    full = model.elbo_partial(data)
+    a, b = model.elbo_partial(data, 0, 9999), model.elbo_partial(data, 9999, N - 9999)
+    assert rel(a[0] + b[0], full[0]) < 1e-11
+    model.free()
+    data.free()
