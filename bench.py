@@ -197,6 +197,15 @@ def main():
                          "expectation + reduce": float(np.mean(expect_ms))},
     }
 
+    # HBM-side traffic of the dominant kernel: PMC counters cannot be read from inside this process, so the
+    # figure is the one measured by tools/run_profile.sh (separate rocprofv3 --pmc passes) for this workload.
+    pmc_path = os.path.join(ROOT, "profiles", "round1", "H_fp64_v2_pmc.json")
+    if args.config == "H" and os.path.exists(pmc_path):
+        pm = json.load(open(pmc_path))
+        out["roofline"]["traffic"] = pm["strip_kernel<double,64,16,256>"]["traffic_bytes_per_launch"]
+        out["roofline"]["traffic_note"] = ("bytes per launch at the L2<->fabric boundary (FETCH_SIZE x2 + WRITE_SIZE, "
+                                           "profiles/round1/H_fp64_v2_pmc.json); includes Infinity-Cache hits of the per-workgroup "
+                                           "scratch strips; algorithmic HBM bytes are 88 MB")
     if rank == 0 and world == 1 and not args.no_kuf:
         # Kuf assembly alone (SVA:216): M x n column-major written once -> HBM-write bound
         es = 8 if dtype == "f64" else 4
@@ -207,8 +216,11 @@ def main():
         t_kuf = float(np.median(times[1:]))
         bytes_alg = es * (M * n + n * d + M * d)
         gbs = bytes_alg / (t_kuf * 1e-3) / 1e9
+        kuf_traffic = None
+        if args.config == "H" and os.path.exists(pmc_path):
+            kuf_traffic = json.load(open(pmc_path))["kuf_kernel<double,32>"]["traffic_bytes_per_launch"]
         out["kuf_roofline"] = {"kernel": "kuf_kernel", "bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS,
-                               "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS, "traffic": None,
+                               "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS, "traffic": kuf_traffic,
                                "bytes_per_launch": bytes_alg, "ms_per_launch": t_kuf}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(p, family, lik, min(args.cpu_sample, n), n)
