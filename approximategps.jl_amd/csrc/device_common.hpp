@@ -56,7 +56,29 @@ struct Vec16 {
 // ---------------------------------------------------------------------------------------------
 enum : int { KSE = 0, KM32 = 1, KM52 = 2 };
 
-__device__ __forceinline__ double kexp(double v) { return exp(v); }
+// exp(v) for the kernel functions (v <= 0 there).  Cody-Waite reduction by ln2 (hi/lo), degree-13 Taylor
+// polynomial on |r| <= ln2/2 (truncation 4e-18), v_ldexp: ~20 VALU instructions, <= 2 ulp; f64 MFMA does not
+// co-execute with VALU work, so the Kuf generation inside the strip kernel pays for every instruction.
+__device__ __forceinline__ double kexp(double v) {
+  const double n = rint(v * 1.4426950408889634074);
+  double r = fma(n, -6.93147180369123816490e-01, v);
+  r = fma(n, -1.90821492927058770002e-10, r);
+  double p = 1.6059043836821613e-10;            // 1/13!
+  p = fma(p, r, 2.08767569878681e-09);          // 1/12!
+  p = fma(p, r, 2.505210838544172e-08);         // 1/11!
+  p = fma(p, r, 2.755731922398589e-07);         // 1/10!
+  p = fma(p, r, 2.7557319223985893e-06);        // 1/9!
+  p = fma(p, r, 2.48015873015873e-05);          // 1/8!
+  p = fma(p, r, 1.984126984126984e-04);         // 1/7!
+  p = fma(p, r, 1.3888888888888889e-03);        // 1/6!
+  p = fma(p, r, 8.333333333333333e-03);         // 1/5!
+  p = fma(p, r, 4.1666666666666664e-02);        // 1/4!
+  p = fma(p, r, 1.6666666666666666e-01);        // 1/3!
+  p = fma(p, r, 0.5);
+  p = fma(p, r, 1.0);
+  p = fma(p, r, 1.0);
+  return ldexp(p, int(n));                      // n < -1074 flushes to 0, as exp does
+}
 __device__ __forceinline__ float kexp(float v) { return expf(v); }
 __device__ __forceinline__ double ksqrt(double v) { return sqrt(v); }
 __device__ __forceinline__ float ksqrt(float v) { return sqrtf(v); }

@@ -278,61 +278,60 @@ __global__ void final_reduce_kernel(const double* __restrict__ partial, const un
 }
 
 // ---------------------------------------------------------------------------------------------
-// standalone Kuf assembly (SVA:216): M x len column-major, HBM-write bound.
-// A workgroup writes a 128(i) x TJ(j) tile; each thread owns VEC consecutive rows (one 16-byte store
-// per column) so a wave's store instruction covers whole 128-byte lines of one column.
+// standalone Kuf assembly (SVA:216): M x len column-major, HBM-write bound (s*(M + d) bytes per point).
+// A 256-thread workgroup owns 64*VEC rows (inducing points) x JB columns (data points): every thread keeps
+// its VEC rows of the scaled z in registers for the whole block, the four waves take interleaved columns,
+// and a wave's store instruction writes 1 KB of ONE output column (whole 128-byte lines).  The scaled x of
+// the block sits in LDS and is read as a broadcast.
 // ---------------------------------------------------------------------------------------------
-template <typename T, int TJ>
+template <typename T, int DREG, int JB, int FAMILY>
 __global__ void __launch_bounds__(k256) kuf_kernel(KernelParams kp, const T* __restrict__ zs, int64_t M, int64_t Mp,
-                                                        const T* __restrict__ x, int64_t ldx, int64_t off, int64_t len,
-                                                        T* __restrict__ K) {
+                                                    const T* __restrict__ x, int64_t ldx, int64_t off, int64_t len,
+                                                    T* __restrict__ K) {
   constexpr int VEC = Vec16<T>::N;
   using V = typename Vec16<T>::type;
-  constexpr int TI = 128;
-  constexpr int IG = TI / VEC;          // row groups
-  constexpr int JG = k256 / IG;     // column groups
-  constexpr int RJ = TJ / JG;           // columns per thread
-  constexpr int DMAX = 32;
-  __shared__ T xt[DMAX][TJ];
+  __shared__ T xt[JB * DREG];
   const int d = kp.d;
   const T* __restrict__ invl = static_cast<const T*>(kp.invl);
-  const int64_t j0 = int64_t(blockIdx.x) * TJ;
-  const int64_t i0 = int64_t(blockIdx.y) * TI;
-  for (int e = threadIdx.x; e < d * TJ; e += k256) {
-    const int f = e / TJ, c = e % TJ;
+  const int64_t j0 = int64_t(blockIdx.x) * JB;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t i = (int64_t(blockIdx.y) * 64 + lane) * VEC;
+  for (int e = threadIdx.x; e < JB * DREG; e += k256) {
+    const int c = e / DREG, f = e % DREG;
     int64_t g = j0 + c;
     g = g < len ? g : len - 1;
-    xt[f][c] = x[int64_t(f) * ldx + off + g] * invl[f];
+    xt[e] = (f < d) ? x[int64_t(f) * ldx + off + g] * invl[f] : T(0);
+  }
+  T z[DREG][VEC];
+#pragma unroll
+  for (int f = 0; f < DREG; ++f) {
+    V zv = V(0);
+    if (f < d && i < Mp) zv = *reinterpret_cast<const V*>(zs + int64_t(f) * Mp + i);  // Mp multiple of 128: aligned
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) z[f][e] = zv[e];
   }
   __syncthreads();
-  const int ig = threadIdx.x % IG, jg = threadIdx.x / IG;
-  const int64_t i = i0 + int64_t(ig) * VEC;
-  T r2[RJ][VEC];
-#pragma unroll
-  for (int q = 0; q < RJ; ++q)
-#pragma unroll
-    for (int e = 0; e < VEC; ++e) r2[q][e] = T(0);
-  for (int f = 0; f < d; ++f) {
-    const V zv = *reinterpret_cast<const V*>(zs + int64_t(f) * Mp + i);   // Mp is a multiple of 128: in bounds, aligned
-#pragma unroll
-    for (int q = 0; q < RJ; ++q) {
-      const T xv = xt[f][jg * RJ + q];
-#pragma unroll
-      for (int e = 0; e < VEC; ++e) {
-        const T df = xv - zv[e];
-        r2[q][e] = fma(df, df, r2[q][e]);
-      }
-    }
-  }
   const T variance = T(kp.variance);
   const bool vec_ok = (M % VEC == 0) && (i + VEC <= M);
+#pragma unroll 2
+  for (int c = wave; c < JB; c += 4) {
+    const int64_t j = j0 + c;
+    if (j >= len) break;
+    T r2[VEC];
 #pragma unroll
-  for (int q = 0; q < RJ; ++q) {
-    const int64_t j = j0 + jg * RJ + q;
-    if (j >= len) continue;
+    for (int e = 0; e < VEC; ++e) r2[e] = T(0);
+#pragma unroll
+    for (int f = 0; f < DREG; ++f) {
+      const T xv = xt[c * DREG + f];
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) {
+        const T df = xv - z[f][e];
+        r2[e] = fma(df, df, r2[e]);
+      }
+    }
     V out;
 #pragma unroll
-    for (int e = 0; e < VEC; ++e) out[e] = kappa<T>(kp.family, r2[q][e], variance);
+    for (int e = 0; e < VEC; ++e) out[e] = kappa<T>(FAMILY, r2[e], variance);   // FAMILY is a compile-time constant
     if (vec_ok) {
       *reinterpret_cast<V*>(K + j * M + i) = out;
     } else {
@@ -414,16 +413,38 @@ void launch_final_reduce(hipStream_t s, const double* partial, const unsigned* n
   hipLaunchKernelGGL(final_reduce_kernel, dim3(1), dim3(k256), 0, s, partial, negcnt, n, out);
 }
 
+template <typename T, int FAMILY>
+static void launch_kuf_f(hipStream_t s, const KernelParams& kp, const T* zs, int64_t M, int64_t Mp, const T* x, int64_t ldx,
+                         int64_t off, int64_t len, T* Kuf) {
+  constexpr int VEC = Vec16<T>::N, JB = 256;
+  const unsigned gy = (unsigned)((Mp + 64 * VEC - 1) / (64 * VEC));
+  if (kp.d <= 8)
+    hipLaunchKernelGGL((kuf_kernel<T, 8, JB, FAMILY>), dim3((unsigned)((len + JB - 1) / JB), gy), dim3(k256), 0, s, kp, zs, M, Mp,
+                       x, ldx, off, len, Kuf);
+  else if (kp.d <= 16)
+    hipLaunchKernelGGL((kuf_kernel<T, 16, JB, FAMILY>), dim3((unsigned)((len + JB - 1) / JB), gy), dim3(k256), 0, s, kp, zs, M, Mp,
+                       x, ldx, off, len, Kuf);
+  else
+    hipLaunchKernelGGL((kuf_kernel<T, 32, JB / 2, FAMILY>), dim3((unsigned)((len + JB / 2 - 1) / (JB / 2)), gy), dim3(k256), 0, s,
+                       kp, zs, M, Mp, x, ldx, off, len, Kuf);
+}
+
+template <typename T>
+static void launch_kuf_t(hipStream_t s, const KernelParams& kp, const T* zs, int64_t M, int64_t Mp, const T* x, int64_t ldx,
+                         int64_t off, int64_t len, T* Kuf) {
+  if (kp.family == KSE) launch_kuf_f<T, KSE>(s, kp, zs, M, Mp, x, ldx, off, len, Kuf);
+  else if (kp.family == KM32) launch_kuf_f<T, KM32>(s, kp, zs, M, Mp, x, ldx, off, len, Kuf);
+  else launch_kuf_f<T, KM52>(s, kp, zs, M, Mp, x, ldx, off, len, Kuf);
+}
+
 void launch_kuf(int dtype, hipStream_t s, const KernelParams& kp, const void* zs, int64_t M, int64_t Mp, const void* x,
                 int64_t ldx, int64_t off, int64_t len, void* Kuf) {
-  constexpr int TJ = 32;
-  dim3 grid((unsigned)((len + TJ - 1) / TJ), (unsigned)(Mp / 128));
   if (dtype == 0)
-    hipLaunchKernelGGL((kuf_kernel<double, TJ>), grid, dim3(k256), 0, s, kp, static_cast<const double*>(zs), M, Mp,
-                       static_cast<const double*>(x), ldx, off, len, static_cast<double*>(Kuf));
+    launch_kuf_t<double>(s, kp, static_cast<const double*>(zs), M, Mp, static_cast<const double*>(x), ldx, off, len,
+                         static_cast<double*>(Kuf));
   else
-    hipLaunchKernelGGL((kuf_kernel<float, TJ>), grid, dim3(k256), 0, s, kp, static_cast<const float*>(zs), M, Mp,
-                       static_cast<const float*>(x), ldx, off, len, static_cast<float*>(Kuf));
+    launch_kuf_t<float>(s, kp, static_cast<const float*>(zs), M, Mp, static_cast<const float*>(x), ldx, off, len,
+                        static_cast<float*>(Kuf));
 }
 
 }  // namespace svgp
