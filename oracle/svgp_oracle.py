@@ -514,3 +514,107 @@ def synth_problem(
     rt = lambda a: np.asarray(a, dtype=dtype).astype(np.float64)
     sva = SVA(kernel, rt(z), rt(m), rt(Lq), jitter=jitter)
     return rt(x), rt(y), sva, sigma2
+
+
+# ----------------------------------------------------------------------------
+# reverse-mode gradient of the NonCentered ELBO.  The reference obtains it from Zygote
+# (examples/a-regression/script.jl:188-194, test/SparseVariationalApproximationModule.jl:170-175); this is
+# the hand-derived adjoint of elbo_terms(), pinned by central finite differences in tests/test_oracle_grad.py.
+# ----------------------------------------------------------------------------
+def _dkappa_dr2(kernel: Kernel, r2: np.ndarray) -> np.ndarray:
+    """d k / d r² (including the variance factor)."""
+    var = kernel.variance
+    if kernel.family == KERNEL_SE:
+        return -0.5 * var * np.exp(-0.5 * r2)
+    r = np.sqrt(r2)
+    if kernel.family == KERNEL_MATERN32:
+        return -1.5 * var * np.exp(-_SQRT3 * r)
+    return -(5.0 / 6.0) * var * (1.0 + _SQRT5 * r) * np.exp(-_SQRT5 * r)
+
+
+def _dloglik(lik: int, f, y, sigma2):
+    """d log p(y|f) / d f."""
+    if lik == LIK_GAUSSIAN:
+        return (y - f) / sigma2
+    if lik == LIK_BERNOULLI_LOGISTIC:
+        return y - 1.0 / (1.0 + np.exp(-f))
+    return y - np.exp(f)
+
+
+def expected_loglik_grads(lik, mu, v, y, sigma2=1.0, quadrature_n=0):
+    """(dE/dmu_i, dE/dv_i, dE/dsigma2) of expected_loglik() with sigma = sqrt(v)."""
+    if quadrature_n == 0 and lik == LIK_GAUSSIAN:
+        r = y - mu
+        return r / sigma2, np.full_like(mu, -0.5 / sigma2), float(np.sum(-0.5 * (1.0 / sigma2 - (r * r + v) / sigma2**2)))
+    if quadrature_n == 0 and lik == LIK_POISSON_EXP:
+        e = np.exp(mu + 0.5 * v)
+        return y - e, -0.5 * e, 0.0
+    n = quadrature_n or DEFAULT_GH_POINTS
+    xs, ws = gausshermite(n)
+    ws = ws / math.sqrt(math.pi)
+    sd = np.sqrt(v)
+    gmu = np.zeros_like(mu)
+    gv = np.zeros_like(mu)
+    gs2 = 0.0
+    for xj, wj in zip(xs, ws):
+        f = math.sqrt(2.0) * sd * xj + mu
+        d = _dloglik(lik, f, y, sigma2)
+        gmu += wj * d
+        gv += wj * d * xj / (math.sqrt(2.0) * sd)
+        if lik == LIK_GAUSSIAN:
+            gs2 += float(np.sum(wj * (-0.5 / sigma2 + 0.5 * (y - f) ** 2 / sigma2**2)))
+    return gmu, gv, gs2
+
+
+def chol_backward(L: np.ndarray, Lbar: np.ndarray) -> np.ndarray:
+    """Adjoint of L = chol(K): symmetric Kbar with <Kbar, dK> = <Lbar, dL> for symmetric dK (Murray 2016)."""
+    Phi = np.tril(L.T @ np.tril(Lbar))
+    Phi[np.diag_indices_from(Phi)] *= 0.5
+    S = sla.solve_triangular(L, sla.solve_triangular(L, Phi, lower=True, trans="T").T, lower=True, trans="T").T
+    return 0.5 * (S + S.T)
+
+
+def elbo_grad(sva: SVA, x, y, lik=LIK_GAUSSIAN, sigma2=1.0, num_data=None, quadrature_n=0):
+    """-> (elbo, dict of gradients w.r.t. variance, inv_lengthscale[d], z[d,M], m[M], Lq[M,M] lower, lik_sigma2, mean_const)."""
+    assert not sva.centered, "gradient is implemented for the NonCentered parametrisation"
+    x = _as_dn(np.asarray(x, dtype=np.float64))
+    y = np.asarray(y, dtype=np.float64)
+    k = sva.kernel
+    il = k.inv_lengthscale
+    z, m, Lq = sva.z.astype(np.float64), sva.m.astype(np.float64), np.tril(sva.Lq).astype(np.float64)
+    M, n = z.shape[1], x.shape[1]
+    scale = (float(num_data) if num_data is not None else float(n)) / n
+    r2_uf = _scaled_sqdist(k, z, x)
+    Kuf = _kappa(k, r2_uf)
+    r2_uu = _scaled_sqdist(k, z, z)
+    Kuu = _kappa(k, r2_uu) + sva.jitter * np.eye(M)
+    Lk = _chol_lower_checked(Kuu.copy())
+    A = sla.solve_triangular(Lk, Kuf, lower=True)
+    C = Lq.T @ A
+    mu = sva.mean_const + A.T @ m
+    v = k.variance - np.sum(A * A, 0) + np.sum(C * C, 0) + DEFAULT_SIGMA2
+    E = expected_loglik(lik, mu, np.sqrt(v), y, sigma2, quadrature_n)
+    gmu, gv, gs2 = expected_loglik_grads(lik, mu, v, y, sigma2, quadrature_n)
+    gmu, gv, gs2 = scale * gmu, scale * gv, scale * gs2
+    kl = prior_kl(sva)
+    # adjoints
+    Abar = np.outer(m, gmu) + 2.0 * (Lq @ C - A) * gv[None, :]
+    m_bar = A @ gmu - m
+    Lq_bar = np.tril(2.0 * (A * gv[None, :]) @ C.T) - (Lq - np.diag(1.0 / np.diag(Lq)))
+    P = sla.solve_triangular(Lk, Abar, lower=True, trans="T")          # Kuf_bar
+    Lk_bar = -np.tril(P @ A.T)
+    H = chol_backward(Lk, Lk_bar)                                       # Kuu_bar (symmetric)
+    # kernel parameters
+    var_bar = float(np.sum(P * Kuf) / k.variance + np.sum(H * (Kuu - sva.jitter * np.eye(M))) / k.variance + np.sum(gv))
+    Wf = P * _dkappa_dr2(k, r2_uf)
+    Wu = H * _dkappa_dr2(k, r2_uu)
+    il_bar = np.zeros_like(il)
+    z_bar = np.zeros_like(z)
+    for f in range(z.shape[0]):
+        dzx = z[f][:, None] - x[f][None, :]
+        dzz = z[f][:, None] - z[f][None, :]
+        il_bar[f] = 2.0 * il[f] * (np.sum(Wf * dzx * dzx) + np.sum(Wu * dzz * dzz))
+        z_bar[f] = 2.0 * il[f] ** 2 * (np.sum(Wf * dzx, 1) + 2.0 * np.sum(Wu * dzz, 1))
+    grads = dict(variance=var_bar, inv_lengthscale=il_bar, z=z_bar, m=m_bar, Lq=Lq_bar, lik_sigma2=gs2,
+                 mean_const=float(np.sum(gmu)))
+    return E * scale - kl, grads
