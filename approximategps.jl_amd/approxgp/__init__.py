@@ -12,6 +12,7 @@ from .gp import (GP, BernoulliLikelihood, DefaultExpectationMethod, FiniteGP, Ga
 from .kernels import (ARDTransform, Matern32Kernel, Matern52Kernel, ScaledKernel, ScaleTransform, SEKernel,
                       SqExponentialKernel, TransformedKernel, with_lengthscale)
 from .sva import (SVGP, ApproxPosteriorGP, Centered, NonCentered, SparseVariationalApproximation, approx_lml, elbo,
+                  elbo_and_gradient,
                   inducing_points, posterior, prior_kl)
 
 __all__ = [n for n in dir() if not n.startswith("_")]

@@ -37,6 +37,11 @@ class Terms(C.Structure):
     ]
 
 
+class Grads(C.Structure):
+    _fields_ = [("variance", C.c_double), ("lik_sigma2", C.c_double), ("mean_const", C.c_double),
+                ("inv_lengthscale", C.POINTER(C.c_double)), ("z", C.c_void_p), ("m", C.c_void_p), ("Lq", C.c_void_p)]
+
+
 class Timing(C.Structure):
     _fields_ = [("ms_total", C.c_double), ("ms_prep", C.c_double), ("ms_strip", C.c_double), ("ms_expect", C.c_double),
                 ("ms_kuf", C.c_double),
@@ -60,6 +65,8 @@ SYMBOLS = {
     "svgp_model_free": (C.c_int32, [_P, _P]),
     "svgp_elbo": (C.c_int32, [_P, _P, _P, C.c_int64, C.c_int64, C.c_double, C.POINTER(C.c_double), C.POINTER(Terms)]),
     "svgp_elbo_partial": (C.c_int32, [_P, _P, _P, C.c_int64, C.c_int64, C.POINTER(C.c_double)]),
+    "svgp_elbo_grad": (C.c_int32, [_P, _P, _P, C.c_int64, C.c_int64, C.c_double, C.POINTER(C.c_double), C.POINTER(Terms),
+                                   C.POINTER(Grads)]),
     "svgp_prior_kl": (C.c_int32, [_P, _P, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "svgp_elbo_host": (C.c_int32, [_P, C.POINTER(ModelDesc), C.c_int32, C.c_int64, _P, _P, C.c_double,
                                    C.POINTER(C.c_double), C.POINTER(Terms)]),
@@ -286,6 +293,23 @@ class DeviceModel:
         buf = (C.c_double * 4)()
         self.ctx.check(self.ctx.lib.svgp_elbo_partial(self.ctx.h, self.h, data.h, off, length, buf))
         return np.array(buf[:], dtype=np.float64)
+
+    def elbo_grad(self, data: DeviceData, off=0, length=None, num_data=0.0, z_shape=None):
+        """-> (elbo, terms, dict(variance, inv_lengthscale, z, m, Lq, lik_sigma2, mean_const)); z in the layout it was given."""
+        length = data.n - off if length is None else length
+        dt = np_dtype(self.dtype)
+        il = np.zeros(self.d)
+        zshape = z_shape if z_shape is not None else ((self.M,) if self.d == 1 else (self.d, self.M))
+        zb = np.zeros(zshape, dtype=dt, order="F")
+        mb = np.zeros(self.M, dtype=dt)
+        Lb = np.zeros((self.M, self.M), dtype=dt, order="F")
+        g = Grads(0.0, 0.0, 0.0, il.ctypes.data_as(C.POINTER(C.c_double)), _ptr(zb), _ptr(mb), _ptr(Lb))
+        out, terms = C.c_double(), Terms()
+        rc = self.ctx.lib.svgp_elbo_grad(self.ctx.h, self.h, data.h, off, length, float(num_data), C.byref(out),
+                                         C.byref(terms), C.byref(g))
+        self.ctx.check(rc, terms)
+        return out.value, terms, dict(variance=g.variance, inv_lengthscale=il, z=zb, m=mb, Lq=Lb,
+                                      lik_sigma2=g.lik_sigma2, mean_const=g.mean_const)
 
     def prior_kl(self):
         kl, ld = C.c_double(), C.c_double()

@@ -119,6 +119,32 @@ def elbo(sva: SparseVariationalApproximation, fx, y, *, num_data=None, quadratur
     return (val, terms) if return_terms else val
 
 
+def elbo_and_gradient(sva: SparseVariationalApproximation, fx, y, *, num_data=None, quadrature=None, ctx=None, dtype=None):
+    """ELBO and its gradient w.r.t. (kernel variance, inverse lengthscales, inducing inputs z, mean(q) m, the lower factor
+    Lq of cov(q), Gaussian noise σ², ConstMean) — what `Zygote.gradient(-elbo, ...)` yields for the reference's training
+    loops (examples/a-regression/script.jl:188-194); the Julia shim wraps it as a ChainRulesCore.rrule."""
+    if isinstance(fx, FiniteGP):
+        if not fx.is_isotropic():
+            raise RuntimeError("The observation noise fx.Σy must be homoscedastic.")
+        lfx = LatentFiniteGP(fx, GaussianLikelihood(float(fx.Sigma_y)))
+    else:
+        lfx = fx
+    if sva.fz.f is not lfx.fx.f:
+        raise ValueError("(Latent)FiniteGP prior is not consistent with SparseVariationalApproximation's")
+    ctx = ctx or _ffi.default_context()
+    desc, keep = _desc(sva, lfx.lik, quadrature, dtype)
+    y = np.asarray(y)
+    data = _ffi.DeviceData(ctx, lfx.fx.x, y, _ffi.np_dtype(desc.dtype))
+    model = _ffi.DeviceModel(ctx, desc, keep)
+    try:
+        val, _, grads = model.elbo_grad(data, 0, y.shape[0], float(num_data) if num_data is not None else 0.0,
+                                        z_shape=np.asarray(sva.fz.x).shape)
+    finally:
+        model.free()
+        data.free()
+    return val, grads
+
+
 def approx_lml(sva, l_fx, ys, **kwargs):
     """API.approx_lml (SVA:276-280): forwards to elbo."""
     return elbo(sva, l_fx, ys, **kwargs)

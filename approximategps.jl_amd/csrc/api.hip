@@ -30,6 +30,25 @@ struct svgp_ctx {
   double* mom = nullptr;      size_t mom_cap = 0;           // [2][mom_cap] per-point mean / variance
   double* d_res = nullptr;    // [8] device results
   void* kuf_buf = nullptr;    size_t kuf_bytes = 0;
+  struct GradWs* gws = nullptr;  // gradient workspace, cached by problem shape
+};
+
+// device buffers of svgp_elbo_grad, sized by (dtype, Mp, d, nc)
+struct GradWs {
+  int dtype = -1, d = 0, nslices = 1, ns_uf = 1, ns_uu = 1, rb = 1;
+  int64_t Mp = 0, nc = 0;
+  std::vector<void*> all;
+  void *A = nullptr, *C = nullptr, *Ab = nullptr, *At = nullptr, *Ct = nullptr, *Pt = nullptr, *gmu = nullptr, *gv = nullptr;
+  void *Lqp = nullptr, *S = nullptr, *G1 = nullptr, *G2 = nullptr, *LkRM = nullptr, *LbarRM = nullptr, *Phi = nullptr,
+       *tmp = nullptr, *H = nullptr, *zbar = nullptr, *mbar = nullptr, *Lqbar = nullptr;
+  double *rp_uf = nullptr, *sp_uf = nullptr, *rp_uu = nullptr, *sp_uu = nullptr, *partial5 = nullptr, *sums = nullptr,
+         *invl_d = nullptr, *scal_out = nullptr;
+  size_t rp_uf_b = 0, sp_uf_b = 0, rp_uu_b = 0, sp_uu_b = 0, g_b = 0;
+  void release() {
+    for (void* p : all)
+      if (p) hipFree(p);
+    all.clear();
+  }
 };
 
 struct svgp_data {
@@ -300,7 +319,10 @@ struct StripOuts {
   void* var = nullptr;
   void* A = nullptr;
   void* C = nullptr;
+  void* At = nullptr;
+  void* Ct = nullptr;
   int64_t lda = 0;
+  bool skip_expect = false;   // gradient path: the moments are consumed by grad_moments instead
 };
 
 // enqueue the fused strip kernel + final reduce over points [off, off+len) of (x, y)
@@ -322,6 +344,8 @@ int enqueue_strips(svgp_ctx* ctx, svgp_model* m, const void* x, int64_t ldx, con
   a.mom_var = ctx->mom + ctx->mom_cap;
   a.A_out = o.A;
   a.C_out = o.C;
+  a.At_out = o.At;
+  a.Ct_out = o.Ct;
   a.lda = o.lda;
   a.ldx = ldx;
   a.off = off;
@@ -341,6 +365,7 @@ int enqueue_strips(svgp_ctx* ctx, svgp_model* m, const void* x, int64_t ldx, con
   launch_strip(m->dtype, ctx->stream, a, nt, grid, nstrips);
   KCHECK(ctx, "strip");
   HIPC(ctx, hipEventRecord(ctx->ev[2], ctx->stream));
+  if (o.skip_expect) return SVGP_OK;
   launch_expect(m->dtype, ctx->stream, lp, a.mom_mu, a.mom_var, y, off, len, ctx->partial, ctx->negcnt, o.mu, o.var);
   KCHECK(ctx, "expect");
   launch_final_reduce(ctx->stream, ctx->partial, ctx->negcnt, expect_blocks(len), ctx->d_res);
@@ -509,6 +534,7 @@ int32_t svgp_ctx_destroy(svgp_ctx* c) {
   if (c->mom) hipFree(c->mom);
   if (c->d_res) hipFree(c->d_res);
   if (c->kuf_buf) hipFree(c->kuf_buf);
+  if (c->gws) { c->gws->release(); delete c->gws; }
   for (auto& e : c->ev)
     if (e) hipEventDestroy(e);
   if (c->own_stream) hipStreamDestroy(c->stream);
@@ -831,3 +857,176 @@ int32_t svgp_predict_cross_cov(svgp_ctx* ctx, svgp_model* m, int32_t layout, int
 }
 
 }  // extern "C"
+
+namespace {
+
+int grad_workspace(svgp_ctx* ctx, svgp_model* m, int64_t len, GradWs** out) {
+  const size_t es = m->es;
+  const int64_t Mp = m->Mp;
+  int64_t cap = int64_t(1.0e9 / double(Mp * int64_t(es))) / 128 * 128;
+  cap = cap < 128 ? 128 : (cap > 65536 ? 65536 : cap);
+  int64_t nc = (len + 127) / 128 * 128;
+  nc = nc < cap ? nc : cap;
+  GradWs* w = ctx->gws;
+  if (w && w->dtype == m->dtype && w->Mp == Mp && w->d == m->d && w->nc >= nc) { *out = w; return SVGP_OK; }
+  if (w) { w->release(); delete w; ctx->gws = nullptr; }
+  w = new (std::nothrow) GradWs();
+  if (!w) return SVGP_OOM;
+  w->dtype = m->dtype; w->Mp = Mp; w->d = m->d; w->nc = nc;
+  const int nP = int(Mp / 128), ntiles = nP * (nP + 1) / 2;
+  int ns = (2 * ctx->num_cus + ntiles - 1) / ntiles;
+  w->nslices = ns < 1 ? 1 : (ns > 16 ? 16 : ns);
+  w->rb = grad_rowblocks(m->d, Mp);
+  int nu = (2 * ctx->num_cus + w->rb - 1) / w->rb;
+  w->ns_uf = nu < 1 ? 1 : (nu > 128 ? 128 : nu);
+  w->ns_uu = 8;
+  const int dreg = grad_dreg(m->d);
+  const size_t mn = size_t(Mp) * size_t(nc) * es, mm = size_t(Mp) * size_t(Mp) * es;
+  w->g_b = size_t(w->nslices) * mm;
+  w->rp_uf_b = size_t(w->ns_uf) * (2 + dreg) * Mp * 8; w->sp_uf_b = size_t(w->ns_uf) * w->rb * (1 + dreg) * 8;
+  w->rp_uu_b = size_t(w->ns_uu) * (2 + dreg) * Mp * 8; w->sp_uu_b = size_t(w->ns_uu) * w->rb * (1 + dreg) * 8;
+  struct { void** p; size_t b; } req[] = {
+      {&w->A, mn}, {&w->C, mn}, {&w->Ab, mn}, {&w->At, mn}, {&w->Ct, mn}, {&w->Pt, mn}, {&w->gmu, size_t(nc) * es},
+      {&w->gv, size_t(nc) * es}, {&w->Lqp, mm}, {&w->S, mm}, {&w->G1, w->g_b}, {&w->G2, w->g_b}, {&w->LkRM, mm},
+      {&w->LbarRM, mm}, {&w->Phi, mm}, {&w->tmp, mm}, {&w->H, mm}, {&w->zbar, size_t(m->M) * m->d * es},
+      {&w->mbar, size_t(m->M) * es}, {&w->Lqbar, size_t(m->M) * m->M * es}, {(void**)&w->rp_uf, w->rp_uf_b},
+      {(void**)&w->sp_uf, w->sp_uf_b}, {(void**)&w->rp_uu, w->rp_uu_b}, {(void**)&w->sp_uu, w->sp_uu_b},
+      {(void**)&w->partial5, 1024 * 5 * 8}, {(void**)&w->sums, 8 * 8}, {(void**)&w->invl_d, size_t(m->d) * 8},
+      {(void**)&w->scal_out, size_t(1 + dreg) * 8}};
+  for (auto& r : req) {
+    if (hipMalloc(r.p, r.b) != hipSuccess) {
+      w->release();
+      delete w;
+      return fail(ctx, SVGP_OOM, "hipMalloc failed for the gradient workspace");
+    }
+    w->all.push_back(*r.p);
+  }
+  // point-major / k-major chunk buffers are read beyond the written columns of a short last chunk: start from zeros
+  for (void* p : {w->A, w->C, w->Ab, w->At, w->Ct, w->Pt})
+    if (hipMemsetAsync(p, 0, mn, ctx->stream) != hipSuccess) return fail(ctx, SVGP_HIP_ERROR, "memset failed");
+  ctx->gws = w;
+  *out = w;
+  return SVGP_OK;
+}
+
+}  // namespace
+
+extern "C" int32_t svgp_elbo_grad(svgp_ctx* ctx, svgp_model* m, const svgp_data* data, int64_t off, int64_t len,
+                                  double num_data, double* elbo_out, svgp_terms* terms_out, svgp_grads* g) {
+  int rc = check_batch(ctx, m, data, off, len, true);
+  if (rc) return rc;
+  if (!g) return fail(ctx, SVGP_INVALID_ARG, "null gradient output");
+  if (m->desc.parametrization != SVGP_NONCENTERED)
+    return fail(ctx, SVGP_UNSUPPORTED, "svgp_elbo_grad supports the NonCentered parametrisation only");
+  HIPC(ctx, hipSetDevice(ctx->device));
+  hipStream_t s = ctx->stream;
+  GradWs* w = nullptr;
+  rc = grad_workspace(ctx, m, len, &w);
+  if (rc) return rc;
+  const int dt = m->dtype;
+  const int64_t Mp = m->Mp, M = m->M, nc = w->nc;
+  const size_t es = m->es, mm = size_t(Mp) * Mp * es;
+  const int dreg = grad_dreg(m->d);
+  const double scale = (num_data > 0 ? num_data : double(len)) / double(len);
+  HIPC(ctx, hipEventRecord(ctx->ev[0], s));
+  rc = enqueue_prep(ctx, m);
+  if (rc) return rc;
+  HIPC(ctx, hipEventRecord(ctx->ev[1], s));
+  // accumulators
+  HIPC(ctx, hipMemsetAsync(w->G1, 0, w->g_b, s));
+  HIPC(ctx, hipMemsetAsync(w->G2, 0, w->g_b, s));
+  HIPC(ctx, hipMemsetAsync(w->rp_uf, 0, w->rp_uf_b, s));
+  HIPC(ctx, hipMemsetAsync(w->sp_uf, 0, w->sp_uf_b, s));
+  HIPC(ctx, hipMemsetAsync(w->rp_uu, 0, w->rp_uu_b, s));
+  HIPC(ctx, hipMemsetAsync(w->sp_uu, 0, w->sp_uu_b, s));
+  HIPC(ctx, hipMemsetAsync(w->sums, 0, 8 * 8, s));
+  HIPC(ctx, hipMemsetAsync(w->S, 0, mm, s));
+  HIPC(ctx, hipMemcpyAsync(w->invl_d, m->invl_host.data(), size_t(m->d) * 8, hipMemcpyHostToDevice, s));
+  launch_pad_lower(dt, s, m->Lq_raw, M, Mp, w->Lqp);
+  launch_sdiag(dt, s, m->T, Mp, w->S);
+  launch_spanels(dt, s, m->L, m->T, w->S, Mp);
+  KCHECK(ctx, "grad prep");
+  LikParams lp{};
+  lp.lik = m->desc.likelihood;
+  lp.gh_n = m->gh_n;
+  lp.sigma2 = m->desc.likelihood == SVGP_LIK_GAUSSIAN ? m->desc.lik_sigma2 : 1.0;
+  lp.gh_x = m->gh_x;
+  lp.gh_w = m->gh_w;
+  lp.clamp_neg_var = (m->desc.neg_var_policy == SVGP_NEGVAR_CLAMP);
+  lp.mean_const = m->desc.mean_const;
+  const KernelParams kp = kparams(m);
+  for (int64_t c0 = 0; c0 < len; c0 += nc) {
+    const int64_t clen = (len - c0 < nc) ? len - c0 : nc;
+    const int64_t ncp = (clen + 127) / 128 * 128;
+    StripOuts o;
+    o.A = w->A; o.C = w->C; o.At = w->At; o.Ct = w->Ct; o.lda = nc; o.skip_expect = true;
+    rc = enqueue_strips(ctx, m, data->x, data->ldx, nullptr, off + c0, clen, o);
+    if (rc) return rc;
+    launch_grad_moments(dt, s, lp, scale, ctx->mom, ctx->mom + ctx->mom_cap, data->y, off + c0, clen, ncp, w->gmu, w->gv,
+                        w->partial5, w->sums);
+    KCHECK(ctx, "grad_moments");
+    launch_abar(dt, s, w->Lqp, w->C, w->A, m->mp, w->gmu, w->gv, w->Ab, Mp, nc, ncp);
+    KCHECK(ctx, "abar");
+    launch_solve_t(dt, s, w->S, w->Ab, w->Pt, Mp, nc, ncp, ctx->num_cus);
+    KCHECK(ctx, "solve_t");
+    int64_t sl = ((ncp + w->nslices - 1) / w->nslices + 127) / 128 * 128;
+    launch_gemm_pm(dt, s, w->At, w->Ct, w->gv, 2.0, Mp, ncp, sl, w->nslices, w->G1);
+    launch_gemm_pm(dt, s, w->Pt, w->At, nullptr, 1.0, Mp, ncp, sl, w->nslices, w->G2);
+    KCHECK(ctx, "gemm_pm");
+    int64_t ksl = ((clen + w->ns_uf - 1) / w->ns_uf + 127) / 128 * 128;
+    launch_kgrad(dt, s, kp, m->zs, Mp, data->x, data->ldx, off + c0, 0, clen, clen, w->Pt, w->At, w->gmu, ksl, w->ns_uf,
+                 w->rp_uf, w->sp_uf);
+    KCHECK(ctx, "kgrad uf");
+  }
+  // M-sized tail: Lq_bar, Lk_bar -> Kuu_bar -> kernel parameters
+  launch_finish_mm(dt, s, w->G1, w->G2, w->nslices, Mp, M, m->Lq_raw, w->Lqbar, w->LbarRM);
+  launch_lower_to_rowmajor(dt, s, m->L, Mp, w->LkRM);
+  HIPC(ctx, hipMemsetAsync(w->Phi, 0, mm, s));
+  launch_gemm_pm(dt, s, w->LkRM, w->LbarRM, nullptr, 1.0, Mp, Mp, Mp, 1, w->Phi);
+  launch_phi(dt, s, w->Phi, Mp);
+  launch_solve_t(dt, s, w->S, w->Phi, nullptr, Mp, Mp, Mp, ctx->num_cus);
+  launch_transpose(dt, s, w->Phi, Mp, w->tmp);
+  launch_solve_t(dt, s, w->S, w->tmp, nullptr, Mp, Mp, Mp, ctx->num_cus);
+  launch_symmetrize(dt, s, w->tmp, Mp, w->H);
+  KCHECK(ctx, "chol backward");
+  launch_kgrad(dt, s, kp, m->zs, Mp, m->zs, Mp, 0, 1, M, M, w->H, nullptr, nullptr, 128, w->ns_uu, w->rp_uu, w->sp_uu);
+  launch_finish_kgrad(dt, s, m->d, M, Mp, m->zs, w->invl_d, w->rp_uf, w->ns_uf, w->rp_uu, w->ns_uu, w->sp_uf, w->ns_uf * w->rb,
+                      w->sp_uu, w->ns_uu * w->rb, m->m_raw, m->desc.layout_z, m->desc.variance, w->zbar, w->mbar, w->scal_out);
+  KCHECK(ctx, "kgrad uu / finish");
+  HIPC(ctx, hipEventRecord(ctx->ev[3], s));
+  // read back
+  double sums[8];
+  std::vector<double> sc(1 + dreg);
+  PrepScalars ps;
+  HIPC(ctx, hipMemcpyAsync(sums, w->sums, sizeof sums, hipMemcpyDeviceToHost, s));
+  HIPC(ctx, hipMemcpyAsync(sc.data(), w->scal_out, sc.size() * 8, hipMemcpyDeviceToHost, s));
+  HIPC(ctx, hipMemcpyAsync(ps.scal, m->scal, sizeof(ps.scal), hipMemcpyDeviceToHost, s));
+  HIPC(ctx, hipMemcpyAsync(&ps.info, m->info, sizeof(int), hipMemcpyDeviceToHost, s));
+  if (g->z) HIPC(ctx, hipMemcpyAsync(g->z, w->zbar, size_t(M) * m->d * es, hipMemcpyDeviceToHost, s));
+  if (g->m) HIPC(ctx, hipMemcpyAsync(g->m, w->mbar, size_t(M) * es, hipMemcpyDeviceToHost, s));
+  if (g->Lq) HIPC(ctx, hipMemcpyAsync(g->Lq, w->Lqbar, size_t(M) * M * es, hipMemcpyDeviceToHost, s));
+  HIPC(ctx, hipStreamSynchronize(s));
+  finish_prep(m, ps);
+  float t01 = 0, t13 = 0;
+  hipEventElapsedTime(&t01, ctx->ev[0], ctx->ev[1]);
+  hipEventElapsedTime(&t13, ctx->ev[1], ctx->ev[3]);
+  ctx->timing = svgp_timing{};
+  ctx->timing.ms_prep = t01;
+  ctx->timing.ms_strip = t13;
+  ctx->timing.ms_total = t01 + t13;
+  const double E = sums[0], nneg = sums[4];
+  const double elbo = E * scale - m->kl;
+  g->variance = sc[0] + sums[2];
+  g->lik_sigma2 = sums[3];
+  g->mean_const = sums[1];
+  if (g->inv_lengthscale)
+    for (int f = 0; f < m->d; ++f) g->inv_lengthscale[f] = sc[1 + f];
+  if (terms_out) {
+    terms_out->elbo = elbo; terms_out->expectation = E; terms_out->kl = m->kl; terms_out->scale = scale;
+    terms_out->logdet_kuu = m->logdet_kuu; terms_out->n_points = len; terms_out->n_neg_var = (int64_t)nneg;
+    terms_out->chol_info = m->chol_info; terms_out->reserved = 0;
+  }
+  rc = status_of(ctx, m, nneg);
+  if (elbo_out) *elbo_out = (rc == SVGP_OK) ? elbo : NAN;
+  return rc;
+}

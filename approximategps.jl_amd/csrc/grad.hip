@@ -1,0 +1,552 @@
+// grad.hip — reverse-mode gradient of the NonCentered ELBO (the reference differentiates
+// elbo with Zygote: examples/a-regression/script.jl:188-194, test/SparseVariationalApproximationModule.jl:170-175).
+// Hand-derived adjoint of the forward path (oracle/svgp_oracle.py: elbo_grad is the same derivation):
+//   per point      g_mu = s dE/dmu, g_v = s dE/dv                                   (grad_moments_kernel)
+//   Abar = m g_mu' + 2 (Lq C - A) diag(g_v)        A = Lk \ Kuf, C = Lq'A           (abar_kernel, MFMA)
+//   P    = Lk' \ Abar   (= Kuf_bar)                                                 (solve_t_kernel, MFMA panels)
+//   Lq_bar = tril(2 A diag(g_v) C') - (Lq - diag(1/Lq_ii)),  Lk_bar = -tril(P A')   (gemm_pm_kernel, MFMA)
+//   Kuu_bar = sym(Lk^-T Phi(Lk' Lk_bar) Lk^-1)                                      (gemm_pm + solve_t twice)
+//   kernel parameters / inducing inputs from sum_ij P_ij dK_ij and Kuu_bar_ij dKuu_ij (kgrad_kernel)
+// The data are processed in chunks of columns; per chunk the strip kernel leaves A and C in HBM in both
+// orientations ([Mp][nc] for the panel recurrences, [nc][Mp] for the products contracted over points).
+#include "device_common.hpp"
+#include "kernels.hpp"
+#include "lik.hpp"
+
+namespace svgp {
+namespace {
+
+template <typename T>
+__global__ void __launch_bounds__(k256) grad_moments_kernel(LikParams lp, double scale, const double* __restrict__ mom_mu,
+                                                            const double* __restrict__ mom_var, const T* __restrict__ y,
+                                                            int64_t off, int64_t len, int64_t npad, T* __restrict__ gmu,
+                                                            T* __restrict__ gv, double* __restrict__ partial) {
+  __shared__ double sh[5][k256];
+  const double log_sigma2 = log(lp.sigma2);
+  double acc[5] = {0, 0, 0, 0, 0};  // E, sum g_mu, sum g_v, dE/dsigma2, n_neg
+  for (int64_t i = int64_t(blockIdx.x) * k256 + threadIdx.x; i < npad; i += int64_t(gridDim.x) * k256) {
+    double a = 0.0, b = 0.0;
+    if (i < len) {
+      const double mu = mom_mu[i];
+      double v = mom_var[i] + kDefaultSigma2;
+      bool bad = v < 0.0;
+      if (bad) {
+        acc[4] += 1.0;
+        if (lp.clamp_neg_var) { v = 0.0; bad = false; }
+      }
+      if (!bad) {
+        const double yv = double(y[off + i]);
+        double gs2;
+        expected_loglik_grad_point(lp, mu, v, yv, a, b, gs2);
+        acc[0] += expected_loglik_point(lp, mu, v, yv, log_sigma2);
+        a *= scale;
+        b *= scale;
+        acc[1] += a;
+        acc[2] += b;
+        acc[3] += gs2 * scale;
+      }
+    }
+    gmu[i] = T(a);
+    gv[i] = T(b);
+  }
+  for (int q = 0; q < 5; ++q) sh[q][threadIdx.x] = acc[q];
+  __syncthreads();
+  for (int w = k256 / 2; w > 0; w >>= 1) {
+    if (int(threadIdx.x) < w)
+      for (int q = 0; q < 5; ++q) sh[q][threadIdx.x] += sh[q][threadIdx.x + w];
+    __syncthreads();
+  }
+  if (threadIdx.x < 5) partial[blockIdx.x * 5 + threadIdx.x] = sh[threadIdx.x][0];
+}
+
+// out[q] += sum over blocks of partial[b][q]  (fixed order)
+__global__ void sum5_kernel(const double* __restrict__ partial, int nblocks, double* __restrict__ out) {
+  if (threadIdx.x < 5) {
+    double s = 0.0;
+    for (int b = 0; b < nblocks; ++b) s += partial[b * 5 + threadIdx.x];
+    out[threadIdx.x] += s;
+  }
+}
+
+// Abar[r][c] = m[r] g_mu[c] + 2 g_v[c] ((Lq C)[r][c] - A[r][c]);  Lq lower triangular, Mp x Mp column-major
+template <typename T>
+__global__ void __launch_bounds__(kThreads, 2) abar_kernel(const T* __restrict__ Lqp, const T* __restrict__ C,
+                                                            const T* __restrict__ A, const T* __restrict__ mp,
+                                                            const T* __restrict__ gmu, const T* __restrict__ gv,
+                                                            T* __restrict__ Abar, int64_t Mp, int64_t ld) {
+  using G = TileGemm<T, kNB, 16, kThreads>;
+  using QRegs = typename G::QRegs;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  T* smem = reinterpret_cast<T*>(smem_raw);
+  const int I = blockIdx.y;
+  const int64_t c0 = int64_t(blockIdx.x) * kNB;
+  typename G::Acc acc;
+  acc.zero();
+  const typename G::QOff qoff = G::q_offsets(ld);
+  auto qload = [&](int t, QRegs& r) { G::load_q(r, C + int64_t(t) * 16 * ld + c0, qoff); };
+  G::loop(acc, Lqp + int64_t(I) * kNB, Mp, (I + 1) * (kNB / 16), qload, smem);
+#pragma unroll
+  for (int i = 0; i < G::MI; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int64_t row = int64_t(I) * kNB + G::acc_row(i, r);
+      const T mr = mp[row];
+#pragma unroll
+      for (int j = 0; j < G::NJ; ++j) {
+        const int64_t col = c0 + G::acc_col(j);
+        const int64_t idx = row * ld + col;
+        Abar[idx] = mr * gmu[col] + T(2) * gv[col] * (acc.v[i][j][r] - A[idx]);
+      }
+    }
+}
+
+// X := Lk' \ X in place for a k-major X ([Mp][ld]): P_I = S[I,I] X_I + sum_{J>I} S[I,J] P_J, panels in descending
+// order, S[I,I] = inv(L_II)', S[I,J] = -inv(L_II)' L[J,I]'.  One workgroup per 64-column strip.
+template <typename T>
+__global__ void __launch_bounds__(k256, 2) solve_t_kernel(const T* __restrict__ S, T* __restrict__ X, T* __restrict__ Xt,
+                                                           int64_t Mp, int64_t ld, int64_t nstrips) {
+  using G = TileGemm<T, 64, 16, k256>;
+  using QRegs = typename G::QRegs;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  T* smem = reinterpret_cast<T*>(smem_raw);
+  const int nP = int(Mp / kNB);
+  const typename G::QOff qoff = G::q_offsets(ld);
+  for (int64_t strip = blockIdx.x; strip < nstrips; strip += gridDim.x) {
+    const int64_t c0 = strip * 64;
+    for (int I = nP - 1; I >= 0; --I) {
+      typename G::Acc acc;
+      acc.zero();
+      const T* xq = X + int64_t(I) * kNB * ld + c0;
+      auto qload = [&](int t, QRegs& r) { G::load_q(r, xq + int64_t(t) * 16 * ld, qoff); };
+      G::loop(acc, S + int64_t(I) * kNB + int64_t(I) * kNB * Mp, Mp, (nP - I) * (kNB / 16), qload, smem);
+#pragma unroll
+      for (int i = 0; i < G::MI; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int j = 0; j < G::NJ; ++j) {
+            const int64_t row = int64_t(I) * kNB + G::acc_row(i, r), col = c0 + G::acc_col(j);
+            X[row * ld + col] = acc.v[i][j][r];
+            if (Xt) Xt[col * Mp + row] = acc.v[i][j][r];
+          }
+      __syncthreads();
+    }
+  }
+}
+
+// out[slice][r][c] += sum_{i in slice} w_i Xt[i][r] Yt[i][c]   (Xt, Yt point-major [n][Mp]; lower tiles only)
+template <typename T>
+__global__ void __launch_bounds__(kThreads, 2) gemm_pm_kernel(const T* __restrict__ Xt, const T* __restrict__ Yt,
+                                                               const T* __restrict__ w, T wscale, int64_t Mp, int64_t n,
+                                                               int64_t slice_len, T* __restrict__ out) {
+  using G = TileGemm<T, kNB, 16, kThreads>;
+  using QRegs = typename G::QRegs;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  T* smem = reinterpret_cast<T*>(smem_raw);
+  int ti = 0, b = blockIdx.x;
+  while (b >= ti + 1) { b -= ti + 1; ++ti; }
+  const int tj = b;
+  const int64_t i0 = int64_t(blockIdx.y) * slice_len;
+  int64_t i1 = i0 + slice_len;
+  i1 = i1 < n ? i1 : n;
+  typename G::Acc acc;
+  acc.zero();
+  if (i1 > i0) {
+    const typename G::QOff qoff = G::q_offsets(Mp);
+    const T* yq = Yt + i0 * Mp + int64_t(tj) * kNB;
+    auto qload = [&](int t, QRegs& r) {
+      G::load_q(r, yq + int64_t(t) * 16 * Mp, qoff);
+      if (w) {
+#pragma unroll
+        for (int p = 0; p < G::Q_PASSES; ++p) {
+          int kk, c;
+          G::q_coord(p, kk, c);
+          const T wk = w[i0 + int64_t(t) * 16 + kk] * wscale;
+#pragma unroll
+          for (int e = 0; e < G::VEC; ++e) r.v[p][e] *= wk;
+        }
+      }
+    };
+    G::loop(acc, Xt + i0 * Mp + int64_t(ti) * kNB, Mp, int((i1 - i0) / 16), qload, smem);
+  }
+  T* o = out + int64_t(blockIdx.y) * Mp * Mp + int64_t(ti) * kNB * Mp + int64_t(tj) * kNB;
+#pragma unroll
+  for (int i = 0; i < G::MI; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int j = 0; j < G::NJ; ++j) o[int64_t(G::acc_row(i, r)) * Mp + G::acc_col(j)] += acc.v[i][j][r];
+}
+
+// kernel value and its derivative w.r.t. r^2 (both including the variance)
+template <typename T, int FAMILY>
+__device__ __forceinline__ void kappa_and_d(T r2, T variance, T& k, T& dk) {
+  if (FAMILY == KSE) {
+    k = variance * kexp(T(-0.5) * r2);
+    dk = T(-0.5) * k;
+  } else if (FAMILY == KM32) {
+    const T s = T(1.7320508075688772935) * ksqrt(r2);
+    const T ex = variance * kexp(-s);
+    k = (T(1) + s) * ex;
+    dk = T(-1.5) * ex;
+  } else {
+    const T s = T(2.2360679774997896964) * ksqrt(r2);
+    const T ex = variance * kexp(-s);
+    k = (T(1) + s + T(5.0 / 3.0) * r2) * ex;
+    dk = T(-5.0 / 6.0) * (T(1) + s) * ex;
+  }
+}
+
+// Row-wise reductions of W = Pt o dK/dr^2 against the points of a slice:
+//   rowpart[slice][0][i] += sum_j W_ij           rowpart[slice][1][i] += sum_j At_ji g_mu_j   (m_bar)
+//   rowpart[slice][2+f][i] += sum_j W_ij xs_fj    scalpart[slice][rb][0] += sum P_ij K_ij,  [1+f] += sum W_ij u_fij^2
+// Pt is point-major [n][Mp]; each thread owns KV rows i for the whole slice (scaled z in registers).
+template <typename T, int DREG, int KV, int FAMILY>
+__global__ void __launch_bounds__(k256) kgrad_kernel(KernelParams kp, const T* __restrict__ zs, int64_t Mp,
+                                                     const T* __restrict__ x, int64_t ldx, int64_t xoff, int prescaled,
+                                                     int64_t n, int64_t nvalid, const T* __restrict__ Pt,
+                                                     const T* __restrict__ At, const T* __restrict__ gmu, int64_t slice_len,
+                                                     double* __restrict__ rowpart, double* __restrict__ scalpart) {
+  constexpr int JB = 128;
+  __shared__ T xt[JB * DREG];
+  __shared__ double red[64 * KV * (2 + DREG)];
+  __shared__ double sred[k256];
+  const int d = kp.d;
+  const T* __restrict__ invl = static_cast<const T*>(kp.invl);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t i = (int64_t(blockIdx.y) * 64 + lane) * KV;
+  const int64_t j0 = int64_t(blockIdx.x) * slice_len;
+  int64_t j1 = j0 + slice_len;
+  j1 = j1 < n ? j1 : n;
+  T z[DREG][KV];
+#pragma unroll
+  for (int f = 0; f < DREG; ++f)
+#pragma unroll
+    for (int e = 0; e < KV; ++e) z[f][e] = (f < d) ? zs[int64_t(f) * Mp + i + e] : T(0);
+  double R[KV], MB[KV], Q[DREG][KV], IL[DREG], S1 = 0.0;
+#pragma unroll
+  for (int e = 0; e < KV; ++e) R[e] = MB[e] = 0.0;
+#pragma unroll
+  for (int f = 0; f < DREG; ++f) {
+    IL[f] = 0.0;
+#pragma unroll
+    for (int e = 0; e < KV; ++e) Q[f][e] = 0.0;
+  }
+  const T variance = T(kp.variance);
+  for (int64_t jb = j0; jb < j1; jb += JB) {
+    __syncthreads();
+    for (int e = threadIdx.x; e < JB * DREG; e += k256) {
+      const int c = e / DREG, f = e % DREG;
+      int64_t g = jb + c;
+      g = g < nvalid ? g : nvalid - 1;
+      T v = T(0);
+      if (f < d) v = prescaled ? x[int64_t(f) * ldx + xoff + g] : x[int64_t(f) * ldx + xoff + g] * invl[f];
+      xt[e] = v;
+    }
+    __syncthreads();
+    for (int c = wave; c < JB && jb + c < j1; c += 4) {
+      const int64_t j = jb + c;
+      T r2[KV], u[DREG][KV];
+#pragma unroll
+      for (int e = 0; e < KV; ++e) r2[e] = T(0);
+#pragma unroll
+      for (int f = 0; f < DREG; ++f) {
+        const T xv = xt[c * DREG + f];
+#pragma unroll
+        for (int e = 0; e < KV; ++e) {
+          u[f][e] = z[f][e] - xv;
+          r2[e] = fma(u[f][e], u[f][e], r2[e]);
+        }
+      }
+      const T gm = (At && gmu) ? gmu[j] : T(0);
+#pragma unroll
+      for (int e = 0; e < KV; ++e) {
+        T k, dk;
+        kappa_and_d<T, FAMILY>(r2[e], variance, k, dk);
+        const T p = Pt[j * Mp + i + e];
+        const double W = double(p) * double(dk);
+        S1 += double(p) * double(k);
+        R[e] += W;
+        if (At) MB[e] += double(At[j * Mp + i + e]) * double(gm);
+#pragma unroll
+        for (int f = 0; f < DREG; ++f) {
+          Q[f][e] += W * double(xt[c * DREG + f]);
+          IL[f] += W * double(u[f][e]) * double(u[f][e]);
+        }
+      }
+    }
+  }
+  // combine the four waves (same rows) in a fixed order, then add into this (slice, row-block)'s partials
+  constexpr int NV = KV * (2 + DREG);
+  for (int w = 0; w < 4; ++w) {
+    __syncthreads();
+    if (wave == w) {
+      double* rr = red + lane * NV;
+#pragma unroll
+      for (int e = 0; e < KV; ++e) {
+        rr[e] = (w ? rr[e] : 0.0) + R[e];
+        rr[KV + e] = (w ? rr[KV + e] : 0.0) + MB[e];
+#pragma unroll
+        for (int f = 0; f < DREG; ++f) rr[(2 + f) * KV + e] = (w ? rr[(2 + f) * KV + e] : 0.0) + Q[f][e];
+      }
+    }
+  }
+  __syncthreads();
+  double* rp = rowpart + int64_t(blockIdx.x) * (2 + DREG) * Mp;
+  for (int t = threadIdx.x; t < 64 * NV; t += k256) {
+    const int ln = t / NV, q = (t % NV) / KV, e = t % KV;
+    rp[int64_t(q) * Mp + (int64_t(blockIdx.y) * 64 + ln) * KV + e] += red[t];
+  }
+  double* sp = scalpart + (int64_t(blockIdx.x) * gridDim.y + blockIdx.y) * (1 + DREG);
+  for (int q = 0; q <= DREG; ++q) {
+    __syncthreads();
+    sred[threadIdx.x] = (q == 0) ? S1 : IL[q - 1];
+    __syncthreads();
+    for (int w = k256 / 2; w > 0; w >>= 1) {
+      if (int(threadIdx.x) < w) sred[threadIdx.x] += sred[threadIdx.x + w];
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) sp[q] += sred[0];
+  }
+}
+
+// ---- small M x M helpers -------------------------------------------------------------------------------------
+template <typename T>
+__global__ void lower_to_rowmajor_kernel(const T* __restrict__ L, int64_t Mp, T* __restrict__ out) {
+  // out[k][r] = L[k + r*Mp] for k >= r else 0   (32x32 LDS transpose)
+  __shared__ T tile[32][33];
+  const int64_t br = int64_t(blockIdx.x) * 32, bk = int64_t(blockIdx.y) * 32;
+  for (int q = threadIdx.y; q < 32; q += blockDim.y) {
+    const int64_t k = bk + threadIdx.x, r = br + q;
+    tile[q][threadIdx.x] = (k >= r) ? L[k + r * Mp] : T(0);
+  }
+  __syncthreads();
+  for (int q = threadIdx.y; q < 32; q += blockDim.y) out[(bk + q) * Mp + br + threadIdx.x] = tile[threadIdx.x][q];
+}
+
+template <typename T>
+__global__ void transpose_kernel(const T* __restrict__ in, int64_t Mp, T* __restrict__ out) {
+  __shared__ T tile[32][33];
+  const int64_t bx = int64_t(blockIdx.x) * 32, by = int64_t(blockIdx.y) * 32;
+  for (int q = threadIdx.y; q < 32; q += blockDim.y) tile[q][threadIdx.x] = in[(by + q) * Mp + bx + threadIdx.x];
+  __syncthreads();
+  for (int q = threadIdx.y; q < 32; q += blockDim.y) out[(bx + q) * Mp + by + threadIdx.x] = tile[threadIdx.x][q];
+}
+
+template <typename T>
+__global__ void symmetrize_kernel(const T* __restrict__ St, int64_t Mp, T* __restrict__ H) {
+  const int64_t c = int64_t(blockIdx.x) * blockDim.x + threadIdx.x, r = blockIdx.y;
+  if (c < Mp) H[r * Mp + c] = T(0.5) * (St[r * Mp + c] + St[c * Mp + r]);
+}
+
+// S diagonal blocks: S[I,I] = inv(L_II)' (T holds inv(L_II))
+template <typename T>
+__global__ void sdiag_kernel(const T* __restrict__ Tm, int64_t Mp, T* __restrict__ S) {
+  const int64_t o = int64_t(blockIdx.y) * kNB * (Mp + 1);
+  for (int e = threadIdx.x; e < kNB * kNB; e += blockDim.x) {
+    const int r = e % kNB, c = e / kNB;
+    S[o + r + int64_t(c) * Mp] = Tm[o + c + int64_t(r) * Mp];
+  }
+}
+
+// Phi = tril(X) with the diagonal halved, in place on a row-major Mp x Mp matrix
+template <typename T>
+__global__ void phi_kernel(T* __restrict__ X, int64_t Mp) {
+  const int64_t c = int64_t(blockIdx.x) * blockDim.x + threadIdx.x, r = blockIdx.y;
+  if (c < Mp) {
+    const T v = X[r * Mp + c];
+    X[r * Mp + c] = c < r ? v : (c == r ? T(0.5) * v : T(0));
+  }
+}
+
+// reduce the split-K slices: Lq_bar (user layout, ld M) and Lk_bar row-major (negated, lower)
+template <typename T>
+__global__ void finish_mm_kernel(const T* __restrict__ G1, const T* __restrict__ G2, int nslices, int64_t Mp, int64_t M,
+                                 const T* __restrict__ Lq, T* __restrict__ Lq_bar, T* __restrict__ LkbarRM) {
+  const int64_t c = int64_t(blockIdx.x) * blockDim.x + threadIdx.x, r = blockIdx.y;
+  if (c >= Mp) return;
+  T g1 = T(0), g2 = T(0);
+  if (c <= r)
+    for (int s = 0; s < nslices; ++s) {
+      g1 += G1[int64_t(s) * Mp * Mp + r * Mp + c];
+      g2 += G2[int64_t(s) * Mp * Mp + r * Mp + c];
+    }
+  LkbarRM[r * Mp + c] = -g2;
+  if (r < M && c < M) {
+    T v = T(0);
+    if (c <= r) {
+      const T l = Lq[r + c * M];
+      v = g1 - (c == r ? l - T(1) / l : l);
+    }
+    Lq_bar[r + c * M] = v;
+  }
+}
+
+// final assembly of the kernel-parameter / inducing-input gradients from the slice partials
+template <typename T>
+__global__ void finish_kgrad_kernel(int d, int dreg, int64_t M, int64_t Mp, const T* __restrict__ zs,
+                                    const double* __restrict__ invl, const double* __restrict__ rp_uf, int ns_uf,
+                                    const double* __restrict__ rp_uu, int ns_uu, const double* __restrict__ sp_uf, int nsp_uf,
+                                    const double* __restrict__ sp_uu, int nsp_uu, const T* __restrict__ m, int layout_z,
+                                    double variance, T* __restrict__ z_bar, T* __restrict__ m_bar, double* __restrict__ scal_out) {
+  // scal_out[0] = sum P K (uf) + sum H K (uu), scal_out[1 + f] = il_bar_f
+  const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  const int64_t stride = int64_t(2 + dreg) * Mp;
+  if (i < M) {
+    double R1 = 0, MB = 0, R2 = 0;
+    for (int s = 0; s < ns_uf; ++s) { R1 += rp_uf[s * stride + i]; MB += rp_uf[s * stride + Mp + i]; }
+    for (int s = 0; s < ns_uu; ++s) R2 += rp_uu[s * stride + i];
+    m_bar[i] = T(MB - double(m[i]));
+    for (int f = 0; f < d; ++f) {
+      double Q1 = 0, Q2 = 0;
+      for (int s = 0; s < ns_uf; ++s) Q1 += rp_uf[s * stride + (2 + f) * Mp + i];
+      for (int s = 0; s < ns_uu; ++s) Q2 += rp_uu[s * stride + (2 + f) * Mp + i];
+      const double zf = double(zs[int64_t(f) * Mp + i]);
+      const double g = 2.0 * invl[f] * ((zf * R1 - Q1) + 2.0 * (zf * R2 - Q2));
+      if (layout_z == 1) z_bar[int64_t(f) * M + i] = T(g);   // RowVecs: M x d column-major
+      else z_bar[i * d + f] = T(g);                           // ColVecs / Vec
+    }
+  }
+  if (blockIdx.x == 0 && int(threadIdx.x) <= d) {
+    const int q = threadIdx.x;
+    double s = 0.0;
+    for (int b = 0; b < nsp_uf; ++b) s += sp_uf[int64_t(b) * (1 + dreg) + q];
+    for (int b = 0; b < nsp_uu; ++b) s += sp_uu[int64_t(b) * (1 + dreg) + q];
+    scal_out[q] = (q == 0) ? s / variance : 2.0 / invl[q - 1] * s;
+  }
+}
+
+template <typename T, int FAMILY>
+void launch_kgrad_f(hipStream_t s, const KernelParams& kp, const T* zs, int64_t Mp, const T* x, int64_t ldx, int64_t xoff,
+                    int prescaled, int64_t n, int64_t nvalid, const T* Pt, const T* At, const T* gmu, int64_t slice_len,
+                    int nslices, double* rowpart, double* scalpart) {
+  if (kp.d <= 8) {
+    dim3 grid((unsigned)nslices, (unsigned)(Mp / 128));
+    hipLaunchKernelGGL((kgrad_kernel<T, 8, 2, FAMILY>), grid, dim3(k256), 0, s, kp, zs, Mp, x, ldx, xoff, prescaled, n, nvalid, Pt,
+                       At, gmu, slice_len, rowpart, scalpart);
+  } else if (kp.d <= 16) {
+    dim3 grid((unsigned)nslices, (unsigned)(Mp / 128));
+    hipLaunchKernelGGL((kgrad_kernel<T, 16, 2, FAMILY>), grid, dim3(k256), 0, s, kp, zs, Mp, x, ldx, xoff, prescaled, n, nvalid,
+                       Pt, At, gmu, slice_len, rowpart, scalpart);
+  } else {
+    dim3 grid((unsigned)nslices, (unsigned)(Mp / 64));
+    hipLaunchKernelGGL((kgrad_kernel<T, 32, 1, FAMILY>), grid, dim3(k256), 0, s, kp, zs, Mp, x, ldx, xoff, prescaled, n, nvalid,
+                       Pt, At, gmu, slice_len, rowpart, scalpart);
+  }
+}
+
+}  // namespace
+
+// ---- launchers -----------------------------------------------------------------------------------------------
+#define GD(dtype, T, ...)               \
+  do {                                  \
+    if ((dtype) == 0) { using T = double; __VA_ARGS__; } else { using T = float; __VA_ARGS__; } \
+  } while (0)
+
+int grad_dreg(int d) { return d <= 8 ? 8 : (d <= 16 ? 16 : 32); }
+int grad_rowblocks(int d, int64_t Mp) { return int(d <= 16 ? Mp / 128 : Mp / 64); }
+
+void launch_grad_moments(int dtype, hipStream_t s, const LikParams& lp, double scale, const double* mom_mu,
+                         const double* mom_var, const void* y, int64_t off, int64_t len, int64_t npad, void* gmu, void* gv,
+                         double* partial, double* sums) {
+  const int64_t b = (npad + k256 - 1) / k256;
+  const int nb = int(b < 1024 ? b : 1024);
+  GD(dtype, T, hipLaunchKernelGGL(grad_moments_kernel<T>, dim3(nb), dim3(k256), 0, s, lp, scale, mom_mu, mom_var, (const T*)y, off,
+                                  len, npad, (T*)gmu, (T*)gv, partial));
+  hipLaunchKernelGGL(sum5_kernel, dim3(1), dim3(64), 0, s, partial, nb, sums);
+}
+
+void launch_abar(int dtype, hipStream_t s, const void* Lqp, const void* C, const void* A, const void* mp, const void* gmu,
+                 const void* gv, void* Abar, int64_t Mp, int64_t ld, int64_t ncols) {
+  dim3 grid((unsigned)(ncols / kNB), (unsigned)(Mp / kNB));
+  GD(dtype, T, {
+    using G = TileGemm<T, kNB, 16, kThreads>;
+    set_max_lds(reinterpret_cast<const void*>(abar_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, int(G::LDS_BYTES));
+    hipLaunchKernelGGL(abar_kernel<T>, grid, dim3(kThreads), G::LDS_BYTES, s, (const T*)Lqp, (const T*)C, (const T*)A,
+                       (const T*)mp, (const T*)gmu, (const T*)gv, (T*)Abar, Mp, ld);
+  });
+}
+
+void launch_sdiag(int dtype, hipStream_t s, const void* Tm, int64_t Mp, void* S) {
+  dim3 grid(1, (unsigned)(Mp / kNB));
+  GD(dtype, T, hipLaunchKernelGGL(sdiag_kernel<T>, grid, dim3(k256), 0, s, (const T*)Tm, Mp, (T*)S));
+}
+
+void launch_solve_t(int dtype, hipStream_t s, const void* S, void* X, void* Xt, int64_t Mp, int64_t ld, int64_t ncols,
+                    int num_cus) {
+  const int64_t nstrips = ncols / 64;
+  const int64_t cap = int64_t(num_cus) * 2;
+  const int grid = int(nstrips < cap ? nstrips : cap);
+  GD(dtype, T, {
+    using G = TileGemm<T, 64, 16, k256>;
+    set_max_lds(reinterpret_cast<const void*>(solve_t_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, int(G::LDS_BYTES));
+    hipLaunchKernelGGL(solve_t_kernel<T>, dim3(grid), dim3(k256), G::LDS_BYTES, s, (const T*)S, (T*)X, (T*)Xt, Mp, ld, nstrips);
+  });
+}
+
+void launch_gemm_pm(int dtype, hipStream_t s, const void* Xt, const void* Yt, const void* w, double wscale, int64_t Mp,
+                    int64_t n, int64_t slice_len, int nslices, void* out) {
+  const int nP = int(Mp / kNB);
+  dim3 grid((unsigned)(nP * (nP + 1) / 2), (unsigned)nslices);
+  GD(dtype, T, {
+    using G = TileGemm<T, kNB, 16, kThreads>;
+    set_max_lds(reinterpret_cast<const void*>(gemm_pm_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, int(G::LDS_BYTES));
+    hipLaunchKernelGGL(gemm_pm_kernel<T>, grid, dim3(kThreads), G::LDS_BYTES, s, (const T*)Xt, (const T*)Yt, (const T*)w, T(wscale),
+                       Mp, n, slice_len, (T*)out);
+  });
+}
+
+void launch_kgrad(int dtype, hipStream_t s, const KernelParams& kp, const void* zs, int64_t Mp, const void* x, int64_t ldx,
+                  int64_t xoff, int prescaled, int64_t n, int64_t nvalid, const void* Pt, const void* At, const void* gmu,
+                  int64_t slice_len, int nslices, double* rowpart, double* scalpart) {
+  GD(dtype, T, {
+    if (kp.family == KSE)
+      launch_kgrad_f<T, KSE>(s, kp, (const T*)zs, Mp, (const T*)x, ldx, xoff, prescaled, n, nvalid, (const T*)Pt, (const T*)At,
+                             (const T*)gmu, slice_len, nslices, rowpart, scalpart);
+    else if (kp.family == KM32)
+      launch_kgrad_f<T, KM32>(s, kp, (const T*)zs, Mp, (const T*)x, ldx, xoff, prescaled, n, nvalid, (const T*)Pt, (const T*)At,
+                              (const T*)gmu, slice_len, nslices, rowpart, scalpart);
+    else
+      launch_kgrad_f<T, KM52>(s, kp, (const T*)zs, Mp, (const T*)x, ldx, xoff, prescaled, n, nvalid, (const T*)Pt, (const T*)At,
+                              (const T*)gmu, slice_len, nslices, rowpart, scalpart);
+  });
+}
+
+void launch_lower_to_rowmajor(int dtype, hipStream_t s, const void* L, int64_t Mp, void* out) {
+  dim3 grid((unsigned)(Mp / 32), (unsigned)(Mp / 32)), block(32, 8);
+  GD(dtype, T, hipLaunchKernelGGL(lower_to_rowmajor_kernel<T>, grid, block, 0, s, (const T*)L, Mp, (T*)out));
+}
+
+void launch_transpose(int dtype, hipStream_t s, const void* in, int64_t Mp, void* out) {
+  dim3 grid((unsigned)(Mp / 32), (unsigned)(Mp / 32)), block(32, 8);
+  GD(dtype, T, hipLaunchKernelGGL(transpose_kernel<T>, grid, block, 0, s, (const T*)in, Mp, (T*)out));
+}
+
+void launch_symmetrize(int dtype, hipStream_t s, const void* St, int64_t Mp, void* H) {
+  dim3 grid((unsigned)((Mp + 255) / 256), (unsigned)Mp);
+  GD(dtype, T, hipLaunchKernelGGL(symmetrize_kernel<T>, grid, dim3(256), 0, s, (const T*)St, Mp, (T*)H));
+}
+
+void launch_phi(int dtype, hipStream_t s, void* X, int64_t Mp) {
+  dim3 grid((unsigned)((Mp + 255) / 256), (unsigned)Mp);
+  GD(dtype, T, hipLaunchKernelGGL(phi_kernel<T>, grid, dim3(256), 0, s, (T*)X, Mp));
+}
+
+void launch_finish_mm(int dtype, hipStream_t s, const void* G1, const void* G2, int nslices, int64_t Mp, int64_t M,
+                      const void* Lq, void* Lq_bar, void* LkbarRM) {
+  dim3 grid((unsigned)((Mp + 255) / 256), (unsigned)Mp);
+  GD(dtype, T, hipLaunchKernelGGL(finish_mm_kernel<T>, grid, dim3(256), 0, s, (const T*)G1, (const T*)G2, nslices, Mp, M,
+                                  (const T*)Lq, (T*)Lq_bar, (T*)LkbarRM));
+}
+
+void launch_finish_kgrad(int dtype, hipStream_t s, int d, int64_t M, int64_t Mp, const void* zs, const double* invl,
+                         const double* rp_uf, int ns_uf, const double* rp_uu, int ns_uu, const double* sp_uf, int nsp_uf,
+                         const double* sp_uu, int nsp_uu, const void* m, int layout_z, double variance, void* z_bar,
+                         void* m_bar, double* scal_out) {
+  dim3 grid((unsigned)((M + 255) / 256));
+  GD(dtype, T, hipLaunchKernelGGL(finish_kgrad_kernel<T>, grid, dim3(256), 0, s, d, grad_dreg(d), M, Mp, (const T*)zs, invl, rp_uf,
+                                  ns_uf, rp_uu, ns_uu, sp_uf, nsp_uf, sp_uu, nsp_uu, (const T*)m, layout_z, variance, (T*)z_bar,
+                                  (T*)m_bar, scal_out));
+}
+
+}  // namespace svgp

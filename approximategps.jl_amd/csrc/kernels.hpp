@@ -69,6 +69,8 @@ struct StripArgs {
   double* mom_var;   // [len] posterior variance, before the 1e-18 of f_post(x) (SVA:251)
   void* A_out;       // nullable: A  = Lk \ Kuf as a k-major [Mp][lda] matrix (predict-cov path)
   void* C_out;       // nullable: B'A
+  void* At_out;      // nullable: the same A, point-major [n][Mp] (column-major Julia A): gradient path
+  void* Ct_out;      // nullable: B'A point-major
   int64_t lda;
   int64_t ldx, off, len;
   int64_t Mp, M;
@@ -93,5 +95,34 @@ void launch_kuf(int dtype, hipStream_t s, const KernelParams& kp, const void* zs
 void launch_cov_assemble(int dtype, hipStream_t s, const KernelParams& kp, const void* xa, int64_t ldxa, int64_t na,
                          const void* xb, int64_t ldxb, int64_t nb, const void* Aa, const void* Ca, int64_t lda,
                          const void* Ab, const void* Cb, int64_t ldb, int64_t Mp, void* out);
+
+// ---- grad.hip (reverse-mode gradient of the NonCentered ELBO) -------------------------------------------
+constexpr double kDefaultSigma2 = 1e-18;  // AbstractGPs.default_σ² added by f_post(x) (SVA:354)
+int grad_dreg(int d);
+int grad_rowblocks(int d, int64_t Mp);
+void launch_spanels(int dtype, hipStream_t s, const void* L, const void* T, void* S, int64_t Mp);
+void launch_sdiag(int dtype, hipStream_t s, const void* Tm, int64_t Mp, void* S);
+void launch_grad_moments(int dtype, hipStream_t s, const LikParams& lp, double scale, const double* mom_mu,
+                         const double* mom_var, const void* y, int64_t off, int64_t len, int64_t npad, void* gmu, void* gv,
+                         double* partial, double* sums);
+void launch_abar(int dtype, hipStream_t s, const void* Lqp, const void* C, const void* A, const void* mp, const void* gmu,
+                 const void* gv, void* Abar, int64_t Mp, int64_t ld, int64_t ncols);
+void launch_solve_t(int dtype, hipStream_t s, const void* S, void* X, void* Xt, int64_t Mp, int64_t ld, int64_t ncols,
+                    int num_cus);
+void launch_gemm_pm(int dtype, hipStream_t s, const void* Xt, const void* Yt, const void* w, double wscale, int64_t Mp,
+                    int64_t n, int64_t slice_len, int nslices, void* out);
+void launch_kgrad(int dtype, hipStream_t s, const KernelParams& kp, const void* zs, int64_t Mp, const void* x, int64_t ldx,
+                  int64_t xoff, int prescaled, int64_t n, int64_t nvalid, const void* Pt, const void* At, const void* gmu,
+                  int64_t slice_len, int nslices, double* rowpart, double* scalpart);
+void launch_lower_to_rowmajor(int dtype, hipStream_t s, const void* L, int64_t Mp, void* out);
+void launch_transpose(int dtype, hipStream_t s, const void* in, int64_t Mp, void* out);
+void launch_symmetrize(int dtype, hipStream_t s, const void* St, int64_t Mp, void* H);
+void launch_phi(int dtype, hipStream_t s, void* X, int64_t Mp);
+void launch_finish_mm(int dtype, hipStream_t s, const void* G1, const void* G2, int nslices, int64_t Mp, int64_t M,
+                      const void* Lq, void* Lq_bar, void* LkbarRM);
+void launch_finish_kgrad(int dtype, hipStream_t s, int d, int64_t M, int64_t Mp, const void* zs, const double* invl,
+                         const double* rp_uf, int ns_uf, const double* rp_uu, int ns_uu, const double* sp_uf, int nsp_uf,
+                         const double* sp_uu, int nsp_uu, const void* m, int layout_z, double variance, void* z_bar,
+                         void* m_bar, double* scal_out);
 
 }  // namespace svgp

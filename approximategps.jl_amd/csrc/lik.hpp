@@ -1,0 +1,78 @@
+// lik.hpp — likelihood device functions shared by expect_kernel (strip.hip) and the gradient path (grad.hip):
+// log p(y|f), its expectation under N(mu, v) and the derivatives of that expectation  [GPLikelihoods].
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "kernels.hpp"
+
+namespace svgp {
+
+
+__device__ __forceinline__ double softplus_d(double s) { return fmax(s, 0.0) + log1p(exp(-fabs(s))); }
+
+// log p(y | f)  [GPLikelihoods]
+__device__ __forceinline__ double loglik_point(int lik, double f, double y, double sigma2, double log_sigma2) {
+  if (lik == 0) {
+    const double r = y - f;
+    return -0.5 * (1.8378770664093453 + log_sigma2 + r * r / sigma2);
+  }
+  if (lik == 1) return -softplus_d(y > 0.5 ? -f : f);
+  return y * f - exp(f) - lgamma(y + 1.0);
+}
+
+// E_{N(mu, v)}[log p(y|f)]: closed form (gh_n == 0) or Gauss-Hermite  [GPLikelihoods.expected_loglikelihood]
+__device__ __forceinline__ double expected_loglik_point(const LikParams& lp, double mu, double v, double y,
+                                                        double log_sigma2) {
+  if (lp.gh_n == 0) {
+    if (lp.lik == 0) {
+      const double r = y - mu;
+      return -0.5 * (1.8378770664093453 + log_sigma2 + (r * r + v) / lp.sigma2);
+    }
+    return y * mu - exp(mu + 0.5 * v) - lgamma(y + 1.0);  // Poisson, exp link
+  }
+  const double s = 1.4142135623730951 * sqrt(v);
+  double acc = 0.0;
+  for (int q = 0; q < lp.gh_n; ++q) acc += lp.gh_w[q] * loglik_point(lp.lik, s * lp.gh_x[q] + mu, y, lp.sigma2, log_sigma2);
+  return acc;  // weights are pre-divided by sqrt(pi)
+}
+
+
+// d log p(y|f) / df
+__device__ __forceinline__ double dloglik_point(int lik, double f, double y, double sigma2) {
+  if (lik == 0) return (y - f) / sigma2;
+  if (lik == 1) return y - 1.0 / (1.0 + exp(-f));
+  return y - exp(f);
+}
+
+// (dE/dmu, dE/dv, dE/dsigma2) of expected_loglik_point: closed forms, or Gauss-Hermite with
+// dE/dmu = sum w g'(f_q), dE/dv = sum w g'(f_q) x_q / sqrt(2 v)
+__device__ __forceinline__ void expected_loglik_grad_point(const LikParams& lp, double mu, double v, double y, double& gmu,
+                                                           double& gv, double& gs2) {
+  gs2 = 0.0;
+  if (lp.gh_n == 0) {
+    if (lp.lik == 0) {
+      const double r = y - mu;
+      gmu = r / lp.sigma2;
+      gv = -0.5 / lp.sigma2;
+      gs2 = -0.5 * (1.0 / lp.sigma2 - (r * r + v) / (lp.sigma2 * lp.sigma2));
+    } else {
+      const double e = exp(mu + 0.5 * v);
+      gmu = y - e;
+      gv = -0.5 * e;
+    }
+    return;
+  }
+  const double s = 1.4142135623730951 * sqrt(v);
+  const double inv_s = s > 0.0 ? 1.0 / s : 0.0;
+  gmu = 0.0;
+  gv = 0.0;
+  for (int q = 0; q < lp.gh_n; ++q) {
+    const double f = s * lp.gh_x[q] + mu;
+    const double dl = dloglik_point(lp.lik, f, y, lp.sigma2);
+    gmu += lp.gh_w[q] * dl;
+    gv += lp.gh_w[q] * dl * lp.gh_x[q] * inv_s;
+    if (lp.lik == 0) gs2 += lp.gh_w[q] * (-0.5 / lp.sigma2 + 0.5 * (y - f) * (y - f) / (lp.sigma2 * lp.sigma2));
+  }
+}
+
+}  // namespace svgp

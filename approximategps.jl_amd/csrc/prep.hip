@@ -205,7 +205,7 @@ __global__ void __launch_bounds__(k256) potf2_kernel(T* __restrict__ A, T* __res
 // ------------------------------------------------------------------------------------------------
 // 128x128 MFMA tile kernels used by the blocked Cholesky and the T panels.
 // ------------------------------------------------------------------------------------------------
-enum : int { MODE_TRSM = 0, MODE_SYRK = 1, MODE_TPANEL = 2 };
+enum : int { MODE_TRSM = 0, MODE_SYRK = 1, MODE_TPANEL = 2, MODE_SPANEL = 3 };
 
 __device__ __forceinline__ void tri_index(int b, int& i, int& j) {  // b -> (i >= j) in row-major triangle order
   i = 0;
@@ -217,7 +217,8 @@ __device__ __forceinline__ void tri_index(int b, int& i, int& j) {  // b -> (i >
 }
 
 template <typename T, int MODE>
-__global__ void __launch_bounds__(kThreads, 2) tile128_kernel(T* __restrict__ A, T* __restrict__ Tm, int64_t ld, int p) {
+__global__ void __launch_bounds__(kThreads, 2) tile128_kernel(T* __restrict__ A, T* __restrict__ Tm, int64_t ld, int p,
+                                                               T* __restrict__ Sout = nullptr) {
   using G = TileGemm<T, kNB, 16>;
   using QRegs = typename G::QRegs;
   constexpr int NB = kNB;
@@ -257,6 +258,23 @@ __global__ void __launch_bounds__(kThreads, 2) tile128_kernel(T* __restrict__ A,
       for (int r = 0; r < 4; ++r)
 #pragma unroll
         for (int b = 0; b < G::NJ; ++b) C[G::acc_col(b) + int64_t(G::acc_row(a, r)) * ld] -= acc.v[a][b][r];
+  } else if (MODE == MODE_SPANEL) {
+    // gradient path: S[I, J] = -inv(L_II)' L[J, I]' for J > I, computed as its transpose -L[J, I] inv(L_II);
+    // here `A` is L and `Tm` holds inv(L_II) in its diagonal blocks and receives S in `Sout` (= A2)
+    int ti, tj;
+    tri_index(blockIdx.x, ti, tj);
+    const int J = ti + 1, I = tj;
+    const T* P = A + int64_t(J) * NB + int64_t(I) * NB * ld;
+    const T* Q = Tm + int64_t(I) * NB + int64_t(I) * NB * ld;  // element (k, c) at Q[k + c*ld]
+    auto qload = [&](int t, QRegs& r) { G::load_q_trans(r, Q + int64_t(t) * 16, ld); };
+    G::loop(acc, P, ld, NB / 16, qload, smem);
+    T* C = Sout + int64_t(I) * NB + int64_t(J) * NB * ld;
+#pragma unroll
+    for (int a = 0; a < G::MI; ++a)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int b = 0; b < G::NJ; ++b) C[G::acc_col(b) + int64_t(G::acc_row(a, r)) * ld] = -acc.v[a][b][r];
   } else {
     // T[I, J] = -inv(L_II) L[I, J],  J < I
     int ti, tj;
@@ -576,6 +594,21 @@ void launch_kuu(int dtype, hipStream_t s, const KernelParams& kp, const void* zs
 
 void launch_potrf(int dtype, hipStream_t s, void* A, void* T, int64_t Mp, int* info) {
   SVGP_DISPATCH(dtype, potrf_t<double>(s, (double*)A, (double*)T, Mp, info), potrf_t<float>(s, (float*)A, (float*)T, Mp, info));
+}
+
+template <typename T>
+void spanels_t(hipStream_t s, const T* L, const T* Tm, T* S, int64_t Mp) {
+  using G = TileGemm<T, kNB, 16>;
+  const int nP = int(Mp / kNB);
+  set_max_lds(reinterpret_cast<const void*>(tile128_kernel<T, MODE_SPANEL>), hipFuncAttributeMaxDynamicSharedMemorySize, int(G::LDS_BYTES));
+  if (nP > 1)
+    hipLaunchKernelGGL((tile128_kernel<T, MODE_SPANEL>), dim3(nP * (nP - 1) / 2), dim3(kThreads), G::LDS_BYTES, s,
+                       const_cast<T*>(L), const_cast<T*>(Tm), Mp, 0, S);
+}
+
+void launch_spanels(int dtype, hipStream_t s, const void* L, const void* T, void* S, int64_t Mp) {
+  SVGP_DISPATCH(dtype, spanels_t<double>(s, (const double*)L, (const double*)T, (double*)S, Mp),
+                spanels_t<float>(s, (const float*)L, (const float*)T, (float*)S, Mp));
 }
 
 void launch_tpanels(int dtype, hipStream_t s, const void* L, void* T, int64_t Mp) {

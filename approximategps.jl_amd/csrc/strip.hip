@@ -14,42 +14,13 @@
 // Roofline: MFMA-bound (2 Mp² flops per point); algorithmic HBM bytes are only x, y.
 #include "device_common.hpp"
 #include "kernels.hpp"
+#include "lik.hpp"
 
 #include <cstdlib>
 
 namespace svgp {
 
 namespace {
-
-constexpr double kDefaultSigma2 = 1e-18;  // AbstractGPs.default_σ² added by f_post(x) (SVA:354)
-
-__device__ __forceinline__ double softplus_d(double s) { return fmax(s, 0.0) + log1p(exp(-fabs(s))); }
-
-// log p(y | f)  [GPLikelihoods]
-__device__ __forceinline__ double loglik_point(int lik, double f, double y, double sigma2, double log_sigma2) {
-  if (lik == 0) {
-    const double r = y - f;
-    return -0.5 * (1.8378770664093453 + log_sigma2 + r * r / sigma2);
-  }
-  if (lik == 1) return -softplus_d(y > 0.5 ? -f : f);
-  return y * f - exp(f) - lgamma(y + 1.0);
-}
-
-// E_{N(mu, v)}[log p(y|f)]: closed form (gh_n == 0) or Gauss-Hermite  [GPLikelihoods.expected_loglikelihood]
-__device__ __forceinline__ double expected_loglik_point(const LikParams& lp, double mu, double v, double y,
-                                                        double log_sigma2) {
-  if (lp.gh_n == 0) {
-    if (lp.lik == 0) {
-      const double r = y - mu;
-      return -0.5 * (1.8378770664093453 + log_sigma2 + (r * r + v) / lp.sigma2);
-    }
-    return y * mu - exp(mu + 0.5 * v) - lgamma(y + 1.0);  // Poisson, exp link
-  }
-  const double s = 1.4142135623730951 * sqrt(v);
-  double acc = 0.0;
-  for (int q = 0; q < lp.gh_n; ++q) acc += lp.gh_w[q] * loglik_point(lp.lik, s * lp.gh_x[q] + mu, y, lp.sigma2, log_sigma2);
-  return acc;  // weights are pre-divided by sqrt(pi)
-}
 
 template <typename T, int NT, int BK, int NTHR>
 __global__ void __launch_bounds__(NTHR, 2) strip_kernel(StripArgs a, int64_t nstrips) {
@@ -143,6 +114,7 @@ __global__ void __launch_bounds__(NTHR, 2) strip_kernel(StripArgs a, int64_t nst
             work[int64_t(row) * NT + col] = val;
 #endif
             if (a.A_out) static_cast<T*>(a.A_out)[int64_t(row) * a.lda + c0 + col] = val;
+            if (a.At_out) static_cast<T*>(a.At_out)[(c0 + col) * Mp + row] = val;
 #if !(defined(SVGP_ABLATE) && (SVGP_ABLATE & 16))
             const double dv = double(val);
             sA[j] = fma(dv, dv, sA[j]);
@@ -171,6 +143,7 @@ __global__ void __launch_bounds__(NTHR, 2) strip_kernel(StripArgs a, int64_t nst
           for (int j = 0; j < NJ; ++j) {
             const T val = acc.v[i][j][r];
             if (a.C_out) static_cast<T*>(a.C_out)[int64_t(J * NB + G::acc_row(i, r)) * a.lda + c0 + G::acc_col(j)] = val;
+            if (a.Ct_out) static_cast<T*>(a.Ct_out)[(c0 + G::acc_col(j)) * Mp + J * NB + G::acc_row(i, r)] = val;
             const double dv = double(val);
             sC[j] = fma(dv, dv, sC[j]);
           }

@@ -149,6 +149,22 @@ int32_t svgp_elbo_host(svgp_ctx* ctx, const svgp_model_desc* desc, int32_t layou
                        const void* x_host, const void* y_host, double num_data, double* elbo_out,
                        svgp_terms* terms_out);
 
+/* ---- gradient of the ELBO (what Zygote produces for the reference's training loops:
+ * examples/a-regression/script.jl:188-194, test/SparseVariationalApproximationModule.jl:170-175).  NonCentered only
+ * (SVGP_UNSUPPORTED otherwise).  Every output array is caller-allocated host memory; z, m, Lq gradients have the
+ * dtype / layout of the corresponding svgp_model_desc arrays (Lq: lower triangle, upper zeroed); NULL skips one. */
+typedef struct svgp_grads {
+  double variance;          /* d elbo / d kernel variance */
+  double lik_sigma2;        /* d elbo / d GaussianLikelihood sigma^2 (0 for other likelihoods) */
+  double mean_const;        /* d elbo / d ConstMean value */
+  double* inv_lengthscale;  /* d entries */
+  void* z;
+  void* m;
+  void* Lq;
+} svgp_grads;
+int32_t svgp_elbo_grad(svgp_ctx* ctx, svgp_model* model, const svgp_data* data, int64_t batch_off, int64_t batch_len,
+                       double num_data, double* elbo_out, svgp_terms* terms_out, svgp_grads* grads_out);
+
 /* ---- posterior(sva)  replaces SVA:115-136 (Centered) / SVA:160-187 (NonCentered) -------------
  * fills ApproxPosteriorGP.data = (Kuu = Cholesky(Lk), B, α): Lk_out M×M lower (upper zeroed),
  * alpha_out M, B_out M×M (NULL to skip; NonCentered B is the caller's Lq). */

@@ -1,0 +1,90 @@
+"""GPU parity of svgp_elbo_grad against the oracle's analytic gradient (itself pinned by finite differences in
+tests/test_oracle_grad.py).  Tolerances: fp64 relative 1e-6 of the gradient's max-norm per block, fp32 2e-3."""
+import numpy as np
+import pytest
+
+import svgp_oracle as o
+from approxgp import _ffi
+from helpers import device_model, rel
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = _ffi.Context(0)
+    yield c
+    c.close()
+
+
+def _close(a, b, tol):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    scale = max(np.abs(b).max(), 1e-12)
+    assert np.abs(a - b).max() <= tol * scale, (np.abs(a - b).max(), scale)
+
+
+CASES = [
+    (300, 20, 1, o.KERNEL_SE, o.LIK_GAUSSIAN, 0),
+    (777, 200, 3, o.KERNEL_MATERN32, o.LIK_GAUSSIAN, 0),
+    (1500, 256, 8, o.KERNEL_SE, o.LIK_GAUSSIAN, 0),
+    (900, 300, 16, o.KERNEL_MATERN52, o.LIK_BERNOULLI_LOGISTIC, 0),
+    (640, 129, 2, o.KERNEL_SE, o.LIK_POISSON_EXP, 0),
+    (513, 64, 5, o.KERNEL_MATERN52, o.LIK_GAUSSIAN, 9),
+]
+
+
+@pytest.mark.parametrize("N,M,d,family,lik,qn", CASES)
+@pytest.mark.parametrize("dtype,tol", [(np.float64, 1e-6), (np.float32, 2e-3)])
+def test_gradient_matches_oracle(ctx, N, M, d, family, lik, qn, dtype, tol):
+    x, y, sva, s2 = o.synth_problem(300 + N, N, M, d, family=family, lik=lik, dtype=dtype)
+    sva.mean_const = 0.1
+    val_ref, g_ref = o.elbo_grad(sva, x, y, lik=lik, sigma2=s2, num_data=2.5 * N, quadrature_n=qn)
+    model = device_model(ctx, sva, dtype=dtype, lik=lik, sigma2=s2, quadrature_n=qn)
+    data = _ffi.DeviceData(ctx, x, y, dtype)
+    val, terms, g = model.elbo_grad(data, 0, N, 2.5 * N)
+    assert rel(val, val_ref) < (1e-8 if dtype == np.float64 else 1e-4)
+    _close(g["m"], g_ref["m"], tol)
+    _close(g["Lq"], g_ref["Lq"], tol)
+    _close(g["z"].reshape(g_ref["z"].shape, order="F") if d > 1 else g["z"], g_ref["z"] if d > 1 else g_ref["z"][0], tol)
+    _close(g["inv_lengthscale"], g_ref["inv_lengthscale"], tol)
+    _close([g["variance"]], [g_ref["variance"]], tol)
+    _close([g["mean_const"]], [g_ref["mean_const"]], tol)
+    if lik == o.LIK_GAUSSIAN:
+        _close([g["lik_sigma2"]], [g_ref["lik_sigma2"]], tol)
+    # same value as the forward-only entry point
+    assert rel(val, model.elbo(data, 0, N, 2.5 * N)[0]) < 1e-12
+    model.free()
+    data.free()
+
+
+def test_gradient_chunked_and_minibatch(ctx):
+    """A batch larger than one workspace chunk (M = 512 -> chunks of 65536 columns) and a minibatch window."""
+    N, M, d = 70_000, 512, 4
+    x, y, sva, s2 = o.synth_problem(44, N, M, d)
+    model = device_model(ctx, sva, sigma2=s2)
+    data = _ffi.DeviceData(ctx, x, y, np.float64)
+    val, _, g = model.elbo_grad(data, 0, N, float(N))
+    val_ref, g_ref = o.elbo_grad(sva, x, y, sigma2=s2)
+    assert rel(val, val_ref) < 1e-8
+    for k in ("m", "Lq", "inv_lengthscale"):
+        _close(g[k], g_ref[k], 1e-6)
+    _close(g["z"], g_ref["z"], 1e-6)
+    off, nb = 12_345, 3000
+    val, _, g = model.elbo_grad(data, off, nb, float(N))
+    val_ref, g_ref = o.elbo_grad(sva, x[:, off:off + nb], y[off:off + nb], sigma2=s2, num_data=N)
+    assert rel(val, val_ref) < 1e-8
+    _close(g["z"], g_ref["z"], 1e-6)
+    _close(g["Lq"], g_ref["Lq"], 1e-6)
+    model.free()
+    data.free()
+
+
+def test_gradient_unsupported_for_centered(ctx):
+    x, y, sva, s2 = o.synth_problem(45, 100, 10, 2)
+    c = o.SVA(sva.kernel, sva.z, sva.m, sva.Lq, jitter=sva.jitter, centered=True)
+    model = device_model(ctx, c, sigma2=s2)
+    data = _ffi.DeviceData(ctx, x, y, np.float64)
+    with pytest.raises(_ffi.UnsupportedError):
+        model.elbo_grad(data)
+    model.free()
+    data.free()
