@@ -874,14 +874,16 @@ int grad_workspace(svgp_ctx* ctx, svgp_model* m, int64_t len, GradWs** out) {
   if (!w) return SVGP_OOM;
   w->dtype = m->dtype; w->Mp = Mp; w->d = m->d; w->nc = nc;
   const int nP = int(Mp / 128), ntiles = nP * (nP + 1) / 2;
-  int ns = (2 * ctx->num_cus + ntiles - 1) / ntiles;
+  int ns = (2 * ctx->num_cus) / ntiles;   // tiles x slices just under two workgroups' worth per CU: no ragged tail
   w->nslices = ns < 1 ? 1 : (ns > 16 ? 16 : ns);
   w->rb = grad_rowblocks(m->d, Mp);
   int nu = (2 * ctx->num_cus + w->rb - 1) / w->rb;
   w->ns_uf = nu < 1 ? 1 : (nu > 128 ? 128 : nu);
   w->ns_uu = 8;
   const int dreg = grad_dreg(m->d);
-  const size_t mn = size_t(Mp) * size_t(nc) * es, mm = size_t(Mp) * size_t(Mp) * es;
+  // k-major chunk buffers use a leading dimension of nc + 64: a power-of-two row stride (512 KB at nc = 65536) aliases
+  // every row of a store instruction onto the same memory channels
+  const size_t mn = size_t(Mp) * size_t(nc + 64) * es, mm = size_t(Mp) * size_t(Mp) * es;
   w->g_b = size_t(w->nslices) * mm;
   w->rp_uf_b = size_t(w->ns_uf) * (2 + dreg) * Mp * 8; w->sp_uf_b = size_t(w->ns_uf) * w->rb * (1 + dreg) * 8;
   w->rp_uu_b = size_t(w->ns_uu) * (2 + dreg) * Mp * 8; w->sp_uu_b = size_t(w->ns_uu) * w->rb * (1 + dreg) * 8;
@@ -924,7 +926,7 @@ extern "C" int32_t svgp_elbo_grad(svgp_ctx* ctx, svgp_model* m, const svgp_data*
   rc = grad_workspace(ctx, m, len, &w);
   if (rc) return rc;
   const int dt = m->dtype;
-  const int64_t Mp = m->Mp, M = m->M, nc = w->nc;
+  const int64_t Mp = m->Mp, M = m->M, nc = w->nc, ldk = nc + 64;
   const size_t es = m->es, mm = size_t(Mp) * Mp * es;
   const int dreg = grad_dreg(m->d);
   const double scale = (num_data > 0 ? num_data : double(len)) / double(len);
@@ -959,15 +961,18 @@ extern "C" int32_t svgp_elbo_grad(svgp_ctx* ctx, svgp_model* m, const svgp_data*
     const int64_t clen = (len - c0 < nc) ? len - c0 : nc;
     const int64_t ncp = (clen + 127) / 128 * 128;
     StripOuts o;
-    o.A = w->A; o.C = w->C; o.At = w->At; o.Ct = w->Ct; o.lda = nc; o.skip_expect = true;
+    o.A = w->A; o.C = w->C; o.lda = ldk; o.skip_expect = true;   // k-major [Mp][nc]; point-major copies by transposition
     rc = enqueue_strips(ctx, m, data->x, data->ldx, nullptr, off + c0, clen, o);
     if (rc) return rc;
+    launch_to_point_major(dt, s, w->A, ldk, Mp, ncp, w->At);
+    launch_to_point_major(dt, s, w->C, ldk, Mp, ncp, w->Ct);
     launch_grad_moments(dt, s, lp, scale, ctx->mom, ctx->mom + ctx->mom_cap, data->y, off + c0, clen, ncp, w->gmu, w->gv,
                         w->partial5, w->sums);
     KCHECK(ctx, "grad_moments");
-    launch_abar(dt, s, w->Lqp, w->C, w->A, m->mp, w->gmu, w->gv, w->Ab, Mp, nc, ncp);
+    launch_abar(dt, s, w->Lqp, w->C, w->A, m->mp, w->gmu, w->gv, w->Ab, Mp, ldk, ncp);
     KCHECK(ctx, "abar");
-    launch_solve_t(dt, s, w->S, w->Ab, w->Pt, Mp, nc, ncp, ctx->num_cus);
+    launch_solve_t(dt, s, w->S, w->Ab, nullptr, Mp, ldk, ncp, ctx->num_cus);
+    launch_to_point_major(dt, s, w->Ab, ldk, Mp, ncp, w->Pt);
     KCHECK(ctx, "solve_t");
     int64_t sl = ((ncp + w->nslices - 1) / w->nslices + 127) / 128 * 128;
     launch_gemm_pm(dt, s, w->At, w->Ct, w->gv, 2.0, Mp, ncp, sl, w->nslices, w->G1);

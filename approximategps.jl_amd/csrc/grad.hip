@@ -333,6 +333,17 @@ __global__ void transpose_kernel(const T* __restrict__ in, int64_t Mp, T* __rest
   for (int q = threadIdx.y; q < 32; q += blockDim.y) out[(bx + q) * Mp + by + threadIdx.x] = tile[threadIdx.x][q];
 }
 
+// out[c][r] = in[r][c]: k-major [Mp][ld] -> point-major [ncols][Mp] (64x64 tiles through LDS, both sides coalesced)
+template <typename T>
+__global__ void __launch_bounds__(k256) to_point_major_kernel(const T* __restrict__ in, int64_t ld, int64_t Mp, T* __restrict__ out) {
+  __shared__ T tile[64][65];
+  const int64_t c0 = int64_t(blockIdx.x) * 64, r0 = int64_t(blockIdx.y) * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  for (int q = ty; q < 64; q += 4) tile[q][tx] = in[(r0 + q) * ld + c0 + tx];
+  __syncthreads();
+  for (int q = ty; q < 64; q += 4) out[(c0 + q) * Mp + r0 + tx] = tile[tx][q];
+}
+
 template <typename T>
 __global__ void symmetrize_kernel(const T* __restrict__ St, int64_t Mp, T* __restrict__ H) {
   const int64_t c = int64_t(blockIdx.x) * blockDim.x + threadIdx.x, r = blockIdx.y;
@@ -520,6 +531,11 @@ void launch_lower_to_rowmajor(int dtype, hipStream_t s, const void* L, int64_t M
 void launch_transpose(int dtype, hipStream_t s, const void* in, int64_t Mp, void* out) {
   dim3 grid((unsigned)(Mp / 32), (unsigned)(Mp / 32)), block(32, 8);
   GD(dtype, T, hipLaunchKernelGGL(transpose_kernel<T>, grid, block, 0, s, (const T*)in, Mp, (T*)out));
+}
+
+void launch_to_point_major(int dtype, hipStream_t s, const void* in, int64_t ld, int64_t Mp, int64_t ncols, void* out) {
+  dim3 grid((unsigned)(ncols / 64), (unsigned)(Mp / 64));
+  GD(dtype, T, hipLaunchKernelGGL(to_point_major_kernel<T>, grid, dim3(k256), 0, s, (const T*)in, ld, Mp, (T*)out));
 }
 
 void launch_symmetrize(int dtype, hipStream_t s, const void* St, int64_t Mp, void* H) {

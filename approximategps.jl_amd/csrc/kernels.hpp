@@ -116,6 +116,7 @@ void launch_kgrad(int dtype, hipStream_t s, const KernelParams& kp, const void* 
                   int64_t slice_len, int nslices, double* rowpart, double* scalpart);
 void launch_lower_to_rowmajor(int dtype, hipStream_t s, const void* L, int64_t Mp, void* out);
 void launch_transpose(int dtype, hipStream_t s, const void* in, int64_t Mp, void* out);
+void launch_to_point_major(int dtype, hipStream_t s, const void* in, int64_t ld, int64_t Mp, int64_t ncols, void* out);
 void launch_symmetrize(int dtype, hipStream_t s, const void* St, int64_t Mp, void* H);
 void launch_phi(int dtype, hipStream_t s, void* X, int64_t Mp);
 void launch_finish_mm(int dtype, hipStream_t s, const void* G1, const void* G2, int nslices, int64_t Mp, int64_t M,

@@ -33,6 +33,8 @@ CONFIGS = {
     # name: (n_per_gpu, M, d, family, lik, dtype)
     "H": (1_000_000, 1024, 8, SE, GAUSS, "f64"),      # headline metric
     "H32": (1_000_000, 1024, 8, SE, GAUSS, "f32"),
+    "H896": (1_000_000, 896, 8, SE, GAUSS, "f64"),     # leading-dimension experiments (Mp*8 not a power of two)
+    "H1152": (1_000_000, 1152, 8, SE, GAUSS, "f64"),
     "C2": (100_000, 512, 8, SE, GAUSS, "f64"),
     "C3": (1_000_000, 2048, 16, M52, BERN, "f32"),
     "C4": (100_000, 8192, 8, SE, GAUSS, "f32"),
@@ -104,6 +106,7 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=20000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kuf", action="store_true")
+    ap.add_argument("--no-grad", action="store_true")
     args = ap.parse_args()
 
     import torch
@@ -222,6 +225,16 @@ def main():
         out["kuf_roofline"] = {"kernel": "kuf_kernel", "bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS,
                                "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS, "traffic": kuf_traffic,
                                "bytes_per_launch": bytes_alg, "ms_per_launch": t_kuf}
+    if rank == 0 and world == 1 and not args.no_grad:
+        # value-and-gradient evaluation (svgp_elbo_grad: what a training step costs), same workload, same residency
+        model.elbo_grad(data, 0, n, num_data)
+        tg = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            model.elbo_grad(data, 0, n, num_data)
+            tg.append(time.perf_counter() - t0)
+        out["value_and_gradient"] = {"evals_per_s": 1.0 / min(tg), "ms_per_eval": 1e3 * min(tg),
+                                     "ratio_to_forward": 1e3 * min(tg) / ms_per_step}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(p, family, lik, min(args.cpu_sample, n), n)
         out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
