@@ -88,3 +88,56 @@ def test_gradient_unsupported_for_centered(ctx):
         model.elbo_grad(data)
     model.free()
     data.free()
+
+
+def test_optimised_posterior_matches_exact_gpr(ctx):
+    """The reference's only end-to-end test (test/SparseVariationalApproximationModule.jl:136-186): N = M = 20,
+    z = x, NonCentered, jitter 1e-5; optimise (m, A) on -elbo and compare the posterior with exact GP regression
+    (atol 1e-4).  The reference runs 20 000 Adam steps through Zygote; here L-BFGS drives svgp_elbo_grad."""
+    from scipy.optimize import minimize
+
+    rng = np.random.default_rng(654321)
+    N = 20
+    x = rng.random(N) * 10
+    y = np.sin(x) + 0.9 * np.cos(x * 1.6) + 0.4 * rng.random(N)
+    kernel = o.make_kernel([0.2, 0.6])
+    s2, jitter = 0.1, 1e-5
+    tril = np.tril_indices(N)
+    data = _ffi.DeviceData(ctx, x, y, np.float64)
+    sva0 = o.SVA(kernel, x.copy(), np.zeros(N), np.eye(N), jitter=jitter)
+    model = device_model(ctx, sva0, sigma2=s2)
+
+    def unpack(theta):
+        m = theta[:N]
+        L = np.zeros((N, N))
+        L[tril] = theta[N:]
+        return m, L
+
+    def fun(theta):
+        m, L = unpack(theta)
+        d = np.diag(L).copy()
+        L[np.diag_indices(N)] = np.exp(d)          # positive diagonal through an exp reparametrisation
+        sva = o.SVA(kernel, x.copy(), m, L, jitter=jitter)
+        from helpers import desc_from_oracle
+        desc, keep = desc_from_oracle(sva, sigma2=s2)
+        model.update(desc, keep)
+        val, _, g = model.elbo_grad(data, 0, N, float(N))
+        gL = np.asarray(g["Lq"]).copy()
+        gL[np.diag_indices(N)] *= np.exp(d)
+        return -val, -np.concatenate([g["m"], gL[tril]])
+
+    theta0 = np.concatenate([np.zeros(N), np.zeros(len(tril[0]))])
+    res = minimize(fun, theta0, jac=True, method="L-BFGS-B", options=dict(maxiter=3000, maxfun=6000, ftol=1e-15, gtol=1e-9))
+    m, L = unpack(res.x)
+    L[np.diag_indices(N)] = np.exp(np.diag(L))
+    sva = o.SVA(kernel, x.copy(), m, L, jitter=jitter)
+    from helpers import desc_from_oracle
+    desc, keep = desc_from_oracle(sva, sigma2=s2)
+    model.update(desc, keep)
+    mean, var, cov = model.predict(x, True, True, True)
+    mu_ref, cov_ref = o.exact_gp_posterior(kernel, x, s2, y, x)
+    np.testing.assert_allclose(mean, mu_ref, atol=1e-4)   # ref :184
+    np.testing.assert_allclose(cov, cov_ref, atol=1e-4)   # ref :185
+    assert -res.fun <= o.exact_gp_logpdf(kernel, x, s2, y) + 1e-6
+    model.free()
+    data.free()
