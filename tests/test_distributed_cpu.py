@@ -52,6 +52,40 @@ def _worker(rank, world, port, out):
     dist.destroy_process_group()
 
 
+def _grad_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for p in (os.path.join(root, "approximategps.jl_amd"), os.path.join(root, "oracle")):
+        sys.path.insert(0, p)
+    import torch.distributed as dist
+
+    import svgp_oracle as o
+    from approxgp.distributed import allreduce_value_and_gradient, shard_range
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    N = 203
+    x, y, sva, s2 = o.synth_problem(22, N, 9, 2, family=o.KERNEL_MATERN52)
+    lo, hi = shard_range(N, rank, world)
+    # what svgp_elbo_grad returns on this rank's shard with num_data * len_r / n_global
+    val, g = o.elbo_grad(sva, x[:, lo:hi], y[lo:hi], sigma2=s2, num_data=5e3 * (hi - lo) / N)
+    tot, gt = allreduce_value_and_gradient(val, g, sva.m, sva.Lq, o.prior_kl(sva))
+    if rank == 0:
+        ref, gr = o.elbo_grad(sva, x, y, sigma2=s2, num_data=5e3)
+        errs = [abs(tot - ref) / abs(ref)] + [float(np.abs(np.asarray(gt[k]) - np.asarray(gr[k])).max() / max(np.abs(np.asarray(gr[k])).max(), 1e-12))
+                                               for k in ("variance", "lik_sigma2", "mean_const", "inv_lengthscale", "z", "m", "Lq")]
+        np.save(out, np.array(errs))
+    dist.destroy_process_group()
+
+
+def test_two_rank_gloo_gradient_equals_single_process(tmp_path):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = str(tmp_path / "gres.npy")
+    mp.spawn(_grad_worker, args=(2, port, out), nprocs=2, join=True)
+    assert np.load(out).max() < 1e-10
+
+
 def test_two_rank_gloo_elbo_equals_single_process(tmp_path):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
