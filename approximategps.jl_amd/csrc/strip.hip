@@ -334,9 +334,13 @@ static int env_int(const char* name, int dflt) {
   return e ? atoi(e) : dflt;
 }
 
-int strip_nt(int /*dtype*/, int64_t /*Mp*/, int64_t /*len*/) {
-  static const int nt = env_int("SVGP_STRIP_NT", 64) == 128 ? 128 : 64;
-  return nt;
+int strip_nt(int dtype, int64_t Mp, int64_t /*len*/) {
+  // f64: 64-point strips; f32: 128-point strips (a wave then owns 64 x 64 = 16 MFMA tiles, the same 64 accumulator
+  // VGPRs as the f64 wave, and twice the MFMA work per barrier and per byte of T/U).  SVGP_STRIP_NT overrides.
+  static const int forced = env_int("SVGP_STRIP_NT", 0);
+  if (forced == 64 || forced == 128) return forced;
+  // measured (same box): H32 22.4 -> 20.5 ms, C3 84.1 -> 77.8 ms, C5 5.9 -> 5.4 ms; C4 (Mp = 8192) 131.7 -> 136.0 ms
+  return dtype == 0 ? 64 : env_int("SVGP_F32_NT", Mp <= 2048 ? 128 : 64);
 }
 
 size_t strip_work_bytes(int dtype, int64_t Mp, int nt, int grid) {
@@ -345,8 +349,7 @@ size_t strip_work_bytes(int dtype, int64_t Mp, int nt, int grid) {
 
 int strip_grid(int dtype, int nt, int64_t nstrips, int num_cus) {
   // two workgroups per CU (measured: a third f32 workgroup fits but is 7 % slower; SVGP_WG_PER_CU overrides)
-  (void)dtype;
-  const int per_cu = env_int("SVGP_WG_PER_CU", nt == 64 ? 2 : 1);
+  const int per_cu = env_int("SVGP_WG_PER_CU", (nt == 64 || dtype == 1) ? 2 : 1);
   const int64_t cap = int64_t(num_cus) * per_cu;
   return int(nstrips < cap ? nstrips : cap);
 }
@@ -356,6 +359,8 @@ void launch_strip(int dtype, hipStream_t s, const StripArgs& a, int nt, int grid
   if (nt == 64) {
     if (dtype == 0) launch_strip_t<double, 64, 16, 256>(s, a, grid, nstrips);
     else launch_strip_t<float, 64, 16, 256>(s, a, grid, nstrips);   // BK = 32 measured identical
+  } else if (dtype == 1 && env_int("SVGP_F32_THREADS", 256) == 256) {
+    launch_strip_t<float, 128, 16, 256>(s, a, grid, nstrips);
   } else if (dtype == 0) {
     if (bk32 && a.kp.d <= 8) launch_strip_t<double, 128, 32, 512>(s, a, grid, nstrips);
     else launch_strip_t<double, 128, 16, 512>(s, a, grid, nstrips);
