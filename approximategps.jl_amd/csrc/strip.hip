@@ -22,8 +22,8 @@ namespace svgp {
 
 namespace {
 
-template <typename T, int NT, int BK, int NTHR>
-__global__ void __launch_bounds__(NTHR, 2) strip_kernel(StripArgs a, int64_t nstrips) {
+template <typename T, int NT, int BK, int NTHR, int MINW = 2>
+__global__ void __launch_bounds__(NTHR, MINW) strip_kernel(StripArgs a, int64_t nstrips) {
   using G = TileGemm<T, NT, BK, NTHR>;
   using Acc = typename G::Acc;
   using QRegs = typename G::QRegs;
@@ -315,11 +315,11 @@ __global__ void __launch_bounds__(k256) kuf_kernel(KernelParams kp, const T* __r
   }
 }
 
-template <typename T, int NT, int BK, int NTHR>
+template <typename T, int NT, int BK, int NTHR, int MINW = 2>
 void launch_strip_t(hipStream_t s, const StripArgs& a, int grid, int64_t nstrips) {
   using G = TileGemm<T, NT, BK, NTHR>;
   const size_t lds = G::LDS_BYTES + size_t(a.kp.d) * NT * sizeof(T);
-  auto kern = strip_kernel<T, NT, BK, NTHR>;
+  auto kern = strip_kernel<T, NT, BK, NTHR, MINW>;
   set_max_lds(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
   hipLaunchKernelGGL(kern, dim3(grid), dim3(NTHR), lds, s, a, nstrips);
 }
@@ -329,6 +329,7 @@ void launch_strip_t(hipStream_t s, const StripArgs& a, int grid, int64_t nstrips
 // Strip geometry.  Default: 64-point strips on 256-thread workgroups, two workgroups per CU, so the two
 // waves on a SIMD belong to different workgroups and do not park at the same barrier.
 // SVGP_STRIP_NT=128 selects the 128-point / 512-thread build, SVGP_STRIP_BK=32 the 32-deep k-step (tuning knobs).
+// Measured and rejected for f64: 64 x 64 per wave on one workgroup per CU (1 wave/SIMD): 54.9 ms vs 42.1 ms at H.
 static int env_int(const char* name, int dflt) {
   const char* e = getenv(name);
   return e ? atoi(e) : dflt;
