@@ -29,6 +29,7 @@ struct svgp_ctx {
   double* partial = nullptr;  unsigned* negcnt = nullptr;  // [1024] per-block sums of the expectation kernel
   double* mom = nullptr;      size_t mom_cap = 0;           // [2][mom_cap] per-point mean / variance
   double* d_res = nullptr;    // [8] device results
+  unsigned* counter = nullptr; // strip queue head of the running strip launch
   void* kuf_buf = nullptr;    size_t kuf_bytes = 0;
   struct GradWs* gws = nullptr;  // gradient workspace, cached by problem shape
 };
@@ -340,6 +341,7 @@ int enqueue_strips(svgp_ctx* ctx, svgp_model* m, const void* x, int64_t ldx, con
   a.mp = m->mp;
   a.x = x;
   a.work = ctx->work;
+  a.counter = ctx->counter;
   a.mom_mu = ctx->mom;
   a.mom_var = ctx->mom + ctx->mom_cap;
   a.A_out = o.A;
@@ -362,6 +364,7 @@ int enqueue_strips(svgp_ctx* ctx, svgp_model* m, const void* x, int64_t ldx, con
   lp.gh_w = m->gh_w;
   lp.clamp_neg_var = (m->desc.neg_var_policy == SVGP_NEGVAR_CLAMP);
   lp.mean_const = m->desc.mean_const;
+  HIPC(ctx, hipMemsetAsync(ctx->counter, 0, sizeof(unsigned), ctx->stream));
   launch_strip(m->dtype, ctx->stream, a, nt, grid, nstrips);
   KCHECK(ctx, "strip");
   HIPC(ctx, hipEventRecord(ctx->ev[2], ctx->stream));
@@ -518,7 +521,7 @@ int32_t svgp_ctx_create(int32_t device_id, void* stream, svgp_ctx** out) {
   }
   for (auto& e : c->ev)
     if (hipEventCreate(&e) != hipSuccess) { delete c; return SVGP_HIP_ERROR; }
-  if (hipMalloc(&c->d_res, 8 * sizeof(double)) != hipSuccess || hipMalloc(&c->partial, 1024 * sizeof(double)) != hipSuccess ||
+  if (hipMalloc(&c->d_res, 8 * sizeof(double)) != hipSuccess || hipMalloc(&c->counter, 64) != hipSuccess || hipMalloc(&c->partial, 1024 * sizeof(double)) != hipSuccess ||
       hipMalloc(&c->negcnt, 1024 * sizeof(unsigned)) != hipSuccess) { delete c; return SVGP_OOM; }
   *out = c;
   return SVGP_OK;
@@ -533,6 +536,7 @@ int32_t svgp_ctx_destroy(svgp_ctx* c) {
   if (c->negcnt) hipFree(c->negcnt);
   if (c->mom) hipFree(c->mom);
   if (c->d_res) hipFree(c->d_res);
+  if (c->counter) hipFree(c->counter);
   if (c->kuf_buf) hipFree(c->kuf_buf);
   if (c->gws) { c->gws->release(); delete c->gws; }
   for (auto& e : c->ev)

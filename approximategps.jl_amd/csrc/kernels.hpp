@@ -64,6 +64,7 @@ struct StripArgs {
   const void* zs;    // [d][Mp] scaled inducing inputs
   const void* mp;    // [Mp] padded mean of q
   const void* x;     // [d][ldx] feature-major inputs
+  unsigned* counter; // zeroed before the launch: dynamic strip queue (strips beyond the first gridDim.x)
   void* work;        // grid * Mp * NT elements: per-workgroup A strip
   double* mom_mu;    // [len] posterior mean of every point of the batch      (SVA:250)
   double* mom_var;   // [len] posterior variance, before the 1e-18 of f_post(x) (SVA:251)

@@ -47,8 +47,13 @@ __global__ void __launch_bounds__(NTHR, MINW) strip_kernel(StripArgs a, int64_t 
   const int tid = threadIdx.x, lane = tid & 63;
   const typename G::QOff qoff = G::q_offsets(NT);           // per-thread byte offsets inside a scratch-strip tile
 
-  for (int64_t strip = blockIdx.x; strip < nstrips; strip += gridDim.x) {
+  // Strips are handed out dynamically (one atomic per strip): workgroups that run alone on their CU near the end
+  // of the launch take more strips, which removes most of the ragged last round (C2: 3.05 rounds of strips).
+  // Which workgroup evaluates a strip does not change its arithmetic, so results stay bitwise reproducible.
+  __shared__ unsigned next_strip;
+  for (int64_t strip = blockIdx.x; strip < nstrips;) {
     const int64_t c0 = strip * NT;                          // first column of the strip inside the batch
+    if (tid == 0) next_strip = gridDim.x + atomicAdd(a.counter, 1u);
     const int64_t last = a.off + a.len - 1;
     // scaled inputs of the strip -> LDS (columns past the batch end replicate the last point; masked later)
     for (int e = tid; e < d * NT; e += NTHR) {
@@ -177,6 +182,8 @@ __global__ void __launch_bounds__(NTHR, MINW) strip_kernel(StripArgs a, int64_t 
       a.mom_mu[c0 + tid] = a.mean_const + qm;
       a.mom_var[c0 + tid] = a.kp.variance - qa + qc;
     }
+    __syncthreads();
+    strip = next_strip;
     __syncthreads();
   }
 }
