@@ -209,33 +209,43 @@ struct TileGemm {
     T a[MI], b[NJ];
   };
   // per-thread element offsets of its fragment inside a P / Q tile (slab 0)
+  // Row tiles are interleaved over the two wave rows (wave row wr owns 16-row tiles 2i + wr, i < MI) so that
+  // skipping the structurally-zero tiles of a triangular diagonal block stays balanced between them.
+  static __device__ __forceinline__ int wave_row() { return __builtin_amdgcn_readfirstlane(int(threadIdx.x >> 6)) / WC; }
   static __device__ __forceinline__ int frag_a_off() {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    return (lane >> 4) * PLD + (wave / WC) * (MI * 16) + (lane & 15);
+    return (lane >> 4) * PLD + (wave / WC) * 16 + (lane & 15);
   }
   static __device__ __forceinline__ int frag_b_off() {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     return (lane >> 4) * QLD + (wave % WC) * (NJ * 16) + (lane & 15);
   }
   // fa / fb already point at this thread's fragment of slab 0 of buffer 0; BUF and KSLAB are immediates
-  template <int BUF, int KSLAB>
+  // ILO..IHI (compile time) is the range of this wave's row tiles i that are not structurally zero in the step
+  template <int BUF, int KSLAB, int ILO = 0, int IHI = MI - 1>
   static __device__ __forceinline__ void load_frag(Frag& f, const T* __restrict__ fa, const T* __restrict__ fb) {
 #pragma unroll
-    for (int i = 0; i < MI; ++i) f.a[i] = fa[BUF * STAGE + KSLAB * 4 * PLD + i * 16];
+    for (int i = 0; i < MI; ++i)
+      if (i >= ILO && i <= IHI) f.a[i] = fa[BUF * STAGE + KSLAB * 4 * PLD + i * 32];
+    if (ILO <= IHI) {
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) f.b[j] = fb[BUF * STAGE + KSLAB * 4 * QLD + j * 16];
+      for (int j = 0; j < NJ; ++j) f.b[j] = fb[BUF * STAGE + KSLAB * 4 * QLD + j * 16];
+    }
   }
+  template <int ILO = 0, int IHI = MI - 1>
   static __device__ __forceinline__ void mma_frag(Acc& acc, const Frag& f) {
 #pragma unroll
     for (int i = 0; i < MI; ++i)
+      if (i >= ILO && i <= IHI) {
 #pragma unroll
-      for (int j = 0; j < NJ; ++j) acc.v[i][j] = Mfma16<T>::mma(f.a[i], f.b[j], acc.v[i][j]);
+        for (int j = 0; j < NJ; ++j) acc.v[i][j] = Mfma16<T>::mma(f.a[i], f.b[j], acc.v[i][j]);
+      }
   }
 
   // element (row, col) of acc.v[i][j][r] inside the 128 x NT tile
   static __device__ __forceinline__ int acc_row(int i, int r) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    return (wave / WC) * (MI * 16) + i * 16 + Mfma16<T>::row(lane, r);
+    return (2 * i + wave / WC) * 16 + Mfma16<T>::row(lane, r);
   }
   static __device__ __forceinline__ int acc_col(int j) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -254,7 +264,8 @@ struct TileGemm {
   //     fragment reads of step t+1, so the write -> barrier -> read latency hides under them;
   //   * global loads of tile t+2 are in flight during step t+1 and land in LDS just before its barrier.
   // Ends with all waves past their last LDS read.
-  template <int BUF, typename QLoad>
+  // NLO/NHI: tile range of the NEXT step (its slab-0 fragments are read behind this step's barrier)
+  template <int BUF, int ILO, int IHI, typename QLoad>
   static __device__ __forceinline__ void step(Acc& acc, Frag (&f)[2], PRegs& pr, QRegs& qr, const T* __restrict__ Pbase,
                                               int64_t pstride, const POff& poff, int t, int nsteps, QLoad& qload,
                                               T* __restrict__ smem, const T* __restrict__ fa, const T* __restrict__ fb) {
@@ -263,14 +274,14 @@ struct TileGemm {
     const bool more = (t + 1 < nsteps);
 #pragma unroll
     for (int ks = 0; ks + 1 < KS; ++ks) {
-      if (ks == 0) load_frag<BUF, 1>(f[1], fa, fb);
-      if (ks == 1) load_frag<BUF, 2>(f[0], fa, fb);
-      if (ks == 2) load_frag<BUF, 3>(f[1], fa, fb);
-      if (ks == 3) load_frag<BUF, 4 < KS ? 4 : 0>(f[0], fa, fb);
-      if (ks == 4) load_frag<BUF, 5 < KS ? 5 : 0>(f[1], fa, fb);
-      if (ks == 5) load_frag<BUF, 6 < KS ? 6 : 0>(f[0], fa, fb);
-      if (ks == 6) load_frag<BUF, 7 < KS ? 7 : 0>(f[1], fa, fb);
-      mma_frag(acc, f[ks & 1]);
+      if (ks == 0) load_frag<BUF, 1, ILO, IHI>(f[1], fa, fb);
+      if (ks == 1) load_frag<BUF, 2, ILO, IHI>(f[0], fa, fb);
+      if (ks == 2) load_frag<BUF, 3, ILO, IHI>(f[1], fa, fb);
+      if (ks == 3) load_frag<BUF, 4 < KS ? 4 : 0, ILO, IHI>(f[0], fa, fb);
+      if (ks == 4) load_frag<BUF, 5 < KS ? 5 : 0, ILO, IHI>(f[1], fa, fb);
+      if (ks == 5) load_frag<BUF, 6 < KS ? 6 : 0, ILO, IHI>(f[0], fa, fb);
+      if (ks == 6) load_frag<BUF, 7 < KS ? 7 : 0, ILO, IHI>(f[1], fa, fb);
+      mma_frag<ILO, IHI>(acc, f[ks & 1]);
     }
     if (more) {
       T* Pn = smem + (BUF ^ 1) * STAGE;
@@ -279,20 +290,37 @@ struct TileGemm {
     }
     __syncthreads();
     if (more) {
-      load_frag<BUF ^ 1, 0>(f[0], fa, fb);
+      load_frag<BUF ^ 1, 0>(f[0], fa, fb);   // all tiles: the next step's range is not known at compile time
       if (t + 2 < nsteps) {
         load_p(pr, Pbase + int64_t(t + 2) * pstride, poff);
         qload(t + 2, qr);
       }
     }
-    mma_frag(acc, f[(KS - 1) & 1]);
+    mma_frag<ILO, IHI>(acc, f[(KS - 1) & 1]);
   }
+
+  // The NB/BK = 8 steps that multiply a triangular diagonal block (lower: T's inv(L_II), upper: U's block of B') are
+  // written out with compile-time tile ranges.  A wave row wr owns tiles 2i + wr; lower step SD touches tiles >= SD,
+  // i.e. i >= SD/2 for the slower wave row (the barrier makes a step as long as its slower row, so both rows use the
+  // same range: no branch on wr); upper step SD touches tiles <= SD, i.e. i <= SD/2.  20 of 32 tile-steps remain.
+  // Straight-line code: no per-step dispatch, no per-MFMA predicates (both measured slower).
+#define SVGP_DSTEP(B, LO, HI, TT) step<B, LO, HI>(acc, f, pr, qr, Pbase, pstride, poff, (TT), nsteps, qload, smem, fa, fb)
 
   template <typename QLoad>
   static __device__ __forceinline__ void loop(Acc& acc, const T* __restrict__ Pbase, int64_t ldp, int nsteps,
                                               QLoad&& qload, T* __restrict__ smem) {
+    loop_tri<0>(acc, Pbase, ldp, nsteps, qload, smem);
+  }
+
+  // TRI = 0: every step is a full tile.  TRI = +1: the LAST NB/BK steps multiply a lower-triangular diagonal block.
+  // TRI = -1: the FIRST NB/BK steps multiply an upper-triangular diagonal block.  (nsteps is a multiple of NB/BK.)
+  template <int TRI, typename QLoad>
+  static __device__ __forceinline__ void loop_tri(Acc& acc, const T* __restrict__ Pbase, int64_t ldp, int nsteps,
+                                                  QLoad&& qload, T* __restrict__ smem) {
     if (nsteps <= 0) return;
     static_assert(BK <= 32, "step() enumerates at most 8 k-slabs");
+    constexpr int ND = NB / BK;
+    static_assert(TRI == 0 || (ND == 8 && MI == 4), "triangular steps are written out for BK = 16, 128-row panels");
     const POff poff = p_offsets(ldp);
     const int64_t pstride = int64_t(BK) * ldp;
     const T* fa = smem + frag_a_off();
@@ -311,13 +339,24 @@ struct TileGemm {
     Frag f[2];
     load_frag<0, 0>(f[0], fa, fb);
     int t = 0;
-    for (; t + 1 < nsteps; t += 2) {
-      step<0>(acc, f, pr, qr, Pbase, pstride, poff, t, nsteps, qload, smem, fa, fb);
-      step<1>(acc, f, pr, qr, Pbase, pstride, poff, t + 1, nsteps, qload, smem, fa, fb);
+    if (TRI < 0) {
+      SVGP_DSTEP(0, 0, 0, 0); SVGP_DSTEP(1, 0, 0, 1); SVGP_DSTEP(0, 0, 1, 2); SVGP_DSTEP(1, 0, 1, 3);
+      SVGP_DSTEP(0, 0, 2, 4); SVGP_DSTEP(1, 0, 2, 5); SVGP_DSTEP(0, 0, 3, 6); SVGP_DSTEP(1, 0, 3, 7);
+      t = ND;
     }
-    if (t < nsteps) step<0>(acc, f, pr, qr, Pbase, pstride, poff, t, nsteps, qload, smem, fa, fb);
+    const int nreg = (TRI > 0) ? nsteps - ND : nsteps;
+    for (; t + 1 < nreg; t += 2) {
+      step<0, 0, MI - 1>(acc, f, pr, qr, Pbase, pstride, poff, t, nsteps, qload, smem, fa, fb);
+      step<1, 0, MI - 1>(acc, f, pr, qr, Pbase, pstride, poff, t + 1, nsteps, qload, smem, fa, fb);
+    }
+    if (t < nreg) step<0, 0, MI - 1>(acc, f, pr, qr, Pbase, pstride, poff, t, nsteps, qload, smem, fa, fb);
+    if (TRI > 0) {
+      SVGP_DSTEP(0, 0, 3, nreg + 0); SVGP_DSTEP(1, 0, 3, nreg + 1); SVGP_DSTEP(0, 1, 3, nreg + 2); SVGP_DSTEP(1, 1, 3, nreg + 3);
+      SVGP_DSTEP(0, 2, 3, nreg + 4); SVGP_DSTEP(1, 2, 3, nreg + 5); SVGP_DSTEP(0, 3, 3, nreg + 6); SVGP_DSTEP(1, 3, 3, nreg + 7);
+    }
     __syncthreads();  // the tail MFMAs read no LDS, but callers reuse the staging buffers right away
   }
+#undef SVGP_DSTEP
 };
 
 }  // namespace svgp

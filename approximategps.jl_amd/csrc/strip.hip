@@ -16,6 +16,10 @@
 #include "kernels.hpp"
 #include "lik.hpp"
 
+#ifndef SVGP_TRI
+#define SVGP_TRI 3   // bit 1: skip zero tiles of T diagonal blocks (phase 1), bit 2: of U diagonal blocks (phase 2)
+#endif
+
 #include <cstdlib>
 
 namespace svgp {
@@ -102,7 +106,8 @@ __global__ void __launch_bounds__(NTHR, MINW) strip_kernel(StripArgs a, int64_t 
           }
         }
       };
-      G::loop(acc, Tm + int64_t(I) * NB, Mp, (I + 1) * (NB / BK), qload, smem);
+      // the last NB/BK steps multiply the lower-triangular inv(L_II): their zero 16-row tiles are skipped
+      G::template loop_tri<(BK == 16 && (SVGP_TRI & 1)) ? 1 : 0>(acc, Tm + int64_t(I) * NB, Mp, (I + 1) * (NB / BK), qload, smem);
 
       // epilogue: A_I -> scratch strip, column sums in fp64
 #pragma unroll
@@ -139,7 +144,9 @@ __global__ void __launch_bounds__(NTHR, MINW) strip_kernel(StripArgs a, int64_t 
       acc.zero();
       const T* wq = work + int64_t(J) * NB * NT;
       auto qload = [&](int t, QRegs& r) { G::load_q(r, wq + int64_t(t) * BK * NT, qoff); };
-      G::loop(acc, U + int64_t(J) * NB + int64_t(J) * NB * Mp, Mp, (nP - J) * (NB / BK), qload, smem);
+      // the first NB/BK steps multiply the upper-triangular diagonal block of B': zero tiles skipped likewise
+      G::template loop_tri<(BK == 16 && (SVGP_TRI & 2)) ? -1 : 0>(acc, U + int64_t(J) * NB + int64_t(J) * NB * Mp, Mp, (nP - J) * (NB / BK), qload,
+                                                 smem);
 #pragma unroll
       for (int i = 0; i < MI; ++i)
 #pragma unroll
