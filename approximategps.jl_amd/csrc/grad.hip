@@ -84,7 +84,7 @@ __global__ void __launch_bounds__(kThreads, 2) abar_kernel(const T* __restrict__
   acc.zero();
   const typename G::QOff qoff = G::q_offsets(ld);
   auto qload = [&](int t, QRegs& r) { G::load_q(r, C + int64_t(t) * 16 * ld + c0, qoff); };
-  G::loop(acc, Lqp + int64_t(I) * kNB, Mp, (I + 1) * (kNB / 16), qload, smem);
+  G::template loop_tri<1>(acc, Lqp + int64_t(I) * kNB, Mp, (I + 1) * (kNB / 16), qload, smem);   // last 8 steps: lower-triangular Lq_II
 #pragma unroll
   for (int i = 0; i < G::MI; ++i)
 #pragma unroll
@@ -118,7 +118,7 @@ __global__ void __launch_bounds__(k256, 2) solve_t_kernel(const T* __restrict__ 
       acc.zero();
       const T* xq = X + int64_t(I) * kNB * ld + c0;
       auto qload = [&](int t, QRegs& r) { G::load_q(r, xq + int64_t(t) * 16 * ld, qoff); };
-      G::loop(acc, S + int64_t(I) * kNB + int64_t(I) * kNB * Mp, Mp, (nP - I) * (kNB / 16), qload, smem);
+      G::template loop_tri<-1>(acc, S + int64_t(I) * kNB + int64_t(I) * kNB * Mp, Mp, (nP - I) * (kNB / 16), qload, smem);   // first 8: upper-triangular inv(L_II)'
 #pragma unroll
       for (int i = 0; i < G::MI; ++i)
 #pragma unroll
