@@ -202,12 +202,12 @@ def main():
 
     # HBM-side traffic of the dominant kernel: PMC counters cannot be read from inside this process, so the
     # figure is the one measured by tools/run_profile.sh (separate rocprofv3 --pmc passes) for this workload.
-    pmc_path = os.path.join(ROOT, "profiles", "round1", "H_fp64_v2_pmc.json")
+    pmc_path = os.path.join(ROOT, "profiles", "round1", "H_fp64_v3_pmc.json")
     if args.config == "H" and os.path.exists(pmc_path):
         pm = json.load(open(pmc_path))
         out["roofline"]["traffic"] = pm["strip_kernel<double,64,16,256>"]["traffic_bytes_per_launch"]
         out["roofline"]["traffic_note"] = ("bytes per launch at the L2<->fabric boundary (FETCH_SIZE x2 + WRITE_SIZE, "
-                                           "profiles/round1/H_fp64_v2_pmc.json); includes Infinity-Cache hits of the per-workgroup "
+                                           "profiles/round1/H_fp64_v3_pmc.json); includes Infinity-Cache hits of the per-workgroup "
                                            "scratch strips; algorithmic HBM bytes are 88 MB")
     if rank == 0 and world == 1 and not args.no_kuf:
         # Kuf assembly alone (SVA:216): M x n column-major written once -> HBM-write bound
@@ -221,7 +221,7 @@ def main():
         gbs = bytes_alg / (t_kuf * 1e-3) / 1e9
         kuf_traffic = None
         if args.config == "H" and os.path.exists(pmc_path):
-            kuf_traffic = json.load(open(pmc_path))["kuf_kernel<double,32>"]["traffic_bytes_per_launch"]
+            kuf_traffic = json.load(open(pmc_path))["kuf_kernel<double,8,256,SE>"]["traffic_bytes_per_launch"]
         out["kuf_roofline"] = {"kernel": "kuf_kernel", "bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS,
                                "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS, "traffic": kuf_traffic,
                                "bytes_per_launch": bytes_alg, "ms_per_launch": t_kuf}
