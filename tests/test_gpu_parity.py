@@ -249,3 +249,49 @@ def test_python_mirror_end_to_end(ctx):
     np.testing.assert_allclose(mu, mu_ref, rtol=1e-9, atol=1e-10)
     np.testing.assert_allclose(v, v_ref, rtol=1e-9, atol=1e-10)
     assert ag.prior_kl(sva, ctx=ctx) == pytest.approx(o.prior_kl(osva), rel=1e-10)
+
+
+@pytest.mark.parametrize("dtype,tol", [(np.float64, F64_RTOL), (np.float32, F32_RTOL)])
+def test_high_dimensional_inputs_and_tiny_models(ctx, dtype, tol):
+    """d = 20 exercises the 32-feature register paths of the Kuf / gradient kernels; M = 1 and M = 2 the padding."""
+    for N, M, d, fam in ((400, 70, 20, o.KERNEL_MATERN52), (90, 1, 3, o.KERNEL_SE), (65, 2, 12, o.KERNEL_MATERN32)):
+        x, y, sva, s2 = o.synth_problem(900 + M, N, M, d, family=fam, dtype=dtype)
+        ref = o.elbo_terms(sva, x, y, sigma2=s2, num_data=7.0 * N)
+        model = device_model(ctx, sva, dtype=dtype, sigma2=s2)
+        data = _ffi.DeviceData(ctx, x, y, dtype)
+        val, t = model.elbo(data, 0, N, 7.0 * N)
+        assert rel(val, ref.elbo) < tol
+        K = model.kuf(data, 0, N)
+        np.testing.assert_allclose(K, o.kernelmatrix(sva.kernel, sva.z, x), rtol=1e-11 if dtype == np.float64 else 3e-5,
+                                   atol=1e-13 if dtype == np.float64 else 3e-6)
+        _, _, g = model.elbo_grad(data, 0, N, 7.0 * N)
+        _, g_ref = o.elbo_grad(sva, x, y, sigma2=s2, num_data=7.0 * N)
+        gt = 1e-6 if dtype == np.float64 else 3e-3
+        for k in ("m", "Lq", "inv_lengthscale"):
+            a, b = np.asarray(g[k], dtype=np.float64), np.asarray(g_ref[k])
+            assert np.abs(a - b).max() <= gt * max(np.abs(b).max(), 1e-12)
+        zb = np.asarray(g["z"], dtype=np.float64).reshape(g_ref["z"].shape, order="F")
+        assert np.abs(zb - g_ref["z"]).max() <= gt * max(np.abs(g_ref["z"]).max(), 1e-12)
+        model.free()
+        data.free()
+
+
+def test_one_shot_elbo_host_entry_point(ctx):
+    """svgp_elbo_host: the literal drop-in for an ad-hoc elbo(sva, fx, y) call (host x, y, no handles)."""
+    import ctypes as C
+
+    from helpers import desc_from_oracle
+
+    x, y, sva, s2 = o.synth_problem(77, 500, 33, 4, family=o.KERNEL_MATERN32)
+    desc, keep = desc_from_oracle(sva, sigma2=s2)
+    xb, yb = np.asfortranarray(x), np.ascontiguousarray(y)
+    out, terms = C.c_double(), _ffi.Terms()
+    rc = ctx.lib.svgp_elbo_host(ctx.h, C.byref(desc), _ffi.COLVECS, 500, xb.ctypes.data_as(C.c_void_p),
+                                yb.ctypes.data_as(C.c_void_p), 1234.0, C.byref(out), C.byref(terms))
+    assert rc == _ffi.OK
+    assert rel(out.value, o.elbo(sva, x, y, sigma2=s2, num_data=1234.0)) < F64_RTOL
+    assert terms.n_points == 500 and terms.scale == pytest.approx(1234.0 / 500)
+    # argument errors come back as status codes with a message, never as exceptions/aborts
+    rc = ctx.lib.svgp_elbo_host(ctx.h, C.byref(desc), _ffi.COLVECS, 500, xb.ctypes.data_as(C.c_void_p), None, 0.0,
+                                C.byref(out), None)
+    assert rc == _ffi.INVALID_ARG and b"null" in ctx.lib.svgp_last_error(ctx.h)
