@@ -41,7 +41,7 @@ struct GradWs {
   std::vector<void*> all;
   void *A = nullptr, *C = nullptr, *Ab = nullptr, *At = nullptr, *Ct = nullptr, *Pt = nullptr, *gmu = nullptr, *gv = nullptr;
   void *Lqp = nullptr, *S = nullptr, *G1 = nullptr, *G2 = nullptr, *LkRM = nullptr, *LbarRM = nullptr, *Phi = nullptr,
-       *tmp = nullptr, *H = nullptr, *zbar = nullptr, *mbar = nullptr, *Lqbar = nullptr;
+       *tmp = nullptr, *H = nullptr, *zbar = nullptr, *mbar = nullptr, *Lqbar = nullptr, *BbarRM = nullptr, *rbar = nullptr;
   double *rp_uf = nullptr, *sp_uf = nullptr, *rp_uu = nullptr, *sp_uu = nullptr, *partial5 = nullptr, *sums = nullptr,
          *invl_d = nullptr, *scal_out = nullptr;
   size_t rp_uf_b = 0, sp_uf_b = 0, rp_uu_b = 0, sp_uu_b = 0, g_b = 0;
@@ -895,7 +895,7 @@ int grad_workspace(svgp_ctx* ctx, svgp_model* m, int64_t len, GradWs** out) {
       {&w->A, mn}, {&w->C, mn}, {&w->Ab, mn}, {&w->At, mn}, {&w->Ct, mn}, {&w->Pt, mn}, {&w->gmu, size_t(nc) * es},
       {&w->gv, size_t(nc) * es}, {&w->Lqp, mm}, {&w->S, mm}, {&w->G1, w->g_b}, {&w->G2, w->g_b}, {&w->LkRM, mm},
       {&w->LbarRM, mm}, {&w->Phi, mm}, {&w->tmp, mm}, {&w->H, mm}, {&w->zbar, size_t(m->M) * m->d * es},
-      {&w->mbar, size_t(m->M) * es}, {&w->Lqbar, size_t(m->M) * m->M * es}, {(void**)&w->rp_uf, w->rp_uf_b},
+      {&w->mbar, size_t(m->M) * es}, {&w->Lqbar, size_t(m->M) * m->M * es}, {&w->BbarRM, mm}, {&w->rbar, size_t(Mp) * es}, {(void**)&w->rp_uf, w->rp_uf_b},
       {(void**)&w->sp_uf, w->sp_uf_b}, {(void**)&w->rp_uu, w->rp_uu_b}, {(void**)&w->sp_uu, w->sp_uu_b},
       {(void**)&w->partial5, 1024 * 5 * 8}, {(void**)&w->sums, 8 * 8}, {(void**)&w->invl_d, size_t(m->d) * 8},
       {(void**)&w->scal_out, size_t(1 + dreg) * 8}};
@@ -922,8 +922,7 @@ extern "C" int32_t svgp_elbo_grad(svgp_ctx* ctx, svgp_model* m, const svgp_data*
   int rc = check_batch(ctx, m, data, off, len, true);
   if (rc) return rc;
   if (!g) return fail(ctx, SVGP_INVALID_ARG, "null gradient output");
-  if (m->desc.parametrization != SVGP_NONCENTERED)
-    return fail(ctx, SVGP_UNSUPPORTED, "svgp_elbo_grad supports the NonCentered parametrisation only");
+  const bool centered = (m->desc.parametrization == SVGP_CENTERED);
   HIPC(ctx, hipSetDevice(ctx->device));
   hipStream_t s = ctx->stream;
   GradWs* w = nullptr;
@@ -948,7 +947,9 @@ extern "C" int32_t svgp_elbo_grad(svgp_ctx* ctx, svgp_model* m, const svgp_data*
   HIPC(ctx, hipMemsetAsync(w->sums, 0, 8 * 8, s));
   HIPC(ctx, hipMemsetAsync(w->S, 0, mm, s));
   HIPC(ctx, hipMemcpyAsync(w->invl_d, m->invl_host.data(), size_t(m->d) * 8, hipMemcpyHostToDevice, s));
-  launch_pad_lower(dt, s, m->Lq_raw, M, Mp, w->Lqp);
+  // the adjoint runs on the whitened problem: (m~, B) are (m, Lq) for NonCentered and (Lk \\ (m - c), Lk \\ Lq) for Centered
+  const void* Bq = centered ? m->B : w->Lqp;
+  if (!centered) launch_pad_lower(dt, s, m->Lq_raw, M, Mp, w->Lqp);
   launch_sdiag(dt, s, m->T, Mp, w->S);
   launch_spanels(dt, s, m->L, m->T, w->S, Mp);
   KCHECK(ctx, "grad prep");
@@ -973,7 +974,7 @@ extern "C" int32_t svgp_elbo_grad(svgp_ctx* ctx, svgp_model* m, const svgp_data*
     launch_grad_moments(dt, s, lp, scale, ctx->mom, ctx->mom + ctx->mom_cap, data->y, off + c0, clen, ncp, w->gmu, w->gv,
                         w->partial5, w->sums);
     KCHECK(ctx, "grad_moments");
-    launch_abar(dt, s, w->Lqp, w->C, w->A, m->mp, w->gmu, w->gv, w->Ab, Mp, ldk, ncp);
+    launch_abar(dt, s, Bq, w->C, w->A, m->mp, w->gmu, w->gv, w->Ab, Mp, ldk, ncp);
     KCHECK(ctx, "abar");
     launch_solve_t(dt, s, w->S, w->Ab, nullptr, Mp, ldk, ncp, ctx->num_cus);
     launch_to_point_major(dt, s, w->Ab, ldk, Mp, ncp, w->Pt);
@@ -988,7 +989,21 @@ extern "C" int32_t svgp_elbo_grad(svgp_ctx* ctx, svgp_model* m, const svgp_data*
     KCHECK(ctx, "kgrad uf");
   }
   // M-sized tail: Lq_bar, Lk_bar -> Kuu_bar -> kernel parameters
-  launch_finish_mm(dt, s, w->G1, w->G2, w->nslices, Mp, M, m->Lq_raw, w->Lqbar, w->LbarRM);
+  launch_finish_mm(dt, s, w->G1, w->G2, w->nslices, Mp, M, centered ? m->B : m->Lq_raw, centered ? Mp : M, w->Lqbar,
+                   centered ? w->BbarRM : nullptr, w->LbarRM);
+  if (centered) {
+    // chain through m~ = Lk \ (m - c) and B = Lk \ Lq:  m_bar = Lk^-T m~_bar,  R = Lk^-T B_bar,  Lq_bar = tril(R),
+    // Lk_bar -= tril(m_bar m~') + tril(R B')
+    launch_mbar(dt, s, w->rp_uf, w->ns_uf, int64_t(2 + dreg) * Mp, m->mp, M, Mp, w->rbar);
+    launch_trsv2(dt, s, m->L, m->T, Mp, 1, w->rbar);
+    launch_solve_t(dt, s, w->S, w->BbarRM, nullptr, Mp, Mp, Mp, ctx->num_cus);
+    launch_rm_tril_to_user(dt, s, w->BbarRM, Mp, M, w->Lqbar);
+    launch_transpose(dt, s, w->BbarRM, Mp, w->tmp);
+    HIPC(ctx, hipMemsetAsync(w->Phi, 0, mm, s));
+    launch_gemm_pm(dt, s, w->tmp, m->B, nullptr, 1.0, Mp, Mp, Mp, 1, w->Phi);
+    launch_lbar_adjust(dt, s, w->LbarRM, w->Phi, w->rbar, m->mp, Mp);
+    KCHECK(ctx, "centered chain");
+  }
   launch_lower_to_rowmajor(dt, s, m->L, Mp, w->LkRM);
   HIPC(ctx, hipMemsetAsync(w->Phi, 0, mm, s));
   launch_gemm_pm(dt, s, w->LkRM, w->LbarRM, nullptr, 1.0, Mp, Mp, Mp, 1, w->Phi);
@@ -1000,7 +1015,8 @@ extern "C" int32_t svgp_elbo_grad(svgp_ctx* ctx, svgp_model* m, const svgp_data*
   KCHECK(ctx, "chol backward");
   launch_kgrad(dt, s, kp, m->zs, Mp, m->zs, Mp, 0, 1, M, M, w->H, nullptr, nullptr, 128, w->ns_uu, w->rp_uu, w->sp_uu);
   launch_finish_kgrad(dt, s, m->d, M, Mp, m->zs, w->invl_d, w->rp_uf, w->ns_uf, w->rp_uu, w->ns_uu, w->sp_uf, w->ns_uf * w->rb,
-                      w->sp_uu, w->ns_uu * w->rb, m->m_raw, m->desc.layout_z, m->desc.variance, w->zbar, w->mbar, w->scal_out);
+                      w->sp_uu, w->ns_uu * w->rb, m->mp, m->desc.layout_z, m->desc.variance, w->zbar, centered ? nullptr : w->mbar,
+                      w->scal_out);
   KCHECK(ctx, "kgrad uu / finish");
   HIPC(ctx, hipEventRecord(ctx->ev[3], s));
   // read back
@@ -1012,7 +1028,8 @@ extern "C" int32_t svgp_elbo_grad(svgp_ctx* ctx, svgp_model* m, const svgp_data*
   HIPC(ctx, hipMemcpyAsync(ps.scal, m->scal, sizeof(ps.scal), hipMemcpyDeviceToHost, s));
   HIPC(ctx, hipMemcpyAsync(&ps.info, m->info, sizeof(int), hipMemcpyDeviceToHost, s));
   if (g->z) HIPC(ctx, hipMemcpyAsync(g->z, w->zbar, size_t(M) * m->d * es, hipMemcpyDeviceToHost, s));
-  if (g->m) HIPC(ctx, hipMemcpyAsync(g->m, w->mbar, size_t(M) * es, hipMemcpyDeviceToHost, s));
+  std::vector<char> mhost(size_t(M) * es);
+  HIPC(ctx, hipMemcpyAsync(mhost.data(), centered ? w->rbar : w->mbar, size_t(M) * es, hipMemcpyDeviceToHost, s));
   if (g->Lq) HIPC(ctx, hipMemcpyAsync(g->Lq, w->Lqbar, size_t(M) * M * es, hipMemcpyDeviceToHost, s));
   HIPC(ctx, hipStreamSynchronize(s));
   finish_prep(m, ps);
@@ -1027,7 +1044,11 @@ extern "C" int32_t svgp_elbo_grad(svgp_ctx* ctx, svgp_model* m, const svgp_data*
   const double elbo = E * scale - m->kl;
   g->variance = sc[0] + sums[2];
   g->lik_sigma2 = sums[3];
-  g->mean_const = sums[1];
+  if (g->m) memcpy(g->m, mhost.data(), mhost.size());
+  double msum = 0.0;   // Centered: mean_const also enters through m~ = Lk \\ (m - c)
+  if (centered)
+    for (int64_t i = 0; i < M; ++i) msum += (dt == SVGP_F64) ? reinterpret_cast<double*>(mhost.data())[i] : double(reinterpret_cast<float*>(mhost.data())[i]);
+  g->mean_const = sums[1] - msum;
   if (g->inv_lengthscale)
     for (int f = 0; f < m->d; ++f) g->inv_lengthscale[f] = sc[1 + f];
   if (terms_out) {

@@ -373,7 +373,8 @@ __global__ void phi_kernel(T* __restrict__ X, int64_t Mp) {
 // reduce the split-K slices: Lq_bar (user layout, ld M) and Lk_bar row-major (negated, lower)
 template <typename T>
 __global__ void finish_mm_kernel(const T* __restrict__ G1, const T* __restrict__ G2, int nslices, int64_t Mp, int64_t M,
-                                 const T* __restrict__ Lq, T* __restrict__ Lq_bar, T* __restrict__ LkbarRM) {
+                                 const T* __restrict__ Lq, int64_t ldq, T* __restrict__ Lq_bar, T* __restrict__ BbarRM,
+                                 T* __restrict__ LkbarRM) {
   const int64_t c = int64_t(blockIdx.x) * blockDim.x + threadIdx.x, r = blockIdx.y;
   if (c >= Mp) return;
   T g1 = T(0), g2 = T(0);
@@ -383,14 +384,43 @@ __global__ void finish_mm_kernel(const T* __restrict__ G1, const T* __restrict__
       g2 += G2[int64_t(s) * Mp * Mp + r * Mp + c];
     }
   LkbarRM[r * Mp + c] = -g2;
-  if (r < M && c < M) {
-    T v = T(0);
-    if (c <= r) {
-      const T l = Lq[r + c * M];
-      v = g1 - (c == r ? l - T(1) / l : l);
-    }
-    Lq_bar[r + c * M] = v;
+  T v = T(0);
+  if (r < M && c <= r) {
+    const T l = Lq[r + c * ldq];
+    v = g1 - (c == r ? l - T(1) / l : l);
   }
+  if (BbarRM) BbarRM[r * Mp + c] = v;                    // Centered: adjoint of B = Lk \ Lq, row-major for the solve
+  else if (r < M && c < M) Lq_bar[r + c * M] = v;
+}
+
+// Centered chain rule helpers ------------------------------------------------------------------------------
+// vec[i] = sum_slices rowpart[s][1][i] - mtilde[i]   (adjoint of the whitened mean), zero padded
+template <typename T>
+__global__ void mbar_kernel(const double* __restrict__ rp_uf, int ns, int64_t stride, const T* __restrict__ mt, int64_t M,
+                            int64_t Mp, T* __restrict__ vec) {
+  const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= Mp) return;
+  double s = 0.0;
+  if (i < M) {
+    for (int q = 0; q < ns; ++q) s += rp_uf[q * stride + Mp + i];
+    s -= double(mt[i]);
+  }
+  vec[i] = T(s);
+}
+
+// LkbarRM[r][c] -= (R B')[r][c] + rbar[r] mtilde[c]  for c <= r
+template <typename T>
+__global__ void lbar_adjust_kernel(T* __restrict__ LkbarRM, const T* __restrict__ RBt, const T* __restrict__ rbar,
+                                   const T* __restrict__ mt, int64_t Mp) {
+  const int64_t c = int64_t(blockIdx.x) * blockDim.x + threadIdx.x, r = blockIdx.y;
+  if (c < Mp && c <= r) LkbarRM[r * Mp + c] -= RBt[r * Mp + c] + rbar[r] * mt[c];
+}
+
+// user-layout (column-major, ld M) lower triangle of a row-major Mp x Mp matrix
+template <typename T>
+__global__ void rm_tril_to_user_kernel(const T* __restrict__ R, int64_t Mp, int64_t M, T* __restrict__ out) {
+  const int64_t r = int64_t(blockIdx.x) * blockDim.x + threadIdx.x, c = blockIdx.y;
+  if (r < M) out[r + c * M] = (c <= r) ? R[r * Mp + c] : T(0);
 }
 
 // final assembly of the kernel-parameter / inducing-input gradients from the slice partials
@@ -407,7 +437,7 @@ __global__ void finish_kgrad_kernel(int d, int dreg, int64_t M, int64_t Mp, cons
     double R1 = 0, MB = 0, R2 = 0;
     for (int s = 0; s < ns_uf; ++s) { R1 += rp_uf[s * stride + i]; MB += rp_uf[s * stride + Mp + i]; }
     for (int s = 0; s < ns_uu; ++s) R2 += rp_uu[s * stride + i];
-    m_bar[i] = T(MB - double(m[i]));
+    if (m_bar) m_bar[i] = T(MB - double(m[i]));
     for (int f = 0; f < d; ++f) {
       double Q1 = 0, Q2 = 0;
       for (int s = 0; s < ns_uf; ++s) Q1 += rp_uf[s * stride + (2 + f) * Mp + i];
@@ -549,10 +579,27 @@ void launch_phi(int dtype, hipStream_t s, void* X, int64_t Mp) {
 }
 
 void launch_finish_mm(int dtype, hipStream_t s, const void* G1, const void* G2, int nslices, int64_t Mp, int64_t M,
-                      const void* Lq, void* Lq_bar, void* LkbarRM) {
+                      const void* Lq, int64_t ldq, void* Lq_bar, void* BbarRM, void* LkbarRM) {
   dim3 grid((unsigned)((Mp + 255) / 256), (unsigned)Mp);
   GD(dtype, T, hipLaunchKernelGGL(finish_mm_kernel<T>, grid, dim3(256), 0, s, (const T*)G1, (const T*)G2, nslices, Mp, M,
-                                  (const T*)Lq, (T*)Lq_bar, (T*)LkbarRM));
+                                  (const T*)Lq, ldq, (T*)Lq_bar, (T*)BbarRM, (T*)LkbarRM));
+}
+
+void launch_mbar(int dtype, hipStream_t s, const double* rp_uf, int ns, int64_t stride, const void* mt, int64_t M, int64_t Mp,
+                 void* vec) {
+  GD(dtype, T, hipLaunchKernelGGL(mbar_kernel<T>, dim3((unsigned)((Mp + 255) / 256)), dim3(256), 0, s, rp_uf, ns, stride,
+                                  (const T*)mt, M, Mp, (T*)vec));
+}
+
+void launch_lbar_adjust(int dtype, hipStream_t s, void* LkbarRM, const void* RBt, const void* rbar, const void* mt, int64_t Mp) {
+  dim3 grid((unsigned)((Mp + 255) / 256), (unsigned)Mp);
+  GD(dtype, T, hipLaunchKernelGGL(lbar_adjust_kernel<T>, grid, dim3(256), 0, s, (T*)LkbarRM, (const T*)RBt, (const T*)rbar,
+                                  (const T*)mt, Mp));
+}
+
+void launch_rm_tril_to_user(int dtype, hipStream_t s, const void* R, int64_t Mp, int64_t M, void* out) {
+  dim3 grid((unsigned)((M + 255) / 256), (unsigned)M);
+  GD(dtype, T, hipLaunchKernelGGL(rm_tril_to_user_kernel<T>, grid, dim3(256), 0, s, (const T*)R, Mp, M, (T*)out));
 }
 
 void launch_finish_kgrad(int dtype, hipStream_t s, int d, int64_t M, int64_t Mp, const void* zs, const double* invl,

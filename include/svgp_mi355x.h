@@ -150,8 +150,8 @@ int32_t svgp_elbo_host(svgp_ctx* ctx, const svgp_model_desc* desc, int32_t layou
                        svgp_terms* terms_out);
 
 /* ---- gradient of the ELBO (what Zygote produces for the reference's training loops:
- * examples/a-regression/script.jl:188-194, test/SparseVariationalApproximationModule.jl:170-175).  NonCentered only
- * (SVGP_UNSUPPORTED otherwise).  Every output array is caller-allocated host memory; z, m, Lq gradients have the
+ * examples/a-regression/script.jl:188-194, test/SparseVariationalApproximationModule.jl:170-175).  Both parametrisations
+ * (Centered: the adjoint runs on the whitened (Lk \\ (m - c), Lk \\ Lq) and is chained back through Lk).  Every output array is caller-allocated host memory; z, m, Lq gradients have the
  * dtype / layout of the corresponding svgp_model_desc arrays (Lq: lower triangle, upper zeroed); NULL skips one. */
 typedef struct svgp_grads {
   double variance;          /* d elbo / d kernel variance */

@@ -575,13 +575,16 @@ def chol_backward(L: np.ndarray, Lbar: np.ndarray) -> np.ndarray:
 
 
 def elbo_grad(sva: SVA, x, y, lik=LIK_GAUSSIAN, sigma2=1.0, num_data=None, quadrature_n=0):
-    """-> (elbo, dict of gradients w.r.t. variance, inv_lengthscale[d], z[d,M], m[M], Lq[M,M] lower, lik_sigma2, mean_const)."""
-    assert not sva.centered, "gradient is implemented for the NonCentered parametrisation"
+    """-> (elbo, dict of gradients w.r.t. variance, inv_lengthscale[d], z[d,M], m[M], Lq[M,M] lower, lik_sigma2, mean_const).
+
+    Centered: with m~ = Lk \\ (m - c), B = Lk \\ Lq the ELBO equals the NonCentered one evaluated at (m~, B) (the KL
+    included), so the NonCentered adjoint is chained through the two triangular solves:
+    m_bar = Lk^-T m~_bar, Lq_bar = tril(Lk^-T B_bar), Lk_bar -= tril(m_bar m~') + tril((Lk^-T B_bar) B'), c_bar -= sum(m_bar)."""
     x = _as_dn(np.asarray(x, dtype=np.float64))
     y = np.asarray(y, dtype=np.float64)
     k = sva.kernel
     il = k.inv_lengthscale
-    z, m, Lq = sva.z.astype(np.float64), sva.m.astype(np.float64), np.tril(sva.Lq).astype(np.float64)
+    z = sva.z.astype(np.float64)
     M, n = z.shape[1], x.shape[1]
     scale = (float(num_data) if num_data is not None else float(n)) / n
     r2_uf = _scaled_sqdist(k, z, x)
@@ -589,6 +592,11 @@ def elbo_grad(sva: SVA, x, y, lik=LIK_GAUSSIAN, sigma2=1.0, num_data=None, quadr
     r2_uu = _scaled_sqdist(k, z, z)
     Kuu = _kappa(k, r2_uu) + sva.jitter * np.eye(M)
     Lk = _chol_lower_checked(Kuu.copy())
+    if sva.centered:
+        m = sla.solve_triangular(Lk, sva.m.astype(np.float64) - sva.mean_const, lower=True)
+        Lq = sla.solve_triangular(Lk, np.tril(sva.Lq).astype(np.float64), lower=True)
+    else:
+        m, Lq = sva.m.astype(np.float64), np.tril(sva.Lq).astype(np.float64)
     A = sla.solve_triangular(Lk, Kuf, lower=True)
     C = Lq.T @ A
     mu = sva.mean_const + A.T @ m
@@ -596,13 +604,20 @@ def elbo_grad(sva: SVA, x, y, lik=LIK_GAUSSIAN, sigma2=1.0, num_data=None, quadr
     E = expected_loglik(lik, mu, np.sqrt(v), y, sigma2, quadrature_n)
     gmu, gv, gs2 = expected_loglik_grads(lik, mu, v, y, sigma2, quadrature_n)
     gmu, gv, gs2 = scale * gmu, scale * gv, scale * gs2
-    kl = prior_kl(sva)
-    # adjoints
+    kl = 0.5 * (np.sum(Lq * Lq) + m @ m - M - 2.0 * np.sum(np.log(np.diag(Lq))))
+    # adjoints of the whitened problem
     Abar = np.outer(m, gmu) + 2.0 * (Lq @ C - A) * gv[None, :]
     m_bar = A @ gmu - m
     Lq_bar = np.tril(2.0 * (A * gv[None, :]) @ C.T) - (Lq - np.diag(1.0 / np.diag(Lq)))
     P = sla.solve_triangular(Lk, Abar, lower=True, trans="T")          # Kuf_bar
     Lk_bar = -np.tril(P @ A.T)
+    c_bar = float(np.sum(gmu))
+    if sva.centered:
+        r_bar = sla.solve_triangular(Lk, m_bar, lower=True, trans="T")
+        R = sla.solve_triangular(Lk, Lq_bar, lower=True, trans="T")
+        Lk_bar -= np.tril(np.outer(r_bar, m)) + np.tril(R @ Lq.T)
+        c_bar -= float(np.sum(r_bar))
+        m_bar, Lq_bar = r_bar, np.tril(R)
     H = chol_backward(Lk, Lk_bar)                                       # Kuu_bar (symmetric)
     # kernel parameters
     var_bar = float(np.sum(P * Kuf) / k.variance + np.sum(H * (Kuu - sva.jitter * np.eye(M))) / k.variance + np.sum(gv))
@@ -615,6 +630,5 @@ def elbo_grad(sva: SVA, x, y, lik=LIK_GAUSSIAN, sigma2=1.0, num_data=None, quadr
         dzz = z[f][:, None] - z[f][None, :]
         il_bar[f] = 2.0 * il[f] * (np.sum(Wf * dzx * dzx) + np.sum(Wu * dzz * dzz))
         z_bar[f] = 2.0 * il[f] ** 2 * (np.sum(Wf * dzx, 1) + 2.0 * np.sum(Wu * dzz, 1))
-    grads = dict(variance=var_bar, inv_lengthscale=il_bar, z=z_bar, m=m_bar, Lq=Lq_bar, lik_sigma2=gs2,
-                 mean_const=float(np.sum(gmu)))
+    grads = dict(variance=var_bar, inv_lengthscale=il_bar, z=z_bar, m=m_bar, Lq=Lq_bar, lik_sigma2=gs2, mean_const=c_bar)
     return E * scale - kl, grads

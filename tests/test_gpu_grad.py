@@ -79,13 +79,38 @@ def test_gradient_chunked_and_minibatch(ctx):
     data.free()
 
 
-def test_gradient_unsupported_for_centered(ctx):
-    x, y, sva, s2 = o.synth_problem(45, 100, 10, 2)
-    c = o.SVA(sva.kernel, sva.z, sva.m, sva.Lq, jitter=sva.jitter, centered=True)
-    model = device_model(ctx, c, sigma2=s2)
-    data = _ffi.DeviceData(ctx, x, y, np.float64)
-    with pytest.raises(_ffi.UnsupportedError):
-        model.elbo_grad(data)
+CENTERED_CASES = [
+    (300, 20, 1, o.KERNEL_SE, o.LIK_GAUSSIAN, 0),
+    (777, 200, 3, o.KERNEL_MATERN32, o.LIK_GAUSSIAN, 0),
+    (900, 300, 16, o.KERNEL_MATERN52, o.LIK_BERNOULLI_LOGISTIC, 0),
+    (513, 64, 5, o.KERNEL_SE, o.LIK_GAUSSIAN, 7),
+    (640, 129, 2, o.KERNEL_SE, o.LIK_POISSON_EXP, 0),
+]
+
+
+@pytest.mark.parametrize("N,M,d,family,lik,qn", CENTERED_CASES)
+@pytest.mark.parametrize("dtype,tol", [(np.float64, 1e-6), (np.float32, 5e-3)])
+def test_centered_gradient_matches_oracle(ctx, N, M, d, family, lik, qn, dtype, tol):
+    """Centered parametrisation (q(u) = N(m, Lq Lq')): the device whitens, runs the NonCentered adjoint and chains back
+    through Lk (src/SparseVariationalApproximationModule.jl:115-136 under Zygote)."""
+    x, y, nc, s2 = o.synth_problem(500 + N, N, M, d, family=family, lik=lik, dtype=dtype)
+    jit = 1e-4 if dtype == np.float64 else 1e-2   # Lk \\ Lq amplifies rounding by cond(Lk): keep fp32 inside 1e-4
+    tame = 0.1 if lik == o.LIK_POISSON_EXP else 1.0   # keep exp(mu + v/2) in a range fp32 can resolve to 1e-4
+    sva = o.SVA(nc.kernel, nc.z, tame * (nc.m + 0.3), 0.7 * tame * nc.Lq, jitter=jit, mean_const=0.15, centered=True)
+    val_ref, g_ref = o.elbo_grad(sva, x, y, lik=lik, sigma2=s2, num_data=1.5 * N, quadrature_n=qn)
+    model = device_model(ctx, sva, dtype=dtype, lik=lik, sigma2=s2, quadrature_n=qn)
+    data = _ffi.DeviceData(ctx, x, y, dtype)
+    val, terms, g = model.elbo_grad(data, 0, N, 1.5 * N)
+    assert rel(val, val_ref) < (1e-8 if dtype == np.float64 else 1e-4)
+    _close(g["m"], g_ref["m"], tol)
+    _close(g["Lq"], g_ref["Lq"], tol)
+    _close(g["z"].reshape(g_ref["z"].shape, order="F") if d > 1 else g["z"], g_ref["z"] if d > 1 else g_ref["z"][0], tol)
+    _close(g["inv_lengthscale"], g_ref["inv_lengthscale"], tol)
+    _close([g["variance"]], [g_ref["variance"]], tol)
+    _close([g["mean_const"]], [g_ref["mean_const"]], tol)
+    if lik == o.LIK_GAUSSIAN:
+        _close([g["lik_sigma2"]], [g_ref["lik_sigma2"]], tol)
+    assert rel(val, model.elbo(data, 0, N, 1.5 * N)[0]) < 1e-12
     model.free()
     data.free()
 

@@ -44,3 +44,26 @@ def test_gradient_matches_finite_differences(family, lik, qn):
     assert g["mean_const"] == pytest.approx(float(_fd(lambda t: with_(c=float(t[0])), np.array([0.2]), 1e-6)[0]), rel=2e-6, abs=2e-6)
     if lik == o.LIK_GAUSSIAN:
         assert g["lik_sigma2"] == pytest.approx(float(_fd(lambda t: with_(s2=float(t[0])), np.array([s2]), 1e-6)[0]), rel=2e-6, abs=2e-6)
+
+
+@pytest.mark.parametrize("family,lik", [(o.KERNEL_SE, o.LIK_GAUSSIAN), (o.KERNEL_MATERN52, o.LIK_BERNOULLI_LOGISTIC)])
+def test_centered_gradient_matches_finite_differences(family, lik):
+    x, y, nc, s2 = o.synth_problem(41 + family, 35, 6, 2, family=family, lik=lik)
+    sva = o.SVA(nc.kernel, nc.z, nc.m + 0.3, 0.7 * nc.Lq, jitter=1e-4, mean_const=0.15, centered=True)
+    kw = dict(lik=lik, num_data=80.0)
+    val, g = o.elbo_grad(sva, x, y, sigma2=s2, **kw)
+    assert val == pytest.approx(o.elbo(sva, x, y, sigma2=s2, **kw), rel=1e-12)
+
+    def with_(**ch):
+        k = o.Kernel(family, ch.get("variance", sva.kernel.variance), ch.get("il", sva.kernel.inv_lengthscale))
+        s = o.SVA(k, ch.get("z", sva.z), ch.get("m", sva.m), ch.get("Lq", sva.Lq), jitter=sva.jitter,
+                  mean_const=ch.get("c", sva.mean_const), centered=True)
+        return o.elbo(s, x, y, sigma2=s2, **kw)
+
+    tol = dict(rtol=5e-6, atol=5e-6)
+    np.testing.assert_allclose(g["m"], _fd(lambda t: with_(m=t), sva.m.copy(), 1e-6), **tol)
+    np.testing.assert_allclose(g["z"], _fd(lambda t: with_(z=t), sva.z.copy(), 1e-6), **tol)
+    np.testing.assert_allclose(g["inv_lengthscale"], _fd(lambda t: with_(il=t), sva.kernel.inv_lengthscale.copy(), 1e-6), **tol)
+    np.testing.assert_allclose(g["Lq"], np.tril(_fd(lambda t: with_(Lq=np.tril(t)), sva.Lq.copy(), 1e-6)), **tol)
+    assert g["variance"] == pytest.approx(float(_fd(lambda t: with_(variance=float(t[0])), np.array([sva.kernel.variance]), 1e-6)[0]), rel=5e-6, abs=5e-6)
+    assert g["mean_const"] == pytest.approx(float(_fd(lambda t: with_(c=float(t[0])), np.array([0.15]), 1e-6)[0]), rel=5e-6, abs=5e-6)
