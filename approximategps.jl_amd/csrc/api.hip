@@ -47,7 +47,7 @@ struct GradWs {
   size_t rp_uf_b = 0, sp_uf_b = 0, rp_uu_b = 0, sp_uu_b = 0, g_b = 0;
   void release() {
     for (void* p : all)
-      if (p) hipFree(p);
+      if (p) (void)hipFree(p);
     all.clear();
   }
 };
@@ -229,8 +229,8 @@ int upload_params(svgp_ctx* ctx, svgp_model* m, const svgp_model_desc* d) {
   }
   const int gh = effective_gh(*d);
   if (gh != m->gh_n) {
-    if (m->gh_x) hipFree(m->gh_x);
-    if (m->gh_w) hipFree(m->gh_w);
+    if (m->gh_x) (void)hipFree(m->gh_x);
+    if (m->gh_w) (void)hipFree(m->gh_w);
     m->gh_x = m->gh_w = nullptr;
     m->gh_n = gh;
     if (gh > 0) {
@@ -299,14 +299,14 @@ void finish_prep(svgp_model* m, const PrepScalars& ps) {
 
 int ensure_scratch(svgp_ctx* ctx, size_t work_bytes, size_t npoints) {
   if (work_bytes > ctx->work_bytes) {
-    if (ctx->work) hipFree(ctx->work);
+    if (ctx->work) (void)hipFree(ctx->work);
     ctx->work = nullptr;
     ctx->work_bytes = 0;
     HIPC(ctx, hipMalloc(&ctx->work, work_bytes));
     ctx->work_bytes = work_bytes;
   }
   if (npoints > ctx->mom_cap) {
-    if (ctx->mom) hipFree(ctx->mom);
+    if (ctx->mom) (void)hipFree(ctx->mom);
     ctx->mom = nullptr;
     ctx->mom_cap = 0;
     HIPC(ctx, hipMalloc(&ctx->mom, 2 * npoints * sizeof(double)));
@@ -407,9 +407,9 @@ int run_elbo(svgp_ctx* ctx, svgp_model* m, const svgp_data* data, int64_t off, i
   HIPC(ctx, hipStreamSynchronize(s));
   finish_prep(m, ps);
   float t01 = 0, t12 = 0, t23 = 0;
-  hipEventElapsedTime(&t01, ctx->ev[0], ctx->ev[1]);
-  hipEventElapsedTime(&t12, ctx->ev[1], ctx->ev[2]);
-  hipEventElapsedTime(&t23, ctx->ev[2], ctx->ev[3]);
+  (void)hipEventElapsedTime(&t01, ctx->ev[0], ctx->ev[1]);
+  (void)hipEventElapsedTime(&t12, ctx->ev[1], ctx->ev[2]);
+  (void)hipEventElapsedTime(&t23, ctx->ev[2], ctx->ev[3]);
   ctx->timing.ms_prep = t01;
   ctx->timing.ms_strip = t12;
   ctx->timing.ms_expect = t23;
@@ -463,7 +463,7 @@ int make_data(svgp_ctx* ctx, int dtype, int layout, int d, int64_t n, const void
   hipError_t e = hipMalloc(&D->x, size_t(n) * d * es);
   if (e == hipSuccess && y_host) e = hipMalloc(&D->y, size_t(n) * es);
   if (e != hipSuccess) {
-    if (D->x) hipFree(D->x);
+    if (D->x) (void)hipFree(D->x);
     delete D;
     return fail(ctx, SVGP_OOM, "hipMalloc failed for data");
   }
@@ -473,7 +473,7 @@ int make_data(svgp_ctx* ctx, int dtype, int layout, int d, int64_t n, const void
     HIPC(ctx, hipMemcpyAsync(tmp, x_host, size_t(n) * d * es, hipMemcpyHostToDevice, s));
     launch_transpose_colvecs(dtype, s, tmp, d, n, D->ldx, D->x);
     HIPC(ctx, hipStreamSynchronize(s));
-    hipFree(tmp);
+    (void)hipFree(tmp);
   } else {
     HIPC(ctx, hipMemcpyAsync(D->x, x_host, size_t(n) * d * es, hipMemcpyHostToDevice, s));
   }
@@ -529,19 +529,19 @@ int32_t svgp_ctx_create(int32_t device_id, void* stream, svgp_ctx** out) {
 
 int32_t svgp_ctx_destroy(svgp_ctx* c) {
   if (!c) return SVGP_OK;
-  hipSetDevice(c->device);
-  hipStreamSynchronize(c->stream);
-  if (c->work) hipFree(c->work);
-  if (c->partial) hipFree(c->partial);
-  if (c->negcnt) hipFree(c->negcnt);
-  if (c->mom) hipFree(c->mom);
-  if (c->d_res) hipFree(c->d_res);
-  if (c->counter) hipFree(c->counter);
-  if (c->kuf_buf) hipFree(c->kuf_buf);
+  (void)hipSetDevice(c->device);
+  (void)hipStreamSynchronize(c->stream);
+  if (c->work) (void)hipFree(c->work);
+  if (c->partial) (void)hipFree(c->partial);
+  if (c->negcnt) (void)hipFree(c->negcnt);
+  if (c->mom) (void)hipFree(c->mom);
+  if (c->d_res) (void)hipFree(c->d_res);
+  if (c->counter) (void)hipFree(c->counter);
+  if (c->kuf_buf) (void)hipFree(c->kuf_buf);
   if (c->gws) { c->gws->release(); delete c->gws; }
   for (auto& e : c->ev)
-    if (e) hipEventDestroy(e);
-  if (c->own_stream) hipStreamDestroy(c->stream);
+    if (e) (void)hipEventDestroy(e);
+  if (c->own_stream) (void)hipStreamDestroy(c->stream);
   delete c;
   return SVGP_OK;
 }
@@ -581,10 +581,10 @@ int32_t svgp_data_wrap_device(svgp_ctx* ctx, int32_t dtype, int32_t d, int64_t n
 
 int32_t svgp_data_free(svgp_ctx* ctx, svgp_data* D) {
   if (!D) return SVGP_OK;
-  if (ctx) hipSetDevice(ctx->device);
+  if (ctx) (void)hipSetDevice(ctx->device);
   if (D->own) {
-    if (D->x) hipFree(D->x);
-    if (D->y) hipFree(D->y);
+    if (D->x) (void)hipFree(D->x);
+    if (D->y) (void)hipFree(D->y);
   }
   delete D;
   return SVGP_OK;
@@ -592,10 +592,10 @@ int32_t svgp_data_free(svgp_ctx* ctx, svgp_data* D) {
 
 int32_t svgp_model_free(svgp_ctx* ctx, svgp_model* m) {
   if (!m) return SVGP_OK;
-  if (ctx) hipSetDevice(ctx->device);
+  if (ctx) (void)hipSetDevice(ctx->device);
   void* bufs[] = {m->z_raw, m->m_raw, m->Lq_raw, m->invl, m->zs, m->L, m->T, m->U, m->mp, m->B, m->scal, m->info, m->gh_x, m->gh_w};
   for (void* b : bufs)
-    if (b) hipFree(b);
+    if (b) (void)hipFree(b);
   delete m;
   return SVGP_OK;
 }
@@ -723,7 +723,7 @@ int32_t svgp_kuf(svgp_ctx* ctx, svgp_model* m, const svgp_data* data, int64_t of
   hipStream_t s = ctx->stream;
   const size_t bytes = size_t(m->M) * size_t(len) * m->es;
   if (bytes > ctx->kuf_bytes) {
-    if (ctx->kuf_buf) hipFree(ctx->kuf_buf);
+    if (ctx->kuf_buf) (void)hipFree(ctx->kuf_buf);
     ctx->kuf_buf = nullptr;
     ctx->kuf_bytes = 0;
     HIPC(ctx, hipMalloc(&ctx->kuf_buf, bytes));
@@ -737,7 +737,7 @@ int32_t svgp_kuf(svgp_ctx* ctx, svgp_model* m, const svgp_data* data, int64_t of
   if (Kuf_out_host) HIPC(ctx, hipMemcpyAsync(Kuf_out_host, ctx->kuf_buf, bytes, hipMemcpyDeviceToHost, s));
   HIPC(ctx, hipStreamSynchronize(s));
   float t = 0;
-  hipEventElapsedTime(&t, ctx->ev[0], ctx->ev[1]);
+  (void)hipEventElapsedTime(&t, ctx->ev[0], ctx->ev[1]);
   ctx->timing = svgp_timing{};
   ctx->timing.ms_kuf = t;
   ctx->timing.ms_total = t;
@@ -777,7 +777,7 @@ int32_t svgp_posterior(svgp_ctx* ctx, svgp_model* m, void* Lk_out, void* alpha_o
     HIPC(ctx, hipStreamSynchronize(s));
   }
   HIPC(ctx, hipGetLastError());
-  hipFree(tmp);
+  (void)hipFree(tmp);
   return SVGP_OK;
 }
 
@@ -816,7 +816,7 @@ static int32_t predict_impl(svgp_ctx* ctx, svgp_model* m, int32_t layout, int64_
   }
   auto cleanup = [&]() {
     for (void* p : {mu, var, Ax, Cx, Ay, Cy, cov})
-      if (p) hipFree(p);
+      if (p) (void)hipFree(p);
     svgp_data_free(ctx, X);
     svgp_data_free(ctx, Y);
   };
@@ -838,12 +838,12 @@ static int32_t predict_impl(svgp_ctx* ctx, svgp_model* m, int32_t layout, int64_
   hipError_t le = hipGetLastError();
   if (rc == SVGP_OK && le != hipSuccess) rc = fail(ctx, SVGP_HIP_ERROR, hipGetErrorString(le));
   if (rc == SVGP_OK) {
-    if (mean_out) hipMemcpyAsync(mean_out, mu, size_t(nx) * es, hipMemcpyDeviceToHost, s);
-    if (var_out) hipMemcpyAsync(var_out, var, size_t(nx) * es, hipMemcpyDeviceToHost, s);
-    if (want_cov) hipMemcpyAsync(cov_out, cov, size_t(nx) * size_t(cross ? ny : nx) * es, hipMemcpyDeviceToHost, s);
+    if (mean_out) (void)hipMemcpyAsync(mean_out, mu, size_t(nx) * es, hipMemcpyDeviceToHost, s);
+    if (var_out) (void)hipMemcpyAsync(var_out, var, size_t(nx) * es, hipMemcpyDeviceToHost, s);
+    if (want_cov) (void)hipMemcpyAsync(cov_out, cov, size_t(nx) * size_t(cross ? ny : nx) * es, hipMemcpyDeviceToHost, s);
     if (hipStreamSynchronize(s) != hipSuccess) rc = fail(ctx, SVGP_HIP_ERROR, "stream sync failed in predict");
   } else {
-    hipStreamSynchronize(s);
+    (void)hipStreamSynchronize(s);
   }
   cleanup();
   return rc;
@@ -1034,8 +1034,8 @@ extern "C" int32_t svgp_elbo_grad(svgp_ctx* ctx, svgp_model* m, const svgp_data*
   HIPC(ctx, hipStreamSynchronize(s));
   finish_prep(m, ps);
   float t01 = 0, t13 = 0;
-  hipEventElapsedTime(&t01, ctx->ev[0], ctx->ev[1]);
-  hipEventElapsedTime(&t13, ctx->ev[1], ctx->ev[3]);
+  (void)hipEventElapsedTime(&t01, ctx->ev[0], ctx->ev[1]);
+  (void)hipEventElapsedTime(&t13, ctx->ev[1], ctx->ev[3]);
   ctx->timing = svgp_timing{};
   ctx->timing.ms_prep = t01;
   ctx->timing.ms_strip = t13;

@@ -79,9 +79,16 @@ __device__ __forceinline__ double kexp(double v) {
   p = fma(p, r, 1.0);
   return ldexp(p, int(n));                      // n < -1074 flushes to 0, as exp does
 }
-__device__ __forceinline__ float kexp(float v) { return expf(v); }
+// fp32: v_exp_f32 on v*log2(e) with the rounding residual of that product applied as a first-order correction
+// (5 instructions, <= 2 ulp; libm's expf costs ~12 with its range handling).  Results below the normal range flush to 0.
+__device__ __forceinline__ float kexp(float v) {
+  const float hi = v * 1.44269504088896341f;
+  const float lo = fmaf(v, 1.44269504088896341f, -hi) + v * 1.92596299112661746e-8f;   // log2(e) = hi + lo split
+  const float e = __builtin_amdgcn_exp2f(hi);
+  return fmaf(e, lo * 0.693147180559945309f, e);
+}
 __device__ __forceinline__ double ksqrt(double v) { return sqrt(v); }
-__device__ __forceinline__ float ksqrt(float v) { return sqrtf(v); }
+__device__ __forceinline__ float ksqrt(float v) { return __builtin_amdgcn_sqrtf(v); }   // v_sqrt_f32, 1 ulp
 
 template <typename T>
 __device__ __forceinline__ T kappa(int family, T r2, T variance) {

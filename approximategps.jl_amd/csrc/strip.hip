@@ -266,65 +266,110 @@ __global__ void final_reduce_kernel(const double* __restrict__ partial, const un
 
 // ---------------------------------------------------------------------------------------------
 // standalone Kuf assembly (SVA:216): M x len column-major, HBM-write bound (s*(M + d) bytes per point).
-// A 256-thread workgroup owns 64*VEC rows (inducing points) x JB columns (data points): every thread keeps
-// its VEC rows of the scaled z in registers for the whole block, the four waves take interleaved columns,
-// and a wave's store instruction writes 1 KB of ONE output column (whole 128-byte lines).  The scaled x of
-// the block sits in LDS and is read as a broadcast.
+// The pairwise distances of a 16-point x 16-inducing tile are one MFMA chain over the features,
+//   r2 = |x|^2 + |z|^2 - 2 x.z  (accumulator preloaded with the two norms, B operand = -2 z),
+// which leaves the VALU only the kernel function itself (f64 MFMA and VALU do not co-execute, and the direct
+// (x - z)^2 form costs 2 d VALU instructions per element).  SE folds everything into the exponent:
+//   acc = log(variance) - r2/2,  K = exp(min(acc, log variance)).
+// A 256-thread workgroup owns 256 inducing rows x JB points; a wave owns 64 rows: its -2z fragments stay in
+// registers for the whole block, the scaled x tile and its norms sit in LDS.  MFMA column c of block b is inducing
+// row (b / VEC) 16 VEC + c VEC + b % VEC, so a lane ends up with VEC consecutive rows of one column of Kuf and a
+// wave's store instruction writes 256 contiguous bytes of each of 4 columns.
+// Rounding: |x|^2 + |z|^2 - 2 x.z carries an absolute error of a few ulp of (|x|^2 + |z|^2) in r2, i.e. of that size
+// relative in K — parity with kernelmatrix() is tested at 1e-12 (f64) / 2e-5 (f32).
 // ---------------------------------------------------------------------------------------------
-template <typename T, int DREG, int JB, int FAMILY>
-__global__ void __launch_bounds__(k256) kuf_kernel(KernelParams kp, const T* __restrict__ zs, int64_t M, int64_t Mp,
+template <typename T, int DREG, int FAMILY>
+__global__ void __launch_bounds__(k256, 2) kuf_kernel(KernelParams kp, const T* __restrict__ zs, int64_t M, int64_t Mp,
                                                     const T* __restrict__ x, int64_t ldx, int64_t off, int64_t len,
                                                     T* __restrict__ K) {
-  constexpr int VEC = Vec16<T>::N;
+  constexpr int VEC = Vec16<T>::N, NBLK = 4, JB = 256, XLD = JB + 16, KS = DREG / 4;
   using V = typename Vec16<T>::type;
-  __shared__ T xt[JB * DREG];
+  using acc_t = typename Mfma16<T>::acc_t;
+  static_assert(JB == k256, "one staged point per thread");
+  __shared__ T xs[DREG * XLD];   // scaled inputs of the block, feature-major
+  __shared__ T xn[JB];           // c0 + c1 |x|^2
   const int d = kp.d;
   const T* __restrict__ invl = static_cast<const T*>(kp.invl);
-  const int64_t j0 = int64_t(blockIdx.x) * JB;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int64_t i = (int64_t(blockIdx.y) * 64 + lane) * VEC;
-  for (int e = threadIdx.x; e < JB * DREG; e += k256) {
-    const int c = e / DREG, f = e % DREG;
-    int64_t g = j0 + c;
-    g = g < len ? g : len - 1;
-    xt[e] = (f < d) ? x[int64_t(f) * ldx + off + g] * invl[f] : T(0);
-  }
-  T z[DREG][VEC];
-#pragma unroll
-  for (int f = 0; f < DREG; ++f) {
-    V zv = V(0);
-    if (f < d && i < Mp) zv = *reinterpret_cast<const V*>(zs + int64_t(f) * Mp + i);  // Mp multiple of 128: aligned
-#pragma unroll
-    for (int e = 0; e < VEC; ++e) z[f][e] = zv[e];
-  }
-  __syncthreads();
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c = lane & 15, kq = lane >> 4;
+  // consecutive workgroups walk down the inducing rows of the same JB columns: the workgroups in flight write whole
+  // columns, i.e. one contiguous region of Kuf, instead of a 1-2 KB piece out of every column
+  const int nI = int((M + 255) / 256);
+  const int64_t j0 = int64_t(blockIdx.x / nI) * JB;
+  const int64_t ibase = (int64_t(blockIdx.x % nI) * 4 + wave) * 64;
   const T variance = T(kp.variance);
-  const bool vec_ok = (M % VEC == 0) && (i + VEC <= M);
-#pragma unroll 2
-  for (int c = wave; c < JB; c += 4) {
-    const int64_t j = j0 + c;
-    if (j >= len) break;
-    T r2[VEC];
-#pragma unroll
-    for (int e = 0; e < VEC; ++e) r2[e] = T(0);
+  const T c1 = (FAMILY == KSE) ? T(-0.5) : T(1);
+  const T c0 = (FAMILY == KSE) ? T(log(kp.variance)) : T(0);
+  const T bscale = (FAMILY == KSE) ? T(1) : T(-2);
+  {
+    int64_t g = j0 + tid;
+    g = g < len ? g : len - 1;
+    T s = T(0);
 #pragma unroll
     for (int f = 0; f < DREG; ++f) {
-      const T xv = xt[c * DREG + f];
-#pragma unroll
-      for (int e = 0; e < VEC; ++e) {
-        const T df = xv - z[f][e];
-        r2[e] = fma(df, df, r2[e]);
-      }
+      const T v = (f < d) ? x[int64_t(f) * ldx + off + g] * invl[f] : T(0);
+      xs[f * XLD + tid] = v;
+      s = fma(v, v, s);
     }
-    V out;
+    xn[tid] = fma(c1, s, c0);
+  }
+  T zb[NBLK][KS], zn[NBLK];
 #pragma unroll
-    for (int e = 0; e < VEC; ++e) out[e] = kappa<T>(FAMILY, r2[e], variance);   // FAMILY is a compile-time constant
-    if (vec_ok) {
-      *reinterpret_cast<V*>(K + j * M + i) = out;
-    } else {
+  for (int b = 0; b < NBLK; ++b) {
+    const int64_t i = ibase + (b / VEC) * (16 * VEC) + c * VEC + (b % VEC);
+    T s = T(0);
+    for (int f = 0; f < d; ++f) {
+      const T v = (i < Mp) ? zs[int64_t(f) * Mp + i] : T(0);
+      s = fma(v, v, s);
+    }
+    zn[b] = c1 * s;
 #pragma unroll
-      for (int e = 0; e < VEC; ++e)
-        if (i + e < M) K[j * M + i + e] = out[e];
+    for (int q = 0; q < KS; ++q) {
+      const int f = 4 * q + kq;
+      zb[b][q] = (f < d && i < Mp) ? bscale * zs[int64_t(f) * Mp + i] : T(0);
+    }
+  }
+  __syncthreads();
+  if (ibase >= M) return;
+  const bool vec_ok = (M % VEC == 0);
+  for (int jg = 0; jg < JB / 16; ++jg) {
+    const int64_t jb = j0 + jg * 16;
+    if (jb >= len) break;
+    T a[KS], xr[4];
+#pragma unroll
+    for (int q = 0; q < KS; ++q) a[q] = xs[(4 * q + kq) * XLD + jg * 16 + c];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) xr[r] = xn[jg * 16 + Mfma16<T>::row(lane, r)];
+    acc_t acc[NBLK];
+#pragma unroll
+    for (int b = 0; b < NBLK; ++b)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[b][r] = xr[r] + zn[b];
+#pragma unroll
+    for (int q = 0; q < KS; ++q)
+#pragma unroll
+      for (int b = 0; b < NBLK; ++b) acc[b] = Mfma16<T>::mma(a[q], zb[b][q], acc[b]);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int64_t j = jb + Mfma16<T>::row(lane, r);
+      if (j >= len) continue;
+#pragma unroll
+      for (int g = 0; g < NBLK / VEC; ++g) {
+        V out;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+          const T v = acc[g * VEC + e][r];
+          out[e] = (FAMILY == KSE) ? kexp(v < c0 ? v : c0) : kappa<T>(FAMILY, v > T(0) ? v : T(0), variance);
+        }
+        const int64_t i = ibase + g * (16 * VEC) + c * VEC;
+        T* dst = K + j * M + i;
+        if (vec_ok && i + VEC <= M) {
+          *reinterpret_cast<V*>(dst) = out;
+        } else {
+#pragma unroll
+          for (int e = 0; e < VEC; ++e)
+            if (i + e < M) dst[e] = out[e];
+        }
+      }
     }
   }
 }
@@ -409,17 +454,14 @@ void launch_final_reduce(hipStream_t s, const double* partial, const unsigned* n
 template <typename T, int FAMILY>
 static void launch_kuf_f(hipStream_t s, const KernelParams& kp, const T* zs, int64_t M, int64_t Mp, const T* x, int64_t ldx,
                          int64_t off, int64_t len, T* Kuf) {
-  constexpr int VEC = Vec16<T>::N, JB = 256;
-  const unsigned gy = (unsigned)((Mp + 64 * VEC - 1) / (64 * VEC));
-  if (kp.d <= 8)
-    hipLaunchKernelGGL((kuf_kernel<T, 8, JB, FAMILY>), dim3((unsigned)((len + JB - 1) / JB), gy), dim3(k256), 0, s, kp, zs, M, Mp,
-                       x, ldx, off, len, Kuf);
-  else if (kp.d <= 16)
-    hipLaunchKernelGGL((kuf_kernel<T, 16, JB, FAMILY>), dim3((unsigned)((len + JB - 1) / JB), gy), dim3(k256), 0, s, kp, zs, M, Mp,
-                       x, ldx, off, len, Kuf);
-  else
-    hipLaunchKernelGGL((kuf_kernel<T, 32, JB / 2, FAMILY>), dim3((unsigned)((len + JB / 2 - 1) / (JB / 2)), gy), dim3(k256), 0, s,
-                       kp, zs, M, Mp, x, ldx, off, len, Kuf);
+  const dim3 grid((unsigned)(((len + 255) / 256) * ((M + 255) / 256)));
+#define SVGP_KUF_LAUNCH(DREG) \
+  hipLaunchKernelGGL((kuf_kernel<T, DREG, FAMILY>), grid, dim3(k256), 0, s, kp, zs, M, Mp, x, ldx, off, len, Kuf)
+  if (kp.d <= 4) SVGP_KUF_LAUNCH(4);
+  else if (kp.d <= 8) SVGP_KUF_LAUNCH(8);
+  else if (kp.d <= 16) SVGP_KUF_LAUNCH(16);
+  else SVGP_KUF_LAUNCH(32);
+#undef SVGP_KUF_LAUNCH
 }
 
 template <typename T>

@@ -1,0 +1,87 @@
+#!/usr/bin/env python3
+"""Summarise one tools/run_profile.sh output directory (gpurun_out/prof_<tag>) into the two files committed under
+profiles/: <name>_kernel_stats.csv (rocprofv3 --stats, verbatim) and <name>_pmc.json (per-kernel PMC means).
+
+usage: summarize_profile.py gpurun_out/prof_<tag> profiles/round1/<name>
+
+FETCH_SIZE is doubled as MI355X_MICROARCH.md prescribes for gfx950 (wide loads are tallied at half)."""
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+from collections import defaultdict
+
+
+def short(name):
+    n = name.replace("void svgp::(anonymous namespace)::", "").replace("svgp::", "")
+    return n.split("(")[0]
+
+
+def counters(d):
+    acc = defaultdict(lambda: defaultdict(list))
+    for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+        disp, grid = defaultdict(dict), {}
+        for r in csv.DictReader(open(f)):
+            disp[(r["Dispatch_Id"], r["Kernel_Name"])][r["Counter_Name"]] = float(r["Counter_Value"])
+            grid[(r["Dispatch_Id"], r["Kernel_Name"])] = int(r["Grid_Size"])
+        gmax = defaultdict(int)
+        for (_, k), g in grid.items():
+            gmax[k] = max(gmax[k], g)
+        for (i, k), c in disp.items():
+            if grid[(i, k)] != gmax[k]:
+                continue   # only the full-size launches of a kernel (the bench's own), not helper-sized ones
+            for cn, v in c.items():
+                acc[short(k)][cn].append(v)
+    return {k: {cn: sum(v) / len(v) for cn, v in c.items()} for k, c in acc.items()}
+
+
+def main():
+    src, dst = sys.argv[1], sys.argv[2]
+    stats = sorted(glob.glob(os.path.join(src, "stats", "**", "*kernel_stats.csv"), recursive=True), key=os.path.getsize)[-1]
+    shutil.copy(stats, dst + "_kernel_stats.csv")
+    trace = stats.replace("kernel_stats", "kernel_trace")
+    rows = [(short(r["Kernel_Name"]), int(r["Grid_Size_X"]) * int(r["Grid_Size_Y"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+            for r in csv.DictReader(open(trace))]
+    gmax = defaultdict(int)
+    for k, g, _ in rows:
+        gmax[k] = max(gmax[k], g)
+    dur = defaultdict(list)
+    for k, g, t in rows:
+        if g == gmax[k]:
+            dur[k].append(t)
+    ms = {k: sum(v) / len(v) / 1e6 for k, v in dur.items()}
+    tot = {k: sum(v) for k, v in dur.items()}
+    out = {"source": "tools/run_profile.sh: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ_* in three separate passes",
+           "bench_line": json.loads(open(os.path.join(src, "bench_plain.json")).read().strip().splitlines()[-1])}
+    fetch, write, sq = (counters(os.path.join(src, p)) for p in ("fetch", "write", "sq"))
+    for k in sorted(tot, key=tot.get, reverse=True)[:8]:
+        e = {"ms_per_launch_rocprof": round(ms[k], 4)}
+        if k in fetch and "FETCH_SIZE" in fetch[k]:
+            e["FETCH_SIZE_KB_raw"] = fetch[k]["FETCH_SIZE"]
+            e["fetch_bytes_corrected"] = 2.0 * 1024.0 * fetch[k]["FETCH_SIZE"]
+        if k in write and "WRITE_SIZE" in write[k]:
+            e["write_bytes"] = 1024.0 * write[k]["WRITE_SIZE"]
+        if "fetch_bytes_corrected" in e and "write_bytes" in e:
+            e["traffic_bytes_per_launch"] = e["fetch_bytes_corrected"] + e["write_bytes"]
+        c = sq.get(k, {})
+        if "GRBM_GUI_ACTIVE" in c:
+            e["GRBM_GUI_ACTIVE"] = c["GRBM_GUI_ACTIVE"]
+            e["clock_GHz"] = round(c["GRBM_GUI_ACTIVE"] / 8.0 / (ms[k] * 1e6), 3)   # summed over the 8 XCDs
+            if "SQ_VALU_MFMA_BUSY_CYCLES" in c:
+                # busy cycles are summed over the 1024 SIMDs of the chip
+                e["mfma_busy_frac"] = round(c["SQ_VALU_MFMA_BUSY_CYCLES"] / (c["GRBM_GUI_ACTIVE"] * 1024.0 / 8.0), 4)
+            for n in ("SQ_INSTS_MFMA", "SQ_INSTS_VALU"):
+                if n in c:
+                    e[n] = c[n]
+            if c.get("SQ_WAVE_CYCLES"):
+                e["SQ_WAIT_ANY/SQ_WAVE_CYCLES"] = c.get("SQ_WAIT_ANY", 0.0) / c["SQ_WAVE_CYCLES"]
+                e["SQ_WAIT_INST_ANY/SQ_WAVE_CYCLES"] = c.get("SQ_WAIT_INST_ANY", 0.0) / c["SQ_WAVE_CYCLES"]
+        out[k] = e
+    json.dump(out, open(dst + "_pmc.json", "w"), indent=1)
+    print(json.dumps({k: v for k, v in out.items() if k not in ("source", "bench_line")}, indent=1)[:3000])
+
+
+if __name__ == "__main__":
+    main()
