@@ -329,10 +329,10 @@ struct StripOuts {
 // enqueue the fused strip kernel + final reduce over points [off, off+len) of (x, y)
 int enqueue_strips(svgp_ctx* ctx, svgp_model* m, const void* x, int64_t ldx, const void* y, int64_t off, int64_t len,
                    const StripOuts& o) {
-  const int nt = strip_nt(m->dtype, m->Mp, len);
-  const int64_t nstrips = (len + nt - 1) / nt;
-  const int grid = strip_grid(m->dtype, nt, nstrips, ctx->num_cus);
-  int rc = ensure_scratch(ctx, strip_work_bytes(m->dtype, m->Mp, nt, grid), size_t(len));
+  const StripPlan plan = strip_plan(m->dtype, m->Mp, len, ctx->num_cus);
+  const size_t wb_main = plan.grid ? strip_work_bytes(m->dtype, m->Mp, plan.nt, plan.grid) : 0;
+  const size_t wb_tail = plan.nt_tail ? strip_work_bytes(m->dtype, m->Mp, plan.nt_tail, plan.grid_tail) : 0;
+  int rc = ensure_scratch(ctx, wb_main > wb_tail ? wb_main : wb_tail, size_t(len));
   if (rc) return rc;
   StripArgs a{};
   a.T = m->T;
@@ -364,16 +364,36 @@ int enqueue_strips(svgp_ctx* ctx, svgp_model* m, const void* x, int64_t ldx, con
   lp.gh_w = m->gh_w;
   lp.clamp_neg_var = (m->desc.neg_var_policy == SVGP_NEGVAR_CLAMP);
   lp.mean_const = m->desc.mean_const;
-  HIPC(ctx, hipMemsetAsync(ctx->counter, 0, sizeof(unsigned), ctx->stream));
-  launch_strip(m->dtype, ctx->stream, a, nt, grid, nstrips);
-  KCHECK(ctx, "strip");
+  if (plan.grid) {
+    StripArgs am = a;
+    am.len = plan.points;
+    HIPC(ctx, hipMemsetAsync(ctx->counter, 0, sizeof(unsigned), ctx->stream));
+    launch_strip(m->dtype, ctx->stream, am, plan.nt, plan.grid, plan.nstrips);
+    KCHECK(ctx, "strip");
+  }
+  if (plan.nt_tail) {   // remaining points as half-width strips: same arithmetic per point, outputs shifted by plan.points
+    StripArgs at = a;
+    const int64_t sh = plan.points;
+    const size_t es = m->es;
+    at.off = off + sh;
+    at.len = len - sh;
+    at.mom_mu = a.mom_mu + sh;
+    at.mom_var = a.mom_var + sh;
+    if (a.A_out) at.A_out = static_cast<char*>(a.A_out) + size_t(sh) * es;
+    if (a.C_out) at.C_out = static_cast<char*>(a.C_out) + size_t(sh) * es;
+    if (a.At_out) at.At_out = static_cast<char*>(a.At_out) + size_t(sh) * size_t(m->Mp) * es;
+    if (a.Ct_out) at.Ct_out = static_cast<char*>(a.Ct_out) + size_t(sh) * size_t(m->Mp) * es;
+    HIPC(ctx, hipMemsetAsync(ctx->counter, 0, sizeof(unsigned), ctx->stream));
+    launch_strip(m->dtype, ctx->stream, at, plan.nt_tail, plan.grid_tail, plan.nstrips_tail);
+    KCHECK(ctx, "strip tail");
+  }
   HIPC(ctx, hipEventRecord(ctx->ev[2], ctx->stream));
   if (o.skip_expect) return SVGP_OK;
   launch_expect(m->dtype, ctx->stream, lp, a.mom_mu, a.mom_var, y, off, len, ctx->partial, ctx->negcnt, o.mu, o.var);
   KCHECK(ctx, "expect");
   launch_final_reduce(ctx->stream, ctx->partial, ctx->negcnt, expect_blocks(len), ctx->d_res);
   KCHECK(ctx, "final_reduce");
-  ctx->timing.strip_launches = 1;
+  ctx->timing.strip_launches = (plan.grid ? 1 : 0) + (plan.nt_tail ? 1 : 0);
   HIPC(ctx, hipGetLastError());
   return SVGP_OK;
 }

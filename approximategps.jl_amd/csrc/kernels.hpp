@@ -81,6 +81,13 @@ struct StripArgs {
 int strip_nt(int dtype, int64_t Mp, int64_t len);                 // column-strip width chosen for a problem
 size_t strip_work_bytes(int dtype, int64_t Mp, int nt, int grid);  // workspace bytes
 int strip_grid(int dtype, int nt, int64_t nstrips, int num_cus);
+struct StripPlan {       // regular-width launch over the first `points` points, then an optional half-width tail launch
+  int nt, grid;
+  int64_t nstrips, points;
+  int nt_tail, grid_tail;
+  int64_t nstrips_tail;
+};
+StripPlan strip_plan(int dtype, int64_t Mp, int64_t len, int num_cus);
 void launch_strip(int dtype, hipStream_t s, const StripArgs& a, int nt, int grid, int64_t nstrips);
 // marginals + expected log-likelihood of every point (SVA:354-355): per-block sums into partial/negcnt
 int expect_blocks(int64_t len);

@@ -409,14 +409,39 @@ size_t strip_work_bytes(int dtype, int64_t Mp, int nt, int grid) {
 
 int strip_grid(int dtype, int nt, int64_t nstrips, int num_cus) {
   // two workgroups per CU (measured: a third f32 workgroup fits but is 7 % slower; SVGP_WG_PER_CU overrides)
-  const int per_cu = env_int("SVGP_WG_PER_CU", (nt == 64 || dtype == 1) ? 2 : 1);
+  const int per_cu = env_int("SVGP_WG_PER_CU", (nt <= 64 || dtype == 1) ? 2 : 1);
   const int64_t cap = int64_t(num_cus) * per_cu;
   return int(nstrips < cap ? nstrips : cap);
 }
 
+// Strip schedule of one batch.  A batch with fewer regular-width strips than half the workgroup slots (minibatches:
+// 4096 points are 64 strips for 512 slots) leaves most of the chip idle, so it runs as half-width strips instead (the
+// narrower build: half the MFMA work per strip, twice the T/U bytes per flop) — measured at M = 1024 on 4096 / 16384
+// points: 0.86 -> 0.55 ms / 0.93 -> 0.76 ms (f64), 0.78 -> 0.47 / 0.80 -> 0.51 ms (f32).  Per-point arithmetic does not
+// depend on the strip width, so the ELBO is bitwise the same (tests/test_gpu_parity.py).
+// Measured and rejected: running the last partial round of a large batch as a second, half-width launch (N = 1e5:
+// 4.59 vs 4.62 ms, N = 2e5: 8.05 vs 8.31 ms) — the single launch's dynamic queue already hands the last strips to the
+// workgroups that finish first, and those then run alone on their CU at ~0.65 of the paired strip time.
+StripPlan strip_plan(int dtype, int64_t Mp, int64_t len, int num_cus) {
+  StripPlan p{};
+  const int W = strip_nt(dtype, Mp, len);
+  const int W2 = (dtype == 0 && W == 64) ? 32 : (dtype == 1 && W == 128) ? 64 : 0;
+  const int64_t S = (len + W - 1) / W;
+  p.nt = W; p.nstrips = S; p.points = len; p.grid = strip_grid(dtype, W, S, num_cus);
+  static const int enabled = env_int("SVGP_TAIL", 1);
+  if (!W2 || !enabled) return p;
+  const int64_t S2 = (len + W2 - 1) / W2;
+  if (S2 > strip_grid(dtype, W2, INT64_MAX, num_cus)) return p;
+  p.nstrips = 0; p.points = 0; p.grid = 0;
+  p.nt_tail = W2; p.nstrips_tail = S2; p.grid_tail = strip_grid(dtype, W2, S2, num_cus);
+  return p;
+}
+
 void launch_strip(int dtype, hipStream_t s, const StripArgs& a, int nt, int grid, int64_t nstrips) {
   static const bool bk32 = env_int("SVGP_STRIP_BK", 16) == 32;
-  if (nt == 64) {
+  if (nt == 32 && dtype == 0) {
+    launch_strip_t<double, 32, 16, 256>(s, a, grid, nstrips);
+  } else if (nt == 64) {
     if (dtype == 0) launch_strip_t<double, 64, 16, 256>(s, a, grid, nstrips);
     else launch_strip_t<float, 64, 16, 256>(s, a, grid, nstrips);   // BK = 32 measured identical
   } else if (dtype == 1 && env_int("SVGP_F32_THREADS", 256) == 256) {

@@ -11,6 +11,8 @@ import svgp_oracle as o
 from approxgp import _ffi
 from helpers import device_model, rel
 
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
 pytestmark = pytest.mark.gpu
 
 F64_RTOL = 1e-8
@@ -295,3 +297,26 @@ def test_one_shot_elbo_host_entry_point(ctx):
     rc = ctx.lib.svgp_elbo_host(ctx.h, C.byref(desc), _ffi.COLVECS, 500, xb.ctypes.data_as(C.c_void_p), None, 0.0,
                                 C.byref(out), None)
     assert rc == _ffi.INVALID_ARG and b"null" in ctx.lib.svgp_last_error(ctx.h)
+
+
+def test_half_width_strips_are_bitwise_identical():
+    """Small batches run as half-width strips (strip_plan); the per-point arithmetic must not depend on the width.
+    SVGP_TAIL is read once per process, so the two schedules run in two child processes."""
+    import os
+    import subprocess
+    import sys
+
+    code = (
+        "import sys, numpy as np; sys.path[:0] = [%r, %r, %r]\n"
+        "import svgp_oracle as o; from approxgp import _ffi; from helpers import device_model\n"
+        "ctx = _ffi.Context(0)\n"
+        "for dt in (np.float64, np.float32):\n"
+        "    x, y, sva, s2 = o.synth_problem(77, 5000, 200, 3, dtype=dt)\n"
+        "    m = device_model(ctx, sva, dtype=dt, sigma2=s2); d = _ffi.DeviceData(ctx, x, y, dt)\n"
+        "    print(repr(m.elbo(d, 0, 5000, 5000.0)[0]), repr(m.elbo(d, 100, 777, 5000.0)[0]))\n"
+    ) % (os.path.join(ROOT, "oracle"), os.path.join(ROOT, "approximategps.jl_amd"), os.path.join(ROOT, "tests"))
+    outs = []
+    for tail in ("0", "1"):
+        env = dict(os.environ, SVGP_TAIL=tail)
+        outs.append(subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, check=True).stdout)
+    assert outs[0] == outs[1] and len(outs[0].split()) == 4, outs
