@@ -16,7 +16,9 @@ equivalences and bounds only).  This restatement is therefore pinned by
   * derived known-answer tests (Titsias collapsed bound, GH == analytic for a
     Gaussian likelihood, K_uf' alpha == A' m, 50-digit mpmath restatement in
     oracle/svgp_oracle_mp.py),
-not by reference outputs.
+not by reference outputs.  oracle/reference_julia.jl evaluates the real
+reference on the committed tests/golden/*.npz inputs and prints its difference
+from the oracle values stored there -- the way to pin this for anyone with Julia.
 
 Every function cites the reference lines it follows.  Paths are relative to
 /root/reference; ``SVA`` = src/SparseVariationalApproximationModule.jl.
