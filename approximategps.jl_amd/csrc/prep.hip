@@ -294,6 +294,50 @@ __global__ void __launch_bounds__(kThreads, 2) tile128_kernel(T* __restrict__ A,
   }
 }
 
+// Latency-bound small-grid variant of the TRSM / SYRK tiles: one 128x128 f64 tile product is 14 us of MFMA time on a
+// single CU, and a panel step of a small Kuu has only a handful of tiles, so each output tile is split into 128/NT column
+// chunks on 256-thread workgroups (f64: 4 x (128 x 32), f32: 2 x (128 x 64)) that run on different CUs
+// (rocprofv3, M = 1024 f64: TRSM 22.5 -> 11.9 us, SYRK 28 -> 12-19 us per panel step).
+template <typename T, int MODE, int NT>
+__global__ void __launch_bounds__(k256, 2) chol_tile_kernel(T* __restrict__ A, const T* __restrict__ Tm, int64_t ld, int p) {
+  using G = TileGemm<T, NT, 16, k256>;
+  using QRegs = typename G::QRegs;
+  constexpr int NB = kNB, NCH = NB / NT;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  T* smem = reinterpret_cast<T*>(smem_raw);
+  typename G::Acc acc;
+  acc.zero();
+  const int chunk = blockIdx.x % NCH, tile = blockIdx.x / NCH;
+  int i, j;
+  const T* P;
+  if (MODE == MODE_TRSM) {       // L[i, p] = A[i, p] inv(L_pp)'  (see tile128_kernel)
+    i = p + 1 + tile;
+    j = p;
+    P = Tm + int64_t(p) * NB + int64_t(p) * NB * ld;
+  } else {                       // A[i, j] -= L[i, p] L[j, p]'
+    int ti, tj;
+    tri_index(tile, ti, tj);
+    i = p + 1 + ti;
+    j = p + 1 + tj;
+    P = A + int64_t(j) * NB + int64_t(p) * NB * ld;
+  }
+  const T* Q = A + int64_t(i) * NB + int64_t(p) * NB * ld + chunk * NT;
+  const typename G::QOff qoff = G::q_offsets(ld);
+  auto qload = [&](int t, QRegs& r) { G::load_q(r, Q + int64_t(t) * 16 * ld, qoff); };
+  G::loop(acc, P, ld, NB / 16, qload, smem);
+  T* C = A + int64_t(i) * NB + int64_t(j) * NB * ld + chunk * NT;
+#pragma unroll
+  for (int a = 0; a < G::MI; ++a)
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int b = 0; b < G::NJ; ++b) {
+        T* dst = C + G::acc_col(b) + int64_t(G::acc_row(a, r)) * ld;
+        if (MODE == MODE_TRSM) *dst = acc.v[a][b][r];
+        else *dst -= acc.v[a][b][r];
+      }
+}
+
 // ------------------------------------------------------------------------------------------------
 template <typename T>
 __global__ void pack_q_kernel(const T* __restrict__ Lq, int64_t ldq, const T* __restrict__ m, int64_t M, int64_t Mp,
@@ -536,8 +580,11 @@ void potrf_t(hipStream_t s, T* A, T* Tm, int64_t Mp, int* info) {
   const int nP = int(Mp / kNB);
   const size_t lds_potf2 = (size_t(kNB) * (kNB + 1) + 8 * 16 * 17) * sizeof(T);
   set_max_lds(reinterpret_cast<const void*>(potf2_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds_potf2));
-  set_max_lds(reinterpret_cast<const void*>(tile128_kernel<T, MODE_TRSM>), hipFuncAttributeMaxDynamicSharedMemorySize, int(G::LDS_BYTES));
+  constexpr int CNT = sizeof(T) == 8 ? 32 : 64, NCH = kNB / CNT;
+  using GS = TileGemm<T, CNT, 16, k256>;
   set_max_lds(reinterpret_cast<const void*>(tile128_kernel<T, MODE_SYRK>), hipFuncAttributeMaxDynamicSharedMemorySize, int(G::LDS_BYTES));
+  set_max_lds(reinterpret_cast<const void*>(chol_tile_kernel<T, MODE_TRSM, CNT>), hipFuncAttributeMaxDynamicSharedMemorySize, int(GS::LDS_BYTES));
+  set_max_lds(reinterpret_cast<const void*>(chol_tile_kernel<T, MODE_SYRK, CNT>), hipFuncAttributeMaxDynamicSharedMemorySize, int(GS::LDS_BYTES));
   for (int p = 0; p < nP; ++p) {
     T* diagA = A + int64_t(p) * kNB * (Mp + 1);
     T* diagT = Tm + int64_t(p) * kNB * (Mp + 1);
@@ -545,9 +592,13 @@ void potrf_t(hipStream_t s, T* A, T* Tm, int64_t Mp, int* info) {
     dbg("potf2", s);
     const int n = nP - p - 1;
     if (n > 0) {
-      hipLaunchKernelGGL((tile128_kernel<T, MODE_TRSM>), dim3(n), dim3(kThreads), G::LDS_BYTES, s, A, Tm, Mp, p);
-      dbg("tile128 trsm", s);
-      hipLaunchKernelGGL((tile128_kernel<T, MODE_SYRK>), dim3(n * (n + 1) / 2), dim3(kThreads), G::LDS_BYTES, s, A, Tm, Mp, p);
+      hipLaunchKernelGGL((chol_tile_kernel<T, MODE_TRSM, CNT>), dim3(n * NCH), dim3(k256), GS::LDS_BYTES, s, A, Tm, Mp, p);
+      dbg("chol trsm", s);
+      const int nt = n * (n + 1) / 2;
+      if (nt >= 256)   // a trailing matrix that fills the chip by itself: full 128 x 128 tiles (half the operand traffic)
+        hipLaunchKernelGGL((tile128_kernel<T, MODE_SYRK>), dim3(nt), dim3(kThreads), G::LDS_BYTES, s, A, Tm, Mp, p);
+      else
+        hipLaunchKernelGGL((chol_tile_kernel<T, MODE_SYRK, CNT>), dim3(nt * NCH), dim3(k256), GS::LDS_BYTES, s, A, Tm, Mp, p);
     }
   }
 }
