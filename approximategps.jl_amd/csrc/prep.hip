@@ -76,6 +76,31 @@ __device__ __forceinline__ float readlane_t(float v, int srclane) {
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), srclane));
 }
 
+// 1/sqrt(d) from the hardware estimate (v_rsq: ~24 bits) and Newton steps; with the residual corrections at the use
+// sites the pivot and the scaled column are within 1 ulp of sqrt / divide, at a third of their dependent latency
+// (the libm sqrt + divide chain was the longest part of every one of the 128 serial column steps of a block).
+__device__ __forceinline__ double krsqrt(double d) {
+  double r = __builtin_amdgcn_rsq(d);
+  r = fma(0.5 * r, fma(-d * r, r, 1.0), r);
+  r = fma(0.5 * r, fma(-d * r, r, 1.0), r);
+  return r;
+}
+__device__ __forceinline__ float krsqrt(float d) {
+  float r = __builtin_amdgcn_rsqf(d);
+  r = fmaf(0.5f * r, fmaf(-d * r, r, 1.0f), r);
+  return r;
+}
+
+#ifdef SVGP_POTF2_STAMPS   // diagnostic build (tools/build_ablate.sh stamps): s_memtime at the phase boundaries of potf2
+__device__ unsigned long long g_potf2_stamps[64];
+#define SVGP_STAMP(i) do { if (threadIdx.x == 0) g_potf2_stamps[i] = clock64(); } while (0)
+extern "C" int svgp_debug_potf2_stamps(unsigned long long* out) {
+  return int(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_potf2_stamps), sizeof(g_potf2_stamps)));
+}
+#else
+#define SVGP_STAMP(i)
+#endif
+
 template <typename T>
 __global__ void __launch_bounds__(k256) potf2_kernel(T* __restrict__ A, T* __restrict__ Tm, int64_t ld,
                                                       int* __restrict__ info, int pbase) {
@@ -88,6 +113,7 @@ __global__ void __launch_bounds__(k256) potf2_kernel(T* __restrict__ A, T* __res
   __shared__ int failed;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l15 = lane & 15, g = lane >> 4;
+  SVGP_STAMP(0);
   if (tid == 0) failed = (*info != 0) ? -1 : 0;
   for (int e = tid; e < NB * NB; e += k256) {
     const int i = e % NB, j = e / NB;
@@ -96,43 +122,61 @@ __global__ void __launch_bounds__(k256) potf2_kernel(T* __restrict__ A, T* __res
   __syncthreads();
   if (failed) return;  // an earlier panel already reported the first bad pivot
 
+  SVGP_STAMP(1);
   for (int p = 0; p < NBLK; ++p) {
     const int o = 16 * p;
+    SVGP_STAMP(2 + 4 * p);
     if (wave == 0) {
-      // ---- 16x16 Cholesky in registers: every 16-lane group redundantly holds row l15 ----
-      T row[16];
+      // ---- 16x16 Cholesky AND its inverse in registers, left-looking: lane l15 (every 16-lane group redundantly) owns
+      // row l15 of L and column l15 of X = inv(L).  Step j broadcasts row j of L once (v_readlane from lane j) and that
+      // one broadcast serves both the column update  L[i][j] = (A[i][j] - sum_s L[i][s] L[j][s]) / L[j][j]  and the
+      // inverse row  X[j][c] = (delta_jc - sum_k L[j][k] X[k][c]) / L[j][j]: 272 readlanes per block instead of the 544
+      // of a right-looking factor followed by a separate inversion (the readlanes, not the arithmetic, are the cost).
+      T row[16], x[16];
 #pragma unroll
       for (int c = 0; c < 16; ++c) row[c] = sm[(o + l15) * LD + o + c];
       int bad = 0;
 #pragma unroll
       for (int j = 0; j < 16; ++j) {
-        const T d = readlane_t(row[j], j);
+        T bj[16];
+#pragma unroll
+        for (int k = 0; k < j; ++k) bj[k] = readlane_t(row[k], j);
+        T t0 = row[j], t1 = T(0), s0 = (l15 == j) ? T(1) : T(0), s1 = T(0);
+#pragma unroll
+        for (int k = 0; k < j; ++k) {
+          if (k & 1) {
+            t1 = fma(-row[k], bj[k], t1);
+            s1 = fma(-bj[k], x[k], s1);
+          } else {
+            t0 = fma(-row[k], bj[k], t0);
+            s0 = fma(-bj[k], x[k], s0);
+          }
+        }
+        const T t = t0 + t1;
+        const T d = readlane_t(t, j);
         if (!(d > T(0)) && !bad) bad = j + 1;
-        const T dj = ksqrt(d);
-        const T lij = (l15 == j) ? dj : row[j] / dj;
-        row[j] = lij;
-#pragma unroll
-        for (int k = j + 1; k < 16; ++k) row[k] = fma(-lij, readlane_t(lij, k), row[k]);
-      }
-      // ---- X = inv(D): X D = I, row l15 per lane, D[k][c] fetched from lane k ----
-      T x[16];
-#pragma unroll
-      for (int c = 15; c >= 0; --c) {
-        T s = (l15 == c) ? T(1) : T(0);
-#pragma unroll
-        for (int k = c + 1; k < 16; ++k) s = fma(-x[k], readlane_t(row[c], k), s);
-        x[c] = (c <= l15) ? s / readlane_t(row[c], c) : T(0);
+        const T rj = krsqrt(d);
+        T dj = d * rj;
+        dj = fma(fma(-dj, dj, d), T(0.5) * rj, dj);           // sqrt(d)
+        T lij = t * rj;
+        lij = fma(fma(-lij, dj, t), rj, lij);                 // t / sqrt(d)
+        const T sx = s0 + s1;
+        T xj = sx * rj;
+        xj = fma(fma(-xj, dj, sx), rj, xj);
+        row[j] = (l15 == j) ? dj : lij;
+        x[j] = (l15 <= j) ? xj : T(0);
       }
       if (lane < 16) {
 #pragma unroll
         for (int c = 0; c < 16; ++c) {
           if (c <= l15) sm[(o + l15) * LD + o + c] = row[c];
-          dinv[(p * 16 + l15) * DL + c] = x[c];
+          dinv[(p * 16 + c) * DL + l15] = x[c];
         }
         if (bad && lane == 0) failed = pbase + o + bad;
       }
     }
     __syncthreads();
+    SVGP_STAMP(3 + 4 * p);
     if (failed) {
       if (tid == 0) *info = failed;
       return;
@@ -149,6 +193,7 @@ __global__ void __launch_bounds__(k256) potf2_kernel(T* __restrict__ A, T* __res
       for (int r = 0; r < 4; ++r) sm[(16 * t + M16::row(lane, r)) * LD + o + l15] = acc[r];
     }
     __syncthreads();
+    SVGP_STAMP(4 + 4 * p);
     // ---- trailing update: A[ti, tj] -= L[ti, p] L[tj, p]'  for p < tj <= ti ----
     {
       const int n = NBLK - p - 1;
@@ -169,6 +214,7 @@ __global__ void __launch_bounds__(k256) potf2_kernel(T* __restrict__ A, T* __res
       }
     }
     __syncthreads();
+    SVGP_STAMP(5 + 4 * p);
   }
 
   // ---- X = inv(L) by 16-blocks; wave w owns block columns w and 7-w; X[ti,tj]' lives at block (tj,ti) ----
@@ -193,6 +239,7 @@ __global__ void __launch_bounds__(k256) potf2_kernel(T* __restrict__ A, T* __res
     }
   }
   __syncthreads();
+  SVGP_STAMP(40);
   for (int e = tid; e < NB * NB; e += k256) {
     const int r = e % NB, c = e / NB;
     if (r >= c) A[r + int64_t(c) * ld] = sm[r * LD + c];
@@ -200,6 +247,7 @@ __global__ void __launch_bounds__(k256) potf2_kernel(T* __restrict__ A, T* __res
     if (r >= c) x = ((r >> 4) == (c >> 4)) ? dinv[((r >> 4) * 16 + (r & 15)) * DL + (c & 15)] : sm[c * LD + r];
     Tm[r + int64_t(c) * ld] = x;
   }
+  SVGP_STAMP(41);
 }
 
 // ------------------------------------------------------------------------------------------------

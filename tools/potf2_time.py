@@ -22,3 +22,15 @@ for dt in ("f64", "f32"):
         ts.append(ctx.timing().ms_prep)
     out.append(f"{dt} {np.median(ts[2:])*1e3:.1f} us")
 print(os.environ.get("SVGP_MI355X_LIB", "default").split("/")[-1], " ".join(out))
+
+import ctypes
+L = ctypes.CDLL(os.environ.get("SVGP_MI355X_LIB", _ffi.LIB_PATH))
+if hasattr(L, "svgp_debug_potf2_stamps"):
+    buf = (ctypes.c_ulonglong * 64)()
+    L.svgp_debug_potf2_stamps(buf)
+    s = np.array(list(buf), dtype=np.float64)
+    tot = s[41] - s[0]
+    print(f"clock64 ticks: total {tot:.0f}; load {s[1]-s[0]:.0f}; store {s[41]-s[40]:.0f}; inverse {s[40]-s[33]:.0f}")
+    for p in range(8):
+        b = 2 + 4 * p
+        print(f"  block {p}: factor {s[b+1]-s[b]:.0f}  panel {s[b+2]-s[b+1]:.0f}  trailing {s[b+3]-s[b+2]:.0f}")
