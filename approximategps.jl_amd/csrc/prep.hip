@@ -101,6 +101,66 @@ extern "C" int svgp_debug_potf2_stamps(unsigned long long* out) {
 #define SVGP_STAMP(i)
 #endif
 
+// wave 0's part of a block step: factor the 16x16 diagonal block at offset o (already updated) and invert it.
+// 16x16 Cholesky AND its inverse in registers, left-looking: lane l15 (every 16-lane group redundantly) owns row l15 of
+// L and column l15 of X = inv(L).  Step j broadcasts row j of L once (v_readlane from lane j) and that one broadcast
+// serves both the column update  L[i][j] = (A[i][j] - sum_s L[i][s] L[j][s]) / L[j][j]  and the inverse row
+// X[j][c] = (delta_jc - sum_k L[j][k] X[k][c]) / L[j][j].  A step is a chain of ~45 dependent VALU operations
+// (~360 cycles; s_memtime stamps): 128 such steps are the critical path of the whole block.
+template <typename T>
+__device__ __forceinline__ int factor16(T* __restrict__ sm, T* __restrict__ dinv, int LD, int DL, int o, int p, int lane) {
+  const int l15 = lane & 15;
+  T row[16], x[16];
+#pragma unroll
+  for (int c = 0; c < 16; ++c) row[c] = sm[(o + l15) * LD + o + c];
+  int bad = 0;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    T bj[16];
+#pragma unroll
+    for (int k = 0; k < j; ++k) bj[k] = readlane_t(row[k], j);
+    T t0 = row[j], t1 = T(0), s0 = (l15 == j) ? T(1) : T(0), s1 = T(0);
+#pragma unroll
+    for (int k = 0; k < j; ++k) {
+      if (k & 1) {
+        t1 = fma(-row[k], bj[k], t1);
+        s1 = fma(-bj[k], x[k], s1);
+      } else {
+        t0 = fma(-row[k], bj[k], t0);
+        s0 = fma(-bj[k], x[k], s0);
+      }
+    }
+    const T t = t0 + t1;
+    const T d = readlane_t(t, j);
+    if (!(d > T(0)) && !bad) bad = j + 1;
+    const T rj = krsqrt(d);
+    T dj = d * rj;
+    dj = fma(fma(-dj, dj, d), T(0.5) * rj, dj);           // sqrt(d)
+    T lij = t * rj;
+    lij = fma(fma(-lij, dj, t), rj, lij);                 // t / sqrt(d)
+    const T sx = s0 + s1;
+    T xj = sx * rj;
+    xj = fma(fma(-xj, dj, sx), rj, xj);
+    row[j] = (l15 == j) ? dj : lij;
+    x[j] = (l15 <= j) ? xj : T(0);
+  }
+  if (lane < 16) {
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+      if (c <= l15) sm[(o + l15) * LD + o + c] = row[c];
+      dinv[(p * 16 + c) * DL + l15] = x[c];
+    }
+  }
+  return bad;
+}
+
+// Block step p, with lookahead: after the panel  L[t,p] = A[t,p] inv(D_p)'  (all waves), wave 0 updates only the next
+// diagonal block and factors it (the serial chain above) WHILE waves 1-3 do the rest of the trailing update
+// A[ti,tj] -= L[ti,p] L[tj,p]'  and row p of the block inverse  X[p,tj] = -inv(D_p) sum_{tj<=s<p} L[p,s] X[s,tj]
+// (the accumulator of the sum is fed straight back as the B operand of the second product: register r of a 16x16 result
+// is k-slab r of a B fragment when A is read with k = Mfma16::row(lane, r); X[ti,tj]' lives in the strictly upper block
+// (tj,ti) of the LDS image).  Critical path per block: panel + one tile update + factor16; everything else hides
+// behind the factor (s_memtime: 115k -> ~70k cycles per 128-block).
 template <typename T>
 __global__ void __launch_bounds__(k256) potf2_kernel(T* __restrict__ A, T* __restrict__ Tm, int64_t ld,
                                                       int* __restrict__ info, int pbase) {
@@ -115,73 +175,40 @@ __global__ void __launch_bounds__(k256) potf2_kernel(T* __restrict__ A, T* __res
   const int l15 = lane & 15, g = lane >> 4;
   SVGP_STAMP(0);
   if (tid == 0) failed = (*info != 0) ? -1 : 0;
-  for (int e = tid; e < NB * NB; e += k256) {
-    const int i = e % NB, j = e / NB;
-    sm[i * LD + j] = A[i + int64_t(j) * ld];
+  {
+    // 64 elements per thread, 16 loads in flight at a time (a plain loop waits for every load before its LDS store)
+    constexpr int U = 16;
+    for (int e0 = tid; e0 < NB * NB; e0 += k256 * U) {
+      T v[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int e = e0 + u * k256;
+        v[u] = A[(e % NB) + int64_t(e / NB) * ld];
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int e = e0 + u * k256;
+        sm[(e % NB) * LD + e / NB] = v[u];
+      }
+    }
   }
   __syncthreads();
   if (failed) return;  // an earlier panel already reported the first bad pivot
-
   SVGP_STAMP(1);
+  if (wave == 0) {
+    const int bad = factor16(sm, dinv, LD, DL, 0, 0, lane);
+    if (bad && lane == 0) failed = pbase + bad;
+  }
+  __syncthreads();
+
   for (int p = 0; p < NBLK; ++p) {
     const int o = 16 * p;
     SVGP_STAMP(2 + 4 * p);
-    if (wave == 0) {
-      // ---- 16x16 Cholesky AND its inverse in registers, left-looking: lane l15 (every 16-lane group redundantly) owns
-      // row l15 of L and column l15 of X = inv(L).  Step j broadcasts row j of L once (v_readlane from lane j) and that
-      // one broadcast serves both the column update  L[i][j] = (A[i][j] - sum_s L[i][s] L[j][s]) / L[j][j]  and the
-      // inverse row  X[j][c] = (delta_jc - sum_k L[j][k] X[k][c]) / L[j][j]: 272 readlanes per block instead of the 544
-      // of a right-looking factor followed by a separate inversion (the readlanes, not the arithmetic, are the cost).
-      T row[16], x[16];
-#pragma unroll
-      for (int c = 0; c < 16; ++c) row[c] = sm[(o + l15) * LD + o + c];
-      int bad = 0;
-#pragma unroll
-      for (int j = 0; j < 16; ++j) {
-        T bj[16];
-#pragma unroll
-        for (int k = 0; k < j; ++k) bj[k] = readlane_t(row[k], j);
-        T t0 = row[j], t1 = T(0), s0 = (l15 == j) ? T(1) : T(0), s1 = T(0);
-#pragma unroll
-        for (int k = 0; k < j; ++k) {
-          if (k & 1) {
-            t1 = fma(-row[k], bj[k], t1);
-            s1 = fma(-bj[k], x[k], s1);
-          } else {
-            t0 = fma(-row[k], bj[k], t0);
-            s0 = fma(-bj[k], x[k], s0);
-          }
-        }
-        const T t = t0 + t1;
-        const T d = readlane_t(t, j);
-        if (!(d > T(0)) && !bad) bad = j + 1;
-        const T rj = krsqrt(d);
-        T dj = d * rj;
-        dj = fma(fma(-dj, dj, d), T(0.5) * rj, dj);           // sqrt(d)
-        T lij = t * rj;
-        lij = fma(fma(-lij, dj, t), rj, lij);                 // t / sqrt(d)
-        const T sx = s0 + s1;
-        T xj = sx * rj;
-        xj = fma(fma(-xj, dj, sx), rj, xj);
-        row[j] = (l15 == j) ? dj : lij;
-        x[j] = (l15 <= j) ? xj : T(0);
-      }
-      if (lane < 16) {
-#pragma unroll
-        for (int c = 0; c < 16; ++c) {
-          if (c <= l15) sm[(o + l15) * LD + o + c] = row[c];
-          dinv[(p * 16 + c) * DL + l15] = x[c];
-        }
-        if (bad && lane == 0) failed = pbase + o + bad;
-      }
-    }
-    __syncthreads();
-    SVGP_STAMP(3 + 4 * p);
     if (failed) {
       if (tid == 0) *info = failed;
       return;
     }
-    // ---- panel: L[t, p] = A[t, p] inv(D)' ----
+    // ---- panel: L[t, p] = A[t, p] inv(D_p)' ----
     for (int t = p + 1 + wave; t < NBLK; t += 4) {
       acc_t acc = {0, 0, 0, 0};
 #pragma unroll
@@ -193,59 +220,76 @@ __global__ void __launch_bounds__(k256) potf2_kernel(T* __restrict__ A, T* __res
       for (int r = 0; r < 4; ++r) sm[(16 * t + M16::row(lane, r)) * LD + o + l15] = acc[r];
     }
     __syncthreads();
-    SVGP_STAMP(4 + 4 * p);
-    // ---- trailing update: A[ti, tj] -= L[ti, p] L[tj, p]'  for p < tj <= ti ----
-    {
+    SVGP_STAMP(3 + 4 * p);
+    auto update_tile = [&](int ti, int tj) {   // A[ti, tj] -= L[ti, p] L[tj, p]'
+      const int bi = 16 * ti, bj = 16 * tj;
+      acc_t acc = {0, 0, 0, 0};
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const int k = 4 * s + g;
+        acc = M16::mma(sm[(bi + l15) * LD + o + k], sm[(bj + l15) * LD + o + k], acc);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) sm[(bi + M16::row(lane, r)) * LD + bj + l15] -= acc[r];
+    };
+    const bool last = (p + 1 == NBLK);          // no next factor: wave 0 joins the inverse-row work
+    if (wave == 0 && !last) {
+      update_tile(p + 1, p + 1);
+      const int bad = factor16(sm, dinv, LD, DL, o + 16, p + 1, lane);
+      if (bad && lane == 0) failed = pbase + o + 16 + bad;
+    } else {
+      // trailing tiles p < tj <= ti except (p+1, p+1), then row p of the block inverse, dealt round-robin to the workers
+      const int nw = last ? 4 : 3, me = last ? wave : wave - 1;
       const int n = NBLK - p - 1;
-      int ti = 0, tj = 0;  // walk the lower triangle of n x n tiles in row-major order
-      for (int idx = 0; idx < n * (n + 1) / 2; ++idx) {
-        if ((idx & 3) == wave) {
-          const int bi = 16 * (p + 1 + ti), bj = 16 * (p + 1 + tj);
-          acc_t acc = {0, 0, 0, 0};
+      int ti = 0, tj = 0, idx = 0;
+      for (int q = 0; q < n * (n + 1) / 2; ++q) {
+        if (q > 0 && (idx++ % nw) == me) update_tile(p + 1 + ti, p + 1 + tj);
+        if (++tj > ti) { tj = 0; ++ti; }
+      }
+      for (int tj2 = 0; tj2 < p; ++tj2) {
+        if ((idx++ % nw) != me) continue;
+        acc_t acc = {0, 0, 0, 0};
+        for (int sb = tj2; sb < p; ++sb) {
 #pragma unroll
           for (int s = 0; s < 4; ++s) {
             const int k = 4 * s + g;
-            acc = M16::mma(sm[(bi + l15) * LD + o + k], sm[(bj + l15) * LD + o + k], acc);
+            const T a = sm[(o + l15) * LD + 16 * sb + k];
+            const T b = (sb == tj2) ? dinv[(tj2 * 16 + k) * DL + l15] : sm[(16 * tj2 + l15) * LD + 16 * sb + k];
+            acc = M16::mma(a, b, acc);
           }
-#pragma unroll
-          for (int r = 0; r < 4; ++r) sm[(bi + M16::row(lane, r)) * LD + bj + l15] -= acc[r];
         }
-        if (++tj > ti) { tj = 0; ++ti; }
+        acc_t x = {0, 0, 0, 0};
+#pragma unroll
+        for (int s = 0; s < 4; ++s) x = M16::mma(dinv[(p * 16 + l15) * DL + M16::row(lane, s)], acc[s], x);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sm[(16 * tj2 + l15) * LD + o + M16::row(lane, r)] = -x[r];
       }
     }
     __syncthreads();
-    SVGP_STAMP(5 + 4 * p);
+    SVGP_STAMP(4 + 4 * p);
   }
-
-  // ---- X = inv(L) by 16-blocks; wave w owns block columns w and 7-w; X[ti,tj]' lives at block (tj,ti) ----
-  for (int pass = 0; pass < 2; ++pass) {
-    const int tj = pass == 0 ? wave : NBLK - 1 - wave;
-    for (int ti = tj + 1; ti < NBLK; ++ti) {
-      acc_t acc = {0, 0, 0, 0};
-      for (int sb = tj; sb < ti; ++sb) {
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-          const int k = 4 * s + g;
-          const T a = sm[(16 * ti + l15) * LD + 16 * sb + k];
-          const T b = (sb == tj) ? dinv[(tj * 16 + k) * DL + l15] : sm[(16 * tj + l15) * LD + 16 * sb + k];
-          acc = M16::mma(a, b, acc);
-        }
-      }
-      acc_t x = {0, 0, 0, 0};
-#pragma unroll
-      for (int s = 0; s < 4; ++s) x = M16::mma(dinv[(ti * 16 + l15) * DL + M16::row(lane, s)], acc[s], x);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) sm[(16 * tj + l15) * LD + 16 * ti + M16::row(lane, r)] = -x[r];
-    }
+  if (failed) {   // a bad pivot in the last block
+    if (tid == 0) *info = failed;
+    return;
   }
-  __syncthreads();
   SVGP_STAMP(40);
-  for (int e = tid; e < NB * NB; e += k256) {
-    const int r = e % NB, c = e / NB;
-    if (r >= c) A[r + int64_t(c) * ld] = sm[r * LD + c];
-    T x = T(0);
-    if (r >= c) x = ((r >> 4) == (c >> 4)) ? dinv[((r >> 4) * 16 + (r & 15)) * DL + (c & 15)] : sm[c * LD + r];
-    Tm[r + int64_t(c) * ld] = x;
+  {
+    constexpr int U = 8;
+    for (int e0 = tid; e0 < NB * NB; e0 += k256 * U) {
+      T lv[U], xv[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int e = e0 + u * k256, r = e % NB, c = e / NB;
+        lv[u] = sm[r * LD + c];
+        xv[u] = ((r >> 4) == (c >> 4)) ? dinv[((r >> 4) * 16 + (r & 15)) * DL + (c & 15)] : sm[c * LD + r];
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int e = e0 + u * k256, r = e % NB, c = e / NB;
+        if (r >= c) A[r + int64_t(c) * ld] = lv[u];
+        Tm[r + int64_t(c) * ld] = (r >= c) ? xv[u] : T(0);
+      }
+    }
   }
   SVGP_STAMP(41);
 }

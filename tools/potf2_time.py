@@ -30,7 +30,7 @@ if hasattr(L, "svgp_debug_potf2_stamps"):
     L.svgp_debug_potf2_stamps(buf)
     s = np.array(list(buf), dtype=np.float64)
     tot = s[41] - s[0]
-    print(f"clock64 ticks: total {tot:.0f}; load {s[1]-s[0]:.0f}; store {s[41]-s[40]:.0f}; inverse {s[40]-s[33]:.0f}")
+    print(f"clock64 ticks: total {tot:.0f}; load {s[1]-s[0]:.0f}; first factor {s[2]-s[1]:.0f}; store {s[41]-s[40]:.0f}")
     for p in range(8):
         b = 2 + 4 * p
-        print(f"  block {p}: factor {s[b+1]-s[b]:.0f}  panel {s[b+2]-s[b+1]:.0f}  trailing {s[b+3]-s[b+2]:.0f}")
+        print(f"  block {p}: panel {s[b+1]-s[b]:.0f}  lookahead phase (next factor | trailing + inverse row) {s[b+2]-s[b+1]:.0f}")
