@@ -67,6 +67,8 @@ SYMBOLS = {
     "svgp_elbo_partial": (C.c_int32, [_P, _P, _P, C.c_int64, C.c_int64, C.POINTER(C.c_double)]),
     "svgp_elbo_grad": (C.c_int32, [_P, _P, _P, C.c_int64, C.c_int64, C.c_double, C.POINTER(C.c_double), C.POINTER(Terms),
                                    C.POINTER(Grads)]),
+    "svgp_elbo_grad_shard": (C.c_int32, [_P, _P, _P, C.c_int64, C.c_int64, C.c_double, C.c_double, C.POINTER(C.c_double),
+                                         C.POINTER(Terms), C.POINTER(Grads)]),
     "svgp_prior_kl": (C.c_int32, [_P, _P, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "svgp_elbo_host": (C.c_int32, [_P, C.POINTER(ModelDesc), C.c_int32, C.c_int64, _P, _P, C.c_double,
                                    C.POINTER(C.c_double), C.POINTER(Terms)]),
@@ -294,8 +296,9 @@ class DeviceModel:
         self.ctx.check(self.ctx.lib.svgp_elbo_partial(self.ctx.h, self.h, data.h, off, length, buf))
         return np.array(buf[:], dtype=np.float64)
 
-    def elbo_grad(self, data: DeviceData, off=0, length=None, num_data=0.0, z_shape=None):
-        """-> (elbo, terms, dict(variance, inv_lengthscale, z, m, Lq, lik_sigma2, mean_const)); z in the layout it was given."""
+    def elbo_grad(self, data: DeviceData, off=0, length=None, num_data=0.0, z_shape=None, shard=None):
+        """-> (elbo, terms, dict(variance, inv_lengthscale, z, m, Lq, lik_sigma2, mean_const)); z in the layout it was given.
+        shard = (scale, kl_weight) evaluates the data-parallel shard form svgp_elbo_grad_shard instead."""
         length = data.n - off if length is None else length
         dt = np_dtype(self.dtype)
         il = np.zeros(self.d)
@@ -305,8 +308,12 @@ class DeviceModel:
         Lb = np.zeros((self.M, self.M), dtype=dt, order="F")
         g = Grads(0.0, 0.0, 0.0, il.ctypes.data_as(C.POINTER(C.c_double)), _ptr(zb), _ptr(mb), _ptr(Lb))
         out, terms = C.c_double(), Terms()
-        rc = self.ctx.lib.svgp_elbo_grad(self.ctx.h, self.h, data.h, off, length, float(num_data), C.byref(out),
-                                         C.byref(terms), C.byref(g))
+        if shard is None:
+            rc = self.ctx.lib.svgp_elbo_grad(self.ctx.h, self.h, data.h, off, length, float(num_data), C.byref(out),
+                                             C.byref(terms), C.byref(g))
+        else:
+            rc = self.ctx.lib.svgp_elbo_grad_shard(self.ctx.h, self.h, data.h, off, length, float(shard[0]), float(shard[1]),
+                                                   C.byref(out), C.byref(terms), C.byref(g))
         self.ctx.check(rc, terms)
         return out.value, terms, dict(variance=g.variance, inv_lengthscale=il, z=zb, m=mb, Lq=Lb,
                                       lik_sigma2=g.lik_sigma2, mean_const=g.mean_const)

@@ -40,22 +40,21 @@ def combine(total, kl: float, num_data: float):
     return sum_e * (float(num_data) / n_global) - kl
 
 
-def allreduce_value_and_gradient(value, grads, m, Lq, kl, group=None, device=None):
-    """Data-parallel value-and-gradient.  Every rank evaluated F_r = s·E_r − KL on its own shard with
-    s = num_data / n_global (svgp_elbo_grad with num_data·len_r/n_global).  ONE all-reduce of the flat vector
+def allreduce_value_and_gradient(value, grads, group=None, device=None):
+    """Data-parallel value-and-gradient.  Every rank evaluated its shard with svgp_elbo_grad_shard:
+    F_r = s·E_r − KL / W with s = num_data / n_global and W = world size, so the global ELBO and its gradient are the
+    plain SUM over ranks — for both parametrisations (the Centered KL depends on the kernel parameters too, so a
+    host-side correction of the KL gradient would not do).  ONE all-reduce of the flat vector
     [F_r, variance, lik_sigma2, mean_const, inv_lengthscale(d), z(M·d), m(M), Lq(M²)] (fp64; ≈ 8.4 MB at M = 1024:
-    the only place the per-link xGMI ring bound matters) sums them; the KL, counted once per rank, is put back
-    (W − 1 copies of KL and of ∇KL = (m, Lq − diag(1/Lq_ii)), which only touch m and Lq)."""
+    the only place the per-link xGMI ring bound matters)."""
     import torch
     import torch.distributed as dist
 
     keys = ("variance", "lik_sigma2", "mean_const", "inv_lengthscale", "z", "m", "Lq")
     parts = [np.atleast_1d(np.asarray(value, dtype=np.float64))] + [np.asarray(grads[k], dtype=np.float64).ravel(order="F") for k in keys]
     flat = torch.from_numpy(np.concatenate(parts)).to(device if device is not None else "cpu")
-    world = 1
     if dist.is_available() and dist.is_initialized():
         dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
-        world = dist.get_world_size(group)
     flat = flat.cpu().numpy()
     out, pos = {}, 1
     for k in keys:
@@ -63,10 +62,7 @@ def allreduce_value_and_gradient(value, grads, m, Lq, kl, group=None, device=Non
         n = int(np.prod(shape)) if shape else 1
         out[k] = flat[pos:pos + n].reshape(shape, order="F") if shape else float(flat[pos])
         pos += n
-    Lq = np.tril(np.asarray(Lq, dtype=np.float64))
-    out["m"] = out["m"] + (world - 1) * np.asarray(m, dtype=np.float64)
-    out["Lq"] = out["Lq"] + (world - 1) * (Lq - np.diag(1.0 / np.diag(Lq)))
-    return float(flat[0]) + (world - 1) * float(kl), out
+    return float(flat[0]), out
 
 
 class ShardedELBO:
@@ -82,7 +78,7 @@ class ShardedELBO:
         total = allreduce_partials(partial, self.group, self.device)
         return combine(total, kl, self.num_data)
 
-    def step_grad(self, off: int, length: int, n_global: int, m, Lq):
+    def step_grad(self, off: int, length: int, n_global: int, world: int):
         """Value and gradient of the global minibatch ELBO; `n_global` = total points all ranks evaluate this step."""
-        val, terms, g = self.model.elbo_grad(self.data, off, length, self.num_data * length / n_global)
-        return allreduce_value_and_gradient(val, g, m, Lq, terms.kl, self.group, self.device)
+        val, _, g = self.model.elbo_grad(self.data, off, length, shard=(self.num_data / n_global, 1.0 / world))
+        return allreduce_value_and_gradient(val, g, self.group, self.device)

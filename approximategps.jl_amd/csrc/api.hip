@@ -937,11 +937,14 @@ int grad_workspace(svgp_ctx* ctx, svgp_model* m, int64_t len, GradWs** out) {
 
 }  // namespace
 
-extern "C" int32_t svgp_elbo_grad(svgp_ctx* ctx, svgp_model* m, const svgp_data* data, int64_t off, int64_t len,
-                                  double num_data, double* elbo_out, svgp_terms* terms_out, svgp_grads* g) {
+namespace {
+// value = scale * sum_i E_i - klw * KL and its gradient over points [off, off + len)
+int elbo_grad_impl(svgp_ctx* ctx, svgp_model* m, const svgp_data* data, int64_t off, int64_t len, double scale, double klw,
+                   double* elbo_out, svgp_terms* terms_out, svgp_grads* g) {
   int rc = check_batch(ctx, m, data, off, len, true);
   if (rc) return rc;
   if (!g) return fail(ctx, SVGP_INVALID_ARG, "null gradient output");
+  if (!(scale > 0.0) || !(klw >= 0.0)) return fail(ctx, SVGP_INVALID_ARG, "scale must be positive and kl_weight non-negative");
   const bool centered = (m->desc.parametrization == SVGP_CENTERED);
   HIPC(ctx, hipSetDevice(ctx->device));
   hipStream_t s = ctx->stream;
@@ -952,7 +955,6 @@ extern "C" int32_t svgp_elbo_grad(svgp_ctx* ctx, svgp_model* m, const svgp_data*
   const int64_t Mp = m->Mp, M = m->M, nc = w->nc, ldk = nc + 64;
   const size_t es = m->es, mm = size_t(Mp) * Mp * es;
   const int dreg = grad_dreg(m->d);
-  const double scale = (num_data > 0 ? num_data : double(len)) / double(len);
   HIPC(ctx, hipEventRecord(ctx->ev[0], s));
   rc = enqueue_prep(ctx, m);
   if (rc) return rc;
@@ -1009,12 +1011,12 @@ extern "C" int32_t svgp_elbo_grad(svgp_ctx* ctx, svgp_model* m, const svgp_data*
     KCHECK(ctx, "kgrad uf");
   }
   // M-sized tail: Lq_bar, Lk_bar -> Kuu_bar -> kernel parameters
-  launch_finish_mm(dt, s, w->G1, w->G2, w->nslices, Mp, M, centered ? m->B : m->Lq_raw, centered ? Mp : M, w->Lqbar,
+  launch_finish_mm(dt, s, w->G1, w->G2, w->nslices, Mp, M, centered ? m->B : m->Lq_raw, centered ? Mp : M, klw, w->Lqbar,
                    centered ? w->BbarRM : nullptr, w->LbarRM);
   if (centered) {
     // chain through m~ = Lk \ (m - c) and B = Lk \ Lq:  m_bar = Lk^-T m~_bar,  R = Lk^-T B_bar,  Lq_bar = tril(R),
     // Lk_bar -= tril(m_bar m~') + tril(R B')
-    launch_mbar(dt, s, w->rp_uf, w->ns_uf, int64_t(2 + dreg) * Mp, m->mp, M, Mp, w->rbar);
+    launch_mbar(dt, s, w->rp_uf, w->ns_uf, int64_t(2 + dreg) * Mp, m->mp, klw, M, Mp, w->rbar);
     launch_trsv2(dt, s, m->L, m->T, Mp, 1, w->rbar);
     launch_solve_t(dt, s, w->S, w->BbarRM, nullptr, Mp, Mp, Mp, ctx->num_cus);
     launch_rm_tril_to_user(dt, s, w->BbarRM, Mp, M, w->Lqbar);
@@ -1035,7 +1037,7 @@ extern "C" int32_t svgp_elbo_grad(svgp_ctx* ctx, svgp_model* m, const svgp_data*
   KCHECK(ctx, "chol backward");
   launch_kgrad(dt, s, kp, m->zs, Mp, m->zs, Mp, 0, 1, M, M, w->H, nullptr, nullptr, 128, w->ns_uu, w->rp_uu, w->sp_uu);
   launch_finish_kgrad(dt, s, m->d, M, Mp, m->zs, w->invl_d, w->rp_uf, w->ns_uf, w->rp_uu, w->ns_uu, w->sp_uf, w->ns_uf * w->rb,
-                      w->sp_uu, w->ns_uu * w->rb, m->mp, m->desc.layout_z, m->desc.variance, w->zbar, centered ? nullptr : w->mbar,
+                      w->sp_uu, w->ns_uu * w->rb, m->mp, klw, m->desc.layout_z, m->desc.variance, w->zbar, centered ? nullptr : w->mbar,
                       w->scal_out);
   KCHECK(ctx, "kgrad uu / finish");
   HIPC(ctx, hipEventRecord(ctx->ev[3], s));
@@ -1061,7 +1063,7 @@ extern "C" int32_t svgp_elbo_grad(svgp_ctx* ctx, svgp_model* m, const svgp_data*
   ctx->timing.ms_strip = t13;
   ctx->timing.ms_total = t01 + t13;
   const double E = sums[0], nneg = sums[4];
-  const double elbo = E * scale - m->kl;
+  const double elbo = E * scale - klw * m->kl;
   g->variance = sc[0] + sums[2];
   g->lik_sigma2 = sums[3];
   if (g->m) memcpy(g->m, mhost.data(), mhost.size());
@@ -1079,4 +1081,18 @@ extern "C" int32_t svgp_elbo_grad(svgp_ctx* ctx, svgp_model* m, const svgp_data*
   rc = status_of(ctx, m, nneg);
   if (elbo_out) *elbo_out = (rc == SVGP_OK) ? elbo : NAN;
   return rc;
+}
+}  // namespace
+
+extern "C" int32_t svgp_elbo_grad(svgp_ctx* ctx, svgp_model* m, const svgp_data* data, int64_t off, int64_t len,
+                                  double num_data, double* elbo_out, svgp_terms* terms_out, svgp_grads* g) {
+  if (len < 1) return ctx ? fail(ctx, SVGP_INVALID_ARG, "batch range outside the data") : SVGP_INVALID_ARG;
+  return elbo_grad_impl(ctx, m, data, off, len, (num_data > 0 ? num_data : double(len)) / double(len), 1.0, elbo_out,
+                        terms_out, g);
+}
+
+extern "C" int32_t svgp_elbo_grad_shard(svgp_ctx* ctx, svgp_model* m, const svgp_data* data, int64_t off, int64_t len,
+                                        double scale, double kl_weight, double* value_out, svgp_terms* terms_out,
+                                        svgp_grads* g) {
+  return elbo_grad_impl(ctx, m, data, off, len, scale, kl_weight, value_out, terms_out, g);
 }

@@ -373,8 +373,8 @@ __global__ void phi_kernel(T* __restrict__ X, int64_t Mp) {
 // reduce the split-K slices: Lq_bar (user layout, ld M) and Lk_bar row-major (negated, lower)
 template <typename T>
 __global__ void finish_mm_kernel(const T* __restrict__ G1, const T* __restrict__ G2, int nslices, int64_t Mp, int64_t M,
-                                 const T* __restrict__ Lq, int64_t ldq, T* __restrict__ Lq_bar, T* __restrict__ BbarRM,
-                                 T* __restrict__ LkbarRM) {
+                                 const T* __restrict__ Lq, int64_t ldq, T klw, T* __restrict__ Lq_bar,
+                                 T* __restrict__ BbarRM, T* __restrict__ LkbarRM) {
   const int64_t c = int64_t(blockIdx.x) * blockDim.x + threadIdx.x, r = blockIdx.y;
   if (c >= Mp) return;
   T g1 = T(0), g2 = T(0);
@@ -387,7 +387,7 @@ __global__ void finish_mm_kernel(const T* __restrict__ G1, const T* __restrict__
   T v = T(0);
   if (r < M && c <= r) {
     const T l = Lq[r + c * ldq];
-    v = g1 - (c == r ? l - T(1) / l : l);
+    v = g1 - klw * (c == r ? l - T(1) / l : l);   // klw * d KL / d Lq
   }
   if (BbarRM) BbarRM[r * Mp + c] = v;                    // Centered: adjoint of B = Lk \ Lq, row-major for the solve
   else if (r < M && c < M) Lq_bar[r + c * M] = v;
@@ -396,14 +396,14 @@ __global__ void finish_mm_kernel(const T* __restrict__ G1, const T* __restrict__
 // Centered chain rule helpers ------------------------------------------------------------------------------
 // vec[i] = sum_slices rowpart[s][1][i] - mtilde[i]   (adjoint of the whitened mean), zero padded
 template <typename T>
-__global__ void mbar_kernel(const double* __restrict__ rp_uf, int ns, int64_t stride, const T* __restrict__ mt, int64_t M,
-                            int64_t Mp, T* __restrict__ vec) {
+__global__ void mbar_kernel(const double* __restrict__ rp_uf, int ns, int64_t stride, const T* __restrict__ mt, double klw,
+                            int64_t M, int64_t Mp, T* __restrict__ vec) {
   const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
   if (i >= Mp) return;
   double s = 0.0;
   if (i < M) {
     for (int q = 0; q < ns; ++q) s += rp_uf[q * stride + Mp + i];
-    s -= double(mt[i]);
+    s -= klw * double(mt[i]);
   }
   vec[i] = T(s);
 }
@@ -428,8 +428,9 @@ template <typename T>
 __global__ void finish_kgrad_kernel(int d, int dreg, int64_t M, int64_t Mp, const T* __restrict__ zs,
                                     const double* __restrict__ invl, const double* __restrict__ rp_uf, int ns_uf,
                                     const double* __restrict__ rp_uu, int ns_uu, const double* __restrict__ sp_uf, int nsp_uf,
-                                    const double* __restrict__ sp_uu, int nsp_uu, const T* __restrict__ m, int layout_z,
-                                    double variance, T* __restrict__ z_bar, T* __restrict__ m_bar, double* __restrict__ scal_out) {
+                                    const double* __restrict__ sp_uu, int nsp_uu, const T* __restrict__ m, double klw,
+                                    int layout_z, double variance, T* __restrict__ z_bar, T* __restrict__ m_bar,
+                                    double* __restrict__ scal_out) {
   // scal_out[0] = sum P K (uf) + sum H K (uu), scal_out[1 + f] = il_bar_f
   const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
   const int64_t stride = int64_t(2 + dreg) * Mp;
@@ -437,7 +438,7 @@ __global__ void finish_kgrad_kernel(int d, int dreg, int64_t M, int64_t Mp, cons
     double R1 = 0, MB = 0, R2 = 0;
     for (int s = 0; s < ns_uf; ++s) { R1 += rp_uf[s * stride + i]; MB += rp_uf[s * stride + Mp + i]; }
     for (int s = 0; s < ns_uu; ++s) R2 += rp_uu[s * stride + i];
-    if (m_bar) m_bar[i] = T(MB - double(m[i]));
+    if (m_bar) m_bar[i] = T(MB - klw * double(m[i]));   // klw * d KL / d m
     for (int f = 0; f < d; ++f) {
       double Q1 = 0, Q2 = 0;
       for (int s = 0; s < ns_uf; ++s) Q1 += rp_uf[s * stride + (2 + f) * Mp + i];
@@ -579,16 +580,16 @@ void launch_phi(int dtype, hipStream_t s, void* X, int64_t Mp) {
 }
 
 void launch_finish_mm(int dtype, hipStream_t s, const void* G1, const void* G2, int nslices, int64_t Mp, int64_t M,
-                      const void* Lq, int64_t ldq, void* Lq_bar, void* BbarRM, void* LkbarRM) {
+                      const void* Lq, int64_t ldq, double klw, void* Lq_bar, void* BbarRM, void* LkbarRM) {
   dim3 grid((unsigned)((Mp + 255) / 256), (unsigned)Mp);
   GD(dtype, T, hipLaunchKernelGGL(finish_mm_kernel<T>, grid, dim3(256), 0, s, (const T*)G1, (const T*)G2, nslices, Mp, M,
-                                  (const T*)Lq, ldq, (T*)Lq_bar, (T*)BbarRM, (T*)LkbarRM));
+                                  (const T*)Lq, ldq, T(klw), (T*)Lq_bar, (T*)BbarRM, (T*)LkbarRM));
 }
 
-void launch_mbar(int dtype, hipStream_t s, const double* rp_uf, int ns, int64_t stride, const void* mt, int64_t M, int64_t Mp,
-                 void* vec) {
+void launch_mbar(int dtype, hipStream_t s, const double* rp_uf, int ns, int64_t stride, const void* mt, double klw, int64_t M,
+                 int64_t Mp, void* vec) {
   GD(dtype, T, hipLaunchKernelGGL(mbar_kernel<T>, dim3((unsigned)((Mp + 255) / 256)), dim3(256), 0, s, rp_uf, ns, stride,
-                                  (const T*)mt, M, Mp, (T*)vec));
+                                  (const T*)mt, klw, M, Mp, (T*)vec));
 }
 
 void launch_lbar_adjust(int dtype, hipStream_t s, void* LkbarRM, const void* RBt, const void* rbar, const void* mt, int64_t Mp) {
@@ -604,11 +605,11 @@ void launch_rm_tril_to_user(int dtype, hipStream_t s, const void* R, int64_t Mp,
 
 void launch_finish_kgrad(int dtype, hipStream_t s, int d, int64_t M, int64_t Mp, const void* zs, const double* invl,
                          const double* rp_uf, int ns_uf, const double* rp_uu, int ns_uu, const double* sp_uf, int nsp_uf,
-                         const double* sp_uu, int nsp_uu, const void* m, int layout_z, double variance, void* z_bar,
-                         void* m_bar, double* scal_out) {
+                         const double* sp_uu, int nsp_uu, const void* m, double klw, int layout_z, double variance,
+                         void* z_bar, void* m_bar, double* scal_out) {
   dim3 grid((unsigned)((M + 255) / 256));
   GD(dtype, T, hipLaunchKernelGGL(finish_kgrad_kernel<T>, grid, dim3(256), 0, s, d, grad_dreg(d), M, Mp, (const T*)zs, invl, rp_uf,
-                                  ns_uf, rp_uu, ns_uu, sp_uf, nsp_uf, sp_uu, nsp_uu, (const T*)m, layout_z, variance, (T*)z_bar,
+                                  ns_uf, rp_uu, ns_uu, sp_uf, nsp_uf, sp_uu, nsp_uu, (const T*)m, klw, layout_z, variance, (T*)z_bar,
                                   (T*)m_bar, scal_out));
 }
 

@@ -128,14 +128,14 @@ void launch_to_point_major(int dtype, hipStream_t s, const void* in, int64_t ld,
 void launch_symmetrize(int dtype, hipStream_t s, const void* St, int64_t Mp, void* H);
 void launch_phi(int dtype, hipStream_t s, void* X, int64_t Mp);
 void launch_finish_mm(int dtype, hipStream_t s, const void* G1, const void* G2, int nslices, int64_t Mp, int64_t M,
-                      const void* Lq, int64_t ldq, void* Lq_bar, void* BbarRM, void* LkbarRM);
-void launch_mbar(int dtype, hipStream_t s, const double* rp_uf, int ns, int64_t stride, const void* mt, int64_t M, int64_t Mp,
-                 void* vec);
+                      const void* Lq, int64_t ldq, double klw, void* Lq_bar, void* BbarRM, void* LkbarRM);
+void launch_mbar(int dtype, hipStream_t s, const double* rp_uf, int ns, int64_t stride, const void* mt, double klw, int64_t M,
+                 int64_t Mp, void* vec);
 void launch_lbar_adjust(int dtype, hipStream_t s, void* LkbarRM, const void* RBt, const void* rbar, const void* mt, int64_t Mp);
 void launch_rm_tril_to_user(int dtype, hipStream_t s, const void* R, int64_t Mp, int64_t M, void* out);
 void launch_finish_kgrad(int dtype, hipStream_t s, int d, int64_t M, int64_t Mp, const void* zs, const double* invl,
                          const double* rp_uf, int ns_uf, const double* rp_uu, int ns_uu, const double* sp_uf, int nsp_uf,
-                         const double* sp_uu, int nsp_uu, const void* m, int layout_z, double variance, void* z_bar,
-                         void* m_bar, double* scal_out);
+                         const double* sp_uu, int nsp_uu, const void* m, double klw, int layout_z, double variance,
+                         void* z_bar, void* m_bar, double* scal_out);
 
 }  // namespace svgp

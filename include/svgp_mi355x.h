@@ -164,6 +164,14 @@ typedef struct svgp_grads {
 } svgp_grads;
 int32_t svgp_elbo_grad(svgp_ctx* ctx, svgp_model* model, const svgp_data* data, int64_t batch_off, int64_t batch_len,
                        double num_data, double* elbo_out, svgp_terms* terms_out, svgp_grads* grads_out);
+/* data-parallel shard of the value-and-gradient (the gradient counterpart of svgp_elbo_partial):
+ *   value = scale * Σ_{i in shard} E_{q(f_i)}[log p(y_i|f_i)] - kl_weight * KL   and its gradient.
+ * With scale = num_data / n_global and kl_weight = 1 / world_size on every rank, ONE sum all-reduce of
+ * (value, gradients) is the global ELBO (SVA:355-359) and its gradient, for both parametrisations
+ * (terms_out->elbo holds the same value; terms_out->scale = scale). */
+int32_t svgp_elbo_grad_shard(svgp_ctx* ctx, svgp_model* model, const svgp_data* data, int64_t batch_off, int64_t batch_len,
+                             double scale, double kl_weight, double* value_out, svgp_terms* terms_out,
+                             svgp_grads* grads_out);
 
 /* ---- posterior(sva)  replaces SVA:115-136 (Centered) / SVA:160-187 (NonCentered) -------------
  * fills ApproxPosteriorGP.data = (Kuu = Cholesky(Lk), B, α): Lk_out M×M lower (upper zeroed),

@@ -576,12 +576,15 @@ def chol_backward(L: np.ndarray, Lbar: np.ndarray) -> np.ndarray:
     return 0.5 * (S + S.T)
 
 
-def elbo_grad(sva: SVA, x, y, lik=LIK_GAUSSIAN, sigma2=1.0, num_data=None, quadrature_n=0):
+def elbo_grad(sva: SVA, x, y, lik=LIK_GAUSSIAN, sigma2=1.0, num_data=None, quadrature_n=0, kl_weight=1.0):
     """-> (elbo, dict of gradients w.r.t. variance, inv_lengthscale[d], z[d,M], m[M], Lq[M,M] lower, lik_sigma2, mean_const).
 
     Centered: with m~ = Lk \\ (m - c), B = Lk \\ Lq the ELBO equals the NonCentered one evaluated at (m~, B) (the KL
     included), so the NonCentered adjoint is chained through the two triangular solves:
-    m_bar = Lk^-T m~_bar, Lq_bar = tril(Lk^-T B_bar), Lk_bar -= tril(m_bar m~') + tril((Lk^-T B_bar) B'), c_bar -= sum(m_bar)."""
+    m_bar = Lk^-T m~_bar, Lq_bar = tril(Lk^-T B_bar), Lk_bar -= tril(m_bar m~') + tril((Lk^-T B_bar) B'), c_bar -= sum(m_bar).
+
+    kl_weight: value = E * num_data / n - kl_weight * KL (a data-parallel shard uses 1 / world_size, so that a plain sum
+    over ranks is the global ELBO and gradient)."""
     x = _as_dn(np.asarray(x, dtype=np.float64))
     y = np.asarray(y, dtype=np.float64)
     k = sva.kernel
@@ -609,8 +612,8 @@ def elbo_grad(sva: SVA, x, y, lik=LIK_GAUSSIAN, sigma2=1.0, num_data=None, quadr
     kl = 0.5 * (np.sum(Lq * Lq) + m @ m - M - 2.0 * np.sum(np.log(np.diag(Lq))))
     # adjoints of the whitened problem
     Abar = np.outer(m, gmu) + 2.0 * (Lq @ C - A) * gv[None, :]
-    m_bar = A @ gmu - m
-    Lq_bar = np.tril(2.0 * (A * gv[None, :]) @ C.T) - (Lq - np.diag(1.0 / np.diag(Lq)))
+    m_bar = A @ gmu - kl_weight * m
+    Lq_bar = np.tril(2.0 * (A * gv[None, :]) @ C.T) - kl_weight * (Lq - np.diag(1.0 / np.diag(Lq)))
     P = sla.solve_triangular(Lk, Abar, lower=True, trans="T")          # Kuf_bar
     Lk_bar = -np.tril(P @ A.T)
     c_bar = float(np.sum(gmu))
@@ -633,4 +636,4 @@ def elbo_grad(sva: SVA, x, y, lik=LIK_GAUSSIAN, sigma2=1.0, num_data=None, quadr
         il_bar[f] = 2.0 * il[f] * (np.sum(Wf * dzx * dzx) + np.sum(Wu * dzz * dzz))
         z_bar[f] = 2.0 * il[f] ** 2 * (np.sum(Wf * dzx, 1) + 2.0 * np.sum(Wu * dzz, 1))
     grads = dict(variance=var_bar, inv_lengthscale=il_bar, z=z_bar, m=m_bar, Lq=Lq_bar, lik_sigma2=gs2, mean_const=c_bar)
-    return E * scale - kl, grads
+    return E * scale - kl_weight * kl, grads

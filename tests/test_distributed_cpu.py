@@ -64,15 +64,17 @@ def _grad_worker(rank, world, port, out):
 
     dist.init_process_group("gloo", rank=rank, world_size=world)
     N = 203
-    x, y, sva, s2 = o.synth_problem(22, N, 9, 2, family=o.KERNEL_MATERN52)
+    x, y, nc, s2 = o.synth_problem(22, N, 9, 2, family=o.KERNEL_MATERN52)
     lo, hi = shard_range(N, rank, world)
-    # what svgp_elbo_grad returns on this rank's shard with num_data * len_r / n_global
-    val, g = o.elbo_grad(sva, x[:, lo:hi], y[lo:hi], sigma2=s2, num_data=5e3 * (hi - lo) / N)
-    tot, gt = allreduce_value_and_gradient(val, g, sva.m, sva.Lq, o.prior_kl(sva))
-    if rank == 0:
+    errs = []
+    for sva in (nc, o.SVA(nc.kernel, nc.z, nc.m + 0.3, 0.7 * nc.Lq, jitter=1e-4, mean_const=0.15, centered=True)):
+        # what svgp_elbo_grad_shard returns on this rank: scale = num_data / n_global on the shard's sum, KL / world
+        val, g = o.elbo_grad(sva, x[:, lo:hi], y[lo:hi], sigma2=s2, num_data=5e3 * (hi - lo) / N, kl_weight=1.0 / world)
+        tot, gt = allreduce_value_and_gradient(val, g)
         ref, gr = o.elbo_grad(sva, x, y, sigma2=s2, num_data=5e3)
-        errs = [abs(tot - ref) / abs(ref)] + [float(np.abs(np.asarray(gt[k]) - np.asarray(gr[k])).max() / max(np.abs(np.asarray(gr[k])).max(), 1e-12))
-                                               for k in ("variance", "lik_sigma2", "mean_const", "inv_lengthscale", "z", "m", "Lq")]
+        errs += [abs(tot - ref) / abs(ref)] + [float(np.abs(np.asarray(gt[k]) - np.asarray(gr[k])).max() / max(np.abs(np.asarray(gr[k])).max(), 1e-12))
+                                                for k in ("variance", "lik_sigma2", "mean_const", "inv_lengthscale", "z", "m", "Lq")]
+    if rank == 0:
         np.save(out, np.array(errs))
     dist.destroy_process_group()
 

@@ -166,3 +166,36 @@ def test_optimised_posterior_matches_exact_gpr(ctx):
     assert -res.fun <= o.exact_gp_logpdf(kernel, x, s2, y) + 1e-6
     model.free()
     data.free()
+
+
+@pytest.mark.parametrize("centered", [False, True])
+def test_shard_gradients_sum_to_the_global_gradient(ctx, centered):
+    """svgp_elbo_grad_shard (scale = num_data / n_global, kl_weight = 1 / world) on two shards of the batch: the plain
+    sum over the 'ranks' is the full-batch value and gradient, for both parametrisations (what the RCCL all-reduce of
+    approxgp/distributed.py adds up)."""
+    N, M, d, world = 1001, 150, 3, 2
+    x, y, nc, s2 = o.synth_problem(61, N, M, d, family=o.KERNEL_MATERN32)
+    sva = o.SVA(nc.kernel, nc.z, nc.m + 0.3, 0.7 * nc.Lq, jitter=1e-4, mean_const=0.15, centered=True) if centered else nc
+    model = device_model(ctx, sva, sigma2=s2)
+    data = _ffi.DeviceData(ctx, x, y, np.float64)
+    full_val, _, full = model.elbo_grad(data, 0, N, 7.0 * N)
+    from approxgp.distributed import shard_range
+    tot_val, tot = 0.0, None
+    for r in range(world):
+        lo, hi = shard_range(N, r, world)
+        v, t, g = model.elbo_grad(data, lo, hi - lo, shard=(7.0, 1.0 / world))
+        assert t.scale == 7.0
+        tot_val += v
+        tot = g if tot is None else {k: np.asarray(tot[k]) + np.asarray(g[k]) for k in g}
+    assert rel(tot_val, full_val) < 1e-12
+    for k in full:
+        _close(tot[k], full[k], 1e-10)
+    # and against the oracle's shard form
+    lo, hi = shard_range(N, 1, world)
+    v, _, g = model.elbo_grad(data, lo, hi - lo, shard=(7.0, 0.5))
+    v_ref, g_ref = o.elbo_grad(sva, x[:, lo:hi], y[lo:hi], sigma2=s2, num_data=7.0 * (hi - lo), kl_weight=0.5)
+    assert rel(v, v_ref) < 1e-8
+    for k in ("m", "Lq", "inv_lengthscale"):
+        _close(g[k], g_ref[k], 1e-6)
+    model.free()
+    data.free()
