@@ -66,6 +66,17 @@ class PoissonLikelihood:
     """exp link"""
 
 
+@dataclass(frozen=True)
+class ExponentialLikelihood:
+    """exp link: y ~ Exponential(rate exp f)  [GPLikelihoods]"""
+
+
+@dataclass(frozen=True)
+class GammaLikelihood:
+    """exp link: y ~ Gamma(shape alpha, scale exp f)  [GPLikelihoods]"""
+    alpha: float = 1.0
+
+
 @dataclass(eq=False)
 class LatentGP:
     f: GP

@@ -10,7 +10,7 @@ import numpy as np
 
 from . import _ffi
 from .gp import (BernoulliLikelihood, DefaultExpectationMethod, FiniteGP, GaussHermiteExpectation,
-                 GaussianLikelihood, LatentFiniteGP, MvNormal, PoissonLikelihood, _as_dn)
+                 GaussianLikelihood, LatentFiniteGP, MvNormal, PoissonLikelihood, ExponentialLikelihood, GammaLikelihood, _as_dn)
 from .kernels import unpack_kernel
 
 
@@ -54,7 +54,8 @@ def SVGP(*args):
 
 
 _LIK = {GaussianLikelihood: _ffi.LIK_GAUSSIAN, BernoulliLikelihood: _ffi.LIK_BERNOULLI_LOGISTIC,
-        PoissonLikelihood: _ffi.LIK_POISSON_EXP}
+        PoissonLikelihood: _ffi.LIK_POISSON_EXP, ExponentialLikelihood: _ffi.LIK_EXPONENTIAL_EXP,
+        GammaLikelihood: _ffi.LIK_GAMMA_EXP}
 
 
 def _desc(sva: SparseVariationalApproximation, lik=None, quadrature=None, dtype=None, neg_var_policy=_ffi.NEGVAR_ERROR):
@@ -72,6 +73,8 @@ def _desc(sva: SparseVariationalApproximation, lik=None, quadrature=None, dtype=
         lik_code = _LIK[type(lik)]
         if isinstance(lik, GaussianLikelihood):
             s2 = float(lik.sigma2)
+        elif isinstance(lik, GammaLikelihood):
+            s2 = float(lik.alpha)   # the shape travels in the likelihood-parameter slot of the ABI
     qn = 0
     if isinstance(quadrature, GaussHermiteExpectation):
         qn = int(quadrature.n)

@@ -12,6 +12,7 @@
 
 #include "../../include/svgp_mi355x.h"
 #include "kernels.hpp"
+#include "lik.hpp"
 
 using namespace svgp;
 
@@ -191,7 +192,7 @@ int validate_desc(svgp_ctx* ctx, const svgp_model_desc* d) {
   if (!d) return fail(ctx, SVGP_INVALID_ARG, "null model descriptor");
   if (d->dtype != SVGP_F64 && d->dtype != SVGP_F32) return fail(ctx, SVGP_INVALID_ARG, "dtype must be SVGP_F64 or SVGP_F32");
   if (d->kernel < 0 || d->kernel > SVGP_KERNEL_MATERN52) return fail(ctx, SVGP_UNSUPPORTED, "unsupported kernel family");
-  if (d->likelihood < 0 || d->likelihood > SVGP_LIK_POISSON_EXP) return fail(ctx, SVGP_UNSUPPORTED, "unsupported likelihood");
+  if (d->likelihood < 0 || d->likelihood > SVGP_LIK_GAMMA_EXP) return fail(ctx, SVGP_UNSUPPORTED, "unsupported likelihood");
   if (d->parametrization != SVGP_NONCENTERED && d->parametrization != SVGP_CENTERED)
     return fail(ctx, SVGP_INVALID_ARG, "parametrization must be SVGP_NONCENTERED or SVGP_CENTERED");
   if (d->d < 1 || d->d > 32) return fail(ctx, SVGP_UNSUPPORTED, "input dimension must be in 1..32");
@@ -202,12 +203,18 @@ int validate_desc(svgp_ctx* ctx, const svgp_model_desc* d) {
   if (!d->inv_lengthscale || !d->z || !d->m || !d->Lq) return fail(ctx, SVGP_INVALID_ARG, "null parameter array");
   if (!(d->variance > 0)) return fail(ctx, SVGP_INVALID_ARG, "kernel variance must be positive");
   if (d->likelihood == SVGP_LIK_GAUSSIAN && !(d->lik_sigma2 > 0)) return fail(ctx, SVGP_INVALID_ARG, "Gaussian likelihood needs sigma2 > 0");
+  if (d->likelihood == SVGP_LIK_GAMMA_EXP && !(d->lik_sigma2 > 0)) return fail(ctx, SVGP_INVALID_ARG, "Gamma likelihood needs shape alpha > 0");
   return SVGP_OK;
+}
+
+// Gaussian sigma^2 / Gamma shape alpha; 1 for the parameter-free likelihoods
+double lik_param(const svgp_model_desc& d) {
+  return (d.likelihood == SVGP_LIK_GAUSSIAN || d.likelihood == SVGP_LIK_GAMMA_EXP) ? d.lik_sigma2 : 1.0;
 }
 
 int effective_gh(const svgp_model_desc& d) {
   if (d.quadrature_n > 0) return d.quadrature_n;
-  if (d.likelihood == SVGP_LIK_GAUSSIAN || d.likelihood == SVGP_LIK_POISSON_EXP) return 0;  // closed forms
+  if (d.likelihood != SVGP_LIK_BERNOULLI_LOGISTIC) return 0;  // closed forms [GPLikelihoods AnalyticExpectation]
   return 20;  // DefaultExpectationMethod -> GaussHermiteExpectation(20)  [GPLikelihoods]
 }
 
@@ -359,7 +366,8 @@ int enqueue_strips(svgp_ctx* ctx, svgp_model* m, const void* x, int64_t ldx, con
   LikParams lp{};
   lp.lik = m->desc.likelihood;
   lp.gh_n = m->gh_n;
-  lp.sigma2 = m->desc.likelihood == SVGP_LIK_GAUSSIAN ? m->desc.lik_sigma2 : 1.0;
+  lp.sigma2 = lik_param(m->desc);
+  lp.digamma_alpha = m->desc.likelihood == SVGP_LIK_GAMMA_EXP ? digamma_d(m->desc.lik_sigma2) : 0.0;
   lp.gh_x = m->gh_x;
   lp.gh_w = m->gh_w;
   lp.clamp_neg_var = (m->desc.neg_var_policy == SVGP_NEGVAR_CLAMP);
@@ -978,7 +986,8 @@ int elbo_grad_impl(svgp_ctx* ctx, svgp_model* m, const svgp_data* data, int64_t 
   LikParams lp{};
   lp.lik = m->desc.likelihood;
   lp.gh_n = m->gh_n;
-  lp.sigma2 = m->desc.likelihood == SVGP_LIK_GAUSSIAN ? m->desc.lik_sigma2 : 1.0;
+  lp.sigma2 = lik_param(m->desc);
+  lp.digamma_alpha = m->desc.likelihood == SVGP_LIK_GAMMA_EXP ? digamma_d(m->desc.lik_sigma2) : 0.0;
   lp.gh_x = m->gh_x;
   lp.gh_w = m->gh_w;
   lp.clamp_neg_var = (m->desc.neg_var_policy == SVGP_NEGVAR_CLAMP);

@@ -16,7 +16,8 @@ struct KernelParams {
 struct LikParams {
   int lik;            // SVGP_LIK_*
   int gh_n;           // 0 = closed form
-  double sigma2;
+  double sigma2;      // likelihood parameter: Gaussian sigma^2, Gamma shape alpha (1 otherwise)
+  double digamma_alpha;  // digamma(alpha) for the Gamma likelihood's parameter gradient
   const double* gh_x; // [gh_n] nodes (device)
   const double* gh_w; // [gh_n] weights / sqrt(pi) (device)
   int clamp_neg_var;

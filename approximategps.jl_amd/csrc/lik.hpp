@@ -10,6 +10,18 @@ namespace svgp {
 
 __device__ __forceinline__ double softplus_d(double s) { return fmax(s, 0.0) + log1p(exp(-fabs(s))); }
 
+// digamma: recurrence up to x >= 6, then the asymptotic series (|error| < 1e-14)
+__host__ __device__ inline double digamma_d(double x) {
+  double r = 0.0;
+  while (x < 6.0) {
+    r -= 1.0 / x;
+    x += 1.0;
+  }
+  const double f = 1.0 / (x * x);
+  return r + log(x) - 0.5 / x -
+         f * (1.0 / 12.0 - f * (1.0 / 120.0 - f * (1.0 / 252.0 - f * (1.0 / 240.0 - f * (1.0 / 132.0)))));
+}
+
 // log p(y | f)  [GPLikelihoods]
 __device__ __forceinline__ double loglik_point(int lik, double f, double y, double sigma2, double log_sigma2) {
   if (lik == 0) {
@@ -17,7 +29,9 @@ __device__ __forceinline__ double loglik_point(int lik, double f, double y, doub
     return -0.5 * (1.8378770664093453 + log_sigma2 + r * r / sigma2);
   }
   if (lik == 1) return -softplus_d(y > 0.5 ? -f : f);
-  return y * f - exp(f) - lgamma(y + 1.0);
+  if (lik == 2) return y * f - exp(f) - lgamma(y + 1.0);
+  if (lik == 3) return f - y * exp(f);                                           // Exponential(rate e^f)
+  return (sigma2 - 1.0) * log(y) - y * exp(-f) - sigma2 * f - lgamma(sigma2);    // Gamma(alpha = sigma2, scale e^f)
 }
 
 // E_{N(mu, v)}[log p(y|f)]: closed form (gh_n == 0) or Gauss-Hermite  [GPLikelihoods.expected_loglikelihood]
@@ -28,7 +42,9 @@ __device__ __forceinline__ double expected_loglik_point(const LikParams& lp, dou
       const double r = y - mu;
       return -0.5 * (1.8378770664093453 + log_sigma2 + (r * r + v) / lp.sigma2);
     }
-    return y * mu - exp(mu + 0.5 * v) - lgamma(y + 1.0);  // Poisson, exp link
+    if (lp.lik == 2) return y * mu - exp(mu + 0.5 * v) - lgamma(y + 1.0);  // Poisson, exp link
+    if (lp.lik == 3) return mu - y * exp(mu + 0.5 * v);                    // Exponential, exp link
+    return (lp.sigma2 - 1.0) * log(y) - y * exp(0.5 * v - mu) - lp.sigma2 * mu - lgamma(lp.sigma2);  // Gamma, exp link
   }
   const double s = 1.4142135623730951 * sqrt(v);
   double acc = 0.0;
@@ -41,7 +57,9 @@ __device__ __forceinline__ double expected_loglik_point(const LikParams& lp, dou
 __device__ __forceinline__ double dloglik_point(int lik, double f, double y, double sigma2) {
   if (lik == 0) return (y - f) / sigma2;
   if (lik == 1) return y - 1.0 / (1.0 + exp(-f));
-  return y - exp(f);
+  if (lik == 2) return y - exp(f);
+  if (lik == 3) return 1.0 - y * exp(f);
+  return y * exp(-f) - sigma2;
 }
 
 // (dE/dmu, dE/dv, dE/dsigma2) of expected_loglik_point: closed forms, or Gauss-Hermite with
@@ -55,10 +73,19 @@ __device__ __forceinline__ void expected_loglik_grad_point(const LikParams& lp, 
       gmu = r / lp.sigma2;
       gv = -0.5 / lp.sigma2;
       gs2 = -0.5 * (1.0 / lp.sigma2 - (r * r + v) / (lp.sigma2 * lp.sigma2));
-    } else {
+    } else if (lp.lik == 2) {
       const double e = exp(mu + 0.5 * v);
       gmu = y - e;
       gv = -0.5 * e;
+    } else if (lp.lik == 3) {
+      const double e = y * exp(mu + 0.5 * v);
+      gmu = 1.0 - e;
+      gv = -0.5 * e;
+    } else {
+      const double e = y * exp(0.5 * v - mu);
+      gmu = e - lp.sigma2;
+      gv = -0.5 * e;
+      gs2 = log(y) - mu - lp.digamma_alpha;      // d/d alpha
     }
     return;
   }
@@ -72,6 +99,7 @@ __device__ __forceinline__ void expected_loglik_grad_point(const LikParams& lp, 
     gmu += lp.gh_w[q] * dl;
     gv += lp.gh_w[q] * dl * lp.gh_x[q] * inv_s;
     if (lp.lik == 0) gs2 += lp.gh_w[q] * (-0.5 / lp.sigma2 + 0.5 * (y - f) * (y - f) / (lp.sigma2 * lp.sigma2));
+    if (lp.lik == 4) gs2 += lp.gh_w[q] * (log(y) - f - lp.digamma_alpha);
   }
 }
 

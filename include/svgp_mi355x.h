@@ -51,7 +51,13 @@ enum { SVGP_COLVECS = 0, SVGP_ROWVECS = 1, SVGP_VEC = 2 };
 enum { SVGP_KERNEL_SE = 0, SVGP_KERNEL_MATERN32 = 1, SVGP_KERNEL_MATERN52 = 2 };
 
 /* likelihoods [GPLikelihoods]; SVA:307-317 wraps FiniteGP noise as GAUSSIAN(σ² = fx.Σy[1]) */
-enum { SVGP_LIK_GAUSSIAN = 0, SVGP_LIK_BERNOULLI_LOGISTIC = 1, SVGP_LIK_POISSON_EXP = 2 };
+enum {
+  SVGP_LIK_GAUSSIAN = 0,
+  SVGP_LIK_BERNOULLI_LOGISTIC = 1,
+  SVGP_LIK_POISSON_EXP = 2,      /* PoissonLikelihood(exp):      y ~ Poisson(exp f) */
+  SVGP_LIK_EXPONENTIAL_EXP = 3,  /* ExponentialLikelihood(exp):  y ~ Exponential(rate exp f) */
+  SVGP_LIK_GAMMA_EXP = 4         /* GammaLikelihood(alpha, exp): y ~ Gamma(shape alpha, scale exp f); alpha in lik_sigma2 */
+};
 
 /* SVA:41 Centered, SVA:57 NonCentered (the 2-arg constructor's default, SVA:93-95) */
 enum { SVGP_NONCENTERED = 0, SVGP_CENTERED = 1 };
@@ -80,7 +86,7 @@ typedef struct svgp_model_desc {
   const double* inv_lengthscale; /* d entries; isotropic = all equal */
   double mean_const;       /* ConstMean value, 0 for ZeroMean */
   double jitter;           /* fz.Σy (isotropic), part of Kuu (src/utils.jl:17) */
-  double lik_sigma2;       /* GaussianLikelihood σ² */
+  double lik_sigma2;       /* likelihood parameter: GaussianLikelihood σ², GammaLikelihood shape α; unused otherwise */
   const void* z;           /* inducing inputs */
   const void* m;           /* mean(q), M */
   const void* Lq;          /* _chol_lower(_chol_cov(q)) (src/utils.jl:15,18), M×M, upper triangle ignored */
@@ -155,7 +161,7 @@ int32_t svgp_elbo_host(svgp_ctx* ctx, const svgp_model_desc* desc, int32_t layou
  * dtype / layout of the corresponding svgp_model_desc arrays (Lq: lower triangle, upper zeroed); NULL skips one. */
 typedef struct svgp_grads {
   double variance;          /* d elbo / d kernel variance */
-  double lik_sigma2;        /* d elbo / d GaussianLikelihood sigma^2 (0 for other likelihoods) */
+  double lik_sigma2;        /* d elbo / d likelihood parameter (Gaussian sigma^2, Gamma alpha; 0 otherwise) */
   double mean_const;        /* d elbo / d ConstMean value */
   double* inv_lengthscale;  /* d entries */
   void* z;

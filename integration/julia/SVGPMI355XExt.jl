@@ -107,6 +107,8 @@ unpack_mean(::Any) = nothing
 unpack_lik(l::GaussianLikelihood) = (Int32(0), Float64(only(l.σ²)))
 unpack_lik(::BernoulliLikelihood{<:LogisticLink}) = (Int32(1), 1.0)
 unpack_lik(::PoissonLikelihood{<:ExpLink}) = (Int32(2), 1.0)
+unpack_lik(::ExponentialLikelihood{<:ExpLink}) = (Int32(3), 1.0)
+unpack_lik(l::GammaLikelihood{<:Any,<:ExpLink}) = (Int32(4), Float64(only(l.α)))   # shape in the parameter slot
 unpack_lik(::Any) = nothing
 
 layout(x::ColVecs) = (Int32(0), x.X, size(x.X, 1))

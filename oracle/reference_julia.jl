@@ -27,7 +27,8 @@ function check(path)
     # q = MvNormal(m, PDMat(Cholesky(LowerTriangular(A))))  as in examples/a-regression/script.jl:110-111
     q = MvNormal(vec(g["m"]), PDMat(Cholesky(LowerTriangular(g["Lq"]))))
     sva = SparseVariationalApproximation(f(z, scalar(g["jitter"])), q)          # NonCentered (SVA:93-95)
-    lik = lk == 0 ? GaussianLikelihood(scalar(g["sigma2"])) : lk == 1 ? BernoulliLikelihood() : PoissonLikelihood()
+    lik = lk == 0 ? GaussianLikelihood(scalar(g["sigma2"])) : lk == 1 ? BernoulliLikelihood() :
+          lk == 2 ? PoissonLikelihood() : lk == 3 ? ExponentialLikelihood() : GammaLikelihood(scalar(g["sigma2"]))  # shape α stored in "sigma2"
     quad = qn == 0 ? GPLikelihoods.DefaultExpectationMethod() : GaussHermiteExpectation(qn)
     nd = scalar(g["num_data"]) < 0 ? length(y) : scalar(g["num_data"])
     lfx = LatentGP(f, lik, 1e-18)(x)

@@ -38,7 +38,7 @@ from typing import Optional, Tuple
 
 import numpy as np
 import scipy.linalg as sla
-from scipy.special import gammaln
+from scipy.special import digamma, gammaln
 
 # ----------------------------------------------------------------------------
 # constants of the dependency layer
@@ -53,6 +53,8 @@ KERNEL_MATERN52 = 2
 LIK_GAUSSIAN = 0
 LIK_BERNOULLI_LOGISTIC = 1
 LIK_POISSON_EXP = 2
+LIK_EXPONENTIAL_EXP = 3  # ExponentialLikelihood(exp): y ~ Exponential(rate exp f)  [dep GPLikelihoods]
+LIK_GAMMA_EXP = 4        # GammaLikelihood(alpha, exp): y ~ Gamma(shape alpha, scale exp f); alpha passed as `sigma2`
 
 _SQRT3 = math.sqrt(3.0)
 _SQRT5 = math.sqrt(5.0)
@@ -300,6 +302,10 @@ def loglik(lik: int, f: np.ndarray, y: np.ndarray, sigma2: float = 1.0) -> np.nd
         return -np.logaddexp(0.0, s)
     if lik == LIK_POISSON_EXP:
         return y * f - np.exp(f) - gammaln(y + 1.0)
+    if lik == LIK_EXPONENTIAL_EXP:   # logpdf(Exponential(scale = 1 / exp f), y)
+        return f - y * np.exp(f)
+    if lik == LIK_GAMMA_EXP:         # logpdf(Gamma(alpha, scale = exp f), y), alpha = sigma2
+        return (sigma2 - 1.0) * np.log(y) - y * np.exp(-f) - sigma2 * f - gammaln(sigma2)
     raise ValueError("unknown likelihood")
 
 
@@ -313,8 +319,8 @@ def expected_loglik(
 ) -> float:
     """expected_loglikelihood(quadrature, lik, q_f, y) -> scalar (SVA:355).
 
-    quadrature_n == 0 is DefaultExpectationMethod: analytic for Gaussian (and Poisson with
-    exp link), otherwise Gauss–Hermite with 20 points.  quadrature_n > 0 forces GH-n:
+    quadrature_n == 0 is DefaultExpectationMethod: analytic for Gaussian and for Poisson / Exponential / Gamma with
+    the exp link (E[exp(±f)] = exp(±μ + v/2)), otherwise Gauss–Hermite with 20 points.  quadrature_n > 0 forces GH-n:
     E[g(f)] ≈ π^{-1/2} Σ_j w_j g(√2 σ x_j + μ).
     """
     if quadrature_n == 0:
@@ -324,6 +330,10 @@ def expected_loglik(
         if lik == LIK_POISSON_EXP:
             v = sigma * sigma
             return float(np.sum(y * mu - np.exp(mu + 0.5 * v) - gammaln(y + 1.0)))
+        if lik == LIK_EXPONENTIAL_EXP:
+            return float(np.sum(mu - y * np.exp(mu + 0.5 * sigma * sigma)))
+        if lik == LIK_GAMMA_EXP:
+            return float(np.sum((sigma2 - 1.0) * np.log(y) - y * np.exp(0.5 * sigma * sigma - mu) - sigma2 * mu - gammaln(sigma2)))
         quadrature_n = DEFAULT_GH_POINTS
     xs, ws = gausshermite(quadrature_n)
     acc = np.zeros_like(mu, dtype=np.float64)
@@ -509,8 +519,13 @@ def synth_problem(
     elif lik == LIK_BERNOULLI_LOGISTIC:
         p = 1.0 / (1.0 + np.exp(-2.0 * np.sin(s)))
         y = (rng.random(N) < p).astype(np.float64)
-    else:
+    elif lik == LIK_POISSON_EXP:
         y = rng.poisson(np.exp(np.sin(s))).astype(np.float64)
+    elif lik == LIK_EXPONENTIAL_EXP:
+        y = rng.exponential(np.exp(-np.sin(s)))
+    else:
+        sigma2 = 2.5  # the Gamma shape alpha travels in the likelihood-parameter slot
+        y = rng.gamma(sigma2, np.exp(np.sin(s)))
     if jitter is None:
         jitter = 1e-5 if np.dtype(dtype) == np.float64 else 1e-3
     rt = lambda a: np.asarray(a, dtype=dtype).astype(np.float64)
@@ -540,17 +555,28 @@ def _dloglik(lik: int, f, y, sigma2):
         return (y - f) / sigma2
     if lik == LIK_BERNOULLI_LOGISTIC:
         return y - 1.0 / (1.0 + np.exp(-f))
-    return y - np.exp(f)
+    if lik == LIK_POISSON_EXP:
+        return y - np.exp(f)
+    if lik == LIK_EXPONENTIAL_EXP:
+        return 1.0 - y * np.exp(f)
+    return y * np.exp(-f) - sigma2
 
 
 def expected_loglik_grads(lik, mu, v, y, sigma2=1.0, quadrature_n=0):
-    """(dE/dmu_i, dE/dv_i, dE/dsigma2) of expected_loglik() with sigma = sqrt(v)."""
+    """(dE/dmu_i, dE/dv_i, dE/dsigma2) of expected_loglik() with sigma = sqrt(v); `sigma2` is the likelihood
+    parameter (Gaussian sigma^2, Gamma shape alpha)."""
     if quadrature_n == 0 and lik == LIK_GAUSSIAN:
         r = y - mu
         return r / sigma2, np.full_like(mu, -0.5 / sigma2), float(np.sum(-0.5 * (1.0 / sigma2 - (r * r + v) / sigma2**2)))
     if quadrature_n == 0 and lik == LIK_POISSON_EXP:
         e = np.exp(mu + 0.5 * v)
         return y - e, -0.5 * e, 0.0
+    if quadrature_n == 0 and lik == LIK_EXPONENTIAL_EXP:
+        e = y * np.exp(mu + 0.5 * v)
+        return 1.0 - e, -0.5 * e, 0.0
+    if quadrature_n == 0 and lik == LIK_GAMMA_EXP:
+        e = y * np.exp(0.5 * v - mu)
+        return e - sigma2, -0.5 * e, float(np.sum(np.log(y) - mu - digamma(sigma2)))
     n = quadrature_n or DEFAULT_GH_POINTS
     xs, ws = gausshermite(n)
     ws = ws / math.sqrt(math.pi)
@@ -565,6 +591,8 @@ def expected_loglik_grads(lik, mu, v, y, sigma2=1.0, quadrature_n=0):
         gv += wj * d * xj / (math.sqrt(2.0) * sd)
         if lik == LIK_GAUSSIAN:
             gs2 += float(np.sum(wj * (-0.5 / sigma2 + 0.5 * (y - f) ** 2 / sigma2**2)))
+        if lik == LIK_GAMMA_EXP:
+            gs2 += float(np.sum(wj * (np.log(y) - f - digamma(sigma2))))
     return gmu, gv, gs2
 
 

@@ -19,11 +19,16 @@ CASES = [
     ("m52_bern_gh20", 3, 300, 40, 4, o.KERNEL_MATERN52, o.LIK_BERNOULLI_LOGISTIC, 0, 1234.5),
     ("m32_poisson", 4, 257, 17, 2, o.KERNEL_MATERN32, o.LIK_POISSON_EXP, 0, None),
     ("se_gauss_gh7", 5, 129, 130, 3, o.KERNEL_SE, o.LIK_GAUSSIAN, 7, 5000.0),
+    ("m52_gamma", 6, 211, 23, 3, o.KERNEL_MATERN52, o.LIK_GAMMA_EXP, 0, 999.0),
+    ("se_exponential_gh11", 7, 150, 31, 2, o.KERNEL_SE, o.LIK_EXPONENTIAL_EXP, 11, None),
 ]
 
 
 def main():
+    only = sys.argv[1:]   # optional: names of the cases to (re)generate
     for name, cid, N, M, d, fam, lik, qn, nd in CASES:
+        if only and name not in only:
+            continue
         x, y, sva, s2 = o.synth_problem(cid, N, M, d, family=fam, lik=lik)
         if name.startswith("c1"):
             rng = np.random.default_rng(99)

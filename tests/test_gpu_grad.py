@@ -30,6 +30,9 @@ CASES = [
     (900, 300, 16, o.KERNEL_MATERN52, o.LIK_BERNOULLI_LOGISTIC, 0),
     (640, 129, 2, o.KERNEL_SE, o.LIK_POISSON_EXP, 0),
     (513, 64, 5, o.KERNEL_MATERN52, o.LIK_GAUSSIAN, 9),
+    (450, 70, 3, o.KERNEL_MATERN32, o.LIK_EXPONENTIAL_EXP, 0),
+    (500, 60, 2, o.KERNEL_SE, o.LIK_GAMMA_EXP, 0),
+    (400, 33, 2, o.KERNEL_MATERN52, o.LIK_GAMMA_EXP, 8),
 ]
 
 
@@ -49,7 +52,7 @@ def test_gradient_matches_oracle(ctx, N, M, d, family, lik, qn, dtype, tol):
     _close(g["inv_lengthscale"], g_ref["inv_lengthscale"], tol)
     _close([g["variance"]], [g_ref["variance"]], tol)
     _close([g["mean_const"]], [g_ref["mean_const"]], tol)
-    if lik == o.LIK_GAUSSIAN:
+    if lik in (o.LIK_GAUSSIAN, o.LIK_GAMMA_EXP):   # the likelihood parameter: sigma^2 / Gamma shape
         _close([g["lik_sigma2"]], [g_ref["lik_sigma2"]], tol)
     # same value as the forward-only entry point
     assert rel(val, model.elbo(data, 0, N, 2.5 * N)[0]) < 1e-12

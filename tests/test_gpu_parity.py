@@ -44,6 +44,9 @@ CASES = [
     (900, 300, 16, o.KERNEL_MATERN52, o.LIK_BERNOULLI_LOGISTIC, 0),  # C3 kernel/lik, GH-20
     (640, 129, 2, o.KERNEL_SE, o.LIK_POISSON_EXP, 0),
     (513, 64, 5, o.KERNEL_MATERN52, o.LIK_GAUSSIAN, 9),       # GH on a Gaussian (K2)
+    (700, 96, 3, o.KERNEL_MATERN32, o.LIK_EXPONENTIAL_EXP, 0),  # exp-link closed forms
+    (650, 80, 4, o.KERNEL_SE, o.LIK_GAMMA_EXP, 0),
+    (333, 40, 2, o.KERNEL_SE, o.LIK_GAMMA_EXP, 12),             # Gamma through Gauss-Hermite
     (130, 140, 2, o.KERNEL_SE, o.LIK_GAUSSIAN, 0),            # M > N
     (1, 5, 1, o.KERNEL_SE, o.LIK_GAUSSIAN, 0),                # a single point
 ]
@@ -63,7 +66,7 @@ def test_elbo_fp64_matches_oracle(ctx, N, M, d, family, lik, qn):
     assert (t.n_points, t.n_neg_var, t.chol_info) == (N, 0, 0)
 
 
-@pytest.mark.parametrize("N,M,d,family,lik,qn", CASES[:6])
+@pytest.mark.parametrize("N,M,d,family,lik,qn", CASES[:9])
 def test_elbo_fp32_matches_oracle(ctx, N, M, d, family, lik, qn):
     x, y, sva, s2 = o.synth_problem(100 + N, N, M, d, family=family, lik=lik, dtype=np.float32)
     ref = o.elbo_terms(sva, x, y, lik=lik, sigma2=s2, quadrature_n=qn)

@@ -148,3 +148,22 @@ def test_minibatch_scale_and_negative_variance():
     bad.kernel = o.Kernel(o.KERNEL_SE, -1.0, sva.kernel.inv_lengthscale)  # forces Kuu indefinite
     with pytest.raises(o.PosDefException):
         o.posterior(bad)
+
+
+@pytest.mark.parametrize("lik", [o.LIK_POISSON_EXP, o.LIK_EXPONENTIAL_EXP, o.LIK_GAMMA_EXP])
+def test_exp_link_closed_forms_match_numerical_integration(lik):
+    """AnalyticExpectation of the exp-link likelihoods [GPLikelihoods]: E[exp(±f)] = exp(±mu + v/2).  Checked against
+    adaptive quadrature of log p(y|f) N(f; mu, v) and against Gauss-Hermite with 40 points."""
+    from scipy.integrate import quad
+
+    rng = np.random.default_rng(5)
+    mu, sd = rng.standard_normal(6) * 0.7, 0.2 + rng.random(6)
+    alpha = 2.5
+    y = np.array([0.0, 1.0, 3.0, 2.0, 5.0, 1.0]) if lik == o.LIK_POISSON_EXP else 0.1 + rng.random(6) * 3
+    closed = o.expected_loglik(lik, mu, sd, y, sigma2=alpha)
+    ref = 0.0
+    for m_, s_, y_ in zip(mu, sd, y):
+        f = lambda t: float(o.loglik(lik, np.array([t]), np.array([y_]), alpha)[0]) * np.exp(-0.5 * ((t - m_) / s_) ** 2) / (s_ * np.sqrt(2 * np.pi))
+        ref += quad(f, m_ - 12 * s_, m_ + 12 * s_, epsabs=1e-13, epsrel=1e-13, limit=400)[0]
+    assert closed == pytest.approx(ref, rel=1e-10)
+    assert closed == pytest.approx(o.expected_loglik(lik, mu, sd, y, sigma2=alpha, quadrature_n=40), rel=1e-12)

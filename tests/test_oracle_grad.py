@@ -20,7 +20,8 @@ def _fd(fun, x0, h):
 
 
 @pytest.mark.parametrize("family", [o.KERNEL_SE, o.KERNEL_MATERN32, o.KERNEL_MATERN52])
-@pytest.mark.parametrize("lik,qn", [(o.LIK_GAUSSIAN, 0), (o.LIK_BERNOULLI_LOGISTIC, 0), (o.LIK_POISSON_EXP, 0), (o.LIK_GAUSSIAN, 7)])
+@pytest.mark.parametrize("lik,qn", [(o.LIK_GAUSSIAN, 0), (o.LIK_BERNOULLI_LOGISTIC, 0), (o.LIK_POISSON_EXP, 0), (o.LIK_GAUSSIAN, 7),
+                                    (o.LIK_EXPONENTIAL_EXP, 0), (o.LIK_GAMMA_EXP, 0), (o.LIK_GAMMA_EXP, 9)])
 def test_gradient_matches_finite_differences(family, lik, qn):
     x, y, sva, s2 = o.synth_problem(31 + family, 40, 7, 3, family=family, lik=lik)
     sva.mean_const = 0.2
@@ -42,7 +43,7 @@ def test_gradient_matches_finite_differences(family, lik, qn):
     np.testing.assert_allclose(g["Lq"], np.tril(fdL), **tol)
     assert g["variance"] == pytest.approx(float(_fd(lambda t: with_(variance=float(t[0])), np.array([sva.kernel.variance]), 1e-6)[0]), rel=2e-6, abs=2e-6)
     assert g["mean_const"] == pytest.approx(float(_fd(lambda t: with_(c=float(t[0])), np.array([0.2]), 1e-6)[0]), rel=2e-6, abs=2e-6)
-    if lik == o.LIK_GAUSSIAN:
+    if lik in (o.LIK_GAUSSIAN, o.LIK_GAMMA_EXP):   # the likelihood parameter: sigma^2 / Gamma shape alpha
         assert g["lik_sigma2"] == pytest.approx(float(_fd(lambda t: with_(s2=float(t[0])), np.array([s2]), 1e-6)[0]), rel=2e-6, abs=2e-6)
 
 
