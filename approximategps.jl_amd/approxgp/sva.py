@@ -9,7 +9,7 @@ from dataclasses import dataclass
 import numpy as np
 
 from . import _ffi
-from .gp import (BernoulliLikelihood, DefaultExpectationMethod, FiniteGP, GaussHermiteExpectation,
+from .gp import (DEFAULT_SIGMA2, BernoulliLikelihood, DefaultExpectationMethod, FiniteGP, GaussHermiteExpectation,
                  GaussianLikelihood, LatentFiniteGP, MvNormal, PoissonLikelihood, ExponentialLikelihood, GammaLikelihood, _as_dn)
 from .kernels import unpack_kernel
 
@@ -190,6 +190,16 @@ class ApproxPosteriorGP:
     def mean_and_cov(self, x):  # SVA:237-244
         m, _, c = self._model.predict(x, True, False, True)
         return m, c
+
+    def rand(self, x, n_samples=1, jitter=DEFAULT_SIGMA2, rng=None):
+        """rand(f_post(x, jitter), n_samples) (examples/b-classification/script.jl:153) [dep AbstractGPs: mean +
+        cholesky(cov + jitter I).L ξ].  The moments come from the device (svgp_predict); the n x n factorisation of
+        the test covariance is host-side, as in the reference.  -> (n, n_samples)."""
+        m, c = self.mean_and_cov(x)
+        m, c = np.asarray(m, dtype=np.float64), np.asarray(c, dtype=np.float64)
+        L = np.linalg.cholesky(c + float(jitter) * np.eye(c.shape[0]))
+        rng = rng if rng is not None else np.random.default_rng()
+        return m[:, None] + L @ rng.standard_normal((c.shape[0], int(n_samples)))
 
     def marginals(self, x):
         """marginals(f_post(x)) (SVA:354): (μ, σ) of Normal.(μ, sqrt.(v + 1e-18))."""

@@ -256,6 +256,17 @@ def test_python_mirror_end_to_end(ctx):
     np.testing.assert_allclose(mu, mu_ref, rtol=1e-9, atol=1e-10)
     np.testing.assert_allclose(v, v_ref, rtol=1e-9, atol=1e-10)
     assert ag.prior_kl(sva, ctx=ctx) == pytest.approx(o.prior_kl(osva), rel=1e-10)
+    # rand(f_post(x, jitter), n): sample moments against the device moments (examples/b-classification/script.jl:153)
+    xs = np.linspace(-1, 1, 7)
+    smp = post.rand(xs, 20000, jitter=1e-9, rng=np.random.default_rng(3))
+    ms, cs = post.mean_and_cov(xs)
+    assert smp.shape == (7, 20000)
+    np.testing.assert_allclose(smp.mean(axis=1), ms, atol=4 * np.sqrt(np.diag(cs).max() / 20000))
+    np.testing.assert_allclose(np.cov(smp), cs, atol=0.05 * np.abs(cs).max())
+    # Gamma likelihood through the mirror's classes (shape in the likelihood-parameter slot)
+    yg = np.random.default_rng(4).gamma(2.0, np.exp(np.sin(3 * x[:100])))
+    lg = ag.LatentGP(f, ag.GammaLikelihood(2.0), 1e-18)(x[:100])
+    assert rel(ag.elbo(sva, lg, yg, ctx=ctx), o.elbo(osva, x[:100], yg, lik=o.LIK_GAMMA_EXP, sigma2=2.0)) < F64_RTOL
 
 
 @pytest.mark.parametrize("dtype,tol", [(np.float64, F64_RTOL), (np.float32, F32_RTOL)])

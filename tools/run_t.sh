@@ -1,2 +1,2 @@
 cd $GRAFT_REPO_ROOT
-timeout 900 python -m pytest tests -m gpu -x -q -k golden 2>&1 | tail -4
+timeout 900 python -m pytest tests -m gpu -x -q -k "mirror" 2>&1 | tail -8
