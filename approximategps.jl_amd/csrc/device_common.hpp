@@ -180,6 +180,37 @@ struct TileGemm {
 #pragma unroll
     for (int p = 0; p < P_PASSES; ++p) *reinterpret_cast<V*>(Ps + (kk0 + p * P_RPP) * PLD + c) = r.v[p];
   }
+  // --- P tile global -> LDS without registers (LDS-DMA, global_load_lds_dwordx4): a k-row of the f64 tile is 128 x 8 B =
+  // 64 lanes x 16 B, exactly one wave instruction, and the padded LDS rows (PLD) stay legal because no instruction's
+  // bytes cross a row.  Wave w moves rows w, w + NW, ...  The LDS address is wave-uniform (M0), the global address is
+  // the wave-uniform tile base plus a fixed per-lane 32-bit offset.  Removes the tile's ds_write pass and its staging
+  // registers from the step; completion is covered by the vmcnt(0) of the step's closing __syncthreads().
+#ifndef SVGP_DMA_P
+#define SVGP_DMA_P 1
+#endif
+  static constexpr int NW = NTHR / 64;
+  static constexpr bool kDmaP = SVGP_DMA_P && (NB * sizeof(T) == 1024) && (BK % NW == 0);
+  static constexpr int D_ROWS = BK / NW;
+  struct DOff { uint32_t o[D_ROWS]; };
+  static __device__ __forceinline__ DOff d_offsets(int64_t ld) {
+    DOff r;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int q = 0; q < D_ROWS; ++q) r.o[q] = uint32_t((int64_t(wave + q * NW) * ld + lane * VEC) * sizeof(T));
+    return r;
+  }
+  static __device__ __forceinline__ void dma_p(const T* __restrict__ src, const DOff& off, T* __restrict__ Ps) {
+#if defined(SVGP_ABLATE) && (SVGP_ABLATE & 1)
+    (void)src; (void)off; (void)Ps;
+    return;
+#endif
+    const int wv = __builtin_amdgcn_readfirstlane(int(threadIdx.x >> 6));
+    const char* base = reinterpret_cast<const char*>(src);
+#pragma unroll
+    for (int q = 0; q < D_ROWS; ++q)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + off.o[q]),
+                                       (__attribute__((address_space(3))) void*)(Ps + (wv + q * NW) * PLD), 16, 0, 0);
+  }
   static __device__ __forceinline__ void load_q(QRegs& r, const T* __restrict__ src, const QOff& off) {
 #if defined(SVGP_ABLATE) && (SVGP_ABLATE & 2)
     (void)src; (void)off; asm volatile("" : "+v"(r.v[0]));  // diagnostic build: skip the Q-tile loads
@@ -274,8 +305,9 @@ struct TileGemm {
   // NLO/NHI: tile range of the NEXT step (its slab-0 fragments are read behind this step's barrier)
   template <int BUF, int ILO, int IHI, typename QLoad>
   static __device__ __forceinline__ void step(Acc& acc, Frag (&f)[2], PRegs& pr, QRegs& qr, const T* __restrict__ Pbase,
-                                              int64_t pstride, const POff& poff, int t, int nsteps, QLoad& qload,
-                                              T* __restrict__ smem, const T* __restrict__ fa, const T* __restrict__ fb) {
+                                              int64_t pstride, const POff& poff, const DOff& doff, int t, int nsteps,
+                                              QLoad& qload, T* __restrict__ smem, const T* __restrict__ fa,
+                                              const T* __restrict__ fb) {
     constexpr int KS = BK / 4;
     static_assert(KS % 2 == 0, "the fragment ping-pong needs an even number of k-slabs per step");
     const bool more = (t + 1 < nsteps);
@@ -292,15 +324,21 @@ struct TileGemm {
     }
     if (more) {
       T* Pn = smem + (BUF ^ 1) * STAGE;
-      store_p(pr, Pn);
+      if constexpr (!kDmaP) store_p(pr, Pn);
       store_q(qr, Pn + P_TILE);
     }
-    __syncthreads();
+    __syncthreads();   // with LDS-DMA: also the vmcnt(0) that lands the P tile of step t + 1
     if (more) {
       load_frag<BUF ^ 1, 0>(f[0], fa, fb);   // all tiles: the next step's range is not known at compile time
       if (t + 2 < nsteps) {
-        load_p(pr, Pbase + int64_t(t + 2) * pstride, poff);
-        qload(t + 2, qr);
+        if constexpr (kDmaP) {
+          // Q first: a generated Q tile consumes its own loads at once, which would drain a DMA issued before it
+          qload(t + 2, qr);
+          dma_p(Pbase + int64_t(t + 2) * pstride, doff, smem + BUF * STAGE);   // this step's buffer is free again
+        } else {
+          load_p(pr, Pbase + int64_t(t + 2) * pstride, poff);
+          qload(t + 2, qr);
+        }
       }
     }
     mma_frag<ILO, IHI>(acc, f[(KS - 1) & 1]);
@@ -311,7 +349,7 @@ struct TileGemm {
   // i.e. i >= SD/2 for the slower wave row (the barrier makes a step as long as its slower row, so both rows use the
   // same range: no branch on wr); upper step SD touches tiles <= SD, i.e. i <= SD/2.  20 of 32 tile-steps remain.
   // Straight-line code: no per-step dispatch, no per-MFMA predicates (both measured slower).
-#define SVGP_DSTEP(B, LO, HI, TT) step<B, LO, HI>(acc, f, pr, qr, Pbase, pstride, poff, (TT), nsteps, qload, smem, fa, fb)
+#define SVGP_DSTEP(B, LO, HI, TT) step<B, LO, HI>(acc, f, pr, qr, Pbase, pstride, poff, doff, (TT), nsteps, qload, smem, fa, fb)
 
   template <typename QLoad>
   static __device__ __forceinline__ void loop(Acc& acc, const T* __restrict__ Pbase, int64_t ldp, int nsteps,
@@ -329,19 +367,30 @@ struct TileGemm {
     constexpr int ND = NB / BK;
     static_assert(TRI == 0 || (ND == 8 && MI == 4), "triangular steps are written out for BK = 16, 128-row panels");
     const POff poff = p_offsets(ldp);
+    const DOff doff = d_offsets(ldp);
     const int64_t pstride = int64_t(BK) * ldp;
     const T* fa = smem + frag_a_off();
     const T* fb = smem + P_TILE + frag_b_off();
     PRegs pr;
     QRegs qr;
-    load_p(pr, Pbase, poff);
-    qload(0, qr);
-    store_p(pr, smem);
+    if constexpr (kDmaP) {
+      qload(0, qr);
+      dma_p(Pbase, doff, smem);
+    } else {
+      load_p(pr, Pbase, poff);
+      qload(0, qr);
+      store_p(pr, smem);
+    }
     store_q(qr, smem + P_TILE);
     __syncthreads();
     if (nsteps > 1) {
-      load_p(pr, Pbase + pstride, poff);
-      qload(1, qr);
+      if constexpr (kDmaP) {
+        qload(1, qr);
+        dma_p(Pbase + pstride, doff, smem + STAGE);
+      } else {
+        load_p(pr, Pbase + pstride, poff);
+        qload(1, qr);
+      }
     }
     Frag f[2];
     load_frag<0, 0>(f[0], fa, fb);
@@ -353,10 +402,10 @@ struct TileGemm {
     }
     const int nreg = (TRI > 0) ? nsteps - ND : nsteps;
     for (; t + 1 < nreg; t += 2) {
-      step<0, 0, MI - 1>(acc, f, pr, qr, Pbase, pstride, poff, t, nsteps, qload, smem, fa, fb);
-      step<1, 0, MI - 1>(acc, f, pr, qr, Pbase, pstride, poff, t + 1, nsteps, qload, smem, fa, fb);
+      step<0, 0, MI - 1>(acc, f, pr, qr, Pbase, pstride, poff, doff, t, nsteps, qload, smem, fa, fb);
+      step<1, 0, MI - 1>(acc, f, pr, qr, Pbase, pstride, poff, doff, t + 1, nsteps, qload, smem, fa, fb);
     }
-    if (t < nreg) step<0, 0, MI - 1>(acc, f, pr, qr, Pbase, pstride, poff, t, nsteps, qload, smem, fa, fb);
+    if (t < nreg) step<0, 0, MI - 1>(acc, f, pr, qr, Pbase, pstride, poff, doff, t, nsteps, qload, smem, fa, fb);
     if (TRI > 0) {
       SVGP_DSTEP(0, 0, 3, nreg + 0); SVGP_DSTEP(1, 0, 3, nreg + 1); SVGP_DSTEP(0, 1, 3, nreg + 2); SVGP_DSTEP(1, 1, 3, nreg + 3);
       SVGP_DSTEP(0, 2, 3, nreg + 4); SVGP_DSTEP(1, 2, 3, nreg + 5); SVGP_DSTEP(0, 3, 3, nreg + 6); SVGP_DSTEP(1, 3, 3, nreg + 7);
