@@ -1,5 +1,7 @@
 cd $GRAFT_REPO_ROOT
-timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -3
-CFGS="H C2 C4" bash tools/run_ab.sh
-python tools/grad_time.py 2>/dev/null | tail -3
-SVGP_MI355X_LIB=$PWD/approximategps.jl_amd/csrc/ablate/libsvgp_prev.so python tools/grad_time.py 2>/dev/null | tail -3
+A=$PWD/approximategps.jl_amd/csrc/ablate
+for rep in 1 2; do
+python tools/ablate_time.py H 2>/dev/null
+for v in 1 2 3; do SVGP_MI355X_LIB=$A/libsvgp_nt$v.so python tools/ablate_time.py H 2>/dev/null; done
+done
+for v in 0 3; do L=$A/libsvgp_nt$v.so; [ $v = 0 ] && L=$PWD/approximategps.jl_amd/csrc/libsvgp_mi355x.so; SVGP_MI355X_LIB=$L python tools/ablate_time.py H32 2>/dev/null; SVGP_MI355X_LIB=$L python tools/ablate_time.py C4 2>/dev/null; done
