@@ -9,6 +9,8 @@
 //   kernel parameters / inducing inputs from sum_ij P_ij dK_ij and Kuu_bar_ij dKuu_ij (kgrad_kernel)
 // The data are processed in chunks of columns; per chunk the strip kernel leaves A and C in HBM in both
 // orientations ([Mp][nc] for the panel recurrences, [nc][Mp] for the products contracted over points).
+#include <cstdlib>
+
 #include "device_common.hpp"
 #include "kernels.hpp"
 #include "lik.hpp"
@@ -135,15 +137,19 @@ __global__ void __launch_bounds__(k256, 2) solve_t_kernel(const T* __restrict__ 
 }
 
 // out[slice][r][c] += sum_{i in slice} w_i Xt[i][r] Yt[i][c]   (Xt, Yt point-major [n][Mp]; lower tiles only)
-template <typename T>
-__global__ void __launch_bounds__(kThreads, 2) gemm_pm_kernel(const T* __restrict__ Xt, const T* __restrict__ Yt,
-                                                               const T* __restrict__ w, T wscale, int64_t Mp, int64_t n,
-                                                               int64_t slice_len, T* __restrict__ out) {
-  using G = TileGemm<T, kNB, 16, kThreads>;
+// NT = 128 / 512 threads: one workgroup per 128 x 128 output tile; NT = 64 / 256 threads: two 128 x 64 halves on
+// separate workgroups (the strip kernel's geometry: the two waves of a SIMD belong to different workgroups)
+template <typename T, int NT, int NTHR>
+__global__ void __launch_bounds__(NTHR, 2) gemm_pm_kernel(const T* __restrict__ Xt, const T* __restrict__ Yt,
+                                                           const T* __restrict__ w, T wscale, int64_t Mp, int64_t n,
+                                                           int64_t slice_len, T* __restrict__ out) {
+  using G = TileGemm<T, NT, 16, NTHR>;
   using QRegs = typename G::QRegs;
+  constexpr int NCH = kNB / NT;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   T* smem = reinterpret_cast<T*>(smem_raw);
-  int ti = 0, b = blockIdx.x;
+  const int chunk = blockIdx.x % NCH;
+  int ti = 0, b = blockIdx.x / NCH;
   while (b >= ti + 1) { b -= ti + 1; ++ti; }
   const int tj = b;
   const int64_t i0 = int64_t(blockIdx.y) * slice_len;
@@ -153,7 +159,7 @@ __global__ void __launch_bounds__(kThreads, 2) gemm_pm_kernel(const T* __restric
   acc.zero();
   if (i1 > i0) {
     const typename G::QOff qoff = G::q_offsets(Mp);
-    const T* yq = Yt + i0 * Mp + int64_t(tj) * kNB;
+    const T* yq = Yt + i0 * Mp + int64_t(tj) * kNB + chunk * NT;
     auto qload = [&](int t, QRegs& r) {
       G::load_q(r, yq + int64_t(t) * 16 * Mp, qoff);
       if (w) {
@@ -169,7 +175,7 @@ __global__ void __launch_bounds__(kThreads, 2) gemm_pm_kernel(const T* __restric
     };
     G::loop(acc, Xt + i0 * Mp + int64_t(ti) * kNB, Mp, int((i1 - i0) / 16), qload, smem);
   }
-  T* o = out + int64_t(blockIdx.y) * Mp * Mp + int64_t(ti) * kNB * Mp + int64_t(tj) * kNB;
+  T* o = out + int64_t(blockIdx.y) * Mp * Mp + int64_t(ti) * kNB * Mp + int64_t(tj) * kNB + chunk * NT;
 #pragma unroll
   for (int i = 0; i < G::MI; ++i)
 #pragma unroll
@@ -528,13 +534,24 @@ void launch_solve_t(int dtype, hipStream_t s, const void* S, void* X, void* Xt, 
 
 void launch_gemm_pm(int dtype, hipStream_t s, const void* Xt, const void* Yt, const void* w, double wscale, int64_t Mp,
                     int64_t n, int64_t slice_len, int nslices, void* out) {
-  const int nP = int(Mp / kNB);
-  dim3 grid((unsigned)(nP * (nP + 1) / 2), (unsigned)nslices);
+  const int nP = int(Mp / kNB), ntiles = nP * (nP + 1) / 2;
+  // f64: 128 x 64 halves on 256-thread workgroups (same-box: H value-and-gradient 141.0 -> 138.4 ms); f32: no difference
+  static const int forced = [] { const char* e = getenv("SVGP_GEMM_PM_NT"); return e ? atoi(e) : 0; }();   // tuning knob
+  const int nt = forced ? forced : (dtype == 0 ? 64 : 128);
   GD(dtype, T, {
-    using G = TileGemm<T, kNB, 16, kThreads>;
-    set_max_lds(reinterpret_cast<const void*>(gemm_pm_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, int(G::LDS_BYTES));
-    hipLaunchKernelGGL(gemm_pm_kernel<T>, grid, dim3(kThreads), G::LDS_BYTES, s, (const T*)Xt, (const T*)Yt, (const T*)w, T(wscale),
-                       Mp, n, slice_len, (T*)out);
+    if (nt == 64) {
+      using G = TileGemm<T, 64, 16, k256>;
+      auto kern = gemm_pm_kernel<T, 64, k256>;
+      set_max_lds(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, int(G::LDS_BYTES));
+      hipLaunchKernelGGL(kern, dim3((unsigned)(ntiles * 2), (unsigned)nslices), dim3(k256), G::LDS_BYTES, s, (const T*)Xt,
+                         (const T*)Yt, (const T*)w, T(wscale), Mp, n, slice_len, (T*)out);
+    } else {
+      using G = TileGemm<T, kNB, 16, kThreads>;
+      auto kern = gemm_pm_kernel<T, kNB, kThreads>;
+      set_max_lds(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, int(G::LDS_BYTES));
+      hipLaunchKernelGGL(kern, dim3((unsigned)ntiles, (unsigned)nslices), dim3(kThreads), G::LDS_BYTES, s, (const T*)Xt,
+                         (const T*)Yt, (const T*)w, T(wscale), Mp, n, slice_len, (T*)out);
+    }
   });
 }
 
