@@ -998,10 +998,17 @@ int elbo_grad_impl(svgp_ctx* ctx, svgp_model* m, const svgp_data* data, int64_t 
     const int64_t ncp = (clen + 127) / 128 * 128;
     StripOuts o;
     o.A = w->A; o.C = w->C; o.lda = ldk; o.skip_expect = true;   // k-major [Mp][nc]; point-major copies by transposition
+    // f64: the strip kernel also scatters the point-major copies itself (32 B pieces; L2 merges them) instead of two
+    // transposition passes: value-and-gradient 137.0 -> 134.5 ms at H; f32 (16 B pieces): 73.8 -> 75.0 ms, so not there
+    static const int direct_env = [] { const char* e = getenv("SVGP_GRAD_DIRECT_T"); return e ? atoi(e) : -1; }();
+    const bool direct_t = direct_env >= 0 ? direct_env != 0 : dt == SVGP_F64;
+    if (direct_t) { o.At = w->At; o.Ct = w->Ct; }
     rc = enqueue_strips(ctx, m, data->x, data->ldx, nullptr, off + c0, clen, o);
     if (rc) return rc;
-    launch_to_point_major(dt, s, w->A, ldk, Mp, ncp, w->At);
-    launch_to_point_major(dt, s, w->C, ldk, Mp, ncp, w->Ct);
+    if (!direct_t) {
+      launch_to_point_major(dt, s, w->A, ldk, Mp, ncp, w->At);
+      launch_to_point_major(dt, s, w->C, ldk, Mp, ncp, w->Ct);
+    }
     launch_grad_moments(dt, s, lp, scale, ctx->mom, ctx->mom + ctx->mom_cap, data->y, off + c0, clen, ncp, w->gmu, w->gv,
                         w->partial5, w->sums);
     KCHECK(ctx, "grad_moments");

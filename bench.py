@@ -103,7 +103,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--config", default="H", choices=sorted(CONFIGS))
-    ap.add_argument("--cpu-sample", type=int, default=20000)
+    ap.add_argument("--cpu-sample", type=int, default=100000)   # ~10 s of host work at H
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kuf", action="store_true")
     ap.add_argument("--no-grad", action="store_true")
