@@ -895,8 +895,10 @@ namespace {
 int grad_workspace(svgp_ctx* ctx, svgp_model* m, int64_t len, GradWs** out) {
   const size_t es = m->es;
   const int64_t Mp = m->Mp;
-  int64_t cap = int64_t(1.0e9 / double(Mp * int64_t(es))) / 128 * 128;
-  cap = cap < 128 ? 128 : (cap > 65536 ? 65536 : cap);
+  static const int64_t cap_cols = [] { const char* e = getenv("SVGP_GRAD_CHUNK"); return e ? atoll(e) : 65536ll; }();   // tuning knob
+  static const double cap_bytes = [] { const char* e = getenv("SVGP_GRAD_CHUNK_BYTES"); return e ? atof(e) : 1.0e9; }();
+  int64_t cap = int64_t(cap_bytes / double(Mp * int64_t(es))) / 128 * 128;
+  cap = cap < 128 ? 128 : (cap > cap_cols ? cap_cols : cap);
   int64_t nc = (len + 127) / 128 * 128;
   nc = nc < cap ? nc : cap;
   GradWs* w = ctx->gws;
