@@ -195,6 +195,7 @@ def main():
     value = world * args.steps / elapsed                    # 1e6-point ELBO evaluations per second, whole job
     strip_avg_ms = float(np.mean(strip_ms))
     Mp = (M + 127) // 128 * 128
+    strip_w = 64 if (dtype == "f64" or Mp > 2048) else 128   # strip.hip: strip_nt()
     flops_strip = 2.0 * M * M * n                           # algorithmic: trsm + trmm
     ach = flops_strip / (strip_avg_ms * 1e-3) / 1e12
     out = {
@@ -212,7 +213,10 @@ def main():
         "roofline": {"kernel": "strip_kernel (fused Kuf -> trsm -> trmm)", "bound": "mfma", "achieved": ach,
                      "peak": PEAK_TFLOPS[dtype], "unit": "TFLOP/s", "frac": ach / PEAK_TFLOPS[dtype], "traffic": None,
                      "flops_per_launch": flops_strip, "ms_per_launch": strip_avg_ms,
-                     "executed_flops_per_launch": 2.0 * (Mp * Mp + Mp * 128.0) * math.ceil(n / 128) * 128},
+                     # MFMA work actually issued: full 128-row blocks below the diagonal + 20 of the 32 tile-steps of every
+                     # (triangular) diagonal block, per phase, on whole strips (matches SQ_INSTS_MFMA x 2048 of the PMC profile)
+                     "executed_flops_per_launch": 2.0 * 2.0 * 128 * 128 * ((Mp // 128) * (Mp // 128 - 1) / 2 + 0.625 * (Mp // 128))
+                     * strip_w * math.ceil(n / strip_w)},
         "breakdown_ms": {"prep (Kuu, cholesky, T panels, KL)": float(np.mean(prep_ms)), "strip": strip_avg_ms,
                          "expectation + reduce": float(np.mean(expect_ms))},
     }
