@@ -266,6 +266,36 @@ function value_and_grads(ÏƒÂ², invl, Z::Array{T}, m::Vector{T}, Lq::Matrix{T}, Ï
     return out[], (g.variance, gl, gz, gm, gLq, g.lik_sigma2, g.mean_const)
 end
 
+"""
+    shard_value_and_grads(ÏƒÂ², invl, Z, m, Lq, ÏƒÂ²lik, c, meta, D, off, len, scale, kl_weight)
+
+Data-parallel shard (one Julia process per GPU, MPI.jl / NCCL.jl for the collective): `scaleÂ·Î£E âˆ’ kl_weightÂ·KL` and its
+gradient over this rank's window.  With `scale = num_data / n_global`, `kl_weight = 1 / world_size` on every rank, ONE
+sum all-reduce of `(value, gradients...)` is the global ELBO and gradient (SVA:355-359), for both parametrisations.
+"""
+function shard_value_and_grads(ÏƒÂ², invl, Z::Array{T}, m::Vector{T}, Lq::Matrix{T}, ÏƒÂ²lik, c, meta, D, off, len, scale, kl_weight) where {T}
+    fam, par, lik, qn, lz, jit = meta
+    d = length(invl)
+    invl64 = collect(Float64, invl)
+    desc = ModelDesc(T === Float64 ? 0 : 1, fam, par, lik, qn, lz, 0, d, length(m), Float64(ÏƒÂ²), pointer(invl64),
+                     Float64(c), Float64(jit), Float64(ÏƒÂ²lik), pointer(Z), pointer(m), pointer(Lq))
+    out, terms = Ref{Float64}(), Terms()
+    gl, gz, gm, gLq = zeros(Float64, d), similar(Z), similar(m), similar(Lq)
+    g = Grads(0, 0, 0, pointer(gl), pointer(gz), pointer(gm), pointer(gLq))
+    GC.@preserve invl64 Z m Lq gl gz gm gLq begin
+        h = Ref{Ptr{Cvoid}}()
+        check(ccall((:svgp_model_create, lib), Int32, (Ptr{Cvoid}, Ref{ModelDesc}, Ptr{Ptr{Cvoid}}), ctx(), desc, h))
+        try
+            check(ccall((:svgp_elbo_grad_shard, lib), Int32,
+                        (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64, Float64, Float64, Ref{Float64}, Ref{Terms}, Ref{Grads}),
+                        ctx(), h[], D.h, off, len, Float64(scale), Float64(kl_weight), out, terms, g), terms)
+        finally
+            ccall((:svgp_model_free, lib), Int32, (Ptr{Cvoid}, Ptr{Cvoid}), ctx(), h[])
+        end
+    end
+    return out[], (g.variance, gl, gz, gm, gLq, g.lik_sigma2, g.mean_const)
+end
+
 function ChainRulesCore.rrule(::typeof(svgp_elbo_flat), ÏƒÂ², invl, Z, m, Lq, ÏƒÂ²lik, c, meta, D, off, len, num_data)
     val, (gÏƒÂ², gl, gz, gm, gLq, gÏƒÂ²lik, gc) = value_and_grads(ÏƒÂ², invl, Z, m, Lq, ÏƒÂ²lik, c, meta, D, off, len, num_data, true)
     function pullback(Î”)
