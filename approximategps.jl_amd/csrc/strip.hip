@@ -26,6 +26,16 @@ namespace svgp {
 
 namespace {
 
+#ifdef SVGP_STRIP_STAMPS   // diagnostic build (tools/build_ablate.sh stripstamps): s_memtime at the phase boundaries of one strip
+__device__ unsigned long long g_strip_stamps[128];
+#define SVGP_SSTAMP(i) do { if (stamping && threadIdx.x == 0) g_strip_stamps[i] = clock64(); } while (0)
+extern "C" int svgp_debug_strip_stamps(unsigned long long* out) {
+  return int(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_strip_stamps), sizeof(g_strip_stamps)));
+}
+#else
+#define SVGP_SSTAMP(i)
+#endif
+
 template <typename T, int NT, int BK, int NTHR, int MINW = 2>
 __global__ void __launch_bounds__(NTHR, MINW) strip_kernel(StripArgs a, int64_t nstrips) {
   using G = TileGemm<T, NT, BK, NTHR>;
@@ -55,7 +65,13 @@ __global__ void __launch_bounds__(NTHR, MINW) strip_kernel(StripArgs a, int64_t 
   // of the launch take more strips, which removes most of the ragged last round (C2: 3.05 rounds of strips).
   // Which workgroup evaluates a strip does not change its arithmetic, so results stay bitwise reproducible.
   __shared__ unsigned next_strip;
+  int strips_done = 0;
   for (int64_t strip = blockIdx.x; strip < nstrips;) {
+#ifdef SVGP_STRIP_STAMPS
+    const bool stamping = (blockIdx.x == 37 && strips_done == 3);   // a steady-state strip of one workgroup
+#endif
+    ++strips_done;
+    SVGP_SSTAMP(0);
     const int64_t c0 = strip * NT;                          // first column of the strip inside the batch
     if (tid == 0) next_strip = gridDim.x + atomicAdd(a.counter, 1u);
     const int64_t last = a.off + a.len - 1;
@@ -73,7 +89,9 @@ __global__ void __launch_bounds__(NTHR, MINW) strip_kernel(StripArgs a, int64_t 
     for (int j = 0; j < NJ; ++j) sA[j] = sM[j] = sC[j] = 0.0;
 
     // ---------------- phase 1: A = Lk \ Kuf, panel by panel ----------------
+    SVGP_SSTAMP(1);
     for (int I = 0; I < nP; ++I) {
+      SVGP_SSTAMP(2 + 3 * I);
       Acc acc;
       acc.zero();
       const int gen_from = I * (NB / BK);
@@ -109,6 +127,7 @@ __global__ void __launch_bounds__(NTHR, MINW) strip_kernel(StripArgs a, int64_t 
       // the last NB/BK steps multiply the lower-triangular inv(L_II): their zero 16-row tiles are skipped
       G::template loop_tri<(BK == 16 && (SVGP_TRI & 1)) ? 1 : 0>(acc, Tm + int64_t(I) * NB, Mp, (I + 1) * (NB / BK), qload, smem);
 
+      SVGP_SSTAMP(3 + 3 * I);
       // epilogue: A_I -> scratch strip, column sums in fp64
 #pragma unroll
       for (int i = 0; i < MI; ++i) {
@@ -136,10 +155,12 @@ __global__ void __launch_bounds__(NTHR, MINW) strip_kernel(StripArgs a, int64_t 
         }
       }
       __syncthreads();  // scratch rows of panel I visible to the whole workgroup
+      SVGP_SSTAMP(4 + 3 * I);
     }
 
     // ---------------- phase 2: C = B' A ----------------
     for (int J = 0; J < nP; ++J) {
+      SVGP_SSTAMP(60 + 2 * J);
       Acc acc;
       acc.zero();
       const T* wq = work + int64_t(J) * NB * NT;
@@ -147,6 +168,7 @@ __global__ void __launch_bounds__(NTHR, MINW) strip_kernel(StripArgs a, int64_t 
       // the first NB/BK steps multiply the upper-triangular diagonal block of B': zero tiles skipped likewise
       G::template loop_tri<(BK == 16 && (SVGP_TRI & 2)) ? -1 : 0>(acc, U + int64_t(J) * NB + int64_t(J) * NB * Mp, Mp, (nP - J) * (NB / BK), qload,
                                                  smem);
+      SVGP_SSTAMP(61 + 2 * J);
 #pragma unroll
       for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -161,6 +183,7 @@ __global__ void __launch_bounds__(NTHR, MINW) strip_kernel(StripArgs a, int64_t 
           }
     }
 
+    SVGP_SSTAMP(100);
     // ---------------- per-point moments: mu = mean + A'm (SVA:250), v = k(x,x) - ΣA² + ΣC² (SVA:251) ----------------
     double* red = reinterpret_cast<double*>(smem_raw);       // [3][WR][NT]; staging is idle here
 #pragma unroll
@@ -192,6 +215,7 @@ __global__ void __launch_bounds__(NTHR, MINW) strip_kernel(StripArgs a, int64_t 
     __syncthreads();
     strip = next_strip;
     __syncthreads();
+    SVGP_SSTAMP(101);
   }
 }
 
