@@ -46,6 +46,13 @@ __global__ void __launch_bounds__(NTHR, MINW) strip_kernel(StripArgs a, int64_t 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   T* smem = reinterpret_cast<T*>(smem_raw);                 // staging (2 buffers), reused as reduction scratch
   T* xs = smem + 2 * G::STAGE;                              // [d][NT] inputs of the strip, scaled by 1/l
+  // [d][128] scaled inducing inputs of the current row panel.  The generated k-steps used to fetch their z values from
+  // global memory inside the pipeline and wait for them on the spot: s_memtime stamps showed a generated step taking
+  // ~11k cycles against ~3k for a streamed one, 27 % of a strip.  The panel's z block is now fetched into registers at
+  // the start of the PREVIOUS panel's epilogue by LDS-DMA (no registers: a staging-register version spilled 60 VGPRs
+  // more), so the latency hides under the epilogue and lands with the epilogue's closing barrier.
+  const bool zlds = a.z_in_lds != 0;
+  T* zl = xs + a.kp.d * NT;
 
   const T* __restrict__ Tm = static_cast<const T*>(a.T);
   const T* __restrict__ U = static_cast<const T*>(a.U);
@@ -60,6 +67,19 @@ __global__ void __launch_bounds__(NTHR, MINW) strip_kernel(StripArgs a, int64_t 
   T* __restrict__ work = static_cast<T*>(a.work) + int64_t(blockIdx.x) * Mp * NT;
   const int tid = threadIdx.x, lane = tid & 63;
   const typename G::QOff qoff = G::q_offsets(NT);           // per-thread byte offsets inside a scratch-strip tile
+  // one global_load_lds_dwordx4 moves 1 KiB = 128 f64 (one feature row of the block) or 256 f32 (two rows)
+  auto z_block_dma = [&](int I) {
+    constexpr int EPI = 1024 / int(sizeof(T));              // elements per instruction
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ninstr = d * NB / EPI;
+    const int eo = lane * (16 / int(sizeof(T)));            // element offset of this lane inside the instruction's KiB
+    for (int q = wv; q < ninstr; q += NTHR / 64) {
+      const int e = q * EPI + eo;
+      const T* g = zs + int64_t(e / NB) * Mp + int64_t(I) * NB + e % NB;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                       (__attribute__((address_space(3))) void*)(zl + q * EPI), 16, 0, 0);
+    }
+  };
 
   // Strips are handed out dynamically (one atomic per strip): workgroups that run alone on their CU near the end
   // of the launch take more strips, which removes most of the ragged last round (C2: 3.05 rounds of strips).
@@ -82,6 +102,7 @@ __global__ void __launch_bounds__(NTHR, MINW) strip_kernel(StripArgs a, int64_t 
       g = g > last ? last : g;
       xs[e] = x[int64_t(f) * a.ldx + g] * invl[f];
     }
+    if (zlds) z_block_dma(0);
     __syncthreads();
 
     double sA[NJ], sM[NJ], sC[NJ];
@@ -107,8 +128,9 @@ __global__ void __launch_bounds__(NTHR, MINW) strip_kernel(StripArgs a, int64_t 
             T r2[VEC];
 #pragma unroll
             for (int e = 0; e < VEC; ++e) r2[e] = T(0);
+            const int kloc = (t - gen_from) * BK + kk;      // row inside the panel
             for (int f = 0; f < d; ++f) {
-              const T zf = zs[int64_t(f) * Mp + k];
+              const T zf = zlds ? zl[f * NB + kloc] : zs[int64_t(f) * Mp + k];
 #pragma unroll
               for (int e = 0; e < VEC; ++e) {
                 const T df = xs[f * NT + c + e] - zf;
@@ -128,6 +150,7 @@ __global__ void __launch_bounds__(NTHR, MINW) strip_kernel(StripArgs a, int64_t 
       G::template loop_tri<(BK == 16 && (SVGP_TRI & 1)) ? 1 : 0>(acc, Tm + int64_t(I) * NB, Mp, (I + 1) * (NB / BK), qload, smem);
 
       SVGP_SSTAMP(3 + 3 * I);
+      if (zlds && I + 1 < nP) z_block_dma(I + 1);   // every wave is past the loop's closing barrier: block I is dead
       // epilogue: A_I -> scratch strip, column sums in fp64
 #pragma unroll
       for (int i = 0; i < MI; ++i) {
@@ -154,7 +177,7 @@ __global__ void __launch_bounds__(NTHR, MINW) strip_kernel(StripArgs a, int64_t 
           }
         }
       }
-      __syncthreads();  // scratch rows of panel I visible to the whole workgroup
+      __syncthreads();  // scratch rows of panel I visible to the whole workgroup; also lands the next z block (vmcnt(0))
       SVGP_SSTAMP(4 + 3 * I);
     }
 
@@ -401,10 +424,16 @@ __global__ void __launch_bounds__(k256, 2) kuf_kernel(KernelParams kp, const T* 
 template <typename T, int NT, int BK, int NTHR, int MINW = 2>
 void launch_strip_t(hipStream_t s, const StripArgs& a, int grid, int64_t nstrips) {
   using G = TileGemm<T, NT, BK, NTHR>;
-  const size_t lds = G::LDS_BYTES + size_t(a.kp.d) * NT * sizeof(T);
+  size_t lds = G::LDS_BYTES + size_t(a.kp.d) * NT * sizeof(T);
+  // the z block of a row panel in LDS, when it leaves room for MINW workgroups per CU (160 KiB) and is whole DMA pieces
+  const size_t zbytes = size_t(a.kp.d) * kNB * sizeof(T);
+  StripArgs b = a;
+  // f64 only: same-box A/B H 37.9 -> 36.4 ms, C2 1.41 -> 1.33 ms; fp32 did not gain (H32 19.0 -> 19.4 ms, C3 / C5 flat)
+  b.z_in_lds = (sizeof(T) == 8) && (zbytes % 1024 == 0) && (MINW * (lds + zbytes + 1024) <= size_t(160) * 1024);
+  if (b.z_in_lds) lds += zbytes;
   auto kern = strip_kernel<T, NT, BK, NTHR, MINW>;
   set_max_lds(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(NTHR), lds, s, a, nstrips);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(NTHR), lds, s, b, nstrips);
 }
 
 }  // namespace
