@@ -21,6 +21,7 @@
 #endif
 
 #include <cstdlib>
+#include <type_traits>
 
 namespace svgp {
 
@@ -28,7 +29,7 @@ namespace {
 
 #ifdef SVGP_STRIP_STAMPS   // diagnostic build (tools/build_ablate.sh stripstamps): s_memtime at the phase boundaries of one strip
 __device__ unsigned long long g_strip_stamps[128];
-#define SVGP_SSTAMP(i) do { if (stamping && threadIdx.x == 0) g_strip_stamps[i] = clock64(); } while (0)
+#define SVGP_SSTAMP(i) do { if (stamping && threadIdx.x == 0) g_strip_stamps[i] += clock64(); } while (0)   // sums over strips
 extern "C" int svgp_debug_strip_stamps(unsigned long long* out) {
   return int(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_strip_stamps), sizeof(g_strip_stamps)));
 }
@@ -52,7 +53,11 @@ __global__ void __launch_bounds__(NTHR, MINW) strip_kernel(StripArgs a, int64_t 
   // the start of the PREVIOUS panel's epilogue by LDS-DMA (no registers: a staging-register version spilled 60 VGPRs
   // more), so the latency hides under the epilogue and lands with the epilogue's closing barrier.
   const bool zlds = a.z_in_lds != 0;
-  T* zl = xs + a.kp.d * NT;
+  // z_in_lds == 2: d <= 8 and both LDS images are 8 features tall, zero padded: the generation below is then a fully
+  // unrolled 8-feature body per kernel family (no per-feature loop, no per-element family switch)
+  const bool fast8 = a.z_in_lds == 2;
+  const int dl = fast8 ? 8 : a.kp.d;                        // feature rows of xs / zl
+  T* zl = xs + dl * NT;
 
   const T* __restrict__ Tm = static_cast<const T*>(a.T);
   const T* __restrict__ U = static_cast<const T*>(a.U);
@@ -85,10 +90,14 @@ __global__ void __launch_bounds__(NTHR, MINW) strip_kernel(StripArgs a, int64_t 
   // of the launch take more strips, which removes most of the ragged last round (C2: 3.05 rounds of strips).
   // Which workgroup evaluates a strip does not change its arithmetic, so results stay bitwise reproducible.
   __shared__ unsigned next_strip;
+  if (fast8) {
+    for (int e = tid + d * NB; e < 8 * NB; e += NTHR) zl[e] = T(0);   // rows the DMA never writes
+  }
   int strips_done = 0;
   for (int64_t strip = blockIdx.x; strip < nstrips;) {
 #ifdef SVGP_STRIP_STAMPS
-    const bool stamping = (blockIdx.x == 37 && strips_done == 3);   // a steady-state strip of one workgroup
+    const bool stamping = (blockIdx.x == 37 && strips_done >= 1);   // every strip of one workgroup but its first
+    if (stamping && threadIdx.x == 0) g_strip_stamps[127] += 1;
 #endif
     ++strips_done;
     SVGP_SSTAMP(0);
@@ -96,11 +105,11 @@ __global__ void __launch_bounds__(NTHR, MINW) strip_kernel(StripArgs a, int64_t 
     if (tid == 0) next_strip = gridDim.x + atomicAdd(a.counter, 1u);
     const int64_t last = a.off + a.len - 1;
     // scaled inputs of the strip -> LDS (columns past the batch end replicate the last point; masked later)
-    for (int e = tid; e < d * NT; e += NTHR) {
+    for (int e = tid; e < dl * NT; e += NTHR) {
       const int f = e / NT, c = e % NT;
       int64_t g = a.off + c0 + c;
       g = g > last ? last : g;
-      xs[e] = x[int64_t(f) * a.ldx + g] * invl[f];
+      xs[e] = (f < d) ? x[int64_t(f) * a.ldx + g] * invl[f] : T(0);
     }
     if (zlds) z_block_dma(0);
     __syncthreads();
@@ -119,6 +128,40 @@ __global__ void __launch_bounds__(NTHR, MINW) strip_kernel(StripArgs a, int64_t 
       auto qload = [&](int t, QRegs& r) {
         if (t < gen_from) {
           G::load_q(r, work + int64_t(t) * BK * NT, qoff);
+        } else if (fast8) {
+          auto gen = [&](auto fam) {
+            constexpr int F = decltype(fam)::value;
+            using V = typename G::V;
+            int kk0, c;
+            G::q_coord(0, kk0, c);
+            V xv[8];
+#pragma unroll
+            for (int f = 0; f < 8; ++f) xv[f] = *reinterpret_cast<const V*>(xs + f * NT + c);   // same columns in every pass
+#pragma unroll
+            for (int p = 0; p < G::Q_PASSES; ++p) {
+              int kk;
+              G::q_coord(p, kk, c);
+              const int kloc = (t - gen_from) * BK + kk;    // row inside the panel
+              T r2[VEC];
+#pragma unroll
+              for (int e = 0; e < VEC; ++e) r2[e] = T(0);
+#pragma unroll
+              for (int f = 0; f < 8; ++f) {
+                const T zf = zl[f * NB + kloc];
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) {
+                  const T df = xv[f][e] - zf;
+                  r2[e] = fma(df, df, r2[e]);
+                }
+              }
+              const bool valid = int64_t(t) * BK + kk < M;
+#pragma unroll
+              for (int e = 0; e < VEC; ++e) r.v[p][e] = valid ? kappa<T>(F, r2[e], variance) : T(0);
+            }
+          };
+          if (family == KSE) gen(std::integral_constant<int, KSE>{});
+          else if (family == KM32) gen(std::integral_constant<int, KM32>{});
+          else gen(std::integral_constant<int, KM52>{});
         } else {
 #pragma unroll
           for (int p = 0; p < G::Q_PASSES; ++p) {
@@ -424,13 +467,17 @@ __global__ void __launch_bounds__(k256, 2) kuf_kernel(KernelParams kp, const T* 
 template <typename T, int NT, int BK, int NTHR, int MINW = 2>
 void launch_strip_t(hipStream_t s, const StripArgs& a, int grid, int64_t nstrips) {
   using G = TileGemm<T, NT, BK, NTHR>;
-  size_t lds = G::LDS_BYTES + size_t(a.kp.d) * NT * sizeof(T);
+  const bool small_d = sizeof(T) == 8 && a.kp.d <= 8;     // 8-feature fast generation (f64): both images 8 rows tall
+  const size_t dl = small_d ? 8 : size_t(a.kp.d);
+  size_t lds = G::LDS_BYTES + dl * NT * sizeof(T);
   // the z block of a row panel in LDS, when it leaves room for MINW workgroups per CU (160 KiB) and is whole DMA pieces
-  const size_t zbytes = size_t(a.kp.d) * kNB * sizeof(T);
+  const size_t zbytes = dl * kNB * sizeof(T);
   StripArgs b = a;
   // f64 only: same-box A/B H 37.9 -> 36.4 ms, C2 1.41 -> 1.33 ms; fp32 did not gain (H32 19.0 -> 19.4 ms, C3 / C5 flat)
   b.z_in_lds = (sizeof(T) == 8) && (zbytes % 1024 == 0) && (MINW * (lds + zbytes + 1024) <= size_t(160) * 1024);
   if (b.z_in_lds) lds += zbytes;
+  else lds = G::LDS_BYTES + size_t(a.kp.d) * NT * sizeof(T);
+  if (b.z_in_lds && small_d) b.z_in_lds = 2;
   auto kern = strip_kernel<T, NT, BK, NTHR, MINW>;
   set_max_lds(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
   hipLaunchKernelGGL(kern, dim3(grid), dim3(NTHR), lds, s, b, nstrips);

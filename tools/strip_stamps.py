@@ -13,12 +13,14 @@ p = bench.synth(0, n, M, d, family, lik, dtype)
 ctx = _ffi.Context(0)
 desc, keep = _ffi.make_desc(p["np_dt"], family, p["variance"], p["inv_l"], p["z"], p["m"], p["Lq"], p["jitter"], likelihood=lik, lik_sigma2=p["sigma2"])
 model = _ffi.DeviceModel(ctx, desc, keep); data = _ffi.DeviceData(ctx, p["x"], p["y"], p["np_dt"])
-for _ in range(2):
-    model.elbo(data, 0, n, float(n))
+model.elbo(data, 0, n, float(n))     # the stamps are sums over every strip (but the first) of one workgroup, one launch
 L = ctypes.CDLL(os.environ.get("SVGP_MI355X_LIB", _ffi.LIB_PATH))
 buf = (ctypes.c_ulonglong * 128)()
 L.svgp_debug_strip_stamps(buf)
-s = np.array(list(buf), dtype=np.float64)
+raw = np.array([int(v) for v in buf], dtype=object)
+cnt = int(raw[127])
+s = np.array([float((int(v) - int(raw[0])) % (1 << 64)) / max(cnt, 1) for v in raw[:127]] + [0.0])   # mean offsets from the strip start
+print(f"averaged over {cnt} strips")
 nP = (M + 127) // 128
 print(f"{cfg}: strip total {s[101]-s[0]:.0f} ticks (100 MHz s_memtime: x10 ns); x staging {s[1]-s[0]:.0f}; final moments {s[101]-s[100]:.0f}")
 l1 = [s[3 + 3 * I] - s[2 + 3 * I] for I in range(nP)]; e1 = [s[4 + 3 * I] - s[3 + 3 * I] for I in range(nP)]
