@@ -52,10 +52,12 @@ __global__ void __launch_bounds__(NTHR, MINW) strip_kernel(StripArgs a, int64_t 
   // ~11k cycles against ~3k for a streamed one, 27 % of a strip.  The panel's z block is now fetched into registers at
   // the start of the PREVIOUS panel's epilogue by LDS-DMA (no registers: a staging-register version spilled 60 VGPRs
   // more), so the latency hides under the epilogue and lands with the epilogue's closing barrier.
-  const bool zlds = a.z_in_lds != 0;
+  // f64 only (compile time): the fp32 kernels measured 1 % slower on C3 / C5 with this code in them (117 spilled VGPRs)
+  constexpr bool kZ = sizeof(T) == 8;
+  const bool zlds = kZ && a.z_in_lds != 0;
   // z_in_lds == 2: d <= 8 and both LDS images are 8 features tall, zero padded: the generation below is then a fully
   // unrolled 8-feature body per kernel family (no per-feature loop, no per-element family switch)
-  const bool fast8 = a.z_in_lds == 2;
+  const bool fast8 = kZ && a.z_in_lds >= 2;                 // 2: 8 feature rows
   const int dl = fast8 ? 8 : a.kp.d;                        // feature rows of xs / zl
   T* zl = xs + dl * NT;
 
@@ -76,13 +78,14 @@ __global__ void __launch_bounds__(NTHR, MINW) strip_kernel(StripArgs a, int64_t 
   auto z_block_dma = [&](int I) {
     constexpr int EPI = 1024 / int(sizeof(T));              // elements per instruction
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int ninstr = d * NB / EPI;
+    const int ninstr = (d * NB + EPI - 1) / EPI;
     const int eo = lane * (16 / int(sizeof(T)));            // element offset of this lane inside the instruction's KiB
     for (int q = wv; q < ninstr; q += NTHR / 64) {
       const int e = q * EPI + eo;
       const T* g = zs + int64_t(e / NB) * Mp + int64_t(I) * NB + e % NB;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                       (__attribute__((address_space(3))) void*)(zl + q * EPI), 16, 0, 0);
+      if (e / NB < d)   // fp32, odd d: the second half of the last piece is past the last feature row (EXEC-masked lanes)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                         (__attribute__((address_space(3))) void*)(zl + q * EPI), 16, 0, 0);
     }
   };
 
@@ -91,7 +94,7 @@ __global__ void __launch_bounds__(NTHR, MINW) strip_kernel(StripArgs a, int64_t 
   // Which workgroup evaluates a strip does not change its arithmetic, so results stay bitwise reproducible.
   __shared__ unsigned next_strip;
   if (fast8) {
-    for (int e = tid + d * NB; e < 8 * NB; e += NTHR) zl[e] = T(0);   // rows the DMA never writes
+    for (int e = tid + d * NB; e < dl * NB; e += NTHR) zl[e] = T(0);   // rows the DMA never writes
   }
   int strips_done = 0;
   for (int64_t strip = blockIdx.x; strip < nstrips;) {
@@ -129,39 +132,43 @@ __global__ void __launch_bounds__(NTHR, MINW) strip_kernel(StripArgs a, int64_t 
         if (t < gen_from) {
           G::load_q(r, work + int64_t(t) * BK * NT, qoff);
         } else if (fast8) {
-          auto gen = [&](auto fam) {
-            constexpr int F = decltype(fam)::value;
-            using V = typename G::V;
-            int kk0, c;
-            G::q_coord(0, kk0, c);
-            V xv[8];
+          // (a body generic over 8 / 16 feature rows and both dtypes cost the f64 kernel 2 % against this one; an fp32
+          // version gained 1 % on H32 and lost 1-1.5 % on C3 / C5, so fp32 keeps the per-feature loop below)
+          if constexpr (sizeof(T) == 8) {
+            auto gen = [&](auto fam) {
+              constexpr int F = decltype(fam)::value;
+              using V = typename G::V;
+              int kk0, c;
+              G::q_coord(0, kk0, c);
+              V xv[8];
 #pragma unroll
-            for (int f = 0; f < 8; ++f) xv[f] = *reinterpret_cast<const V*>(xs + f * NT + c);   // same columns in every pass
+              for (int f = 0; f < 8; ++f) xv[f] = *reinterpret_cast<const V*>(xs + f * NT + c);   // same columns in every pass
 #pragma unroll
-            for (int p = 0; p < G::Q_PASSES; ++p) {
-              int kk;
-              G::q_coord(p, kk, c);
-              const int kloc = (t - gen_from) * BK + kk;    // row inside the panel
-              T r2[VEC];
+              for (int p = 0; p < G::Q_PASSES; ++p) {
+                int kk;
+                G::q_coord(p, kk, c);
+                const int kloc = (t - gen_from) * BK + kk;    // row inside the panel
+                T r2[VEC];
 #pragma unroll
-              for (int e = 0; e < VEC; ++e) r2[e] = T(0);
+                for (int e = 0; e < VEC; ++e) r2[e] = T(0);
 #pragma unroll
-              for (int f = 0; f < 8; ++f) {
-                const T zf = zl[f * NB + kloc];
+                for (int f = 0; f < 8; ++f) {
+                  const T zf = zl[f * NB + kloc];
 #pragma unroll
-                for (int e = 0; e < VEC; ++e) {
-                  const T df = xv[f][e] - zf;
-                  r2[e] = fma(df, df, r2[e]);
+                  for (int e = 0; e < VEC; ++e) {
+                    const T df = xv[f][e] - zf;
+                    r2[e] = fma(df, df, r2[e]);
+                  }
                 }
-              }
-              const bool valid = int64_t(t) * BK + kk < M;
+                const bool valid = int64_t(t) * BK + kk < M;
 #pragma unroll
-              for (int e = 0; e < VEC; ++e) r.v[p][e] = valid ? kappa<T>(F, r2[e], variance) : T(0);
-            }
-          };
-          if (family == KSE) gen(std::integral_constant<int, KSE>{});
-          else if (family == KM32) gen(std::integral_constant<int, KM32>{});
-          else gen(std::integral_constant<int, KM52>{});
+                for (int e = 0; e < VEC; ++e) r.v[p][e] = valid ? kappa<T>(F, r2[e], variance) : T(0);
+              }
+            };
+            if (family == KSE) gen(std::integral_constant<int, KSE>{});
+            else if (family == KM32) gen(std::integral_constant<int, KM32>{});
+            else gen(std::integral_constant<int, KM52>{});
+          }
         } else {
 #pragma unroll
           for (int p = 0; p < G::Q_PASSES; ++p) {
@@ -467,14 +474,13 @@ __global__ void __launch_bounds__(k256, 2) kuf_kernel(KernelParams kp, const T* 
 template <typename T, int NT, int BK, int NTHR, int MINW = 2>
 void launch_strip_t(hipStream_t s, const StripArgs& a, int grid, int64_t nstrips) {
   using G = TileGemm<T, NT, BK, NTHR>;
-  const bool small_d = sizeof(T) == 8 && a.kp.d <= 8;     // 8-feature fast generation (f64): both images 8 rows tall
+  const bool small_d = sizeof(T) == 8 && a.kp.d <= 8;     // unrolled generation (f64): both LDS images 8 feature rows tall
   const size_t dl = small_d ? 8 : size_t(a.kp.d);
   size_t lds = G::LDS_BYTES + dl * NT * sizeof(T);
   // the z block of a row panel in LDS, when it leaves room for MINW workgroups per CU (160 KiB) and is whole DMA pieces
   const size_t zbytes = dl * kNB * sizeof(T);
   StripArgs b = a;
-  // f64 only: same-box A/B H 37.9 -> 36.4 ms, C2 1.41 -> 1.33 ms; fp32 did not gain (H32 19.0 -> 19.4 ms, C3 / C5 flat)
-  b.z_in_lds = (sizeof(T) == 8) && (zbytes % 1024 == 0) && (MINW * (lds + zbytes + 1024) <= size_t(160) * 1024);
+  b.z_in_lds = sizeof(T) == 8 && (zbytes % 1024 == 0) && (MINW * (lds + zbytes + 1024) <= size_t(160) * 1024);
   if (b.z_in_lds) lds += zbytes;
   else lds = G::LDS_BYTES + size_t(a.kp.d) * NT * sizeof(T);
   if (b.z_in_lds && small_d) b.z_in_lds = 2;
