@@ -54,6 +54,11 @@ __global__ void __launch_bounds__(NTHR, MINW) strip_kernel(StripArgs a, int64_t 
   // more), so the latency hides under the epilogue and lands with the epilogue's closing barrier.
   // f64 only (compile time): the fp32 kernels measured 1 % slower on C3 / C5 with this code in them (117 spilled VGPRs)
   constexpr bool kZ = sizeof(T) == 8;
+  // fp32: the strip's whole Kuf block is generated into the scratch strip BEFORE phase 1 (the epilogue of panel I later
+  // overwrites rows I with A_I), so phase 1 has no generated k-steps at all: fp32 VALU work co-executes with the partner
+  // workgroup's MFMAs, and the generation runs outside the MFMA loop's register pressure.  Same-box A/B: H32 18.94 ->
+  // 17.99 ms, C3 73.0 -> 69.3 ms, C5 5.20 -> 5.05 ms.  f64: 34.3 -> 38.7 ms (f64 VALU time is MFMA time lost), so not there.
+  constexpr bool kPregen = sizeof(T) == 4;
   const bool zlds = kZ && a.z_in_lds != 0;
   // z_in_lds == 2: d <= 8 and both LDS images are 8 features tall, zero padded: the generation below is then a fully
   // unrolled 8-feature body per kernel family (no per-feature loop, no per-element family switch)
@@ -116,6 +121,37 @@ __global__ void __launch_bounds__(NTHR, MINW) strip_kernel(StripArgs a, int64_t 
     }
     if (zlds) z_block_dma(0);
     __syncthreads();
+    if constexpr (kPregen) {
+      auto pregen = [&](auto fam) {
+        constexpr int F = decltype(fam)::value;
+        using V = typename G::V;
+        constexpr int CPR = NT / VEC;                       // vectors per k-row of the scratch strip
+        for (int e = tid; e < int(Mp) * CPR; e += NTHR) {
+          const int k = e / CPR, c = (e % CPR) * VEC;
+          T r2[VEC];
+#pragma unroll
+          for (int q = 0; q < VEC; ++q) r2[q] = T(0);
+#pragma unroll 8
+          for (int f = 0; f < d; ++f) {
+            const T zf = zs[int64_t(f) * Mp + k];
+            const V xf = *reinterpret_cast<const V*>(xs + f * NT + c);
+#pragma unroll
+            for (int q = 0; q < VEC; ++q) {
+              const T df = xf[q] - zf;
+              r2[q] = fma(df, df, r2[q]);
+            }
+          }
+          V out;
+#pragma unroll
+          for (int q = 0; q < VEC; ++q) out[q] = (k < M) ? kappa<T>(F, r2[q], variance) : T(0);
+          *reinterpret_cast<V*>(work + int64_t(k) * NT + c) = out;
+        }
+      };
+      if (family == KSE) pregen(std::integral_constant<int, KSE>{});
+      else if (family == KM32) pregen(std::integral_constant<int, KM32>{});
+      else pregen(std::integral_constant<int, KM52>{});
+      __syncthreads();
+    }
 
     double sA[NJ], sM[NJ], sC[NJ];
 #pragma unroll
@@ -129,7 +165,7 @@ __global__ void __launch_bounds__(NTHR, MINW) strip_kernel(StripArgs a, int64_t 
       acc.zero();
       const int gen_from = I * (NB / BK);
       auto qload = [&](int t, QRegs& r) {
-        if (t < gen_from) {
+        if (kPregen || t < gen_from) {
           G::load_q(r, work + int64_t(t) * BK * NT, qoff);
         } else if (fast8) {
           // (a body generic over 8 / 16 feature rows and both dtypes cost the f64 kernel 2 % against this one; an fp32
