@@ -27,6 +27,71 @@ namespace svgp {
 
 namespace {
 
+// Kuf block of one strip (Mp inducing rows x NT points) written to the workgroup's scratch strip, k-major [Mp][NT].
+// Pairwise distances on the MFMA as in kuf_kernel (r2 = |x|^2 + |z|^2 - 2 x.z, accumulator preloaded with the norms),
+// here with z as the A operand so that a lane's 16-lane group writes 16 consecutive points of one row.  xs: the strip's
+// scaled inputs in LDS, [DL][NT], zero padded to DL feature rows.  A wave owns every (NTHR/64)-th block of 16 rows; the
+// x fragments and column norms are fetched once per strip, the row norms travel by two xor-shuffles and one index shuffle.
+template <typename T, int NT, int NTHR, int F, int DL>
+__device__ __forceinline__ void pregen_mfma(const T* __restrict__ xs, const T* __restrict__ zs, int d, int64_t Mp, int64_t M,
+                                            double variance_d, T* __restrict__ work) {
+  constexpr int KS = DL / 4, JT = NT / 16, NW = NTHR / 64;
+  using M16 = Mfma16<T>;
+  using acc_t = typename M16::acc_t;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l15 = lane & 15, g = lane >> 4;
+  const T variance = T(variance_d);
+  const T c1 = (F == KSE) ? T(-0.5) : T(1);
+  const T c0 = (F == KSE) ? T(log(variance_d)) : T(0);
+  const T ascale = (F == KSE) ? T(1) : T(-2);
+  T xb[JT][KS], xn[JT];
+#pragma unroll
+  for (int jt = 0; jt < JT; ++jt) {
+    T s = T(0);
+#pragma unroll
+    for (int q = 0; q < KS; ++q) {
+      const T v = xs[(4 * q + g) * NT + jt * 16 + l15];
+      xb[jt][q] = v;
+      s = fma(v, v, s);
+    }
+    s += __shfl_xor(s, 16);
+    s += __shfl_xor(s, 32);
+    xn[jt] = fma(c1, s, c0);
+  }
+  for (int kb = wave; kb < int(Mp / 16); kb += NW) {
+    const int64_t k0 = int64_t(kb) * 16;
+    T za[KS];
+    T s = T(0);
+#pragma unroll
+    for (int q = 0; q < KS; ++q) {
+      const int f = 4 * q + g;
+      const T v = (f < d) ? zs[int64_t(f) * Mp + k0 + l15] : T(0);
+      za[q] = ascale * v;
+      s = fma(v, v, s);
+    }
+    s += __shfl_xor(s, 16);
+    s += __shfl_xor(s, 32);
+    s *= c1;                                   // c1 |z|^2 of row l15, in every lane
+    T zn[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) zn[r] = __shfl(s, M16::row(lane, r));
+#pragma unroll
+    for (int jt = 0; jt < JT; ++jt) {
+      acc_t acc;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[r] = xn[jt] + zn[r];
+#pragma unroll
+      for (int q = 0; q < KS; ++q) acc = M16::mma(za[q], xb[jt][q], acc);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int64_t k = k0 + M16::row(lane, r);
+        const T v = acc[r];
+        const T out = (F == KSE) ? kexp(v < c0 ? v : c0) : kappa<T>(F, v > T(0) ? v : T(0), variance);
+        work[k * NT + jt * 16 + l15] = (k < M) ? out : T(0);
+      }
+    }
+  }
+}
+
 #ifdef SVGP_STRIP_STAMPS   // diagnostic build (tools/build_ablate.sh stripstamps): s_memtime at the phase boundaries of one strip
 __device__ unsigned long long g_strip_stamps[128];
 #define SVGP_SSTAMP(i) do { if (stamping && threadIdx.x == 0) g_strip_stamps[i] += clock64(); } while (0)   // sums over strips
@@ -58,12 +123,16 @@ __global__ void __launch_bounds__(NTHR, MINW) strip_kernel(StripArgs a, int64_t 
   // overwrites rows I with A_I), so phase 1 has no generated k-steps at all: fp32 VALU work co-executes with the partner
   // workgroup's MFMAs, and the generation runs outside the MFMA loop's register pressure.  Same-box A/B: H32 18.94 ->
   // 17.99 ms, C3 73.0 -> 69.3 ms, C5 5.20 -> 5.05 ms.  f64: 34.3 -> 38.7 ms (f64 VALU time is MFMA time lost), so not there.
-  constexpr bool kPregen = sizeof(T) == 4;
+#ifndef SVGP_F64_PREGEN
+#define SVGP_F64_PREGEN 0
+#endif
+  constexpr bool kPregen = sizeof(T) == 4 || SVGP_F64_PREGEN;
   const bool zlds = kZ && a.z_in_lds != 0;
   // z_in_lds == 2: d <= 8 and both LDS images are 8 features tall, zero padded: the generation below is then a fully
   // unrolled 8-feature body per kernel family (no per-feature loop, no per-element family switch)
   const bool fast8 = kZ && a.z_in_lds >= 2;                 // 2: 8 feature rows
-  const int dl = fast8 ? 8 : a.kp.d;                        // feature rows of xs / zl
+  const int pre_dl = !kPregen ? 0 : a.kp.d <= 8 ? 8 : a.kp.d <= 16 ? 16 : 0;   // MFMA pre-generation: xs zero padded to 8 / 16 rows
+  const int dl = pre_dl ? pre_dl : fast8 ? 8 : a.kp.d;      // feature rows of xs / zl
   T* zl = xs + dl * NT;
 
   const T* __restrict__ Tm = static_cast<const T*>(a.T);
@@ -147,7 +216,15 @@ __global__ void __launch_bounds__(NTHR, MINW) strip_kernel(StripArgs a, int64_t 
           *reinterpret_cast<V*>(work + int64_t(k) * NT + c) = out;
         }
       };
-      if (family == KSE) pregen(std::integral_constant<int, KSE>{});
+      if (pre_dl == 8) {
+        if (family == KSE) pregen_mfma<T, NT, NTHR, KSE, 8>(xs, zs, d, Mp, M, a.kp.variance, work);
+        else if (family == KM32) pregen_mfma<T, NT, NTHR, KM32, 8>(xs, zs, d, Mp, M, a.kp.variance, work);
+        else pregen_mfma<T, NT, NTHR, KM52, 8>(xs, zs, d, Mp, M, a.kp.variance, work);
+      } else if (pre_dl == 16) {
+        if (family == KSE) pregen_mfma<T, NT, NTHR, KSE, 16>(xs, zs, d, Mp, M, a.kp.variance, work);
+        else if (family == KM32) pregen_mfma<T, NT, NTHR, KM32, 16>(xs, zs, d, Mp, M, a.kp.variance, work);
+        else pregen_mfma<T, NT, NTHR, KM52, 16>(xs, zs, d, Mp, M, a.kp.variance, work);
+      } else if (family == KSE) pregen(std::integral_constant<int, KSE>{});
       else if (family == KM32) pregen(std::integral_constant<int, KM32>{});
       else pregen(std::integral_constant<int, KM52>{});
       __syncthreads();
@@ -510,15 +587,16 @@ __global__ void __launch_bounds__(k256, 2) kuf_kernel(KernelParams kp, const T* 
 template <typename T, int NT, int BK, int NTHR, int MINW = 2>
 void launch_strip_t(hipStream_t s, const StripArgs& a, int grid, int64_t nstrips) {
   using G = TileGemm<T, NT, BK, NTHR>;
-  const bool small_d = sizeof(T) == 8 && a.kp.d <= 8;     // unrolled generation (f64): both LDS images 8 feature rows tall
-  const size_t dl = small_d ? 8 : size_t(a.kp.d);
+  constexpr bool pregen = sizeof(T) == 4 || SVGP_F64_PREGEN;   // keep in step with strip_kernel::kPregen
+  const bool small_d = !pregen && a.kp.d <= 8;            // unrolled generation (f64): both LDS images 8 feature rows tall
+  const size_t dl = pregen ? (a.kp.d <= 8 ? 8 : a.kp.d <= 16 ? 16 : size_t(a.kp.d)) : small_d ? 8 : size_t(a.kp.d);
   size_t lds = G::LDS_BYTES + dl * NT * sizeof(T);
   // the z block of a row panel in LDS, when it leaves room for MINW workgroups per CU (160 KiB) and is whole DMA pieces
   const size_t zbytes = dl * kNB * sizeof(T);
   StripArgs b = a;
-  b.z_in_lds = sizeof(T) == 8 && (zbytes % 1024 == 0) && (MINW * (lds + zbytes + 1024) <= size_t(160) * 1024);
+  b.z_in_lds = !pregen && (zbytes % 1024 == 0) && (MINW * (lds + zbytes + 1024) <= size_t(160) * 1024);
   if (b.z_in_lds) lds += zbytes;
-  else lds = G::LDS_BYTES + size_t(a.kp.d) * NT * sizeof(T);
+  else if (!pregen) lds = G::LDS_BYTES + size_t(a.kp.d) * NT * sizeof(T);
   if (b.z_in_lds && small_d) b.z_in_lds = 2;
   auto kern = strip_kernel<T, NT, BK, NTHR, MINW>;
   set_max_lds(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
