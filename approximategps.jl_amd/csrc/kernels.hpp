@@ -78,7 +78,6 @@ struct StripArgs {
   int64_t Mp, M;
   KernelParams kp;
   double mean_const;
-  int z_in_lds;      // set by the launcher: the scaled z block of a row panel is staged in LDS
 };
 int strip_nt(int dtype, int64_t Mp, int64_t len);                 // column-strip width chosen for a problem
 size_t strip_work_bytes(int dtype, int64_t Mp, int nt, int grid);  // workspace bytes

@@ -112,28 +112,17 @@ __global__ void __launch_bounds__(NTHR, MINW) strip_kernel(StripArgs a, int64_t 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   T* smem = reinterpret_cast<T*>(smem_raw);                 // staging (2 buffers), reused as reduction scratch
   T* xs = smem + 2 * G::STAGE;                              // [d][NT] inputs of the strip, scaled by 1/l
-  // [d][128] scaled inducing inputs of the current row panel.  The generated k-steps used to fetch their z values from
-  // global memory inside the pipeline and wait for them on the spot: s_memtime stamps showed a generated step taking
-  // ~11k cycles against ~3k for a streamed one, 27 % of a strip.  The panel's z block is now fetched into registers at
-  // the start of the PREVIOUS panel's epilogue by LDS-DMA (no registers: a staging-register version spilled 60 VGPRs
-  // more), so the latency hides under the epilogue and lands with the epilogue's closing barrier.
-  // f64 only (compile time): the fp32 kernels measured 1 % slower on C3 / C5 with this code in them (117 spilled VGPRs)
-  constexpr bool kZ = sizeof(T) == 8;
-  // fp32: the strip's whole Kuf block is generated into the scratch strip BEFORE phase 1 (the epilogue of panel I later
-  // overwrites rows I with A_I), so phase 1 has no generated k-steps at all: fp32 VALU work co-executes with the partner
-  // workgroup's MFMAs, and the generation runs outside the MFMA loop's register pressure.  Same-box A/B: H32 18.94 ->
-  // 17.99 ms, C3 73.0 -> 69.3 ms, C5 5.20 -> 5.05 ms.  f64: 34.3 -> 38.7 ms (f64 VALU time is MFMA time lost), so not there.
-#ifndef SVGP_F64_PREGEN
-#define SVGP_F64_PREGEN 0
-#endif
-  constexpr bool kPregen = sizeof(T) == 4 || SVGP_F64_PREGEN;
-  const bool zlds = kZ && a.z_in_lds != 0;
-  // z_in_lds == 2: d <= 8 and both LDS images are 8 features tall, zero padded: the generation below is then a fully
-  // unrolled 8-feature body per kernel family (no per-feature loop, no per-element family switch)
-  const bool fast8 = kZ && a.z_in_lds >= 2;                 // 2: 8 feature rows
-  const int pre_dl = !kPregen ? 0 : a.kp.d <= 8 ? 8 : a.kp.d <= 16 ? 16 : 0;   // MFMA pre-generation: xs zero padded to 8 / 16 rows
-  const int dl = pre_dl ? pre_dl : fast8 ? 8 : a.kp.d;      // feature rows of xs / zl
-  T* zl = xs + dl * NT;
+  // The strip's whole Kuf block (SVA:216) is generated into the scratch strip BEFORE phase 1 (pregen_mfma; the epilogue of
+  // panel I later overwrites rows I with A_I), so every k-step of both phases streams its Q tile.  History, measured with
+  // s_memtime stamps inside one strip (tools/strip_stamps.py): generating the panel's Kuf rows inside the k-loop made a
+  // generated step cost 11k cycles against 3k for a streamed one (64 of them = 27 % of a strip): z fetched from global
+  // memory and waited for on the spot, a run-time loop over the features with a per-element family switch, and all of it
+  // under the MFMA loop's register pressure (up to 117 spilled VGPRs).  Staging z in LDS + an unrolled body brought H from
+  // 37.9 to 34.3 ms; moving the generation out of the loop altogether, onto MFMA distances, gave 34.0 ms (f64) and
+  // H32 18.9 -> 17.45, C3 73.0 -> 68.4, C5 5.20 -> 4.83 ms (fp32, whose VALU work co-executes with the partner
+  // workgroup's MFMAs).
+  const int pre_dl = a.kp.d <= 8 ? 8 : a.kp.d <= 16 ? 16 : 0;   // MFMA pre-generation: xs zero padded to 8 / 16 feature rows
+  const int dl = pre_dl ? pre_dl : a.kp.d;                      // feature rows of xs
 
   const T* __restrict__ Tm = static_cast<const T*>(a.T);
   const T* __restrict__ U = static_cast<const T*>(a.U);
@@ -148,35 +137,20 @@ __global__ void __launch_bounds__(NTHR, MINW) strip_kernel(StripArgs a, int64_t 
   T* __restrict__ work = static_cast<T*>(a.work) + int64_t(blockIdx.x) * Mp * NT;
   const int tid = threadIdx.x, lane = tid & 63;
   const typename G::QOff qoff = G::q_offsets(NT);           // per-thread byte offsets inside a scratch-strip tile
-  // one global_load_lds_dwordx4 moves 1 KiB = 128 f64 (one feature row of the block) or 256 f32 (two rows)
-  auto z_block_dma = [&](int I) {
-    constexpr int EPI = 1024 / int(sizeof(T));              // elements per instruction
-    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int ninstr = (d * NB + EPI - 1) / EPI;
-    const int eo = lane * (16 / int(sizeof(T)));            // element offset of this lane inside the instruction's KiB
-    for (int q = wv; q < ninstr; q += NTHR / 64) {
-      const int e = q * EPI + eo;
-      const T* g = zs + int64_t(e / NB) * Mp + int64_t(I) * NB + e % NB;
-      if (e / NB < d)   // fp32, odd d: the second half of the last piece is past the last feature row (EXEC-masked lanes)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                         (__attribute__((address_space(3))) void*)(zl + q * EPI), 16, 0, 0);
-    }
-  };
 
   // Strips are handed out dynamically (one atomic per strip): workgroups that run alone on their CU near the end
   // of the launch take more strips, which removes most of the ragged last round (C2: 3.05 rounds of strips).
   // Which workgroup evaluates a strip does not change its arithmetic, so results stay bitwise reproducible.
   __shared__ unsigned next_strip;
-  if (fast8) {
-    for (int e = tid + d * NB; e < dl * NB; e += NTHR) zl[e] = T(0);   // rows the DMA never writes
-  }
+#ifdef SVGP_STRIP_STAMPS
   int strips_done = 0;
+#endif
   for (int64_t strip = blockIdx.x; strip < nstrips;) {
 #ifdef SVGP_STRIP_STAMPS
     const bool stamping = (blockIdx.x == 37 && strips_done >= 1);   // every strip of one workgroup but its first
     if (stamping && threadIdx.x == 0) g_strip_stamps[127] += 1;
-#endif
     ++strips_done;
+#endif
     SVGP_SSTAMP(0);
     const int64_t c0 = strip * NT;                          // first column of the strip inside the batch
     if (tid == 0) next_strip = gridDim.x + atomicAdd(a.counter, 1u);
@@ -188,9 +162,8 @@ __global__ void __launch_bounds__(NTHR, MINW) strip_kernel(StripArgs a, int64_t 
       g = g > last ? last : g;
       xs[e] = (f < d) ? x[int64_t(f) * a.ldx + g] * invl[f] : T(0);
     }
-    if (zlds) z_block_dma(0);
     __syncthreads();
-    if constexpr (kPregen) {
+    {
       auto pregen = [&](auto fam) {
         constexpr int F = decltype(fam)::value;
         using V = typename G::V;
@@ -240,80 +213,11 @@ __global__ void __launch_bounds__(NTHR, MINW) strip_kernel(StripArgs a, int64_t 
       SVGP_SSTAMP(2 + 3 * I);
       Acc acc;
       acc.zero();
-      const int gen_from = I * (NB / BK);
-      auto qload = [&](int t, QRegs& r) {
-        if (kPregen || t < gen_from) {
-          G::load_q(r, work + int64_t(t) * BK * NT, qoff);
-        } else if (fast8) {
-          // (a body generic over 8 / 16 feature rows and both dtypes cost the f64 kernel 2 % against this one; an fp32
-          // version gained 1 % on H32 and lost 1-1.5 % on C3 / C5, so fp32 keeps the per-feature loop below)
-          if constexpr (sizeof(T) == 8) {
-            auto gen = [&](auto fam) {
-              constexpr int F = decltype(fam)::value;
-              using V = typename G::V;
-              int kk0, c;
-              G::q_coord(0, kk0, c);
-              V xv[8];
-#pragma unroll
-              for (int f = 0; f < 8; ++f) xv[f] = *reinterpret_cast<const V*>(xs + f * NT + c);   // same columns in every pass
-#pragma unroll
-              for (int p = 0; p < G::Q_PASSES; ++p) {
-                int kk;
-                G::q_coord(p, kk, c);
-                const int kloc = (t - gen_from) * BK + kk;    // row inside the panel
-                T r2[VEC];
-#pragma unroll
-                for (int e = 0; e < VEC; ++e) r2[e] = T(0);
-#pragma unroll
-                for (int f = 0; f < 8; ++f) {
-                  const T zf = zl[f * NB + kloc];
-#pragma unroll
-                  for (int e = 0; e < VEC; ++e) {
-                    const T df = xv[f][e] - zf;
-                    r2[e] = fma(df, df, r2[e]);
-                  }
-                }
-                const bool valid = int64_t(t) * BK + kk < M;
-#pragma unroll
-                for (int e = 0; e < VEC; ++e) r.v[p][e] = valid ? kappa<T>(F, r2[e], variance) : T(0);
-              }
-            };
-            if (family == KSE) gen(std::integral_constant<int, KSE>{});
-            else if (family == KM32) gen(std::integral_constant<int, KM32>{});
-            else gen(std::integral_constant<int, KM52>{});
-          }
-        } else {
-#pragma unroll
-          for (int p = 0; p < G::Q_PASSES; ++p) {
-            int kk, c;
-            G::q_coord(p, kk, c);
-            const int64_t k = int64_t(t) * BK + kk;         // inducing index (row of Kuf)
-            T r2[VEC];
-#pragma unroll
-            for (int e = 0; e < VEC; ++e) r2[e] = T(0);
-            const int kloc = (t - gen_from) * BK + kk;      // row inside the panel
-            for (int f = 0; f < d; ++f) {
-              const T zf = zlds ? zl[f * NB + kloc] : zs[int64_t(f) * Mp + k];
-#pragma unroll
-              for (int e = 0; e < VEC; ++e) {
-                const T df = xs[f * NT + c + e] - zf;
-                r2[e] = fma(df, df, r2[e]);
-              }
-            }
-#pragma unroll
-#if defined(SVGP_ABLATE) && (SVGP_ABLATE & 8)
-            for (int e = 0; e < VEC; ++e) r.v[p][e] = (k < M) ? r2[e] * variance : T(0);   // diagnostic: no exp
-#else
-            for (int e = 0; e < VEC; ++e) r.v[p][e] = (k < M) ? kappa<T>(family, r2[e], variance) : T(0);
-#endif
-          }
-        }
-      };
+      auto qload = [&](int t, QRegs& r) { G::load_q(r, work + int64_t(t) * BK * NT, qoff); };
       // the last NB/BK steps multiply the lower-triangular inv(L_II): their zero 16-row tiles are skipped
       G::template loop_tri<(BK == 16 && (SVGP_TRI & 1)) ? 1 : 0>(acc, Tm + int64_t(I) * NB, Mp, (I + 1) * (NB / BK), qload, smem);
 
       SVGP_SSTAMP(3 + 3 * I);
-      if (zlds && I + 1 < nP) z_block_dma(I + 1);   // every wave is past the loop's closing barrier: block I is dead
       // epilogue: A_I -> scratch strip, column sums in fp64
 #pragma unroll
       for (int i = 0; i < MI; ++i) {
@@ -340,7 +244,7 @@ __global__ void __launch_bounds__(NTHR, MINW) strip_kernel(StripArgs a, int64_t 
           }
         }
       }
-      __syncthreads();  // scratch rows of panel I visible to the whole workgroup; also lands the next z block (vmcnt(0))
+      __syncthreads();  // scratch rows of panel I visible to the whole workgroup
       SVGP_SSTAMP(4 + 3 * I);
     }
 
@@ -587,20 +491,11 @@ __global__ void __launch_bounds__(k256, 2) kuf_kernel(KernelParams kp, const T* 
 template <typename T, int NT, int BK, int NTHR, int MINW = 2>
 void launch_strip_t(hipStream_t s, const StripArgs& a, int grid, int64_t nstrips) {
   using G = TileGemm<T, NT, BK, NTHR>;
-  constexpr bool pregen = sizeof(T) == 4 || SVGP_F64_PREGEN;   // keep in step with strip_kernel::kPregen
-  const bool small_d = !pregen && a.kp.d <= 8;            // unrolled generation (f64): both LDS images 8 feature rows tall
-  const size_t dl = pregen ? (a.kp.d <= 8 ? 8 : a.kp.d <= 16 ? 16 : size_t(a.kp.d)) : small_d ? 8 : size_t(a.kp.d);
-  size_t lds = G::LDS_BYTES + dl * NT * sizeof(T);
-  // the z block of a row panel in LDS, when it leaves room for MINW workgroups per CU (160 KiB) and is whole DMA pieces
-  const size_t zbytes = dl * kNB * sizeof(T);
-  StripArgs b = a;
-  b.z_in_lds = !pregen && (zbytes % 1024 == 0) && (MINW * (lds + zbytes + 1024) <= size_t(160) * 1024);
-  if (b.z_in_lds) lds += zbytes;
-  else if (!pregen) lds = G::LDS_BYTES + size_t(a.kp.d) * NT * sizeof(T);
-  if (b.z_in_lds && small_d) b.z_in_lds = 2;
+  const size_t dl = a.kp.d <= 8 ? 8 : a.kp.d <= 16 ? 16 : size_t(a.kp.d);   // strip_kernel: feature rows of its x image
+  const size_t lds = G::LDS_BYTES + dl * NT * sizeof(T);
   auto kern = strip_kernel<T, NT, BK, NTHR, MINW>;
   set_max_lds(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(NTHR), lds, s, b, nstrips);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(NTHR), lds, s, a, nstrips);
 }
 
 }  // namespace
