@@ -94,7 +94,8 @@ __device__ __forceinline__ void pregen_mfma(const T* __restrict__ xs, const T* _
 
 #ifdef SVGP_STRIP_STAMPS   // diagnostic build (tools/build_ablate.sh stripstamps): s_memtime at the phase boundaries of one strip
 __device__ unsigned long long g_strip_stamps[128];
-#define SVGP_SSTAMP(i) do { if (stamping && threadIdx.x == 0) g_strip_stamps[i] += clock64(); } while (0)   // sums over strips
+__shared__ unsigned long long s_strip_stamps[128];   // accumulated in LDS (a global read-modify-write per stamp costs ~2k cycles)
+#define SVGP_SSTAMP(i) do { if (stamping && threadIdx.x == 0) s_strip_stamps[i] += clock64(); } while (0)   // sums over strips
 extern "C" int svgp_debug_strip_stamps(unsigned long long* out) {
   return int(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_strip_stamps), sizeof(g_strip_stamps)));
 }
@@ -144,11 +145,13 @@ __global__ void __launch_bounds__(NTHR, MINW) strip_kernel(StripArgs a, int64_t 
   __shared__ unsigned next_strip;
 #ifdef SVGP_STRIP_STAMPS
   int strips_done = 0;
+  if (threadIdx.x < 128) s_strip_stamps[threadIdx.x] = 0;
+  __syncthreads();
 #endif
   for (int64_t strip = blockIdx.x; strip < nstrips;) {
 #ifdef SVGP_STRIP_STAMPS
     const bool stamping = (blockIdx.x == 37 && strips_done >= 1);   // every strip of one workgroup but its first
-    if (stamping && threadIdx.x == 0) g_strip_stamps[127] += 1;
+    if (stamping && threadIdx.x == 0) s_strip_stamps[127] += 1;
     ++strips_done;
 #endif
     SVGP_SSTAMP(0);
@@ -307,6 +310,9 @@ __global__ void __launch_bounds__(NTHR, MINW) strip_kernel(StripArgs a, int64_t 
     __syncthreads();
     SVGP_SSTAMP(101);
   }
+#ifdef SVGP_STRIP_STAMPS
+  if (blockIdx.x == 37 && threadIdx.x < 128) g_strip_stamps[threadIdx.x] = s_strip_stamps[threadIdx.x];
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------
