@@ -1,4 +1,3 @@
 cd $GRAFT_REPO_ROOT
-bash tools/run_profile.sh r1e_H H
-bash tools/run_profile.sh r1e_C5 C5
-bash tools/run_all.sh
+bash tools/run_profile.sh r1f_H H
+bash tools/run_profile.sh r1f_H32 H32
