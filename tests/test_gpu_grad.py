@@ -202,3 +202,36 @@ def test_shard_gradients_sum_to_the_global_gradient(ctx, centered):
         _close(g[k], g_ref[k], 1e-6)
     model.free()
     data.free()
+
+
+def test_randomized_gradient_sweep(ctx):
+    """Seeded sweep of svgp_elbo_grad over ragged shapes, families, likelihoods and both parametrisations (fp64)."""
+    rng = np.random.default_rng(77)
+    liks = [o.LIK_GAUSSIAN, o.LIK_BERNOULLI_LOGISTIC, o.LIK_POISSON_EXP, o.LIK_EXPONENTIAL_EXP, o.LIK_GAMMA_EXP]
+    for case in range(14):
+        N = int(rng.integers(2, 900))
+        M = int(rng.choice([1, 5, 16, 127, 129, 190]))
+        d = int(rng.choice([1, 3, 8, 9, 16, 19]))
+        fam = int(rng.integers(0, 3))
+        lik = liks[case % len(liks)]
+        centered = bool(case % 3 == 1)
+        x, y, nc, s2 = o.synth_problem(5000 + case, N, M, d, family=fam, lik=lik)
+        tame = 0.1 if lik in (o.LIK_POISSON_EXP, o.LIK_EXPONENTIAL_EXP, o.LIK_GAMMA_EXP) else 1.0
+        sva = o.SVA(nc.kernel, nc.z, tame * nc.m, nc.Lq if not centered else 0.7 * nc.Lq, jitter=1e-4, mean_const=0.05,
+                    centered=centered)
+        qn = int(rng.choice([0, 0, 7]))
+        val_ref, g_ref = o.elbo_grad(sva, x, y, lik=lik, sigma2=s2, num_data=3.0 * N, quadrature_n=qn)
+        model = device_model(ctx, sva, lik=lik, sigma2=s2, quadrature_n=qn)
+        data = _ffi.DeviceData(ctx, x, y, np.float64)
+        val, _, g = model.elbo_grad(data, 0, N, 3.0 * N)
+        info = (case, N, M, d, fam, lik, centered, qn)
+        assert rel(val, val_ref) < 1e-8, info
+        for k in ("m", "Lq", "inv_lengthscale"):
+            a, b = np.asarray(g[k], dtype=np.float64), np.asarray(g_ref[k])
+            assert np.abs(a - b).max() <= 1e-6 * max(np.abs(b).max(), 1e-12), (k,) + info
+        zb = np.asarray(g["z"], dtype=np.float64).reshape(g_ref["z"].shape, order="F") if d > 1 else np.asarray(g["z"])[None, :]
+        assert np.abs(zb - g_ref["z"]).max() <= 1e-6 * max(np.abs(g_ref["z"]).max(), 1e-12), ("z",) + info
+        for k in ("variance", "mean_const"):
+            assert abs(g[k] - g_ref[k]) <= 1e-6 * max(abs(g_ref[k]), 1e-9) + 1e-9, (k,) + info
+        model.free()
+        data.free()

@@ -336,3 +336,28 @@ def test_half_width_strips_are_bitwise_identical():
         env = dict(os.environ, SVGP_TAIL=tail)
         outs.append(subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, check=True).stdout)
     assert outs[0] == outs[1] and len(outs[0].split()) == 4, outs
+
+
+def test_randomized_shapes_and_models(ctx):
+    """Seeded sweep over ragged shapes, every kernel family / likelihood / parametrisation and both dtypes: exercises the
+    8-, 16- and >16-feature generation paths, half-width strips, M < 16 and M just past a 128 block."""
+    rng = np.random.default_rng(20260313)
+    liks = [o.LIK_GAUSSIAN, o.LIK_BERNOULLI_LOGISTIC, o.LIK_POISSON_EXP, o.LIK_EXPONENTIAL_EXP, o.LIK_GAMMA_EXP]
+    for case in range(36):
+        N = int(rng.integers(1, 1500))
+        M = int(rng.choice([1, 3, 15, 16, 17, 127, 128, 129, 200, 257]))
+        d = int(rng.choice([1, 2, 5, 8, 9, 13, 16, 17, 24]))
+        fam = int(rng.integers(0, 3))
+        lik = liks[case % len(liks)]
+        dtype = np.float64 if case % 3 else np.float32
+        centered = bool(case % 4 == 1)
+        x, y, nc, s2 = o.synth_problem(3000 + case, N, M, d, family=fam, lik=lik, dtype=dtype)
+        tame = 0.1 if lik in (o.LIK_POISSON_EXP, o.LIK_EXPONENTIAL_EXP, o.LIK_GAMMA_EXP) else 1.0
+        jit = 1e-4 if dtype == np.float64 else 1e-2
+        sva = o.SVA(nc.kernel, nc.z, tame * nc.m, nc.Lq if not centered else 0.7 * nc.Lq, jitter=jit, mean_const=0.05,
+                    centered=centered)
+        qn = int(rng.choice([0, 0, 5, 20]))
+        ref = o.elbo(sva, x, y, lik=lik, sigma2=s2, num_data=2.0 * N, quadrature_n=qn)
+        val, _ = _run(ctx, sva, x, y, dtype=dtype, lik=lik, sigma2=s2, qn=qn, num_data=2.0 * N)
+        tol = F64_RTOL if dtype == np.float64 else F32_RTOL
+        assert rel(val, ref) < tol, (case, N, M, d, fam, lik, dtype, centered, qn, val, ref)
