@@ -1,0 +1,38 @@
+#!/usr/bin/env python
+"""Soak: create / evaluate / free models and data of changing shapes for a while; device memory must return to its
+starting level and repeated evaluations must be bitwise stable."""
+import os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "approximategps.jl_amd")); sys.path.insert(0, os.path.join(ROOT, "oracle")); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import torch
+import svgp_oracle as o
+from approxgp import _ffi
+from helpers import device_model
+
+secs = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+ctx = _ffi.Context(0)
+free0 = torch.cuda.mem_get_info()[0]
+rng = np.random.default_rng(1)
+t0, it, first = time.time(), 0, {}
+while time.time() - t0 < secs:
+    case = it % 7
+    N, M, d = [(5000, 300, 3), (70000, 1024, 8), (333, 17, 1), (20000, 129, 16), (9000, 512, 20), (64, 2, 2), (40000, 2048, 8)][case]
+    dtype = np.float64 if case % 2 == 0 else np.float32
+    x, y, sva, s2 = o.synth_problem(case, N, M, d, dtype=dtype)
+    model = device_model(ctx, sva, dtype=dtype, sigma2=s2)
+    data = _ffi.DeviceData(ctx, x, y, dtype)
+    v1 = model.elbo(data, 0, N, float(N))[0]
+    v2 = model.elbo(data, 0, N, float(N))[0]
+    g = model.elbo_grad(data, 0, N, float(N))[0]
+    assert v1 == v2 and abs(g - v1) <= 1e-12 * abs(v1) * (1 if dtype == np.float64 else 1e6), (case, v1, v2, g)   # the gradient path reduces E in another (fixed) order
+    assert first.setdefault(case, v1) == v1, (case, first[case], v1)
+    model.predict(x[:, :50] if d > 1 else x[0, :50], True, True, True)
+    model.free(); data.free()
+    it += 1
+torch.cuda.synchronize()
+free1 = torch.cuda.mem_get_info()[0]
+print(f"{it} iterations in {time.time()-t0:.0f} s; free device memory {free0/2**30:.2f} -> {free1/2**30:.2f} GiB (workspaces of the context stay allocated)")
+ctx.close()
+free2 = torch.cuda.mem_get_info()[0]
+print(f"after ctx.close(): {free2/2**30:.2f} GiB free; leaked {max(free0-free2,0)/2**20:.1f} MiB")
