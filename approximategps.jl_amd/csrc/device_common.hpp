@@ -105,14 +105,14 @@ __device__ __forceinline__ T kappa(int family, T r2, T variance) {
 // ---------------------------------------------------------------------------------------------
 // TileGemm: acc(128 x NT) += P(128 x K) * Q(K x NT) on an NTHR-thread workgroup
 // ---------------------------------------------------------------------------------------------
-template <typename T, int NT, int BK, int NTHR = kThreads>
+template <typename T, int NT, int BK, int NTHR = kThreads, int PAD = 16>
 struct TileGemm {
   static constexpr int NB = kNB;
   static constexpr int WR = 2, WC = NTHR / 128;  // wave grid: a wave owns 64 rows x NT/WC columns
   static constexpr int MI = NB / WR / 16;        // 16-row tiles per wave (4)
   static constexpr int NJ = NT / WC / 16;        // 16-col tiles per wave (2 for 128 cols x 8 waves or 64 cols x 4 waves)
-  static constexpr int PLD = NB + 16;            // LDS leading dims: +16 elements makes the 4 k-rows a
-  static constexpr int QLD = NT + 16;            // 64-lane fragment read touches land on disjoint banks
+  static constexpr int PLD = NB + PAD;           // LDS leading dims: +16 elements makes the 4 k-rows a
+  static constexpr int QLD = NT + PAD;           // 64-lane fragment read touches land on disjoint banks
   static constexpr int VEC = Vec16<T>::N;
   using V = typename Vec16<T>::type;
   using acc_t = typename Mfma16<T>::acc_t;

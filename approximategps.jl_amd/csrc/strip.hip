@@ -103,16 +103,17 @@ extern "C" int svgp_debug_strip_stamps(unsigned long long* out) {
 #define SVGP_SSTAMP(i)
 #endif
 
-template <typename T, int NT, int BK, int NTHR, int MINW = 2>
+template <typename T, int NT, int BK, int NTHR, int MINW = 2, int PAD = 16>
 __global__ void __launch_bounds__(NTHR, MINW) strip_kernel(StripArgs a, int64_t nstrips) {
-  using G = TileGemm<T, NT, BK, NTHR>;
+  using G = TileGemm<T, NT, BK, NTHR, PAD>;
   using Acc = typename G::Acc;
   using QRegs = typename G::QRegs;
   constexpr int NB = G::NB, MI = G::MI, NJ = G::NJ, VEC = G::VEC;
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   T* smem = reinterpret_cast<T*>(smem_raw);                 // staging (2 buffers), reused as reduction scratch
-  T* xs = smem + 2 * G::STAGE;                              // [d][NT] inputs of the strip, scaled by 1/l
+  T* xs = smem;   // [dl][NT] inputs of the strip, scaled by 1/l: only the pre-generation pass reads them, so they alias the
+                  // (then idle) staging buffers
   // The strip's whole Kuf block (SVA:216) is generated into the scratch strip BEFORE phase 1 (pregen_mfma; the epilogue of
   // panel I later overwrites rows I with A_I), so every k-step of both phases streams its Q tile.  History, measured with
   // s_memtime stamps inside one strip (tools/strip_stamps.py): generating the panel's Kuf rows inside the k-loop made a
@@ -494,12 +495,12 @@ __global__ void __launch_bounds__(k256, 2) kuf_kernel(KernelParams kp, const T* 
   }
 }
 
-template <typename T, int NT, int BK, int NTHR, int MINW = 2>
+template <typename T, int NT, int BK, int NTHR, int MINW = 2, int PAD = 16>
 void launch_strip_t(hipStream_t s, const StripArgs& a, int grid, int64_t nstrips) {
-  using G = TileGemm<T, NT, BK, NTHR>;
-  const size_t dl = a.kp.d <= 8 ? 8 : a.kp.d <= 16 ? 16 : size_t(a.kp.d);   // strip_kernel: feature rows of its x image
-  const size_t lds = G::LDS_BYTES + dl * NT * sizeof(T);
-  auto kern = strip_kernel<T, NT, BK, NTHR, MINW>;
+  using G = TileGemm<T, NT, BK, NTHR, PAD>;
+  const size_t lds = G::LDS_BYTES;   // the strip's x image (<= 32 feature rows) aliases the staging buffers
+  static_assert(G::LDS_BYTES >= size_t(32) * NT * sizeof(T), "x image must fit the staging buffers");
+  auto kern = strip_kernel<T, NT, BK, NTHR, MINW, PAD>;
   set_max_lds(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
   hipLaunchKernelGGL(kern, dim3(grid), dim3(NTHR), lds, s, a, nstrips);
 }
