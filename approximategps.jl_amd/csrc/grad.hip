@@ -71,17 +71,17 @@ __global__ void sum5_kernel(const double* __restrict__ partial, int nblocks, dou
 }
 
 // Abar[r][c] = m[r] g_mu[c] + 2 g_v[c] ((Lq C)[r][c] - A[r][c]);  Lq lower triangular, Mp x Mp column-major
-template <typename T>
-__global__ void __launch_bounds__(kThreads, 2) abar_kernel(const T* __restrict__ Lqp, const T* __restrict__ C,
-                                                            const T* __restrict__ A, const T* __restrict__ mp,
-                                                            const T* __restrict__ gmu, const T* __restrict__ gv,
-                                                            T* __restrict__ Abar, int64_t Mp, int64_t ld) {
-  using G = TileGemm<T, kNB, 16, kThreads>;
+template <typename T, int NT, int NTHR>
+__global__ void __launch_bounds__(NTHR, 2) abar_kernel(const T* __restrict__ Lqp, const T* __restrict__ C,
+                                                        const T* __restrict__ A, const T* __restrict__ mp,
+                                                        const T* __restrict__ gmu, const T* __restrict__ gv,
+                                                        T* __restrict__ Abar, int64_t Mp, int64_t ld) {
+  using G = TileGemm<T, NT, 16, NTHR>;
   using QRegs = typename G::QRegs;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   T* smem = reinterpret_cast<T*>(smem_raw);
-  const int I = blockIdx.y;
-  const int64_t c0 = int64_t(blockIdx.x) * kNB;
+  const int I = int(gridDim.y) - 1 - int(blockIdx.y);   // long panels first
+  const int64_t c0 = int64_t(blockIdx.x) * NT;
   typename G::Acc acc;
   acc.zero();
   const typename G::QOff qoff = G::q_offsets(ld);
@@ -506,12 +506,22 @@ void launch_grad_moments(int dtype, hipStream_t s, const LikParams& lp, double s
 
 void launch_abar(int dtype, hipStream_t s, const void* Lqp, const void* C, const void* A, const void* mp, const void* gmu,
                  const void* gv, void* Abar, int64_t Mp, int64_t ld, int64_t ncols) {
-  dim3 grid((unsigned)(ncols / kNB), (unsigned)(Mp / kNB));
+  static const int forced = [] { const char* e = getenv("SVGP_ABAR_NT"); return e ? atoi(e) : 0; }();   // tuning knob
+  const int nt = forced ? forced : 64;   // 128 x 64 tiles on 256 threads: H value-and-gradient 130.2 -> 129.7 ms, H32 72.3 -> 71.9 ms
   GD(dtype, T, {
-    using G = TileGemm<T, kNB, 16, kThreads>;
-    set_max_lds(reinterpret_cast<const void*>(abar_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, int(G::LDS_BYTES));
-    hipLaunchKernelGGL(abar_kernel<T>, grid, dim3(kThreads), G::LDS_BYTES, s, (const T*)Lqp, (const T*)C, (const T*)A,
-                       (const T*)mp, (const T*)gmu, (const T*)gv, (T*)Abar, Mp, ld);
+    if (nt == 64) {
+      using G = TileGemm<T, 64, 16, k256>;
+      auto kern = abar_kernel<T, 64, k256>;
+      set_max_lds(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, int(G::LDS_BYTES));
+      hipLaunchKernelGGL(kern, dim3((unsigned)(ncols / 64), (unsigned)(Mp / kNB)), dim3(k256), G::LDS_BYTES, s, (const T*)Lqp,
+                         (const T*)C, (const T*)A, (const T*)mp, (const T*)gmu, (const T*)gv, (T*)Abar, Mp, ld);
+    } else {
+      using G = TileGemm<T, kNB, 16, kThreads>;
+      auto kern = abar_kernel<T, kNB, kThreads>;
+      set_max_lds(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, int(G::LDS_BYTES));
+      hipLaunchKernelGGL(kern, dim3((unsigned)(ncols / kNB), (unsigned)(Mp / kNB)), dim3(kThreads), G::LDS_BYTES, s,
+                         (const T*)Lqp, (const T*)C, (const T*)A, (const T*)mp, (const T*)gmu, (const T*)gv, (T*)Abar, Mp, ld);
+    }
   });
 }
 
