@@ -178,6 +178,24 @@ def main():
                         "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS, "traffic": None,
                         "bytes_per_launch": bytes_alg, "ms_per_launch": t_kuf,
                         "ms_per_launch_all": [round(t, 4) for t in times]}
+        # what a plain write-only stream of the same size reaches on this box (report both)
+        try:
+            buf = torch.empty(M * n, dtype=torch.float64 if dtype == "f64" else torch.float32, device=dev)
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+            ts = []
+            for _ in range(6):
+                ev[0].record()
+                buf.fill_(1.0)
+                ev[1].record()
+                torch.cuda.synchronize()
+                ts.append(ev[0].elapsed_time(ev[1]))
+            t_fill = float(np.median(ts[1:]))
+            kuf_roofline["stream_write_GBps"] = es * M * n / (t_fill * 1e-3) / 1e9
+            kuf_roofline["frac_of_stream_write"] = gbs / kuf_roofline["stream_write_GBps"]
+            del buf
+        except Exception as e:  # noqa: BLE001
+            kuf_roofline["stream_write_GBps"] = None
+            kuf_roofline["stream_write_error"] = repr(e)
 
     for _ in range(args.warmup):
         step()
