@@ -413,6 +413,141 @@ struct TileGemm {
     __syncthreads();  // the tail MFMAs read no LDS, but callers reuse the staging buffers right away
   }
 #undef SVGP_DSTEP
+
+  // ==================================================================================================
+  // Fully asynchronous K loop (f64, NT = 64): BOTH operand tiles travel global -> LDS by LDS-DMA, through THREE LDS
+  // buffers, so a tile has two whole steps to land instead of one; the loop body holds no ordinary vector-memory
+  // instruction, no ds_write and no staging register, and the only wait is one counted `s_waitcnt vmcnt(N)` in front
+  // of the step's raw `s_barrier` (a `__syncthreads()` would drain the tile still in flight).
+  //   * P tile: as dma_p (one 1 KiB k-row per instruction).
+  //   * Q tile: its source is a contiguous [BK][NT] block (the scratch strip), k-rows of 512 B; an instruction moves a PAIR
+  //     of rows into 1 KiB of LDS.  Rows 2p and 2p+1 then sit 128 dwords apart = the same banks, so the odd row is stored
+  //     with its columns XOR 16 (the swizzle is applied to the per-lane SOURCE address; LDS stays linear): the four k-rows
+  //     of a fragment read land on disjoint banks, and the fragment of column tile j of an odd row is read from tile j^1.
+  // Tile t lives in buffer t % 3.  After the barrier that ends step t buffer t % 3 is free and receives tile t + 3.
+  // ==================================================================================================
+  static constexpr bool kAsync = kDmaP && (NT * sizeof(T) == 512) && (NJ == 2) && ((BK / 2) % NW == 0);
+  static constexpr int NBUF = 3;
+  static constexpr int QPP = 2 * NT;                        // one row pair of the Q tile in LDS (elements)
+  static constexpr int QA_TILE = (BK / 2) * QPP;
+  static constexpr int DQ = (BK / 2) / NW;                  // row pairs per wave and tile
+  static constexpr int DMA_PER_TILE = D_ROWS + DQ;          // DMA instructions per wave and tile
+  static constexpr size_t ASYNC_LDS_BYTES = size_t(NBUF) * (P_TILE + QA_TILE) * sizeof(T);
+
+  struct AOff { uint32_t p[D_ROWS]; uint32_t q[DQ]; };
+  static __device__ __forceinline__ AOff a_offsets(int64_t ldp) {
+    AOff r;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int q = 0; q < D_ROWS; ++q) r.p[q] = uint32_t((int64_t(wave + q * NW) * ldp + lane * VEC) * sizeof(T));
+    const int row = lane >> 5, slot = (lane & 31) * VEC;   // this lane's 16 bytes inside the pair's KiB: row 0/1, column slot
+#pragma unroll
+    for (int q = 0; q < DQ; ++q)
+      r.q[q] = uint32_t((((wave + q * NW) * 2 + row) * NT + (slot ^ (row * 16))) * sizeof(T));
+    return r;
+  }
+  static __device__ __forceinline__ void dma_tile(const T* __restrict__ psrc, const T* __restrict__ qsrc, const AOff& off,
+                                                  T* __restrict__ Pb, T* __restrict__ Qb) {
+    const int wv = __builtin_amdgcn_readfirstlane(int(threadIdx.x >> 6));
+    const char* pb = reinterpret_cast<const char*>(psrc);
+    const char* qb = reinterpret_cast<const char*>(qsrc);
+#pragma unroll
+    for (int q = 0; q < D_ROWS; ++q)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pb + off.p[q]),
+                                       (__attribute__((address_space(3))) void*)(Pb + (wv + q * NW) * PLD), 16, 0, 0);
+#pragma unroll
+    for (int q = 0; q < DQ; ++q)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(qb + off.q[q]),
+                                       (__attribute__((address_space(3))) void*)(Qb + (wv + q * NW) * QPP), 16, 0, 0);
+  }
+  // all but the wave's N newest vector-memory operations done, every LDS read returned, then the workgroup barrier
+  template <int N>
+  static __device__ __forceinline__ void wait_barrier() {
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(N) : "memory");
+  }
+  struct AFrag { const T* a; const T* b0; const T* b1; };   // this thread's fragment origin in buffer 0
+  static __device__ __forceinline__ AFrag afrag(const T* smem) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, l15 = lane & 15, odd = g & 1;
+    AFrag r;
+    r.a = smem + g * PLD + (wave / WC) * 16 + l15;
+    const T* qb = smem + NBUF * P_TILE + (g >> 1) * QPP + odd * NT + (wave % WC) * (NJ * 16) + l15;
+    r.b0 = qb + (0 ^ odd) * 16;
+    r.b1 = qb + (1 ^ odd) * 16;
+    return r;
+  }
+  template <int KSLAB, int ILO = 0, int IHI = MI - 1>
+  static __device__ __forceinline__ void load_afrag(Frag& f, const T* __restrict__ fa, const T* __restrict__ fb0,
+                                                    const T* __restrict__ fb1) {
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+      if (i >= ILO && i <= IHI) f.a[i] = fa[KSLAB * 4 * PLD + i * 32];
+    if (ILO <= IHI) {
+      f.b[0] = fb0[KSLAB * 2 * QPP];
+      f.b[1] = fb1[KSLAB * 2 * QPP];
+    }
+  }
+  // one k-step on tile t (buffer b, advanced on return); QSrc: t -> wave-uniform pointer to the contiguous Q tile of step t
+  template <int ILO, int IHI, typename QSrc>
+  static __device__ __forceinline__ void astep(Acc& acc, Frag (&f)[2], const T* __restrict__ Pbase, int64_t pstride,
+                                               const AOff& off, int t, int nsteps, QSrc& qsrc, T* __restrict__ smem,
+                                               int& b, const AFrag& fr) {
+    constexpr int KS = BK / 4;
+    static_assert(KS == 4, "written for 16-deep steps");
+    const T* fa = fr.a + b * P_TILE;
+    const T* fb0 = fr.b0 + b * QA_TILE;
+    const T* fb1 = fr.b1 + b * QA_TILE;
+    load_afrag<1, ILO, IHI>(f[1], fa, fb0, fb1);
+    mma_frag<ILO, IHI>(acc, f[0]);
+    load_afrag<2, ILO, IHI>(f[0], fa, fb0, fb1);
+    mma_frag<ILO, IHI>(acc, f[1]);
+    load_afrag<3, ILO, IHI>(f[1], fa, fb0, fb1);
+    mma_frag<ILO, IHI>(acc, f[0]);
+    if (t + 1 < nsteps) {
+      // tile t + 1 must be in LDS for every wave: of this wave's DMAs only the newest group (tile t + 2) may still fly
+      if (t + 2 < nsteps) wait_barrier<DMA_PER_TILE>();
+      else wait_barrier<0>();
+      const int bn = (b + 1 == NBUF) ? 0 : b + 1;
+      load_afrag<0>(f[0], fr.a + bn * P_TILE, fr.b0 + bn * QA_TILE, fr.b1 + bn * QA_TILE);   // all tiles: next range unknown here
+      if (t + 3 < nsteps)   // buffer b (tile t) is free now
+        dma_tile(Pbase + int64_t(t + 3) * pstride, qsrc(t + 3), off, smem + b * P_TILE, smem + NBUF * P_TILE + b * QA_TILE);
+      b = bn;
+    }
+    mma_frag<ILO, IHI>(acc, f[1]);
+  }
+#define SVGP_ASTEP(LO, HI, TT) astep<LO, HI>(acc, f, Pbase, pstride, off, (TT), nsteps, qsrc, smem, b, fr)
+  template <int TRI, typename QSrc>
+  static __device__ __forceinline__ void loop_tri_async(Acc& acc, const T* __restrict__ Pbase, int64_t ldp, int nsteps,
+                                                        QSrc&& qsrc, T* __restrict__ smem) {
+    if (nsteps <= 0) return;
+    constexpr int ND = NB / BK;
+    static_assert(TRI == 0 || (ND == 8 && MI == 4), "triangular steps are written out for BK = 16, 128-row panels");
+    const AOff off = a_offsets(ldp);
+    const int64_t pstride = int64_t(BK) * ldp;
+    const AFrag fr = afrag(smem);
+    T* Qs = smem + NBUF * P_TILE;
+    dma_tile(Pbase, qsrc(0), off, smem, Qs);
+    if (nsteps > 1) dma_tile(Pbase + pstride, qsrc(1), off, smem + P_TILE, Qs + QA_TILE);
+    if (nsteps > 2) dma_tile(Pbase + 2 * pstride, qsrc(2), off, smem + 2 * P_TILE, Qs + 2 * QA_TILE);
+    if (nsteps > 2) wait_barrier<2 * DMA_PER_TILE>();
+    else if (nsteps > 1) wait_barrier<DMA_PER_TILE>();
+    else wait_barrier<0>();
+    Frag f[2];
+    load_afrag<0>(f[0], fr.a, fr.b0, fr.b1);
+    int b = 0, t = 0;
+    if (TRI < 0) {
+      SVGP_ASTEP(0, 0, 0); SVGP_ASTEP(0, 0, 1); SVGP_ASTEP(0, 1, 2); SVGP_ASTEP(0, 1, 3);
+      SVGP_ASTEP(0, 2, 4); SVGP_ASTEP(0, 2, 5); SVGP_ASTEP(0, 3, 6); SVGP_ASTEP(0, 3, 7);
+      t = ND;
+    }
+    const int nreg = (TRI > 0) ? nsteps - ND : nsteps;
+    for (; t < nreg; ++t) astep<0, MI - 1>(acc, f, Pbase, pstride, off, t, nsteps, qsrc, smem, b, fr);
+    if (TRI > 0) {
+      SVGP_ASTEP(0, 3, nreg + 0); SVGP_ASTEP(0, 3, nreg + 1); SVGP_ASTEP(1, 3, nreg + 2); SVGP_ASTEP(1, 3, nreg + 3);
+      SVGP_ASTEP(2, 3, nreg + 4); SVGP_ASTEP(2, 3, nreg + 5); SVGP_ASTEP(3, 3, nreg + 6); SVGP_ASTEP(3, 3, nreg + 7);
+    }
+    __syncthreads();  // callers reuse the LDS right away; also drains nothing (every DMA was waited for)
+  }
+#undef SVGP_ASTEP
 };
 
 }  // namespace svgp

@@ -16,6 +16,9 @@
 #include "kernels.hpp"
 #include "lik.hpp"
 
+#ifndef SVGP_ASYNC
+#define SVGP_ASYNC 1   // f64 64-point strips: both operand tiles by LDS-DMA through three LDS buffers (TileGemm::loop_tri_async)
+#endif
 #ifndef SVGP_TRI
 #define SVGP_TRI 3   // bit 1: skip zero tiles of T diagonal blocks (phase 1), bit 2: of U diagonal blocks (phase 2)
 #endif
@@ -217,9 +220,14 @@ __global__ void __launch_bounds__(NTHR, MINW) strip_kernel(StripArgs a, int64_t 
       SVGP_SSTAMP(2 + 3 * I);
       Acc acc;
       acc.zero();
-      auto qload = [&](int t, QRegs& r) { G::load_q(r, work + int64_t(t) * BK * NT, qoff); };
       // the last NB/BK steps multiply the lower-triangular inv(L_II): their zero 16-row tiles are skipped
-      G::template loop_tri<(BK == 16 && (SVGP_TRI & 1)) ? 1 : 0>(acc, Tm + int64_t(I) * NB, Mp, (I + 1) * (NB / BK), qload, smem);
+      if constexpr (SVGP_ASYNC && G::kAsync) {
+        auto qsrc = [&](int t) { return work + int64_t(t) * BK * NT; };
+        G::template loop_tri_async<(SVGP_TRI & 1) ? 1 : 0>(acc, Tm + int64_t(I) * NB, Mp, (I + 1) * (NB / BK), qsrc, smem);
+      } else {
+        auto qload = [&](int t, QRegs& r) { G::load_q(r, work + int64_t(t) * BK * NT, qoff); };
+        G::template loop_tri<(BK == 16 && (SVGP_TRI & 1)) ? 1 : 0>(acc, Tm + int64_t(I) * NB, Mp, (I + 1) * (NB / BK), qload, smem);
+      }
 
       SVGP_SSTAMP(3 + 3 * I);
       // epilogue: A_I -> scratch strip, column sums in fp64
@@ -258,10 +266,16 @@ __global__ void __launch_bounds__(NTHR, MINW) strip_kernel(StripArgs a, int64_t 
       Acc acc;
       acc.zero();
       const T* wq = work + int64_t(J) * NB * NT;
-      auto qload = [&](int t, QRegs& r) { G::load_q(r, wq + int64_t(t) * BK * NT, qoff); };
       // the first NB/BK steps multiply the upper-triangular diagonal block of B': zero tiles skipped likewise
-      G::template loop_tri<(BK == 16 && (SVGP_TRI & 2)) ? -1 : 0>(acc, U + int64_t(J) * NB + int64_t(J) * NB * Mp, Mp, (nP - J) * (NB / BK), qload,
-                                                 smem);
+      if constexpr (SVGP_ASYNC && G::kAsync) {
+        auto qsrc = [&](int t) { return wq + int64_t(t) * BK * NT; };
+        G::template loop_tri_async<(SVGP_TRI & 2) ? -1 : 0>(acc, U + int64_t(J) * NB + int64_t(J) * NB * Mp, Mp, (nP - J) * (NB / BK), qsrc,
+                                                            smem);
+      } else {
+        auto qload = [&](int t, QRegs& r) { G::load_q(r, wq + int64_t(t) * BK * NT, qoff); };
+        G::template loop_tri<(BK == 16 && (SVGP_TRI & 2)) ? -1 : 0>(acc, U + int64_t(J) * NB + int64_t(J) * NB * Mp, Mp, (nP - J) * (NB / BK), qload,
+                                                   smem);
+      }
       SVGP_SSTAMP(61 + 2 * J);
 #pragma unroll
       for (int i = 0; i < MI; ++i)
@@ -498,7 +512,8 @@ __global__ void __launch_bounds__(k256, 2) kuf_kernel(KernelParams kp, const T* 
 template <typename T, int NT, int BK, int NTHR, int MINW = 2, int PAD = 16>
 void launch_strip_t(hipStream_t s, const StripArgs& a, int grid, int64_t nstrips) {
   using G = TileGemm<T, NT, BK, NTHR, PAD>;
-  const size_t lds = G::LDS_BYTES;   // the strip's x image (<= 32 feature rows) aliases the staging buffers
+  // the strip's x image (<= 32 feature rows) aliases the staging buffers
+  const size_t lds = (SVGP_ASYNC && G::kAsync) ? G::ASYNC_LDS_BYTES : G::LDS_BYTES;
   static_assert(G::LDS_BYTES >= size_t(32) * NT * sizeof(T), "x image must fit the staging buffers");
   auto kern = strip_kernel<T, NT, BK, NTHR, MINW, PAD>;
   set_max_lds(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
