@@ -426,21 +426,31 @@ struct TileGemm {
   //     of a fragment read land on disjoint banks, and the fragment of column tile j of an odd row is read from tile j^1.
   // Tile t lives in buffer t % 3.  After the barrier that ends step t buffer t % 3 is free and receives tile t + 3.
   // ==================================================================================================
-  static constexpr bool kAsync = kDmaP && (NT * sizeof(T) == 512) && (NJ == 2) && ((BK / 2) % NW == 0);
+  // fp32 (128-point strips): the P tile's k-rows are 512 B too and use the same row-pair + XOR-16 image (the fragment of
+  // row tile 2i + wr of an odd k-row is read from tile 2i + (wr ^ 1)).
+  static constexpr bool kPairP = (NB * sizeof(T) == 512);   // P k-rows of 512 B: row-pair image; 1 KiB rows: padded rows (PLD)
+  static constexpr bool kAsync = (SVGP_DMA_P != 0) && (NB * sizeof(T) == 1024 || kPairP) && (NT * sizeof(T) == 512) &&
+                                 BK == 16 && NTHR == 256;
   static constexpr int NBUF = 3;
   static constexpr int QPP = 2 * NT;                        // one row pair of the Q tile in LDS (elements)
   static constexpr int QA_TILE = (BK / 2) * QPP;
+  static constexpr int PPP = 2 * NB;                        // one row pair of the P tile (pair image)
+  static constexpr int PA_TILE = kPairP ? (BK / 2) * PPP : P_TILE;
   static constexpr int DQ = (BK / 2) / NW;                  // row pairs per wave and tile
-  static constexpr int DMA_PER_TILE = D_ROWS + DQ;          // DMA instructions per wave and tile
-  static constexpr size_t ASYNC_LDS_BYTES = size_t(NBUF) * (P_TILE + QA_TILE) * sizeof(T);
+  static constexpr int DP = kPairP ? (BK / 2) / NW : BK / NW;   // P instructions per wave and tile
+  static constexpr int DMA_PER_TILE = DP + DQ;              // DMA instructions per wave and tile
+  static constexpr size_t ASYNC_LDS_BYTES = size_t(NBUF) * (PA_TILE + QA_TILE) * sizeof(T);
 
-  struct AOff { uint32_t p[D_ROWS]; uint32_t q[DQ]; };
+  struct AOff { uint32_t p[DP]; uint32_t q[DQ]; };
   static __device__ __forceinline__ AOff a_offsets(int64_t ldp) {
     AOff r;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int row = lane >> 5, slot = (lane & 31) * VEC;   // this lane's 16 bytes inside a pair's KiB: row 0/1, column slot
 #pragma unroll
-    for (int q = 0; q < D_ROWS; ++q) r.p[q] = uint32_t((int64_t(wave + q * NW) * ldp + lane * VEC) * sizeof(T));
-    const int row = lane >> 5, slot = (lane & 31) * VEC;   // this lane's 16 bytes inside the pair's KiB: row 0/1, column slot
+    for (int q = 0; q < DP; ++q) {
+      if constexpr (kPairP) r.p[q] = uint32_t((int64_t((wave + q * NW) * 2 + row) * ldp + (slot ^ (row * 16))) * sizeof(T));
+      else r.p[q] = uint32_t((int64_t(wave + q * NW) * ldp + lane * VEC) * sizeof(T));
+    }
 #pragma unroll
     for (int q = 0; q < DQ; ++q)
       r.q[q] = uint32_t((((wave + q * NW) * 2 + row) * NT + (slot ^ (row * 16))) * sizeof(T));
@@ -452,9 +462,10 @@ struct TileGemm {
     const char* pb = reinterpret_cast<const char*>(psrc);
     const char* qb = reinterpret_cast<const char*>(qsrc);
 #pragma unroll
-    for (int q = 0; q < D_ROWS; ++q)
+    for (int q = 0; q < DP; ++q)
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pb + off.p[q]),
-                                       (__attribute__((address_space(3))) void*)(Pb + (wv + q * NW) * PLD), 16, 0, 0);
+                                       (__attribute__((address_space(3))) void*)(Pb + (wv + q * NW) * (kPairP ? PPP : PLD)), 16, 0,
+                                       0);
 #pragma unroll
     for (int q = 0; q < DQ; ++q)
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(qb + off.q[q]),
@@ -465,12 +476,15 @@ struct TileGemm {
   static __device__ __forceinline__ void wait_barrier() {
     asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(N) : "memory");
   }
-  struct AFrag { const T* a; const T* b0; const T* b1; };   // this thread's fragment origin in buffer 0
+  // this thread's fragment origins in buffer 0: column tile j of an odd k-row is read from tile j ^ 1, so even and odd
+  // tiles get their own origin (b0: j even, b1: j odd); the same for the row tiles of a pair-image P tile
+  struct AFrag { const T* a; const T* b0; const T* b1; };
   static __device__ __forceinline__ AFrag afrag(const T* smem) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, l15 = lane & 15, odd = g & 1;
     AFrag r;
-    r.a = smem + g * PLD + (wave / WC) * 16 + l15;
-    const T* qb = smem + NBUF * P_TILE + (g >> 1) * QPP + odd * NT + (wave % WC) * (NJ * 16) + l15;
+    if constexpr (kPairP) r.a = smem + (g >> 1) * PPP + odd * NB + ((wave / WC) ^ odd) * 16 + l15;
+    else r.a = smem + g * PLD + (wave / WC) * 16 + l15;
+    const T* qb = smem + NBUF * PA_TILE + (g >> 1) * QPP + odd * NT + (wave % WC) * (NJ * 16) + l15;
     r.b0 = qb + (0 ^ odd) * 16;
     r.b1 = qb + (1 ^ odd) * 16;
     return r;
@@ -478,12 +492,17 @@ struct TileGemm {
   template <int KSLAB, int ILO = 0, int IHI = MI - 1>
   static __device__ __forceinline__ void load_afrag(Frag& f, const T* __restrict__ fa, const T* __restrict__ fb0,
                                                     const T* __restrict__ fb1) {
+    constexpr int ASLAB = kPairP ? KSLAB * 2 * PPP : KSLAB * 4 * PLD;
 #pragma unroll
     for (int i = 0; i < MI; ++i)
-      if (i >= ILO && i <= IHI) f.a[i] = fa[KSLAB * 4 * PLD + i * 32];
+      if (i >= ILO && i <= IHI) f.a[i] = fa[ASLAB + i * 32];
     if (ILO <= IHI) {
-      f.b[0] = fb0[KSLAB * 2 * QPP];
-      f.b[1] = fb1[KSLAB * 2 * QPP];
+      static_assert(NJ % 2 == 0, "column tiles come in even / odd pairs");
+#pragma unroll
+      for (int j = 0; j < NJ; j += 2) {
+        f.b[j] = fb0[KSLAB * 2 * QPP + j * 16];
+        f.b[j + 1] = fb1[KSLAB * 2 * QPP + j * 16];
+      }
     }
   }
   // one k-step on tile t (buffer b, advanced on return); QSrc: t -> wave-uniform pointer to the contiguous Q tile of step t
@@ -493,7 +512,7 @@ struct TileGemm {
                                                int& b, const AFrag& fr) {
     constexpr int KS = BK / 4;
     static_assert(KS == 4, "written for 16-deep steps");
-    const T* fa = fr.a + b * P_TILE;
+    const T* fa = fr.a + b * PA_TILE;
     const T* fb0 = fr.b0 + b * QA_TILE;
     const T* fb1 = fr.b1 + b * QA_TILE;
     load_afrag<1, ILO, IHI>(f[1], fa, fb0, fb1);
@@ -507,9 +526,9 @@ struct TileGemm {
       if (t + 2 < nsteps) wait_barrier<DMA_PER_TILE>();
       else wait_barrier<0>();
       const int bn = (b + 1 == NBUF) ? 0 : b + 1;
-      load_afrag<0>(f[0], fr.a + bn * P_TILE, fr.b0 + bn * QA_TILE, fr.b1 + bn * QA_TILE);   // all tiles: next range unknown here
+      load_afrag<0>(f[0], fr.a + bn * PA_TILE, fr.b0 + bn * QA_TILE, fr.b1 + bn * QA_TILE);   // all tiles: next range unknown here
       if (t + 3 < nsteps)   // buffer b (tile t) is free now
-        dma_tile(Pbase + int64_t(t + 3) * pstride, qsrc(t + 3), off, smem + b * P_TILE, smem + NBUF * P_TILE + b * QA_TILE);
+        dma_tile(Pbase + int64_t(t + 3) * pstride, qsrc(t + 3), off, smem + b * PA_TILE, smem + NBUF * PA_TILE + b * QA_TILE);
       b = bn;
     }
     mma_frag<ILO, IHI>(acc, f[1]);
@@ -524,10 +543,10 @@ struct TileGemm {
     const AOff off = a_offsets(ldp);
     const int64_t pstride = int64_t(BK) * ldp;
     const AFrag fr = afrag(smem);
-    T* Qs = smem + NBUF * P_TILE;
+    T* Qs = smem + NBUF * PA_TILE;
     dma_tile(Pbase, qsrc(0), off, smem, Qs);
-    if (nsteps > 1) dma_tile(Pbase + pstride, qsrc(1), off, smem + P_TILE, Qs + QA_TILE);
-    if (nsteps > 2) dma_tile(Pbase + 2 * pstride, qsrc(2), off, smem + 2 * P_TILE, Qs + 2 * QA_TILE);
+    if (nsteps > 1) dma_tile(Pbase + pstride, qsrc(1), off, smem + PA_TILE, Qs + QA_TILE);
+    if (nsteps > 2) dma_tile(Pbase + 2 * pstride, qsrc(2), off, smem + 2 * PA_TILE, Qs + 2 * QA_TILE);
     if (nsteps > 2) wait_barrier<2 * DMA_PER_TILE>();
     else if (nsteps > 1) wait_barrier<DMA_PER_TILE>();
     else wait_barrier<0>();
