@@ -247,12 +247,12 @@ def main():
 
     # HBM-side traffic of the dominant kernel: PMC counters cannot be read from inside this process, so the
     # figure is the one measured by tools/run_profile.sh (separate rocprofv3 --pmc passes) for this workload.
-    pmc_path = os.path.join(ROOT, "profiles", "round1", "H_fp64_v6_pmc.json")
+    pmc_path = os.path.join(ROOT, "profiles", "round1", "H_fp64_v7_pmc.json")
     if args.config == "H" and os.path.exists(pmc_path):
         pm = json.load(open(pmc_path))
         out["roofline"]["traffic"] = pm["strip_kernel<double, 64, 16, 256, 2>"]["traffic_bytes_per_launch"]
         out["roofline"]["traffic_note"] = ("bytes per launch at the L2<->fabric boundary (FETCH_SIZE x2 + WRITE_SIZE, "
-                                           "profiles/round1/H_fp64_v6_pmc.json); includes Infinity-Cache hits of the per-workgroup "
+                                           "profiles/round1/H_fp64_v7_pmc.json); includes Infinity-Cache hits of the per-workgroup "
                                            "scratch strips; algorithmic HBM bytes are 88 MB")
     if kuf_roofline is not None:
         if args.config == "H" and os.path.exists(pmc_path):
