@@ -306,6 +306,8 @@ def main():
     os.dup2(saved_stdout, 1)
     os.close(saved_stdout)
     if rank == 0:
+        if world > 1:
+            time.sleep(1.0)   # let the other ranks finish their teardown chatter: the JSON stays the last line even in a merged capture
         sys.stdout.write(json.dumps(out) + "\n")
         sys.stdout.flush()
 
