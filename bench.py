@@ -250,13 +250,15 @@ def main():
     pmc_path = os.path.join(ROOT, "profiles", "round1", "H_fp64_v7_pmc.json")
     if args.config == "H" and os.path.exists(pmc_path):
         pm = json.load(open(pmc_path))
-        out["roofline"]["traffic"] = pm["strip_kernel<double, 64, 16, 256, 2>"]["traffic_bytes_per_launch"]
+        out["roofline"]["traffic"] = next((v.get("traffic_bytes_per_launch") for k, v in pm.items()
+                                           if k.startswith("strip_kernel<double")), None)
         out["roofline"]["traffic_note"] = ("bytes per launch at the L2<->fabric boundary (FETCH_SIZE x2 + WRITE_SIZE, "
                                            "profiles/round1/H_fp64_v7_pmc.json); includes Infinity-Cache hits of the per-workgroup "
                                            "scratch strips; algorithmic HBM bytes are 88 MB")
     if kuf_roofline is not None:
         if args.config == "H" and os.path.exists(pmc_path):
-            kuf_roofline["traffic"] = json.load(open(pmc_path))["kuf_kernel<double, 8, 0>"]["traffic_bytes_per_launch"]
+            kuf_roofline["traffic"] = next((v.get("traffic_bytes_per_launch") for k, v in json.load(open(pmc_path)).items()
+                                            if k.startswith("kuf_kernel<double")), None)
         out["kuf_roofline"] = kuf_roofline
     if rank == 0 and world == 1 and not args.no_grad:
         # value-and-gradient evaluation (svgp_elbo_grad: what a training step costs), same workload, same residency
