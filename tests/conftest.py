@@ -3,6 +3,10 @@
 import os
 import sys
 
+# torch bundles its own copy of the HIP runtime; in a process that uses both torch.cuda and libsvgp_mi355x.so it has to be
+# loaded first (the library then binds to the already loaded runtime; the other order leaves torch without GPUs)
+import torch  # noqa: F401
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "approximategps.jl_amd"), os.path.join(ROOT, "oracle")):
     if p not in sys.path:

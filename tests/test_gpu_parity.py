@@ -361,3 +361,28 @@ def test_randomized_shapes_and_models(ctx):
         val, _ = _run(ctx, sva, x, y, dtype=dtype, lik=lik, sigma2=s2, qn=qn, num_data=2.0 * N)
         tol = F64_RTOL if dtype == np.float64 else F32_RTOL
         assert rel(val, ref) < tol, (case, N, M, d, fam, lik, dtype, centered, qn, val, ref)
+
+
+def test_wrap_device_memory_zero_copy(ctx):
+    """svgp_data_wrap_device: x (feature-major [d][ldx]) and y already live in HBM (here: torch tensors, with a leading
+    dimension larger than n); same ELBO as the uploaded copy, and the library must not free the caller's memory."""
+    import torch
+
+    N, M, d, ldx = 1234, 70, 3, 1300
+    x, y, sva, s2 = o.synth_problem(91, N, M, d)
+    xt = torch.zeros((d, ldx), dtype=torch.float64, device="cuda:0")
+    xt[:, :N] = torch.from_numpy(np.ascontiguousarray(x))
+    yt = torch.from_numpy(np.ascontiguousarray(y)).to("cuda:0")
+    torch.cuda.synchronize()
+    model = device_model(ctx, sva, sigma2=s2)
+    up = _ffi.DeviceData(ctx, x, y, np.float64)
+    wrapped = _ffi.DeviceData.wrap(ctx, np.float64, d, N, ldx, xt.data_ptr(), yt.data_ptr())
+    a = model.elbo(up, 0, N, 2.0 * N)[0]
+    b = model.elbo(wrapped, 0, N, 2.0 * N)[0]
+    c = model.elbo(wrapped, 100, 500, 2.0 * N)[0]
+    assert a == b
+    assert rel(c, o.elbo(sva, x[:, 100:600], y[100:600], sigma2=s2, num_data=2.0 * N)) < F64_RTOL
+    wrapped.free()
+    assert float(xt[0, 0].item()) == x[0, 0] and float(yt[3].item()) == y[3]   # still the caller's, still intact
+    up.free()
+    model.free()
