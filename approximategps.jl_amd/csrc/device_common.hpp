@@ -202,17 +202,29 @@ struct TileGemm {
     for (int q = 0; q < D_ROWS; ++q) r.o[q] = uint32_t((int64_t(wave + q * NW) * ld + lane * VEC) * sizeof(T));
     return r;
   }
+  // One instruction: LDS destination in M0 (wave-uniform), source = scalar base + 32-bit per-lane offset.  Written as inline
+  // assembly because the builtin materialises the full 64-bit address in VGPRs (a v_lshl_add_u64 per instruction - f64 VALU
+  // work is MFMA time); the hardware's vmcnt still counts these, the compiler merely does not know (it can only over-wait).
+  // M0 is written without the compiler's knowledge: a kernel that uses this loop must hold no other M0 user (the builtin
+  // LDS-DMA of the two-buffer loop, ds_gws, s_movrel) - the asynchronous kernels do not.  Same-box A/B: H 33.9 -> 33.3 ms,
+  // H32 17.46 -> 16.86, C3 67.5 -> 65.7, C5 4.81 -> 4.74, C2 1.19 -> 1.15 ms; VALU instructions per 32-MFMA step 17 -> 11.
+  static __device__ __forceinline__ void glds16(const void* sbase, uint32_t voff, const T* lds) {
+#if SVGP_DMA_ASM
+    const uint32_t l = uint32_t(uintptr_t((__attribute__((address_space(3))) T*)(lds)));
+    asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(l), "v"(voff), "s"(sbase) : "memory");
+#else
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(reinterpret_cast<const char*>(sbase) + voff),
+                                     (__attribute__((address_space(3))) void*)(lds), 16, 0, 0);
+#endif
+  }
   static __device__ __forceinline__ void dma_p(const T* __restrict__ src, const DOff& off, T* __restrict__ Ps) {
 #if defined(SVGP_ABLATE) && (SVGP_ABLATE & 1)
     (void)src; (void)off; (void)Ps;
     return;
 #endif
     const int wv = __builtin_amdgcn_readfirstlane(int(threadIdx.x >> 6));
-    const char* base = reinterpret_cast<const char*>(src);
 #pragma unroll
-    for (int q = 0; q < D_ROWS; ++q)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + off.o[q]),
-                                       (__attribute__((address_space(3))) void*)(Ps + (wv + q * NW) * PLD), 16, 0, 0);
+    for (int q = 0; q < D_ROWS; ++q) glds16(src, off.o[q], Ps + (wv + q * NW) * PLD);
   }
   static __device__ __forceinline__ void load_q(QRegs& r, const T* __restrict__ src, const QOff& off) {
 #if defined(SVGP_ABLATE) && (SVGP_ABLATE & 2)
@@ -458,21 +470,6 @@ struct TileGemm {
     for (int q = 0; q < DQ; ++q)
       r.q[q] = uint32_t((((wave + q * NW) * 2 + row) * NT + (slot ^ (row * 16))) * sizeof(T));
     return r;
-  }
-  // One instruction: LDS destination in M0 (wave-uniform), source = scalar base + 32-bit per-lane offset.  Written as inline
-  // assembly because the builtin materialises the full 64-bit address in VGPRs (a v_lshl_add_u64 per instruction - f64 VALU
-  // work is MFMA time); the hardware's vmcnt still counts these, the compiler merely does not know (it can only over-wait).
-  // M0 is written without the compiler's knowledge: a kernel that uses this loop must hold no other M0 user (the builtin
-  // LDS-DMA of the two-buffer loop, ds_gws, s_movrel) - the asynchronous kernels do not.  Same-box A/B: H 33.9 -> 33.3 ms,
-  // H32 17.46 -> 16.86, C3 67.5 -> 65.7, C5 4.81 -> 4.74, C2 1.19 -> 1.15 ms; VALU instructions per 32-MFMA step 17 -> 11.
-  static __device__ __forceinline__ void glds16(const void* sbase, uint32_t voff, const T* lds) {
-#if SVGP_DMA_ASM
-    const uint32_t l = uint32_t(uintptr_t((__attribute__((address_space(3))) T*)(lds)));
-    asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(l), "v"(voff), "s"(sbase) : "memory");
-#else
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(reinterpret_cast<const char*>(sbase) + voff),
-                                     (__attribute__((address_space(3))) void*)(lds), 16, 0, 0);
-#endif
   }
   static __device__ __forceinline__ void dma_tile(const T* __restrict__ psrc, const T* __restrict__ qsrc, const AOff& off,
                                                   T* __restrict__ Pb, T* __restrict__ Qb) {
