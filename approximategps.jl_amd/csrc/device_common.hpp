@@ -455,9 +455,12 @@ struct TileGemm {
   static constexpr int DP = kPairP ? (BK / 2) / NW : BK / NW;   // P instructions per wave and tile
   static constexpr int DMA_PER_TILE = DP + DQ;              // DMA instructions per wave and tile
   static constexpr size_t ASYNC_LDS_BYTES = size_t(NBUF) * (PA_TILE + QA_TILE) * sizeof(T);
+  // dynamic LDS a kernel that may take either loop has to ask for
+  static constexpr size_t MAX_LDS_BYTES = (kAsync && ASYNC_LDS_BYTES > LDS_BYTES) ? ASYNC_LDS_BYTES : LDS_BYTES;
 
   struct AOff { uint32_t p[DP]; uint32_t q[DQ]; };
-  static __device__ __forceinline__ AOff a_offsets(int64_t ldp) {
+  // ldq: leading dimension of the Q source (its k-rows are ldq elements apart; NT for a contiguous tile)
+  static __device__ __forceinline__ AOff a_offsets(int64_t ldp, int64_t ldq) {
     AOff r;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int row = lane >> 5, slot = (lane & 31) * VEC;   // this lane's 16 bytes inside a pair's KiB: row 0/1, column slot
@@ -468,7 +471,7 @@ struct TileGemm {
     }
 #pragma unroll
     for (int q = 0; q < DQ; ++q)
-      r.q[q] = uint32_t((((wave + q * NW) * 2 + row) * NT + (slot ^ (row * 16))) * sizeof(T));
+      r.q[q] = uint32_t((int64_t((wave + q * NW) * 2 + row) * ldq + (slot ^ (row * 16))) * sizeof(T));
     return r;
   }
   static __device__ __forceinline__ void dma_tile(const T* __restrict__ psrc, const T* __restrict__ qsrc, const AOff& off,
@@ -544,11 +547,11 @@ struct TileGemm {
 #define SVGP_ASTEP(LO, HI, TT) astep<LO, HI>(acc, f, Pbase, pstride, off, (TT), nsteps, qsrc, smem, b, fr)
   template <int TRI, typename QSrc>
   static __device__ __forceinline__ void loop_tri_async(Acc& acc, const T* __restrict__ Pbase, int64_t ldp, int nsteps,
-                                                        QSrc&& qsrc, T* __restrict__ smem) {
+                                                        QSrc&& qsrc, T* __restrict__ smem, int64_t ldq = NT) {
     if (nsteps <= 0) return;
     constexpr int ND = NB / BK;
     static_assert(TRI == 0 || (ND == 8 && MI == 4), "triangular steps are written out for BK = 16, 128-row panels");
-    const AOff off = a_offsets(ldp);
+    const AOff off = a_offsets(ldp, ldq);
     const int64_t pstride = int64_t(BK) * ldp;
     const AFrag fr = afrag(smem);
     T* Qs = smem + NBUF * PA_TILE;
