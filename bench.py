@@ -247,7 +247,7 @@ def main():
 
     # HBM-side traffic of the dominant kernel: PMC counters cannot be read from inside this process, so the
     # figure is the one measured by tools/run_profile.sh (separate rocprofv3 --pmc passes) for this workload.
-    pmc_path = os.path.join(ROOT, "profiles", "round1", "H_fp64_v7_pmc.json")
+    pmc_path = os.path.join(ROOT, "profiles", "round1", "H_fp64_v8_pmc.json")
     pm = {}
     if args.config == "H":
         try:   # a missing / reshaped summary must never cost the benchmark line
@@ -258,7 +258,7 @@ def main():
     if strip_pm is not None:
         out["roofline"]["traffic"] = strip_pm.get("traffic_bytes_per_launch")
         out["roofline"]["traffic_note"] = ("bytes per launch at the L2<->fabric boundary (FETCH_SIZE x2 + WRITE_SIZE, "
-                                           "profiles/round1/H_fp64_v7_pmc.json); includes Infinity-Cache hits of the per-workgroup "
+                                           "profiles/round1/H_fp64_v8_pmc.json); includes Infinity-Cache hits of the per-workgroup "
                                            "scratch strips; algorithmic HBM bytes are 88 MB")
     if kuf_roofline is not None:
         kuf_pm = next((v for k, v in pm.items() if k.startswith("kuf_kernel<double") and isinstance(v, dict)), None)

@@ -1,2 +1,3 @@
 cd $GRAFT_REPO_ROOT
-bash tools/run_profile.sh r1g_H H
+bash tools/run_profile.sh r1h_H H
+bash tools/run_all.sh
