@@ -477,10 +477,14 @@ struct TileGemm {
   static __device__ __forceinline__ void dma_tile(const T* __restrict__ psrc, const T* __restrict__ qsrc, const AOff& off,
                                                   T* __restrict__ Pb, T* __restrict__ Qb) {
     const int wv = __builtin_amdgcn_readfirstlane(int(threadIdx.x >> 6));
+#if !(defined(SVGP_ABLATE) && (SVGP_ABLATE & 1))   // diagnostic builds: bit 1 no P-tile DMA, bit 2 no Q-tile DMA (timing only)
 #pragma unroll
     for (int q = 0; q < DP; ++q) glds16(psrc, off.p[q], Pb + (wv + q * NW) * (kPairP ? PPP : PLD));
+#endif
+#if !(defined(SVGP_ABLATE) && (SVGP_ABLATE & 2))
 #pragma unroll
     for (int q = 0; q < DQ; ++q) glds16(qsrc, off.q[q], Qb + (wv + q * NW) * QPP);
+#endif
   }
   // all but the wave's N newest vector-memory operations done, every LDS read returned, then the workgroup barrier
   template <int N>
