@@ -68,7 +68,7 @@ class PoissonLikelihood:
 
 @dataclass(frozen=True)
 class ExponentialLikelihood:
-    """exp link: y ~ Exponential(rate exp f)  [GPLikelihoods]"""
+    """exp link: y ~ Distributions.Exponential(exp f), i.e. SCALE exp f: log p = -f - y exp(-f)  [GPLikelihoods]"""
 
 
 @dataclass(frozen=True)

@@ -30,7 +30,7 @@ __device__ __forceinline__ double loglik_point(int lik, double f, double y, doub
   }
   if (lik == 1) return -softplus_d(y > 0.5 ? -f : f);
   if (lik == 2) return y * f - exp(f) - lgamma(y + 1.0);
-  if (lik == 3) return f - y * exp(f);                                           // Exponential(rate e^f)
+  if (lik == 3) return -f - y * exp(-f);                                         // Exponential(scale e^f) = Gamma(1, scale e^f)
   return (sigma2 - 1.0) * log(y) - y * exp(-f) - sigma2 * f - lgamma(sigma2);    // Gamma(alpha = sigma2, scale e^f)
 }
 
@@ -43,7 +43,7 @@ __device__ __forceinline__ double expected_loglik_point(const LikParams& lp, dou
       return -0.5 * (1.8378770664093453 + log_sigma2 + (r * r + v) / lp.sigma2);
     }
     if (lp.lik == 2) return y * mu - exp(mu + 0.5 * v) - lgamma(y + 1.0);  // Poisson, exp link
-    if (lp.lik == 3) return mu - y * exp(mu + 0.5 * v);                    // Exponential, exp link
+    if (lp.lik == 3) return -mu - y * exp(0.5 * v - mu);                   // Exponential (scale), exp link
     return (lp.sigma2 - 1.0) * log(y) - y * exp(0.5 * v - mu) - lp.sigma2 * mu - lgamma(lp.sigma2);  // Gamma, exp link
   }
   const double s = 1.4142135623730951 * sqrt(v);
@@ -58,7 +58,7 @@ __device__ __forceinline__ double dloglik_point(int lik, double f, double y, dou
   if (lik == 0) return (y - f) / sigma2;
   if (lik == 1) return y - 1.0 / (1.0 + exp(-f));
   if (lik == 2) return y - exp(f);
-  if (lik == 3) return 1.0 - y * exp(f);
+  if (lik == 3) return y * exp(-f) - 1.0;
   return y * exp(-f) - sigma2;
 }
 
@@ -78,8 +78,8 @@ __device__ __forceinline__ void expected_loglik_grad_point(const LikParams& lp, 
       gmu = y - e;
       gv = -0.5 * e;
     } else if (lp.lik == 3) {
-      const double e = y * exp(mu + 0.5 * v);
-      gmu = 1.0 - e;
+      const double e = y * exp(0.5 * v - mu);
+      gmu = e - 1.0;
       gv = -0.5 * e;
     } else {
       const double e = y * exp(0.5 * v - mu);

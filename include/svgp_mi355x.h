@@ -55,7 +55,7 @@ enum {
   SVGP_LIK_GAUSSIAN = 0,
   SVGP_LIK_BERNOULLI_LOGISTIC = 1,
   SVGP_LIK_POISSON_EXP = 2,      /* PoissonLikelihood(exp):      y ~ Poisson(exp f) */
-  SVGP_LIK_EXPONENTIAL_EXP = 3,  /* ExponentialLikelihood(exp):  y ~ Exponential(rate exp f) */
+  SVGP_LIK_EXPONENTIAL_EXP = 3,  /* ExponentialLikelihood(exp):  y ~ Exponential(scale exp f) = Gamma(1, scale exp f) */
   SVGP_LIK_GAMMA_EXP = 4         /* GammaLikelihood(alpha, exp): y ~ Gamma(shape alpha, scale exp f); alpha in lik_sigma2 */
 };
 

@@ -53,7 +53,7 @@ KERNEL_MATERN52 = 2
 LIK_GAUSSIAN = 0
 LIK_BERNOULLI_LOGISTIC = 1
 LIK_POISSON_EXP = 2
-LIK_EXPONENTIAL_EXP = 3  # ExponentialLikelihood(exp): y ~ Exponential(rate exp f)  [dep GPLikelihoods]
+LIK_EXPONENTIAL_EXP = 3  # ExponentialLikelihood(exp): y ~ Distributions.Exponential(θ = exp f), θ is the SCALE  [dep GPLikelihoods]
 LIK_GAMMA_EXP = 4        # GammaLikelihood(alpha, exp): y ~ Gamma(shape alpha, scale exp f); alpha passed as `sigma2`
 
 _SQRT3 = math.sqrt(3.0)
@@ -302,8 +302,8 @@ def loglik(lik: int, f: np.ndarray, y: np.ndarray, sigma2: float = 1.0) -> np.nd
         return -np.logaddexp(0.0, s)
     if lik == LIK_POISSON_EXP:
         return y * f - np.exp(f) - gammaln(y + 1.0)
-    if lik == LIK_EXPONENTIAL_EXP:   # logpdf(Exponential(scale = 1 / exp f), y)
-        return f - y * np.exp(f)
+    if lik == LIK_EXPONENTIAL_EXP:   # logpdf(Exponential(scale = exp f), y) = -f - y exp(-f)  (oracle/CONVENTIONS.md)
+        return -f - y * np.exp(-f)
     if lik == LIK_GAMMA_EXP:         # logpdf(Gamma(alpha, scale = exp f), y), alpha = sigma2
         return (sigma2 - 1.0) * np.log(y) - y * np.exp(-f) - sigma2 * f - gammaln(sigma2)
     raise ValueError("unknown likelihood")
@@ -331,7 +331,7 @@ def expected_loglik(
             v = sigma * sigma
             return float(np.sum(y * mu - np.exp(mu + 0.5 * v) - gammaln(y + 1.0)))
         if lik == LIK_EXPONENTIAL_EXP:
-            return float(np.sum(mu - y * np.exp(mu + 0.5 * sigma * sigma)))
+            return float(np.sum(-mu - y * np.exp(0.5 * sigma * sigma - mu)))
         if lik == LIK_GAMMA_EXP:
             return float(np.sum((sigma2 - 1.0) * np.log(y) - y * np.exp(0.5 * sigma * sigma - mu) - sigma2 * mu - gammaln(sigma2)))
         quadrature_n = DEFAULT_GH_POINTS
@@ -522,7 +522,7 @@ def synth_problem(
     elif lik == LIK_POISSON_EXP:
         y = rng.poisson(np.exp(np.sin(s))).astype(np.float64)
     elif lik == LIK_EXPONENTIAL_EXP:
-        y = rng.exponential(np.exp(-np.sin(s)))
+        y = rng.exponential(np.exp(np.sin(s)))   # numpy's argument is the scale, as Distributions.Exponential's
     else:
         sigma2 = 2.5  # the Gamma shape alpha travels in the likelihood-parameter slot
         y = rng.gamma(sigma2, np.exp(np.sin(s)))
@@ -558,7 +558,7 @@ def _dloglik(lik: int, f, y, sigma2):
     if lik == LIK_POISSON_EXP:
         return y - np.exp(f)
     if lik == LIK_EXPONENTIAL_EXP:
-        return 1.0 - y * np.exp(f)
+        return y * np.exp(-f) - 1.0
     return y * np.exp(-f) - sigma2
 
 
@@ -572,8 +572,8 @@ def expected_loglik_grads(lik, mu, v, y, sigma2=1.0, quadrature_n=0):
         e = np.exp(mu + 0.5 * v)
         return y - e, -0.5 * e, 0.0
     if quadrature_n == 0 and lik == LIK_EXPONENTIAL_EXP:
-        e = y * np.exp(mu + 0.5 * v)
-        return 1.0 - e, -0.5 * e, 0.0
+        e = y * np.exp(0.5 * v - mu)
+        return e - 1.0, -0.5 * e, 0.0
     if quadrature_n == 0 and lik == LIK_GAMMA_EXP:
         e = y * np.exp(0.5 * v - mu)
         return e - sigma2, -0.5 * e, float(np.sum(np.log(y) - mu - digamma(sigma2)))

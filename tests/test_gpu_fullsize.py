@@ -59,19 +59,25 @@ def test_full_size_subbatches_and_properties(ctx, name, N, M, d, family, lik, dt
 
 
 def test_c4_large_m_cholesky_dominated(ctx):
-    """C4: M = 8192, fp32.  Cholesky/T panels of a 268 MB Kuu; sub-batch against the oracle, logdet against LAPACK."""
-    N, M, d = 20_000, 8192, 8
+    """C4 at its BASELINE size: N = 1e5, M = 8192, fp32.  Cholesky/T panels of a 268 MB Kuu; sub-batches against the
+    oracle at the full M, logdet against LAPACK, additivity / repeatability over the full 1e5 points."""
+    N, M, d = 100_000, 8192, 8
     x, y, sva, s2 = o.synth_problem(4, N, M, d, dtype=np.float32)
     model = device_model(ctx, sva, dtype=np.float32, sigma2=s2)
     data = _ffi.DeviceData(ctx, x, y, np.float32)
     nb = 1000
-    ref = o.elbo_terms(sva, x[:, :nb], y[:nb], sigma2=s2, num_data=N)
-    val, t = model.elbo(data, 0, nb, float(N))
-    assert rel(val, ref.elbo) < 1e-4
-    Lk = o.posterior(sva).Lk
-    assert t.logdet_kuu == pytest.approx(2 * np.log(np.diag(Lk)).sum(), rel=1e-5)
+    post = o.posterior(sva)
+    for off in (0, 61_234, N - nb):
+        mu, sd = o.marginals(post, x[:, off:off + nb])
+        E = o.expected_loglik(o.LIK_GAUSSIAN, mu, sd, y[off:off + nb], s2)
+        ref = E * N / nb - o.prior_kl(sva)
+        val, t = model.elbo(data, off, nb, float(N))
+        assert rel(val, ref) < 1e-4, off
+    assert t.logdet_kuu == pytest.approx(2 * np.log(np.diag(post.Lk)).sum(), rel=1e-5)
     full = model.elbo_partial(data)
-    a, b = model.elbo_partial(data, 0, 9999), model.elbo_partial(data, 9999, N - 9999)
+    assert full[1] == N and full[2] == 0 and full[3] == 0
+    a, b = model.elbo_partial(data, 0, 49_999), model.elbo_partial(data, 49_999, N - 49_999)
     assert rel(a[0] + b[0], full[0]) < 1e-11
+    assert model.elbo_partial(data)[0] == full[0]
     model.free()
     data.free()

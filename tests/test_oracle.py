@@ -167,3 +167,75 @@ def test_exp_link_closed_forms_match_numerical_integration(lik):
         ref += quad(f, m_ - 12 * s_, m_ + 12 * s_, epsabs=1e-13, epsrel=1e-13, limit=400)[0]
     assert closed == pytest.approx(ref, rel=1e-10)
     assert closed == pytest.approx(o.expected_loglik(lik, mu, sd, y, sigma2=alpha, quadrature_n=40), rel=1e-12)
+
+
+def test_exponential_likelihood_is_scale_parametrised():
+    """GPLikelihoods: (l::ExponentialLikelihood)(f) = Exponential(l.invlink(f)) and Distributions.Exponential(θ) has SCALE θ,
+    pdf (1/θ) exp(-y/θ): log p(y|f) = -f - y exp(-f), the Gamma likelihood (shape α, scale exp f) at α = 1, and the
+    AnalyticExpectation is -μ - y exp(v/2 - μ).  Checked against scipy.stats (an independent implementation of both
+    distributions) and between likelihood codes 3 and 4."""
+    from scipy import stats
+
+    rng = np.random.default_rng(11)
+    f = rng.standard_normal(50)
+    y = rng.exponential(np.exp(f))
+    np.testing.assert_allclose(o.loglik(o.LIK_EXPONENTIAL_EXP, f, y), stats.expon(scale=np.exp(f)).logpdf(y), rtol=1e-13)
+    np.testing.assert_allclose(o.loglik(o.LIK_GAMMA_EXP, f, y, 1.0), o.loglik(o.LIK_EXPONENTIAL_EXP, f, y), rtol=1e-13, atol=1e-15)
+    np.testing.assert_allclose(o.loglik(o.LIK_GAMMA_EXP, f, y, 2.5), stats.gamma(a=2.5, scale=np.exp(f)).logpdf(y), rtol=1e-12)
+    k = rng.poisson(np.exp(f)).astype(float)
+    np.testing.assert_allclose(o.loglik(o.LIK_POISSON_EXP, f, k), stats.poisson(np.exp(f)).logpmf(k), rtol=1e-12)
+    b = (rng.random(50) < 0.5).astype(float)
+    np.testing.assert_allclose(o.loglik(o.LIK_BERNOULLI_LOGISTIC, f, b), stats.bernoulli(1 / (1 + np.exp(-f))).logpmf(b), rtol=1e-12)
+    np.testing.assert_allclose(o.loglik(o.LIK_GAUSSIAN, f, y, 0.3), stats.norm(f, np.sqrt(0.3)).logpdf(y), rtol=1e-12)
+    mu, sd = rng.standard_normal(50) * 0.5, 0.3 + rng.random(50)
+    for qn in (0, 30):
+        assert o.expected_loglik(o.LIK_EXPONENTIAL_EXP, mu, sd, y, 1.0, qn) == pytest.approx(
+            o.expected_loglik(o.LIK_GAMMA_EXP, mu, sd, y, 1.0, qn), rel=1e-13)
+    ge, gg = (o.expected_loglik_grads(l, mu, sd**2, y, 1.0, 0) for l in (o.LIK_EXPONENTIAL_EXP, o.LIK_GAMMA_EXP))
+    np.testing.assert_allclose(ge[0], gg[0], rtol=1e-13)
+    np.testing.assert_allclose(ge[1], gg[1], rtol=1e-13)
+
+
+def test_golden_fixtures_are_the_oracle():
+    """tests/golden/*.npz (generated by tests/golden/make_golden.py) still equal the oracle: a regression guard for
+    the oracle itself (the HIP library is compared with the same files on the GPU)."""
+    import glob
+    import os
+
+    paths = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz")))
+    assert len(paths) >= 10
+    for path in paths:
+        g = np.load(path)
+        kernel = o.Kernel(int(g["family"]), float(g["variance"]), g["inv_lengthscale"])
+        sva = o.SVA(kernel, g["z"], g["m"], g["Lq"], jitter=float(g["jitter"]), mean_const=float(g["mean_const"]),
+                    centered=bool(int(g["centered"])))
+        nd = float(g["num_data"])
+        t = o.elbo_terms(sva, g["x"], g["y"], lik=int(g["lik"]), sigma2=float(g["sigma2"]), num_data=nd if nd > 0 else None,
+                         quadrature_n=int(g["quadrature_n"]))
+        assert t.elbo == pytest.approx(float(g["elbo"]), rel=1e-12), path
+        assert t.kl == pytest.approx(float(g["kl"]), rel=1e-12)
+        _, gr = o.elbo_grad(sva, g["x"], g["y"], lik=int(g["lik"]), sigma2=float(g["sigma2"]), num_data=nd if nd > 0 else None,
+                            quadrature_n=int(g["quadrature_n"]))
+        np.testing.assert_allclose(gr["Lq"], g["g_Lq"], rtol=1e-9, atol=1e-10)
+        np.testing.assert_allclose(gr["z"], g["g_z"], rtol=1e-9, atol=1e-10)
+
+
+def test_kl_matches_scipy():
+    """Distributions.kldivergence(q, fz) (SVA:362) and the NonCentered closed form (SVA:364-373) against scipy.stats:
+    KL(q || p) = -H(q) - E_q[log p] with H(q) from multivariate_normal.entropy() and
+    E_q[log p] = log p(mean(q)) - tr(inv(cov p) cov q) / 2."""
+    from scipy import stats
+
+    x, y, nc, s2 = o.synth_problem(21, 30, 9, 2)
+    M = nc.M
+    # Centered: p = N(mean_const, Kuu + jitter I), q = N(m, Lq Lq')
+    c = o.SVA(nc.kernel, nc.z, 0.3 + nc.m, 0.7 * nc.Lq, jitter=nc.jitter, mean_const=0.3, centered=True)
+    Kuu = o.kuu(c)
+    S = c.Lq @ c.Lq.T
+    kl_ref = (-stats.multivariate_normal(c.m, S).entropy() - stats.multivariate_normal(np.full(M, 0.3), Kuu).logpdf(c.m)
+              + 0.5 * np.trace(np.linalg.solve(Kuu, S)))
+    assert o.prior_kl(c) == pytest.approx(kl_ref, rel=1e-10)
+    # NonCentered: p = N(0, I)
+    Sn = nc.Lq @ nc.Lq.T
+    kl_nc = -stats.multivariate_normal(nc.m, Sn).entropy() - stats.multivariate_normal(np.zeros(M), np.eye(M)).logpdf(nc.m) + 0.5 * np.trace(Sn)
+    assert o.prior_kl(nc) == pytest.approx(kl_nc, rel=1e-10)
