@@ -77,7 +77,25 @@ SYMBOLS = {
     "svgp_predict_cross_cov": (C.c_int32, [_P, _P, C.c_int32, C.c_int64, _P, C.c_int64, _P, _P]),
     "svgp_kuf": (C.c_int32, [_P, _P, _P, C.c_int64, C.c_int64, _P]),
     "svgp_gausshermite": (C.c_int32, [C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    # multi-GPU
+    "svgp_comm_unique_id": (C.c_int32, [_P]),
+    "svgp_ctx_attach_comm": (C.c_int32, [_P, _P, C.c_int32, C.c_int32]),
+    "svgp_ctx_detach_comm": (C.c_int32, [_P]),
+    "svgp_ctx_comm_info": (C.c_int32, [_P, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "svgp_group_create": (C.c_int32, [C.c_int32, C.POINTER(C.c_int32), C.POINTER(_P)]),
+    "svgp_group_destroy": (C.c_int32, [_P]),
+    "svgp_group_size": (C.c_int32, [_P]),
+    "svgp_group_ctx": (_P, [_P, C.c_int32]),
+    "svgp_group_last_error": (C.c_char_p, [_P]),
+    "svgp_group_data_upload": (C.c_int32, [_P, C.c_int32, C.c_int32, C.c_int32, C.c_int64, _P, _P, C.POINTER(_P)]),
+    "svgp_group_model_create": (C.c_int32, [_P, C.POINTER(ModelDesc), C.POINTER(_P)]),
+    "svgp_group_model_update": (C.c_int32, [_P, C.POINTER(_P), C.POINTER(ModelDesc)]),
+    "svgp_group_elbo": (C.c_int32, [_P, C.POINTER(_P), C.POINTER(_P), C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_double,
+                                    C.POINTER(C.c_double), C.POINTER(Terms)]),
+    "svgp_group_elbo_grad": (C.c_int32, [_P, C.POINTER(_P), C.POINTER(_P), C.POINTER(C.c_int64), C.POINTER(C.c_int64),
+                                         C.c_double, C.POINTER(C.c_double), C.POINTER(Terms), C.POINTER(Grads)]),
 }
+COMM_ID_BYTES = 128
 
 _lib = None
 
@@ -182,6 +200,32 @@ class Context:
         t = Timing()
         self.lib.svgp_last_timing(self.h, C.byref(t))
         return t
+
+    # ---- multi-GPU: one process per GPU (include/svgp_mi355x.h "multi-GPU") ----
+    def attach_comm(self, comm_id: bytes, world_size: int, rank: int):
+        """Collective over all ranks (ncclCommInitRank).  Afterwards DeviceModel.elbo / elbo_grad on this context are
+        collective and return the GLOBAL ELBO; elbo_partial / elbo_grad(shard=...) stay local."""
+        if len(comm_id) != COMM_ID_BYTES:
+            raise ValueError("communicator id must be SVGP_COMM_ID_BYTES long")
+        buf = C.create_string_buffer(bytes(comm_id), COMM_ID_BYTES)
+        self.check(self.lib.svgp_ctx_attach_comm(self.h, C.cast(buf, C.c_void_p), world_size, rank))
+
+    def detach_comm(self):
+        self.check(self.lib.svgp_ctx_detach_comm(self.h))
+
+    def comm_info(self):
+        w, r = C.c_int32(), C.c_int32()
+        self.lib.svgp_ctx_comm_info(self.h, C.byref(w), C.byref(r))
+        return w.value, r.value
+
+
+def comm_unique_id() -> bytes:
+    """ncclGetUniqueId through the library (rank 0 calls it; the host transports the bytes to the other ranks)."""
+    buf = C.create_string_buffer(COMM_ID_BYTES)
+    rc = load_library().svgp_comm_unique_id(C.cast(buf, C.c_void_p))
+    if rc != OK:
+        raise SvgpError(f"svgp_comm_unique_id failed with status {rc} (is librccl loadable?)")
+    return buf.raw
 
 
 _default_ctx: Context | None = None
@@ -385,3 +429,112 @@ def gausshermite(n: int):
     if rc != OK:
         raise ValueError(f"svgp_gausshermite({n}) failed with status {rc}")
     return xs, ws
+
+
+class _Borrowed:
+    """A member context of a Group seen through the Context interface (the group owns and destroys it)."""
+
+    check = Context.check
+    timing = Context.timing
+    comm_info = Context.comm_info
+
+    def __init__(self, lib, h, device):
+        self.lib, self.h, self.device = lib, C.c_void_p(h), device
+
+
+class Group:
+    """One process driving several GPUs (svgp_group_*): data sharded over the members, the model replicated, and
+    elbo / elbo_grad evaluated on all of them with one RCCL all-reduce issued by the library."""
+
+    def __init__(self, device_ids):
+        self.lib = load_library()
+        ids = (C.c_int32 * len(device_ids))(*device_ids)
+        h = C.c_void_p()
+        rc = self.lib.svgp_group_create(len(device_ids), ids, C.byref(h))
+        if rc != OK:
+            raise SvgpError(f"svgp_group_create failed with status {rc}")
+        self.h, self.n = h, len(device_ids)
+        self.members = [_Borrowed(self.lib, self.lib.svgp_group_ctx(h, i), device_ids[i]) for i in range(self.n)]
+        self._data, self._models = None, None
+
+    def _check(self, rc, terms=None):
+        if rc == OK:
+            return
+        msg = (self.lib.svgp_group_last_error(self.h) or b"").decode()
+        if rc == INVALID_ARG:
+            raise ValueError(msg)
+        if rc == NOT_POSDEF:
+            raise PosDefException(terms.chol_info if terms is not None else -1, msg)
+        if rc == NEG_VARIANCE:
+            raise DomainError(msg)
+        raise SvgpError(f"status {rc}: {msg}")
+
+    def upload(self, x, y, dtype, layout=COLVECS):
+        dt = np_dtype(dtype_code(dtype))
+        x = np.asarray(x, dtype=dt)
+        if x.ndim == 1:
+            layout, d, n, xb = VEC, 1, x.shape[0], np.ascontiguousarray(x)
+        elif layout == COLVECS:
+            (d, n), xb = x.shape, np.asfortranarray(x)
+        else:
+            (n, d), xb = x.shape, np.asfortranarray(x)
+        yb = np.ascontiguousarray(np.asarray(y, dtype=dt))
+        arr = (C.c_void_p * self.n)()
+        self._check(self.lib.svgp_group_data_upload(self.h, dtype_code(dt), layout, d, n, _ptr(xb), _ptr(yb), arr))
+        self._data = arr
+        base, rem = divmod(n, self.n)
+        self.shard_sizes = [base + (1 if i < rem else 0) for i in range(self.n)]
+        return arr
+
+    def create_model(self, desc, keep):
+        arr = (C.c_void_p * self.n)()
+        self._check(self.lib.svgp_group_model_create(self.h, C.byref(desc), arr))
+        self._models, self._M, self._d, self._dtype = arr, desc.M, desc.d, desc.dtype
+        del keep
+        return arr
+
+    def update_model(self, desc, keep):
+        self._check(self.lib.svgp_group_model_update(self.h, self._models, C.byref(desc)))
+        del keep
+
+    def _ranges(self, offs, lens):
+        offs = [0] * self.n if offs is None else list(offs)
+        lens = [s - o for s, o in zip(self.shard_sizes, offs)] if lens is None else list(lens)
+        return (C.c_int64 * self.n)(*offs), (C.c_int64 * self.n)(*lens)
+
+    def elbo(self, offs=None, lens=None, num_data=0.0):
+        o, l = self._ranges(offs, lens)
+        out, terms = C.c_double(), Terms()
+        self._check(self.lib.svgp_group_elbo(self.h, self._models, self._data, o, l, float(num_data), C.byref(out), C.byref(terms)), terms)
+        return out.value, terms
+
+    def elbo_grad(self, offs=None, lens=None, num_data=0.0):
+        o, l = self._ranges(offs, lens)
+        dt = np_dtype(self._dtype)
+        il = np.zeros(self._d)
+        zb = np.zeros((self._M,) if self._d == 1 else (self._d, self._M), dtype=dt, order="F")
+        mb = np.zeros(self._M, dtype=dt)
+        Lb = np.zeros((self._M, self._M), dtype=dt, order="F")
+        g = Grads(0.0, 0.0, 0.0, il.ctypes.data_as(C.POINTER(C.c_double)), _ptr(zb), _ptr(mb), _ptr(Lb))
+        out, terms = C.c_double(), Terms()
+        self._check(self.lib.svgp_group_elbo_grad(self.h, self._models, self._data, o, l, float(num_data), C.byref(out),
+                                                  C.byref(terms), C.byref(g)), terms)
+        return out.value, terms, dict(variance=g.variance, lik_sigma2=g.lik_sigma2, mean_const=g.mean_const,
+                                      inv_lengthscale=il, z=zb, m=mb, Lq=Lb)
+
+    def close(self):
+        if getattr(self, "h", None):
+            for i in range(self.n):
+                if self._models is not None:
+                    self.lib.svgp_model_free(self.members[i].h, self._models[i])
+                if self._data is not None:
+                    self.lib.svgp_data_free(self.members[i].h, self._data[i])
+            self._models = self._data = None
+            self.lib.svgp_group_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

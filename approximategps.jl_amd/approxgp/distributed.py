@@ -1,8 +1,14 @@
 """Data-parallel ELBO: the expectation term Σ_i E_q[log p(y_i|f_i)] is a plain sum over points
 (SVA:355-359), so each rank evaluates its own shard / minibatch with the HIP library and ONE
-all-reduce (RCCL over xGMI on GPUs; gloo in the CPU tests) combines {ΣE, n, n_neg, chol_info};
-the M-sized work (Kuu, Cholesky, KL) is replicated and the KL is subtracted once after the reduce.
-Pure host logic: nothing here computes a partial sum itself."""
+all-reduce combines {ΣE, n, n_neg, status flags}; the M-sized work (Kuu, Cholesky, KL) is replicated
+and the KL is subtracted once after the reduce.
+
+The collective lives INSIDE the library (csrc/comm.hip): `attach_comm_via_torch` hands every rank's context one
+rank of an RCCL communicator, after which `DeviceModel.elbo` / `elbo_grad` are collective — ncclAllReduce on the
+device-resident result vector, on the context's stream, no host hop.  torch.distributed is used once, to carry the
+128-byte communicator id from rank 0 to the others.  The host-side path below (`allreduce_partials` + `combine`, any
+torch.distributed backend) remains for hosts that run their own collective and for the gloo CPU tests of the
+combination rule.  Pure host logic: nothing here computes a partial sum itself."""
 from __future__ import annotations
 
 import numpy as np
@@ -15,6 +21,20 @@ def shard_range(n: int, rank: int, world: int):
     base, rem = divmod(n, world)
     lo = rank * base + min(rank, rem)
     return lo, lo + base + (1 if rank < rem else 0)
+
+
+def attach_comm_via_torch(ctx, group=None):
+    """Give `ctx` its rank of a library-owned RCCL communicator spanning the torch.distributed world (one process per GPU).
+    Rank 0 draws the id with svgp_comm_unique_id, torch.distributed broadcasts the 128 bytes, every rank attaches."""
+    import torch.distributed as dist
+
+    from . import _ffi
+
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    box = [_ffi.comm_unique_id() if rank == 0 else None]
+    dist.broadcast_object_list(box, src=0, group=group)
+    ctx.attach_comm(box[0], world, rank)
+    return world, rank
 
 
 def allreduce_partials(partial, group=None, device=None):
@@ -32,9 +52,11 @@ def allreduce_partials(partial, group=None, device=None):
 
 def combine(total, kl: float, num_data: float):
     """ELBO = ΣE · num_data / n_global − KL  (SVA:357-359) from the all-reduced vector."""
-    sum_e, n_global, n_neg, bad_chol = (float(v) for v in total)
+    sum_e, n_global, n_neg, bad_chol = (float(v) for v in total[:4])
     if bad_chol > 0:
         raise ArithmeticError("Kuu was not positive definite on at least one rank")
+    if len(total) > 4 and float(total[4]) > 0:
+        raise RuntimeError("a rank failed before the collective")
     if n_global <= 0:
         raise ValueError("empty global batch")
     return sum_e * (float(num_data) / n_global) - kl
@@ -67,18 +89,49 @@ def allreduce_value_and_gradient(value, grads, group=None, device=None):
 
 class ShardedELBO:
     """One rank's view of a minibatched, data-parallel ELBO (config C5): holds this rank's shard of the
-    data on its GPU and evaluates `batch` points per step starting at a rotating offset."""
+    data on its GPU and evaluates `batch` points per step starting at a rotating offset.
+
+    With a communicator on the model's context (`attach_comm_via_torch`) the steps are the library's collective
+    svgp_elbo / svgp_elbo_grad.  Without one they fall back to the host-side combination: every rank then reaches the
+    all-reduce even when its own evaluation raised (the error travels in the reduced vector and is raised on all ranks
+    together, so nobody is left waiting inside the collective)."""
 
     def __init__(self, model, data, num_data: float, group=None, device=None):
         self.model, self.data, self.num_data, self.group, self.device = model, data, float(num_data), group, device
+        info = getattr(getattr(model, "ctx", None), "comm_info", None)
+        self.in_library = bool(info and info()[0] > 1) or bool(getattr(model, "force_in_library", False))
 
     def step(self, off: int, length: int):
-        partial = self.model.elbo_partial(self.data, off, length)
-        kl, _ = self.model.prior_kl()
-        total = allreduce_partials(partial, self.group, self.device)
+        if self.in_library:
+            return self.model.elbo(self.data, off, length, self.num_data)[0]
+        err, kl, partial = None, 0.0, np.zeros(4)
+        try:
+            partial = self.model.elbo_partial(self.data, off, length)
+            kl, _ = self.model.prior_kl()
+        except Exception as e:   # noqa: BLE001 - re-raised after the collective
+            err = e
+        vec = [partial[0], partial[1], partial[2], partial[3], 0.0 if err is None else 1.0]
+        total = allreduce_partials5(vec, self.group, self.device)
+        if err is not None:
+            raise err
         return combine(total, kl, self.num_data)
 
     def step_grad(self, off: int, length: int, n_global: int, world: int):
         """Value and gradient of the global minibatch ELBO; `n_global` = total points all ranks evaluate this step."""
+        if self.in_library:
+            val, _, g = self.model.elbo_grad(self.data, off, length, self.num_data)
+            return val, g
         val, _, g = self.model.elbo_grad(self.data, off, length, shard=(self.num_data / n_global, 1.0 / world))
         return allreduce_value_and_gradient(val, g, self.group, self.device)
+
+
+def allreduce_partials5(vec, group=None, device=None):
+    """{ΣE, n_points, n_neg_var, chol flag, failure flag} summed over ranks (host-side path)."""
+    import torch
+    import torch.distributed as dist
+
+    t = torch.tensor([vec[0], vec[1], vec[2], 1.0 if vec[3] != 0 else 0.0, vec[4]], dtype=torch.float64,
+                     device=device if device is not None else "cpu")
+    if dist.is_available() and dist.is_initialized():
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    return t.cpu().numpy()

@@ -11,104 +11,13 @@
 #include <vector>
 
 #include "../../include/svgp_mi355x.h"
+#include "ctx.hpp"
 #include "kernels.hpp"
 #include "lik.hpp"
 
 using namespace svgp;
 
-// ------------------------------------------------------------------------------------------------
-struct svgp_ctx {
-  int device = 0;
-  hipStream_t stream = nullptr;
-  bool own_stream = false;
-  int num_cus = 256;
-  std::string err;
-  svgp_timing timing{};
-  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};  // start, prep done, strip done, all done
-  // growable scratch
-  void* work = nullptr;       size_t work_bytes = 0;
-  double* partial = nullptr;  unsigned* negcnt = nullptr;  // [1024] per-block sums of the expectation kernel
-  double* mom = nullptr;      size_t mom_cap = 0;           // [2][mom_cap] per-point mean / variance
-  double* d_res = nullptr;    // [8] device results
-  unsigned* counter = nullptr; // strip queue head of the running strip launch
-  void* kuf_buf = nullptr;    size_t kuf_bytes = 0;
-  struct GradWs* gws = nullptr;  // gradient workspace, cached by problem shape
-};
-
-// device buffers of svgp_elbo_grad, sized by (dtype, Mp, d, nc)
-struct GradWs {
-  int dtype = -1, d = 0, nslices = 1, ns_uf = 1, ns_uu = 1, rb = 1;
-  int64_t Mp = 0, nc = 0;
-  std::vector<void*> all;
-  void *A = nullptr, *C = nullptr, *Ab = nullptr, *At = nullptr, *Ct = nullptr, *Pt = nullptr, *gmu = nullptr, *gv = nullptr;
-  void *Lqp = nullptr, *S = nullptr, *G1 = nullptr, *G2 = nullptr, *LkRM = nullptr, *LbarRM = nullptr, *Phi = nullptr,
-       *tmp = nullptr, *H = nullptr, *zbar = nullptr, *mbar = nullptr, *Lqbar = nullptr, *BbarRM = nullptr, *rbar = nullptr;
-  double *rp_uf = nullptr, *sp_uf = nullptr, *rp_uu = nullptr, *sp_uu = nullptr, *partial5 = nullptr, *sums = nullptr,
-         *invl_d = nullptr, *scal_out = nullptr;
-  size_t rp_uf_b = 0, sp_uf_b = 0, rp_uu_b = 0, sp_uu_b = 0, g_b = 0;
-  void release() {
-    for (void* p : all)
-      if (p) (void)hipFree(p);
-    all.clear();
-  }
-};
-
-struct svgp_data {
-  int dtype = 0, d = 0;
-  int64_t n = 0, ldx = 0;
-  void* x = nullptr;  // feature-major [d][ldx]
-  void* y = nullptr;
-  bool own = true;
-};
-
-struct svgp_model {
-  svgp_model_desc desc{};
-  std::vector<double> invl_host;
-  int64_t M = 0, Mp = 0;
-  int dtype = 0, d = 0;
-  size_t es = 8;
-  void *z_raw = nullptr, *m_raw = nullptr, *Lq_raw = nullptr;  // user layout
-  void *invl = nullptr, *zs = nullptr, *L = nullptr, *T = nullptr, *U = nullptr, *mp = nullptr, *B = nullptr;
-  double* scal = nullptr;  // [8 + Mp]
-  int* info = nullptr;
-  double *gh_x = nullptr, *gh_w = nullptr;
-  int gh_n = 0;
-  bool prepared = false;
-  // host copies of the last prep's scalars
-  double kl = 0, logdet_kuu = 0;
-  int chol_info = 0;
-};
-
 namespace {
-
-#define HIPC(ctx, call)                                                                            \
-  do {                                                                                             \
-    hipError_t e_ = (call);                                                                        \
-    if (e_ != hipSuccess) {                                                                        \
-      (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e_);                              \
-      return (e_ == hipErrorOutOfMemory) ? SVGP_OOM : SVGP_HIP_ERROR;                              \
-    }                                                                                              \
-  } while (0)
-
-// SVGP_DEBUG_SYNC=1: synchronise and check after every kernel launch, naming the offender.
-bool debug_sync() {
-  static const bool on = [] { const char* e = getenv("SVGP_DEBUG_SYNC"); return e && e[0] == '1'; }();
-  return on;
-}
-#define KCHECK(ctx, name)                                                                          \
-  do {                                                                                             \
-    hipError_t e_ = hipGetLastError();                                                             \
-    if (e_ == hipSuccess && debug_sync()) e_ = hipStreamSynchronize((ctx)->stream);                \
-    if (e_ != hipSuccess) {                                                                        \
-      (ctx)->err = std::string("kernel ") + name + ": " + hipGetErrorString(e_);                   \
-      return SVGP_HIP_ERROR;                                                                       \
-    }                                                                                              \
-  } while (0)
-
-int fail(svgp_ctx* ctx, int code, const std::string& msg) {
-  if (ctx) ctx->err = msg;
-  return code;
-}
 
 size_t esize(int dtype) { return dtype == SVGP_F64 ? 8 : 4; }
 
@@ -399,7 +308,7 @@ int enqueue_strips(svgp_ctx* ctx, svgp_model* m, const void* x, int64_t ldx, con
   if (o.skip_expect) return SVGP_OK;
   launch_expect(m->dtype, ctx->stream, lp, a.mom_mu, a.mom_var, y, off, len, ctx->partial, ctx->negcnt, o.mu, o.var);
   KCHECK(ctx, "expect");
-  launch_final_reduce(ctx->stream, ctx->partial, ctx->negcnt, expect_blocks(len), ctx->d_res);
+  launch_final_reduce(ctx->stream, ctx->partial, ctx->negcnt, expect_blocks(len), m->info, double(len), ctx->d_res);
   KCHECK(ctx, "final_reduce");
   ctx->timing.strip_launches = (plan.grid ? 1 : 0) + (plan.nt_tail ? 1 : 0);
   HIPC(ctx, hipGetLastError());
@@ -416,8 +325,14 @@ int check_batch(svgp_ctx* ctx, const svgp_model* m, const svgp_data* data, int64
   return SVGP_OK;
 }
 
-// prep + strips + readback; returns E, n_neg, and refreshes the model's prep scalars
-int run_elbo(svgp_ctx* ctx, svgp_model* m, const svgp_data* data, int64_t off, int64_t len, double* E, double* nneg) {
+// One evaluation = three stages, so that a process driving several GPUs (svgp_group_*) can enqueue every device before
+// it waits for any:  elbo_enqueue (prep + strips + reduce, asynchronous)  ->  elbo_collective (ONE ncclAllReduce of the
+// device-resident 8-vector d_res on the context's stream; nothing without a communicator)  ->  elbo_finish (read back).
+struct ElboRead {
+  double E = 0, n_points = 0, n_neg = 0, bad_chol = 0, failed = 0;
+};
+
+int elbo_enqueue(svgp_ctx* ctx, svgp_model* m, const svgp_data* data, int64_t off, int64_t len) {
   hipStream_t s = ctx->stream;
   HIPC(ctx, hipSetDevice(ctx->device));
   HIPC(ctx, hipEventRecord(ctx->ev[0], s));
@@ -427,7 +342,36 @@ int run_elbo(svgp_ctx* ctx, svgp_model* m, const svgp_data* data, int64_t off, i
   rc = enqueue_strips(ctx, m, data->x, data->ldx, data->y, off, len, StripOuts{});
   if (rc) return rc;
   HIPC(ctx, hipEventRecord(ctx->ev[3], s));
-  double res[2];
+  return SVGP_OK;
+}
+
+// `local_rc` is the status of this rank's enqueue: a rank that failed still takes part in the collective, with its
+// failure flag set, so that its peers return an error instead of waiting for it forever (they all see failed > 0).
+int elbo_collective(svgp_ctx* ctx, int local_rc) {
+  if (!ctx->comm) return local_rc;
+  if (local_rc != SVGP_OK) {
+    const std::string keep = ctx->err;
+    static const double poison[8] = {0, 0, 0, 0, 1, 0, 0, 0};
+    if (hipSetDevice(ctx->device) != hipSuccess ||
+        hipMemcpyAsync(ctx->d_res, poison, sizeof poison, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) {
+      comm_abort(ctx);
+      ctx->err = keep;
+      return local_rc;
+    }
+    ctx->err = keep;
+  }
+  const int rc = comm_allreduce(ctx, ctx->d_res, 8, SVGP_F64);
+  if (rc != SVGP_OK) {
+    comm_abort(ctx);
+    return local_rc != SVGP_OK ? local_rc : rc;
+  }
+  return local_rc;
+}
+
+int elbo_finish(svgp_ctx* ctx, svgp_model* m, ElboRead* out) {
+  hipStream_t s = ctx->stream;
+  HIPC(ctx, hipSetDevice(ctx->device));
+  double res[5];
   PrepScalars ps;
   HIPC(ctx, hipMemcpyAsync(res, ctx->d_res, sizeof(res), hipMemcpyDeviceToHost, s));
   HIPC(ctx, hipMemcpyAsync(ps.scal, m->scal, sizeof(ps.scal), hipMemcpyDeviceToHost, s));
@@ -443,13 +387,26 @@ int run_elbo(svgp_ctx* ctx, svgp_model* m, const svgp_data* data, int64_t off, i
   ctx->timing.ms_expect = t23;
   ctx->timing.ms_total = t01 + t12 + t23;
   ctx->timing.ms_kuf = 0;
-  *E = res[0];
-  *nneg = res[1];
+  out->E = res[0];
+  out->n_points = res[1];
+  out->n_neg = res[2];
+  out->bad_chol = res[3];
+  out->failed = res[4];
   return SVGP_OK;
 }
 
-int status_of(svgp_ctx* ctx, const svgp_model* m, double nneg) {
-  if (m->chol_info != 0) {
+// prep + strips (+ collective) + readback; refreshes the model's prep scalars
+int run_elbo(svgp_ctx* ctx, svgp_model* m, const svgp_data* data, int64_t off, int64_t len, bool collective, ElboRead* out) {
+  int rc = elbo_enqueue(ctx, m, data, off, len);
+  if (collective) rc = elbo_collective(ctx, rc);
+  if (rc) return rc;
+  return elbo_finish(ctx, m, out);
+}
+
+int status_of(svgp_ctx* ctx, const svgp_model* m, double nneg, double bad_chol = 0, double failed = 0) {
+  if (failed > 0)
+    return fail(ctx, SVGP_RCCL_ERROR, "a peer rank failed before the collective; the data-parallel evaluation was abandoned on every rank");
+  if (m->chol_info != 0 || bad_chol > 0) {
     char buf[160];
     snprintf(buf, sizeof buf, "Kuu is not positive definite: leading minor of order %d (PosDefException)", m->chol_info);
     return fail(ctx, SVGP_NOT_POSDEF, buf);
@@ -549,7 +506,7 @@ int32_t svgp_ctx_create(int32_t device_id, void* stream, svgp_ctx** out) {
   }
   for (auto& e : c->ev)
     if (hipEventCreate(&e) != hipSuccess) { delete c; return SVGP_HIP_ERROR; }
-  if (hipMalloc(&c->d_res, 8 * sizeof(double)) != hipSuccess || hipMalloc(&c->counter, 64) != hipSuccess || hipMalloc(&c->partial, 1024 * sizeof(double)) != hipSuccess ||
+  if (hipMalloc(&c->d_res, 8 * sizeof(double)) != hipSuccess || hipMalloc(&c->d_coll, 8 * sizeof(double)) != hipSuccess || hipMalloc(&c->counter, 64) != hipSuccess || hipMalloc(&c->partial, 1024 * sizeof(double)) != hipSuccess ||
       hipMalloc(&c->negcnt, 1024 * sizeof(unsigned)) != hipSuccess) { delete c; return SVGP_OOM; }
   *out = c;
   return SVGP_OK;
@@ -563,7 +520,9 @@ int32_t svgp_ctx_destroy(svgp_ctx* c) {
   if (c->partial) (void)hipFree(c->partial);
   if (c->negcnt) (void)hipFree(c->negcnt);
   if (c->mom) (void)hipFree(c->mom);
+  if (c->comm) (void)svgp_ctx_detach_comm(c);
   if (c->d_res) (void)hipFree(c->d_res);
+  if (c->d_coll) (void)hipFree(c->d_coll);
   if (c->counter) (void)hipFree(c->counter);
   if (c->kuf_buf) (void)hipFree(c->kuf_buf);
   if (c->gws) { c->gws->release(); delete c->gws; }
@@ -683,37 +642,45 @@ int32_t svgp_elbo_partial(svgp_ctx* ctx, svgp_model* m, const svgp_data* data, i
   int rc = check_batch(ctx, m, data, off, len, true);
   if (rc) return rc;
   if (!partial_out) return fail(ctx, SVGP_INVALID_ARG, "null output");
-  double E = 0, nneg = 0;
-  rc = run_elbo(ctx, m, data, off, len, &E, &nneg);
+  ElboRead r;
+  rc = run_elbo(ctx, m, data, off, len, false, &r);   // always local: no collective
   if (rc) return rc;
-  partial_out[0] = E;
+  partial_out[0] = r.E;
   partial_out[1] = double(len);
-  partial_out[2] = nneg;
+  partial_out[2] = r.n_neg;
   partial_out[3] = double(m->chol_info);
-  return status_of(ctx, m, nneg);
+  return status_of(ctx, m, r.n_neg);
 }
 
+namespace {
+void fill_terms(svgp_terms* t, const svgp_model* m, double elbo, const ElboRead& r, double scale) {
+  if (!t) return;
+  t->elbo = elbo;
+  t->expectation = r.E;
+  t->kl = m->kl;
+  t->scale = scale;
+  t->logdet_kuu = m->logdet_kuu;
+  t->n_points = int64_t(r.n_points);
+  t->n_neg_var = int64_t(r.n_neg);
+  t->chol_info = m->chol_info;
+  t->reserved = 0;
+}
+}  // namespace
+
+// With a communicator attached (svgp_ctx_attach_comm / svgp_group_create) this call is COLLECTIVE: every rank passes
+// its own shard's batch, the ranks' {sum E, n, n_neg, flags} are summed by one ncclAllReduce on the device, and every
+// rank returns the same global ELBO = sum E * num_data / n_global - KL (SVA:355-359; the KL is replicated, not summed).
 int32_t svgp_elbo(svgp_ctx* ctx, svgp_model* m, const svgp_data* data, int64_t off, int64_t len, double num_data,
                   double* elbo_out, svgp_terms* terms_out) {
   int rc = check_batch(ctx, m, data, off, len, true);
+  if (rc) return (ctx && ctx->comm) ? elbo_collective(ctx, rc) : rc;   // keep the peers' collective matched
+  ElboRead r;
+  rc = run_elbo(ctx, m, data, off, len, true, &r);
   if (rc) return rc;
-  double E = 0, nneg = 0;
-  rc = run_elbo(ctx, m, data, off, len, &E, &nneg);
-  if (rc) return rc;
-  const double scale = (num_data > 0 ? num_data : double(len)) / double(len);  // SVA:357-358
-  const double elbo = E * scale - m->kl;                                        // SVA:359
-  if (terms_out) {
-    terms_out->elbo = elbo;
-    terms_out->expectation = E;
-    terms_out->kl = m->kl;
-    terms_out->scale = scale;
-    terms_out->logdet_kuu = m->logdet_kuu;
-    terms_out->n_points = len;
-    terms_out->n_neg_var = (int64_t)nneg;
-    terms_out->chol_info = m->chol_info;
-    terms_out->reserved = 0;
-  }
-  rc = status_of(ctx, m, nneg);
+  const double scale = (num_data > 0 ? num_data : r.n_points) / r.n_points;   // SVA:357-358
+  const double elbo = r.E * scale - m->kl;                                     // SVA:359
+  fill_terms(terms_out, m, elbo, r, scale);
+  rc = status_of(ctx, m, r.n_neg, r.bad_chol, r.failed);
   if (elbo_out) *elbo_out = (rc == SVGP_OK) ? elbo : NAN;
   return rc;
 }
@@ -927,8 +894,7 @@ int grad_workspace(svgp_ctx* ctx, svgp_model* m, int64_t len, GradWs** out) {
       {&w->LbarRM, mm}, {&w->Phi, mm}, {&w->tmp, mm}, {&w->H, mm}, {&w->zbar, size_t(m->M) * m->d * es},
       {&w->mbar, size_t(m->M) * es}, {&w->Lqbar, size_t(m->M) * m->M * es}, {&w->BbarRM, mm}, {&w->rbar, size_t(Mp) * es}, {(void**)&w->rp_uf, w->rp_uf_b},
       {(void**)&w->sp_uf, w->sp_uf_b}, {(void**)&w->rp_uu, w->rp_uu_b}, {(void**)&w->sp_uu, w->sp_uu_b},
-      {(void**)&w->partial5, 1024 * 5 * 8}, {(void**)&w->sums, 8 * 8}, {(void**)&w->invl_d, size_t(m->d) * 8},
-      {(void**)&w->scal_out, size_t(1 + dreg) * 8}};
+      {(void**)&w->partial5, 1024 * 5 * 8}, {(void**)&w->sums, size_t(8 + 1 + dreg) * 8}, {(void**)&w->invl_d, size_t(m->d) * 8}};
   for (auto& r : req) {
     if (hipMalloc(r.p, r.b) != hipSuccess) {
       w->release();
@@ -937,9 +903,14 @@ int grad_workspace(svgp_ctx* ctx, svgp_model* m, int64_t len, GradWs** out) {
     }
     w->all.push_back(*r.p);
   }
+  w->scal_out = w->sums + 8;   // contiguous with sums: the data-parallel path all-reduces [sums | scal_out] in one piece
   // point-major / k-major chunk buffers are read beyond the written columns of a short last chunk: start from zeros
   for (void* p : {w->A, w->C, w->Ab, w->At, w->Ct, w->Pt})
-    if (hipMemsetAsync(p, 0, mn, ctx->stream) != hipSuccess) return fail(ctx, SVGP_HIP_ERROR, "memset failed");
+    if (hipMemsetAsync(p, 0, mn, ctx->stream) != hipSuccess) {
+      w->release();
+      delete w;
+      return fail(ctx, SVGP_HIP_ERROR, "memset failed");
+    }
   ctx->gws = w;
   *out = w;
   return SVGP_OK;
@@ -948,23 +919,41 @@ int grad_workspace(svgp_ctx* ctx, svgp_model* m, int64_t len, GradWs** out) {
 }  // namespace
 
 namespace {
-// value = scale * sum_i E_i - klw * KL and its gradient over points [off, off + len)
-int elbo_grad_impl(svgp_ctx* ctx, svgp_model* m, const svgp_data* data, int64_t off, int64_t len, double scale, double klw,
-                   double* elbo_out, svgp_terms* terms_out, svgp_grads* g) {
-  int rc = check_batch(ctx, m, data, off, len, true);
-  if (rc) return rc;
-  if (!g) return fail(ctx, SVGP_INVALID_ARG, "null gradient output");
-  if (!(scale > 0.0) || !(klw >= 0.0)) return fail(ctx, SVGP_INVALID_ARG, "scale must be positive and kl_weight non-negative");
-  const bool centered = (m->desc.parametrization == SVGP_CENTERED);
+// value = scale * sum_i E_i - klw * KL and its gradient over points [off, off + len): three stages like the forward
+// evaluation.  Data-parallel (a communicator on the context, `collective`): every rank uses scale = num_data / n_global
+// with n_global all-reduced on the device BEFORE the backward pass (grad_moments reads it there; no host hop) and
+// klw = 1 / world, so the plain sum over ranks of (value, gradient) is the global ELBO and its gradient; that sum is ONE
+// grouped ncclAllReduce of {z_bar, m_bar, Lq_bar, [sums | scal_out]} at the end.
+struct GradCall {
+  GradWs* w = nullptr;
+  double scale = 1.0, klw = 1.0, num_data = 0.0;
+  bool collective = false, centered = false;
+  int64_t len = 0;
+};
+
+int grad_enqueue(svgp_ctx* ctx, svgp_model* m, const svgp_data* data, int64_t off, int64_t len, GradCall& gc) {
+  const bool centered = gc.centered = (m->desc.parametrization == SVGP_CENTERED);
   HIPC(ctx, hipSetDevice(ctx->device));
   hipStream_t s = ctx->stream;
   GradWs* w = nullptr;
-  rc = grad_workspace(ctx, m, len, &w);
+  int rc = grad_workspace(ctx, m, len, &w);
   if (rc) return rc;
+  gc.w = w;
+  gc.len = len;
+  const double scale = gc.scale, klw = gc.klw;
+  const double* n_global_dev = nullptr;
+  if (gc.collective) {
+    // the global batch size, summed on the device; the forward strips run while it travels
+    launch_set_f64(s, ctx->d_coll, double(len));
+    rc = comm_allreduce(ctx, ctx->d_coll, 1, SVGP_F64);
+    if (rc) return rc;
+    n_global_dev = ctx->d_coll;
+  }
   const int dt = m->dtype;
   const int64_t Mp = m->Mp, M = m->M, nc = w->nc, ldk = nc + 64;
   const size_t es = m->es, mm = size_t(Mp) * Mp * es;
   const int dreg = grad_dreg(m->d);
+  (void)es;
   HIPC(ctx, hipEventRecord(ctx->ev[0], s));
   rc = enqueue_prep(ctx, m);
   if (rc) return rc;
@@ -976,7 +965,7 @@ int elbo_grad_impl(svgp_ctx* ctx, svgp_model* m, const svgp_data* data, int64_t 
   HIPC(ctx, hipMemsetAsync(w->sp_uf, 0, w->sp_uf_b, s));
   HIPC(ctx, hipMemsetAsync(w->rp_uu, 0, w->rp_uu_b, s));
   HIPC(ctx, hipMemsetAsync(w->sp_uu, 0, w->sp_uu_b, s));
-  HIPC(ctx, hipMemsetAsync(w->sums, 0, 8 * 8, s));
+  HIPC(ctx, hipMemsetAsync(w->sums, 0, size_t(8 + 1 + dreg) * 8, s));
   HIPC(ctx, hipMemsetAsync(w->S, 0, mm, s));
   HIPC(ctx, hipMemcpyAsync(w->invl_d, m->invl_host.data(), size_t(m->d) * 8, hipMemcpyHostToDevice, s));
   // the adjoint runs on the whitened problem: (m~, B) are (m, Lq) for NonCentered and (Lk \\ (m - c), Lk \\ Lq) for Centered
@@ -1011,8 +1000,8 @@ int elbo_grad_impl(svgp_ctx* ctx, svgp_model* m, const svgp_data* data, int64_t 
       launch_to_point_major(dt, s, w->A, ldk, Mp, ncp, w->At);
       launch_to_point_major(dt, s, w->C, ldk, Mp, ncp, w->Ct);
     }
-    launch_grad_moments(dt, s, lp, scale, ctx->mom, ctx->mom + ctx->mom_cap, data->y, off + c0, clen, ncp, w->gmu, w->gv,
-                        w->partial5, w->sums);
+    launch_grad_moments(dt, s, lp, scale, n_global_dev, gc.num_data, ctx->mom, ctx->mom + ctx->mom_cap, data->y, off + c0, clen,
+                        ncp, w->gmu, w->gv, w->partial5, w->sums);
     KCHECK(ctx, "grad_moments");
     launch_abar(dt, s, Bq, w->C, w->A, m->mp, w->gmu, w->gv, w->Ab, Mp, ldk, ncp);
     KCHECK(ctx, "abar");
@@ -1057,8 +1046,58 @@ int elbo_grad_impl(svgp_ctx* ctx, svgp_model* m, const svgp_data* data, int64_t 
   launch_finish_kgrad(dt, s, m->d, M, Mp, m->zs, w->invl_d, w->rp_uf, w->ns_uf, w->rp_uu, w->ns_uu, w->sp_uf, w->ns_uf * w->rb,
                       w->sp_uu, w->ns_uu * w->rb, m->mp, klw, m->desc.layout_z, m->desc.variance, w->zbar, centered ? nullptr : w->mbar,
                       w->scal_out);
+  launch_grad_status(s, w->sums, m->info, double(len));
   KCHECK(ctx, "kgrad uu / finish");
   HIPC(ctx, hipEventRecord(ctx->ev[3], s));
+  return SVGP_OK;
+}
+
+// the gradient's ONE (grouped) all-reduce; a rank whose enqueue failed still takes part with its failure flag set
+int grad_collective(svgp_ctx* ctx, svgp_model* m, GradCall& gc, int local_rc) {
+  if (!ctx->comm || !gc.collective) return local_rc;
+  GradWs* w = gc.w;
+  if (!w) {   // failed before the workspace existed: nothing to reduce with; make the peers fail instead of hang
+    comm_abort(ctx);
+    return local_rc;
+  }
+  const std::string keep = ctx->err;
+  const int dreg = grad_dreg(m->d);
+  if (local_rc != SVGP_OK) {
+    std::vector<double> poison(size_t(8 + 1 + dreg), 0.0);
+    poison[7] = 1.0;
+    if (hipSetDevice(ctx->device) != hipSuccess ||
+        hipMemcpyAsync(w->sums, poison.data(), poison.size() * 8, hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
+        hipStreamSynchronize(ctx->stream) != hipSuccess) {
+      comm_abort(ctx);
+      ctx->err = keep;
+      return local_rc;
+    }
+  }
+  int rc = comm_group_start(ctx);
+  if (rc == SVGP_OK) rc = comm_allreduce(ctx, w->zbar, size_t(m->M) * m->d, m->dtype);
+  if (rc == SVGP_OK) rc = comm_allreduce(ctx, gc.centered ? w->rbar : w->mbar, size_t(m->M), m->dtype);
+  if (rc == SVGP_OK) rc = comm_allreduce(ctx, w->Lqbar, size_t(m->M) * m->M, m->dtype);
+  if (rc == SVGP_OK) rc = comm_allreduce(ctx, w->sums, size_t(8 + 1 + dreg), SVGP_F64);
+  const int rce = comm_group_end(ctx);
+  if (rc == SVGP_OK) rc = rce;
+  if (rc != SVGP_OK) {
+    comm_abort(ctx);
+    if (local_rc != SVGP_OK) ctx->err = keep;
+    return local_rc != SVGP_OK ? local_rc : rc;
+  }
+  if (local_rc != SVGP_OK) ctx->err = keep;
+  return local_rc;
+}
+
+int grad_finish(svgp_ctx* ctx, svgp_model* m, GradCall& gc, double* elbo_out, svgp_terms* terms_out, svgp_grads* g) {
+  hipStream_t s = ctx->stream;
+  HIPC(ctx, hipSetDevice(ctx->device));
+  GradWs* w = gc.w;
+  const int dt = m->dtype;
+  const int64_t M = m->M;
+  const size_t es = m->es;
+  const int dreg = grad_dreg(m->d);
+  const bool centered = gc.centered;
   // read back
   double sums[8];
   std::vector<double> sc(1 + dreg);
@@ -1080,8 +1119,12 @@ int elbo_grad_impl(svgp_ctx* ctx, svgp_model* m, const svgp_data* data, int64_t 
   ctx->timing.ms_prep = t01;
   ctx->timing.ms_strip = t13;
   ctx->timing.ms_total = t01 + t13;
-  const double E = sums[0], nneg = sums[4];
-  const double elbo = E * scale - klw * m->kl;
+  ElboRead r;
+  r.E = sums[0]; r.n_neg = sums[4]; r.n_points = sums[5]; r.bad_chol = gc.collective ? sums[6] : 0.0; r.failed = gc.collective ? sums[7] : 0.0;
+  // collective: the sums are global; scale = num_data / n_global (as on the device), and the KL counts once
+  const double scale = gc.collective ? (gc.num_data > 0 ? gc.num_data / r.n_points : 1.0) : gc.scale;
+  const double klw = gc.collective ? 1.0 : gc.klw;
+  const double elbo = r.E * scale - klw * m->kl;
   g->variance = sc[0] + sums[2];
   g->lik_sigma2 = sums[3];
   if (g->m) memcpy(g->m, mhost.data(), mhost.size());
@@ -1091,26 +1134,187 @@ int elbo_grad_impl(svgp_ctx* ctx, svgp_model* m, const svgp_data* data, int64_t 
   g->mean_const = sums[1] - msum;
   if (g->inv_lengthscale)
     for (int f = 0; f < m->d; ++f) g->inv_lengthscale[f] = sc[1 + f];
-  if (terms_out) {
-    terms_out->elbo = elbo; terms_out->expectation = E; terms_out->kl = m->kl; terms_out->scale = scale;
-    terms_out->logdet_kuu = m->logdet_kuu; terms_out->n_points = len; terms_out->n_neg_var = (int64_t)nneg;
-    terms_out->chol_info = m->chol_info; terms_out->reserved = 0;
-  }
-  rc = status_of(ctx, m, nneg);
+  fill_terms(terms_out, m, elbo, r, scale);
+  const int rc = status_of(ctx, m, r.n_neg, r.bad_chol, r.failed);
   if (elbo_out) *elbo_out = (rc == SVGP_OK) ? elbo : NAN;
   return rc;
 }
+
+int elbo_grad_impl(svgp_ctx* ctx, svgp_model* m, const svgp_data* data, int64_t off, int64_t len, double scale, double klw,
+                   double num_data, bool collective, double* elbo_out, svgp_terms* terms_out, svgp_grads* g) {
+  GradCall gc;
+  gc.collective = collective && ctx && ctx->comm;
+  gc.scale = scale;
+  gc.klw = gc.collective ? 1.0 / double(ctx->world) : klw;
+  gc.num_data = num_data;
+  int rc = check_batch(ctx, m, data, off, len, true);
+  if (rc == SVGP_OK && !g) rc = fail(ctx, SVGP_INVALID_ARG, "null gradient output");
+  if (rc == SVGP_OK && (!(scale > 0.0) || !(klw >= 0.0))) rc = fail(ctx, SVGP_INVALID_ARG, "scale must be positive and kl_weight non-negative");
+  if (rc != SVGP_OK) {
+    if (ctx && gc.collective) comm_abort(ctx);   // argument errors: the peers' collectives cannot be matched
+    return rc;
+  }
+  rc = grad_enqueue(ctx, m, data, off, len, gc);
+  rc = grad_collective(ctx, m, gc, rc);
+  if (rc) return rc;
+  return grad_finish(ctx, m, gc, elbo_out, terms_out, g);
+}
 }  // namespace
 
+// With a communicator attached this call is COLLECTIVE like svgp_elbo: value and gradient of the GLOBAL minibatch ELBO on
+// every rank (one 8-byte all-reduce of the batch size up front, one grouped all-reduce of the gradient at the end).
 extern "C" int32_t svgp_elbo_grad(svgp_ctx* ctx, svgp_model* m, const svgp_data* data, int64_t off, int64_t len,
                                   double num_data, double* elbo_out, svgp_terms* terms_out, svgp_grads* g) {
-  if (len < 1) return ctx ? fail(ctx, SVGP_INVALID_ARG, "batch range outside the data") : SVGP_INVALID_ARG;
-  return elbo_grad_impl(ctx, m, data, off, len, (num_data > 0 ? num_data : double(len)) / double(len), 1.0, elbo_out,
-                        terms_out, g);
+  if (len < 1) {
+    if (ctx && ctx->comm) comm_abort(ctx);
+    return ctx ? fail(ctx, SVGP_INVALID_ARG, "batch range outside the data") : SVGP_INVALID_ARG;
+  }
+  return elbo_grad_impl(ctx, m, data, off, len, (num_data > 0 ? num_data : double(len)) / double(len), 1.0, num_data, true,
+                        elbo_out, terms_out, g);
 }
 
+// always local (no collective): the building block for hosts that run their own all-reduce
 extern "C" int32_t svgp_elbo_grad_shard(svgp_ctx* ctx, svgp_model* m, const svgp_data* data, int64_t off, int64_t len,
                                         double scale, double kl_weight, double* value_out, svgp_terms* terms_out,
                                         svgp_grads* g) {
-  return elbo_grad_impl(ctx, m, data, off, len, scale, kl_weight, value_out, terms_out, g);
+  return elbo_grad_impl(ctx, m, data, off, len, scale, kl_weight, 0.0, false, value_out, terms_out, g);
 }
+
+// ================================================================================================
+// One process, several GPUs (the shape of a Julia host): the group's member contexts each hold one shard of the data and
+// a replica of the model; an evaluation enqueues every device, then issues the members' all-reduces as ONE ncclGroup,
+// then reads device 0.  Same kernels, same collective, same result as the process-per-GPU path.
+extern "C" {
+
+int32_t svgp_group_data_upload(svgp_group* g, int32_t dtype, int32_t layout, int32_t d, int64_t n, const void* x_host,
+                               const void* y_host, svgp_data** shards_out) {
+  if (!g || !shards_out || !x_host || n < int64_t(g->ctxs.size())) return SVGP_INVALID_ARG;
+  if (dtype != SVGP_F64 && dtype != SVGP_F32) return SVGP_INVALID_ARG;
+  const int W = int(g->ctxs.size());
+  const size_t es = esize(dtype);
+  for (int i = 0; i < W; ++i) shards_out[i] = nullptr;
+  int rc = SVGP_OK;
+  for (int i = 0; i < W && rc == SVGP_OK; ++i) {
+    // contiguous shard [lo, hi): the first n % W members get one more point
+    const int64_t base = n / W, rem = n % W, lo = i * base + (i < rem ? i : rem), cnt = base + (i < rem ? 1 : 0);
+    const char* xp = static_cast<const char*>(x_host);
+    const char* yp = static_cast<const char*>(y_host);
+    std::vector<char> gather;
+    const void* xs = nullptr;
+    if (layout == SVGP_ROWVECS && d > 1) {   // n x d column-major: a shard's rows are strided; gather them
+      gather.resize(size_t(cnt) * d * es);
+      for (int f = 0; f < d; ++f) memcpy(gather.data() + size_t(f) * cnt * es, xp + (size_t(f) * n + lo) * es, size_t(cnt) * es);
+      xs = gather.data();
+    } else {
+      xs = xp + size_t(lo) * (layout == SVGP_COLVECS ? d : 1) * es;
+    }
+    rc = svgp_data_upload(g->ctxs[size_t(i)], dtype, layout, d, cnt, xs, yp ? yp + size_t(lo) * es : nullptr, &shards_out[i]);
+    if (rc) g->err = svgp_last_error(g->ctxs[size_t(i)]);
+  }
+  if (rc != SVGP_OK)
+    for (int i = 0; i < W; ++i) {
+      svgp_data_free(g->ctxs[size_t(i)], shards_out[i]);
+      shards_out[i] = nullptr;
+    }
+  return rc;
+}
+
+int32_t svgp_group_model_create(svgp_group* g, const svgp_model_desc* desc, svgp_model** models_out) {
+  if (!g || !models_out) return SVGP_INVALID_ARG;
+  const int W = int(g->ctxs.size());
+  for (int i = 0; i < W; ++i) models_out[i] = nullptr;
+  int rc = SVGP_OK;
+  for (int i = 0; i < W && rc == SVGP_OK; ++i) {
+    rc = svgp_model_create(g->ctxs[size_t(i)], desc, &models_out[i]);
+    if (rc) g->err = svgp_last_error(g->ctxs[size_t(i)]);
+  }
+  if (rc != SVGP_OK)
+    for (int i = 0; i < W; ++i) {
+      svgp_model_free(g->ctxs[size_t(i)], models_out[i]);
+      models_out[i] = nullptr;
+    }
+  return rc;
+}
+
+int32_t svgp_group_model_update(svgp_group* g, svgp_model* const* models, const svgp_model_desc* desc) {
+  if (!g || !models) return SVGP_INVALID_ARG;
+  for (size_t i = 0; i < g->ctxs.size(); ++i) {
+    const int rc = svgp_model_update(g->ctxs[i], models[i], desc);
+    if (rc) { g->err = svgp_last_error(g->ctxs[i]); return rc; }
+  }
+  return SVGP_OK;
+}
+
+const char* svgp_group_last_error(const svgp_group* g) { return g ? g->err.c_str() : "null group"; }
+
+// elbo over the members' batches: member i evaluates points [offs[i], offs[i] + lens[i]) of shards[i]
+int32_t svgp_group_elbo(svgp_group* g, svgp_model* const* models, const svgp_data* const* shards, const int64_t* offs,
+                        const int64_t* lens, double num_data, double* elbo_out, svgp_terms* terms_out) {
+  if (!g || !models || !shards || !offs || !lens) return SVGP_INVALID_ARG;
+  const size_t W = g->ctxs.size();
+  std::vector<int> rcs(W, SVGP_OK);
+  for (size_t i = 0; i < W; ++i) {
+    rcs[i] = check_batch(g->ctxs[i], models[i], shards[i], offs[i], lens[i], true);
+    if (rcs[i] == SVGP_OK) rcs[i] = elbo_enqueue(g->ctxs[i], models[i], shards[i], offs[i], lens[i]);
+  }
+  int rc = comm_group_start(g->ctxs[0]);
+  if (rc == SVGP_OK) {
+    for (size_t i = 0; i < W; ++i) rcs[i] = elbo_collective(g->ctxs[i], rcs[i]);
+    rc = comm_group_end(g->ctxs[0]);
+  }
+  ElboRead r0;
+  for (size_t i = 0; i < W; ++i) {
+    ElboRead r;
+    if (rcs[i] == SVGP_OK) rcs[i] = elbo_finish(g->ctxs[i], models[i], &r);
+    if (i == 0) r0 = r;
+    if (rcs[i] != SVGP_OK && rc == SVGP_OK) { rc = rcs[i]; g->err = svgp_last_error(g->ctxs[i]); }
+  }
+  if (rc != SVGP_OK) return rc;
+  svgp_model* m = models[0];
+  const double scale = (num_data > 0 ? num_data : r0.n_points) / r0.n_points;
+  const double elbo = r0.E * scale - m->kl;
+  fill_terms(terms_out, m, elbo, r0, scale);
+  rc = status_of(g->ctxs[0], m, r0.n_neg, r0.bad_chol, r0.failed);
+  if (rc) g->err = svgp_last_error(g->ctxs[0]);
+  if (elbo_out) *elbo_out = (rc == SVGP_OK) ? elbo : NAN;
+  return rc;
+}
+
+// value and gradient of the same global ELBO; the host knows the global batch size, so only the final grouped all-reduce runs
+int32_t svgp_group_elbo_grad(svgp_group* g, svgp_model* const* models, const svgp_data* const* shards, const int64_t* offs,
+                             const int64_t* lens, double num_data, double* elbo_out, svgp_terms* terms_out,
+                             svgp_grads* grads_out) {
+  if (!g || !models || !shards || !offs || !lens || !grads_out) return SVGP_INVALID_ARG;
+  const size_t W = g->ctxs.size();
+  int64_t n_global = 0;
+  for (size_t i = 0; i < W; ++i) n_global += lens[i];
+  if (n_global < 1) return SVGP_INVALID_ARG;
+  std::vector<int> rcs(W, SVGP_OK);
+  std::vector<GradCall> gcs(W);
+  for (size_t i = 0; i < W; ++i) {
+    GradCall& gc = gcs[i];
+    gc.scale = (num_data > 0 ? num_data : double(n_global)) / double(n_global);
+    gc.klw = 1.0 / double(W);
+    gc.num_data = num_data;
+    gc.collective = false;   // scale known on the host: no batch-size all-reduce
+    rcs[i] = check_batch(g->ctxs[i], models[i], shards[i], offs[i], lens[i], true);
+    if (rcs[i] == SVGP_OK) rcs[i] = grad_enqueue(g->ctxs[i], models[i], shards[i], offs[i], lens[i], gc);
+    gc.collective = true;    // ... but the final reduction and the global bookkeeping of grad_finish apply
+  }
+  int rc = comm_group_start(g->ctxs[0]);
+  if (rc == SVGP_OK) {
+    for (size_t i = 0; i < W; ++i) rcs[i] = grad_collective(g->ctxs[i], models[i], gcs[i], rcs[i]);
+    rc = comm_group_end(g->ctxs[0]);
+  }
+  svgp_grads scratch{};   // members other than 0 only need their status
+  for (size_t i = 0; i < W; ++i) {
+    if (rcs[i] == SVGP_OK) {
+      svgp_grads* out = (i == 0) ? grads_out : &scratch;
+      rcs[i] = grad_finish(g->ctxs[i], models[i], gcs[i], i == 0 ? elbo_out : nullptr, i == 0 ? terms_out : nullptr, out);
+    }
+    if (rcs[i] != SVGP_OK && rc == SVGP_OK) { rc = rcs[i]; g->err = svgp_last_error(g->ctxs[i]); }
+  }
+  return rc;
+}
+
+}  // extern "C"

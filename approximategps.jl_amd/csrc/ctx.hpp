@@ -1,0 +1,122 @@
+// ctx.hpp — internal definitions shared by the host-side translation units of libsvgp_mi355x (api.hip, comm.hip):
+// the opaque handles of include/svgp_mi355x.h and the error macros.  Not part of the C-ABI.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdlib>
+#include <string>
+#include <vector>
+
+#include "../../include/svgp_mi355x.h"
+
+// ------------------------------------------------------------------------------------------------
+struct svgp_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  int num_cus = 256;
+  std::string err;
+  svgp_timing timing{};
+  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};  // start, prep done, strip done, all done
+  // growable scratch
+  void* work = nullptr;       size_t work_bytes = 0;
+  double* partial = nullptr;  unsigned* negcnt = nullptr;  // [1024] per-block sums of the expectation kernel
+  double* mom = nullptr;      size_t mom_cap = 0;           // [2][mom_cap] per-point mean / variance
+  double* d_res = nullptr;    // [8] device results
+  unsigned* counter = nullptr; // strip queue head of the running strip launch
+  void* kuf_buf = nullptr;    size_t kuf_bytes = 0;
+  struct GradWs* gws = nullptr;  // gradient workspace, cached by problem shape
+  // data-parallel communicator (comm.hip): one RCCL rank per context; world == 1 without one
+  void* comm = nullptr;        // ncclComm_t
+  int world = 1, rank = 0;
+  bool comm_owned_by_group = false;
+  double* d_coll = nullptr;    // [8] the all-reduced vector {sum E, n_points, n_neg_var, chol flag, failure flag, ...}
+};
+
+// device buffers of svgp_elbo_grad, sized by (dtype, Mp, d, nc)
+struct GradWs {
+  int dtype = -1, d = 0, nslices = 1, ns_uf = 1, ns_uu = 1, rb = 1;
+  int64_t Mp = 0, nc = 0;
+  std::vector<void*> all;
+  void *A = nullptr, *C = nullptr, *Ab = nullptr, *At = nullptr, *Ct = nullptr, *Pt = nullptr, *gmu = nullptr, *gv = nullptr;
+  void *Lqp = nullptr, *S = nullptr, *G1 = nullptr, *G2 = nullptr, *LkRM = nullptr, *LbarRM = nullptr, *Phi = nullptr,
+       *tmp = nullptr, *H = nullptr, *zbar = nullptr, *mbar = nullptr, *Lqbar = nullptr, *BbarRM = nullptr, *rbar = nullptr;
+  double *rp_uf = nullptr, *sp_uf = nullptr, *rp_uu = nullptr, *sp_uu = nullptr, *partial5 = nullptr, *sums = nullptr,
+         *invl_d = nullptr, *scal_out = nullptr;
+  size_t rp_uf_b = 0, sp_uf_b = 0, rp_uu_b = 0, sp_uu_b = 0, g_b = 0;
+  void release() {
+    for (void* p : all)
+      if (p) (void)hipFree(p);
+    all.clear();
+  }
+};
+
+struct svgp_data {
+  int dtype = 0, d = 0;
+  int64_t n = 0, ldx = 0;
+  void* x = nullptr;  // feature-major [d][ldx]
+  void* y = nullptr;
+  bool own = true;
+};
+
+struct svgp_model {
+  svgp_model_desc desc{};
+  std::vector<double> invl_host;
+  int64_t M = 0, Mp = 0;
+  int dtype = 0, d = 0;
+  size_t es = 8;
+  void *z_raw = nullptr, *m_raw = nullptr, *Lq_raw = nullptr;  // user layout
+  void *invl = nullptr, *zs = nullptr, *L = nullptr, *T = nullptr, *U = nullptr, *mp = nullptr, *B = nullptr;
+  double* scal = nullptr;  // [8 + Mp]
+  int* info = nullptr;
+  double *gh_x = nullptr, *gh_w = nullptr;
+  int gh_n = 0;
+  bool prepared = false;
+  // host copies of the last prep's scalars
+  double kl = 0, logdet_kuu = 0;
+  int chol_info = 0;
+};
+
+// one process driving several GPUs: member contexts share one RCCL communicator (ncclCommInitAll), rank i = member i
+struct svgp_group {
+  std::vector<svgp_ctx*> ctxs;
+  std::string err;
+};
+
+#define HIPC(ctx, call)                                                                            \
+  do {                                                                                             \
+    hipError_t e_ = (call);                                                                        \
+    if (e_ != hipSuccess) {                                                                        \
+      (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e_);                              \
+      return (e_ == hipErrorOutOfMemory) ? SVGP_OOM : SVGP_HIP_ERROR;                              \
+    }                                                                                              \
+  } while (0)
+
+// SVGP_DEBUG_SYNC=1: synchronise and check after every kernel launch, naming the offender.
+inline bool debug_sync() {
+  static const bool on = [] { const char* e = getenv("SVGP_DEBUG_SYNC"); return e && e[0] == '1'; }();
+  return on;
+}
+#define KCHECK(ctx, name)                                                                          \
+  do {                                                                                             \
+    hipError_t e_ = hipGetLastError();                                                             \
+    if (e_ == hipSuccess && debug_sync()) e_ = hipStreamSynchronize((ctx)->stream);                \
+    if (e_ != hipSuccess) {                                                                        \
+      (ctx)->err = std::string("kernel ") + name + ": " + hipGetErrorString(e_);                   \
+      return SVGP_HIP_ERROR;                                                                       \
+    }                                                                                              \
+  } while (0)
+
+namespace svgp {
+// ---- comm.hip: RCCL, loaded lazily with dlopen (the library has no link-time dependency on it) ----
+// in-place sum all-reduce of `count` elements (f64: dtype 0, f32: dtype 1) on the context's stream; no host sync
+int comm_allreduce(svgp_ctx* ctx, void* buf, size_t count, int dtype);
+int comm_group_start(svgp_ctx* ctx);
+int comm_group_end(svgp_ctx* ctx);
+void comm_abort(svgp_ctx* ctx);   // after a local failure that left peers inside a collective: abort instead of hanging
+
+inline int fail(svgp_ctx* ctx, int code, const std::string& msg) {
+  if (ctx) ctx->err = msg;
+  return code;
+}
+}  // namespace svgp

@@ -19,11 +19,13 @@ namespace svgp {
 namespace {
 
 template <typename T>
-__global__ void __launch_bounds__(k256) grad_moments_kernel(LikParams lp, double scale, const double* __restrict__ mom_mu,
+__global__ void __launch_bounds__(k256) grad_moments_kernel(LikParams lp, double scale, const double* __restrict__ n_global_dev,
+                                                            double num_data, const double* __restrict__ mom_mu,
                                                             const double* __restrict__ mom_var, const T* __restrict__ y,
                                                             int64_t off, int64_t len, int64_t npad, T* __restrict__ gmu,
                                                             T* __restrict__ gv, double* __restrict__ partial) {
   __shared__ double sh[5][k256];
+  if (n_global_dev) scale = num_data > 0.0 ? num_data / *n_global_dev : 1.0;   // SVA:357-358 with the all-reduced batch size
   const double log_sigma2 = log(lp.sigma2);
   double acc[5] = {0, 0, 0, 0, 0};  // E, sum g_mu, sum g_v, dE/dsigma2, n_neg
   for (int64_t i = int64_t(blockIdx.x) * k256 + threadIdx.x; i < npad; i += int64_t(gridDim.x) * k256) {
@@ -59,6 +61,13 @@ __global__ void __launch_bounds__(k256) grad_moments_kernel(LikParams lp, double
     __syncthreads();
   }
   if (threadIdx.x < 5) partial[blockIdx.x * 5 + threadIdx.x] = sh[threadIdx.x][0];
+}
+
+__global__ void set_f64_kernel(double* dst, double value) { *dst = value; }
+__global__ void grad_status_kernel(double* sums, const int* chol_info, double n_points) {
+  sums[5] = n_points;
+  sums[6] = (chol_info && *chol_info != 0) ? 1.0 : 0.0;
+  sums[7] = 0.0;
 }
 
 // out[q] += sum over blocks of partial[b][q]  (fixed order)
@@ -494,13 +503,18 @@ void launch_kgrad_f(hipStream_t s, const KernelParams& kp, const T* zs, int64_t 
 int grad_dreg(int d) { return d <= 8 ? 8 : (d <= 16 ? 16 : 32); }
 int grad_rowblocks(int d, int64_t Mp) { return int(d <= 16 ? Mp / 128 : Mp / 64); }
 
-void launch_grad_moments(int dtype, hipStream_t s, const LikParams& lp, double scale, const double* mom_mu,
-                         const double* mom_var, const void* y, int64_t off, int64_t len, int64_t npad, void* gmu, void* gv,
-                         double* partial, double* sums) {
+void launch_set_f64(hipStream_t s, double* dst, double value) { hipLaunchKernelGGL(set_f64_kernel, dim3(1), dim3(1), 0, s, dst, value); }
+void launch_grad_status(hipStream_t s, double* sums, const int* chol_info, double n_points) {
+  hipLaunchKernelGGL(grad_status_kernel, dim3(1), dim3(1), 0, s, sums, chol_info, n_points);
+}
+
+void launch_grad_moments(int dtype, hipStream_t s, const LikParams& lp, double scale, const double* n_global_dev,
+                         double num_data, const double* mom_mu, const double* mom_var, const void* y, int64_t off,
+                         int64_t len, int64_t npad, void* gmu, void* gv, double* partial, double* sums) {
   const int64_t b = (npad + k256 - 1) / k256;
   const int nb = int(b < 1024 ? b : 1024);
-  GD(dtype, T, hipLaunchKernelGGL(grad_moments_kernel<T>, dim3(nb), dim3(k256), 0, s, lp, scale, mom_mu, mom_var, (const T*)y, off,
-                                  len, npad, (T*)gmu, (T*)gv, partial));
+  GD(dtype, T, hipLaunchKernelGGL(grad_moments_kernel<T>, dim3(nb), dim3(k256), 0, s, lp, scale, n_global_dev, num_data, mom_mu,
+                                  mom_var, (const T*)y, off, len, npad, (T*)gmu, (T*)gv, partial));
   hipLaunchKernelGGL(sum5_kernel, dim3(1), dim3(64), 0, s, partial, nb, sums);
 }
 

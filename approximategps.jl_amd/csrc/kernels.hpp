@@ -95,8 +95,10 @@ int expect_blocks(int64_t len);
 void launch_expect(int dtype, hipStream_t s, const LikParams& lp, const double* mom_mu, const double* mom_var,
                    const void* y, int64_t off, int64_t len, double* partial, unsigned* negcnt, void* mu_out,
                    void* var_out);
-// out[0] = sum(partial[0..n)), out[1] = sum(negcnt) in fixed order (deterministic)
-void launch_final_reduce(hipStream_t s, const double* partial, const unsigned* negcnt, int64_t n, double* out);
+// out[0..8) = {sum(partial[0..n)), n_points, sum(negcnt), *chol_info != 0, 0, 0, 0, 0} in fixed order (deterministic):
+// the vector a data-parallel evaluation all-reduces
+void launch_final_reduce(hipStream_t s, const double* partial, const unsigned* negcnt, int64_t n, const int* chol_info,
+                         double n_points, double* out);
 // standalone Kuf (M x len col-major, ld = M)
 void launch_kuf(int dtype, hipStream_t s, const KernelParams& kp, const void* zs, int64_t M, int64_t Mp,
                 const void* x, int64_t ldx, int64_t off, int64_t len, void* Kuf);
@@ -111,9 +113,14 @@ int grad_dreg(int d);
 int grad_rowblocks(int d, int64_t Mp);
 void launch_spanels(int dtype, hipStream_t s, const void* L, const void* T, void* S, int64_t Mp);
 void launch_sdiag(int dtype, hipStream_t s, const void* Tm, int64_t Mp, void* S);
-void launch_grad_moments(int dtype, hipStream_t s, const LikParams& lp, double scale, const double* mom_mu,
-                         const double* mom_var, const void* y, int64_t off, int64_t len, int64_t npad, void* gmu, void* gv,
-                         double* partial, double* sums);
+// scale: num_data / n_batch; with n_global_dev != nullptr (data-parallel: the all-reduced batch size lives on the device)
+// scale = num_data > 0 ? num_data / *n_global_dev : 1
+void launch_grad_moments(int dtype, hipStream_t s, const LikParams& lp, double scale, const double* n_global_dev,
+                         double num_data, const double* mom_mu, const double* mom_var, const void* y, int64_t off,
+                         int64_t len, int64_t npad, void* gmu, void* gv, double* partial, double* sums);
+void launch_set_f64(hipStream_t s, double* dst, double value);
+// sums[5] = n_points, sums[6] = (*chol_info != 0), sums[7] = 0: the status slots of the all-reduced gradient scalars
+void launch_grad_status(hipStream_t s, double* sums, const int* chol_info, double n_points);
 void launch_abar(int dtype, hipStream_t s, const void* Lqp, const void* C, const void* A, const void* mp, const void* gmu,
                  const void* gv, void* Abar, int64_t Mp, int64_t ld, int64_t ncols);
 void launch_solve_t(int dtype, hipStream_t s, const void* S, void* X, void* Xt, int64_t Mp, int64_t ld, int64_t ncols,

@@ -374,8 +374,10 @@ __global__ void __launch_bounds__(k256) expect_kernel(LikParams lp, const double
 }
 
 __global__ void final_reduce_kernel(const double* __restrict__ partial, const unsigned* __restrict__ negcnt, int64_t n,
-                                    double* __restrict__ out) {
-  // fixed-order tree: thread t sums elements t, t+256, ... then a fixed LDS tree -> bitwise reproducible
+                                    const int* __restrict__ chol_info, double n_points, double* __restrict__ out) {
+  // fixed-order tree: thread t sums elements t, t+256, ... then a fixed LDS tree -> bitwise reproducible.
+  // out[0..8) is the vector a data-parallel evaluation all-reduces (comm.hip): {sum E, n_points, n_neg_var, chol flag,
+  // failure flag, 0, 0, 0}
   __shared__ double sh[k256];
   __shared__ double sn[k256];
   double s = 0.0, c = 0.0;
@@ -395,7 +397,10 @@ __global__ void final_reduce_kernel(const double* __restrict__ partial, const un
   }
   if (threadIdx.x == 0) {
     out[0] = sh[0];
-    out[1] = sn[0];
+    out[1] = n_points;
+    out[2] = sn[0];
+    out[3] = (chol_info && *chol_info != 0) ? 1.0 : 0.0;
+    out[4] = out[5] = out[6] = out[7] = 0.0;
   }
 }
 
@@ -609,8 +614,9 @@ void launch_expect(int dtype, hipStream_t s, const LikParams& lp, const double* 
                        partial, negcnt, (float*)mu_out, (float*)var_out);
 }
 
-void launch_final_reduce(hipStream_t s, const double* partial, const unsigned* negcnt, int64_t n, double* out) {
-  hipLaunchKernelGGL(final_reduce_kernel, dim3(1), dim3(k256), 0, s, partial, negcnt, n, out);
+void launch_final_reduce(hipStream_t s, const double* partial, const unsigned* negcnt, int64_t n, const int* chol_info,
+                         double n_points, double* out) {
+  hipLaunchKernelGGL(final_reduce_kernel, dim3(1), dim3(k256), 0, s, partial, negcnt, n, chol_info, n_points, out);
 }
 
 template <typename T, int FAMILY>

@@ -17,6 +17,10 @@
  *   - one svgp_ctx is bound to one GPU and one HIP stream; distinct contexts may be used
  *     concurrently from different threads, one context is not re-entrant.  Calls block until
  *     their host-visible results are written.
+ *   - multi-GPU: a context may carry one rank of an RCCL communicator (svgp_ctx_attach_comm for one process per
+ *     GPU, svgp_group_create for one process driving several GPUs).  svgp_elbo and svgp_elbo_grad are then
+ *     COLLECTIVE: every rank evaluates its own shard and the library sums the partial results with one
+ *     ncclAllReduce over xGMI on the device (no host hop).  Everything else stays local to the context.
  */
 #ifndef SVGP_MI355X_H
 #define SVGP_MI355X_H
@@ -27,7 +31,7 @@
 extern "C" {
 #endif
 
-#define SVGP_ABI_VERSION 1
+#define SVGP_ABI_VERSION 2
 
 /* status codes -> Julia exceptions raised by the shim */
 enum {
@@ -68,6 +72,7 @@ enum { SVGP_NEGVAR_ERROR = 0, SVGP_NEGVAR_CLAMP = 1 };
 typedef struct svgp_ctx svgp_ctx;
 typedef struct svgp_data svgp_data;
 typedef struct svgp_model svgp_model;
+struct svgp_model_desc;
 
 /* Everything a SparseVariationalApproximation + likelihood holds (SVA:59-62):
  *   fz = GP(mean_const, variance * (Base ∘ ARD(inv_lengthscale)))(z, jitter),  q = MvNormal(m, Lq Lq'). */
@@ -125,6 +130,39 @@ int32_t svgp_ctx_destroy(svgp_ctx* ctx);
 const char* svgp_last_error(const svgp_ctx* ctx);
 int32_t svgp_last_timing(const svgp_ctx* ctx, svgp_timing* out);
 
+/* ---- multi-GPU: data-parallel shards of the sum over points (SVA:355-359), SURVEY §8e ----------
+ * The expectation term is a plain sum over data points, so each rank holds a shard of (x, y) in its own HBM,
+ * replicates the M-sized work (Kuu, cholesky, KL) and the ranks' {sum E, n_points, n_neg_var, status flags}
+ * are summed by ONE ncclAllReduce of 8 doubles issued by the library on the context's stream, straight from
+ * the device buffer the reduction kernel wrote.  RCCL is loaded with dlopen on first use (no link-time
+ * dependency; SVGP_RCCL_LIB overrides the library name); failures map to SVGP_RCCL_ERROR.
+ *
+ * One process per GPU: rank 0 calls svgp_comm_unique_id, the host transports the 128 bytes to every rank
+ * (MPI / torch.distributed / Distributed.jl), every rank calls svgp_ctx_attach_comm on its own context
+ * (collective: ncclCommInitRank).  A rank that fails locally still enters the collective with a failure flag,
+ * so its peers return SVGP_RCCL_ERROR instead of waiting for it. */
+#define SVGP_COMM_ID_BYTES 128
+int32_t svgp_comm_unique_id(void* id_out /* SVGP_COMM_ID_BYTES */);
+int32_t svgp_ctx_attach_comm(svgp_ctx* ctx, const void* id, int32_t world_size, int32_t rank);
+int32_t svgp_ctx_detach_comm(svgp_ctx* ctx);
+int32_t svgp_ctx_comm_info(const svgp_ctx* ctx, int32_t* world_size_out, int32_t* rank_out);
+
+/* One process, several GPUs (the natural shape of a Julia host): a group owns one context per device and their
+ * communicator (ncclCommInitAll).  Arrays of handles are indexed by member; svgp_group_ctx(g, i) gives member i's
+ * context for the local calls (svgp_predict, svgp_posterior, svgp_*_free ...). */
+typedef struct svgp_group svgp_group;
+int32_t svgp_group_create(int32_t n_devices, const int32_t* device_ids, svgp_group** out);
+int32_t svgp_group_destroy(svgp_group* group);
+int32_t svgp_group_size(const svgp_group* group);
+svgp_ctx* svgp_group_ctx(svgp_group* group, int32_t member);
+const char* svgp_group_last_error(const svgp_group* group);
+/* uploads x, y once, sharded contiguously by point index over the members (shards_out: n_devices handles) */
+int32_t svgp_group_data_upload(svgp_group* group, int32_t dtype, int32_t layout, int32_t d, int64_t n,
+                               const void* x_host, const void* y_host, svgp_data** shards_out);
+/* one replica of the model per member (models_out: n_devices handles) */
+int32_t svgp_group_model_create(svgp_group* group, const struct svgp_model_desc* desc, svgp_model** models_out);
+int32_t svgp_group_model_update(svgp_group* group, svgp_model* const* models, const struct svgp_model_desc* desc);
+
 /* ---- data: x = lfx.fx.x, y (SVA:340-343) kept resident in HBM ------------------------------ */
 int32_t svgp_data_upload(svgp_ctx* ctx, int32_t dtype, int32_t layout, int32_t d, int64_t n,
                          const void* x_host, const void* y_host, svgp_data** out);
@@ -140,12 +178,15 @@ int32_t svgp_model_update(svgp_ctx* ctx, svgp_model* model, const svgp_model_des
 int32_t svgp_model_free(svgp_ctx* ctx, svgp_model* model);
 
 /* ---- elbo(sva, lfx, y; num_data, quadrature)  replaces SVA:340-360 (and :307-317, :276-280) --- */
-/* evaluates points [batch_off, batch_off + batch_len) of `data`; num_data <= 0 means batch_len. */
+/* evaluates points [batch_off, batch_off + batch_len) of `data`; num_data <= 0 means batch_len.
+ * On a context with a communicator: COLLECTIVE — every rank passes its own shard's batch and gets the global
+ * ELBO = (sum over all ranks' points) * num_data / n_global - KL; terms_out->n_points = n_global. */
 int32_t svgp_elbo(svgp_ctx* ctx, svgp_model* model, const svgp_data* data, int64_t batch_off,
                   int64_t batch_len, double num_data, double* elbo_out, svgp_terms* terms_out);
 /* data-parallel shard: only Σ_i E[log p(y_i|f_i)] over the shard's points (no scale, no KL), so that
  * ranks sum partials with ONE all-reduce and subtract the KL once (SVA:355-359).
- * partial_out[4] = {sum_expectation, n_points, n_neg_var, chol_info}. */
+ * partial_out[4] = {sum_expectation, n_points, n_neg_var, chol_info}.  Always LOCAL (never a collective): the building
+ * block for a host that runs its own all-reduce. */
 int32_t svgp_elbo_partial(svgp_ctx* ctx, svgp_model* model, const svgp_data* data, int64_t batch_off,
                           int64_t batch_len, double partial_out[4]);
 /* KL(q || p) and logdet(Kuu) of the model alone: _prior_kl  SVA:362-373 */
@@ -168,10 +209,20 @@ typedef struct svgp_grads {
   void* m;
   void* Lq;
 } svgp_grads;
+/* On a context with a communicator: COLLECTIVE — value and gradient of the global ELBO on every rank (the batch size
+ * is all-reduced on the device before the backward pass, the gradient by one grouped ncclAllReduce after it). */
 int32_t svgp_elbo_grad(svgp_ctx* ctx, svgp_model* model, const svgp_data* data, int64_t batch_off, int64_t batch_len,
                        double num_data, double* elbo_out, svgp_terms* terms_out, svgp_grads* grads_out);
+/* the same two evaluations driven from one process over the members of a group: member i evaluates points
+ * [offs[i], offs[i] + lens[i]) of shards[i]; results are the global ones (read from member 0). */
+int32_t svgp_group_elbo(svgp_group* group, svgp_model* const* models, const svgp_data* const* shards,
+                        const int64_t* offs, const int64_t* lens, double num_data, double* elbo_out,
+                        svgp_terms* terms_out);
+int32_t svgp_group_elbo_grad(svgp_group* group, svgp_model* const* models, const svgp_data* const* shards,
+                             const int64_t* offs, const int64_t* lens, double num_data, double* elbo_out,
+                             svgp_terms* terms_out, svgp_grads* grads_out);
 /* data-parallel shard of the value-and-gradient (the gradient counterpart of svgp_elbo_partial):
- *   value = scale * Σ_{i in shard} E_{q(f_i)}[log p(y_i|f_i)] - kl_weight * KL   and its gradient.
+ *   value = scale * Σ_{i in shard} E_{q(f_i)}[log p(y_i|f_i)] - kl_weight * KL   and its gradient.  Always LOCAL.
  * With scale = num_data / n_global and kl_weight = 1 / world_size on every rank, ONE sum all-reduce of
  * (value, gradients) is the global ELBO (SVA:355-359) and its gradient, for both parametrisations
  * (terms_out->elbo holds the same value; terms_out->scale = scale). */

@@ -96,3 +96,49 @@ def test_two_rank_gloo_elbo_equals_single_process(tmp_path):
     mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
     val, full = np.load(out)
     assert val == pytest.approx(full, rel=1e-12)
+
+
+def _failing_worker(rank, world, port, out):
+    """Rank 1's evaluation raises (a DomainError-like condition that depends on its shard): both ranks must come out of
+    the step with an exception instead of rank 0 waiting in the all-reduce forever (distributed.py)."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "approximategps.jl_amd"))
+    import datetime
+
+    import torch.distributed as dist
+
+    from approxgp.distributed import ShardedELBO
+
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=60))
+
+    class Model:
+        def elbo_partial(self, data, off, length):
+            if rank == 1:
+                raise ArithmeticError("negative variance on this shard")
+            return np.array([-12.5, float(length), 0.0, 0.0])
+
+        def prior_kl(self):
+            return 0.75, 0.0
+
+    sh = ShardedELBO(Model(), None, 1000.0)
+    try:
+        sh.step(0, 10)
+        res = "no exception"
+    except ArithmeticError as e:
+        res = "own:" + str(e)
+    except RuntimeError as e:
+        res = "peer:" + str(e)
+    with open(f"{out}.{rank}", "w") as f:
+        f.write(res)
+    dist.destroy_process_group()
+
+
+def test_failing_rank_does_not_hang_the_others(tmp_path):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = str(tmp_path / "fail")
+    mp.spawn(_failing_worker, args=(2, port, out), nprocs=2, join=True)
+    assert open(out + ".0").read().startswith("peer:a rank failed")
+    assert open(out + ".1").read().startswith("own:negative variance")

@@ -60,3 +60,94 @@ def test_two_ranks_on_one_gpu_match_single_process(tmp_path, centered):
     errs = np.load(out)
     assert errs[0] < 1e-8 and errs[1] < 1e-8, errs      # fp64 ELBO contract
     assert errs[2:].max() < 1e-6, errs                  # gradient blocks, relative to their max-norm
+
+
+# ---- the collective INSIDE the library (csrc/comm.hip) -----------------------------------------------------------
+# The test box has one GPU and RCCL refuses the same device twice in one communicator, so what runs here is a world of
+# one rank: the full code path (dlopen of librccl, ncclCommInitRank / ncclCommInitAll, ncclAllReduce of the
+# device-resident vectors on the context's stream, grouped gradient all-reduce, status flags), with a sum over one rank.
+def _problem(centered, dtype=np.float64):
+    import svgp_oracle as o
+
+    N, M, d = 3001, 96, 3
+    x, y, nc, s2 = o.synth_problem(72, N, M, d, family=o.KERNEL_MATERN52, dtype=dtype)
+    sva = o.SVA(nc.kernel, nc.z, nc.m + 0.2, 0.8 * nc.Lq, jitter=nc.jitter, mean_const=0.1, centered=True) if centered else nc
+    return x, y, sva, s2
+
+
+@pytest.mark.parametrize("centered", [False, True])
+def test_library_collective_world_of_one(centered):
+    for p in (os.path.join(ROOT, "approximategps.jl_amd"), os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import svgp_oracle as o
+    from approxgp import _ffi
+    from helpers import device_model
+
+    x, y, sva, s2 = _problem(centered)
+    ctx = _ffi.Context(0)
+    model = device_model(ctx, sva, sigma2=s2)
+    data = _ffi.DeviceData(ctx, x, y, np.float64)
+    local = model.elbo(data, 100, 1500, 9000.0)
+    lv, _, lg = model.elbo_grad(data, 100, 1500, 9000.0)
+    ctx.attach_comm(_ffi.comm_unique_id(), 1, 0)
+    assert ctx.comm_info() == (1, 0)
+    val, t = model.elbo(data, 100, 1500, 9000.0)            # collective path: ncclAllReduce on d_res
+    assert val == local[0] and t.n_points == 1500 and t.scale == 6.0
+    gv, gt, gg = model.elbo_grad(data, 100, 1500, 9000.0)   # n_global all-reduced on the device, grouped gradient all-reduce
+    assert abs(gv - lv) <= 1e-12 * abs(lv) and gt.n_points == 1500
+    for k in ("variance", "lik_sigma2", "mean_const", "inv_lengthscale", "z", "m", "Lq"):
+        np.testing.assert_allclose(np.asarray(gg[k]), np.asarray(lg[k]), rtol=1e-12, atol=1e-13)
+    assert abs(val - o.elbo(sva, x[:, 100:1600], y[100:1600], sigma2=s2, num_data=9000.0)) <= 1e-8 * abs(val)
+    # a local argument error still goes through the collective and comes back as the argument error
+    with pytest.raises(ValueError):
+        model.elbo(data, 2900, 500, 0.0)
+    assert model.elbo(data, 100, 1500, 9000.0)[0] == val      # and the communicator is still usable
+    # status travels in the reduced vector: a non-PD Kuu is reported collectively
+    bad = device_model(ctx, o.SVA(sva.kernel, sva.z, sva.m, sva.Lq, jitter=-1.0, centered=sva.centered, mean_const=sva.mean_const))
+    with pytest.raises(_ffi.PosDefException):
+        bad.elbo(data, 0, 500, 0.0)
+    ctx.detach_comm()
+    assert ctx.comm_info() == (1, 0)
+    assert model.elbo(data, 100, 1500, 9000.0)[0] == val
+    for h in (bad, model, data):
+        h.free()
+    ctx.close()
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_group_of_one_device_matches_plain_context(dtype):
+    """svgp_group_* (one process driving the GPUs, ncclCommInitAll): upload sharding, replicated model, group elbo and
+    value-and-gradient against the plain single-context calls on the same data."""
+    for p in (os.path.join(ROOT, "approximategps.jl_amd"), os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    from approxgp import _ffi
+    from helpers import desc_from_oracle, device_model
+
+    x, y, sva, s2 = _problem(False, dtype)
+    ctx = _ffi.Context(0)
+    model = device_model(ctx, sva, dtype=dtype, sigma2=s2)
+    data = _ffi.DeviceData(ctx, x, y, dtype)
+    ref, rt = model.elbo(data, 0, None, 12000.0)
+    rv, _, rg = model.elbo_grad(data, 200, 2048, 12000.0)
+    grp = _ffi.Group([0])
+    grp.upload(x, y, dtype)
+    desc, keep = desc_from_oracle(sva, dtype=dtype, sigma2=s2)
+    grp.create_model(desc, keep)
+    val, t = grp.elbo(num_data=12000.0)
+    assert val == ref and t.n_points == x.shape[1] and t.kl == rt.kl
+    gv, gt, gg = grp.elbo_grad(offs=[200], lens=[2048], num_data=12000.0)
+    tol = 1e-12 if dtype == np.float64 else 1e-5
+    assert abs(gv - rv) <= tol * abs(rv)
+    for k in ("variance", "inv_lengthscale", "z", "m", "Lq"):
+        np.testing.assert_allclose(np.asarray(gg[k], dtype=np.float64), np.asarray(rg[k], dtype=np.float64), rtol=tol, atol=tol)
+    # RowVecs upload goes through the strided gather
+    grp2 = _ffi.Group([0])
+    grp2.upload(np.ascontiguousarray(x.T), y, dtype, layout=_ffi.ROWVECS)
+    desc, keep = desc_from_oracle(sva, dtype=dtype, sigma2=s2)
+    grp2.create_model(desc, keep)
+    assert grp2.elbo(num_data=12000.0)[0] == ref
+    for h in (grp2, grp, model, data):
+        (h.close if hasattr(h, "close") else h.free)()
+    ctx.close()
