@@ -9,9 +9,12 @@ A step is ONE full ELBO evaluation (reference elbo(sva, lfx, y), SVA:340-360) ov
 data already resident in HBM: Kuu assembly, cholesky(Kuu), diagonal-block inverses / T panels, KL, then the
 fused Kuf -> trsm -> trmm -> expectation pass over every point, and the read-back of the scalar.
 Workload H: N = 1e6 points per GPU, M = 1024, d = 8, SE-ARD, Gaussian likelihood, fp64,
-NonCentered.  With N GPUs every rank holds its own 1e6-point shard (weak scaling), evaluates its partial
-sum, and ONE all-reduce (RCCL) of 4 doubles combines them; `value` is then whole-job 1e6-point ELBO
-evaluations per second.
+NonCentered.  With N GPUs every rank holds its own 1e6-point shard (weak scaling) and calls the library's COLLECTIVE
+svgp_elbo: the ranks' partial sums are combined by ONE ncclAllReduce of 8 doubles issued inside the library on the
+device-resident result (csrc/comm.hip; torch.distributed only carries the 128-byte communicator id and the timing
+barrier); `value` is then whole-job 1e6-point ELBO evaluations per second.  The same line carries `c5_minibatch`:
+BASELINE's 8-GPU configuration C5 (fp32, 2^18 points per GPU per step, num_data = 1e8) through the same path.
+Inputs come from approxgp/synthetic.py, the one §8d recipe the parity tests use too (z = first M points of x + 1e-3 noise).
 """
 import argparse
 import json
@@ -30,54 +33,71 @@ SE, M32, M52 = 0, 1, 2
 GAUSS, BERN, POIS = 0, 1, 2
 
 CONFIGS = {
-    # name: (n_per_gpu, M, d, family, lik, dtype)
-    "H": (1_000_000, 1024, 8, SE, GAUSS, "f64"),      # headline metric
-    "H32": (1_000_000, 1024, 8, SE, GAUSS, "f32"),
-    "H896": (1_000_000, 896, 8, SE, GAUSS, "f64"),     # leading-dimension experiments (Mp*8 not a power of two)
-    "H1152": (1_000_000, 1152, 8, SE, GAUSS, "f64"),
-    "C2": (100_000, 512, 8, SE, GAUSS, "f64"),
-    "C3": (1_000_000, 2048, 16, M52, BERN, "f32"),
-    "C4": (100_000, 8192, 8, SE, GAUSS, "f32"),
-    "C5": (262_144, 1024, 8, SE, GAUSS, "f32"),        # per-GPU minibatch of the 8-GPU config
+    # name: (n_per_gpu, M, d, family, lik, dtype, §8d config id = seed offset)
+    "H": (1_000_000, 1024, 8, SE, GAUSS, "f64", 6),      # headline metric
+    "H32": (1_000_000, 1024, 8, SE, GAUSS, "f32", 6),
+    "H896": (1_000_000, 896, 8, SE, GAUSS, "f64", 6),     # leading-dimension experiments (Mp*8 not a power of two)
+    "H1152": (1_000_000, 1152, 8, SE, GAUSS, "f64", 6),
+    "C2": (100_000, 512, 8, SE, GAUSS, "f64", 2),
+    "C3": (1_000_000, 2048, 16, M52, BERN, "f32", 3),
+    "C4": (100_000, 8192, 8, SE, GAUSS, "f32", 4),
+    "C5": (262_144, 1024, 8, SE, GAUSS, "f32", 5),        # per-GPU minibatch of the 8-GPU config
 }
+C5_NUM_DATA = 1.0e8
 PEAK_TFLOPS = {"f64": 78.6, "f32": 157.3}  # MI355X dense matrix peaks (AMD spec; MI355X_MICROARCH.md for f32)
 PEAK_HBM_GBS = 8000.0
 
 
 def synth(config_id, n, M, d, family, lik, dtype, rank=0):
-    """SURVEY §8d synthetic problem; the model is identical on every rank, the data shard is per rank."""
-    rng = np.random.default_rng(20260313 + config_id)
-    z = rng.standard_normal((d, M)) + 1e-3 * rng.standard_normal((d, M))
-    ell = math.sqrt(d) * (0.75 + 0.5 * np.arange(d) / d)
-    m = 0.1 * rng.standard_normal(M)
-    Lq = np.eye(M) + 0.05 * np.tril(rng.standard_normal((M, M))) / math.sqrt(M)
-    Lq[np.diag_indices(M)] = np.abs(np.diag(Lq))
-    drng = np.random.default_rng(977 * (rank + 1) + config_id)
-    x = drng.standard_normal((d, n))
-    s = x.sum(axis=0) / math.sqrt(d)
-    sigma2 = 0.3
-    if lik == GAUSS:
-        y = np.sin(s) + math.sqrt(sigma2) * drng.standard_normal(n)
-    else:
-        y = (drng.random(n) < 1.0 / (1.0 + np.exp(-2.0 * np.sin(s)))).astype(np.float64)
+    """SURVEY §8d synthetic problem from the shared recipe (approxgp/synthetic.py): the model is identical on every
+    rank (z = the first M points of shard 0 + 1e-3 noise), the data shard is per rank."""
+    from approxgp.synthetic import synth_arrays
+
     np_dt = np.float64 if dtype == "f64" else np.float32
-    jitter = 1e-5 if dtype == "f64" else 1e-3
-    rt = lambda a: np.asarray(a, dtype=np_dt)
-    return dict(x=rt(x), y=rt(y), z=rt(z), m=rt(m), Lq=rt(Lq), inv_l=1.0 / ell, variance=1.3, sigma2=sigma2,
-                jitter=jitter, np_dt=np_dt)
+    a = synth_arrays(config_id, n, M, d, lik=lik, dtype=np_dt, shard=rank)
+    rt = lambda v: np.asarray(v, dtype=np_dt)
+    return dict(x=rt(a["x"]), y=rt(a["y"]), z=rt(a["z"]), m=rt(a["m"]), Lq=rt(a["Lq"]), inv_l=a["inv_lengthscale"],
+                variance=a["variance"], sigma2=a["sigma2"], jitter=a["jitter"], np_dt=np_dt)
 
 
-def cpu_baseline(p, family, lik, sample, n_full):
+def mem_available_bytes():
+    try:
+        for line in open("/proc/meminfo"):
+            if line.startswith("MemAvailable:"):
+                return int(line.split()[1]) * 1024
+    except OSError:
+        pass
+    return 0
+
+
+def cpu_baseline(p, family, lik, sample, n_full, M):
     """The CPU restatement (oracle, reference operation order: materialise Kuf, trsm, trmm, reductions) timed on
-    the host cores on a bounded sample of the same workload, extrapolated linearly in N."""
+    the host cores.  SURVEY §8d: at the FULL workload when the host has room for the reference's M x N temporaries
+    (MemAvailable >= 5 M N 8 bytes; one evaluation, ~30 s at H), otherwise on a bounded sample extrapolated linearly in N."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import svgp_oracle as o
 
     kernel = o.Kernel(family, p["variance"], p["inv_l"])
     f64 = lambda a: np.asarray(a, dtype=np.float64)
     sva = o.SVA(kernel, f64(p["z"]), f64(p["m"]), f64(p["Lq"]), jitter=p["jitter"])
+    avail, need = mem_available_bytes(), 5 * M * n_full * 8
+    try:
+        from threadpoolctl import threadpool_info
+        threads = max([t.get("num_threads", 1) for t in threadpool_info()] or [os.cpu_count()])
+    except Exception:  # noqa: BLE001
+        threads = os.cpu_count()
+    base = {"unit": "evals/s", "cores": threads, "kind": "port", "host_cpus": os.cpu_count(),
+            "mem_available_GB": round(avail / 1e9, 1), "mem_needed_full_GB": round(need / 1e9, 1)}
+    o.elbo(sva, f64(p["x"][:, :2000]), f64(p["y"][:2000]), lik=lik, sigma2=p["sigma2"])  # warm BLAS threads
+    if avail >= need and os.environ.get("BENCH_CPU_SAMPLE_ONLY") != "1":
+        xs, ys = f64(p["x"]), f64(p["y"])
+        t0 = time.perf_counter()
+        o.elbo(sva, xs, ys, lik=lik, sigma2=p["sigma2"])
+        t_full = time.perf_counter() - t0
+        return dict(base, value=1.0 / t_full,
+                    sample=f"oracle/svgp_oracle.py (numpy + scipy-OpenBLAS, fp64, {threads} BLAS threads) on ALL {n_full} points, "
+                           f"one evaluation = {t_full:.1f} s (no extrapolation)")
     xs, ys = f64(p["x"][:, :sample]), f64(p["y"][:sample])
-    o.elbo(sva, xs[:, :2000], ys[:2000], lik=lik, sigma2=p["sigma2"])  # warm BLAS threads
     t_small = []
     for _ in range(2):
         t0 = time.perf_counter()
@@ -89,24 +109,117 @@ def cpu_baseline(p, family, lik, sample, n_full):
         o.elbo(sva, xs, ys, lik=lik, sigma2=p["sigma2"])
         ts.append(time.perf_counter() - t0)
     t_s, t_2k = float(np.median(ts)), float(min(t_small))
-    per_point = max(t_s - t_2k, 1e-9) / (sample - 2000)          # data-proportional part
+    per_point = max(t_s - t_2k, 1e-9) / max(sample - 2000, 1)    # data-proportional part
     fixed = max(t_2k - 2000 * per_point, 0.0)                    # cholesky(Kuu) etc.
     t_full = fixed + per_point * n_full
-    return {"value": 1.0 / t_full, "unit": "evals/s", "cores": os.cpu_count(), "kind": "port",
-            "sample": f"oracle/svgp_oracle.py (numpy + scipy-OpenBLAS, fp64) on {sample} of the {n_full} points, "
-                      f"median of 3 = {t_s:.2f} s; extrapolated linearly in N to {t_full:.1f} s/eval"}
+    return dict(base, value=1.0 / t_full,
+                sample=f"oracle/svgp_oracle.py (numpy + scipy-OpenBLAS, fp64, {threads} BLAS threads) on {sample} of the {n_full} "
+                       f"points (host RAM below 5 M N 8 bytes), median of 3 = {t_s:.2f} s; extrapolated linearly in N to {t_full:.1f} s/eval")
+
+
+def profile_traffic(config, kernel_prefix):
+    """HBM-side traffic of a kernel: PMC counters cannot be read from inside this process, so the figure is the one
+    measured by tools/run_profile.sh (separate rocprofv3 --pmc passes, FETCH_SIZE doubled as MI355X_MICROARCH.md
+    prescribes for gfx950) and committed under profiles/.  It is labelled with its source, and marked stale when the
+    kernel sources changed after the profile was taken (the summary records their hash)."""
+    import glob
+    import hashlib
+
+    h = hashlib.sha256()
+    for f in ("strip.hip", "device_common.hpp"):
+        h.update(open(os.path.join(ROOT, "approximategps.jl_amd", "csrc", f), "rb").read())
+    cur = h.hexdigest()[:16]
+    cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "round*", f"{config}_*_pmc.json")), key=os.path.getmtime)
+    for path in reversed(cands):
+        try:
+            pm = json.load(open(path))
+        except (OSError, ValueError):
+            continue
+        e = next((v for k, v in pm.items() if k.startswith(kernel_prefix) and isinstance(v, dict)), None)
+        if e is None or e.get("traffic_bytes_per_launch") is None:
+            continue
+        src_hash = pm.get("kernel_source_sha16")
+        return {"traffic": e["traffic_bytes_per_launch"], "traffic_source": os.path.relpath(path, ROOT) + " (rocprofv3 --pmc, not measured in this run)",
+                "traffic_stale": (src_hash != cur) if src_hash else None, "hbm_share_note": pm.get("hbm_share_note")}
+    return None
+
+
+def bench_config(args, name, ctx, torch, dist, dev, world, rank, use_dist, steps, warmup, num_data_override=None):
+    """Times `steps` full elbo evaluations of config `name` (after `warmup`), barrier + synchronize on both sides, MAX over
+    ranks.  Returns (dict of measurements, model, data, p) with the model and data still resident."""
+    from approxgp import _ffi
+
+    n, M, d, family, lik, dtype, cid = CONFIGS[name]
+    p = synth(cid, n, M, d, family, lik, dtype, rank)
+    desc, keep = _ffi.make_desc(p["np_dt"], family, p["variance"], p["inv_l"], p["z"], p["m"], p["Lq"], p["jitter"],
+                                likelihood=lik, lik_sigma2=p["sigma2"])
+    model = _ffi.DeviceModel(ctx, desc, keep)
+    data = _ffi.DeviceData(ctx, p["x"], p["y"], p["np_dt"])
+    num_data = float(num_data_override if num_data_override else n * world)
+
+    def step():
+        # prep + fused strips + reduce (HIP library); with a communicator on ctx this call is the library's collective:
+        # ONE ncclAllReduce of the device-resident 8-vector, every rank gets the global ELBO
+        return model.elbo(data, 0, n, num_data)
+
+    def fence():
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(warmup):
+        step()
+    strip_ms, prep_ms, expect_ms = [], [], []
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        val, terms = step()
+        t = ctx.timing()
+        strip_ms.append(t.ms_strip)
+        prep_ms.append(t.ms_prep)
+        expect_ms.append(t.ms_expect)
+    fence()
+    elapsed = time.perf_counter() - t0
+    if use_dist:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    Mp = (M + 127) // 128 * 128
+    strip_w = 64 if (dtype == "f64" or Mp > 2048) else 128   # strip.hip: strip_nt()
+    strip_avg_ms = float(np.mean(strip_ms))
+    flops_strip = 2.0 * M * M * n                           # algorithmic: trsm + trmm (SURVEY §8d)
+    ach = flops_strip / (strip_avg_ms * 1e-3) / 1e12
+    res = {
+        "elapsed": elapsed, "ms_per_step": 1e3 * elapsed / steps, "evals_per_s": world * steps / elapsed,
+        "points_per_s": n * world * steps / elapsed, "elbo": val, "n_points_global": int(terms.n_points),
+        "roofline": {"kernel": "strip_kernel (fused Kuf -> trsm -> trmm)", "bound": "mfma", "achieved": ach,
+                     "peak": PEAK_TFLOPS[dtype], "unit": "TFLOP/s", "frac": ach / PEAK_TFLOPS[dtype], "traffic": None,
+                     "flops_per_launch": flops_strip, "ms_per_launch": strip_avg_ms,
+                     # MFMA work actually issued: full 128-row blocks below the diagonal + 20 of the 32 tile-steps of every
+                     # (triangular) diagonal block, per phase, on whole strips (matches SQ_INSTS_MFMA x 2048 of the PMC profile)
+                     "executed_flops_per_launch": 2.0 * 2.0 * 128 * 128 * ((Mp // 128) * (Mp // 128 - 1) / 2 + 0.625 * (Mp // 128))
+                     * strip_w * math.ceil(n / strip_w)},
+        "breakdown_ms": {"prep (Kuu, cholesky, T panels, KL)": float(np.mean(prep_ms)), "strip": strip_avg_ms,
+                         "expectation + reduce (+ all-reduce)": float(np.mean(expect_ms))},
+        "workload": f"{name}: N={n} points per GPU, M={M}, d={d}, {['SE', 'Matern32', 'Matern52'][family]}-ARD, "
+                    f"{['Gaussian', 'Bernoulli-logistic GH-20', 'Poisson'][lik]}, {dtype}, NonCentered; "
+                    "one step = one full elbo(sva, lfx, y) incl. cholesky(Kuu)",
+        "num_data": num_data,
+    }
+    return res, model, data, p
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=100)      # H: 100 x 34 ms: a timed region of > 3 s
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", default="H", choices=sorted(CONFIGS))
-    ap.add_argument("--cpu-sample", type=int, default=100000)   # ~10 s of host work at H
+    ap.add_argument("--cpu-sample", type=int, default=100000)   # ~10 s of host work at H (used when RAM is short)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kuf", action="store_true")
     ap.add_argument("--no-grad", action="store_true")
+    ap.add_argument("--no-c5", action="store_true")
     args = ap.parse_args()
 
     # Everything but the final JSON line goes to stderr: RCCL prints a version banner (and warnings) on the C stdout,
@@ -130,181 +243,145 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     use_dist = world > 1 or os.environ.get("BENCH_FORCE_DIST") == "1"   # the env knob exercises the RCCL path on one GPU
+    stream = torch.cuda.current_stream().cuda_stream
+    ctx = _ffi.Context(local_rank, stream if stream else None)
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        from approxgp.distributed import attach_comm_via_torch
+        attach_comm_via_torch(ctx)                            # the library's own RCCL communicator (ncclCommInitRank)
+        assert ctx.comm_info() == (world, rank)
 
-    n, M, d, family, lik, dtype = CONFIGS[args.config]
-    cid = sorted(CONFIGS).index(args.config)
-    p = synth(cid, n, M, d, family, lik, dtype, rank)
-    stream = torch.cuda.current_stream().cuda_stream
-    ctx = _ffi.Context(local_rank, stream if stream else None)
-    desc, keep = _ffi.make_desc(p["np_dt"], family, p["variance"], p["inv_l"], p["z"], p["m"], p["Lq"], p["jitter"],
-                                likelihood=lik, lik_sigma2=p["sigma2"])
-    model = _ffi.DeviceModel(ctx, desc, keep)
-    data = _ffi.DeviceData(ctx, p["x"], p["y"], p["np_dt"])
-    num_data = float(n * world)
+    name = args.config
+    n, M, d, family, lik, dtype, cid = CONFIGS[name]
+    res, model, data, p = bench_config(args, name, ctx, torch, dist, dev, world, rank, use_dist, args.steps, args.warmup)
+    num_data = res["num_data"]
+    out = {
+        "metric": "SVGP ELBO evals/sec at N=1e6, M=1024" if name in ("H", "H32") else f"SVGP ELBO evals/sec ({name})",
+        "value": res["evals_per_s"], "unit": "evals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": res["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": dtype, "data": "synthetic",
+        "config": {"workload": res["workload"], "global_points": n * world, "points_per_s": res["points_per_s"],
+                   "parallelism": f"data-parallel shards x{world}; one 8-double ncclAllReduce per eval inside the library "
+                                  "(svgp_elbo on a context with a communicator)" if use_dist else "single GPU",
+                   "elbo": res["elbo"], "timed_region_s": res["elapsed"]},
+        "roofline": res["roofline"], "breakdown_ms": res["breakdown_ms"],
+    }
+    if use_dist:
+        assert res["n_points_global"] == n * world, (res["n_points_global"], n, world)
+    tr = profile_traffic(name, "strip_kernel<") if rank == 0 else None
+    if tr:
+        out["roofline"].update({k: v for k, v in tr.items() if v is not None or k == "traffic_stale"})
+        out["roofline"]["traffic_note"] = ("bytes per launch at the L2<->fabric boundary (FETCH_SIZE x2 + WRITE_SIZE); includes "
+                                           "Infinity-Cache hits of the per-workgroup scratch strips; algorithmic HBM bytes are "
+                                           f"{(8 if dtype == 'f64' else 4) * n * (d + 1) + 16 * n} B")
 
-    from approxgp.distributed import allreduce_partials, combine
-
-    def step():
-        part = model.elbo_partial(data, 0, n)              # prep + fused strips + read-back (HIP library)
-        kl, _ = model.prior_kl()                           # cached scalars of the same prep
-        if use_dist:
-            part = allreduce_partials(part, device=dev)    # ONE RCCL all-reduce of 4 doubles
-        else:
-            part = np.array([part[0], part[1], part[2], 1.0 if part[3] else 0.0])
-        return combine(part, kl, num_data)
-
-    def fence():
-        if use_dist:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    # Kuf assembly alone (SVA:216): M x n column-major written once -> HBM-write bound.  Measured before the ELBO loop
-    # (its own launches, its own HIP events): the figure is a property of this kernel, not of what ran before it.
-    kuf_roofline = None
+    # Kuf assembly alone (SVA:216): M x n column-major written once -> HBM-write bound.  Its own launches, its own HIP
+    # events (recorded by the library on its stream around the launch), AFTER the ELBO loop so the clocks are up:
+    # median and p95 over 32 launches.
     if rank == 0 and world == 1 and not args.no_kuf:
         es = 8 if dtype == "f64" else 4
         times = []
-        for _ in range(8):
+        for _ in range(34):
             model.kuf(data, 0, n, fetch=False)
             times.append(ctx.timing().ms_kuf)
-        t_kuf = float(np.median(times[1:]))
+        times = times[2:]
+        t_kuf = float(np.median(times))
         bytes_alg = es * (M * n + n * d + M * d)
         gbs = bytes_alg / (t_kuf * 1e-3) / 1e9
         kuf_roofline = {"kernel": "kuf_kernel", "bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS,
                         "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS, "traffic": None,
-                        "bytes_per_launch": bytes_alg, "ms_per_launch": t_kuf,
-                        "ms_per_launch_all": [round(t, 4) for t in times]}
+                        "bytes_per_launch": bytes_alg, "ms_per_launch": t_kuf, "launches": len(times),
+                        "ms_p95": float(np.percentile(times, 95)), "ms_min": float(np.min(times)),
+                        "GBps_p95_launch": bytes_alg / (float(np.percentile(times, 95)) * 1e-3) / 1e9}
         # what a plain write-only stream of the same size reaches on this box (report both)
         try:
             buf = torch.empty(M * n, dtype=torch.float64 if dtype == "f64" else torch.float32, device=dev)
             ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
             ts = []
-            for _ in range(6):
+            for _ in range(12):
                 ev[0].record()
                 buf.fill_(1.0)
                 ev[1].record()
                 torch.cuda.synchronize()
                 ts.append(ev[0].elapsed_time(ev[1]))
-            t_fill = float(np.median(ts[1:]))
+            t_fill = float(np.median(ts[2:]))
             kuf_roofline["stream_write_GBps"] = es * M * n / (t_fill * 1e-3) / 1e9
             kuf_roofline["frac_of_stream_write"] = gbs / kuf_roofline["stream_write_GBps"]
             del buf
         except Exception as e:  # noqa: BLE001
             kuf_roofline["stream_write_GBps"] = None
             kuf_roofline["stream_write_error"] = repr(e)
-
-    for _ in range(args.warmup):
-        step()
-    strip_ms, prep_ms, expect_ms = [], [], []
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        val = step()
-        t = ctx.timing()
-        strip_ms.append(t.ms_strip)
-        prep_ms.append(t.ms_prep)
-        expect_ms.append(t.ms_expect)
-    fence()
-    elapsed = time.perf_counter() - t0
-    if use_dist:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
-
-    ms_per_step = 1e3 * elapsed / args.steps
-    value = world * args.steps / elapsed                    # 1e6-point ELBO evaluations per second, whole job
-    strip_avg_ms = float(np.mean(strip_ms))
-    Mp = (M + 127) // 128 * 128
-    strip_w = 64 if (dtype == "f64" or Mp > 2048) else 128   # strip.hip: strip_nt()
-    flops_strip = 2.0 * M * M * n                           # algorithmic: trsm + trmm
-    ach = flops_strip / (strip_avg_ms * 1e-3) / 1e12
-    out = {
-        "metric": "SVGP ELBO evals/sec at N=1e6, M=1024" if args.config in ("H", "H32") else f"SVGP ELBO evals/sec ({args.config})",
-        "value": value, "unit": "evals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": dtype, "data": "synthetic",
-        "config": {"workload": f"{args.config}: N={n} points per GPU, M={M}, d={d}, "
-                               f"{['SE', 'Matern32', 'Matern52'][family]}-ARD, "
-                               f"{['Gaussian', 'Bernoulli-logistic GH-20', 'Poisson'][lik]}, {dtype}, NonCentered; "
-                               "one step = one full elbo(sva, lfx, y) incl. cholesky(Kuu)",
-                   "global_points": n * world, "points_per_s": n * world * args.steps / elapsed,
-                   "parallelism": f"data-parallel shards x{world}, one 4-double all-reduce per eval",
-                   "elbo": val},
-        "roofline": {"kernel": "strip_kernel (fused Kuf -> trsm -> trmm)", "bound": "mfma", "achieved": ach,
-                     "peak": PEAK_TFLOPS[dtype], "unit": "TFLOP/s", "frac": ach / PEAK_TFLOPS[dtype], "traffic": None,
-                     "flops_per_launch": flops_strip, "ms_per_launch": strip_avg_ms,
-                     # MFMA work actually issued: full 128-row blocks below the diagonal + 20 of the 32 tile-steps of every
-                     # (triangular) diagonal block, per phase, on whole strips (matches SQ_INSTS_MFMA x 2048 of the PMC profile)
-                     "executed_flops_per_launch": 2.0 * 2.0 * 128 * 128 * ((Mp // 128) * (Mp // 128 - 1) / 2 + 0.625 * (Mp // 128))
-                     * strip_w * math.ceil(n / strip_w)},
-        "breakdown_ms": {"prep (Kuu, cholesky, T panels, KL)": float(np.mean(prep_ms)), "strip": strip_avg_ms,
-                         "expectation + reduce": float(np.mean(expect_ms))},
-    }
-
-    # HBM-side traffic of the dominant kernel: PMC counters cannot be read from inside this process, so the
-    # figure is the one measured by tools/run_profile.sh (separate rocprofv3 --pmc passes) for this workload.
-    pmc_path = os.path.join(ROOT, "profiles", "round1", "H_fp64_v8_pmc.json")
-    pm = {}
-    if args.config == "H":
-        try:   # a missing / reshaped summary must never cost the benchmark line
-            pm = json.load(open(pmc_path))
-        except (OSError, ValueError):
-            pm = {}
-    strip_pm = next((v for k, v in pm.items() if k.startswith("strip_kernel<double") and isinstance(v, dict)), None)
-    if strip_pm is not None:
-        out["roofline"]["traffic"] = strip_pm.get("traffic_bytes_per_launch")
-        out["roofline"]["traffic_note"] = ("bytes per launch at the L2<->fabric boundary (FETCH_SIZE x2 + WRITE_SIZE, "
-                                           "profiles/round1/H_fp64_v8_pmc.json); includes Infinity-Cache hits of the per-workgroup "
-                                           "scratch strips; algorithmic HBM bytes are 88 MB")
-    if kuf_roofline is not None:
-        kuf_pm = next((v for k, v in pm.items() if k.startswith("kuf_kernel<double") and isinstance(v, dict)), None)
-        if kuf_pm is not None:
-            kuf_roofline["traffic"] = kuf_pm.get("traffic_bytes_per_launch")
+        tk = profile_traffic(name, "kuf_kernel<")
+        if tk:
+            kuf_roofline.update({k: v for k, v in tk.items() if k != "hbm_share_note" and (v is not None or k == "traffic_stale")})
         out["kuf_roofline"] = kuf_roofline
-    if rank == 0 and world == 1 and not args.no_grad:
-        # value-and-gradient evaluation (svgp_elbo_grad: what a training step costs), same workload, same residency
+
+    def fence():
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    if not args.no_grad:
+        # value-and-gradient evaluation (svgp_elbo_grad: what a training step costs), same workload, same residency; on N > 1
+        # GPUs the library's collective form (batch size all-reduced on the device, one grouped gradient all-reduce).
+        # Reported beside the headline, never part of it; a failure here must not cost the main line.
         try:
             model.elbo_grad(data, 0, n, num_data)
-            tg = []
-            for _ in range(3):
-                t0 = time.perf_counter()
-                model.elbo_grad(data, 0, n, num_data)
-                tg.append(time.perf_counter() - t0)
-            out["value_and_gradient"] = {"evals_per_s": 1.0 / min(tg), "ms_per_eval": 1e3 * min(tg),
-                                         "ratio_to_forward": 1e3 * min(tg) / ms_per_step}
-        except Exception as e:  # noqa: BLE001  (reported beside the headline, never part of it)
-            out["value_and_gradient"] = {"error": repr(e)}
-    if use_dist and not args.no_grad:
-        # data-parallel training step: every rank's shard gradient (svgp_elbo_grad_shard), ONE sum all-reduce of the flat
-        # [value, gradients] vector (about 8.4 MB fp64 at M = 1024) over RCCL.  Reported beside the headline, never part of it;
-        # a failure here must not cost the main line.
-        try:
-            from approxgp.distributed import ShardedELBO
-            sh = ShardedELBO(model, data, num_data=num_data, device=dev)
-            sh.step_grad(0, n, n_global=n * world, world=world)
             fence()
             t0 = time.perf_counter()
-            for _ in range(3):
-                gval, _ = sh.step_grad(0, n, n_global=n * world, world=world)
+            reps = 3
+            for _ in range(reps):
+                gval, _, _ = model.elbo_grad(data, 0, n, num_data)
             fence()
-            tg = torch.tensor([(time.perf_counter() - t0) / 3], dtype=torch.float64, device=dev)
-            dist.all_reduce(tg, op=dist.ReduceOp.MAX)
-            out["distributed_value_and_gradient"] = {"ms_per_step": 1e3 * float(tg.item()), "global_points": n * world,
-                                                     "value": gval}
+            tg = (time.perf_counter() - t0) / reps
+            if use_dist:
+                tt = torch.tensor([tg], dtype=torch.float64, device=dev)
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                tg = float(tt.item())
+            out["value_and_gradient"] = {"evals_per_s": world / tg, "ms_per_eval": 1e3 * tg,
+                                         "ratio_to_forward": 1e3 * tg / res["ms_per_step"], "value": gval}
         except Exception as e:  # noqa: BLE001
-            out["distributed_value_and_gradient"] = {"error": repr(e)}
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        try:
-            out["cpu_baseline"] = cpu_baseline(p, family, lik, min(args.cpu_sample, n), n)
-            out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
-        except Exception as e:  # noqa: BLE001
-            out["cpu_baseline"] = {"value": None, "unit": "evals/s", "cores": os.cpu_count(), "kind": "port", "sample": "failed: " + repr(e)}
+            out["value_and_gradient"] = {"error": repr(e)}
     model.free()
     data.free()
+
+    if name == "H" and not args.no_c5:
+        # BASELINE config C5 (8 x MI355X: minibatched ELBO, N = 1e8, per-GPU batch 2^18, M = 1024, fp32) through the same
+        # collective path: every rank evaluates its own 2^18-point minibatch per step, scale = 1e8 / (world * 2^18).
+        try:
+            c5, m5, d5, _ = bench_config(args, "C5", ctx, torch, dist, dev, world, rank, use_dist, max(20, args.steps), 5,
+                                         num_data_override=C5_NUM_DATA)
+            c5out = {"workload": c5["workload"] + f"; num_data = {C5_NUM_DATA:.0e}, global minibatch = {world} x 262144",
+                     "minibatch_steps_per_s": c5["evals_per_s"] / world, "ms_per_step": c5["ms_per_step"],
+                     "points_per_s": c5["points_per_s"], "dtype": "f32", "roofline": c5["roofline"],
+                     "breakdown_ms": c5["breakdown_ms"], "elbo": c5["elbo"]}
+            if not args.no_grad:
+                m5.elbo_grad(d5, 0, 262144, C5_NUM_DATA)
+                fence()
+                t0 = time.perf_counter()
+                for _ in range(5):
+                    m5.elbo_grad(d5, 0, 262144, C5_NUM_DATA)
+                fence()
+                tg = (time.perf_counter() - t0) / 5
+                if use_dist:
+                    tt = torch.tensor([tg], dtype=torch.float64, device=dev)
+                    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                    tg = float(tt.item())
+                c5out["training_step_ms (value + gradient, all-reduced)"] = 1e3 * tg
+            m5.free()
+            d5.free()
+            out["c5_minibatch"] = c5out
+        except Exception as e:  # noqa: BLE001
+            out["c5_minibatch"] = {"error": repr(e)}
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        try:
+            out["cpu_baseline"] = cpu_baseline(p, family, lik, min(args.cpu_sample, n), n, M)
+            out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
+        except Exception as e:  # noqa: BLE001
+            out["cpu_baseline"] = {"value": None, "unit": "evals/s", "cores": os.cpu_count(), "kind": "port", "sample": "failed: " + repr(e)}
     ctx.close()
     if use_dist:
         dist.barrier()

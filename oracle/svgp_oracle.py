@@ -502,35 +502,20 @@ def synth_problem(
     jitter: Optional[float] = None,
 ):
     """Seeded synthetic (x, y, sva, lik params) per SURVEY §8d.  Returned arrays are fp64
-    rounded through ``dtype`` so fp32 runs and the fp64 oracle see identical inputs."""
-    rng = np.random.default_rng(20260313 + config_id)
-    x = rng.standard_normal((d, N))
-    zbase = x[:, :M] if M <= N else rng.standard_normal((d, M))  # more inducing points than data: fresh draws
-    z = zbase + 1e-3 * rng.standard_normal((d, M))
-    ell = math.sqrt(d) * (0.75 + 0.5 * np.arange(d) / d)
-    kernel = Kernel(family, 1.3, 1.0 / ell)
-    m = 0.1 * rng.standard_normal(M)
-    Lq = np.eye(M) + 0.05 * np.tril(rng.standard_normal((M, M))) / math.sqrt(M)
-    Lq[np.diag_indices(M)] = np.abs(np.diag(Lq))
-    s = x.sum(axis=0) / math.sqrt(d)
-    sigma2 = 0.3
-    if lik == LIK_GAUSSIAN:
-        y = np.sin(s) + math.sqrt(sigma2) * rng.standard_normal(N)
-    elif lik == LIK_BERNOULLI_LOGISTIC:
-        p = 1.0 / (1.0 + np.exp(-2.0 * np.sin(s)))
-        y = (rng.random(N) < p).astype(np.float64)
-    elif lik == LIK_POISSON_EXP:
-        y = rng.poisson(np.exp(np.sin(s))).astype(np.float64)
-    elif lik == LIK_EXPONENTIAL_EXP:
-        y = rng.exponential(np.exp(np.sin(s)))   # numpy's argument is the scale, as Distributions.Exponential's
-    else:
-        sigma2 = 2.5  # the Gamma shape alpha travels in the likelihood-parameter slot
-        y = rng.gamma(sigma2, np.exp(np.sin(s)))
-    if jitter is None:
-        jitter = 1e-5 if np.dtype(dtype) == np.float64 else 1e-3
-    rt = lambda a: np.asarray(a, dtype=dtype).astype(np.float64)
-    sva = SVA(kernel, rt(z), rt(m), rt(Lq), jitter=jitter)
-    return rt(x), rt(y), sva, sigma2
+    rounded through ``dtype`` so fp32 runs and the fp64 oracle see identical inputs.  The recipe itself lives in
+    approxgp/synthetic.py (pure numpy input generation, shared with bench.py so the benchmarked problem is the tested
+    one); this wrapper only packs the arrays into the oracle's SVA."""
+    try:
+        from approxgp.synthetic import synth_arrays
+    except ImportError:  # oracle used on its own: the package sits beside this directory
+        import os
+        import sys
+
+        sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "approximategps.jl_amd"))
+        from approxgp.synthetic import synth_arrays
+    a = synth_arrays(config_id, N, M, d, lik=lik, dtype=dtype, jitter=jitter)
+    sva = SVA(Kernel(family, a["variance"], a["inv_lengthscale"]), a["z"], a["m"], a["Lq"], jitter=a["jitter"])
+    return a["x"], a["y"], sva, a["sigma2"]
 
 
 # ----------------------------------------------------------------------------

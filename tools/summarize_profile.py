@@ -53,7 +53,13 @@ def main():
             dur[k].append(t)
     ms = {k: sum(v) / len(v) / 1e6 for k, v in dur.items()}
     tot = {k: sum(v) for k, v in dur.items()}
+    import hashlib
+    h = hashlib.sha256()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for f in ("strip.hip", "device_common.hpp"):
+        h.update(open(os.path.join(root, "approximategps.jl_amd", "csrc", f), "rb").read())
     out = {"source": "tools/run_profile.sh: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ_* in three separate passes",
+           "kernel_source_sha16": h.hexdigest()[:16],   # bench.py marks the traffic figure stale when strip.hip / device_common.hpp changed since
            "bench_line": json.loads(open(os.path.join(src, "bench_plain.json")).read().strip().splitlines()[-1])}
     fetch, write, sq = (counters(os.path.join(src, p)) for p in ("fetch", "write", "sq"))
     for k in sorted(tot, key=tot.get, reverse=True)[:8]:
