@@ -882,19 +882,20 @@ int grad_workspace(svgp_ctx* ctx, svgp_model* m, int64_t len, GradWs** out) {
   w->ns_uf = nu < 1 ? 1 : (nu > 128 ? 128 : nu);
   w->ns_uu = 8;
   const int dreg = grad_dreg(m->d);
-  // k-major chunk buffers use a leading dimension of nc + 64: a power-of-two row stride (512 KB at nc = 65536) aliases
-  // every row of a store instruction onto the same memory channels
-  const size_t mn = size_t(Mp) * size_t(nc + 64) * es, mm = size_t(Mp) * size_t(Mp) * es;
+  const size_t mn = size_t(Mp) * size_t(nc) * es, mm = size_t(Mp) * size_t(Mp) * es;
   w->g_b = size_t(w->nslices) * mm;
   w->rp_uf_b = size_t(w->ns_uf) * (2 + dreg) * Mp * 8; w->sp_uf_b = size_t(w->ns_uf) * w->rb * (1 + dreg) * 8;
   w->rp_uu_b = size_t(w->ns_uu) * (2 + dreg) * Mp * 8; w->sp_uu_b = size_t(w->ns_uu) * w->rb * (1 + dreg) * 8;
+  w->part5_strips = nc / 32 + 2;   // narrowest strips: 32 points
   struct { void** p; size_t b; } req[] = {
-      {&w->A, mn}, {&w->C, mn}, {&w->Ab, mn}, {&w->At, mn}, {&w->Ct, mn}, {&w->Pt, mn}, {&w->gmu, size_t(nc) * es},
-      {&w->gv, size_t(nc) * es}, {&w->Lqp, mm}, {&w->S, mm}, {&w->G1, w->g_b}, {&w->G2, w->g_b}, {&w->LkRM, mm},
+      {&w->At, mn}, {&w->Pt, mn}, {&w->gmu, size_t(nc) * es},
+      {&w->gv, size_t(nc) * es}, {&w->Lqp, mm}, {&w->S, mm}, {&w->G1, w->g_b}, {&w->G2, mm}, {&w->LkRM, mm},
       {&w->LbarRM, mm}, {&w->Phi, mm}, {&w->tmp, mm}, {&w->H, mm}, {&w->zbar, size_t(m->M) * m->d * es},
-      {&w->mbar, size_t(m->M) * es}, {&w->Lqbar, size_t(m->M) * m->M * es}, {&w->BbarRM, mm}, {&w->rbar, size_t(Mp) * es}, {(void**)&w->rp_uf, w->rp_uf_b},
+      {&w->mbar, size_t(m->M) * es}, {&w->Lqbar, size_t(m->M) * m->M * es}, {&w->BbarRM, mm}, {&w->rbar, size_t(Mp) * es},
+      {&w->W2, mm}, {&w->Rcm, mm}, {&w->G1p, mm}, {&w->alpha, size_t(Mp) * es}, {(void**)&w->avec, size_t(Mp) * 8},
+      {(void**)&w->rp_uf, w->rp_uf_b},
       {(void**)&w->sp_uf, w->sp_uf_b}, {(void**)&w->rp_uu, w->rp_uu_b}, {(void**)&w->sp_uu, w->sp_uu_b},
-      {(void**)&w->partial5, 1024 * 5 * 8}, {(void**)&w->sums, size_t(8 + 1 + dreg) * 8}, {(void**)&w->invl_d, size_t(m->d) * 8}};
+      {(void**)&w->partial5, size_t(w->part5_strips) * 5 * 8}, {(void**)&w->sums, size_t(8 + 1 + dreg) * 8}, {(void**)&w->invl_d, size_t(m->d) * 8}};
   for (auto& r : req) {
     if (hipMalloc(r.p, r.b) != hipSuccess) {
       w->release();
@@ -904,8 +905,8 @@ int grad_workspace(svgp_ctx* ctx, svgp_model* m, int64_t len, GradWs** out) {
     w->all.push_back(*r.p);
   }
   w->scal_out = w->sums + 8;   // contiguous with sums: the data-parallel path all-reduces [sums | scal_out] in one piece
-  // point-major / k-major chunk buffers are read beyond the written columns of a short last chunk: start from zeros
-  for (void* p : {w->A, w->C, w->Ab, w->At, w->Ct, w->Pt})
+  // the point-major chunk buffers are read beyond the written points of a short last chunk (against g_v = 0): start from zeros
+  for (void* p : {w->At, w->Pt})
     if (hipMemsetAsync(p, 0, mn, ctx->stream) != hipSuccess) {
       w->release();
       delete w;
@@ -950,17 +951,16 @@ int grad_enqueue(svgp_ctx* ctx, svgp_model* m, const svgp_data* data, int64_t of
     n_global_dev = ctx->d_coll;
   }
   const int dt = m->dtype;
-  const int64_t Mp = m->Mp, M = m->M, nc = w->nc, ldk = nc + 64;
+  const int64_t Mp = m->Mp, M = m->M, nc = w->nc;
   const size_t es = m->es, mm = size_t(Mp) * Mp * es;
   const int dreg = grad_dreg(m->d);
-  (void)es;
   HIPC(ctx, hipEventRecord(ctx->ev[0], s));
   rc = enqueue_prep(ctx, m);
   if (rc) return rc;
   HIPC(ctx, hipEventRecord(ctx->ev[1], s));
   // accumulators
   HIPC(ctx, hipMemsetAsync(w->G1, 0, w->g_b, s));
-  HIPC(ctx, hipMemsetAsync(w->G2, 0, w->g_b, s));
+  HIPC(ctx, hipMemsetAsync(w->G2, 0, mm, s));
   HIPC(ctx, hipMemsetAsync(w->rp_uf, 0, w->rp_uf_b, s));
   HIPC(ctx, hipMemsetAsync(w->sp_uf, 0, w->sp_uf_b, s));
   HIPC(ctx, hipMemsetAsync(w->rp_uu, 0, w->rp_uu_b, s));
@@ -968,11 +968,17 @@ int grad_enqueue(svgp_ctx* ctx, svgp_model* m, const svgp_data* data, int64_t of
   HIPC(ctx, hipMemsetAsync(w->sums, 0, size_t(8 + 1 + dreg) * 8, s));
   HIPC(ctx, hipMemsetAsync(w->S, 0, mm, s));
   HIPC(ctx, hipMemcpyAsync(w->invl_d, m->invl_host.data(), size_t(m->d) * 8, hipMemcpyHostToDevice, s));
-  // the adjoint runs on the whitened problem: (m~, B) are (m, Lq) for NonCentered and (Lk \\ (m - c), Lk \\ Lq) for Centered
+  // the adjoint runs on the whitened problem: (m~, B) are (m, Lq) for NonCentered and (Lk^-1 (m - c), Lk^-1 Lq) for Centered
   const void* Bq = centered ? m->B : w->Lqp;
   if (!centered) launch_pad_lower(dt, s, m->Lq_raw, M, Mp, w->Lqp);
   launch_sdiag(dt, s, m->T, Mp, w->S);
   launch_spanels(dt, s, m->L, m->T, w->S, Mp);
+  // M-sized operands of the strips' phase 3:  alpha = Lk^-T m~,  R = Lk^-T (B B' - I)  (column-major: the P operand of the GEMM)
+  HIPC(ctx, hipMemcpyAsync(w->alpha, m->mp, size_t(Mp) * es, hipMemcpyDeviceToDevice, s));
+  launch_trsv2(dt, s, m->L, m->T, Mp, 1, w->alpha);
+  launch_gemm_pm(dt, s, Bq, Bq, nullptr, 1.0, Mp, Mp, Mp, 1, w->G2);       // lower tiles of B B' (row-major)
+  launch_sym_from_lower(dt, s, w->G2, 1, Mp, 1.0, w->tmp);                 // B B' - I, full
+  launch_solve_t(dt, s, w->S, w->tmp, w->Rcm, Mp, Mp, Mp, ctx->num_cus);   // Lk' \ . ; the transposed copy is R column-major
   KCHECK(ctx, "grad prep");
   LikParams lp{};
   lp.lik = m->desc.likelihood;
@@ -987,39 +993,45 @@ int grad_enqueue(svgp_ctx* ctx, svgp_model* m, const svgp_data* data, int64_t of
   for (int64_t c0 = 0; c0 < len; c0 += nc) {
     const int64_t clen = (len - c0 < nc) ? len - c0 : nc;
     const int64_t ncp = (clen + 127) / 128 * 128;
-    StripOuts o;
-    o.A = w->A; o.C = w->C; o.lda = ldk; o.skip_expect = true;   // k-major [Mp][nc]; point-major copies by transposition
-    // f64: the strip kernel also scatters the point-major copies itself (32 B pieces; L2 merges them) instead of two
-    // transposition passes: value-and-gradient 137.0 -> 134.5 ms at H; f32 (16 B pieces): 73.8 -> 75.0 ms, so not there
-    static const int direct_env = [] { const char* e = getenv("SVGP_GRAD_DIRECT_T"); return e ? atoi(e) : -1; }();
-    const bool direct_t = direct_env >= 0 ? direct_env != 0 : dt == SVGP_F64;
-    if (direct_t) { o.At = w->At; o.Ct = w->Ct; }
-    rc = enqueue_strips(ctx, m, data->x, data->ldx, nullptr, off + c0, clen, o);
+    // forward strips + likelihood gradients + phase 3 in ONE launch: leaves A, P point-major and g_mu, g_v of the chunk
+    const StripPlan plan = strip_plan(dt, Mp, clen, ctx->num_cus);
+    const int nt = plan.grid ? plan.nt : plan.nt_tail, grid = plan.grid ? plan.grid : plan.grid_tail;
+    const int64_t nstrips = plan.grid ? plan.nstrips : plan.nstrips_tail;
+    rc = ensure_scratch(ctx, strip_work_bytes(dt, Mp, nt, grid), 1);
     if (rc) return rc;
-    if (!direct_t) {
-      launch_to_point_major(dt, s, w->A, ldk, Mp, ncp, w->At);
-      launch_to_point_major(dt, s, w->C, ldk, Mp, ncp, w->Ct);
-    }
-    launch_grad_moments(dt, s, lp, scale, n_global_dev, gc.num_data, ctx->mom, ctx->mom + ctx->mom_cap, data->y, off + c0, clen,
-                        ncp, w->gmu, w->gv, w->partial5, w->sums);
-    KCHECK(ctx, "grad_moments");
-    launch_abar(dt, s, Bq, w->C, w->A, m->mp, w->gmu, w->gv, w->Ab, Mp, ldk, ncp);
-    KCHECK(ctx, "abar");
-    launch_solve_t(dt, s, w->S, w->Ab, nullptr, Mp, ldk, ncp, ctx->num_cus);
-    launch_to_point_major(dt, s, w->Ab, ldk, Mp, ncp, w->Pt);
-    KCHECK(ctx, "solve_t");
+    if (nstrips > w->part5_strips) return fail(ctx, SVGP_HIP_ERROR, "internal: strip partial buffer too small");
+    HIPC(ctx, hipMemsetAsync(w->gmu, 0, size_t(ncp) * es, s));
+    HIPC(ctx, hipMemsetAsync(w->gv, 0, size_t(ncp) * es, s));
+    StripArgs a{};
+    a.T = m->T; a.U = m->U; a.zs = m->zs; a.mp = m->mp; a.x = data->x; a.work = ctx->work; a.counter = ctx->counter;
+    a.At_out = w->At; a.ldx = data->ldx; a.off = off + c0; a.len = clen; a.Mp = Mp; a.M = M; a.kp = kp;
+    a.mean_const = m->desc.mean_const;
+    a.R = w->Rcm; a.alpha = w->alpha; a.Pt_out = w->Pt; a.gmu_out = w->gmu; a.gv_out = w->gv; a.y = data->y;
+    a.part5 = w->partial5; a.lp = lp; a.scale = scale; a.n_global_dev = n_global_dev; a.num_data = gc.num_data;
+    HIPC(ctx, hipMemsetAsync(ctx->counter, 0, sizeof(unsigned), s));
+    launch_strip_grad(dt, s, a, nt, grid, nstrips);
+    KCHECK(ctx, "strip (value and gradient)");
+    launch_sum5(s, w->partial5, int(nstrips), w->sums);
     int64_t sl = ((ncp + w->nslices - 1) / w->nslices + 127) / 128 * 128;
-    launch_gemm_pm(dt, s, w->At, w->Ct, w->gv, 2.0, Mp, ncp, sl, w->nslices, w->G1);
-    launch_gemm_pm(dt, s, w->Pt, w->At, nullptr, 1.0, Mp, ncp, sl, w->nslices, w->G2);
-    KCHECK(ctx, "gemm_pm");
+    launch_gemm_pm(dt, s, w->At, w->At, w->gv, 2.0, Mp, ncp, sl, w->nslices, w->G1);   // W += A diag(2 g_v) A' (lower tiles)
+    KCHECK(ctx, "syrk");
     int64_t ksl = ((clen + w->ns_uf - 1) / w->ns_uf + 127) / 128 * 128;
     launch_kgrad(dt, s, kp, m->zs, Mp, data->x, data->ldx, off + c0, 0, clen, clen, w->Pt, w->At, w->gmu, ksl, w->ns_uf,
                  w->rp_uf, w->sp_uf);
     KCHECK(ctx, "kgrad uf");
   }
-  // M-sized tail: Lq_bar, Lk_bar -> Kuu_bar -> kernel parameters
-  launch_finish_mm(dt, s, w->G1, w->G2, w->nslices, Mp, M, centered ? m->B : m->Lq_raw, centered ? Mp : M, klw, w->Lqbar,
-                   centered ? w->BbarRM : nullptr, w->LbarRM);
+  HIPC(ctx, hipEventRecord(ctx->ev[2], s));
+  // M-sized tail.  With W = A diag(2 g_v) A' and a = A g_mu:
+  //   Lq_bar = tril(W B) - klw dKL/dB,   Lk_bar = -tril(alpha a' + R W)     (B = Lq whitened; W, R carry the factors 2)
+  launch_sym_from_lower(dt, s, w->G1, w->nslices, Mp, 0.0, w->W2);
+  HIPC(ctx, hipMemsetAsync(w->G1p, 0, mm, s));
+  HIPC(ctx, hipMemsetAsync(w->G2, 0, mm, s));
+  launch_gemm_pm(dt, s, w->W2, m->U, nullptr, 1.0, Mp, Mp, Mp, 1, w->G1p);    // (W B)[r][c] = sum_i W[i][r] B'[c][i]
+  launch_gemm_pm(dt, s, w->Rcm, w->W2, nullptr, 1.0, Mp, Mp, Mp, 1, w->G2);   // (R W)[r][c] = sum_i R[r][i] W[i][c]
+  launch_avec(s, w->rp_uf, w->ns_uf, int64_t(2 + dreg) * Mp, Mp, w->avec);
+  launch_finish_mm2(dt, s, w->G1p, w->G2, w->alpha, w->avec, Mp, M, centered ? m->B : m->Lq_raw, centered ? Mp : M, klw, w->Lqbar,
+                    centered ? w->BbarRM : nullptr, w->LbarRM);
+  KCHECK(ctx, "Lq_bar / Lk_bar");
   if (centered) {
     // chain through m~ = Lk \ (m - c) and B = Lk \ Lq:  m_bar = Lk^-T m~_bar,  R = Lk^-T B_bar,  Lq_bar = tril(R),
     // Lk_bar -= tril(m_bar m~') + tril(R B')

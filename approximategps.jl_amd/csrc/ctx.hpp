@@ -38,11 +38,13 @@ struct GradWs {
   int dtype = -1, d = 0, nslices = 1, ns_uf = 1, ns_uu = 1, rb = 1;
   int64_t Mp = 0, nc = 0;
   std::vector<void*> all;
-  void *A = nullptr, *C = nullptr, *Ab = nullptr, *At = nullptr, *Ct = nullptr, *Pt = nullptr, *gmu = nullptr, *gv = nullptr;
+  void *At = nullptr, *Pt = nullptr, *gmu = nullptr, *gv = nullptr;   // per chunk: A and P = Kuf_bar point-major [nc][Mp], g_mu, g_v
   void *Lqp = nullptr, *S = nullptr, *G1 = nullptr, *G2 = nullptr, *LkRM = nullptr, *LbarRM = nullptr, *Phi = nullptr,
        *tmp = nullptr, *H = nullptr, *zbar = nullptr, *mbar = nullptr, *Lqbar = nullptr, *BbarRM = nullptr, *rbar = nullptr;
+  void *W2 = nullptr, *Rcm = nullptr, *G1p = nullptr, *alpha = nullptr;   // W = A diag(2 g_v) A', R = Lk^-T (Lq Lq' - I), 2 W Lq, Lk^-T m
   double *rp_uf = nullptr, *sp_uf = nullptr, *rp_uu = nullptr, *sp_uu = nullptr, *partial5 = nullptr, *sums = nullptr,
-         *invl_d = nullptr, *scal_out = nullptr;
+         *invl_d = nullptr, *scal_out = nullptr, *avec = nullptr;
+  int64_t part5_strips = 0;
   size_t rp_uf_b = 0, sp_uf_b = 0, rp_uu_b = 0, sp_uu_b = 0, g_b = 0;
   void release() {
     for (void* p : all)

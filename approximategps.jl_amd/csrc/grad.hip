@@ -79,6 +79,45 @@ __global__ void sum5_kernel(const double* __restrict__ partial, int nblocks, dou
   }
 }
 
+// ---- M x M helpers of the fused gradient path (svgp_elbo_grad, api.hip: grad_enqueue) ---------------------------------
+// out (row-major, FULL symmetric) = sum over slices of the lower tiles in G (row-major), minus `eye` on the diagonal
+template <typename T>
+__global__ void sym_from_lower_kernel(const T* __restrict__ G, int nslices, int64_t Mp, T eye, T* __restrict__ out) {
+  const int64_t c = int64_t(blockIdx.x) * blockDim.x + threadIdx.x, r = blockIdx.y;
+  if (c >= Mp) return;
+  const int64_t lo = (c <= r) ? r * Mp + c : c * Mp + r;   // element of the lower triangle (tiles on the diagonal are full)
+  T v = T(0);
+  for (int s = 0; s < nslices; ++s) v += G[int64_t(s) * Mp * Mp + lo];
+  out[r * Mp + c] = v - (r == c ? eye : T(0));
+}
+
+// avec[c] = sum over slices of rowpart[s][1][c]  ( = (A g_mu)_c, the data part of m_bar )
+__global__ void avec_kernel(const double* __restrict__ rp_uf, int ns, int64_t stride, int64_t Mp, double* __restrict__ avec) {
+  const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= Mp) return;
+  double s = 0.0;
+  for (int q = 0; q < ns; ++q) s += rp_uf[q * stride + Mp + i];
+  avec[i] = s;
+}
+
+// Lq_bar = tril(G1) - klw dKL/dLq  with G1 = 2 W Lq (row-major);  Lk_bar = -tril(G2 + alpha a')  with G2 = 2 R W (row-major)
+template <typename T>
+__global__ void finish_mm2_kernel(const T* __restrict__ G1, const T* __restrict__ G2, const T* __restrict__ alpha,
+                                  const double* __restrict__ avec, int64_t Mp, int64_t M, const T* __restrict__ Lq, int64_t ldq,
+                                  T klw, T* __restrict__ Lq_bar, T* __restrict__ BbarRM, T* __restrict__ LkbarRM) {
+  const int64_t c = int64_t(blockIdx.x) * blockDim.x + threadIdx.x, r = blockIdx.y;
+  if (c >= Mp) return;
+  const bool low = c <= r;
+  LkbarRM[r * Mp + c] = low ? -(G2[r * Mp + c] + alpha[r] * T(avec[c])) : T(0);
+  T v = T(0);
+  if (r < M && low) {
+    const T l = Lq[r + c * ldq];
+    v = G1[r * Mp + c] - klw * (c == r ? l - T(1) / l : l);   // klw * d KL / d Lq
+  }
+  if (BbarRM) BbarRM[r * Mp + c] = v;                    // Centered: adjoint of B = Lk \\ Lq, row-major for the solve
+  else if (r < M && c < M) Lq_bar[r + c * M] = v;
+}
+
 // Abar[r][c] = m[r] g_mu[c] + 2 g_v[c] ((Lq C)[r][c] - A[r][c]);  Lq lower triangular, Mp x Mp column-major
 template <typename T, int NT, int NTHR>
 __global__ void __launch_bounds__(NTHR, 2) abar_kernel(const T* __restrict__ Lqp, const T* __restrict__ C,
@@ -516,6 +555,26 @@ void launch_grad_moments(int dtype, hipStream_t s, const LikParams& lp, double s
   GD(dtype, T, hipLaunchKernelGGL(grad_moments_kernel<T>, dim3(nb), dim3(k256), 0, s, lp, scale, n_global_dev, num_data, mom_mu,
                                   mom_var, (const T*)y, off, len, npad, (T*)gmu, (T*)gv, partial));
   hipLaunchKernelGGL(sum5_kernel, dim3(1), dim3(64), 0, s, partial, nb, sums);
+}
+
+void launch_sum5(hipStream_t s, const double* partial, int nblocks, double* sums) {
+  hipLaunchKernelGGL(sum5_kernel, dim3(1), dim3(64), 0, s, partial, nblocks, sums);
+}
+
+void launch_sym_from_lower(int dtype, hipStream_t s, const void* G, int nslices, int64_t Mp, double eye, void* out) {
+  dim3 grid((unsigned)((Mp + 255) / 256), (unsigned)Mp);
+  GD(dtype, T, hipLaunchKernelGGL(sym_from_lower_kernel<T>, grid, dim3(256), 0, s, (const T*)G, nslices, Mp, T(eye), (T*)out));
+}
+
+void launch_avec(hipStream_t s, const double* rp_uf, int ns, int64_t stride, int64_t Mp, double* avec) {
+  hipLaunchKernelGGL(avec_kernel, dim3((unsigned)((Mp + 255) / 256)), dim3(256), 0, s, rp_uf, ns, stride, Mp, avec);
+}
+
+void launch_finish_mm2(int dtype, hipStream_t s, const void* G1, const void* G2, const void* alpha, const double* avec, int64_t Mp,
+                       int64_t M, const void* Lq, int64_t ldq, double klw, void* Lq_bar, void* BbarRM, void* LkbarRM) {
+  dim3 grid((unsigned)((Mp + 255) / 256), (unsigned)Mp);
+  GD(dtype, T, hipLaunchKernelGGL(finish_mm2_kernel<T>, grid, dim3(256), 0, s, (const T*)G1, (const T*)G2, (const T*)alpha, avec, Mp,
+                                  M, (const T*)Lq, ldq, T(klw), (T*)Lq_bar, (T*)BbarRM, (T*)LkbarRM));
 }
 
 void launch_abar(int dtype, hipStream_t s, const void* Lqp, const void* C, const void* A, const void* mp, const void* gmu,

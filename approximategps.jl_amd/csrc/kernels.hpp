@@ -78,6 +78,18 @@ struct StripArgs {
   int64_t Mp, M;
   KernelParams kp;
   double mean_const;
+  // ---- value-and-gradient strips (launch_strip_grad): phase 3 of the same kernel, P = Kuf_bar for the strip's points ----
+  const void* R;        // Mp x Mp col-major: Lk^-T (Lq Lq' - I)
+  const void* alpha;    // [Mp] Lk^-T m
+  void* Pt_out;         // point-major [n][Mp]: P = alpha g_mu' + 2 (R A) diag(g_v)
+  void* gmu_out;        // [n] g_mu = scale dE/dmu (compute dtype), also read by kgrad
+  void* gv_out;         // [n] g_v
+  const void* y;        // observations of the batch (index off + i)
+  double* part5;        // [nstrips][5] per-strip {E, sum g_mu, sum g_v, dE/dsigma2, n_neg}
+  LikParams lp;
+  double scale;               // num_data / n_batch ...
+  const double* n_global_dev; // ... or, data-parallel, num_data / *n_global_dev (0 -> 1)
+  double num_data;
 };
 int strip_nt(int dtype, int64_t Mp, int64_t len);                 // column-strip width chosen for a problem
 size_t strip_work_bytes(int dtype, int64_t Mp, int nt, int grid);  // workspace bytes
@@ -90,6 +102,9 @@ struct StripPlan {       // regular-width launch over the first `points` points,
 };
 StripPlan strip_plan(int dtype, int64_t Mp, int64_t len, int num_cus);
 void launch_strip(int dtype, hipStream_t s, const StripArgs& a, int nt, int grid, int64_t nstrips);
+// the value-and-gradient form: phases 1-2 as launch_strip, then the per-point likelihood gradients and phase 3
+// (a dense Mp x Mp GEMM on the strip's A, still in its scratch strip); writes At_out, Pt_out, gmu_out, gv_out, part5
+void launch_strip_grad(int dtype, hipStream_t s, const StripArgs& a, int nt, int grid, int64_t nstrips);
 // marginals + expected log-likelihood of every point (SVA:354-355): per-block sums into partial/negcnt
 int expect_blocks(int64_t len);
 void launch_expect(int dtype, hipStream_t s, const LikParams& lp, const double* mom_mu, const double* mom_var,
@@ -130,6 +145,13 @@ void launch_gemm_pm(int dtype, hipStream_t s, const void* Xt, const void* Yt, co
 void launch_kgrad(int dtype, hipStream_t s, const KernelParams& kp, const void* zs, int64_t Mp, const void* x, int64_t ldx,
                   int64_t xoff, int prescaled, int64_t n, int64_t nvalid, const void* Pt, const void* At, const void* gmu,
                   int64_t slice_len, int nslices, double* rowpart, double* scalpart);
+// fused gradient path: sums of the per-strip partials, W = A diag(2 g_v) A' from its split-K lower tiles, (A g_mu), and the
+// assembly of Lq_bar / Lk_bar from G1 = 2 W Lq, G2 = 2 R W and the rank-one term alpha (A g_mu)'
+void launch_sum5(hipStream_t s, const double* partial, int nblocks, double* sums);
+void launch_sym_from_lower(int dtype, hipStream_t s, const void* G, int nslices, int64_t Mp, double eye, void* out);
+void launch_avec(hipStream_t s, const double* rp_uf, int ns, int64_t stride, int64_t Mp, double* avec);
+void launch_finish_mm2(int dtype, hipStream_t s, const void* G1, const void* G2, const void* alpha, const double* avec, int64_t Mp,
+                       int64_t M, const void* Lq, int64_t ldq, double klw, void* Lq_bar, void* BbarRM, void* LkbarRM);
 void launch_lower_to_rowmajor(int dtype, hipStream_t s, const void* L, int64_t Mp, void* out);
 void launch_transpose(int dtype, hipStream_t s, const void* in, int64_t Mp, void* out);
 void launch_to_point_major(int dtype, hipStream_t s, const void* in, int64_t ld, int64_t Mp, int64_t ncols, void* out);

@@ -106,7 +106,31 @@ extern "C" int svgp_debug_strip_stamps(unsigned long long* out) {
 #define SVGP_SSTAMP(i)
 #endif
 
-template <typename T, int NT, int BK, int NTHR, int MINW = 2, int PAD = 16>
+// d E[log p] / d (mu, v) of one point for the value-and-gradient strips.  Not inlined: lgamma / exp / log1p and the
+// Gauss-Hermite loop must not take part in the register allocation of the MFMA loops around the call (146 spilled VGPRs
+// when they did).
+struct PointGrads { double e, gmu, gv, gs2; };
+__device__ __noinline__ PointGrads strip_point_grads(LikParams lp, double mu, double v, double yv, double scale) {
+  // everything by value: taking the address of the kernel argument block would move it (and with it the wave-uniform
+  // operand base pointers of the LDS-DMA instructions) from SGPRs to scratch memory
+  double a = 0.0, b = 0.0, gs2 = 0.0;
+  expected_loglik_grad_point(lp, mu, v, yv, a, b, gs2);
+  PointGrads r;
+  r.e = expected_loglik_point(lp, mu, v, yv, log(lp.sigma2));
+  r.gmu = a * scale;
+  r.gv = b * scale;
+  r.gs2 = gs2 * scale;
+  return r;
+}
+
+// GRAD: the value-and-gradient form (svgp_elbo_grad).  After phases 1-2 the workgroup knows (mu, v) of its strip's
+// points, so it evaluates the likelihood gradients (g_mu, g_v) = scale dE/d(mu, v) itself and runs
+//   phase 3:  P = Kuf_bar = Lk' \ Abar = alpha g_mu' + 2 (R A) diag(g_v),   R = Lk^-T (Lq Lq' - I),  alpha = Lk^-T m
+// as ONE dense Mp x Mp GEMM on the A strip that is still in its scratch strip (the adjoint's two triangular products
+// Lq (Lq'A) - A and Lk' \ . folded into a precomputed M x M matrix: same flops, no dependence on C, no trip of A / C /
+// Abar through HBM as k-major matrices).  Outputs: A and P point-major (for the products contracted over points: the
+// SYRK W = A diag(g_v) A' and the kernel-gradient reductions), g_mu, g_v, and five per-strip sums.
+template <typename T, int NT, int BK, int NTHR, int MINW = 2, int PAD = 16, bool GRAD = false>
 __global__ void __launch_bounds__(NTHR, MINW) strip_kernel(StripArgs a, int64_t nstrips) {
   using G = TileGemm<T, NT, BK, NTHR, PAD>;
   using Acc = typename G::Acc;
@@ -147,6 +171,7 @@ __global__ void __launch_bounds__(NTHR, MINW) strip_kernel(StripArgs a, int64_t 
   // of the launch take more strips, which removes most of the ragged last round (C2: 3.05 rounds of strips).
   // Which workgroup evaluates a strip does not change its arithmetic, so results stay bitwise reproducible.
   __shared__ unsigned next_strip;
+  __shared__ T s_gmu[GRAD ? NT : 1], s_gv[GRAD ? NT : 1];   // the strip's likelihood gradients, read by phase 3's epilogue
 #ifdef SVGP_STRIP_STAMPS
   int strips_done = 0;
   if (threadIdx.x < 128) s_strip_stamps[threadIdx.x] = 0;
@@ -309,18 +334,90 @@ __global__ void __launch_bounds__(NTHR, MINW) strip_kernel(StripArgs a, int64_t 
       }
     }
     __syncthreads();
-    if (tid < NT && c0 + tid < a.len) {
-      double qa = 0, qm = 0, qc = 0;
+    if constexpr (!GRAD) {
+      if (tid < NT && c0 + tid < a.len) {
+        double qa = 0, qm = 0, qc = 0;
 #pragma unroll
-      for (int w = 0; w < G::WR; ++w) {
-        qa += red[(0 * G::WR + w) * NT + tid];
-        qm += red[(1 * G::WR + w) * NT + tid];
-        qc += red[(2 * G::WR + w) * NT + tid];
+        for (int w = 0; w < G::WR; ++w) {
+          qa += red[(0 * G::WR + w) * NT + tid];
+          qm += red[(1 * G::WR + w) * NT + tid];
+          qc += red[(2 * G::WR + w) * NT + tid];
+        }
+        a.mom_mu[c0 + tid] = a.mean_const + qm;
+        a.mom_var[c0 + tid] = a.kp.variance - qa + qc;
       }
-      a.mom_mu[c0 + tid] = a.mean_const + qm;
-      a.mom_var[c0 + tid] = a.kp.variance - qa + qc;
+      __syncthreads();
+    } else {
+      // ---- marginals + d E[log p] / d (mu, v) of the strip's points (SVA:354-355 and their adjoint), one thread per point
+      double e5[5] = {0, 0, 0, 0, 0};   // E, sum g_mu, sum g_v, dE/dsigma2, n_neg
+      double gm = 0.0, gvv = 0.0;
+      if (tid < NT && c0 + tid < a.len) {
+        double qa = 0, qm = 0, qc = 0;
+#pragma unroll
+        for (int w = 0; w < G::WR; ++w) {
+          qa += red[(0 * G::WR + w) * NT + tid];
+          qm += red[(1 * G::WR + w) * NT + tid];
+          qc += red[(2 * G::WR + w) * NT + tid];
+        }
+        const double mu = a.mean_const + qm;
+        double v = a.kp.variance - qa + qc + kDefaultSigma2;
+        const double scale = a.n_global_dev ? (a.num_data > 0.0 ? a.num_data / *a.n_global_dev : 1.0) : a.scale;
+        bool bad = v < 0.0;
+        if (bad) {
+          e5[4] = 1.0;
+          if (a.lp.clamp_neg_var) { v = 0.0; bad = false; }
+        }
+        if (!bad) {
+          const double yv = double(static_cast<const T*>(a.y)[a.off + c0 + tid]);
+          const PointGrads pg = strip_point_grads(a.lp, mu, v, yv, scale);
+          e5[0] = pg.e; e5[1] = gm = pg.gmu; e5[2] = gvv = pg.gv; e5[3] = pg.gs2;
+        }
+        static_cast<T*>(a.gmu_out)[c0 + tid] = T(gm);
+        static_cast<T*>(a.gv_out)[c0 + tid] = T(gvv);
+      }
+      __syncthreads();   // every read of red[] done
+      if (tid < NT) {
+        s_gmu[tid] = T(gm);
+        s_gv[tid] = T(gvv);
+#pragma unroll
+        for (int q = 0; q < 5; ++q) red[q * NT + tid] = e5[q];
+      }
+      __syncthreads();
+      if (tid < 5) {   // fixed order: bitwise reproducible
+        double sacc = 0.0;
+        for (int c = 0; c < NT; ++c) sacc += red[tid * NT + c];
+        a.part5[strip * 5 + tid] = sacc;
+      }
+      __syncthreads();   // staging free again
+      // ---------------- phase 3: P = alpha g_mu' + 2 (R A) diag(g_v), panel by panel (dense: every k-step is a full tile) ----
+      const T* __restrict__ Rm = static_cast<const T*>(a.R);
+      const T* __restrict__ alpha = static_cast<const T*>(a.alpha);
+      T* __restrict__ Pt = static_cast<T*>(a.Pt_out);
+      for (int I = 0; I < nP; ++I) {
+        Acc acc;
+        acc.zero();
+        if constexpr (SVGP_ASYNC && G::kAsync) {
+          auto qsrc = [&](int t) { return work + int64_t(t) * BK * NT; };
+          G::template loop_tri_async<0>(acc, Rm + int64_t(I) * NB, Mp, nP * (NB / BK), qsrc, smem);
+        } else {
+          auto qload = [&](int t, QRegs& r) { G::load_q(r, work + int64_t(t) * BK * NT, qoff); };
+          G::template loop_tri<0>(acc, Rm + int64_t(I) * NB, Mp, nP * (NB / BK), qload, smem);
+        }
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+          const int col = G::acc_col(j);
+          const T g2 = T(2) * s_gv[col], g1 = s_gmu[col];
+#pragma unroll
+          for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int row = I * NB + G::acc_row(i, r);
+              Pt[(c0 + col) * Mp + row] = fma(g2, acc.v[i][j][r], alpha[row] * g1);
+            }
+        }
+      }
+      __syncthreads();
     }
-    __syncthreads();
     strip = next_strip;
     __syncthreads();
     SVGP_SSTAMP(101);
@@ -514,13 +611,14 @@ __global__ void __launch_bounds__(k256, 2) kuf_kernel(KernelParams kp, const T* 
   }
 }
 
-template <typename T, int NT, int BK, int NTHR, int MINW = 2, int PAD = 16>
+template <typename T, int NT, int BK, int NTHR, int MINW = 2, int PAD = 16, bool GRAD = false>
 void launch_strip_t(hipStream_t s, const StripArgs& a, int grid, int64_t nstrips) {
   using G = TileGemm<T, NT, BK, NTHR, PAD>;
   // the strip's x image (<= 32 feature rows) aliases the staging buffers
   const size_t lds = (SVGP_ASYNC && G::kAsync) ? G::ASYNC_LDS_BYTES : G::LDS_BYTES;
   static_assert(G::LDS_BYTES >= size_t(32) * NT * sizeof(T), "x image must fit the staging buffers");
-  auto kern = strip_kernel<T, NT, BK, NTHR, MINW, PAD>;
+  static_assert(G::LDS_BYTES >= size_t(5) * NT * sizeof(double), "the five per-strip sums reuse the staging buffers");
+  auto kern = strip_kernel<T, NT, BK, NTHR, MINW, PAD, GRAD>;
   set_max_lds(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
   hipLaunchKernelGGL(kern, dim3(grid), dim3(NTHR), lds, s, a, nstrips);
 }
@@ -594,6 +692,16 @@ void launch_strip(int dtype, hipStream_t s, const StripArgs& a, int nt, int grid
   } else {
     if (bk32 && a.kp.d <= 8) launch_strip_t<float, 128, 32, 512>(s, a, grid, nstrips);
     else launch_strip_t<float, 128, 16, 512>(s, a, grid, nstrips);
+  }
+}
+
+void launch_strip_grad(int dtype, hipStream_t s, const StripArgs& a, int nt, int grid, int64_t nstrips) {
+  if (dtype == 0) {
+    if (nt == 32) launch_strip_t<double, 32, 16, 256, 2, 16, true>(s, a, grid, nstrips);
+    else launch_strip_t<double, 64, 16, 256, 2, 16, true>(s, a, grid, nstrips);
+  } else {
+    if (nt == 64) launch_strip_t<float, 64, 16, 256, 2, 16, true>(s, a, grid, nstrips);
+    else launch_strip_t<float, 128, 16, 256, 2, 16, true>(s, a, grid, nstrips);
   }
 }
 

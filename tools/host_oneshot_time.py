@@ -9,8 +9,8 @@ import torch  # noqa: F401  (HIP runtime load order)
 import bench
 from approxgp import _ffi
 cfg = sys.argv[1] if len(sys.argv) > 1 else "H"
-n, M, d, family, lik, dtype = bench.CONFIGS[cfg]
-p = bench.synth(0, n, M, d, family, lik, dtype)
+n, M, d, family, lik, dtype, cid = bench.CONFIGS[cfg]
+p = bench.synth(cid, n, M, d, family, lik, dtype)
 ctx = _ffi.Context(0)
 desc, keep = _ffi.make_desc(p["np_dt"], family, p["variance"], p["inv_l"], p["z"], p["m"], p["Lq"], p["jitter"], likelihood=lik, lik_sigma2=p["sigma2"])
 xb = np.asfortranarray(p["x"]); yb = np.ascontiguousarray(p["y"])

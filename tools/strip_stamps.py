@@ -7,9 +7,9 @@ sys.path.insert(0, os.path.join(ROOT, "approximategps.jl_amd")); sys.path.insert
 import bench
 from approxgp import _ffi
 cfg = sys.argv[1] if len(sys.argv) > 1 else "H"
-n, M, d, family, lik, dtype = bench.CONFIGS[cfg]
+n, M, d, family, lik, dtype, cid = bench.CONFIGS[cfg]
 n = min(n, 400_000)
-p = bench.synth(0, n, M, d, family, lik, dtype)
+p = bench.synth(cid, n, M, d, family, lik, dtype)
 ctx = _ffi.Context(0)
 desc, keep = _ffi.make_desc(p["np_dt"], family, p["variance"], p["inv_l"], p["z"], p["m"], p["Lq"], p["jitter"], likelihood=lik, lik_sigma2=p["sigma2"])
 model = _ffi.DeviceModel(ctx, desc, keep); data = _ffi.DeviceData(ctx, p["x"], p["y"], p["np_dt"])
