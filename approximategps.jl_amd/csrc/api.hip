@@ -974,8 +974,10 @@ int grad_enqueue(svgp_ctx* ctx, svgp_model* m, const svgp_data* data, int64_t of
   launch_sdiag(dt, s, m->T, Mp, w->S);
   launch_spanels(dt, s, m->L, m->T, w->S, Mp);
   // M-sized operands of the strips' phase 3:  alpha = Lk^-T m~,  R = Lk^-T (B B' - I)  (column-major: the P operand of the GEMM)
-  HIPC(ctx, hipMemcpyAsync(w->alpha, m->mp, size_t(Mp) * es, hipMemcpyDeviceToDevice, s));
-  launch_trsv2(dt, s, m->L, m->T, Mp, 1, w->alpha);
+  // alpha as column 0 of an Mp x 64 block through the MFMA panel solve (the one-vector trsv takes 0.7 ms at M = 1024)
+  launch_vec_to_block(dt, s, m->mp, Mp, w->Phi);
+  launch_solve_t(dt, s, w->S, w->Phi, nullptr, Mp, 64, 64, ctx->num_cus);
+  launch_block_to_vec(dt, s, w->Phi, Mp, w->alpha);
   launch_gemm_pm(dt, s, Bq, Bq, nullptr, 1.0, Mp, Mp, Mp, 1, w->G2);       // lower tiles of B B' (row-major)
   launch_sym_from_lower(dt, s, w->G2, 1, Mp, 1.0, w->tmp);                 // B B' - I, full
   launch_solve_t(dt, s, w->S, w->tmp, w->Rcm, Mp, Mp, Mp, ctx->num_cus);   // Lk' \ . ; the transposed copy is R column-major

@@ -70,13 +70,15 @@ __global__ void grad_status_kernel(double* sums, const int* chol_info, double n_
   sums[7] = 0.0;
 }
 
-// out[q] += sum over blocks of partial[b][q]  (fixed order)
-__global__ void sum5_kernel(const double* __restrict__ partial, int nblocks, double* __restrict__ out) {
-  if (threadIdx.x < 5) {
-    double s = 0.0;
-    for (int b = 0; b < nblocks; ++b) s += partial[b * 5 + threadIdx.x];
-    out[threadIdx.x] += s;
-  }
+// out[q] += sum over blocks of partial[b][q]: wave q sums its column (lane l takes blocks l, l + 64, ... in order, then a
+// fixed shuffle tree), so the result does not depend on anything but the inputs (a single thread walking 1024 strips
+// cost 170 us per chunk: 2.7 ms of an H evaluation)
+__global__ void __launch_bounds__(320) sum5_kernel(const double* __restrict__ partial, int nblocks, double* __restrict__ out) {
+  const int q = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  double s = 0.0;
+  for (int b = lane; b < nblocks; b += 64) s += partial[b * 5 + q];
+  for (int w = 32; w > 0; w >>= 1) s += __shfl_down(s, w);
+  if (lane == 0) out[q] += s;
 }
 
 // ---- M x M helpers of the fused gradient path (svgp_elbo_grad, api.hip: grad_enqueue) ---------------------------------
@@ -89,6 +91,18 @@ __global__ void sym_from_lower_kernel(const T* __restrict__ G, int nslices, int6
   T v = T(0);
   for (int s = 0; s < nslices; ++s) v += G[int64_t(s) * Mp * Mp + lo];
   out[r * Mp + c] = v - (r == c ? eye : T(0));
+}
+
+// a vector as column 0 of an Mp x 64 k-major block (zeros elsewhere) and back: lets solve_t_kernel do a one-vector solve
+template <typename T>
+__global__ void vec_to_block_kernel(const T* __restrict__ v, int64_t Mp, T* __restrict__ X) {
+  const int64_t e = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (e < Mp * 64) X[e] = (e % 64 == 0) ? v[e / 64] : T(0);
+}
+template <typename T>
+__global__ void block_to_vec_kernel(const T* __restrict__ X, int64_t Mp, T* __restrict__ v) {
+  const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i < Mp) v[i] = X[i * 64];
 }
 
 // avec[c] = sum over slices of rowpart[s][1][c]  ( = (A g_mu)_c, the data part of m_bar )
@@ -554,16 +568,23 @@ void launch_grad_moments(int dtype, hipStream_t s, const LikParams& lp, double s
   const int nb = int(b < 1024 ? b : 1024);
   GD(dtype, T, hipLaunchKernelGGL(grad_moments_kernel<T>, dim3(nb), dim3(k256), 0, s, lp, scale, n_global_dev, num_data, mom_mu,
                                   mom_var, (const T*)y, off, len, npad, (T*)gmu, (T*)gv, partial));
-  hipLaunchKernelGGL(sum5_kernel, dim3(1), dim3(64), 0, s, partial, nb, sums);
+  hipLaunchKernelGGL(sum5_kernel, dim3(1), dim3(320), 0, s, partial, nb, sums);
 }
 
 void launch_sum5(hipStream_t s, const double* partial, int nblocks, double* sums) {
-  hipLaunchKernelGGL(sum5_kernel, dim3(1), dim3(64), 0, s, partial, nblocks, sums);
+  hipLaunchKernelGGL(sum5_kernel, dim3(1), dim3(320), 0, s, partial, nblocks, sums);
 }
 
 void launch_sym_from_lower(int dtype, hipStream_t s, const void* G, int nslices, int64_t Mp, double eye, void* out) {
   dim3 grid((unsigned)((Mp + 255) / 256), (unsigned)Mp);
   GD(dtype, T, hipLaunchKernelGGL(sym_from_lower_kernel<T>, grid, dim3(256), 0, s, (const T*)G, nslices, Mp, T(eye), (T*)out));
+}
+
+void launch_vec_to_block(int dtype, hipStream_t s, const void* v, int64_t Mp, void* X) {
+  GD(dtype, T, hipLaunchKernelGGL(vec_to_block_kernel<T>, dim3((unsigned)((Mp * 64 + 255) / 256)), dim3(256), 0, s, (const T*)v, Mp, (T*)X));
+}
+void launch_block_to_vec(int dtype, hipStream_t s, const void* X, int64_t Mp, void* v) {
+  GD(dtype, T, hipLaunchKernelGGL(block_to_vec_kernel<T>, dim3((unsigned)((Mp + 255) / 256)), dim3(256), 0, s, (const T*)X, Mp, (T*)v));
 }
 
 void launch_avec(hipStream_t s, const double* rp_uf, int ns, int64_t stride, int64_t Mp, double* avec) {

@@ -149,6 +149,8 @@ void launch_kgrad(int dtype, hipStream_t s, const KernelParams& kp, const void* 
 // assembly of Lq_bar / Lk_bar from G1 = 2 W Lq, G2 = 2 R W and the rank-one term alpha (A g_mu)'
 void launch_sum5(hipStream_t s, const double* partial, int nblocks, double* sums);
 void launch_sym_from_lower(int dtype, hipStream_t s, const void* G, int nslices, int64_t Mp, double eye, void* out);
+void launch_vec_to_block(int dtype, hipStream_t s, const void* v, int64_t Mp, void* X);   // v -> column 0 of an Mp x 64 block
+void launch_block_to_vec(int dtype, hipStream_t s, const void* X, int64_t Mp, void* v);
 void launch_avec(hipStream_t s, const double* rp_uf, int ns, int64_t stride, int64_t Mp, double* avec);
 void launch_finish_mm2(int dtype, hipStream_t s, const void* G1, const void* G2, const void* alpha, const double* avec, int64_t Mp,
                        int64_t M, const void* Lq, int64_t ldq, double klw, void* Lq_bar, void* BbarRM, void* LkbarRM);

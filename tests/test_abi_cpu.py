@@ -98,3 +98,18 @@ def test_make_desc_layouts():
     assert (desc.d, desc.M, desc.layout_z, desc.dtype) == (1, 7, _ffi.VEC, _ffi.F32)
     with pytest.raises(ValueError):
         _ffi.make_desc(np.float64, 0, 1.0, 1.0, np.zeros(7), np.zeros(6), np.eye(7), 1e-6)
+
+
+def test_struct_layouts_match_the_julia_binding():
+    """integration/julia/src/SVGPMI355X.jl declares the same structs field for field; its test file asserts exactly these
+    sizes and offsets, so the layouts the GPU tests exercise through ctypes are the layouts Julia's ccall passes."""
+    assert C.sizeof(_ffi.ModelDesc) == 104 and _ffi.ModelDesc.M.offset == 32 and _ffi.ModelDesc.Lq.offset == 96
+    assert C.sizeof(_ffi.Terms) == 64 and _ffi.Terms.chol_info.offset == 56
+    assert C.sizeof(_ffi.Grads) == 56 and _ffi.Grads.inv_lengthscale.offset == 24
+    src = open(os.path.join(ROOT, "integration", "julia", "src", "SVGPMI355X.jl")).read()
+    # every C symbol the Julia binding ccall's is one the header declares (and the library exports)
+    called = set(re.findall(r"ccall\(\(:(svgp_[a-z_0-9]+), lib\)", src))
+    assert called and called <= set(_ffi.SYMBOLS), called - set(_ffi.SYMBOLS)
+    # field order of the Julia struct = field order of the ctypes struct
+    jl_fields = re.findall(r"(\w+)::(?:Int32|Int64|Float64|Ptr\{\w+\})", src[src.index("struct ModelDesc"):src.index("mutable struct Terms")])
+    assert jl_fields == [f[0] for f in _ffi.ModelDesc._fields_]
