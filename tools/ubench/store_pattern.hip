@@ -1,0 +1,76 @@
+// store_pattern.hip — what does the Kuf kernel's store pattern cost by itself?  Write-only kernels over an M x n column-major
+// f64 matrix (M = 1024, n = 1e6: 8.19 GB), no arithmetic:
+//   fill      : plain grid-stride 16-B stores (1 KiB contiguous per wave instruction): the write roofline of the box
+//   kuf       : the Kuf kernel's mapping: a 256-thread workgroup owns 256 rows x 256 columns, a wave instruction writes
+//               4 columns x 256 B; consecutive workgroups walk down the rows of the same 256 columns
+//   kuf_nt    : the same with nontemporal stores
+//   col1k     : a workgroup owns the same 256 x 256 block but a wave instruction writes 1 KiB of ONE column
+//               (wave w: rows 0..127 of columns w, w+4, ...; then rows 128..255)
+//   col1k_nt  : nontemporal
+//   col8k     : a workgroup owns ALL 1024 rows of 64 columns: a wave instruction writes 1 KiB, a workgroup pass 4 KiB,
+//               whole 8 KiB columns finished back to back
+// build: hipcc -O3 --offload-arch=gfx950 store_pattern.hip -o store_pattern ; run: ./store_pattern
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+#include <algorithm>
+using V2 = double __attribute__((ext_vector_type(2)));
+constexpr int64_t M = 1024, N = 1000000;
+
+template <bool NT> __device__ __forceinline__ void st(V2* p, V2 v) {
+  if (NT) __builtin_nontemporal_store(v, p); else *p = v;
+}
+__global__ void fill_k(V2* K, int64_t n2) {
+  for (int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n2; i += int64_t(gridDim.x) * blockDim.x) K[i] = V2{1.0, 2.0};
+}
+template <bool NT> __global__ void __launch_bounds__(256) kuf_k(double* K) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 15, kq = lane >> 4;
+  const int nI = int(M / 256);
+  const int64_t j0 = int64_t(blockIdx.x / nI) * 256, ibase = (int64_t(blockIdx.x % nI) * 4 + wave) * 64;
+  for (int jg = 0; jg < 16; ++jg)
+    for (int r = 0; r < 4; ++r) {
+      const int64_t j = j0 + jg * 16 + kq + 4 * r;
+      if (j >= N) continue;
+      for (int g = 0; g < 2; ++g) st<NT>(reinterpret_cast<V2*>(K + j * M + ibase + g * 32 + c * 2), V2{double(j), double(g)});
+    }
+}
+template <bool NT> __global__ void __launch_bounds__(256) col1k_k(double* K) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nI = int(M / 256);
+  const int64_t j0 = int64_t(blockIdx.x / nI) * 256, ibase = int64_t(blockIdx.x % nI) * 256;
+  for (int jj = wave; jj < 256; jj += 4) {
+    const int64_t j = j0 + jj;
+    if (j >= N) break;
+    for (int h = 0; h < 2; ++h) st<NT>(reinterpret_cast<V2*>(K + j * M + ibase + h * 128 + lane * 2), V2{double(j), double(h)});
+  }
+}
+template <bool NT> __global__ void __launch_bounds__(256) col8k_k(double* K) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t j0 = int64_t(blockIdx.x) * 64;
+  for (int jj = 0; jj < 64; ++jj) {
+    const int64_t j = j0 + jj;
+    if (j >= N) break;
+    for (int h = 0; h < 2; ++h) st<NT>(reinterpret_cast<V2*>(K + j * M + (h * 4 + wave) * 128 + lane * 2), V2{double(j), double(h)});
+  }
+}
+template <typename F> void timeit(const char* name, F launch) {
+  hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+  std::vector<float> ts;
+  for (int i = 0; i < 12; ++i) { hipEventRecord(a); launch(); hipEventRecord(b); hipEventSynchronize(b); float t; hipEventElapsedTime(&t, a, b); ts.push_back(t); }
+  std::sort(ts.begin() + 2, ts.end());
+  const float med = ts[2 + 5];
+  printf("%-10s median %.3f ms  %.0f GB/s   (min %.3f)\n", name, med, M * N * 8.0 / med / 1e6, ts[2]);
+}
+int main() {
+  double* K; if (hipMalloc(&K, M * N * 8) != hipSuccess) return 1;
+  const unsigned gk = unsigned(((N + 255) / 256) * (M / 256));
+  timeit("fill", [&] { hipLaunchKernelGGL(fill_k, dim3(256 * 8), dim3(256), 0, 0, reinterpret_cast<V2*>(K), M * N / 2); });
+  timeit("kuf", [&] { hipLaunchKernelGGL(kuf_k<false>, dim3(gk), dim3(256), 0, 0, K); });
+  timeit("kuf_nt", [&] { hipLaunchKernelGGL(kuf_k<true>, dim3(gk), dim3(256), 0, 0, K); });
+  timeit("col1k", [&] { hipLaunchKernelGGL(col1k_k<false>, dim3(gk), dim3(256), 0, 0, K); });
+  timeit("col1k_nt", [&] { hipLaunchKernelGGL(col1k_k<true>, dim3(gk), dim3(256), 0, 0, K); });
+  timeit("col8k", [&] { hipLaunchKernelGGL(col8k_k<false>, dim3(unsigned((N + 63) / 64)), dim3(256), 0, 0, K); });
+  timeit("col8k_nt", [&] { hipLaunchKernelGGL(col8k_k<true>, dim3(unsigned((N + 63) / 64)), dim3(256), 0, 0, K); });
+  timeit("fill", [&] { hipLaunchKernelGGL(fill_k, dim3(256 * 8), dim3(256), 0, 0, reinterpret_cast<V2*>(K), M * N / 2); });
+  return 0;
+}
