@@ -11,16 +11,16 @@ what=$1; shift
 for v in "$@"; do
   if [ "$what" = strip ]; then
     hipcc -O3 -std=c++17 --offload-arch=gfx950 -fPIC -DSVGP_ABLATE=$v -c "$SRC/strip.hip" -o "$OUT/strip_$v.o" 2>/dev/null
-    hipcc --offload-arch=gfx950 -shared -fPIC -o "$OUT/libsvgp_strip_$v.so" "$SRC/prep.o" "$OUT/strip_$v.o" "$SRC/grad.o" "$SRC/api.o"
+    hipcc --offload-arch=gfx950 -shared -fPIC -o "$OUT/libsvgp_strip_$v.so" "$SRC/prep.o" "$OUT/strip_$v.o" "$SRC/grad.o" "$SRC/api.o" "$SRC/comm.o" -ldl
   elif [ "$what" = stripstamps ]; then
     hipcc -O3 -std=c++17 --offload-arch=gfx950 -fPIC -DSVGP_STRIP_STAMPS -c "$SRC/strip.hip" -o "$OUT/strip_stamps.o" 2>/dev/null
-    hipcc --offload-arch=gfx950 -shared -fPIC -o "$OUT/libsvgp_stripstamps.so" "$SRC/prep.o" "$OUT/strip_stamps.o" "$SRC/grad.o" "$SRC/api.o"
+    hipcc --offload-arch=gfx950 -shared -fPIC -o "$OUT/libsvgp_stripstamps.so" "$SRC/prep.o" "$OUT/strip_stamps.o" "$SRC/grad.o" "$SRC/api.o" "$SRC/comm.o" -ldl
   elif [ "$what" = stamps ]; then
     hipcc -O3 -std=c++17 --offload-arch=gfx950 -fPIC -DSVGP_POTF2_STAMPS -c "$SRC/prep.hip" -o "$OUT/prep_stamps.o" 2>/dev/null
-    hipcc --offload-arch=gfx950 -shared -fPIC -o "$OUT/libsvgp_stamps.so" "$OUT/prep_stamps.o" "$SRC/strip.o" "$SRC/grad.o" "$SRC/api.o"
+    hipcc --offload-arch=gfx950 -shared -fPIC -o "$OUT/libsvgp_stamps.so" "$OUT/prep_stamps.o" "$SRC/strip.o" "$SRC/grad.o" "$SRC/api.o" "$SRC/comm.o" -ldl
   else
     hipcc -O3 -std=c++17 --offload-arch=gfx950 -fPIC -DSVGP_POTF2_ABLATE=$v -c "$SRC/prep.hip" -o "$OUT/prep_$v.o" 2>/dev/null
-    hipcc --offload-arch=gfx950 -shared -fPIC -o "$OUT/libsvgp_potf2_$v.so" "$OUT/prep_$v.o" "$SRC/strip.o" "$SRC/grad.o" "$SRC/api.o"
+    hipcc --offload-arch=gfx950 -shared -fPIC -o "$OUT/libsvgp_potf2_$v.so" "$OUT/prep_$v.o" "$SRC/strip.o" "$SRC/grad.o" "$SRC/api.o" "$SRC/comm.o" -ldl
   fi
 done
 ls "$OUT"/*.so

@@ -53,6 +53,38 @@ template <bool NT> __global__ void __launch_bounds__(256) col8k_k(double* K) {
     for (int h = 0; h < 2; ++h) st<NT>(reinterpret_cast<V2*>(K + j * M + (h * 4 + wave) * 128 + lane * 2), V2{double(j), double(h)});
   }
 }
+// the Kuf kernel's per-instruction pattern (4 columns x 256 B) but a workgroup owns ALL M rows of JB columns.
+// ORDER 0: for 16-column group { for 256-row chunk { ... } }  (a column's 8 KiB completes within 4 consecutive chunk steps)
+// ORDER 1: for 256-row chunk { for 16-column group { ... } }  (z fragments could stay in registers per chunk)
+template <int JB, int ORDER> __global__ void __launch_bounds__(256) own_k(double* K) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 15, kq = lane >> 4;
+  const int64_t j0 = int64_t(blockIdx.x) * JB;
+  constexpr int NG = JB / 16, NC = int(M / 256);
+  for (int o = 0; o < NG * NC; ++o) {
+    const int jg = ORDER == 0 ? o / NC : o % NG, rc = ORDER == 0 ? o % NC : o / NG;
+    const int64_t ibase = rc * 256 + wave * 64;
+    for (int r = 0; r < 4; ++r) {
+      const int64_t j = j0 + jg * 16 + kq + 4 * r;
+      if (j >= N) continue;
+      for (int g = 0; g < 2; ++g) *reinterpret_cast<V2*>(K + j * M + ibase + g * 32 + c * 2) = V2{double(j), double(g)};
+    }
+  }
+}
+// a workgroup owns RW rows (a 8*RW-byte piece of every column) of JB columns; consecutive workgroups walk down the rows
+template <int JB, int RW> __global__ void __launch_bounds__(256) part_k(double* K) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 15, kq = lane >> 4;
+  constexpr int NR = int(M / RW), NG = JB / 16, NC = RW / 256;
+  const int64_t j0 = int64_t(blockIdx.x / NR) * JB, r0 = int64_t(blockIdx.x % NR) * RW;
+  for (int jg = 0; jg < NG; ++jg)
+    for (int rc = 0; rc < NC; ++rc) {
+      const int64_t ibase = r0 + rc * 256 + wave * 64;
+      for (int r = 0; r < 4; ++r) {
+        const int64_t j = j0 + jg * 16 + kq + 4 * r;
+        if (j >= N) continue;
+        for (int g = 0; g < 2; ++g) *reinterpret_cast<V2*>(K + j * M + ibase + g * 32 + c * 2) = V2{double(j), double(g)};
+      }
+    }
+}
 template <typename F> void timeit(const char* name, F launch) {
   hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
   std::vector<float> ts;
@@ -71,6 +103,17 @@ int main() {
   timeit("col1k_nt", [&] { hipLaunchKernelGGL(col1k_k<true>, dim3(gk), dim3(256), 0, 0, K); });
   timeit("col8k", [&] { hipLaunchKernelGGL(col8k_k<false>, dim3(unsigned((N + 63) / 64)), dim3(256), 0, 0, K); });
   timeit("col8k_nt", [&] { hipLaunchKernelGGL(col8k_k<true>, dim3(unsigned((N + 63) / 64)), dim3(256), 0, 0, K); });
+  timeit("own64_o0", [&] { hipLaunchKernelGGL((own_k<64, 0>), dim3(unsigned((N + 63) / 64)), dim3(256), 0, 0, K); });
+  timeit("own64_o1", [&] { hipLaunchKernelGGL((own_k<64, 1>), dim3(unsigned((N + 63) / 64)), dim3(256), 0, 0, K); });
+  timeit("own128_o0", [&] { hipLaunchKernelGGL((own_k<128, 0>), dim3(unsigned((N + 127) / 128)), dim3(256), 0, 0, K); });
+  timeit("own128_o1", [&] { hipLaunchKernelGGL((own_k<128, 1>), dim3(unsigned((N + 127) / 128)), dim3(256), 0, 0, K); });
+  timeit("own256_o0", [&] { hipLaunchKernelGGL((own_k<256, 0>), dim3(unsigned((N + 255) / 256)), dim3(256), 0, 0, K); });
+  timeit("own256_o1", [&] { hipLaunchKernelGGL((own_k<256, 1>), dim3(unsigned((N + 255) / 256)), dim3(256), 0, 0, K); });
+  timeit("part64_512", [&] { hipLaunchKernelGGL((part_k<64, 512>), dim3(unsigned((N + 63) / 64) * 2), dim3(256), 0, 0, K); });
+  timeit("part64_256", [&] { hipLaunchKernelGGL((part_k<64, 256>), dim3(unsigned((N + 63) / 64) * 4), dim3(256), 0, 0, K); });
+  timeit("part16_256", [&] { hipLaunchKernelGGL((part_k<16, 256>), dim3(unsigned((N + 15) / 16) * 4), dim3(256), 0, 0, K); });
+  timeit("part256_512", [&] { hipLaunchKernelGGL((part_k<256, 512>), dim3(unsigned((N + 255) / 256) * 2), dim3(256), 0, 0, K); });
+  timeit("own16_o0", [&] { hipLaunchKernelGGL((own_k<16, 0>), dim3(unsigned((N + 15) / 16)), dim3(256), 0, 0, K); });
   timeit("fill", [&] { hipLaunchKernelGGL(fill_k, dim3(256 * 8), dim3(256), 0, 0, reinterpret_cast<V2*>(K), M * N / 2); });
   return 0;
 }
