@@ -624,18 +624,19 @@ __global__ void __launch_bounds__(k256, 2) kuf_kernel(KernelParams kp, const T* 
 template <typename T, int DREG, int FAMILY>
 __global__ void __launch_bounds__(512, 2) kuf_cols_kernel(KernelParams kp, const T* __restrict__ zs, int64_t M, int64_t Mp,
                                                         const T* __restrict__ x, int64_t ldx, int64_t off, int64_t len,
-                                                        T* __restrict__ K, int RW, int nR, int64_t nblk) {
-  // 512 threads = 8 waves share one z image (the LDS footprint, not registers, limits residency: two workgroups per CU
-  // = 4 waves per SIMD, so that one wave's stores and another's arithmetic overlap); waves 0-3 take the even 16-point
-  // groups, waves 4-7 the odd ones; within a group the four waves of a half cover 256 rows per chunk.
-  constexpr int VEC = Vec16<T>::N, NBLK = 4, JB = 128, XLD = JB + 16, KS = DREG / 4, NTH = 512;
+                                                        T* __restrict__ K, int RW, int nR) {
+  // 512 threads = 8 waves share one z image (the LDS footprint, not registers, limits residency).  Persistent: workgroup
+  // w keeps row range w % nR for the whole launch (z image built once, ONE barrier per launch) and its two halves
+  // (waves 0-3, 4-7) take 16-point groups 2 (w / nR) + half, + 2 gridDim / nR, ...; within a group the four waves of a
+  // half cover 256 rows per chunk.  The x fragments of a group come straight from global memory (prefetched one group
+  // ahead) with the norms by wave shuffles, so the main loop has no barrier: with a staged x tile and two barriers per
+  // 128 points, 49 % of the wave cycles were spent waiting (SQ_WAIT_ANY) behind whichever wave the store queue held back.
+  constexpr int VEC = Vec16<T>::N, NBLK = 4, KS = DREG / 4, NTH = 512;
   using V = typename Vec16<T>::type;
   using acc_t = typename Mfma16<T>::acc_t;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   T* zl = reinterpret_cast<T*>(smem_raw);   // [DREG][RW]  bscale * scaled z of the workgroup's rows
   T* znl = zl + DREG * RW;                  // [RW]        c1 |z|^2
-  T* xs = znl + RW;                         // [DREG][XLD] scaled inputs of the workgroup's points
-  T* xn = xs + DREG * XLD;                  // [JB]        c0 + c1 |x|^2
   const int d = kp.d;
   const T* __restrict__ invl = static_cast<const T*>(kp.invl);
   const int tid = threadIdx.x, lane = tid & 63, wave = (tid >> 6) & 3, half = tid >> 8, c = lane & 15, kq = lane >> 4;
@@ -645,109 +646,106 @@ __global__ void __launch_bounds__(512, 2) kuf_cols_kernel(KernelParams kp, const
   const T bscale = (FAMILY == KSE) ? T(1) : T(-2);
   const bool vec_ok = (M % VEC == 0);
   const int nch = RW / 256;
-  // Persistent workgroups (the grid is a multiple of nR): workgroup w keeps row range w % nR for the whole launch, so its
-  // z image is built once, and takes column blocks w / nR, w / nR + gridDim / nR, ...: consecutive workgroups walk down
-  // the row ranges of the same JB columns and the workgroups in flight cover one contiguous run of column blocks.
-  int64_t r0_loaded = -1;
   const int64_t r0 = int64_t(blockIdx.x % nR) * RW;
-  for (int64_t cb = blockIdx.x / nR; cb < nblk; cb += gridDim.x / nR) {
-    const int64_t j0 = cb * JB;
-    __syncthreads();   // every wave is done with the previous block's x tile (and z image)
-    if (tid < JB) {
-      int64_t g = j0 + tid;
-      g = g < len ? g : len - 1;
-      T s = T(0);
+  for (int rl = tid; rl < RW; rl += NTH) {
+    const int64_t i = r0 + rl;
+    T s = T(0);
 #pragma unroll
-      for (int f = 0; f < DREG; ++f) {
-        const T v = (f < d) ? x[int64_t(f) * ldx + off + g] * invl[f] : T(0);
-        xs[f * XLD + tid] = v;
-        s = fma(v, v, s);
-      }
-      xn[tid] = fma(c1, s, c0);
+    for (int f = 0; f < DREG; ++f) {
+      const T v = (f < d && i < Mp) ? zs[int64_t(f) * Mp + i] : T(0);
+      zl[f * RW + rl] = bscale * v;
+      s = fma(v, v, s);
     }
-    if (r0 != r0_loaded) {
-      for (int rl = tid; rl < RW; rl += NTH) {
-        const int64_t i = r0 + rl;
-        T s = T(0);
+    znl[rl] = c1 * s;
+  }
+  T il[KS];
 #pragma unroll
-        for (int f = 0; f < DREG; ++f) {
-          const T v = (f < d && i < Mp) ? zs[int64_t(f) * Mp + i] : T(0);
-          zl[f * RW + rl] = bscale * v;
-          s = fma(v, v, s);
-        }
-        znl[rl] = c1 * s;
-      }
-      r0_loaded = r0;
+  for (int q = 0; q < KS; ++q) il[q] = (4 * q + kq < d) ? invl[4 * q + kq] : T(0);
+  const int64_t ngroups = (len + 15) / 16;
+  const int64_t gstep = 2 * int64_t(gridDim.x / nR);
+  int64_t grp = 2 * int64_t(blockIdx.x / nR) + half;
+  auto load_x = [&](int64_t g16, T (&dst)[KS]) {   // feature 4q + kq of point 16 g16 + c (MFMA A operand), unscaled
+    int64_t g = g16 * 16 + c;
+    g = g < len ? g : len - 1;
+#pragma unroll
+    for (int q = 0; q < KS; ++q) dst[q] = (4 * q + kq < d) ? x[int64_t(4 * q + kq) * ldx + off + g] : T(0);
+  };
+  T an[KS];
+  if (grp < ngroups) load_x(grp, an);
+  __syncthreads();
+  for (; grp < ngroups; grp += gstep) {
+    const int64_t jb = grp * 16;
+    T a[KS], xr[4];
+    T s2 = T(0);
+#pragma unroll
+    for (int q = 0; q < KS; ++q) {
+      a[q] = an[q] * il[q];
+      s2 = fma(a[q], a[q], s2);
     }
-    __syncthreads();
-    for (int jg = half; jg < JB / 16; jg += 2) {
-      const int64_t jb = j0 + jg * 16;
-      if (jb >= len) break;
-      T a[KS], xr[4];
-  #pragma unroll
-      for (int q = 0; q < KS; ++q) a[q] = xs[(4 * q + kq) * XLD + jg * 16 + c];
-  #pragma unroll
-      for (int r = 0; r < 4; ++r) xr[r] = xn[jg * 16 + Mfma16<T>::row(lane, r)];
-      // destination of (r, g = 0, chunk 0): the chunk and g offsets are added as constants below
-      T* dst0[4];
-      bool live[4];
-  #pragma unroll
+    if (grp + gstep < ngroups) load_x(grp + gstep, an);   // in flight during this group's arithmetic
+    s2 += __shfl_xor(s2, 16);
+    s2 += __shfl_xor(s2, 32);
+    const T xnv = fma(c1, s2, c0);               // c0 + c1 |x|^2 of point c, in every lane of column c
+#pragma unroll
+    for (int r = 0; r < 4; ++r) xr[r] = __shfl(xnv, Mfma16<T>::row(lane, r));
+    // destination of (r, g = 0, chunk 0): the chunk and g offsets are added as constants below
+    T* dst0[4];
+    bool live[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int64_t j = jb + Mfma16<T>::row(lane, r);
+      live[r] = j < len;
+      dst0[r] = K + (live[r] ? j : jb) * M + r0 + wave * 64 + c * VEC;
+    }
+    for (int rc = 0; rc < nch; ++rc) {
+      const int rl0 = rc * 256 + wave * 64;
+      const int64_t ibase = r0 + rl0;
+      if (ibase >= M) break;   // wave-uniform
+      acc_t acc[NBLK];
+      T zb[NBLK][KS];
+#pragma unroll
+      for (int b = 0; b < NBLK; ++b) {
+        const int rl = rl0 + (b / VEC) * (16 * VEC) + c * VEC + (b % VEC);
+        const T zn = znl[rl];
+#pragma unroll
+        for (int q = 0; q < KS; ++q) zb[b][q] = zl[(4 * q + kq) * RW + rl];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[b][r] = xr[r] + zn;
+      }
+#pragma unroll
+      for (int q = 0; q < KS; ++q)
+#pragma unroll
+        for (int b = 0; b < NBLK; ++b) acc[b] = Mfma16<T>::mma(a[q], zb[b][q], acc[b]);
+#pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int64_t j = jb + Mfma16<T>::row(lane, r);
-        live[r] = j < len;
-        dst0[r] = K + (live[r] ? j : jb) * M + r0 + wave * 64 + c * VEC;
-      }
-      for (int rc = 0; rc < nch; ++rc) {
-        const int rl0 = rc * 256 + wave * 64;
-        const int64_t ibase = r0 + rl0;
-        if (ibase >= M) break;   // wave-uniform
-        acc_t acc[NBLK];
-        T zb[NBLK][KS];
-  #pragma unroll
-        for (int b = 0; b < NBLK; ++b) {
-          const int rl = rl0 + (b / VEC) * (16 * VEC) + c * VEC + (b % VEC);
-          const T zn = znl[rl];
-  #pragma unroll
-          for (int q = 0; q < KS; ++q) zb[b][q] = zl[(4 * q + kq) * RW + rl];
-  #pragma unroll
-          for (int r = 0; r < 4; ++r) acc[b][r] = xr[r] + zn;
-        }
-  #pragma unroll
-        for (int q = 0; q < KS; ++q)
-  #pragma unroll
-          for (int b = 0; b < NBLK; ++b) acc[b] = Mfma16<T>::mma(a[q], zb[b][q], acc[b]);
-  #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          if (!live[r]) continue;
-  #pragma unroll
-          for (int g = 0; g < NBLK / VEC; ++g) {
-            V out;
-  #pragma unroll
-            for (int e = 0; e < VEC; ++e) {
-              const T v = acc[g * VEC + e][r];
-  #if defined(SVGP_ABLATE) && (SVGP_ABLATE & 64)   // timing only: no kernel function
-              out[e] = v;
-  #else
-              out[e] = (FAMILY == KSE) ? kexp(v < c0 ? v : c0) : kappa<T>(FAMILY, v > T(0) ? v : T(0), variance);
-  #endif
-            }
-            const int64_t i = ibase + g * (16 * VEC) + c * VEC;
-            T* dst = dst0[r] + rc * 256 + g * (16 * VEC);
-  #if defined(SVGP_ABLATE) && (SVGP_ABLATE & 32)   // timing only: no stores (the compare keeps the arithmetic alive)
-            if (out[0] != T(-1.2345e300)) continue;
-  #endif
-            if (vec_ok && i + VEC <= M) {
-              *reinterpret_cast<V*>(dst) = out;
-            } else {
-  #pragma unroll
-              for (int e = 0; e < VEC; ++e)
-                if (i + e < M) dst[e] = out[e];
-            }
+        if (!live[r]) continue;
+#pragma unroll
+        for (int g = 0; g < NBLK / VEC; ++g) {
+          V out;
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) {
+            const T v = acc[g * VEC + e][r];
+#if defined(SVGP_ABLATE) && (SVGP_ABLATE & 64)   // timing only: no kernel function
+            out[e] = v;
+#else
+            out[e] = (FAMILY == KSE) ? kexp(v < c0 ? v : c0) : kappa<T>(FAMILY, v > T(0) ? v : T(0), variance);
+#endif
+          }
+          const int64_t i = ibase + g * (16 * VEC) + c * VEC;
+          T* dst = dst0[r] + rc * 256 + g * (16 * VEC);
+#if defined(SVGP_ABLATE) && (SVGP_ABLATE & 32)   // timing only: no stores (the compare keeps the arithmetic alive)
+          if (out[0] != T(-1.2345e300)) continue;
+#endif
+          if (vec_ok && i + VEC <= M) {
+            *reinterpret_cast<V*>(dst) = out;
+          } else {
+#pragma unroll
+            for (int e = 0; e < VEC; ++e)
+              if (i + e < M) dst[e] = out[e];
           }
         }
       }
     }
-
   }
 }
 
@@ -870,11 +868,15 @@ void launch_final_reduce(hipStream_t s, const double* partial, const unsigned* n
 template <typename T, int FAMILY>
 static void launch_kuf_f(hipStream_t s, const KernelParams& kp, const T* zs, int64_t M, int64_t Mp, const T* x, int64_t ldx,
                          int64_t off, int64_t len, T* Kuf) {
-  // Columns longer than 8 KiB (C4: M = 8192 fp32) keep the 256 x 256 block kernel: there the column-owning kernel's row
-  // ranges are short pieces of long columns again and its lower residency costs more than it gains (same box, C4: 4.5-4.7
-  // vs 5.15-5.2 TB/s); up to 8 KiB it wins (H f64 4.95-5.0 vs 4.18-4.24, H32 5.25-5.5 vs 5.25, C3 4.5-4.65 vs 4.2-4.25).
+  // Which kernel (same-box A/B runs, tools/kuf_ab.sh; TB/s, column-owning vs 256 x 256 blocks):
+  //   H   f64 d 8  SE   M 1024 (8 KiB columns)   4.98-4.99 vs 4.04-4.16      C2 f64 d 8 SE M 512   4.28 vs 3.9
+  //   C3  f32 d 16 M52  M 2048 (8 KiB columns)   4.70      vs 4.17-4.18      H32 f32 d 8 SE M 1024 4.97 vs 5.28
+  //   C4  f32 d 8  SE   M 8192 (32 KiB columns)  4.5-4.7   vs 5.15-5.2
+  // i.e. the column-owning kernel wins where the arithmetic per element is heavy enough to need its barrier-free,
+  // persistent structure (f64; f32 with d > 8) and the column fits one 8 KiB piece; the light f32 d <= 8 case is purely
+  // store-bound in both and the block kernel's higher residency wins by a few per cent.
   static const int forced_v = env_int("SVGP_KUF_V1", -1);   // A/B knob: 1 = block kernel, 0 = column-owning kernel
-  const bool v1 = forced_v >= 0 ? forced_v != 0 : size_t(M) * sizeof(T) > 8192;
+  const bool v1 = forced_v >= 0 ? forced_v != 0 : (size_t(M) * sizeof(T) > 8192 || (sizeof(T) == 4 && kp.d <= 8));
   if (v1) {
     const dim3 grid((unsigned)(((len + 255) / 256) * ((M + 255) / 256)));
 #define SVGP_KUF_LAUNCH(DREG) \
@@ -902,21 +904,20 @@ static void launch_kuf_f(hipStream_t s, const KernelParams& kp, const T* zs, int
     rw = rw < 256 ? 256 : rw;
     rw = rw > mrows ? mrows : rw;
     const int nR = int((M + rw - 1) / rw);
-    const size_t lds = (size_t(DREG + 1) * size_t(rw) + size_t(DREG) * (128 + 16) + 128) * sizeof(T);
+    const size_t lds = size_t(DREG + 1) * size_t(rw) * sizeof(T);
     auto kern = kuf_cols_kernel<T, DREG, FAMILY>;
     set_max_lds(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
-    const int64_t nblk = (len + 127) / 128;   // column blocks
+    const int64_t npairs = (len + 31) / 32;   // a workgroup's two halves take one 16-point group each per step
     int per_cu = 0, dev = 0, cus = 256;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 512, lds) != hipSuccess || per_cu < 1) per_cu = 1;
     (void)hipGetDevice(&dev);
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     static const int forced_wg = env_int("SVGP_KUF_WG_PER_CU", 0);
     if (forced_wg > 0 && forced_wg < per_cu) per_cu = forced_wg;
-    static const int persist = env_int("SVGP_KUF_PERSIST", 1);   // A/B knob: 0 = one column block per workgroup
-    int64_t slots = persist ? int64_t(cus) * per_cu / nR * nR : nblk * nR;
+    int64_t slots = int64_t(cus) * per_cu / nR * nR;
     slots = slots < nR ? nR : slots;
-    const dim3 grid((unsigned)(nblk * nR < slots ? nblk * nR : slots));
-    hipLaunchKernelGGL(kern, grid, dim3(512), lds, s, kp, zs, M, Mp, x, ldx, off, len, Kuf, int(rw), nR, nblk);
+    const dim3 grid((unsigned)(npairs * nR < slots ? npairs * nR : slots));
+    hipLaunchKernelGGL(kern, grid, dim3(512), lds, s, kp, zs, M, Mp, x, ldx, off, len, Kuf, int(rw), nR);
   };
   if (kp.d <= 4) launch(std::integral_constant<int, 4>{});
   else if (kp.d <= 8) launch(std::integral_constant<int, 8>{});

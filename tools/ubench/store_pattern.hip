@@ -85,6 +85,38 @@ template <int JB, int RW> __global__ void __launch_bounds__(256) part_k(double* 
       }
     }
 }
+// own_k<128, 0> plus what the Kuf kernel does between its stores: WHAT bit 1: 8 f64 MFMAs per 8 stores, bit 2: 12 LDS reads,
+// bit 4: ~320 dependent-chain f64 FMAs (the exp polynomials).  Which of them slows the store stream?
+using A4 = double __attribute__((ext_vector_type(4)));
+template <int WHAT, int LDSPAD = 0> __global__ void __launch_bounds__(256) mix_k(double* K, double seed) {
+  __shared__ double lds[2048 + LDSPAD];   // LDSPAD limits residency: 2048 + 2048 doubles = 32 KiB -> 5 workgroups per CU, ...
+  if (LDSPAD && seed == 123.0) lds[2048 + threadIdx.x] = seed;
+  for (int i = threadIdx.x; i < 2048; i += 256) lds[i] = seed * i;
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 15, kq = lane >> 4;
+  const int64_t j0 = int64_t(blockIdx.x) * 128;
+  for (int o = 0; o < 8 * 4; ++o) {
+    const int jg = o / 4, rc = o % 4;
+    const int64_t ibase = rc * 256 + wave * 64;
+    A4 acc[4];
+    for (int b = 0; b < 4; ++b) acc[b] = A4{seed, seed, seed, seed};
+    double zb[8];
+    for (int q = 0; q < 8; ++q) zb[q] = (WHAT & 2) ? lds[(q * 256 + rc * 64 + lane + jg) & 2047] : seed + q;
+    if (WHAT & 1)
+      for (int q = 0; q < 2; ++q)
+        for (int b = 0; b < 4; ++b) acc[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(seed, zb[b * 2 + q], acc[b], 0, 0, 0);
+    for (int r = 0; r < 4; ++r) {
+      const int64_t j = j0 + jg * 16 + kq + 4 * r;
+      if (j >= N) continue;
+      for (int g = 0; g < 2; ++g) {
+        double v0 = acc[2 * g][r] + zb[g], v1 = acc[2 * g + 1][r] + zb[4 + g];
+        if (WHAT & 4)
+          for (int t = 0; t < 20; ++t) { v0 = fma(v0, 0.999, 1e-3); v1 = fma(v1, 0.999, 1e-3); }
+        *reinterpret_cast<V2*>(K + j * M + ibase + g * 32 + c * 2) = V2{v0, v1};
+      }
+    }
+  }
+}
 template <typename F> void timeit(const char* name, F launch) {
   hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
   std::vector<float> ts;
@@ -113,6 +145,15 @@ int main() {
   timeit("part64_256", [&] { hipLaunchKernelGGL((part_k<64, 256>), dim3(unsigned((N + 63) / 64) * 4), dim3(256), 0, 0, K); });
   timeit("part16_256", [&] { hipLaunchKernelGGL((part_k<16, 256>), dim3(unsigned((N + 15) / 16) * 4), dim3(256), 0, 0, K); });
   timeit("part256_512", [&] { hipLaunchKernelGGL((part_k<256, 512>), dim3(unsigned((N + 255) / 256) * 2), dim3(256), 0, 0, K); });
+  timeit("mix_none", [&] { hipLaunchKernelGGL((mix_k<0>), dim3(unsigned((N + 127) / 128)), dim3(256), 0, 0, K, 1.0); });
+  timeit("mix_mfma", [&] { hipLaunchKernelGGL((mix_k<1>), dim3(unsigned((N + 127) / 128)), dim3(256), 0, 0, K, 1.0); });
+  timeit("mix_lds", [&] { hipLaunchKernelGGL((mix_k<2>), dim3(unsigned((N + 127) / 128)), dim3(256), 0, 0, K, 1.0); });
+  timeit("mix_fma", [&] { hipLaunchKernelGGL((mix_k<4>), dim3(unsigned((N + 127) / 128)), dim3(256), 0, 0, K, 1.0); });
+  timeit("mix_all", [&] { hipLaunchKernelGGL((mix_k<7>), dim3(unsigned((N + 127) / 128)), dim3(256), 0, 0, K, 1.0); });
+  timeit("mix_all_5wg", [&] { hipLaunchKernelGGL((mix_k<7, 2048>), dim3(unsigned((N + 127) / 128)), dim3(256), 0, 0, K, 1.0); });
+  timeit("mix_all_4wg", [&] { hipLaunchKernelGGL((mix_k<7, 3072>), dim3(unsigned((N + 127) / 128)), dim3(256), 0, 0, K, 1.0); });
+  timeit("mix_all_3wg", [&] { hipLaunchKernelGGL((mix_k<7, 4608>), dim3(unsigned((N + 127) / 128)), dim3(256), 0, 0, K, 1.0); });
+  timeit("mix_all_2wg", [&] { hipLaunchKernelGGL((mix_k<7, 7168>), dim3(unsigned((N + 127) / 128)), dim3(256), 0, 0, K, 1.0); });
   timeit("own16_o0", [&] { hipLaunchKernelGGL((own_k<16, 0>), dim3(unsigned((N + 15) / 16)), dim3(256), 0, 0, K); });
   timeit("fill", [&] { hipLaunchKernelGGL(fill_k, dim3(256 * 8), dim3(256), 0, 0, reinterpret_cast<V2*>(K), M * N / 2); });
   return 0;
