@@ -245,11 +245,27 @@ struct StripOuts {
 // enqueue the fused strip kernel + final reduce over points [off, off+len) of (x, y)
 int enqueue_strips(svgp_ctx* ctx, svgp_model* m, const void* x, int64_t ldx, const void* y, int64_t off, int64_t len,
                    const StripOuts& o) {
-  const StripPlan plan = strip_plan(m->dtype, m->Mp, len, ctx->num_cus);
+  StripPlan plan = strip_plan(m->dtype, m->Mp, len, ctx->num_cus);
+  if (plan.concurrent_tail && (o.A || o.C || o.At || o.Ct)) plan = strip_plan_single(m->dtype, m->Mp, len, ctx->num_cus);
   const size_t wb_main = plan.grid ? strip_work_bytes(m->dtype, m->Mp, plan.nt, plan.grid) : 0;
   const size_t wb_tail = plan.nt_tail ? strip_work_bytes(m->dtype, m->Mp, plan.nt_tail, plan.grid_tail) : 0;
-  int rc = ensure_scratch(ctx, wb_main > wb_tail ? wb_main : wb_tail, size_t(len));
+  int rc = ensure_scratch(ctx, plan.concurrent_tail ? wb_main : (wb_main > wb_tail ? wb_main : wb_tail), size_t(len));
   if (rc) return rc;
+  if (plan.concurrent_tail) {
+    if (!ctx->stream2) {
+      HIPC(ctx, hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
+      HIPC(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
+      HIPC(ctx, hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
+      HIPC(ctx, hipMalloc(&ctx->counter2, 64));
+    }
+    if (wb_tail > ctx->work2_bytes) {
+      if (ctx->work2) (void)hipFree(ctx->work2);
+      ctx->work2 = nullptr;
+      ctx->work2_bytes = 0;
+      HIPC(ctx, hipMalloc(&ctx->work2, wb_tail));
+      ctx->work2_bytes = wb_tail;
+    }
+  }
   StripArgs a{};
   a.T = m->T;
   a.U = m->U;
@@ -281,6 +297,7 @@ int enqueue_strips(svgp_ctx* ctx, svgp_model* m, const void* x, int64_t ldx, con
   lp.gh_w = m->gh_w;
   lp.clamp_neg_var = (m->desc.neg_var_policy == SVGP_NEGVAR_CLAMP);
   lp.mean_const = m->desc.mean_const;
+  if (plan.concurrent_tail) HIPC(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
   if (plan.grid) {
     StripArgs am = a;
     am.len = plan.points;
@@ -300,9 +317,22 @@ int enqueue_strips(svgp_ctx* ctx, svgp_model* m, const void* x, int64_t ldx, con
     if (a.C_out) at.C_out = static_cast<char*>(a.C_out) + size_t(sh) * es;
     if (a.At_out) at.At_out = static_cast<char*>(a.At_out) + size_t(sh) * size_t(m->Mp) * es;
     if (a.Ct_out) at.Ct_out = static_cast<char*>(a.Ct_out) + size_t(sh) * size_t(m->Mp) * es;
-    HIPC(ctx, hipMemsetAsync(ctx->counter, 0, sizeof(unsigned), ctx->stream));
-    launch_strip(m->dtype, ctx->stream, at, plan.nt_tail, plan.grid_tail, plan.nstrips_tail);
-    KCHECK(ctx, "strip tail");
+    if (plan.concurrent_tail) {
+      // fork: the tail may start as soon as everything before this point on the main stream is done (the prep kernels,
+      // recorded BEFORE the main launch); join: the main stream continues after both launches
+      at.work = ctx->work2;
+      at.counter = ctx->counter2;
+      HIPC(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
+      HIPC(ctx, hipMemsetAsync(ctx->counter2, 0, sizeof(unsigned), ctx->stream2));
+      launch_strip(m->dtype, ctx->stream2, at, plan.nt_tail, plan.grid_tail, plan.nstrips_tail);
+      KCHECK(ctx, "strip tail (concurrent)");
+      HIPC(ctx, hipEventRecord(ctx->ev_join, ctx->stream2));
+      HIPC(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
+    } else {
+      HIPC(ctx, hipMemsetAsync(ctx->counter, 0, sizeof(unsigned), ctx->stream));
+      launch_strip(m->dtype, ctx->stream, at, plan.nt_tail, plan.grid_tail, plan.nstrips_tail);
+      KCHECK(ctx, "strip tail");
+    }
   }
   HIPC(ctx, hipEventRecord(ctx->ev[2], ctx->stream));
   if (o.skip_expect) return SVGP_OK;
@@ -524,6 +554,11 @@ int32_t svgp_ctx_destroy(svgp_ctx* c) {
   if (c->d_res) (void)hipFree(c->d_res);
   if (c->d_coll) (void)hipFree(c->d_coll);
   if (c->counter) (void)hipFree(c->counter);
+  if (c->counter2) (void)hipFree(c->counter2);
+  if (c->work2) (void)hipFree(c->work2);
+  if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+  if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+  if (c->stream2) { (void)hipStreamSynchronize(c->stream2); (void)hipStreamDestroy(c->stream2); }
   if (c->kuf_buf) (void)hipFree(c->kuf_buf);
   if (c->gws) { c->gws->release(); delete c->gws; }
   for (auto& e : c->ev)
@@ -996,7 +1031,7 @@ int grad_enqueue(svgp_ctx* ctx, svgp_model* m, const svgp_data* data, int64_t of
     const int64_t clen = (len - c0 < nc) ? len - c0 : nc;
     const int64_t ncp = (clen + 127) / 128 * 128;
     // forward strips + likelihood gradients + phase 3 in ONE launch: leaves A, P point-major and g_mu, g_v of the chunk
-    const StripPlan plan = strip_plan(dt, Mp, clen, ctx->num_cus);
+    const StripPlan plan = strip_plan_single(dt, Mp, clen, ctx->num_cus);
     const int nt = plan.grid ? plan.nt : plan.nt_tail, grid = plan.grid ? plan.grid : plan.grid_tail;
     const int64_t nstrips = plan.grid ? plan.nstrips : plan.nstrips_tail;
     rc = ensure_scratch(ctx, strip_work_bytes(dt, Mp, nt, grid), 1);

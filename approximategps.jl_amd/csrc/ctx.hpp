@@ -24,6 +24,11 @@ struct svgp_ctx {
   double* mom = nullptr;      size_t mom_cap = 0;           // [2][mom_cap] per-point mean / variance
   double* d_res = nullptr;    // [8] device results
   unsigned* counter = nullptr; // strip queue head of the running strip launch
+  // concurrent narrow-strip launch for the last partial round of a batch (enqueue_strips): its own stream, queue and scratch
+  hipStream_t stream2 = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  unsigned* counter2 = nullptr;
+  void* work2 = nullptr;      size_t work2_bytes = 0;
   void* kuf_buf = nullptr;    size_t kuf_bytes = 0;
   struct GradWs* gws = nullptr;  // gradient workspace, cached by problem shape
   // data-parallel communicator (comm.hip): one RCCL rank per context; world == 1 without one

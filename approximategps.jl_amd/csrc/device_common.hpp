@@ -124,7 +124,8 @@ struct TileGemm {
   static constexpr int Q_RPP = NTHR / Q_TPR;
   static constexpr int Q_PASSES = (BK / Q_RPP) > 0 ? (BK / Q_RPP) : 1;
   static_assert(BK % P_RPP == 0, "BK must be a multiple of the P rows per pass");
-  static_assert(BK % Q_RPP == 0, "BK must be a multiple of the Q rows per pass");
+  static_assert(BK % Q_RPP == 0 || Q_RPP % BK == 0, "BK and the Q rows per pass must divide one another");
+  static constexpr bool Q_PARTIAL = Q_RPP > BK;   // narrow tiles (f32, NT = 32): only the first BK * Q_TPR threads carry Q data
 
   static constexpr int P_TILE = BK * PLD;
   static constexpr int Q_TILE = BK * QLD;
@@ -232,6 +233,7 @@ struct TileGemm {
     return;
 #endif
     const char* base = reinterpret_cast<const char*>(src);
+    if (Q_PARTIAL && int(threadIdx.x) >= BK * Q_TPR) return;
 #pragma unroll
     for (int p = 0; p < Q_PASSES; ++p) r.v[p] = *reinterpret_cast<const V*>(base + off.o[p]);
   }
@@ -247,6 +249,7 @@ struct TileGemm {
   static __device__ __forceinline__ void store_q(const QRegs& r, T* __restrict__ Qs) {
     const int t = threadIdx.x;
     const int kk0 = t / Q_TPR, c = (t % Q_TPR) * VEC;
+    if (Q_PARTIAL && t >= BK * Q_TPR) return;
 #pragma unroll
     for (int p = 0; p < Q_PASSES; ++p) *reinterpret_cast<V*>(Qs + (kk0 + p * Q_RPP) * QLD + c) = r.v[p];
   }

@@ -99,8 +99,10 @@ struct StripPlan {       // regular-width launch over the first `points` points,
   int64_t nstrips, points;
   int nt_tail, grid_tail;
   int64_t nstrips_tail;
+  bool concurrent_tail;   // the tail launch runs on a second stream BESIDE the main one (last partial round of a large batch)
 };
 StripPlan strip_plan(int dtype, int64_t Mp, int64_t len, int num_cus);
+StripPlan strip_plan_single(int dtype, int64_t Mp, int64_t len, int num_cus);   // never a concurrent tail (paths that write A / C)
 void launch_strip(int dtype, hipStream_t s, const StripArgs& a, int nt, int grid, int64_t nstrips);
 // the value-and-gradient form: phases 1-2 as launch_strip, then the per-point likelihood gradients and phase 3
 // (a dense Mp x Mp GEMM on the strip's A, still in its scratch strip); writes At_out, Pt_out, gmu_out, gv_out, part5

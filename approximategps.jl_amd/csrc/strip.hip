@@ -800,25 +800,57 @@ int strip_grid(int dtype, int nt, int64_t nstrips, int num_cus) {
 // Measured and rejected: running the last partial round of a large batch as a second, half-width launch (N = 1e5:
 // 4.59 vs 4.62 ms, N = 2e5: 8.05 vs 8.31 ms) — the single launch's dynamic queue already hands the last strips to the
 // workgroups that finish first, and those then run alone on their CU at ~0.65 of the paired strip time.
+// Large batches whose strip count is not a multiple of the workgroup slots (C2, C4: 1563 strips on 512 slots = 3.05
+// rounds) used to pay a whole strip time for the last 27 strips.  Now the whole rounds run as one launch and the
+// remainder as half-width strips in a SECOND launch on a second stream, concurrently: its workgroups become resident as
+// the main launch's finish (or before them - either way the short jobs fill the ragged end).  A sequential second launch
+// did nothing (kernel boundaries are barriers).  Same-box A/B (tools/cfg_ab.sh): C4 127.8 -> 123.3 ms, C2 1.16 -> 1.135 ms
+// (27 left-over strips = 5 % of a round); H32 16.87 -> 16.98 ms (133 left-over strips = 26 % of a round: the dynamic queue
+// of one launch already spreads those), hence the 15 % threshold.
 StripPlan strip_plan(int dtype, int64_t Mp, int64_t len, int num_cus) {
   StripPlan p{};
   const int W = strip_nt(dtype, Mp, len);
-  const int W2 = (dtype == 0 && W == 64) ? 32 : (dtype == 1 && W == 128) ? 64 : 0;
+  const int W2 = W / 2 >= 32 ? W / 2 : 0;   // f64: 64 -> 32; f32: 128 -> 64, 64 -> 32
   const int64_t S = (len + W - 1) / W;
   p.nt = W; p.nstrips = S; p.points = len; p.grid = strip_grid(dtype, W, S, num_cus);
   static const int enabled = env_int("SVGP_TAIL", 1);
   if (!W2 || !enabled) return p;
   const int64_t S2 = (len + W2 - 1) / W2;
-  if (S2 > strip_grid(dtype, W2, INT64_MAX, num_cus)) return p;
-  p.nstrips = 0; p.points = 0; p.grid = 0;
-  p.nt_tail = W2; p.nstrips_tail = S2; p.grid_tail = strip_grid(dtype, W2, S2, num_cus);
+  const int64_t G = strip_grid(dtype, W, INT64_MAX, num_cus);
+  if (S2 <= strip_grid(dtype, W2, INT64_MAX, num_cus)) {   // small batch: everything as half-width strips
+    p.nstrips = 0; p.points = 0; p.grid = 0;
+    p.nt_tail = W2; p.nstrips_tail = S2; p.grid_tail = strip_grid(dtype, W2, S2, num_cus);
+    return p;
+  }
+  static const int ctail = env_int("SVGP_CTAIL", 1);
+  const int64_t rem = S % G;
+  if (ctail && S > G && rem > 0 && rem * 100 < G * 15) {   // a last round less than 15 % full
+    const int64_t whole = S - rem;
+    p.nstrips = whole; p.points = whole * W; p.grid = int(G);
+    const int64_t left = len - p.points;
+    p.nt_tail = W2; p.nstrips_tail = (left + W2 - 1) / W2; p.grid_tail = strip_grid(dtype, W2, p.nstrips_tail, num_cus);
+    p.concurrent_tail = true;
+  }
   return p;
+}
+
+StripPlan strip_plan_single(int dtype, int64_t Mp, int64_t len, int num_cus) {
+  StripPlan p = strip_plan(dtype, Mp, len, num_cus);
+  if (!p.concurrent_tail) return p;
+  StripPlan q{};
+  q.nt = p.nt;
+  q.nstrips = (len + p.nt - 1) / p.nt;
+  q.points = len;
+  q.grid = strip_grid(dtype, p.nt, q.nstrips, num_cus);
+  return q;
 }
 
 void launch_strip(int dtype, hipStream_t s, const StripArgs& a, int nt, int grid, int64_t nstrips) {
   static const bool bk32 = env_int("SVGP_STRIP_BK", 16) == 32;
   if (nt == 32 && dtype == 0) {
     launch_strip_t<double, 32, 16, 256>(s, a, grid, nstrips);
+  } else if (nt == 32) {
+    launch_strip_t<float, 32, 16, 256>(s, a, grid, nstrips);
   } else if (nt == 64) {
     if (dtype == 0) launch_strip_t<double, 64, 16, 256>(s, a, grid, nstrips);
     else launch_strip_t<float, 64, 16, 256>(s, a, grid, nstrips);   // BK = 32 measured identical
