@@ -468,7 +468,9 @@ int make_data(svgp_ctx* ctx, int dtype, int layout, int d, int64_t n, const void
   if (d < 1 || d > 32 || n < 1 || !x_host) return fail(ctx, SVGP_INVALID_ARG, "bad data shape");
   if (layout < 0 || layout > SVGP_VEC || (layout == SVGP_VEC && d != 1)) return fail(ctx, SVGP_INVALID_ARG, "bad layout");
   const size_t es = esize(dtype);
-  svgp_data* D = new (std::nothrow) svgp_data();
+  DataGuard guard;
+  guard.D = new (std::nothrow) svgp_data();
+  svgp_data* D = guard.D;
   if (!D) return SVGP_OOM;
   D->dtype = dtype;
   D->d = d;
@@ -477,24 +479,19 @@ int make_data(svgp_ctx* ctx, int dtype, int layout, int d, int64_t n, const void
   hipStream_t s = ctx->stream;
   hipError_t e = hipMalloc(&D->x, size_t(n) * d * es);
   if (e == hipSuccess && y_host) e = hipMalloc(&D->y, size_t(n) * es);
-  if (e != hipSuccess) {
-    if (D->x) (void)hipFree(D->x);
-    delete D;
-    return fail(ctx, SVGP_OOM, "hipMalloc failed for data");
-  }
+  if (e != hipSuccess) return fail(ctx, SVGP_OOM, "hipMalloc failed for data");
   if (layout == SVGP_COLVECS && d > 1) {
-    void* tmp = nullptr;
-    HIPC(ctx, hipMalloc(&tmp, size_t(n) * d * es));
-    HIPC(ctx, hipMemcpyAsync(tmp, x_host, size_t(n) * d * es, hipMemcpyHostToDevice, s));
-    launch_transpose_colvecs(dtype, s, tmp, d, n, D->ldx, D->x);
+    DevBuf tmp;
+    HIPC(ctx, tmp.alloc(size_t(n) * d * es));
+    HIPC(ctx, hipMemcpyAsync(tmp.p, x_host, size_t(n) * d * es, hipMemcpyHostToDevice, s));
+    launch_transpose_colvecs(dtype, s, tmp.p, d, n, D->ldx, D->x);
     HIPC(ctx, hipStreamSynchronize(s));
-    (void)hipFree(tmp);
   } else {
     HIPC(ctx, hipMemcpyAsync(D->x, x_host, size_t(n) * d * es, hipMemcpyHostToDevice, s));
   }
   if (y_host) HIPC(ctx, hipMemcpyAsync(D->y, y_host, size_t(n) * es, hipMemcpyHostToDevice, s));
   HIPC(ctx, hipStreamSynchronize(s));
-  *out = D;
+  *out = guard.release();
   return SVGP_OK;
 }
 
@@ -782,8 +779,9 @@ int32_t svgp_posterior(svgp_ctx* ctx, svgp_model* m, void* Lk_out, void* alpha_o
   if (rc) return rc;
   hipStream_t s = ctx->stream;
   const size_t es = m->es, M = size_t(m->M), Mp = size_t(m->Mp);
-  void* tmp = nullptr;
-  HIPC(ctx, hipMalloc(&tmp, (M * M + Mp) * es));
+  DevBuf tmpbuf;
+  HIPC(ctx, tmpbuf.alloc((M * M + Mp) * es));
+  void* tmp = tmpbuf.p;
   void* vec = static_cast<char*>(tmp) + M * M * es;
   if (Lk_out) {
     launch_extract_lower(m->dtype, s, m->L, m->Mp, m->M, tmp);
@@ -807,7 +805,6 @@ int32_t svgp_posterior(svgp_ctx* ctx, svgp_model* m, void* Lk_out, void* alpha_o
     HIPC(ctx, hipStreamSynchronize(s));
   }
   HIPC(ctx, hipGetLastError());
-  (void)hipFree(tmp);
   return SVGP_OK;
 }
 

@@ -115,6 +115,29 @@ inline bool debug_sync() {
   } while (0)
 
 namespace svgp {
+// device memory released on every path out of a function (the HIPC macro returns early)
+struct DevBuf {
+  void* p = nullptr;
+  DevBuf() = default;
+  DevBuf(const DevBuf&) = delete;
+  DevBuf& operator=(const DevBuf&) = delete;
+  ~DevBuf() { if (p) (void)hipFree(p); }
+  hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes); }
+};
+// a svgp_data under construction: freed unless release()d to the caller
+struct DataGuard {
+  svgp_data* D = nullptr;
+  ~DataGuard() {
+    if (!D) return;
+    if (D->own) {
+      if (D->x) (void)hipFree(D->x);
+      if (D->y) (void)hipFree(D->y);
+    }
+    delete D;
+  }
+  svgp_data* release() { svgp_data* d = D; D = nullptr; return d; }
+};
+
 // ---- comm.hip: RCCL, loaded lazily with dlopen (the library has no link-time dependency on it) ----
 // in-place sum all-reduce of `count` elements (f64: dtype 0, f32: dtype 1) on the context's stream; no host sync
 int comm_allreduce(svgp_ctx* ctx, void* buf, size_t count, int dtype);
