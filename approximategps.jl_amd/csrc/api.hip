@@ -231,6 +231,16 @@ int ensure_scratch(svgp_ctx* ctx, size_t work_bytes, size_t npoints) {
   return SVGP_OK;
 }
 
+// second stream (+ fork / join events, its own strip queue head) for launches that run BESIDE the main stream's
+int ensure_stream2(svgp_ctx* ctx) {
+  if (ctx->stream2) return SVGP_OK;
+  HIPC(ctx, hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
+  HIPC(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
+  HIPC(ctx, hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
+  HIPC(ctx, hipMalloc(&ctx->counter2, 64));
+  return SVGP_OK;
+}
+
 struct StripOuts {
   void* mu = nullptr;
   void* var = nullptr;
@@ -252,12 +262,8 @@ int enqueue_strips(svgp_ctx* ctx, svgp_model* m, const void* x, int64_t ldx, con
   int rc = ensure_scratch(ctx, plan.concurrent_tail ? wb_main : (wb_main > wb_tail ? wb_main : wb_tail), size_t(len));
   if (rc) return rc;
   if (plan.concurrent_tail) {
-    if (!ctx->stream2) {
-      HIPC(ctx, hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
-      HIPC(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
-      HIPC(ctx, hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
-      HIPC(ctx, hipMalloc(&ctx->counter2, 64));
-    }
+    rc = ensure_stream2(ctx);
+    if (rc) return rc;
     if (wb_tail > ctx->work2_bytes) {
       if (ctx->work2) (void)hipFree(ctx->work2);
       ctx->work2 = nullptr;
@@ -1045,14 +1051,29 @@ int grad_enqueue(svgp_ctx* ctx, svgp_model* m, const svgp_data* data, int64_t of
     HIPC(ctx, hipMemsetAsync(ctx->counter, 0, sizeof(unsigned), s));
     launch_strip_grad(dt, s, a, nt, grid, nstrips);
     KCHECK(ctx, "strip (value and gradient)");
+    // Knob (off): the kernel-gradient reductions (f64 VALU, latency-bound, no MFMA) on the second stream BESIDE the SYRK
+    // (MFMA-bound); both only read this chunk's A / P / g, the join comes before the next chunk's strips overwrite them.
+    // Measured and not adopted: H 97.8-98.3 vs 98.2-98.4 ms, C5 16.5-16.6 vs 16.6-16.7 ms (same box) - the SYRK's 504
+    // workgroups leave kgrad no room to run beside them.
+    static const int kg_overlap = [] { const char* e = getenv("SVGP_KGRAD_OVERLAP"); return e ? atoi(e) : 0; }();
+    hipStream_t sk = s;
+    if (kg_overlap) {
+      rc = ensure_stream2(ctx);
+      if (rc) return rc;
+      sk = ctx->stream2;
+      HIPC(ctx, hipEventRecord(ctx->ev_fork, s));
+      HIPC(ctx, hipStreamWaitEvent(sk, ctx->ev_fork, 0));
+    }
+    int64_t ksl = ((clen + w->ns_uf - 1) / w->ns_uf + 127) / 128 * 128;
+    launch_kgrad(dt, sk, kp, m->zs, Mp, data->x, data->ldx, off + c0, 0, clen, clen, w->Pt, w->At, w->gmu, ksl, w->ns_uf,
+                 w->rp_uf, w->sp_uf);
+    KCHECK(ctx, "kgrad uf");
+    if (kg_overlap) HIPC(ctx, hipEventRecord(ctx->ev_join, sk));
     launch_sum5(s, w->partial5, int(nstrips), w->sums);
     int64_t sl = ((ncp + w->nslices - 1) / w->nslices + 127) / 128 * 128;
     launch_gemm_pm(dt, s, w->At, w->At, w->gv, 2.0, Mp, ncp, sl, w->nslices, w->G1);   // W += A diag(2 g_v) A' (lower tiles)
     KCHECK(ctx, "syrk");
-    int64_t ksl = ((clen + w->ns_uf - 1) / w->ns_uf + 127) / 128 * 128;
-    launch_kgrad(dt, s, kp, m->zs, Mp, data->x, data->ldx, off + c0, 0, clen, clen, w->Pt, w->At, w->gmu, ksl, w->ns_uf,
-                 w->rp_uf, w->sp_uf);
-    KCHECK(ctx, "kgrad uf");
+    if (kg_overlap) HIPC(ctx, hipStreamWaitEvent(s, ctx->ev_join, 0));
   }
   HIPC(ctx, hipEventRecord(ctx->ev[2], s));
   // M-sized tail.  With W = A diag(2 g_v) A' and a = A g_mu:
