@@ -1109,7 +1109,10 @@ int grad_enqueue(svgp_ctx* ctx, svgp_model* m, const svgp_data* data, int64_t of
   launch_solve_t(dt, s, w->S, w->tmp, nullptr, Mp, Mp, Mp, ctx->num_cus);
   launch_symmetrize(dt, s, w->tmp, Mp, w->H);
   KCHECK(ctx, "chol backward");
-  launch_kgrad(dt, s, kp, m->zs, Mp, m->zs, Mp, 0, 1, M, M, w->H, nullptr, nullptr, 128, w->ns_uu, w->rp_uu, w->sp_uu);
+  // the Kuu part: the ns_uu slices must cover all M columns (a fixed slice of 128 covered only 1024 of them: the kernel-
+  // parameter and z gradients were wrong for M > 1024 until tests/test_gpu_grad.py::test_gradient_large_m_float32_strips)
+  const int64_t uu_sl = ((M + w->ns_uu - 1) / w->ns_uu + 127) / 128 * 128;
+  launch_kgrad(dt, s, kp, m->zs, Mp, m->zs, Mp, 0, 1, M, M, w->H, nullptr, nullptr, uu_sl, w->ns_uu, w->rp_uu, w->sp_uu);
   launch_finish_kgrad(dt, s, m->d, M, Mp, m->zs, w->invl_d, w->rp_uf, w->ns_uf, w->rp_uu, w->ns_uu, w->sp_uf, w->ns_uf * w->rb,
                       w->sp_uu, w->ns_uu * w->rb, m->mp, klw, m->desc.layout_z, m->desc.variance, w->zbar, centered ? nullptr : w->mbar,
                       w->scal_out);

@@ -870,7 +870,8 @@ void launch_strip_grad(int dtype, hipStream_t s, const StripArgs& a, int nt, int
     if (nt == 32) launch_strip_t<double, 32, 16, 256, 2, 16, true>(s, a, grid, nstrips);
     else launch_strip_t<double, 64, 16, 256, 2, 16, true>(s, a, grid, nstrips);
   } else {
-    if (nt == 64) launch_strip_t<float, 64, 16, 256, 2, 16, true>(s, a, grid, nstrips);
+    if (nt == 32) launch_strip_t<float, 32, 16, 256, 2, 16, true>(s, a, grid, nstrips);
+    else if (nt == 64) launch_strip_t<float, 64, 16, 256, 2, 16, true>(s, a, grid, nstrips);
     else launch_strip_t<float, 128, 16, 256, 2, 16, true>(s, a, grid, nstrips);
   }
 }

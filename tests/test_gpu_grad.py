@@ -235,3 +235,43 @@ def test_randomized_gradient_sweep(ctx):
             assert abs(g[k] - g_ref[k]) <= 1e-6 * max(abs(g_ref[k]), 1e-9) + 1e-9, (k,) + info
         model.free()
         data.free()
+
+
+@pytest.mark.parametrize("N", [3000, 40_000])
+def test_gradient_large_m_float32_strips(ctx, N):
+    """Mp > 2048 in fp32 selects the 64-point strips (C4's regime): N = 3000 runs entirely as 32-point half-width strips
+    (forward AND value-and-gradient kernels: the fp32 32-point instantiation), N = 40 000 as 64-point strips with a short
+    last chunk; value and gradient against the oracle at the full M."""
+    M, d = 2100, 4
+    # jitter 0.05 keeps cond(Kuu) small enough for fp32 kernel-parameter gradients (the Cholesky backward squares it)
+    x, y, sva, s2 = o.synth_problem(88, N, M, d, dtype=np.float32, jitter=0.05)
+    model = device_model(ctx, sva, dtype=np.float32, sigma2=s2)
+    data = _ffi.DeviceData(ctx, x, y, np.float32)
+    val_ref, g_ref = o.elbo_grad(sva, x, y, sigma2=s2, num_data=2.0 * N)
+    val, _, g = model.elbo_grad(data, 0, N, 2.0 * N)
+    assert rel(val, val_ref) < 1e-4
+    assert rel(model.elbo(data, 0, N, 2.0 * N)[0], val_ref) < 1e-4
+    for k in ("m", "Lq", "inv_lengthscale"):
+        _close(g[k], g_ref[k], 3e-3)
+    _close(g["z"].reshape(g_ref["z"].shape, order="F"), g_ref["z"], 3e-3)
+    _close([g["variance"]], [g_ref["variance"]], 3e-3)
+    model.free()
+    data.free()
+
+
+def test_gradient_more_than_1024_inducing_points_f64(ctx):
+    """M > 1024 in fp64: every block of the Kuu part of the kernel-parameter / inducing-input gradients (the slices of the
+    uu reduction have to cover all M columns)."""
+    N, M, d = 2500, 1300, 3
+    x, y, sva, s2 = o.synth_problem(89, N, M, d, family=o.KERNEL_MATERN52)
+    model = device_model(ctx, sva, sigma2=s2)
+    data = _ffi.DeviceData(ctx, x, y, np.float64)
+    val_ref, g_ref = o.elbo_grad(sva, x, y, sigma2=s2, num_data=3.0 * N)
+    val, _, g = model.elbo_grad(data, 0, N, 3.0 * N)
+    assert rel(val, val_ref) < 1e-8
+    for k in ("m", "Lq", "inv_lengthscale"):
+        _close(g[k], g_ref[k], 1e-6)
+    _close(g["z"].reshape(g_ref["z"].shape, order="F"), g_ref["z"], 1e-6)
+    _close([g["variance"]], [g_ref["variance"]], 1e-6)
+    model.free()
+    data.free()
