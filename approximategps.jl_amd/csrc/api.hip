@@ -965,6 +965,7 @@ namespace {
 // grouped ncclAllReduce of {z_bar, m_bar, Lq_bar, [sums | scal_out]} at the end.
 struct GradCall {
   GradWs* w = nullptr;
+  const double* n_global_dev = nullptr;
   double scale = 1.0, klw = 1.0, num_data = 0.0;
   bool collective = false, centered = false;
   int64_t len = 0;
@@ -974,20 +975,16 @@ int grad_enqueue(svgp_ctx* ctx, svgp_model* m, const svgp_data* data, int64_t of
   const bool centered = gc.centered = (m->desc.parametrization == SVGP_CENTERED);
   HIPC(ctx, hipSetDevice(ctx->device));
   hipStream_t s = ctx->stream;
-  GradWs* w = nullptr;
-  int rc = grad_workspace(ctx, m, len, &w);
-  if (rc) return rc;
-  gc.w = w;
+  GradWs* w = gc.w;
+  if (!w) {
+    int rcw = grad_workspace(ctx, m, len, &w);
+    if (rcw) return rcw;
+    gc.w = w;
+  }
+  int rc = SVGP_OK;
   gc.len = len;
   const double scale = gc.scale, klw = gc.klw;
-  const double* n_global_dev = nullptr;
-  if (gc.collective) {
-    // the global batch size, summed on the device; the forward strips run while it travels
-    launch_set_f64(s, ctx->d_coll, double(len));
-    rc = comm_allreduce(ctx, ctx->d_coll, 1, SVGP_F64);
-    if (rc) return rc;
-    n_global_dev = ctx->d_coll;
-  }
+  const double* n_global_dev = gc.n_global_dev;   // data-parallel: the all-reduced batch size, on the device (grad_handshake)
   const int dt = m->dtype;
   const int64_t Mp = m->Mp, M = m->M, nc = w->nc;
   const size_t es = m->es, mm = size_t(Mp) * Mp * es;
@@ -1122,6 +1119,38 @@ int grad_enqueue(svgp_ctx* ctx, svgp_model* m, const svgp_data* data, int64_t of
   return SVGP_OK;
 }
 
+// Opening handshake of a collective value-and-gradient call: ONE all-reduce of {batch length, "I cannot take part"}.
+// It gives every rank the global batch size on the device (the backward pass reads num_data / n_global there) and tells
+// every rank, before anything else is enqueued, whether a peer failed its argument checks or its workspace allocation -
+// failures after which that peer could not join the closing all-reduce of the gradient blocks.  Costs one host
+// synchronisation per call (collective mode only).
+int grad_handshake(svgp_ctx* ctx, GradCall& gc, int64_t len, int pre_rc) {
+  const std::string keep = ctx->err;
+  double h[2] = {pre_rc == SVGP_OK ? double(len) : 0.0, pre_rc == SVGP_OK ? 0.0 : 1.0};
+  int rc = SVGP_OK;
+  if (hipSetDevice(ctx->device) != hipSuccess ||
+      hipMemcpyAsync(ctx->d_coll, h, sizeof h, hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
+      hipStreamSynchronize(ctx->stream) != hipSuccess)
+    rc = SVGP_HIP_ERROR;
+  if (rc == SVGP_OK) rc = comm_allreduce(ctx, ctx->d_coll, 2, SVGP_F64);
+  if (rc == SVGP_OK && (hipMemcpyAsync(h, ctx->d_coll, sizeof h, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+                        hipStreamSynchronize(ctx->stream) != hipSuccess))
+    rc = SVGP_HIP_ERROR;
+  if (rc != SVGP_OK) {   // the handshake itself broke: nothing sane can follow on this communicator
+    comm_abort(ctx);
+    if (pre_rc != SVGP_OK) ctx->err = keep;
+    return pre_rc != SVGP_OK ? pre_rc : fail(ctx, SVGP_RCCL_ERROR, "the opening all-reduce of svgp_elbo_grad failed");
+  }
+  if (pre_rc != SVGP_OK) {
+    ctx->err = keep;
+    return pre_rc;
+  }
+  if (h[1] > 0.0)
+    return fail(ctx, SVGP_RCCL_ERROR, "a peer rank could not take part in svgp_elbo_grad (argument or allocation failure); abandoned on every rank");
+  gc.n_global_dev = ctx->d_coll;
+  return SVGP_OK;
+}
+
 // the gradient's ONE (grouped) all-reduce; a rank whose enqueue failed still takes part with its failure flag set
 int grad_collective(svgp_ctx* ctx, svgp_model* m, GradCall& gc, int local_rc) {
   if (!ctx->comm || !gc.collective) return local_rc;
@@ -1220,10 +1249,10 @@ int elbo_grad_impl(svgp_ctx* ctx, svgp_model* m, const svgp_data* data, int64_t 
   int rc = check_batch(ctx, m, data, off, len, true);
   if (rc == SVGP_OK && !g) rc = fail(ctx, SVGP_INVALID_ARG, "null gradient output");
   if (rc == SVGP_OK && (!(scale > 0.0) || !(klw >= 0.0))) rc = fail(ctx, SVGP_INVALID_ARG, "scale must be positive and kl_weight non-negative");
-  if (rc != SVGP_OK) {
-    if (ctx && gc.collective) comm_abort(ctx);   // argument errors: the peers' collectives cannot be matched
-    return rc;
-  }
+  if (rc == SVGP_OK && hipSetDevice(ctx->device) != hipSuccess) rc = fail(ctx, SVGP_HIP_ERROR, "hipSetDevice failed");
+  if (rc == SVGP_OK) rc = grad_workspace(ctx, m, len, &gc.w);
+  if (ctx && gc.collective) rc = grad_handshake(ctx, gc, len, rc);
+  if (rc != SVGP_OK) return rc;
   rc = grad_enqueue(ctx, m, data, off, len, gc);
   rc = grad_collective(ctx, m, gc, rc);
   if (rc) return rc;
@@ -1235,12 +1264,9 @@ int elbo_grad_impl(svgp_ctx* ctx, svgp_model* m, const svgp_data* data, int64_t 
 // every rank (one 8-byte all-reduce of the batch size up front, one grouped all-reduce of the gradient at the end).
 extern "C" int32_t svgp_elbo_grad(svgp_ctx* ctx, svgp_model* m, const svgp_data* data, int64_t off, int64_t len,
                                   double num_data, double* elbo_out, svgp_terms* terms_out, svgp_grads* g) {
-  if (len < 1) {
-    if (ctx && ctx->comm) comm_abort(ctx);
-    return ctx ? fail(ctx, SVGP_INVALID_ARG, "batch range outside the data") : SVGP_INVALID_ARG;
-  }
-  return elbo_grad_impl(ctx, m, data, off, len, (num_data > 0 ? num_data : double(len)) / double(len), 1.0, num_data, true,
-                        elbo_out, terms_out, g);
+  if (!ctx) return SVGP_INVALID_ARG;
+  const double scale = len >= 1 ? (num_data > 0 ? num_data : double(len)) / double(len) : 1.0;   // len < 1 fails check_batch
+  return elbo_grad_impl(ctx, m, data, off, len, scale, 1.0, num_data, true, elbo_out, terms_out, g);
 }
 
 // always local (no collective): the building block for hosts that run their own all-reduce

@@ -103,6 +103,10 @@ def test_library_collective_world_of_one(centered):
     with pytest.raises(ValueError):
         model.elbo(data, 2900, 500, 0.0)
     assert model.elbo(data, 100, 1500, 9000.0)[0] == val      # and the communicator is still usable
+    with pytest.raises(ValueError):                           # the gradient call: argument errors go through its opening handshake
+        model.elbo_grad(data, 2900, 500, 0.0)
+    g2 = model.elbo_grad(data, 100, 1500, 9000.0)
+    assert abs(g2[0] - lv) <= 1e-12 * abs(lv)
     # status travels in the reduced vector: a non-PD Kuu is reported collectively
     bad = device_model(ctx, o.SVA(sva.kernel, sva.z, sva.m, sva.Lq, jitter=-1.0, centered=sva.centered, mean_const=sva.mean_const))
     with pytest.raises(_ffi.PosDefException):
