@@ -447,14 +447,24 @@ struct TileGemm {
   // fp32 (128-point strips): the P tile's k-rows are 512 B too and use the same row-pair + XOR-16 image (the fragment of
   // row tile 2i + wr of an odd k-row is read from tile 2i + (wr ^ 1)).
   static constexpr bool kPairP = (NB * sizeof(T) == 512);   // P k-rows of 512 B: row-pair image; 1 KiB rows: padded rows (PLD)
-  static constexpr bool kAsync = (SVGP_DMA_P != 0) && (NB * sizeof(T) == 1024 || kPairP) && (NT * sizeof(T) == 512) &&
-                                 BK == 16 && NTHR == 256;
+  // Q k-rows of 512 B travel in pairs, of 256 B (fp32, NT = 64: the strips of models with Mp > 2048) four to an instruction:
+  // a KiB of LDS then holds QR rows whose banks coincide, so row r of the unit is stored with its 16-column blocks XOR r
+  // (swizzle on the per-lane SOURCE address); the four k-rows of a fragment read then hit 64 distinct banks, and the
+  // fragment of column tile jt of unit-row r is read from block jt ^ r.
+#ifndef SVGP_ASYNC_QUAD
+#define SVGP_ASYNC_QUAD 1   // 0: the 256-byte-row tiles (fp32 NT = 64) keep the two-buffer loop (A/B builds)
+#endif
+  static constexpr int QR = (NT * sizeof(T) == 256) ? 4 : 2;
+  static constexpr bool kAsync = (SVGP_DMA_P != 0) && (NB * sizeof(T) == 1024 || kPairP) &&
+                                 (NT * sizeof(T) == 512 || (SVGP_ASYNC_QUAD && NT * sizeof(T) == 256)) && BK == 16 &&
+                                 NTHR == 256 && NJ % 2 == 0;
   static constexpr int NBUF = 3;
-  static constexpr int QPP = 2 * NT;                        // one row pair of the Q tile in LDS (elements)
-  static constexpr int QA_TILE = (BK / 2) * QPP;
+  static constexpr int QPP = QR * NT;                       // one row unit (pair / quad) of the Q tile in LDS (elements) = 1 KiB
+  static constexpr int QA_TILE = (BK / QR) * QPP;
+  static constexpr int QSLAB = (4 / QR) * QPP;              // LDS distance between the k-slabs (4 k-rows) of a Q tile
   static constexpr int PPP = 2 * NB;                        // one row pair of the P tile (pair image)
   static constexpr int PA_TILE = kPairP ? (BK / 2) * PPP : P_TILE;
-  static constexpr int DQ = (BK / 2) / NW;                  // row pairs per wave and tile
+  static constexpr int DQ = (BK / QR) / NW;                 // Q instructions per wave and tile
   static constexpr int DP = kPairP ? (BK / 2) / NW : BK / NW;   // P instructions per wave and tile
   static constexpr int DMA_PER_TILE = DP + DQ;              // DMA instructions per wave and tile
   static constexpr size_t ASYNC_LDS_BYTES = size_t(NBUF) * (PA_TILE + QA_TILE) * sizeof(T);
@@ -472,9 +482,11 @@ struct TileGemm {
       if constexpr (kPairP) r.p[q] = uint32_t((int64_t((wave + q * NW) * 2 + row) * ldp + (slot ^ (row * 16))) * sizeof(T));
       else r.p[q] = uint32_t((int64_t(wave + q * NW) * ldp + lane * VEC) * sizeof(T));
     }
+    constexpr int LPR = 64 / QR;                           // lanes per k-row of a Q row unit
+    const int qrow = lane / LPR, qslot = (lane % LPR) * VEC;
 #pragma unroll
     for (int q = 0; q < DQ; ++q)
-      r.q[q] = uint32_t((int64_t((wave + q * NW) * 2 + row) * ldq + (slot ^ (row * 16))) * sizeof(T));
+      r.q[q] = uint32_t((int64_t((wave + q * NW) * QR + qrow) * ldq + (qslot ^ (qrow * 16))) * sizeof(T));
     return r;
   }
   static __device__ __forceinline__ void dma_tile(const T* __restrict__ psrc, const T* __restrict__ qsrc, const AOff& off,
@@ -502,9 +514,11 @@ struct TileGemm {
     AFrag r;
     if constexpr (kPairP) r.a = smem + (g >> 1) * PPP + odd * NB + ((wave / WC) ^ odd) * 16 + l15;
     else r.a = smem + g * PLD + (wave / WC) * 16 + l15;
-    const T* qb = smem + NBUF * PA_TILE + (g >> 1) * QPP + odd * NT + (wave % WC) * (NJ * 16) + l15;
-    r.b0 = qb + (0 ^ odd) * 16;
-    r.b1 = qb + (1 ^ odd) * 16;
+    // k-row g of a slab is row qr of unit qu; its column tile jt sits in block jt ^ qr
+    const int qu = g / QR, qr = g % QR, jt0 = (wave % WC) * NJ;
+    const T* qb = smem + NBUF * PA_TILE + qu * QPP + qr * NT + l15;
+    r.b0 = qb + ((jt0 + 0) ^ qr) * 16;
+    r.b1 = qb + ((jt0 + 1) ^ qr) * 16;
     return r;
   }
   template <int KSLAB, int ILO = 0, int IHI = MI - 1>
@@ -516,10 +530,11 @@ struct TileGemm {
       if (i >= ILO && i <= IHI) f.a[i] = fa[ASLAB + i * 32];
     if (ILO <= IHI) {
       static_assert(NJ % 2 == 0, "column tiles come in even / odd pairs");
+      static_assert(QR == 2 || NJ == 2, "the quad image is written for two column tiles per wave");
 #pragma unroll
-      for (int j = 0; j < NJ; j += 2) {
-        f.b[j] = fb0[KSLAB * 2 * QPP + j * 16];
-        f.b[j + 1] = fb1[KSLAB * 2 * QPP + j * 16];
+      for (int j = 0; j < NJ; j += 2) {   // (jt0 + j) ^ qr = ((jt0 ^ qr) + j) for even j: the XOR only touches the bits below
+        f.b[j] = fb0[KSLAB * QSLAB + j * 16];
+        f.b[j + 1] = fb1[KSLAB * QSLAB + j * 16];
       }
     }
   }
