@@ -109,6 +109,39 @@ extern "C" int svgp_debug_strip_stamps(unsigned long long* out) {
 // d E[log p] / d (mu, v) of one point for the value-and-gradient strips.  Not inlined: lgamma / exp / log1p and the
 // Gauss-Hermite loop must not take part in the register allocation of the MFMA loops around the call (146 spilled VGPRs
 // when they did).
+// Value-and-gradient strips: a 128 x NT accumulator tile -> point-major rows out[(c0 + col) * Mp + row0 + 0..127] through
+// LDS, so that the 128 values of a point leave as one contiguous KiB (f64) / half KiB (f32) per wave instruction instead
+// of the 32- / 16-byte pieces a direct store from the MFMA layout gives (L2 merges those, but the fp32 pieces in
+// particular cost: the round-1 fp32 path preferred two extra transposition passes over them).  The staging buffers are
+// idle in an epilogue; tiles wider than 64 columns go in two passes.  Ends with a barrier (LDS free again).
+template <typename G, typename T, int NT, int NTHR>
+__device__ __forceinline__ void store_tile_point_major(const typename G::Acc& acc, T* __restrict__ smem, T* __restrict__ out,
+                                                       int64_t c0, int64_t Mp, int row0) {
+  constexpr int HC = NT < 64 ? NT : 64, RS = G::NB + (sizeof(T) == 8 ? 4 : 8), VEC = G::VEC, CPR = G::NB / VEC;
+  using V = typename G::V;
+  static_assert(size_t(HC) * RS * sizeof(T) <= ((SVGP_ASYNC && G::kAsync) ? G::ASYNC_LDS_BYTES : G::LDS_BYTES),
+                "the transposition tile must fit the staging buffers");
+#pragma unroll
+  for (int p = 0; p < NT / HC; ++p) {
+#pragma unroll
+    for (int j = 0; j < G::NJ; ++j) {
+      const int col = G::acc_col(j);
+      if (col / HC == p) {
+#pragma unroll
+        for (int i = 0; i < G::MI; ++i)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) smem[(col % HC) * RS + G::acc_row(i, r)] = acc.v[i][j][r];
+      }
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < HC * CPR; e += NTHR) {
+      const int col = e / CPR, rv = (e % CPR) * VEC;
+      *reinterpret_cast<V*>(out + (c0 + p * HC + col) * Mp + row0 + rv) = *reinterpret_cast<const V*>(smem + col * RS + rv);
+    }
+    __syncthreads();
+  }
+}
+
 struct PointGrads { double e, gmu, gv, gs2; };
 __device__ __noinline__ PointGrads strip_point_grads(LikParams lp, double mu, double v, double yv, double scale) {
   // everything by value: taking the address of the kernel argument block would move it (and with it the wave-uniform
@@ -270,7 +303,9 @@ __global__ void __launch_bounds__(NTHR, MINW) strip_kernel(StripArgs a, int64_t 
             work[int64_t(row) * NT + col] = val;
 #endif
             if (a.A_out) static_cast<T*>(a.A_out)[int64_t(row) * a.lda + c0 + col] = val;
-            if (a.At_out) static_cast<T*>(a.At_out)[(c0 + col) * Mp + row] = val;
+            if constexpr (!GRAD) {
+              if (a.At_out) static_cast<T*>(a.At_out)[(c0 + col) * Mp + row] = val;
+            }
 #if !(defined(SVGP_ABLATE) && (SVGP_ABLATE & 16))
             const double dv = double(val);
             sA[j] = fma(dv, dv, sA[j]);
@@ -281,6 +316,7 @@ __global__ void __launch_bounds__(NTHR, MINW) strip_kernel(StripArgs a, int64_t 
           }
         }
       }
+      if constexpr (GRAD) store_tile_point_major<G, T, NT, NTHR>(acc, smem, static_cast<T*>(a.At_out), c0, Mp, I * NB);
       __syncthreads();  // scratch rows of panel I visible to the whole workgroup
       SVGP_SSTAMP(4 + 3 * I);
     }
@@ -410,11 +446,9 @@ __global__ void __launch_bounds__(NTHR, MINW) strip_kernel(StripArgs a, int64_t 
 #pragma unroll
           for (int i = 0; i < MI; ++i)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              const int row = I * NB + G::acc_row(i, r);
-              Pt[(c0 + col) * Mp + row] = fma(g2, acc.v[i][j][r], alpha[row] * g1);
-            }
+            for (int r = 0; r < 4; ++r) acc.v[i][j][r] = fma(g2, acc.v[i][j][r], alpha[I * NB + G::acc_row(i, r)] * g1);
         }
+        store_tile_point_major<G, T, NT, NTHR>(acc, smem, Pt, c0, Mp, I * NB);
       }
       __syncthreads();
     }
