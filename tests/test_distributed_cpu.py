@@ -142,3 +142,25 @@ def test_failing_rank_does_not_hang_the_others(tmp_path):
     mp.spawn(_failing_worker, args=(2, port, out), nprocs=2, join=True)
     assert open(out + ".0").read().startswith("peer:a rank failed")
     assert open(out + ".1").read().startswith("own:negative variance")
+
+
+def test_synthetic_shards_share_the_model():
+    """bench.py --gpus N: every rank draws its own data shard from the SURVEY 8d recipe, but the model (z, m, Lq, kernel)
+    must be rank 0's on every rank (approxgp/synthetic.py), and shard 0 is exactly what the parity tests use."""
+    from approxgp.synthetic import synth_arrays
+
+    a0 = synth_arrays(6, 500, 40, 8)
+    a3 = synth_arrays(6, 500, 40, 8, shard=3)
+    for k in ("z", "m", "Lq", "inv_lengthscale"):
+        np.testing.assert_array_equal(a0[k], a3[k])
+    assert a0["variance"] == a3["variance"] and a0["jitter"] == a3["jitter"]
+    assert not np.array_equal(a0["x"], a3["x"]) and not np.array_equal(a0["y"], a3["y"])
+    np.testing.assert_allclose(a0["z"], a0["x"][:, :40], atol=1e-2)      # z = the first M points of x + 1e-3 noise
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    import svgp_oracle as o
+
+    x, y, sva, s2 = o.synth_problem(6, 500, 40, 8)
+    np.testing.assert_array_equal(x, a0["x"])
+    np.testing.assert_array_equal(sva.z, a0["z"])
+    f32 = synth_arrays(6, 100, 10, 4, dtype=np.float32)
+    assert f32["jitter"] == 1e-3 and np.array_equal(f32["x"], f32["x"].astype(np.float32).astype(np.float64))

@@ -3,6 +3,7 @@
 #   third argument "grad": profile value-and-gradient evaluations (tools/grad_time.py) instead of the forward bench loop
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 O=gpurun_out/prof_$1; C=${2:-H}; mkdir -p $O
+cat approximategps.jl_amd/csrc/strip.hip approximategps.jl_amd/csrc/device_common.hpp | sha256sum | cut -c1-16 > $O/kernel_source_sha16.txt   # what was profiled
 if [ "${3:-}" = "grad" ]; then
   B="tools/grad_time.py $C"; S=""; P=""
 else

@@ -58,8 +58,10 @@ def main():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     for f in ("strip.hip", "device_common.hpp"):
         h.update(open(os.path.join(root, "approximategps.jl_amd", "csrc", f), "rb").read())
+    sha_file = os.path.join(src, "kernel_source_sha16.txt")   # written on the GPU box by run_profile.sh; else the local tree's
+    sha = open(sha_file).read().strip() if os.path.exists(sha_file) else h.hexdigest()[:16]
     out = {"source": "tools/run_profile.sh: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ_* in three separate passes",
-           "kernel_source_sha16": h.hexdigest()[:16],   # bench.py marks the traffic figure stale when strip.hip / device_common.hpp changed since
+           "kernel_source_sha16": sha,   # bench.py marks the traffic figure stale when strip.hip / device_common.hpp changed since
            "bench_line": json.loads(open(os.path.join(src, "bench_plain.json")).read().strip().splitlines()[-1])}
     fetch, write, sq = (counters(os.path.join(src, p)) for p in ("fetch", "write", "sq"))
     for k in sorted(tot, key=tot.get, reverse=True)[:8]:
