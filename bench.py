@@ -129,19 +129,28 @@ def profile_traffic(config, kernel_prefix):
     for f in ("strip.hip", "device_common.hpp"):
         h.update(open(os.path.join(ROOT, "approximategps.jl_amd", "csrc", f), "rb").read())
     cur = h.hexdigest()[:16]
-    cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "round*", f"{config}_*_pmc.json")), key=os.path.getmtime)
-    for path in reversed(cands):
+    # forward profiles of this config (not the value-and-gradient ones), newest round first; a summary taken with exactly the
+    # current kernel sources wins
+    cands = [c for c in sorted(glob.glob(os.path.join(ROOT, "profiles", "round*", f"{config}_*_pmc.json")), reverse=True)
+             if "grad" not in os.path.basename(c)]
+    best = None
+    for path in cands:
         try:
             pm = json.load(open(path))
         except (OSError, ValueError):
             continue
-        e = next((v for k, v in pm.items() if k.startswith(kernel_prefix) and isinstance(v, dict)), None)
-        if e is None or e.get("traffic_bytes_per_launch") is None:
+        hits = [v for k, v in pm.items() if k.startswith(kernel_prefix) and isinstance(v, dict) and v.get("traffic_bytes_per_launch")]
+        if not hits:
             continue
+        e = max(hits, key=lambda v: v["traffic_bytes_per_launch"])   # the main launch, not a concurrent half-width tail
         src_hash = pm.get("kernel_source_sha16")
-        return {"traffic": e["traffic_bytes_per_launch"], "traffic_source": os.path.relpath(path, ROOT) + " (rocprofv3 --pmc, not measured in this run)",
-                "traffic_stale": (src_hash != cur) if src_hash else None, "hbm_share_note": pm.get("hbm_share_note")}
-    return None
+        rec = {"traffic": e["traffic_bytes_per_launch"],
+               "traffic_source": os.path.relpath(path, ROOT) + " (rocprofv3 --pmc, not measured in this run)",
+               "traffic_stale": (src_hash != cur) if src_hash else None, "hbm_share_note": pm.get("hbm_share_note")}
+        if src_hash == cur:
+            return rec
+        best = best or rec
+    return best
 
 
 def bench_config(args, name, ctx, torch, dist, dev, world, rank, use_dist, steps, warmup, num_data_override=None):
