@@ -81,3 +81,41 @@ def test_c4_large_m_cholesky_dominated(ctx):
     assert model.elbo_partial(data)[0] == full[0]
     model.free()
     data.free()
+
+
+GRAD_FULL = [
+    # name, N, M, d, family, lik, dtype, value rtol, gradient tol (of each block's max-norm), sub-batch
+    ("H", 200_000, 1024, 8, o.KERNEL_SE, o.LIK_GAUSSIAN, np.float64, 1e-8, 1e-6, 2500),
+    ("C3", 200_000, 2048, 16, o.KERNEL_MATERN52, o.LIK_BERNOULLI_LOGISTIC, np.float32, 1e-4, 3e-3, 1500),
+    ("C5", 262_144, 1024, 8, o.KERNEL_SE, o.LIK_GAUSSIAN, np.float32, 1e-4, 3e-3, 2500),
+]
+
+
+@pytest.mark.parametrize("name,N,M,d,family,lik,dtype,rtol,gtol,nb", GRAD_FULL)
+def test_full_size_value_and_gradient(ctx, name, N, M, d, family, lik, dtype, rtol, gtol, nb):
+    """The training path at the BASELINE models' full M (round 1 had no gradient test above M = 512, and the Kuu part of the
+    kernel-parameter gradients was wrong for M > 1024): (i) value and every gradient block against the oracle's analytic
+    gradient on a sub-batch window at the full M; (ii) over the whole data set, the shard form (scale, KL / 2 on each of two
+    uneven shards) sums to the one-call gradient - the identity the multi-GPU all-reduce relies on."""
+    x, y, sva, s2 = o.synth_problem(2, N, M, d, family=family, lik=lik, dtype=dtype)
+    model = device_model(ctx, sva, dtype=dtype, lik=lik, sigma2=s2)
+    data = _ffi.DeviceData(ctx, x, y, dtype)
+    off = N // 3
+    val_ref, g_ref = o.elbo_grad(sva, x[:, off:off + nb], y[off:off + nb], lik=lik, sigma2=s2, num_data=float(N))
+    val, _, g = model.elbo_grad(data, off, nb, float(N))
+    assert rel(val, val_ref) < rtol
+    for k in ("m", "Lq", "inv_lengthscale", "z"):
+        a = np.asarray(g[k], dtype=np.float64).reshape(np.shape(g_ref[k]), order="F")
+        assert np.abs(a - g_ref[k]).max() <= gtol * max(np.abs(g_ref[k]).max(), 1e-12), (name, k)
+    assert abs(g["variance"] - g_ref["variance"]) <= gtol * abs(g_ref["variance"])
+    # (ii) shard additivity at full size
+    full_v, _, full_g = model.elbo_grad(data, 0, N, float(N))
+    cut = N // 2 + 12345
+    parts = [model.elbo_grad(data, a, b - a, shard=(1.0, 0.5)) for a, b in ((0, cut), (cut, N))]
+    assert rel(parts[0][0] + parts[1][0], full_v) < (1e-11 if dtype == np.float64 else 1e-6)
+    for k in ("m", "Lq", "z", "inv_lengthscale"):
+        s = np.asarray(parts[0][2][k], dtype=np.float64) + np.asarray(parts[1][2][k], dtype=np.float64)
+        f = np.asarray(full_g[k], dtype=np.float64)
+        assert np.abs(s - f).max() <= (1e-9 if dtype == np.float64 else 2e-4) * max(np.abs(f).max(), 1e-12), (name, k)
+    model.free()
+    data.free()
