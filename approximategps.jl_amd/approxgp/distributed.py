@@ -31,8 +31,15 @@ def attach_comm_via_torch(ctx, group=None):
     from . import _ffi
 
     world, rank = dist.get_world_size(group), dist.get_rank(group)
-    box = [_ffi.comm_unique_id() if rank == 0 else None]
+    box = [None]
+    if rank == 0:
+        try:
+            box[0] = _ffi.comm_unique_id()
+        except Exception as e:  # noqa: BLE001 - every rank has to leave the broadcast, then all of them raise
+            box[0] = e
     dist.broadcast_object_list(box, src=0, group=group)
+    if not isinstance(box[0], (bytes, bytearray)):
+        raise RuntimeError(f"rank 0 could not create the communicator id: {box[0]!r}")
     ctx.attach_comm(box[0], world, rank)
     return world, rank
 

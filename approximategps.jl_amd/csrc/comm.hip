@@ -38,6 +38,10 @@ const Rccl& rccl() {
   static Rccl r;
   static std::once_flag once;
   std::call_once(once, [] {
+    if (const char* off = getenv("SVGP_DISABLE_RCCL"); off && off[0] == '1') {   // test knob: behave as if librccl were absent
+      r.err = "RCCL disabled by SVGP_DISABLE_RCCL";
+      return;
+    }
     const char* env = getenv("SVGP_RCCL_LIB");
     const char* names[] = {env, "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
     // a copy that is already part of the process first (RTLD_NOLOAD), then the loader's search path

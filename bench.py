@@ -153,7 +153,7 @@ def profile_traffic(config, kernel_prefix):
     return best
 
 
-def bench_config(args, name, ctx, torch, dist, dev, world, rank, use_dist, steps, warmup, num_data_override=None):
+def bench_config(args, name, ctx, torch, dist, dev, world, rank, use_dist, steps, warmup, num_data_override=None, host_comm=False):
     """Times `steps` full elbo evaluations of config `name` (after `warmup`), barrier + synchronize on both sides, MAX over
     ranks.  Returns (dict of measurements, model, data, p) with the model and data still resident."""
     from approxgp import _ffi
@@ -166,9 +166,17 @@ def bench_config(args, name, ctx, torch, dist, dev, world, rank, use_dist, steps
     data = _ffi.DeviceData(ctx, p["x"], p["y"], p["np_dt"])
     num_data = float(num_data_override if num_data_override else n * world)
 
+    if host_comm:
+        from approxgp.distributed import ShardedELBO
+        sharded = ShardedELBO(model, data, num_data, device=dev)
+
     def step():
         # prep + fused strips + reduce (HIP library); with a communicator on ctx this call is the library's collective:
         # ONE ncclAllReduce of the device-resident 8-vector, every rank gets the global ELBO
+        if host_comm:   # fallback only: partial sums through torch.distributed
+            class _T:
+                n_points = n * world
+            return sharded.step(0, n), _T
         return model.elbo(data, 0, n, num_data)
 
     def fence():
@@ -252,6 +260,7 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     use_dist = world > 1 or os.environ.get("BENCH_FORCE_DIST") == "1"   # the env knob exercises the RCCL path on one GPU
+    lib_comm_error = None
     stream = torch.cuda.current_stream().cuda_stream
     ctx = _ffi.Context(local_rank, stream if stream else None)
     if use_dist:
@@ -259,12 +268,25 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29531")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         from approxgp.distributed import attach_comm_via_torch
-        attach_comm_via_torch(ctx)                            # the library's own RCCL communicator (ncclCommInitRank)
-        assert ctx.comm_info() == (world, rank)
+        try:
+            attach_comm_via_torch(ctx)                        # the library's own RCCL communicator (ncclCommInitRank)
+            assert ctx.comm_info() == (world, rank)
+        except Exception as e:  # noqa: BLE001
+            # never lose the scaling measurement to a communicator problem: fall back to the host-side combination
+            # (svgp_elbo_partial + ONE torch.distributed all-reduce of 5 doubles) and say so in the output
+            lib_comm_error = repr(e)
+        # every rank must take the same path
+        flag = torch.tensor([0.0 if lib_comm_error is None else 1.0], device=dev)
+        dist.all_reduce(flag)
+        if float(flag.item()) > 0 and lib_comm_error is None:
+            ctx.detach_comm()
+            lib_comm_error = "a peer rank could not attach the library communicator"
 
     name = args.config
     n, M, d, family, lik, dtype, cid = CONFIGS[name]
-    res, model, data, p = bench_config(args, name, ctx, torch, dist, dev, world, rank, use_dist, args.steps, args.warmup)
+    host_comm = use_dist and lib_comm_error is not None
+    res, model, data, p = bench_config(args, name, ctx, torch, dist, dev, world, rank, use_dist, args.steps, args.warmup,
+                                       host_comm=host_comm)
     num_data = res["num_data"]
     out = {
         "metric": "SVGP ELBO evals/sec at N=1e6, M=1024" if name in ("H", "H32") else f"SVGP ELBO evals/sec ({name})",
@@ -272,8 +294,11 @@ def main():
         "ms_per_step": res["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": dtype, "data": "synthetic",
         "config": {"workload": res["workload"], "global_points": n * world, "points_per_s": res["points_per_s"],
-                   "parallelism": f"data-parallel shards x{world}; one 8-double ncclAllReduce per eval inside the library "
-                                  "(svgp_elbo on a context with a communicator)" if use_dist else "single GPU",
+                   "parallelism": ("single GPU" if not use_dist else
+                                   f"data-parallel shards x{world}; one 8-double ncclAllReduce per eval inside the library "
+                                   "(svgp_elbo on a context with a communicator)" if not host_comm else
+                                   f"data-parallel shards x{world}; FALLBACK: host-side all-reduce of the partial sums "
+                                   f"(library communicator unavailable: {lib_comm_error})"),
                    "elbo": res["elbo"], "timed_region_s": res["elapsed"]},
         "roofline": res["roofline"], "breakdown_ms": res["breakdown_ms"],
     }
@@ -332,7 +357,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    if not args.no_grad:
+    if not args.no_grad and not host_comm:
         # value-and-gradient evaluation (svgp_elbo_grad: what a training step costs), same workload, same residency; on N > 1
         # GPUs the library's collective form (batch size all-reduced on the device, one grouped gradient all-reduce).
         # Reported beside the headline, never part of it; a failure here must not cost the main line.
@@ -361,12 +386,12 @@ def main():
         # collective path: every rank evaluates its own 2^18-point minibatch per step, scale = 1e8 / (world * 2^18).
         try:
             c5, m5, d5, _ = bench_config(args, "C5", ctx, torch, dist, dev, world, rank, use_dist, max(20, args.steps), 5,
-                                         num_data_override=C5_NUM_DATA)
+                                         num_data_override=C5_NUM_DATA, host_comm=host_comm)
             c5out = {"workload": c5["workload"] + f"; num_data = {C5_NUM_DATA:.0e}, global minibatch = {world} x 262144",
                      "minibatch_steps_per_s": c5["evals_per_s"] / world, "ms_per_step": c5["ms_per_step"],
                      "points_per_s": c5["points_per_s"], "dtype": "f32", "roofline": c5["roofline"],
                      "breakdown_ms": c5["breakdown_ms"], "elbo": c5["elbo"]}
-            if not args.no_grad:
+            if not args.no_grad and not host_comm:
                 m5.elbo_grad(d5, 0, 262144, C5_NUM_DATA)
                 fence()
                 t0 = time.perf_counter()
