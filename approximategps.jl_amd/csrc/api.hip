@@ -933,7 +933,7 @@ int grad_workspace(svgp_ctx* ctx, svgp_model* m, int64_t len, GradWs** out) {
       {&w->W2, mm}, {&w->Rcm, mm}, {&w->G1p, mm}, {&w->alpha, size_t(Mp) * es}, {(void**)&w->avec, size_t(Mp) * 8},
       {(void**)&w->rp_uf, w->rp_uf_b},
       {(void**)&w->sp_uf, w->sp_uf_b}, {(void**)&w->rp_uu, w->rp_uu_b}, {(void**)&w->sp_uu, w->sp_uu_b},
-      {(void**)&w->partial5, size_t(w->part5_strips) * 5 * 8}, {(void**)&w->sums, size_t(8 + 1 + dreg) * 8}, {(void**)&w->invl_d, size_t(m->d) * 8}};
+      {(void**)&w->partial5, size_t(w->part5_strips) * 5 * 8}, {(void**)&w->apart, size_t(w->part5_strips) * size_t(Mp) * 8}, {(void**)&w->sums, size_t(8 + 1 + dreg) * 8}, {(void**)&w->invl_d, size_t(m->d) * 8}};
   for (auto& r : req) {
     if (hipMalloc(r.p, r.b) != hipSuccess) {
       w->release();
@@ -1044,7 +1044,11 @@ int grad_enqueue(svgp_ctx* ctx, svgp_model* m, const svgp_data* data, int64_t of
     a.At_out = w->At; a.ldx = data->ldx; a.off = off + c0; a.len = clen; a.Mp = Mp; a.M = M; a.kp = kp;
     a.mean_const = m->desc.mean_const;
     a.R = w->Rcm; a.alpha = w->alpha; a.Pt_out = w->Pt; a.gmu_out = w->gmu; a.gv_out = w->gv; a.y = data->y;
-    a.part5 = w->partial5; a.lp = lp; a.scale = scale; a.n_global_dev = n_global_dev; a.num_data = gc.num_data;
+    // A g_mu (the data part of m_bar): fp32 - per strip inside the strip kernel, so that kgrad streams P only; f64 - by kgrad
+    // from A beside P as before (same-box three-way A/B, ms, value-and-gradient: H 97.8 -> 95.4 with the kgrad prefetch alone,
+    // 99.0 with the in-strip form; H32 53.6 -> 53.0 -> 52.35; C5 16.25 -> 16.2 -> 15.9; C3 208.3 -> 217.2 -> 209.6)
+    const bool a_in_strips = (dt == SVGP_F32);
+    a.part5 = w->partial5; a.apart = a_in_strips ? w->apart : nullptr; a.lp = lp; a.scale = scale; a.n_global_dev = n_global_dev; a.num_data = gc.num_data;
     HIPC(ctx, hipMemsetAsync(ctx->counter, 0, sizeof(unsigned), s));
     launch_strip_grad(dt, s, a, nt, grid, nstrips);
     KCHECK(ctx, "strip (value and gradient)");
@@ -1062,8 +1066,9 @@ int grad_enqueue(svgp_ctx* ctx, svgp_model* m, const svgp_data* data, int64_t of
       HIPC(ctx, hipStreamWaitEvent(sk, ctx->ev_fork, 0));
     }
     int64_t ksl = ((clen + w->ns_uf - 1) / w->ns_uf + 127) / 128 * 128;
-    launch_kgrad(dt, sk, kp, m->zs, Mp, data->x, data->ldx, off + c0, 0, clen, clen, w->Pt, w->At, w->gmu, ksl, w->ns_uf,
-                 w->rp_uf, w->sp_uf);
+    if (a_in_strips) launch_apart_reduce(sk, w->apart, int(nstrips), Mp, w->rp_uf + Mp);   // slot 1 of slice 0 of rp_uf
+    launch_kgrad(dt, sk, kp, m->zs, Mp, data->x, data->ldx, off + c0, 0, clen, clen, w->Pt, a_in_strips ? nullptr : w->At,
+                 a_in_strips ? nullptr : w->gmu, ksl, w->ns_uf, w->rp_uf, w->sp_uf);
     KCHECK(ctx, "kgrad uf");
     if (kg_overlap) HIPC(ctx, hipEventRecord(ctx->ev_join, sk));
     launch_sum5(s, w->partial5, int(nstrips), w->sums);

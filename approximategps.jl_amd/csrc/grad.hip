@@ -81,6 +81,21 @@ __global__ void __launch_bounds__(320) sum5_kernel(const double* __restrict__ pa
   if (lane == 0) out[q] += s;
 }
 
+// out[i] += sum over strips of apart[strip][i]: thread (row, group g of 4) sums strips g, g + 4, ... in order, the four groups
+// are combined in a fixed order
+__global__ void __launch_bounds__(k256) apart_reduce_kernel(const double* __restrict__ apart, int nstrips, int64_t Mp,
+                                                            double* __restrict__ out) {
+  __shared__ double sh[4][64];
+  const int rl = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const int64_t i = int64_t(blockIdx.x) * 64 + rl;
+  double s = 0.0;
+  if (i < Mp)
+    for (int st = g; st < nstrips; st += 4) s += apart[int64_t(st) * Mp + i];
+  sh[g][rl] = s;
+  __syncthreads();
+  if (g == 0 && i < Mp) out[i] += ((sh[0][rl] + sh[1][rl]) + sh[2][rl]) + sh[3][rl];
+}
+
 // ---- M x M helpers of the fused gradient path (svgp_elbo_grad, api.hip: grad_enqueue) ---------------------------------
 // out (row-major, FULL symmetric) = sum over slices of the lower tiles in G (row-major), minus `eye` on the diagonal
 template <typename T>
@@ -312,34 +327,54 @@ __global__ void __launch_bounds__(k256) kgrad_kernel(KernelParams kp, const T* _
       xt[e] = v;
     }
     __syncthreads();
-    for (int c = wave; c < JB && jb + c < j1; c += 4) {
-      const int64_t j = jb + c;
-      T r2[KV], u[DREG][KV];
+    // U points of this wave in flight at a time: the kernel streams P (and A) once from HBM with ONE 1 KiB load per point
+    // and wave, and with a single load outstanding per wave it ran at the memory latency (350 us per 65 536-point chunk in
+    // f64 AND in fp32: 5-6 ms of a value-and-gradient evaluation)
+    constexpr int U = 4;
+    for (int c0w = wave; c0w < JB && jb + c0w < j1; c0w += 4 * U) {
+      T pv[U][KV], av[U][KV], gmv[U];
 #pragma unroll
-      for (int e = 0; e < KV; ++e) r2[e] = T(0);
-#pragma unroll
-      for (int f = 0; f < DREG; ++f) {
-        const T xv = xt[c * DREG + f];
+      for (int u = 0; u < U; ++u) {
+        const int c = c0w + 4 * u;
+        const bool ok = c < JB && jb + c < j1;
+        const int64_t j = ok ? jb + c : jb + c0w;
 #pragma unroll
         for (int e = 0; e < KV; ++e) {
-          u[f][e] = z[f][e] - xv;
-          r2[e] = fma(u[f][e], u[f][e], r2[e]);
+          pv[u][e] = Pt[j * Mp + i + e];
+          av[u][e] = At ? At[j * Mp + i + e] : T(0);
         }
+        gmv[u] = (At && gmu) ? gmu[j] : T(0);
       }
-      const T gm = (At && gmu) ? gmu[j] : T(0);
 #pragma unroll
-      for (int e = 0; e < KV; ++e) {
-        T k, dk;
-        kappa_and_d<T, FAMILY>(r2[e], variance, k, dk);
-        const T p = Pt[j * Mp + i + e];
-        const double W = double(p) * double(dk);
-        S1 += double(p) * double(k);
-        R[e] += W;
-        if (At) MB[e] += double(At[j * Mp + i + e]) * double(gm);
+      for (int u = 0; u < U; ++u) {
+        const int c = c0w + 4 * u;
+        if (!(c < JB && jb + c < j1)) break;   // wave-uniform
+        T r2[KV], uu[DREG][KV];
+#pragma unroll
+        for (int e = 0; e < KV; ++e) r2[e] = T(0);
 #pragma unroll
         for (int f = 0; f < DREG; ++f) {
-          Q[f][e] += W * double(xt[c * DREG + f]);
-          IL[f] += W * double(u[f][e]) * double(u[f][e]);
+          const T xv = xt[c * DREG + f];
+#pragma unroll
+          for (int e = 0; e < KV; ++e) {
+            uu[f][e] = z[f][e] - xv;
+            r2[e] = fma(uu[f][e], uu[f][e], r2[e]);
+          }
+        }
+#pragma unroll
+        for (int e = 0; e < KV; ++e) {
+          T k, dk;
+          kappa_and_d<T, FAMILY>(r2[e], variance, k, dk);
+          const T p = pv[u][e];
+          const double W = double(p) * double(dk);
+          S1 += double(p) * double(k);
+          R[e] += W;
+          if (At) MB[e] += double(av[u][e]) * double(gmv[u]);
+#pragma unroll
+          for (int f = 0; f < DREG; ++f) {
+            Q[f][e] += W * double(xt[c * DREG + f]);
+            IL[f] += W * double(uu[f][e]) * double(uu[f][e]);
+          }
         }
       }
     }
@@ -573,6 +608,10 @@ void launch_grad_moments(int dtype, hipStream_t s, const LikParams& lp, double s
 
 void launch_sum5(hipStream_t s, const double* partial, int nblocks, double* sums) {
   hipLaunchKernelGGL(sum5_kernel, dim3(1), dim3(320), 0, s, partial, nblocks, sums);
+}
+
+void launch_apart_reduce(hipStream_t s, const double* apart, int nstrips, int64_t Mp, double* out) {
+  hipLaunchKernelGGL(apart_reduce_kernel, dim3((unsigned)((Mp + 63) / 64)), dim3(k256), 0, s, apart, nstrips, Mp, out);
 }
 
 void launch_sym_from_lower(int dtype, hipStream_t s, const void* G, int nslices, int64_t Mp, double eye, void* out) {

@@ -86,6 +86,7 @@ struct StripArgs {
   void* gv_out;         // [n] g_v
   const void* y;        // observations of the batch (index off + i)
   double* part5;        // [nstrips][5] per-strip {E, sum g_mu, sum g_v, dE/dsigma2, n_neg}
+  double* apart;        // [nstrips][Mp] per-strip A g_mu (the data part of m_bar), reduced over strips in a fixed order
   LikParams lp;
   double scale;               // num_data / n_batch ...
   const double* n_global_dev; // ... or, data-parallel, num_data / *n_global_dev (0 -> 1)
@@ -150,6 +151,8 @@ void launch_kgrad(int dtype, hipStream_t s, const KernelParams& kp, const void* 
 // fused gradient path: sums of the per-strip partials, W = A diag(2 g_v) A' from its split-K lower tiles, (A g_mu), and the
 // assembly of Lq_bar / Lk_bar from G1 = 2 W Lq, G2 = 2 R W and the rank-one term alpha (A g_mu)'
 void launch_sum5(hipStream_t s, const double* partial, int nblocks, double* sums);
+// out[i] += sum over strips of apart[strip][i]  (fixed order)
+void launch_apart_reduce(hipStream_t s, const double* apart, int nstrips, int64_t Mp, double* out);
 void launch_sym_from_lower(int dtype, hipStream_t s, const void* G, int nslices, int64_t Mp, double eye, void* out);
 void launch_vec_to_block(int dtype, hipStream_t s, const void* v, int64_t Mp, void* X);   // v -> column 0 of an Mp x 64 block
 void launch_block_to_vec(int dtype, hipStream_t s, const void* X, int64_t Mp, void* v);

@@ -425,6 +425,41 @@ __global__ void __launch_bounds__(NTHR, MINW) strip_kernel(StripArgs a, int64_t 
         a.part5[strip * 5 + tid] = sacc;
       }
       __syncthreads();   // staging free again
+      // a = A g_mu of this strip (the data part of m_bar; A still in the scratch strip): a wave per row, lanes along the
+      // points (coalesced), fixed-order shuffle tree; written per strip and reduced over strips in a fixed order afterwards, so
+      // the kernel-gradient kernel no longer has to stream A from HBM beside P just for these row sums
+      if (a.apart) {   // fp32 only (api.hip): in f64 these VALU cycles are stolen from the MFMA pipe and cost more than they save
+        constexpr int RU = 8, CL = NT / 64 > 0 ? NT / 64 : 1;   // rows in flight per wave (one row at a time ran at the L2 latency)
+        const int wv = tid >> 6, lc = NT >= 64 ? lane : lane % NT;
+        double* __restrict__ ap = a.apart + strip * Mp;
+        double gl[CL];
+#pragma unroll
+        for (int q = 0; q < CL; ++q) gl[q] = (NT >= 64 || lane < NT) ? double(s_gmu[q * 64 + lc]) : 0.0;
+        for (int64_t r0 = int64_t(wv) * RU; r0 < Mp; r0 += int64_t(NTHR / 64) * RU) {   // Mp is a multiple of 128: whole groups
+          T av[RU][CL];
+#pragma unroll
+          for (int u = 0; u < RU; ++u)
+#pragma unroll
+            for (int q = 0; q < CL; ++q) av[u][q] = work[(r0 + u) * NT + q * 64 + lc];
+          double acc1[RU];
+#pragma unroll
+          for (int u = 0; u < RU; ++u) {
+            acc1[u] = 0.0;
+#pragma unroll
+            for (int q = 0; q < CL; ++q) acc1[u] = fma(double(av[u][q]), gl[q], acc1[u]);
+          }
+#pragma unroll
+          for (int w = 32; w > 0; w >>= 1)
+#pragma unroll
+            for (int u = 0; u < RU; ++u) acc1[u] += __shfl_xor(acc1[u], w);
+          if (lane < RU) {
+            double v = acc1[0];
+#pragma unroll
+            for (int u = 1; u < RU; ++u) v = (lane == u) ? acc1[u] : v;
+            ap[r0 + lane] = v;
+          }
+        }
+      }
       // ---------------- phase 3: P = alpha g_mu' + 2 (R A) diag(g_v), panel by panel (dense: every k-step is a full tile) ----
       const T* __restrict__ Rm = static_cast<const T*>(a.R);
       const T* __restrict__ alpha = static_cast<const T*>(a.alpha);
