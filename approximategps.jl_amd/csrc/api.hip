@@ -916,8 +916,9 @@ int grad_workspace(svgp_ctx* ctx, svgp_model* m, int64_t len, GradWs** out) {
   int ns = (2 * ctx->num_cus) / ntiles;   // tiles x slices just under two workgroups' worth per CU: no ragged tail
   w->nslices = ns < 1 ? 1 : (ns > 16 ? 16 : ns);
   w->rb = grad_rowblocks(m->d, Mp);
-  int nu = (2 * ctx->num_cus + w->rb - 1) / w->rb;
-  w->ns_uf = nu < 1 ? 1 : (nu > 128 ? 128 : nu);
+  static const int kg_wg = [] { const char* e = getenv("SVGP_KGRAD_WG_PER_CU"); return e ? atoi(e) : 2; }();   // tuning knob
+  int nu = (kg_wg * ctx->num_cus + w->rb - 1) / w->rb;
+  w->ns_uf = nu < 1 ? 1 : (nu > 256 ? 256 : nu);
   w->ns_uu = 8;
   const int dreg = grad_dreg(m->d);
   const size_t mn = size_t(Mp) * size_t(nc) * es, mm = size_t(Mp) * size_t(Mp) * es;
