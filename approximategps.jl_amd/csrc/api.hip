@@ -934,7 +934,8 @@ int grad_workspace(svgp_ctx* ctx, svgp_model* m, int64_t len, GradWs** out) {
       {&w->W2, mm}, {&w->Rcm, mm}, {&w->G1p, mm}, {&w->alpha, size_t(Mp) * es}, {(void**)&w->avec, size_t(Mp) * 8},
       {(void**)&w->rp_uf, w->rp_uf_b},
       {(void**)&w->sp_uf, w->sp_uf_b}, {(void**)&w->rp_uu, w->rp_uu_b}, {(void**)&w->sp_uu, w->sp_uu_b},
-      {(void**)&w->partial5, size_t(w->part5_strips) * 5 * 8}, {(void**)&w->apart, size_t(w->part5_strips) * size_t(Mp) * 8}, {(void**)&w->sums, size_t(8 + 1 + dreg) * 8}, {(void**)&w->invl_d, size_t(m->d) * 8}};
+      {(void**)&w->partial5, size_t(w->part5_strips) * 5 * 8}, {(void**)&w->apart, size_t(w->part5_strips) * size_t(Mp) * 8}, {(void**)&w->sums, size_t(8 + 1 + dreg) * 8}, {(void**)&w->invl_d, size_t(m->d) * 8},
+      {(void**)&w->kred, (size_t(2 + dreg) * size_t(Mp) + size_t(1 + dreg)) * 8}};
   for (auto& r : req) {
     if (hipMalloc(r.p, r.b) != hipSuccess) {
       w->release();
@@ -1118,7 +1119,7 @@ int grad_enqueue(svgp_ctx* ctx, svgp_model* m, const svgp_data* data, int64_t of
   launch_kgrad(dt, s, kp, m->zs, Mp, m->zs, Mp, 0, 1, M, M, w->H, nullptr, nullptr, uu_sl, w->ns_uu, w->rp_uu, w->sp_uu);
   launch_finish_kgrad(dt, s, m->d, M, Mp, m->zs, w->invl_d, w->rp_uf, w->ns_uf, w->rp_uu, w->ns_uu, w->sp_uf, w->ns_uf * w->rb,
                       w->sp_uu, w->ns_uu * w->rb, m->mp, klw, m->desc.layout_z, m->desc.variance, w->zbar, centered ? nullptr : w->mbar,
-                      w->scal_out);
+                      w->scal_out, w->kred);
   launch_grad_status(s, w->sums, m->info, double(len));
   KCHECK(ctx, "kgrad uu / finish");
   HIPC(ctx, hipEventRecord(ctx->ev[3], s));

@@ -48,7 +48,7 @@ struct GradWs {
        *tmp = nullptr, *H = nullptr, *zbar = nullptr, *mbar = nullptr, *Lqbar = nullptr, *BbarRM = nullptr, *rbar = nullptr;
   void *W2 = nullptr, *Rcm = nullptr, *G1p = nullptr, *alpha = nullptr;   // W = A diag(2 g_v) A', R = Lk^-T (Lq Lq' - I), 2 W Lq, Lk^-T m
   double *rp_uf = nullptr, *sp_uf = nullptr, *rp_uu = nullptr, *sp_uu = nullptr, *partial5 = nullptr, *sums = nullptr,
-         *invl_d = nullptr, *scal_out = nullptr, *avec = nullptr, *apart = nullptr;
+         *invl_d = nullptr, *scal_out = nullptr, *avec = nullptr, *apart = nullptr, *kred = nullptr;
   int64_t part5_strips = 0;
   size_t rp_uf_b = 0, sp_uf_b = 0, rp_uu_b = 0, sp_uu_b = 0, g_b = 0;
   void release() {

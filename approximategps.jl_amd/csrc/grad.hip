@@ -181,17 +181,17 @@ __global__ void __launch_bounds__(NTHR, 2) abar_kernel(const T* __restrict__ Lqp
 
 // X := Lk' \ X in place for a k-major X ([Mp][ld]): P_I = S[I,I] X_I + sum_{J>I} S[I,J] P_J, panels in descending
 // order, S[I,I] = inv(L_II)', S[I,J] = -inv(L_II)' L[J,I]'.  One workgroup per 64-column strip.
-template <typename T>
+template <typename T, int NT>
 __global__ void __launch_bounds__(k256, 2) solve_t_kernel(const T* __restrict__ S, T* __restrict__ X, T* __restrict__ Xt,
                                                            int64_t Mp, int64_t ld, int64_t nstrips) {
-  using G = TileGemm<T, 64, 16, k256>;
+  using G = TileGemm<T, NT, 16, k256>;
   using QRegs = typename G::QRegs;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   T* smem = reinterpret_cast<T*>(smem_raw);
   const int nP = int(Mp / kNB);
   const typename G::QOff qoff = G::q_offsets(ld);
   for (int64_t strip = blockIdx.x; strip < nstrips; strip += gridDim.x) {
-    const int64_t c0 = strip * 64;
+    const int64_t c0 = strip * NT;
     for (int I = nP - 1; I >= 0; --I) {
       typename G::Acc acc;
       acc.zero();
@@ -526,38 +526,69 @@ __global__ void rm_tril_to_user_kernel(const T* __restrict__ R, int64_t Mp, int6
   if (r < M) out[r + c * M] = (c <= r) ? R[r * Mp + c] : T(0);
 }
 
-// final assembly of the kernel-parameter / inducing-input gradients from the slice partials
-template <typename T>
-__global__ void finish_kgrad_kernel(int d, int dreg, int64_t M, int64_t Mp, const T* __restrict__ zs,
-                                    const double* __restrict__ invl, const double* __restrict__ rp_uf, int ns_uf,
-                                    const double* __restrict__ rp_uu, int ns_uu, const double* __restrict__ sp_uf, int nsp_uf,
-                                    const double* __restrict__ sp_uu, int nsp_uu, const T* __restrict__ m, double klw,
-                                    int layout_z, double variance, T* __restrict__ z_bar, T* __restrict__ m_bar,
-                                    double* __restrict__ scal_out) {
-  // scal_out[0] = sum P K (uf) + sum H K (uu), scal_out[1 + f] = il_bar_f
-  const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+// Slice partials of the kernel-gradient reductions, summed in a fixed order by many workgroups (a single pass of M threads
+// over 256 slices x (2 + d) rows was 0.37-0.43 ms of latency per gradient):
+//   red[q][i] = sum_s rp_uf[s][q][i] + (q == 1 ? 0 : 2 sum_s rp_uu[s][q][i])        blockIdx.y = q < 2 + dreg
+//   red_s[q]  = sum_b sp_uf[b][q] + sum_b sp_uu[b][q]                                blockIdx.y = 2 + dreg (q strided over x)
+// (row 1 is m_bar's data part, which has no Kuu term; the factor 2 is the symmetric Kuu's.)
+__global__ void __launch_bounds__(256) kgrad_reduce_kernel(int d, int dreg, int64_t Mp, const double* __restrict__ rp_uf, int ns_uf,
+                                                           const double* __restrict__ rp_uu, int ns_uu,
+                                                           const double* __restrict__ sp_uf, int nsp_uf,
+                                                           const double* __restrict__ sp_uu, int nsp_uu,
+                                                           double* __restrict__ red, double* __restrict__ red_s) {
+  __shared__ double sh[256];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t stride = int64_t(2 + dreg) * Mp;
+  if (int(blockIdx.y) < 2 + dreg) {
+    const int q = blockIdx.y;
+    const int64_t i = int64_t(blockIdx.x) * 64 + lane;
+    double a = 0, b = 0;
+    if (i < Mp) {
+      for (int s = wave; s < ns_uf; s += 4) a += rp_uf[s * stride + q * Mp + i];
+      if (q != 1)
+        for (int s = wave; s < ns_uu; s += 4) b += rp_uu[s * stride + q * Mp + i];
+    }
+    sh[threadIdx.x] = a + 2.0 * b;
+    __syncthreads();
+    if (wave == 0 && i < Mp) red[q * Mp + i] = (sh[lane] + sh[64 + lane]) + (sh[128 + lane] + sh[192 + lane]);
+    return;
+  }
+  for (int q = blockIdx.x; q <= d; q += gridDim.x) {
+    double a = 0;
+    for (int b = threadIdx.x; b < nsp_uf; b += 256) a += sp_uf[int64_t(b) * (1 + dreg) + q];
+    for (int b = threadIdx.x; b < nsp_uu; b += 256) a += sp_uu[int64_t(b) * (1 + dreg) + q];
+    sh[threadIdx.x] = a;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+      if (int(threadIdx.x) < w) sh[threadIdx.x] += sh[threadIdx.x + w];
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) red_s[q] = sh[0];
+    __syncthreads();
+  }
+}
+
+// final assembly of the kernel-parameter / inducing-input gradients from the reduced partials
+template <typename T>
+__global__ void finish_kgrad_kernel(int d, int64_t M, int64_t Mp, const T* __restrict__ zs, const double* __restrict__ invl,
+                                    const double* __restrict__ red, const double* __restrict__ red_s, const T* __restrict__ m,
+                                    double klw, int layout_z, double variance, T* __restrict__ z_bar, T* __restrict__ m_bar,
+                                    double* __restrict__ scal_out) {
+  // scal_out[0] = (sum P K (uf) + sum H K (uu)) / variance, scal_out[1 + f] = il_bar_f
+  const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
   if (i < M) {
-    double R1 = 0, MB = 0, R2 = 0;
-    for (int s = 0; s < ns_uf; ++s) { R1 += rp_uf[s * stride + i]; MB += rp_uf[s * stride + Mp + i]; }
-    for (int s = 0; s < ns_uu; ++s) R2 += rp_uu[s * stride + i];
-    if (m_bar) m_bar[i] = T(MB - klw * double(m[i]));   // klw * d KL / d m
+    const double R = red[i];
+    if (m_bar) m_bar[i] = T(red[Mp + i] - klw * double(m[i]));   // klw * d KL / d m
     for (int f = 0; f < d; ++f) {
-      double Q1 = 0, Q2 = 0;
-      for (int s = 0; s < ns_uf; ++s) Q1 += rp_uf[s * stride + (2 + f) * Mp + i];
-      for (int s = 0; s < ns_uu; ++s) Q2 += rp_uu[s * stride + (2 + f) * Mp + i];
       const double zf = double(zs[int64_t(f) * Mp + i]);
-      const double g = 2.0 * invl[f] * ((zf * R1 - Q1) + 2.0 * (zf * R2 - Q2));
+      const double g = 2.0 * invl[f] * (zf * R - red[(2 + f) * Mp + i]);
       if (layout_z == 1) z_bar[int64_t(f) * M + i] = T(g);   // RowVecs: M x d column-major
       else z_bar[i * d + f] = T(g);                           // ColVecs / Vec
     }
   }
   if (blockIdx.x == 0 && int(threadIdx.x) <= d) {
     const int q = threadIdx.x;
-    double s = 0.0;
-    for (int b = 0; b < nsp_uf; ++b) s += sp_uf[int64_t(b) * (1 + dreg) + q];
-    for (int b = 0; b < nsp_uu; ++b) s += sp_uu[int64_t(b) * (1 + dreg) + q];
-    scal_out[q] = (q == 0) ? s / variance : 2.0 / invl[q - 1] * s;
+    scal_out[q] = (q == 0) ? red_s[0] / variance : 2.0 / invl[q - 1] * red_s[q];
   }
 }
 
@@ -665,13 +696,24 @@ void launch_sdiag(int dtype, hipStream_t s, const void* Tm, int64_t Mp, void* S)
 
 void launch_solve_t(int dtype, hipStream_t s, const void* S, void* X, void* Xt, int64_t Mp, int64_t ld, int64_t ncols,
                     int num_cus) {
-  const int64_t nstrips = ncols / 64;
+  // The panels of a strip are a dependency chain, so the parallelism is the number of column strips: a square M x M right-hand
+  // side has only M / 64 of them (16 at M = 1024 on 256 CUs), hence 32-column strips there (twice the workgroups, half the chain
+  // time each); wide right-hand sides keep the 64-column strips.
+  static const int forced = [] { const char* e = getenv("SVGP_SOLVE_T_NT"); return e ? atoi(e) : 0; }();   // tuning knob
+  const int nt = forced ? forced : (ncols / 64 < num_cus ? 32 : 64);
+  const int64_t nstrips = ncols / nt;
   const int64_t cap = int64_t(num_cus) * 2;
   const int grid = int(nstrips < cap ? nstrips : cap);
   GD(dtype, T, {
-    using G = TileGemm<T, 64, 16, k256>;
-    set_max_lds(reinterpret_cast<const void*>(solve_t_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, int(G::LDS_BYTES));
-    hipLaunchKernelGGL(solve_t_kernel<T>, dim3(grid), dim3(k256), G::LDS_BYTES, s, (const T*)S, (T*)X, (T*)Xt, Mp, ld, nstrips);
+    if (nt == 32) {
+      using G = TileGemm<T, 32, 16, k256>;
+      set_max_lds(reinterpret_cast<const void*>(solve_t_kernel<T, 32>), hipFuncAttributeMaxDynamicSharedMemorySize, int(G::LDS_BYTES));
+      hipLaunchKernelGGL((solve_t_kernel<T, 32>), dim3(grid), dim3(k256), G::LDS_BYTES, s, (const T*)S, (T*)X, (T*)Xt, Mp, ld, nstrips);
+    } else {
+      using G = TileGemm<T, 64, 16, k256>;
+      set_max_lds(reinterpret_cast<const void*>(solve_t_kernel<T, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, int(G::LDS_BYTES));
+      hipLaunchKernelGGL((solve_t_kernel<T, 64>), dim3(grid), dim3(k256), G::LDS_BYTES, s, (const T*)S, (T*)X, (T*)Xt, Mp, ld, nstrips);
+    }
   });
 }
 
@@ -766,11 +808,14 @@ void launch_rm_tril_to_user(int dtype, hipStream_t s, const void* R, int64_t Mp,
 void launch_finish_kgrad(int dtype, hipStream_t s, int d, int64_t M, int64_t Mp, const void* zs, const double* invl,
                          const double* rp_uf, int ns_uf, const double* rp_uu, int ns_uu, const double* sp_uf, int nsp_uf,
                          const double* sp_uu, int nsp_uu, const void* m, double klw, int layout_z, double variance,
-                         void* z_bar, void* m_bar, double* scal_out) {
+                         void* z_bar, void* m_bar, double* scal_out, double* red) {
+  const int dreg = grad_dreg(d);
+  double* red_s = red + int64_t(2 + dreg) * Mp;
+  hipLaunchKernelGGL(kgrad_reduce_kernel, dim3((unsigned)((Mp + 63) / 64), (unsigned)(3 + dreg)), dim3(256), 0, s, d, dreg, Mp, rp_uf,
+                     ns_uf, rp_uu, ns_uu, sp_uf, nsp_uf, sp_uu, nsp_uu, red, red_s);
   dim3 grid((unsigned)((M + 255) / 256));
-  GD(dtype, T, hipLaunchKernelGGL(finish_kgrad_kernel<T>, grid, dim3(256), 0, s, d, grad_dreg(d), M, Mp, (const T*)zs, invl, rp_uf,
-                                  ns_uf, rp_uu, ns_uu, sp_uf, nsp_uf, sp_uu, nsp_uu, (const T*)m, klw, layout_z, variance, (T*)z_bar,
-                                  (T*)m_bar, scal_out));
+  GD(dtype, T, hipLaunchKernelGGL(finish_kgrad_kernel<T>, grid, dim3(256), 0, s, d, M, Mp, (const T*)zs, invl, red, red_s,
+                                  (const T*)m, klw, layout_z, variance, (T*)z_bar, (T*)m_bar, scal_out));
 }
 
 }  // namespace svgp

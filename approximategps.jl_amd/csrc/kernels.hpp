@@ -173,6 +173,6 @@ void launch_rm_tril_to_user(int dtype, hipStream_t s, const void* R, int64_t Mp,
 void launch_finish_kgrad(int dtype, hipStream_t s, int d, int64_t M, int64_t Mp, const void* zs, const double* invl,
                          const double* rp_uf, int ns_uf, const double* rp_uu, int ns_uu, const double* sp_uf, int nsp_uf,
                          const double* sp_uu, int nsp_uu, const void* m, double klw, int layout_z, double variance,
-                         void* z_bar, void* m_bar, double* scal_out);
+                         void* z_bar, void* m_bar, double* scal_out, double* red);
 
 }  // namespace svgp
