@@ -914,7 +914,8 @@ int grad_workspace(svgp_ctx* ctx, svgp_model* m, int64_t len, GradWs** out) {
   w->dtype = m->dtype; w->Mp = Mp; w->d = m->d; w->nc = nc;
   const int nP = int(Mp / 128), ntiles = nP * (nP + 1) / 2;
   int ns = (2 * ctx->num_cus) / ntiles;   // tiles x slices just under two workgroups' worth per CU: no ragged tail
-  w->nslices = ns < 1 ? 1 : (ns > 16 ? 16 : ns);
+  static const int ns_cap = [] { const char* e = getenv("SVGP_GEMM_PM_SLICES_CAP"); return e ? atoi(e) : 64; }();   // tuning knob
+  w->nslices = ns < 1 ? 1 : (ns > ns_cap ? ns_cap : ns);   // (a cap of 16 left C2 - 10 tiles - with 320 workgroups for 512 slots)
   w->rb = grad_rowblocks(m->d, Mp);
   static const int kg_wg = [] { const char* e = getenv("SVGP_KGRAD_WG_PER_CU"); return e ? atoi(e) : 2; }();   // tuning knob
   int nu = (kg_wg * ctx->num_cus + w->rb - 1) / w->rb;
