@@ -14,7 +14,7 @@ OK, INVALID_ARG, NOT_POSDEF, NEG_VARIANCE, UNSUPPORTED, HIP_ERROR, RCCL_ERROR, O
 F64, F32 = 0, 1
 COLVECS, ROWVECS, VEC = 0, 1, 2
 KERNEL_SE, KERNEL_MATERN32, KERNEL_MATERN52 = 0, 1, 2
-LIK_GAUSSIAN, LIK_BERNOULLI_LOGISTIC, LIK_POISSON_EXP, LIK_EXPONENTIAL_EXP, LIK_GAMMA_EXP = 0, 1, 2, 3, 4
+LIK_GAUSSIAN, LIK_BERNOULLI_LOGISTIC, LIK_POISSON_EXP, LIK_EXPONENTIAL_EXP, LIK_GAMMA_EXP, LIK_BERNOULLI_NORMCDF = 0, 1, 2, 3, 4, 5
 NONCENTERED, CENTERED = 0, 1
 NEGVAR_ERROR, NEGVAR_CLAMP = 0, 1
 

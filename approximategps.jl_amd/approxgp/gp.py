@@ -57,8 +57,22 @@ class GaussianLikelihood:
 
 
 @dataclass(frozen=True)
+class LogisticLink:
+    pass
+
+
+@dataclass(frozen=True)
+class NormalCDFLink:
+    """probit: invlink = normcdf  [GPLikelihoods]"""
+
+
+ProbitLink = NormalCDFLink
+
+
+@dataclass(frozen=True)
 class BernoulliLikelihood:
-    """logistic link"""
+    """BernoulliLikelihood(l = logistic): y ~ Bernoulli(l(f)); l is LogisticLink() (default) or NormalCDFLink()"""
+    invlink: object = LogisticLink()
 
 
 @dataclass(frozen=True)

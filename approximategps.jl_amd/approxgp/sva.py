@@ -10,7 +10,8 @@ import numpy as np
 
 from . import _ffi
 from .gp import (DEFAULT_SIGMA2, BernoulliLikelihood, DefaultExpectationMethod, FiniteGP, GaussHermiteExpectation,
-                 GaussianLikelihood, LatentFiniteGP, MvNormal, PoissonLikelihood, ExponentialLikelihood, GammaLikelihood, _as_dn)
+                 GaussianLikelihood, LatentFiniteGP, MvNormal, NormalCDFLink, LogisticLink, PoissonLikelihood, ExponentialLikelihood,
+                 GammaLikelihood, _as_dn)
 from .kernels import unpack_kernel
 
 
@@ -71,6 +72,11 @@ def _desc(sva: SparseVariationalApproximation, lik=None, quadrature=None, dtype=
         if type(lik) not in _LIK:
             raise _ffi.UnsupportedError(f"unsupported likelihood {lik!r}")
         lik_code = _LIK[type(lik)]
+        if isinstance(lik, BernoulliLikelihood):
+            if isinstance(lik.invlink, NormalCDFLink):
+                lik_code = _ffi.LIK_BERNOULLI_NORMCDF
+            elif not isinstance(lik.invlink, LogisticLink):
+                raise _ffi.UnsupportedError(f"unsupported link {lik.invlink!r}")
         if isinstance(lik, GaussianLikelihood):
             s2 = float(lik.sigma2)
         elif isinstance(lik, GammaLikelihood):

@@ -8,7 +8,7 @@ import math
 import numpy as np
 
 # codes of include/svgp_mi355x.h
-LIK_GAUSSIAN, LIK_BERNOULLI_LOGISTIC, LIK_POISSON_EXP, LIK_EXPONENTIAL_EXP, LIK_GAMMA_EXP = 0, 1, 2, 3, 4
+LIK_GAUSSIAN, LIK_BERNOULLI_LOGISTIC, LIK_POISSON_EXP, LIK_EXPONENTIAL_EXP, LIK_GAMMA_EXP, LIK_BERNOULLI_NORMCDF = 0, 1, 2, 3, 4, 5
 
 
 def _observations(rng, x, lik):
@@ -17,7 +17,7 @@ def _observations(rng, x, lik):
     sigma2 = 0.3
     if lik == LIK_GAUSSIAN:
         y = np.sin(s) + math.sqrt(sigma2) * rng.standard_normal(N)
-    elif lik == LIK_BERNOULLI_LOGISTIC:
+    elif lik in (LIK_BERNOULLI_LOGISTIC, LIK_BERNOULLI_NORMCDF):
         p = 1.0 / (1.0 + np.exp(-2.0 * np.sin(s)))
         y = (rng.random(N) < p).astype(np.float64)
     elif lik == LIK_POISSON_EXP:

@@ -101,7 +101,7 @@ int validate_desc(svgp_ctx* ctx, const svgp_model_desc* d) {
   if (!d) return fail(ctx, SVGP_INVALID_ARG, "null model descriptor");
   if (d->dtype != SVGP_F64 && d->dtype != SVGP_F32) return fail(ctx, SVGP_INVALID_ARG, "dtype must be SVGP_F64 or SVGP_F32");
   if (d->kernel < 0 || d->kernel > SVGP_KERNEL_MATERN52) return fail(ctx, SVGP_UNSUPPORTED, "unsupported kernel family");
-  if (d->likelihood < 0 || d->likelihood > SVGP_LIK_GAMMA_EXP) return fail(ctx, SVGP_UNSUPPORTED, "unsupported likelihood");
+  if (d->likelihood < 0 || d->likelihood > SVGP_LIK_BERNOULLI_NORMCDF) return fail(ctx, SVGP_UNSUPPORTED, "unsupported likelihood");
   if (d->parametrization != SVGP_NONCENTERED && d->parametrization != SVGP_CENTERED)
     return fail(ctx, SVGP_INVALID_ARG, "parametrization must be SVGP_NONCENTERED or SVGP_CENTERED");
   if (d->d < 1 || d->d > 32) return fail(ctx, SVGP_UNSUPPORTED, "input dimension must be in 1..32");
@@ -123,7 +123,7 @@ double lik_param(const svgp_model_desc& d) {
 
 int effective_gh(const svgp_model_desc& d) {
   if (d.quadrature_n > 0) return d.quadrature_n;
-  if (d.likelihood != SVGP_LIK_BERNOULLI_LOGISTIC) return 0;  // closed forms [GPLikelihoods AnalyticExpectation]
+  if (d.likelihood != SVGP_LIK_BERNOULLI_LOGISTIC && d.likelihood != SVGP_LIK_BERNOULLI_NORMCDF) return 0;  // closed forms [GPLikelihoods AnalyticExpectation]
   return 20;  // DefaultExpectationMethod -> GaussHermiteExpectation(20)  [GPLikelihoods]
 }
 

@@ -10,6 +10,17 @@ namespace svgp {
 
 __device__ __forceinline__ double softplus_d(double s) { return fmax(s, 0.0) + log1p(exp(-fabs(s))); }
 
+// log Phi(x) and the hazard phi(x) / Phi(x) of the standard normal (the NormalCDFLink Bernoulli), through the scaled
+// complementary error function on the negative side: no underflow and no cancellation in either tail
+__device__ __forceinline__ double log_ndtr_d(double x) {
+  const double u = -0.70710678118654752440 * x;   // Phi(x) = erfc(u) / 2
+  return u > 0.0 ? log(0.5 * erfcx(u)) - u * u : log1p(-0.5 * erfc(-u));
+}
+__device__ __forceinline__ double ndtr_hazard_d(double x) {
+  const double u = -0.70710678118654752440 * x;
+  return u > 0.0 ? 0.79788456080286535588 / erfcx(u) : 0.39894228040143267794 * exp(-u * u) / (1.0 - 0.5 * erfc(-u));
+}
+
 // digamma: recurrence up to x >= 6, then the asymptotic series (|error| < 1e-14)
 __host__ __device__ inline double digamma_d(double x) {
   double r = 0.0;
@@ -31,6 +42,7 @@ __device__ __forceinline__ double loglik_point(int lik, double f, double y, doub
   if (lik == 1) return -softplus_d(y > 0.5 ? -f : f);
   if (lik == 2) return y * f - exp(f) - lgamma(y + 1.0);
   if (lik == 3) return -f - y * exp(-f);                                         // Exponential(scale e^f) = Gamma(1, scale e^f)
+  if (lik == 5) return log_ndtr_d(y > 0.5 ? f : -f);                             // Bernoulli(Phi(f)): log Phi(+-f)
   return (sigma2 - 1.0) * log(y) - y * exp(-f) - sigma2 * f - lgamma(sigma2);    // Gamma(alpha = sigma2, scale e^f)
 }
 
@@ -59,6 +71,7 @@ __device__ __forceinline__ double dloglik_point(int lik, double f, double y, dou
   if (lik == 1) return y - 1.0 / (1.0 + exp(-f));
   if (lik == 2) return y - exp(f);
   if (lik == 3) return y * exp(-f) - 1.0;
+  if (lik == 5) return y > 0.5 ? ndtr_hazard_d(f) : -ndtr_hazard_d(-f);
   return y * exp(-f) - sigma2;
 }
 

@@ -60,7 +60,8 @@ enum {
   SVGP_LIK_BERNOULLI_LOGISTIC = 1,
   SVGP_LIK_POISSON_EXP = 2,      /* PoissonLikelihood(exp):      y ~ Poisson(exp f) */
   SVGP_LIK_EXPONENTIAL_EXP = 3,  /* ExponentialLikelihood(exp):  y ~ Exponential(scale exp f) = Gamma(1, scale exp f) */
-  SVGP_LIK_GAMMA_EXP = 4         /* GammaLikelihood(alpha, exp): y ~ Gamma(shape alpha, scale exp f); alpha in lik_sigma2 */
+  SVGP_LIK_GAMMA_EXP = 4,        /* GammaLikelihood(alpha, exp): y ~ Gamma(shape alpha, scale exp f); alpha in lik_sigma2 */
+  SVGP_LIK_BERNOULLI_NORMCDF = 5 /* BernoulliLikelihood(NormalCDFLink()) (probit): y ~ Bernoulli(Phi(f)); Gauss-Hermite */
 };
 
 /* SVA:41 Centered, SVA:57 NonCentered (the 2-arg constructor's default, SVA:93-95) */

@@ -146,6 +146,7 @@ unpack_mean(::Any) = nothing
 # (code, parameter, has a closed-form expectation [GPLikelihoods AnalyticExpectation])
 unpack_lik(l::GaussianLikelihood) = (Int32(0), Float64(only(l.σ²)), true)
 unpack_lik(::BernoulliLikelihood{<:LogisticLink}) = (Int32(1), 1.0, false)
+unpack_lik(::BernoulliLikelihood{<:NormalCDFLink}) = (Int32(5), 1.0, false)   # probit: y ~ Bernoulli(normcdf(f))
 unpack_lik(::PoissonLikelihood{<:ExpLink}) = (Int32(2), 1.0, true)
 unpack_lik(::ExponentialLikelihood{<:ExpLink}) = (Int32(3), 1.0, true)      # Exponential(scale = exp f), oracle/CONVENTIONS.md
 unpack_lik(l::GammaLikelihood{<:Any,<:ExpLink}) = (Int32(4), Float64(only(l.α)), true)   # shape in the parameter slot

@@ -38,7 +38,7 @@ from typing import Optional, Tuple
 
 import numpy as np
 import scipy.linalg as sla
-from scipy.special import digamma, gammaln
+from scipy.special import digamma, gammaln, log_ndtr
 
 # ----------------------------------------------------------------------------
 # constants of the dependency layer
@@ -55,6 +55,7 @@ LIK_BERNOULLI_LOGISTIC = 1
 LIK_POISSON_EXP = 2
 LIK_EXPONENTIAL_EXP = 3  # ExponentialLikelihood(exp): y ~ Distributions.Exponential(θ = exp f), θ is the SCALE  [dep GPLikelihoods]
 LIK_GAMMA_EXP = 4        # GammaLikelihood(alpha, exp): y ~ Gamma(shape alpha, scale exp f); alpha passed as `sigma2`
+LIK_BERNOULLI_NORMCDF = 5  # BernoulliLikelihood(NormalCDFLink()): y ~ Bernoulli(Φ(f))  [dep GPLikelihoods, StatsFuns.normcdf]
 
 _SQRT3 = math.sqrt(3.0)
 _SQRT5 = math.sqrt(5.0)
@@ -300,6 +301,10 @@ def loglik(lik: int, f: np.ndarray, y: np.ndarray, sigma2: float = 1.0) -> np.nd
         # identical to rounding wherever the reference's log(logistic(f)) is finite.
         s = np.where(y > 0.5, -f, f)
         return -np.logaddexp(0.0, s)
+    if lik == LIK_BERNOULLI_NORMCDF:
+        # logpdf(Bernoulli(Φ(f)), y) = y log Φ(f) + (1-y) log(1-Φ(f)) = log Φ(±f); scipy's log_ndtr keeps both tails
+        # finite where the reference's log(1 - normcdf(f)) rounds to log(0) (|f| > 8.3: GH weights < 1e-13 there)
+        return log_ndtr(np.where(y > 0.5, f, -f))
     if lik == LIK_POISSON_EXP:
         return y * f - np.exp(f) - gammaln(y + 1.0)
     if lik == LIK_EXPONENTIAL_EXP:   # logpdf(Exponential(scale = exp f), y) = -f - y exp(-f)  (oracle/CONVENTIONS.md)
@@ -544,6 +549,9 @@ def _dloglik(lik: int, f, y, sigma2):
         return y - np.exp(f)
     if lik == LIK_EXPONENTIAL_EXP:
         return y * np.exp(-f) - 1.0
+    if lik == LIK_BERNOULLI_NORMCDF:   # d/df log Φ(s f) = s φ(s f) / Φ(s f), s = 2y - 1
+        sgn = np.where(y > 0.5, 1.0, -1.0)
+        return sgn * np.exp(-0.5 * f * f - 0.5 * math.log(2.0 * math.pi) - log_ndtr(sgn * f))
     return y * np.exp(-f) - sigma2
 
 

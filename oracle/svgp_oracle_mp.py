@@ -13,7 +13,7 @@ import mpmath as mp
 mp.mp.dps = 50
 
 SE, MATERN32, MATERN52 = 0, 1, 2
-GAUSSIAN, BERNOULLI_LOGISTIC, POISSON_EXP = 0, 1, 2
+GAUSSIAN, BERNOULLI_LOGISTIC, POISSON_EXP, BERNOULLI_NORMCDF = 0, 1, 2, 5
 
 
 def _k(family, variance, inv_l, a, b):
@@ -69,6 +69,9 @@ def _loglik(lik, f, y, sigma2):
     if lik == BERNOULLI_LOGISTIC:
         p = 1 / (1 + mp.exp(-f))
         return mp.log(p) if y > 0.5 else mp.log(1 - p)
+    if lik == BERNOULLI_NORMCDF:   # the reference's own form: logpdf(Bernoulli(normcdf(f)), y), at 50 digits
+        p = mp.ncdf(f)
+        return mp.log(p) if y > 0.5 else mp.log(1 - p)
     return y * f - mp.exp(f) - mp.loggamma(y + 1)
 
 
@@ -82,7 +85,7 @@ def elbo(family, variance, inv_l, z, m, Lq, jitter, x, y, lik=GAUSSIAN, sigma2=1
     Lk = _chol(Kuu)
     mm = [mp.mpf(v) for v in m]
     L = [[mp.mpf(Lq[i][j]) if j <= i else mp.mpf(0) for j in range(M)] for i in range(M)]
-    if quadrature_n == 0 and lik == BERNOULLI_LOGISTIC:
+    if quadrature_n == 0 and lik in (BERNOULLI_LOGISTIC, BERNOULLI_NORMCDF):
         quadrature_n = 20
     if quadrature_n:
         xs, ws = gausshermite(quadrature_n)

@@ -33,6 +33,7 @@ CASES = [
     (450, 70, 3, o.KERNEL_MATERN32, o.LIK_EXPONENTIAL_EXP, 0),
     (500, 60, 2, o.KERNEL_SE, o.LIK_GAMMA_EXP, 0),
     (400, 33, 2, o.KERNEL_MATERN52, o.LIK_GAMMA_EXP, 8),
+    (520, 90, 3, o.KERNEL_SE, o.LIK_BERNOULLI_NORMCDF, 0),
 ]
 
 
@@ -207,7 +208,7 @@ def test_shard_gradients_sum_to_the_global_gradient(ctx, centered):
 def test_randomized_gradient_sweep(ctx):
     """Seeded sweep of svgp_elbo_grad over ragged shapes, families, likelihoods and both parametrisations (fp64)."""
     rng = np.random.default_rng(77)
-    liks = [o.LIK_GAUSSIAN, o.LIK_BERNOULLI_LOGISTIC, o.LIK_POISSON_EXP, o.LIK_EXPONENTIAL_EXP, o.LIK_GAMMA_EXP]
+    liks = [o.LIK_GAUSSIAN, o.LIK_BERNOULLI_LOGISTIC, o.LIK_POISSON_EXP, o.LIK_EXPONENTIAL_EXP, o.LIK_GAMMA_EXP, o.LIK_BERNOULLI_NORMCDF]
     for case in range(14):
         N = int(rng.integers(2, 900))
         M = int(rng.choice([1, 5, 16, 127, 129, 190]))

@@ -47,6 +47,8 @@ CASES = [
     (700, 96, 3, o.KERNEL_MATERN32, o.LIK_EXPONENTIAL_EXP, 0),  # exp-link closed forms
     (650, 80, 4, o.KERNEL_SE, o.LIK_GAMMA_EXP, 0),
     (333, 40, 2, o.KERNEL_SE, o.LIK_GAMMA_EXP, 12),             # Gamma through Gauss-Hermite
+    (820, 150, 4, o.KERNEL_SE, o.LIK_BERNOULLI_NORMCDF, 0),     # Bernoulli with the NormalCDF (probit) link, GH-20
+    (410, 48, 2, o.KERNEL_MATERN32, o.LIK_BERNOULLI_NORMCDF, 15),
     (130, 140, 2, o.KERNEL_SE, o.LIK_GAUSSIAN, 0),            # M > N
     (1, 5, 1, o.KERNEL_SE, o.LIK_GAUSSIAN, 0),                # a single point
 ]
@@ -66,7 +68,7 @@ def test_elbo_fp64_matches_oracle(ctx, N, M, d, family, lik, qn):
     assert (t.n_points, t.n_neg_var, t.chol_info) == (N, 0, 0)
 
 
-@pytest.mark.parametrize("N,M,d,family,lik,qn", CASES[:9])
+@pytest.mark.parametrize("N,M,d,family,lik,qn", CASES[:10])
 def test_elbo_fp32_matches_oracle(ctx, N, M, d, family, lik, qn):
     x, y, sva, s2 = o.synth_problem(100 + N, N, M, d, family=family, lik=lik, dtype=np.float32)
     ref = o.elbo_terms(sva, x, y, lik=lik, sigma2=s2, quadrature_n=qn)
@@ -309,6 +311,14 @@ def test_python_mirror_end_to_end(ctx):
     yg = np.random.default_rng(4).gamma(2.0, np.exp(np.sin(3 * x[:100])))
     lg = ag.LatentGP(f, ag.GammaLikelihood(2.0), 1e-18)(x[:100])
     assert rel(ag.elbo(sva, lg, yg, ctx=ctx), o.elbo(osva, x[:100], yg, lik=o.LIK_GAMMA_EXP, sigma2=2.0)) < F64_RTOL
+    # Bernoulli with either link through the mirror's classes ("could use other invlink, e.g. normcdf",
+    # examples/c-comparisons/script.jl:33-34); an unknown link is declined, not substituted
+    yb = (np.random.default_rng(5).random(100) < 0.5 + 0.4 * np.sin(3 * x[:100])).astype(float)
+    for lik_obj, code in ((ag.BernoulliLikelihood(), o.LIK_BERNOULLI_LOGISTIC), (ag.BernoulliLikelihood(ag.NormalCDFLink()), o.LIK_BERNOULLI_NORMCDF)):
+        lb = ag.LatentGP(f, lik_obj, 1e-18)(x[:100])
+        assert rel(ag.elbo(sva, lb, yb, ctx=ctx), o.elbo(osva, x[:100], yb, lik=code)) < F64_RTOL
+    with pytest.raises(_ffi.UnsupportedError):
+        ag.elbo(sva, ag.LatentGP(f, ag.BernoulliLikelihood(object()), 1e-18)(x[:100]), yb, ctx=ctx)
 
 
 @pytest.mark.parametrize("dtype,tol", [(np.float64, F64_RTOL), (np.float32, F32_RTOL)])

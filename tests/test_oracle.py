@@ -115,7 +115,7 @@ def test_K4_fusion_identity():
 
 
 @pytest.mark.parametrize("family", [o.KERNEL_SE, o.KERNEL_MATERN32, o.KERNEL_MATERN52])
-@pytest.mark.parametrize("lik", [o.LIK_GAUSSIAN, o.LIK_BERNOULLI_LOGISTIC, o.LIK_POISSON_EXP])
+@pytest.mark.parametrize("lik", [o.LIK_GAUSSIAN, o.LIK_BERNOULLI_LOGISTIC, o.LIK_POISSON_EXP, o.LIK_BERNOULLI_NORMCDF])
 def test_K6_mpmath(family, lik):
     x, y, sva, s2 = o.synth_problem(11 + family, 6, 4, 2, family=family, lik=lik)
     ref = omp.elbo(family, sva.kernel.variance, list(sva.kernel.inv_lengthscale), sva.z.T.tolist(),
@@ -187,6 +187,8 @@ def test_exponential_likelihood_is_scale_parametrised():
     b = (rng.random(50) < 0.5).astype(float)
     np.testing.assert_allclose(o.loglik(o.LIK_BERNOULLI_LOGISTIC, f, b), stats.bernoulli(1 / (1 + np.exp(-f))).logpmf(b), rtol=1e-12)
     np.testing.assert_allclose(o.loglik(o.LIK_GAUSSIAN, f, y, 0.3), stats.norm(f, np.sqrt(0.3)).logpdf(y), rtol=1e-12)
+    # BernoulliLikelihood(NormalCDFLink()): logpdf(Bernoulli(normcdf(f)), y), the reference's naive form where it is finite
+    np.testing.assert_allclose(o.loglik(o.LIK_BERNOULLI_NORMCDF, f, b), stats.bernoulli(stats.norm.cdf(f)).logpmf(b), rtol=1e-12)
     mu, sd = rng.standard_normal(50) * 0.5, 0.3 + rng.random(50)
     for qn in (0, 30):
         assert o.expected_loglik(o.LIK_EXPONENTIAL_EXP, mu, sd, y, 1.0, qn) == pytest.approx(

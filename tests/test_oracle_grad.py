@@ -21,7 +21,7 @@ def _fd(fun, x0, h):
 
 @pytest.mark.parametrize("family", [o.KERNEL_SE, o.KERNEL_MATERN32, o.KERNEL_MATERN52])
 @pytest.mark.parametrize("lik,qn", [(o.LIK_GAUSSIAN, 0), (o.LIK_BERNOULLI_LOGISTIC, 0), (o.LIK_POISSON_EXP, 0), (o.LIK_GAUSSIAN, 7),
-                                    (o.LIK_EXPONENTIAL_EXP, 0), (o.LIK_GAMMA_EXP, 0), (o.LIK_GAMMA_EXP, 9)])
+                                    (o.LIK_EXPONENTIAL_EXP, 0), (o.LIK_GAMMA_EXP, 0), (o.LIK_GAMMA_EXP, 9), (o.LIK_BERNOULLI_NORMCDF, 0)])
 def test_gradient_matches_finite_differences(family, lik, qn):
     x, y, sva, s2 = o.synth_problem(31 + family, 40, 7, 3, family=family, lik=lik)
     sva.mean_const = 0.2
