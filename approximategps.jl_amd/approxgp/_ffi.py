@@ -69,6 +69,9 @@ SYMBOLS = {
                                    C.POINTER(Grads)]),
     "svgp_elbo_grad_shard": (C.c_int32, [_P, _P, _P, C.c_int64, C.c_int64, C.c_double, C.c_double, C.POINTER(C.c_double),
                                          C.POINTER(Terms), C.POINTER(Grads)]),
+    "svgp_marginals": (C.c_int32, [_P, _P, _P, C.c_int64, C.c_int64, _P, _P]),
+    "svgp_elbo_grad_ext": (C.c_int32, [_P, _P, _P, C.c_int64, C.c_int64, C.c_double, C.c_double, _P, _P, C.POINTER(C.c_double),
+                                       C.POINTER(Terms), C.POINTER(Grads)]),
     "svgp_prior_kl": (C.c_int32, [_P, _P, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "svgp_elbo_host": (C.c_int32, [_P, C.POINTER(ModelDesc), C.c_int32, C.c_int64, _P, _P, C.c_double,
                                    C.POINTER(C.c_double), C.POINTER(Terms)]),
@@ -340,9 +343,17 @@ class DeviceModel:
         self.ctx.check(self.ctx.lib.svgp_elbo_partial(self.ctx.h, self.h, data.h, off, length, buf))
         return np.array(buf[:], dtype=np.float64)
 
-    def elbo_grad(self, data: DeviceData, off=0, length=None, num_data=0.0, z_shape=None, shard=None):
+    def marginals(self, data: DeviceData, off=0, length=None):
+        """marginals(f_post(x)) of SVA:354 for the batch: (mu, v + 1e-18) as fp64 arrays (svgp_marginals)."""
+        length = data.n - off if length is None else length
+        mu, var = np.zeros(length), np.zeros(length)
+        self.ctx.check(self.ctx.lib.svgp_marginals(self.ctx.h, self.h, data.h, off, length, _ptr(mu), _ptr(var)))
+        return mu, var
+
+    def elbo_grad(self, data: DeviceData, off=0, length=None, num_data=0.0, z_shape=None, shard=None, ext=None):
         """-> (elbo, terms, dict(variance, inv_lengthscale, z, m, Lq, lik_sigma2, mean_const)); z in the layout it was given.
-        shard = (scale, kl_weight) evaluates the data-parallel shard form svgp_elbo_grad_shard instead."""
+        shard = (scale, kl_weight) evaluates the data-parallel shard form svgp_elbo_grad_shard instead.
+        ext = (sum_e, g_mu, g_v): a likelihood the host evaluated on `marginals` (svgp_elbo_grad_ext)."""
         length = data.n - off if length is None else length
         dt = np_dtype(self.dtype)
         il = np.zeros(self.d)
@@ -352,7 +363,13 @@ class DeviceModel:
         Lb = np.zeros((self.M, self.M), dtype=dt, order="F")
         g = Grads(0.0, 0.0, 0.0, il.ctypes.data_as(C.POINTER(C.c_double)), _ptr(zb), _ptr(mb), _ptr(Lb))
         out, terms = C.c_double(), Terms()
-        if shard is None:
+        if ext is not None:
+            gmu, gv = (np.ascontiguousarray(a, dtype=np.float64) for a in ext[1:])
+            if gmu.shape != (length,) or gv.shape != (length,):
+                raise ValueError("one point gradient per point of the batch")
+            rc = self.ctx.lib.svgp_elbo_grad_ext(self.ctx.h, self.h, data.h, off, length, float(num_data), float(ext[0]),
+                                                 _ptr(gmu), _ptr(gv), C.byref(out), C.byref(terms), C.byref(g))
+        elif shard is None:
             rc = self.ctx.lib.svgp_elbo_grad(self.ctx.h, self.h, data.h, off, length, float(num_data), C.byref(out),
                                              C.byref(terms), C.byref(g))
         else:

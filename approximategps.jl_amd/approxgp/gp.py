@@ -91,6 +91,34 @@ class GammaLikelihood:
     alpha: float = 1.0
 
 
+@dataclass(frozen=True)
+class GenericLikelihood:
+    """A single-latent likelihood the C-ABI does not enumerate (any GPLikelihoods likelihood / link in the reference):
+    log p(y | f) and its f-derivative as vectorised callables (f, y) -> array.  Its expectation under the marginals -
+    SVA:355, the only likelihood-dependent step and O(n) scalar work - is evaluated HERE on the host by Gauss-Hermite, on
+    marginals the device computed (svgp_marginals); the backward pass runs on the device again (svgp_elbo_grad_ext)."""
+    logp: object
+    dlogp: object = None
+
+    def host_expectation(self, mu, var, y, n_points=20, want_grad=False):
+        """-> (sum_i E_i, dE_i/dmu_i, dE_i/dv_i) with E_i = pi^-1/2 sum_j w_j log p(y_i | sqrt(2 v_i) x_j + mu_i)."""
+        xs, ws = np.polynomial.hermite.hermgauss(int(n_points))
+        ws = ws / np.sqrt(np.pi)
+        sd = np.sqrt(var)
+        f = mu[None, :] + np.sqrt(2.0) * sd[None, :] * xs[:, None]
+        sum_e = float((ws[:, None] * self.logp(f, y[None, :])).sum())
+        if not want_grad:
+            return sum_e, None, None
+        if self.dlogp is None:
+            raise UnsupportedGradient("GenericLikelihood needs dlogp for gradients")
+        dl = self.dlogp(f, y[None, :])
+        return sum_e, (ws[:, None] * dl).sum(axis=0), (ws[:, None] * dl * xs[:, None]).sum(axis=0) / (np.sqrt(2.0) * sd)
+
+
+class UnsupportedGradient(RuntimeError):
+    pass
+
+
 @dataclass(eq=False)
 class LatentGP:
     f: GP

@@ -10,7 +10,7 @@ import numpy as np
 
 from . import _ffi
 from .gp import (DEFAULT_SIGMA2, BernoulliLikelihood, DefaultExpectationMethod, FiniteGP, GaussHermiteExpectation,
-                 GaussianLikelihood, LatentFiniteGP, MvNormal, NormalCDFLink, LogisticLink, PoissonLikelihood, ExponentialLikelihood,
+                 GaussianLikelihood, GenericLikelihood, LatentFiniteGP, MvNormal, NormalCDFLink, LogisticLink, PoissonLikelihood, ExponentialLikelihood,
                  GammaLikelihood, _as_dn)
 from .kernels import unpack_kernel
 
@@ -115,6 +115,8 @@ def elbo(sva: SparseVariationalApproximation, fx, y, *, num_data=None, quadratur
     if sva.fz.f is not lfx.fx.f:  # SVA:347-351
         raise ValueError("(Latent)FiniteGP prior is not consistent with SparseVariationalApproximation's")
     ctx = ctx or _ffi.default_context()
+    if isinstance(lfx.lik, GenericLikelihood):
+        return _elbo_host_likelihood(sva, lfx, y, num_data, quadrature, ctx, dtype, False)[0]
     desc, keep = _desc(sva, lfx.lik, quadrature, dtype)
     y = np.asarray(y)
     n = y.shape[0]
@@ -126,6 +128,30 @@ def elbo(sva: SparseVariationalApproximation, fx, y, *, num_data=None, quadratur
         model.free()
         data.free()
     return (val, terms) if return_terms else val
+
+
+def _elbo_host_likelihood(sva, lfx, y, num_data, quadrature, ctx, dtype, want_grad):
+    """The route of a likelihood outside the ABI's enumeration: marginals(f_post(x)) (SVA:354) from the device, SVA:355 on the
+    host, KL / backward pass on the device.  Value: E num_data / n - KL (SVA:357-359)."""
+    if quadrature is not None and not isinstance(quadrature, (GaussHermiteExpectation, DefaultExpectationMethod)):
+        raise _ffi.UnsupportedError(f"unsupported quadrature {quadrature!r}")
+    qn = int(quadrature.n) if isinstance(quadrature, GaussHermiteExpectation) else 20
+    desc, keep = _desc(sva, None, None, dtype)
+    y = np.asarray(y, dtype=np.float64)
+    n = y.shape[0]
+    data = _ffi.DeviceData(ctx, lfx.fx.x, None, _ffi.np_dtype(desc.dtype))
+    model = _ffi.DeviceModel(ctx, desc, keep)
+    try:
+        mu, var = model.marginals(data, 0, n)
+        sum_e, gmu, gv = lfx.lik.host_expectation(mu, var, y, qn, want_grad)
+        nd = float(num_data) if num_data is not None else float(n)
+        if not want_grad:
+            return sum_e * nd / n - model.prior_kl()[0], None
+        val, _, grads = model.elbo_grad(data, 0, n, nd, z_shape=np.asarray(sva.fz.x).shape, ext=(sum_e, gmu, gv))
+        return val, grads
+    finally:
+        model.free()
+        data.free()
 
 
 def elbo_and_gradient(sva: SparseVariationalApproximation, fx, y, *, num_data=None, quadrature=None, ctx=None, dtype=None):
@@ -141,6 +167,8 @@ def elbo_and_gradient(sva: SparseVariationalApproximation, fx, y, *, num_data=No
     if sva.fz.f is not lfx.fx.f:
         raise ValueError("(Latent)FiniteGP prior is not consistent with SparseVariationalApproximation's")
     ctx = ctx or _ffi.default_context()
+    if isinstance(lfx.lik, GenericLikelihood):
+        return _elbo_host_likelihood(sva, lfx, y, num_data, quadrature, ctx, dtype, True)
     desc, keep = _desc(sva, lfx.lik, quadrature, dtype)
     y = np.asarray(y)
     data = _ffi.DeviceData(ctx, lfx.fx.x, y, _ffi.np_dtype(desc.dtype))

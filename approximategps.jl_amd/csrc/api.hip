@@ -563,6 +563,7 @@ int32_t svgp_ctx_destroy(svgp_ctx* c) {
   if (c->ev_join) (void)hipEventDestroy(c->ev_join);
   if (c->stream2) { (void)hipStreamSynchronize(c->stream2); (void)hipStreamDestroy(c->stream2); }
   if (c->kuf_buf) (void)hipFree(c->kuf_buf);
+  if (c->ext_g) (void)hipFree(c->ext_g);
   if (c->gws) { c->gws->release(); delete c->gws; }
   for (auto& e : c->ev)
     if (e) (void)hipEventDestroy(e);
@@ -972,6 +973,9 @@ struct GradCall {
   double scale = 1.0, klw = 1.0, num_data = 0.0;
   bool collective = false, centered = false;
   int64_t len = 0;
+  // host-evaluated likelihood (svgp_elbo_grad_ext): per-point dE/dmu, dE/dv (host, fp64, [len] each) and the host's sum E
+  const double *ext_gmu = nullptr, *ext_gv = nullptr;
+  double ext_sum_e = 0.0;
 };
 
 int grad_enqueue(svgp_ctx* ctx, svgp_model* m, const svgp_data* data, int64_t off, int64_t len, GradCall& gc) {
@@ -1030,6 +1034,17 @@ int grad_enqueue(svgp_ctx* ctx, svgp_model* m, const svgp_data* data, int64_t of
   lp.clamp_neg_var = (m->desc.neg_var_policy == SVGP_NEGVAR_CLAMP);
   lp.mean_const = m->desc.mean_const;
   const KernelParams kp = kparams(m);
+  if (gc.ext_gmu) {   // the host's point gradients: one H2D copy of 2 x len doubles
+    if (size_t(len) > ctx->ext_cap) {
+      if (ctx->ext_g) (void)hipFree(ctx->ext_g);
+      ctx->ext_g = nullptr;
+      ctx->ext_cap = 0;
+      if (hipMalloc(&ctx->ext_g, 2 * size_t(len) * 8) != hipSuccess) return fail(ctx, SVGP_OOM, "hipMalloc failed for the point gradients");
+      ctx->ext_cap = size_t(len);
+    }
+    HIPC(ctx, hipMemcpyAsync(ctx->ext_g, gc.ext_gmu, size_t(len) * 8, hipMemcpyHostToDevice, s));
+    HIPC(ctx, hipMemcpyAsync(ctx->ext_g + ctx->ext_cap, gc.ext_gv, size_t(len) * 8, hipMemcpyHostToDevice, s));
+  }
   for (int64_t c0 = 0; c0 < len; c0 += nc) {
     const int64_t clen = (len - c0 < nc) ? len - c0 : nc;
     const int64_t ncp = (clen + 127) / 128 * 128;
@@ -1047,11 +1062,13 @@ int grad_enqueue(svgp_ctx* ctx, svgp_model* m, const svgp_data* data, int64_t of
     a.At_out = w->At; a.ldx = data->ldx; a.off = off + c0; a.len = clen; a.Mp = Mp; a.M = M; a.kp = kp;
     a.mean_const = m->desc.mean_const;
     a.R = w->Rcm; a.alpha = w->alpha; a.Pt_out = w->Pt; a.gmu_out = w->gmu; a.gv_out = w->gv; a.y = data->y;
+    LikParams lpc = lp;
+    if (gc.ext_gmu) { lpc.lik = kLikExternal; lpc.gh_x = ctx->ext_g + c0; lpc.gh_w = ctx->ext_g + ctx->ext_cap + c0; a.y = nullptr; }
     // A g_mu (the data part of m_bar): fp32 - per strip inside the strip kernel, so that kgrad streams P only; f64 - by kgrad
     // from A beside P as before (same-box three-way A/B, ms, value-and-gradient: H 97.8 -> 95.4 with the kgrad prefetch alone,
     // 99.0 with the in-strip form; H32 53.6 -> 53.0 -> 52.35; C5 16.25 -> 16.2 -> 15.9; C3 208.3 -> 217.2 -> 209.6)
     const bool a_in_strips = (dt == SVGP_F32);
-    a.part5 = w->partial5; a.apart = a_in_strips ? w->apart : nullptr; a.lp = lp; a.scale = scale; a.n_global_dev = n_global_dev; a.num_data = gc.num_data;
+    a.part5 = w->partial5; a.apart = a_in_strips ? w->apart : nullptr; a.lp = lpc; a.scale = scale; a.n_global_dev = n_global_dev; a.num_data = gc.num_data;
     HIPC(ctx, hipMemsetAsync(ctx->counter, 0, sizeof(unsigned), s));
     launch_strip_grad(dt, s, a, nt, grid, nstrips);
     KCHECK(ctx, "strip (value and gradient)");
@@ -1080,6 +1097,7 @@ int grad_enqueue(svgp_ctx* ctx, svgp_model* m, const svgp_data* data, int64_t of
     KCHECK(ctx, "syrk");
     if (kg_overlap) HIPC(ctx, hipStreamWaitEvent(s, ctx->ev_join, 0));
   }
+  if (gc.ext_gmu) launch_add_f64(s, w->sums, gc.ext_sum_e);   // sums[0] = sum E: the host's, before any collective
   HIPC(ctx, hipEventRecord(ctx->ev[2], s));
   // M-sized tail.  With W = A diag(2 g_v) A' and a = A g_mu:
   //   Lq_bar = tril(W B) - klw dKL/dB,   Lk_bar = -tril(alpha a' + R W)     (B = Lq whitened; W, R carry the factors 2)
@@ -1248,13 +1266,15 @@ int grad_finish(svgp_ctx* ctx, svgp_model* m, GradCall& gc, double* elbo_out, sv
 }
 
 int elbo_grad_impl(svgp_ctx* ctx, svgp_model* m, const svgp_data* data, int64_t off, int64_t len, double scale, double klw,
-                   double num_data, bool collective, double* elbo_out, svgp_terms* terms_out, svgp_grads* g) {
+                   double num_data, bool collective, double* elbo_out, svgp_terms* terms_out, svgp_grads* g,
+                   const double* ext_gmu = nullptr, const double* ext_gv = nullptr, double ext_sum_e = 0.0) {
   GradCall gc;
+  gc.ext_gmu = ext_gmu; gc.ext_gv = ext_gv; gc.ext_sum_e = ext_sum_e;
   gc.collective = collective && ctx && ctx->comm;
   gc.scale = scale;
   gc.klw = gc.collective ? 1.0 / double(ctx->world) : klw;
   gc.num_data = num_data;
-  int rc = check_batch(ctx, m, data, off, len, true);
+  int rc = check_batch(ctx, m, data, off, len, ext_gmu == nullptr);   // a host-evaluated likelihood needs no y on the device
   if (rc == SVGP_OK && !g) rc = fail(ctx, SVGP_INVALID_ARG, "null gradient output");
   if (rc == SVGP_OK && (!(scale > 0.0) || !(klw >= 0.0))) rc = fail(ctx, SVGP_INVALID_ARG, "scale must be positive and kl_weight non-negative");
   if (rc == SVGP_OK && hipSetDevice(ctx->device) != hipSuccess) rc = fail(ctx, SVGP_HIP_ERROR, "hipSetDevice failed");
@@ -1282,6 +1302,71 @@ extern "C" int32_t svgp_elbo_grad_shard(svgp_ctx* ctx, svgp_model* m, const svgp
                                         double scale, double kl_weight, double* value_out, svgp_terms* terms_out,
                                         svgp_grads* g) {
   return elbo_grad_impl(ctx, m, data, off, len, scale, kl_weight, 0.0, false, value_out, terms_out, g);
+}
+
+// ---- likelihoods the ABI does not enumerate ("generic GH for user link functions") -------------------
+// The M^2 N work does not depend on the likelihood: only (mu_i, v_i) -> E_i does, and that is O(N) scalar work the host can do
+// with ANY single-latent GPLikelihoods likelihood and quadrature.  svgp_marginals hands the host marginals(f_post(x)) of
+// SVA:354; the host evaluates expected_loglikelihood (SVA:355) and, for training, its derivatives w.r.t. (mu_i, v_i);
+// svgp_elbo_grad_ext runs the same backward pass as svgp_elbo_grad with those point gradients in place of lik.hpp's.
+extern "C" int32_t svgp_marginals(svgp_ctx* ctx, svgp_model* m, const svgp_data* data, int64_t off, int64_t len,
+                                  double* mean_out, double* var_out) {
+  int rc = check_batch(ctx, m, data, off, len, false);
+  if (rc) return rc;
+  if (!mean_out || !var_out) return fail(ctx, SVGP_INVALID_ARG, "null output");
+  hipStream_t s = ctx->stream;
+  HIPC(ctx, hipSetDevice(ctx->device));
+  HIPC(ctx, hipEventRecord(ctx->ev[0], s));
+  rc = enqueue_prep(ctx, m);
+  if (rc) return rc;
+  HIPC(ctx, hipEventRecord(ctx->ev[1], s));
+  StripOuts so;
+  so.skip_expect = true;
+  rc = enqueue_strips(ctx, m, data->x, data->ldx, nullptr, off, len, so);
+  if (rc) return rc;
+  PrepScalars ps;
+  HIPC(ctx, hipMemcpyAsync(mean_out, ctx->mom, size_t(len) * 8, hipMemcpyDeviceToHost, s));
+  HIPC(ctx, hipMemcpyAsync(var_out, ctx->mom + ctx->mom_cap, size_t(len) * 8, hipMemcpyDeviceToHost, s));
+  HIPC(ctx, hipMemcpyAsync(ps.scal, m->scal, sizeof(ps.scal), hipMemcpyDeviceToHost, s));
+  HIPC(ctx, hipMemcpyAsync(&ps.info, m->info, sizeof(int), hipMemcpyDeviceToHost, s));
+  HIPC(ctx, hipStreamSynchronize(s));
+  finish_prep(m, ps);
+  float t01 = 0, t12 = 0;
+  (void)hipEventElapsedTime(&t01, ctx->ev[0], ctx->ev[1]);
+  (void)hipEventElapsedTime(&t12, ctx->ev[1], ctx->ev[2]);
+  ctx->timing = svgp_timing{};
+  ctx->timing.ms_prep = t01;
+  ctx->timing.ms_strip = t12;
+  ctx->timing.ms_total = t01 + t12;
+  double nneg = 0;
+  const bool clamp = m->desc.neg_var_policy == SVGP_NEGVAR_CLAMP;
+  for (int64_t i = 0; i < len; ++i) {   // FiniteGP(f_post, x, 1e-18): the variance the reference's marginals() hold
+    double v = var_out[i] + kDefaultSigma2;
+    if (v < 0.0) { nneg += 1; if (clamp) v = 0.0; }
+    var_out[i] = v;
+  }
+  return status_of(ctx, m, nneg);
+}
+
+// Value and gradient of  scale sum_e - kl_weight KL  with (dE_i/dmu_i, dE_i/dv_i) = (g_mu[i], g_v[i]) supplied by the host
+// (fp64, unscaled, one per point of the batch), scale = num_data / len.  Everything else - outputs, statuses, the collective
+// form on a context with a communicator (sum_e and the gradients are then this rank's shard's) - is svgp_elbo_grad's;
+// grads->lik_sigma2 is 0 (the likelihood's own parameters are the host's).
+extern "C" int32_t svgp_elbo_grad_ext(svgp_ctx* ctx, svgp_model* m, const svgp_data* data, int64_t off, int64_t len,
+                                      double num_data, double sum_e, const double* g_mu, const double* g_v,
+                                      double* elbo_out, svgp_terms* terms_out, svgp_grads* g) {
+  if (!ctx) return SVGP_INVALID_ARG;
+  if (!g_mu || !g_v) {
+    int rc = fail(ctx, SVGP_INVALID_ARG, "null point gradients");
+    if (ctx->comm) {   // keep the peers' opening handshake matched: they return SVGP_RCCL_ERROR instead of waiting
+      GradCall gc;
+      gc.collective = true;
+      rc = grad_handshake(ctx, gc, len, rc);
+    }
+    return rc;
+  }
+  const double scale = len >= 1 ? (num_data > 0 ? num_data : double(len)) / double(len) : 1.0;
+  return elbo_grad_impl(ctx, m, data, off, len, scale, 1.0, num_data, true, elbo_out, terms_out, g, g_mu, g_v, sum_e);
 }
 
 // ================================================================================================

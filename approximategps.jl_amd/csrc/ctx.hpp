@@ -30,6 +30,7 @@ struct svgp_ctx {
   unsigned* counter2 = nullptr;
   void* work2 = nullptr;      size_t work2_bytes = 0;
   void* kuf_buf = nullptr;    size_t kuf_bytes = 0;
+  double* ext_g = nullptr;    size_t ext_cap = 0;           // [2][ext_cap] point gradients of a host-evaluated likelihood
   struct GradWs* gws = nullptr;  // gradient workspace, cached by problem shape
   // data-parallel communicator (comm.hip): one RCCL rank per context; world == 1 without one
   void* comm = nullptr;        // ncclComm_t

@@ -805,6 +805,9 @@ void launch_rm_tril_to_user(int dtype, hipStream_t s, const void* R, int64_t Mp,
   GD(dtype, T, hipLaunchKernelGGL(rm_tril_to_user_kernel<T>, grid, dim3(256), 0, s, (const T*)R, Mp, M, (T*)out));
 }
 
+__global__ void add_f64_kernel(double* p, double v) { *p += v; }
+void launch_add_f64(hipStream_t s, double* p, double v) { hipLaunchKernelGGL(add_f64_kernel, dim3(1), dim3(1), 0, s, p, v); }
+
 void launch_finish_kgrad(int dtype, hipStream_t s, int d, int64_t M, int64_t Mp, const void* zs, const double* invl,
                          const double* rp_uf, int ns_uf, const double* rp_uu, int ns_uu, const double* sp_uf, int nsp_uf,
                          const double* sp_uu, int nsp_uu, const void* m, double klw, int layout_z, double variance,

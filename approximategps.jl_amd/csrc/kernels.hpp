@@ -13,8 +13,10 @@ struct KernelParams {
   const void* invl;  // [d] inverse lengthscales, compute dtype
 };
 
+constexpr int kLikExternal = -1;
 struct LikParams {
-  int lik;            // SVGP_LIK_*
+  int lik;            // SVGP_LIK_*, or kLikExternal: a likelihood the host evaluated (svgp_elbo_grad_ext) - gh_x / gh_w then hold
+                      // the chunk's point gradients dE_i/dmu_i / dE_i/dv_i (unscaled), indexed by the point's position in the chunk
   int gh_n;           // 0 = closed form
   double sigma2;      // likelihood parameter: Gaussian sigma^2, Gamma shape alpha (1 otherwise)
   double digamma_alpha;  // digamma(alpha) for the Gamma likelihood's parameter gradient
@@ -170,6 +172,7 @@ void launch_mbar(int dtype, hipStream_t s, const double* rp_uf, int ns, int64_t 
                  int64_t Mp, void* vec);
 void launch_lbar_adjust(int dtype, hipStream_t s, void* LkbarRM, const void* RBt, const void* rbar, const void* mt, int64_t Mp);
 void launch_rm_tril_to_user(int dtype, hipStream_t s, const void* R, int64_t Mp, int64_t M, void* out);
+void launch_add_f64(hipStream_t s, double* p, double v);   // *p += v
 void launch_finish_kgrad(int dtype, hipStream_t s, int d, int64_t M, int64_t Mp, const void* zs, const double* invl,
                          const double* rp_uf, int ns_uf, const double* rp_uu, int ns_uu, const double* sp_uf, int nsp_uf,
                          const double* sp_uu, int nsp_uu, const void* m, double klw, int layout_z, double variance,

@@ -163,7 +163,7 @@ __device__ __noinline__ PointGrads strip_point_grads(LikParams lp, double mu, do
 // Lq (Lq'A) - A and Lk' \ . folded into a precomputed M x M matrix: same flops, no dependence on C, no trip of A / C /
 // Abar through HBM as k-major matrices).  Outputs: A and P point-major (for the products contracted over points: the
 // SYRK W = A diag(g_v) A' and the kernel-gradient reductions), g_mu, g_v, and five per-strip sums.
-template <typename T, int NT, int BK, int NTHR, int MINW = 2, int PAD = 16, bool GRAD = false>
+template <typename T, int NT, int BK, int NTHR, int MINW = 2, int PAD = 16, bool GRAD = false, bool EXT = false>
 __global__ void __launch_bounds__(NTHR, MINW) strip_kernel(StripArgs a, int64_t nstrips) {
   using G = TileGemm<T, NT, BK, NTHR, PAD>;
   using Acc = typename G::Acc;
@@ -403,7 +403,12 @@ __global__ void __launch_bounds__(NTHR, MINW) strip_kernel(StripArgs a, int64_t 
           e5[4] = 1.0;
           if (a.lp.clamp_neg_var) { v = 0.0; bad = false; }
         }
-        if (!bad) {
+        if constexpr (EXT) {   // svgp_elbo_grad_ext: the host evaluated the likelihood on svgp_marginals; its point gradients
+          if (!bad) {          // come in through gh_x / gh_w (kernels.hpp kLikExternal), E is the host's
+            e5[1] = gm = a.lp.gh_x[c0 + tid] * scale;
+            e5[2] = gvv = a.lp.gh_w[c0 + tid] * scale;
+          }
+        } else if (!bad) {
           const double yv = double(static_cast<const T*>(a.y)[a.off + c0 + tid]);
           const PointGrads pg = strip_point_grads(a.lp, mu, v, yv, scale);
           e5[0] = pg.e; e5[1] = gm = pg.gmu; e5[2] = gvv = pg.gv; e5[3] = pg.gs2;
@@ -828,14 +833,14 @@ __global__ void __launch_bounds__(512, 2) kuf_cols_kernel(KernelParams kp, const
   }
 }
 
-template <typename T, int NT, int BK, int NTHR, int MINW = 2, int PAD = 16, bool GRAD = false>
+template <typename T, int NT, int BK, int NTHR, int MINW = 2, int PAD = 16, bool GRAD = false, bool EXT = false>
 void launch_strip_t(hipStream_t s, const StripArgs& a, int grid, int64_t nstrips) {
   using G = TileGemm<T, NT, BK, NTHR, PAD>;
   // the strip's x image (<= 32 feature rows) aliases the staging buffers
   const size_t lds = (SVGP_ASYNC && G::kAsync) ? G::ASYNC_LDS_BYTES : G::LDS_BYTES;
   static_assert(G::LDS_BYTES >= size_t(32) * NT * sizeof(T), "x image must fit the staging buffers");
   static_assert(G::LDS_BYTES >= size_t(5) * NT * sizeof(double), "the five per-strip sums reuse the staging buffers");
-  auto kern = strip_kernel<T, NT, BK, NTHR, MINW, PAD, GRAD>;
+  auto kern = strip_kernel<T, NT, BK, NTHR, MINW, PAD, GRAD, EXT>;
   set_max_lds(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
   hipLaunchKernelGGL(kern, dim3(grid), dim3(NTHR), lds, s, a, nstrips);
 }
@@ -945,6 +950,17 @@ void launch_strip(int dtype, hipStream_t s, const StripArgs& a, int nt, int grid
 }
 
 void launch_strip_grad(int dtype, hipStream_t s, const StripArgs& a, int nt, int grid, int64_t nstrips) {
+  if (a.lp.lik == kLikExternal) {   // the host-evaluated-likelihood build: a separate instantiation, so the enumerated one
+    if (dtype == 0) {               // is bit for bit the kernel it was (its register allocation is that sensitive)
+      if (nt == 32) launch_strip_t<double, 32, 16, 256, 2, 16, true, true>(s, a, grid, nstrips);
+      else launch_strip_t<double, 64, 16, 256, 2, 16, true, true>(s, a, grid, nstrips);
+    } else {
+      if (nt == 32) launch_strip_t<float, 32, 16, 256, 2, 16, true, true>(s, a, grid, nstrips);
+      else if (nt == 64) launch_strip_t<float, 64, 16, 256, 2, 16, true, true>(s, a, grid, nstrips);
+      else launch_strip_t<float, 128, 16, 256, 2, 16, true, true>(s, a, grid, nstrips);
+    }
+    return;
+  }
   if (dtype == 0) {
     if (nt == 32) launch_strip_t<double, 32, 16, 256, 2, 16, true>(s, a, grid, nstrips);
     else launch_strip_t<double, 64, 16, 256, 2, 16, true>(s, a, grid, nstrips);

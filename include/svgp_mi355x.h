@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define SVGP_ABI_VERSION 2
+#define SVGP_ABI_VERSION 3 /* 3 = 2 + svgp_marginals, svgp_elbo_grad_ext, SVGP_LIK_BERNOULLI_NORMCDF (additions only: v2 callers keep working) */
 
 /* status codes -> Julia exceptions raised by the shim */
 enum {
@@ -230,6 +230,25 @@ int32_t svgp_group_elbo_grad(svgp_group* group, svgp_model* const* models, const
 int32_t svgp_elbo_grad_shard(svgp_ctx* ctx, svgp_model* model, const svgp_data* data, int64_t batch_off, int64_t batch_len,
                              double scale, double kl_weight, double* value_out, svgp_terms* terms_out,
                              svgp_grads* grads_out);
+
+/* ---- any other single-latent likelihood: the host evaluates it on the device-computed marginals ----------------
+ * (SURVEY 8 f4 "generic GH for user link functions".)  Only SVA:355, expected_loglikelihood(quadrature, lik, q_f, y),
+ * depends on the likelihood, and it is O(n) scalar work; everything O(M^2 n) is likelihood-free.  So for a likelihood
+ * the SVGP_LIK_* codes do not enumerate the binding keeps the reference's own GPLikelihoods call and gives it the
+ * device's marginals:
+ *   svgp_marginals        replaces marginals(f_post(x)) of SVA:354: mean_out[i] = mu_i, var_out[i] = v_i + 1e-18
+ *                         (fp64, batch_len each; host); SVGP_NEG_VARIANCE / clamping per neg_var_policy.  Needs no y.
+ *   svgp_elbo_grad_ext    value and gradient of  (num_data / batch_len) * sum_e - KL  where the host passes
+ *                         sum_e = sum_i E_i and g_mu[i] = dE_i/dmu_i, g_v[i] = dE_i/dv_i (fp64, unscaled, host): the
+ *                         same backward pass as svgp_elbo_grad with these in place of the built-in likelihood's;
+ *                         grads_out->lik_sigma2 = 0 (the likelihood's own parameters are the host's to differentiate).
+ *                         On a context with a communicator it is collective exactly like svgp_elbo_grad (sum_e and the
+ *                         point gradients are then this rank's shard's). */
+int32_t svgp_marginals(svgp_ctx* ctx, svgp_model* model, const svgp_data* data, int64_t batch_off, int64_t batch_len,
+                       double* mean_out, double* var_out);
+int32_t svgp_elbo_grad_ext(svgp_ctx* ctx, svgp_model* model, const svgp_data* data, int64_t batch_off, int64_t batch_len,
+                           double num_data, double sum_e, const double* g_mu, const double* g_v, double* elbo_out,
+                           svgp_terms* terms_out, svgp_grads* grads_out);
 
 /* ---- posterior(sva)  replaces SVA:115-136 (Centered) / SVA:160-187 (NonCentered) -------------
  * fills ApproxPosteriorGP.data = (Kuu = Cholesky(Lk), B, α): Lk_out M×M lower (upper zeroed),

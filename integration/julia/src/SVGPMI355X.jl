@@ -174,7 +174,11 @@ isotropic_jitter(::Any) = nothing
 struct Packed{T}
     invl::Vector{Float64}; Z::Array{T}; m::Vector{T}; Lq::Matrix{T}
     desc::ModelDesc
+    ext::Bool        # likelihood not enumerated by the ABI: evaluated HERE on the device marginals (svgp_marginals / svgp_elbo_grad_ext)
 end
+
+# Any single-latent GPLikelihoods likelihood can take the host-evaluated route; the two multi-latent ones cannot.
+ext_ok(l) = l isa GPLikelihoods.AbstractLikelihood && !(l isa CategoricalLikelihood) && !(l isa HeteroscedasticGaussianLikelihood)
 
 compute_type(::Type{Float32}) = Float32
 compute_type(::Type{Float64}) = Float64
@@ -190,9 +194,12 @@ function pack(sva::SparseVariationalApproximation{P}, lik, quadrature, ::Type{T}
     ku = unpack_kernel(sva.fz.f.kernel, d)
     c = unpack_mean(sva.fz.f.mean)
     lk = unpack_lik(lik)
+    ext = lk === nothing
+    ext && !ext_ok(lik) && throw(Unsupported())
+    ext && (lk = (Int32(0), 1.0, true))        # the descriptor's likelihood slot is unused on the host-evaluated route
     jit = isotropic_jitter(sva.fz.Σy)
-    (ku === nothing || c === nothing || lk === nothing || jit === nothing) && throw(Unsupported())
-    qn = quad_n(quadrature, lk[3])
+    (ku === nothing || c === nothing || jit === nothing) && throw(Unsupported())
+    qn = ext ? Int32(0) : quad_n(quadrature, lk[3])
     qn === nothing && throw(Unsupported())
     fam, σ², invl = ku
     m = Vector{T}(mean(sva.q))
@@ -200,7 +207,7 @@ function pack(sva::SparseVariationalApproximation{P}, lik, quadrature, ::Type{T}
     Zd = Array{T}(Z)
     desc = ModelDesc(T === Float64 ? 0 : 1, fam, P === Centered ? 1 : 0, lk[1], qn, lz, 0, d, length(m), σ²,
                      pointer(invl), c, jit, lk[2], pointer(Zd), pointer(m), pointer(Lq))
-    return Packed{T}(invl, Zd, m, Lq, desc)
+    return Packed{T}(invl, Zd, m, Lq, desc, ext)
 end
 
 # ---------------------------------------------------------------------------------------------------------
@@ -218,14 +225,27 @@ function MI355XHooks.try_elbo(sva::SparseVariationalApproximation, lfx, y::Abstr
     return r === nothing ? nothing : r[1]
 end
 
-# value (and, if `want`, the raw gradient blocks) or `nothing`
-function elbo_and_grads(sva, lfx, y, num_data, quadrature, want::Bool)
+# The likelihood-dependent step of SVA:355 kept in Julia: E = expected_loglikelihood(quadrature, lik, marginals, y) on the
+# device's marginals and, under AD (`config` = the caller's RuleConfig), its pullback w.r.t. (lik, mu, v).
+function host_expectation(config, quadrature, lik, μ::Vector{Float64}, v::Vector{Float64}, y)
+    E(l, a, b) = expected_loglikelihood(quadrature, l, Normal.(a, sqrt.(b)), y)      # SVA:354-355
+    config === nothing && return sum(E(lik, μ, v)), nothing
+    val, back = rrule_via_ad(config, E, lik, μ, v)
+    _, Δlik, gμ, gv = back(one(val))
+    return val, (Δlik, collect(Float64, unthunk(gμ)), collect(Float64, unthunk(gv)))
+end
+
+# value (and, if `want`, the raw gradient blocks) or `nothing`; `config`: the AD rule configuration (host-evaluated route only)
+function elbo_and_grads(sva, lfx, y, num_data, quadrature, want::Bool, config=nothing)
     (ENABLED[] && available()) || return nothing
-    T = compute_type(eltype(y))
-    T === nothing && return nothing
     lay = layout(lfx.fx.x)
     lay === nothing && return nothing
     lx, X, dx = lay
+    # the compute type is the inputs' / parameters' float type; the observations only have to convert to it (Bool labels
+    # of a Bernoulli likelihood and Int counts of a Poisson one - examples/b-classification/script.jl:58 - are the normal case)
+    eltype(y) <: Real || return nothing
+    T = compute_type(promote_type(eltype(X), eltype(mean(sva.q))))
+    T === nothing && return nothing
     local p
     try
         p = pack(sva, lfx.lik, quadrature, T)
@@ -241,8 +261,40 @@ function elbo_and_grads(sva, lfx, y, num_data, quadrature, want::Bool)
     gl, gz, gm, gLq = zeros(Float64, d), similar(p.Z), similar(p.m), similar(p.Lq)
     g = Grads(0, 0, 0, pointer(gl), pointer(gz), pointer(gm), pointer(gLq))
     st = Int32(0)
+    Δlik = nothing
     GC.@preserve p Xd yd gl gz gm gLq begin
-        if !want
+        if p.ext
+            # host-evaluated likelihood: marginals from the device, SVA:355 here, the backward pass on the device again
+            want && config === nothing && return nothing
+            hm, hd = Ref{Ptr{Cvoid}}(C_NULL), Ref{Ptr{Cvoid}}(C_NULL)
+            μ, v = zeros(Float64, n), zeros(Float64, n)
+            st = ccall((:svgp_model_create, lib), Int32, (Ptr{Cvoid}, Ref{ModelDesc}, Ptr{Ptr{Cvoid}}), ctx(), p.desc, hm)
+            if st == 0
+                st = ccall((:svgp_data_upload, lib), Int32,
+                           (Ptr{Cvoid}, Int32, Int32, Int32, Int64, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Ptr{Cvoid}}),
+                           ctx(), p.desc.dtype, lx, p.desc.d, n, Xd, C_NULL, hd)
+            end
+            if st == 0
+                st = ccall((:svgp_marginals, lib), Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64, Ptr{Float64}, Ptr{Float64}),
+                           ctx(), hm[], hd[], 0, n, μ, v)
+            end
+            if st == 0
+                sumE, pb = host_expectation(want ? config : nothing, quadrature, lfx.lik, μ, v, y)
+                if want
+                    Δlik, gμ, gv = pb
+                    st = ccall((:svgp_elbo_grad_ext, lib), Int32,
+                               (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64, Float64, Float64, Ptr{Float64}, Ptr{Float64},
+                                Ref{Float64}, Ref{Terms}, Ref{Grads}),
+                               ctx(), hm[], hd[], 0, n, Float64(num_data), Float64(sumE), gμ, gv, out, terms, g)
+                else
+                    kl = Ref{Float64}()
+                    st = ccall((:svgp_prior_kl, lib), Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Ref{Float64}, Ptr{Float64}), ctx(), hm[], kl, C_NULL)
+                    out[] = sumE * Float64(num_data) / n - kl[]                       # SVA:357-359
+                end
+            end
+            ccall((:svgp_data_free, lib), Int32, (Ptr{Cvoid}, Ptr{Cvoid}), ctx(), hd[])
+            ccall((:svgp_model_free, lib), Int32, (Ptr{Cvoid}, Ptr{Cvoid}), ctx(), hm[])
+        elseif !want
             # one-shot entry point: uploads x, y, evaluates, frees (resident handles below avoid the upload in loops)
             st = ccall((:svgp_elbo_host, lib), Int32,
                        (Ptr{Cvoid}, Ref{ModelDesc}, Int32, Int64, Ptr{Cvoid}, Ptr{Cvoid}, Float64, Ref{Float64}, Ref{Terms}),
@@ -266,7 +318,8 @@ function elbo_and_grads(sva, lfx, y, num_data, quadrature, want::Bool)
     end
     st == 4 && return nothing            # SVGP_UNSUPPORTED: decline
     check(st, terms)
-    return out[], (σ²=g.variance, invl=gl, z=gz, m=gm, Lq=gLq, lik=g.lik_sigma2, c=g.mean_const)
+    # `Δlik`: the likelihood's own tangent from the host pullback (host-evaluated route), to be scaled by num_data / n
+    return out[], (σ²=g.variance, invl=gl, z=gz, m=gm, Lq=gLq, lik=g.lik_sigma2, c=g.mean_const, Δlik=Δlik, scale=Float64(num_data) / n)
 end
 
 # ---- structural tangents -------------------------------------------------------------------------------------------
@@ -307,11 +360,12 @@ function lik_tangent(l, glik)
     return NoTangent()
 end
 
-function ChainRulesCore.rrule(::typeof(MI355XHooks.try_elbo), sva::SparseVariationalApproximation, lfx, y::AbstractVector, num_data, quadrature)
+function ChainRulesCore.rrule(config::RuleConfig{>:HasReverseMode}, ::typeof(MI355XHooks.try_elbo), sva::SparseVariationalApproximation, lfx,
+                              y::AbstractVector, num_data, quadrature)
     zero5 = (NoTangent(), NoTangent(), NoTangent(), NoTangent(), NoTangent(), NoTangent())
     decline = (nothing, _ -> zero5)
     sva.q isa MvNormal && sva.q.Σ isa PDMat || return decline       # the tangent of cov(q) is only defined for a stored factor
-    r = elbo_and_grads(sva, lfx, y, num_data, quadrature, true)
+    r = elbo_and_grads(sva, lfx, y, num_data, quadrature, true, config)
     r === nothing && return decline
     val, g = r
     function try_elbo_pullback(Δ)
@@ -322,7 +376,7 @@ function ChainRulesCore.rrule(::typeof(MI355XHooks.try_elbo), sva::SparseVariati
         Δfz = Tangent{typeof(sva.fz)}(; f=Δf, x=inputs_tangent(sva.fz.x, s(g.z)))      # Σy (jitter): not differentiated
         Δsva = Tangent{typeof(sva)}(; fz=Δfz, q=q_tangent(sva.q, s(g.m), s(g.Lq)))
         # the prior of lfx is the SAME object (SVA:347-351), its tangent is already on sva.fz.f; data inputs: none
-        Δlfx = Tangent{typeof(lfx)}(; lik=lik_tangent(lfx.lik, Δ * g.lik))
+        Δlfx = Tangent{typeof(lfx)}(; lik=g.Δlik === nothing ? lik_tangent(lfx.lik, Δ * g.lik) : (Δ * g.scale) * g.Δlik)
         return (NoTangent(), Δsva, Δlfx, NoTangent(), NoTangent(), NoTangent())
     end
     return val, try_elbo_pullback

@@ -7,13 +7,14 @@
 using Test, Random, LinearAlgebra
 using ApproximateGPs, AbstractGPs, KernelFunctions, GPLikelihoods, Distributions, Zygote
 using PDMats: PDMat
+using StatsFuns: normcdf
 const MI = ApproximateGPs.SVGPMI355X
 
 @testset "struct layouts = include/svgp_mi355x.h = approxgp/_ffi.py" begin
     @test sizeof(MI.ModelDesc) == 104 && fieldoffset(MI.ModelDesc, 9) == 32 && fieldoffset(MI.ModelDesc, 17) == 96
     @test sizeof(MI.Terms) == 64 && fieldoffset(MI.Terms, 8) == 56
     @test sizeof(MI.Grads) == 56 && fieldoffset(MI.Grads, 4) == 24
-    @test ccall((:svgp_version, MI.lib), Int32, ()) == 2
+    @test ccall((:svgp_version, MI.lib), Int32, ()) == 3
 end
 
 on(f) = (MI.enable!(true); f())
@@ -52,6 +53,31 @@ end
         @test on(() -> elbo(sva, f(x, T(0.3)), y)) ≈ off(() -> elbo(sva, f(x, T(0.3)), y)) rtol = rtol   # SVA:307-317 wrapper
     @test on(() -> elbo(sva, lfx, y; quadrature=GaussHermiteExpectation(13))) ≈
           off(() -> elbo(sva, lfx, y; quadrature=GaussHermiteExpectation(13))) rtol = rtol
+end
+
+@testset "other links and host-evaluated likelihoods ($T)" for T in (Float64, Float32)
+    rng = MersenneTwister(5)
+    rtol = T === Float64 ? 1e-8 : 1e-4
+    x, y, θ, build, _ = problem(rng, T; lik=BernoulliLikelihood(), base=Matern32Kernel())
+    f, sva = build(θ)
+    # Bool labels (examples/b-classification/script.jl:58) and the normcdf link (examples/c-comparisons/script.jl:33-34): code 5
+    for lik in (BernoulliLikelihood(), BernoulliLikelihood(normcdf)), yy in (y, y .> 0.5)
+        lfx = LatentGP(f, lik, 1e-18)(x)
+        @test on(() -> elbo(sva, lfx, yy; num_data=999)) ≈ off(() -> elbo(sva, lfx, yy; num_data=999)) rtol = rtol
+    end
+    # a likelihood the ABI does not enumerate (Poisson with a non-exp link): svgp_marginals -> GPLikelihoods here -> value;
+    # under Zygote: rrule_via_ad of expected_loglikelihood -> svgp_elbo_grad_ext
+    lik = PoissonLikelihood(x -> log1p(exp(x)))
+    yc = floor.(3 .* rand(rng, T, length(y)))
+    @test MI.unpack_lik(lik) === nothing && MI.ext_ok(lik)
+    lfx = LatentGP(f, lik, 1e-18)(x)
+    @test on(() -> elbo(sva, lfx, yc; num_data=999)) ≈ off(() -> elbo(sva, lfx, yc; num_data=999)) rtol = rtol
+    loss(θ) = (fs = build(θ); -elbo(fs[2], LatentGP(fs[1], lik, 1e-18)(x), yc; num_data=2000))
+    gd = on(() -> Zygote.gradient(loss, θ)[1]); gr = off(() -> Zygote.gradient(loss, θ)[1])
+    tol = T === Float64 ? 1e-6 : 3e-3
+    for k in (:var, :invl, :Z, :m)
+        @test maximum(abs.(getfield(gd, k) .- getfield(gr, k))) <= tol * max(maximum(abs.(getfield(gr, k))), 1e-9)
+    end
 end
 
 @testset "Zygote through elbo: device rrule == Zygote on the reference body ($T, centered = $cen)" for T in (Float64, Float32), cen in (false, true)

@@ -589,6 +589,11 @@ def expected_loglik_grads(lik, mu, v, y, sigma2=1.0, quadrature_n=0):
     return gmu, gv, gs2
 
 
+def elbo_grad_from_point_grads(sva: SVA, x, sum_e, gmu, gv, num_data=None, kl_weight=1.0):
+    """elbo_grad for a likelihood the caller evaluated itself on marginals(f_post(x)): see `point_grads` there."""
+    return elbo_grad(sva, x, None, num_data=num_data, kl_weight=kl_weight, point_grads=(sum_e, gmu, gv))
+
+
 def chol_backward(L: np.ndarray, Lbar: np.ndarray) -> np.ndarray:
     """Adjoint of L = chol(K): symmetric Kbar with <Kbar, dK> = <Lbar, dL> for symmetric dK (Murray 2016)."""
     Phi = np.tril(L.T @ np.tril(Lbar))
@@ -597,7 +602,7 @@ def chol_backward(L: np.ndarray, Lbar: np.ndarray) -> np.ndarray:
     return 0.5 * (S + S.T)
 
 
-def elbo_grad(sva: SVA, x, y, lik=LIK_GAUSSIAN, sigma2=1.0, num_data=None, quadrature_n=0, kl_weight=1.0):
+def elbo_grad(sva: SVA, x, y, lik=LIK_GAUSSIAN, sigma2=1.0, num_data=None, quadrature_n=0, kl_weight=1.0, point_grads=None):
     """-> (elbo, dict of gradients w.r.t. variance, inv_lengthscale[d], z[d,M], m[M], Lq[M,M] lower, lik_sigma2, mean_const).
 
     Centered: with m~ = Lk \\ (m - c), B = Lk \\ Lq the ELBO equals the NonCentered one evaluated at (m~, B) (the KL
@@ -605,9 +610,12 @@ def elbo_grad(sva: SVA, x, y, lik=LIK_GAUSSIAN, sigma2=1.0, num_data=None, quadr
     m_bar = Lk^-T m~_bar, Lq_bar = tril(Lk^-T B_bar), Lk_bar -= tril(m_bar m~') + tril((Lk^-T B_bar) B'), c_bar -= sum(m_bar).
 
     kl_weight: value = E * num_data / n - kl_weight * KL (a data-parallel shard uses 1 / world_size, so that a plain sum
-    over ranks is the global ELBO and gradient)."""
+    over ranks is the global ELBO and gradient).
+
+    point_grads = (sum_e, dE_i/dmu_i, dE_i/dv_i): a likelihood evaluated by the caller on the marginals (the test counterpart
+    of svgp_elbo_grad_ext); `y`, `lik`, `sigma2` and `quadrature_n` are then unused and lik_sigma2's gradient is 0."""
     x = _as_dn(np.asarray(x, dtype=np.float64))
-    y = np.asarray(y, dtype=np.float64)
+    y = None if y is None else np.asarray(y, dtype=np.float64)
     k = sva.kernel
     il = k.inv_lengthscale
     z = sva.z.astype(np.float64)
@@ -627,8 +635,11 @@ def elbo_grad(sva: SVA, x, y, lik=LIK_GAUSSIAN, sigma2=1.0, num_data=None, quadr
     C = Lq.T @ A
     mu = sva.mean_const + A.T @ m
     v = k.variance - np.sum(A * A, 0) + np.sum(C * C, 0) + DEFAULT_SIGMA2
-    E = expected_loglik(lik, mu, np.sqrt(v), y, sigma2, quadrature_n)
-    gmu, gv, gs2 = expected_loglik_grads(lik, mu, v, y, sigma2, quadrature_n)
+    if point_grads is not None:
+        E, gmu, gv, gs2 = float(point_grads[0]), np.asarray(point_grads[1], dtype=np.float64), np.asarray(point_grads[2], dtype=np.float64), 0.0
+    else:
+        E = expected_loglik(lik, mu, np.sqrt(v), y, sigma2, quadrature_n)
+        gmu, gv, gs2 = expected_loglik_grads(lik, mu, v, y, sigma2, quadrature_n)
     gmu, gv, gs2 = scale * gmu, scale * gv, scale * gs2
     kl = 0.5 * (np.sum(Lq * Lq) + m @ m - M - 2.0 * np.sum(np.log(np.diag(Lq))))
     # adjoints of the whitened problem

@@ -19,7 +19,7 @@ import ctypes as C, sys
 sys.path.insert(0, %r)
 from approxgp import _ffi
 lib = _ffi.load_library()
-assert lib.svgp_version() == 2
+assert lib.svgp_version() == 3
 for n in (1, 2, 7, 20, 64, 200):
     xs, ws = (C.c_double * n)(), (C.c_double * n)()
     assert lib.svgp_gausshermite(n, xs, ws) == 0
@@ -47,7 +47,8 @@ print("ASAN_CHILD_OK")
 
 @pytest.mark.skipif(shutil.which("hipcc") is None, reason="needs hipcc to build the instrumented library")
 def test_host_side_under_address_sanitizer():
-    if not os.path.exists(LIB):
+    srcs = glob.glob(os.path.join(ROOT, "approximategps.jl_amd", "csrc", "*.h*")) + [os.path.join(ROOT, "include", "svgp_mi355x.h")]
+    if not os.path.exists(LIB) or os.path.getmtime(LIB) < max(os.path.getmtime(f) for f in srcs):   # never test a stale build
         subprocess.run(["bash", os.path.join(ROOT, "build_asan.sh")], check=True, cwd=ROOT, stdout=subprocess.DEVNULL)
     rt = sorted(glob.glob("/opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.asan-x86_64.so"))
     if not rt:

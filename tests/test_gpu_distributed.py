@@ -99,6 +99,15 @@ def test_library_collective_world_of_one(centered):
     for k in ("variance", "lik_sigma2", "mean_const", "inv_lengthscale", "z", "m", "Lq"):
         np.testing.assert_allclose(np.asarray(gg[k]), np.asarray(lg[k]), rtol=1e-12, atol=1e-13)
     assert abs(val - o.elbo(sva, x[:, 100:1600], y[100:1600], sigma2=s2, num_data=9000.0)) <= 1e-8 * abs(val)
+    # the host-evaluated-likelihood form takes the same collective route (handshake, device-side sum E, grouped all-reduce)
+    mu, var = model.marginals(data, 100, 1500)
+    yb = y[100:1600]
+    e_host = o.expected_loglik(o.LIK_GAUSSIAN, mu, np.sqrt(var), yb, s2)
+    gmu_h, gv_h, _ = o.expected_loglik_grads(o.LIK_GAUSSIAN, mu, var, yb, s2)
+    ev, et, eg = model.elbo_grad(data, 100, 1500, 9000.0, ext=(e_host, gmu_h, gv_h))
+    assert abs(ev - gv) <= 1e-12 * abs(gv) and et.n_points == 1500
+    for k in ("variance", "mean_const", "inv_lengthscale", "z", "m", "Lq"):
+        np.testing.assert_allclose(np.asarray(eg[k]), np.asarray(gg[k]), rtol=1e-9, atol=1e-11)
     # a local argument error still goes through the collective and comes back as the argument error
     with pytest.raises(ValueError):
         model.elbo(data, 2900, 500, 0.0)

@@ -276,3 +276,71 @@ def test_gradient_more_than_1024_inducing_points_f64(ctx):
     _close([g["variance"]], [g_ref["variance"]], 1e-6)
     model.free()
     data.free()
+
+
+# ---- likelihoods the ABI does not enumerate: host-evaluated on the device marginals (svgp_marginals / svgp_elbo_grad_ext) ----
+@pytest.mark.parametrize("dtype,vtol,gtol", [(np.float64, 1e-12, 1e-10), (np.float32, 1e-6, 1e-5)])
+@pytest.mark.parametrize("centered", [False, True])
+def test_host_evaluated_likelihood_equals_builtin(ctx, dtype, vtol, gtol, centered):
+    """The split path must reproduce the fused one when the host evaluates a likelihood the library also has: marginals ->
+    expected log-likelihood and its point gradients on the host (here the oracle's GH-20 Bernoulli, standing in for the
+    reference's GPLikelihoods call) -> svgp_elbo_grad_ext, against svgp_elbo / svgp_elbo_grad with SVGP_LIK_BERNOULLI_LOGISTIC.
+    Two strip-kernel chunks (N > 65536 would be slow on the host side: the chunking is forced by SVGP_GRAD_CHUNK in the soak)."""
+    N, M, d, lik = 3000, 150, 4, o.LIK_BERNOULLI_LOGISTIC
+    x, y, nc, s2 = o.synth_problem(8100, N, M, d, family=o.KERNEL_MATERN52, lik=lik, dtype=dtype)
+    sva = o.SVA(nc.kernel, nc.z, nc.m + 0.1, 0.8 * nc.Lq, jitter=nc.jitter, mean_const=0.05, centered=True) if centered else nc
+    model = device_model(ctx, sva, dtype=dtype, lik=lik, sigma2=s2)
+    data = _ffi.DeviceData(ctx, x, y, dtype)
+    nodata = _ffi.DeviceData(ctx, x, None, dtype)            # the split path needs no observations on the device
+    off, n, num_data = 137, 2500, 9000.0
+    mu, var = model.marginals(nodata, off, n)
+    ref = o.elbo_terms(sva, x[:, off:off + n], y[off:off + n], lik=lik, sigma2=s2, num_data=num_data)
+    np.testing.assert_allclose(mu, ref.mu, rtol=0, atol=(1e-10 if dtype == np.float64 else 2e-3))
+    np.testing.assert_allclose(var, ref.v + 1e-18, rtol=0, atol=(1e-10 if dtype == np.float64 else 2e-3))
+    yb = y[off:off + n]
+    sum_e = o.expected_loglik(lik, mu, np.sqrt(var), yb, s2)
+    gmu, gv, _ = o.expected_loglik_grads(lik, mu, var, yb, s2)
+    val_b, _, g_b = model.elbo_grad(data, off, n, num_data)
+    val_e, t_e, g_e = model.elbo_grad(nodata, off, n, num_data, ext=(sum_e, gmu, gv))
+    assert abs(val_e - val_b) <= vtol * abs(val_b)
+    assert t_e.n_points == n and t_e.scale == pytest.approx(num_data / n)
+    for k in ("variance", "mean_const"):
+        assert abs(g_e[k] - g_b[k]) <= gtol * max(abs(g_b[k]), 1e-6), k
+    assert g_e["lik_sigma2"] == 0.0
+    for k in ("inv_lengthscale", "z", "m", "Lq"):
+        _close(g_e[k], g_b[k], gtol)
+    with pytest.raises(ValueError):
+        model.elbo_grad(nodata, off, n, num_data, ext=(sum_e, gmu[:-1], gv[:-1]))
+    for h in (model, data, nodata):
+        h.free()
+
+
+def test_host_evaluated_custom_likelihood_against_the_oracle(ctx):
+    """A likelihood outside the enumeration (Poisson with a softplus link, GH-20 on the host): the split path against the
+    oracle's analytic backward pass fed with the same point gradients."""
+    N, M, d = 900, 70, 3
+    x, _, sva, _ = o.synth_problem(8200, N, M, d, family=o.KERNEL_SE)
+    rng = np.random.default_rng(5)
+    y = rng.poisson(np.log1p(np.exp(np.sin(x.sum(axis=0))))).astype(np.float64)
+    model = device_model(ctx, sva)
+    data = _ffi.DeviceData(ctx, x, None, np.float64)
+    mu, var = model.marginals(data)
+    xs, ws = o.gausshermite(20)
+    ws = ws / np.sqrt(np.pi)
+    sd = np.sqrt(var)
+    f = mu[None, :] + np.sqrt(2.0) * sd[None, :] * xs[:, None]
+    lam = np.logaddexp(0.0, f)                                   # softplus link
+    logp = y * np.log(lam) - lam
+    dlogp = (y / lam - 1.0) / (1.0 + np.exp(-f))
+    sum_e = float((ws[:, None] * logp).sum())
+    gmu = (ws[:, None] * dlogp).sum(axis=0)
+    gv = (ws[:, None] * dlogp * xs[:, None]).sum(axis=0) / (np.sqrt(2.0) * sd)
+    val, _, g = model.elbo_grad(data, 0, N, 4.0 * N, ext=(sum_e, gmu, gv))
+    val_ref, g_ref = o.elbo_grad_from_point_grads(sva, x, sum_e, gmu, gv, num_data=4.0 * N)
+    assert rel(val, val_ref) < 1e-10
+    for k in ("m", "Lq", "inv_lengthscale"):
+        _close(g[k], g_ref[k], 1e-6)
+    _close(np.asarray(g["z"]).reshape(g_ref["z"].shape, order="F"), g_ref["z"], 1e-6)
+    assert abs(g["variance"] - g_ref["variance"]) <= 1e-6 * abs(g_ref["variance"])
+    model.free()
+    data.free()

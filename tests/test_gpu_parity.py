@@ -319,6 +319,15 @@ def test_python_mirror_end_to_end(ctx):
         assert rel(ag.elbo(sva, lb, yb, ctx=ctx), o.elbo(osva, x[:100], yb, lik=code)) < F64_RTOL
     with pytest.raises(_ffi.UnsupportedError):
         ag.elbo(sva, ag.LatentGP(f, ag.BernoulliLikelihood(object()), 1e-18)(x[:100]), yb, ctx=ctx)
+    # a likelihood outside the enumeration goes the host-evaluated route (marginals from the device, SVA:355 on the host);
+    # written as a GenericLikelihood the logistic Bernoulli must reproduce the built-in one, value and gradient
+    gl = ag.GenericLikelihood(lambda ff, yy: -np.logaddexp(0.0, np.where(yy > 0.5, -ff, ff)), lambda ff, yy: yy - 1.0 / (1.0 + np.exp(-ff)))
+    lb, lgen = ag.LatentGP(f, ag.BernoulliLikelihood(), 1e-18)(x[:100]), ag.LatentGP(f, gl, 1e-18)(x[:100])
+    vb, gb = ag.elbo_and_gradient(sva, lb, yb, num_data=N, ctx=ctx)
+    vg, gg = ag.elbo_and_gradient(sva, lgen, yb, num_data=N, ctx=ctx)
+    assert rel(ag.elbo(sva, lgen, yb, num_data=N, ctx=ctx), vb) < 1e-12 and rel(vg, vb) < 1e-12
+    for k in ("m", "Lq", "z", "inv_lengthscale"):
+        np.testing.assert_allclose(np.asarray(gg[k]), np.asarray(gb[k]), rtol=1e-9, atol=1e-11)
 
 
 @pytest.mark.parametrize("dtype,tol", [(np.float64, F64_RTOL), (np.float32, F32_RTOL)])

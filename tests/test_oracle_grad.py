@@ -68,3 +68,16 @@ def test_centered_gradient_matches_finite_differences(family, lik):
     np.testing.assert_allclose(g["Lq"], np.tril(_fd(lambda t: with_(Lq=np.tril(t)), sva.Lq.copy(), 1e-6)), **tol)
     assert g["variance"] == pytest.approx(float(_fd(lambda t: with_(variance=float(t[0])), np.array([sva.kernel.variance]), 1e-6)[0]), rel=5e-6, abs=5e-6)
     assert g["mean_const"] == pytest.approx(float(_fd(lambda t: with_(c=float(t[0])), np.array([0.15]), 1e-6)[0]), rel=5e-6, abs=5e-6)
+
+
+def test_point_gradient_form_equals_the_fused_form():
+    """elbo_grad_from_point_grads (the oracle side of svgp_elbo_grad_ext) fed with the oracle's own point gradients."""
+    x, y, sva, s2 = o.synth_problem(77, 60, 9, 2, family=o.KERNEL_MATERN32, lik=o.LIK_BERNOULLI_LOGISTIC)
+    val, g = o.elbo_grad(sva, x, y, lik=o.LIK_BERNOULLI_LOGISTIC, num_data=200.0)
+    mu, sd = o.marginals(o.posterior(sva), x)
+    sum_e = o.expected_loglik(o.LIK_BERNOULLI_LOGISTIC, mu, sd, y)
+    gmu, gv, _ = o.expected_loglik_grads(o.LIK_BERNOULLI_LOGISTIC, mu, sd * sd, y)
+    val2, g2 = o.elbo_grad_from_point_grads(sva, x, sum_e, gmu, gv, num_data=200.0)
+    assert val2 == pytest.approx(val, rel=1e-13)
+    for k in ("z", "m", "Lq", "inv_lengthscale"):
+        np.testing.assert_allclose(g2[k], g[k], rtol=1e-10, atol=1e-12)
