@@ -344,3 +344,21 @@ def test_host_evaluated_custom_likelihood_against_the_oracle(ctx):
     assert abs(g["variance"] - g_ref["variance"]) <= 1e-6 * abs(g_ref["variance"])
     model.free()
     data.free()
+
+
+def test_host_evaluated_likelihood_across_gradient_chunks(ctx):
+    """More points than one gradient chunk (65 536 columns): the point gradients of the second chunk are read at its offset."""
+    N, M, d = 70_001, 40, 2
+    x, y, sva, s2 = o.synth_problem(8300, N, M, d)
+    model = device_model(ctx, sva, sigma2=s2)
+    data = _ffi.DeviceData(ctx, x, y, np.float64)
+    mu, var = model.marginals(data)
+    gmu, gv = (y - mu) / s2, np.full(N, -0.5 / s2)
+    sum_e = float(np.sum(-0.5 * (np.log(2 * np.pi * s2) + ((y - mu) ** 2 + var) / s2)))
+    vb, _, gb = model.elbo_grad(data, 0, N, 2.0 * N)
+    ve, _, ge = model.elbo_grad(data, 0, N, 2.0 * N, ext=(sum_e, gmu, gv))
+    assert abs(ve - vb) <= 1e-12 * abs(vb)
+    for k in ("inv_lengthscale", "z", "m", "Lq"):
+        _close(ge[k], gb[k], 1e-10)
+    model.free()
+    data.free()
