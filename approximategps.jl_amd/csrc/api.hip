@@ -978,6 +978,24 @@ struct GradCall {
   double ext_sum_e = 0.0;
 };
 
+// out (lower tiles, pre-zeroed) += Xt' Yt for M x M operands.  One workgroup pair per lower 128-tile is 72 workgroups at
+// M = 1024 for 256 CUs, so the product is split along K into slices whose partials land in `scratch` ([ns][Mp][Mp], here the
+// SYRK's idle slice buffer) and are summed in a fixed order: 110 -> ~50 us per product at M = 1024 (four per gradient).
+void gemm_mm(svgp_ctx* ctx, GradWs* w, int dt, hipStream_t s, const void* Xt, const void* Yt, int64_t Mp, void* out) {
+  const int nP = int(Mp / 128), ntiles = nP * (nP + 1) / 2;
+  int ns = (2 * ctx->num_cus) / (ntiles * (dt == SVGP_F64 ? 2 : 1));   // fill the workgroup slots once (f64: two 128 x 64 halves per tile)
+  if (ns > nP) ns = nP;                         // at least 8 k-steps of 16 per slice
+  if (ns > w->nslices) ns = w->nslices;         // the scratch is the SYRK's [nslices][Mp][Mp]
+  static const int knob = [] { const char* e = getenv("SVGP_GEMM_MM_SPLITK"); return e ? atoi(e) : 1; }();   // A/B knob
+  if (ns < 2 || !knob) {
+    launch_gemm_pm(dt, s, Xt, Yt, nullptr, 1.0, Mp, Mp, Mp, 1, out);
+    return;
+  }
+  const int64_t sl = ((Mp + ns - 1) / ns + 15) / 16 * 16;
+  launch_gemm_pm(dt, s, Xt, Yt, nullptr, 1.0, Mp, Mp, sl, ns, w->G1, 1);
+  launch_sum_slices_lower(dt, s, w->G1, ns, Mp, out);
+}
+
 int grad_enqueue(svgp_ctx* ctx, svgp_model* m, const svgp_data* data, int64_t off, int64_t len, GradCall& gc) {
   const bool centered = gc.centered = (m->desc.parametrization == SVGP_CENTERED);
   HIPC(ctx, hipSetDevice(ctx->device));
@@ -1000,8 +1018,7 @@ int grad_enqueue(svgp_ctx* ctx, svgp_model* m, const svgp_data* data, int64_t of
   rc = enqueue_prep(ctx, m);
   if (rc) return rc;
   HIPC(ctx, hipEventRecord(ctx->ev[1], s));
-  // accumulators
-  HIPC(ctx, hipMemsetAsync(w->G1, 0, w->g_b, s));
+  // accumulators (G1, the SYRK's slice buffer, is zeroed after its use as split-K scratch below)
   HIPC(ctx, hipMemsetAsync(w->G2, 0, mm, s));
   HIPC(ctx, hipMemsetAsync(w->rp_uf, 0, w->rp_uf_b, s));
   HIPC(ctx, hipMemsetAsync(w->sp_uf, 0, w->sp_uf_b, s));
@@ -1020,7 +1037,8 @@ int grad_enqueue(svgp_ctx* ctx, svgp_model* m, const svgp_data* data, int64_t of
   launch_vec_to_block(dt, s, m->mp, Mp, w->Phi);
   launch_solve_t(dt, s, w->S, w->Phi, nullptr, Mp, 64, 64, ctx->num_cus);
   launch_block_to_vec(dt, s, w->Phi, Mp, w->alpha);
-  launch_gemm_pm(dt, s, Bq, Bq, nullptr, 1.0, Mp, Mp, Mp, 1, w->G2);       // lower tiles of B B' (row-major)
+  gemm_mm(ctx, w, dt, s, Bq, Bq, Mp, w->G2);                               // lower tiles of B B' (row-major)
+  HIPC(ctx, hipMemsetAsync(w->G1, 0, w->g_b, s));
   launch_sym_from_lower(dt, s, w->G2, 1, Mp, 1.0, w->tmp);                 // B B' - I, full
   launch_solve_t(dt, s, w->S, w->tmp, w->Rcm, Mp, Mp, Mp, ctx->num_cus);   // Lk' \ . ; the transposed copy is R column-major
   KCHECK(ctx, "grad prep");
@@ -1104,8 +1122,8 @@ int grad_enqueue(svgp_ctx* ctx, svgp_model* m, const svgp_data* data, int64_t of
   launch_sym_from_lower(dt, s, w->G1, w->nslices, Mp, 0.0, w->W2);
   HIPC(ctx, hipMemsetAsync(w->G1p, 0, mm, s));
   HIPC(ctx, hipMemsetAsync(w->G2, 0, mm, s));
-  launch_gemm_pm(dt, s, w->W2, m->U, nullptr, 1.0, Mp, Mp, Mp, 1, w->G1p);    // (W B)[r][c] = sum_i W[i][r] B'[c][i]
-  launch_gemm_pm(dt, s, w->Rcm, w->W2, nullptr, 1.0, Mp, Mp, Mp, 1, w->G2);   // (R W)[r][c] = sum_i R[r][i] W[i][c]
+  gemm_mm(ctx, w, dt, s, w->W2, m->U, Mp, w->G1p);    // (W B)[r][c] = sum_i W[i][r] B'[c][i]
+  gemm_mm(ctx, w, dt, s, w->Rcm, w->W2, Mp, w->G2);   // (R W)[r][c] = sum_i R[r][i] W[i][c]
   launch_avec(s, w->rp_uf, w->ns_uf, int64_t(2 + dreg) * Mp, Mp, w->avec);
   launch_finish_mm2(dt, s, w->G1p, w->G2, w->alpha, w->avec, Mp, M, centered ? m->B : m->Lq_raw, centered ? Mp : M, klw, w->Lqbar,
                     centered ? w->BbarRM : nullptr, w->LbarRM);
@@ -1119,13 +1137,13 @@ int grad_enqueue(svgp_ctx* ctx, svgp_model* m, const svgp_data* data, int64_t of
     launch_rm_tril_to_user(dt, s, w->BbarRM, Mp, M, w->Lqbar);
     launch_transpose(dt, s, w->BbarRM, Mp, w->tmp);
     HIPC(ctx, hipMemsetAsync(w->Phi, 0, mm, s));
-    launch_gemm_pm(dt, s, w->tmp, m->B, nullptr, 1.0, Mp, Mp, Mp, 1, w->Phi);
+    gemm_mm(ctx, w, dt, s, w->tmp, m->B, Mp, w->Phi);
     launch_lbar_adjust(dt, s, w->LbarRM, w->Phi, w->rbar, m->mp, Mp);
     KCHECK(ctx, "centered chain");
   }
   launch_lower_to_rowmajor(dt, s, m->L, Mp, w->LkRM);
   HIPC(ctx, hipMemsetAsync(w->Phi, 0, mm, s));
-  launch_gemm_pm(dt, s, w->LkRM, w->LbarRM, nullptr, 1.0, Mp, Mp, Mp, 1, w->Phi);
+  gemm_mm(ctx, w, dt, s, w->LkRM, w->LbarRM, Mp, w->Phi);
   launch_phi(dt, s, w->Phi, Mp);
   launch_solve_t(dt, s, w->S, w->Phi, nullptr, Mp, Mp, Mp, ctx->num_cus);
   launch_transpose(dt, s, w->Phi, Mp, w->tmp);

@@ -219,7 +219,7 @@ __global__ void __launch_bounds__(k256, 2) solve_t_kernel(const T* __restrict__ 
 template <typename T, int NT, int NTHR>
 __global__ void __launch_bounds__(NTHR, 2) gemm_pm_kernel(const T* __restrict__ Xt, const T* __restrict__ Yt,
                                                            const T* __restrict__ w, T wscale, int64_t Mp, int64_t n,
-                                                           int64_t slice_len, T* __restrict__ out) {
+                                                           int64_t slice_len, T* __restrict__ out, int overwrite) {
   using G = TileGemm<T, NT, 16, NTHR>;
   using QRegs = typename G::QRegs;
   constexpr int NCH = kNB / NT;
@@ -258,7 +258,20 @@ __global__ void __launch_bounds__(NTHR, 2) gemm_pm_kernel(const T* __restrict__ 
 #pragma unroll
     for (int r = 0; r < 4; ++r)
 #pragma unroll
-      for (int j = 0; j < G::NJ; ++j) o[int64_t(G::acc_row(i, r)) * Mp + G::acc_col(j)] += acc.v[i][j][r];
+      for (int j = 0; j < G::NJ; ++j) {
+        T* e = o + int64_t(G::acc_row(i, r)) * Mp + G::acc_col(j);
+        *e = overwrite ? acc.v[i][j][r] : *e + acc.v[i][j][r];
+      }
+}
+
+// out[r][c] += sum_s part[s][r][c] over the lower 128-tiles (the tiles gemm_pm_kernel computes), slices in a fixed order
+template <typename T>
+__global__ void sum_slices_lower_kernel(const T* __restrict__ part, int ns, int64_t Mp, T* __restrict__ out) {
+  const int64_t c = int64_t(blockIdx.x) * blockDim.x + threadIdx.x, r = blockIdx.y;
+  if (c >= Mp || c / kNB > r / kNB) return;
+  T v = T(0);
+  for (int s = 0; s < ns; ++s) v += part[int64_t(s) * Mp * Mp + r * Mp + c];
+  out[r * Mp + c] += v;
 }
 
 // kernel value and its derivative w.r.t. r^2 (both including the variance)
@@ -717,8 +730,13 @@ void launch_solve_t(int dtype, hipStream_t s, const void* S, void* X, void* Xt, 
   });
 }
 
+void launch_sum_slices_lower(int dtype, hipStream_t s, const void* part, int ns, int64_t Mp, void* out) {
+  dim3 grid((unsigned)((Mp + 255) / 256), (unsigned)Mp);
+  GD(dtype, T, hipLaunchKernelGGL(sum_slices_lower_kernel<T>, grid, dim3(256), 0, s, (const T*)part, ns, Mp, (T*)out));
+}
+
 void launch_gemm_pm(int dtype, hipStream_t s, const void* Xt, const void* Yt, const void* w, double wscale, int64_t Mp,
-                    int64_t n, int64_t slice_len, int nslices, void* out) {
+                    int64_t n, int64_t slice_len, int nslices, void* out, int overwrite) {
   const int nP = int(Mp / kNB), ntiles = nP * (nP + 1) / 2;
   // f64: 128 x 64 halves on 256-thread workgroups (same-box: H value-and-gradient 141.0 -> 138.4 ms); f32: no difference
   static const int forced = [] { const char* e = getenv("SVGP_GEMM_PM_NT"); return e ? atoi(e) : 0; }();   // tuning knob
@@ -729,13 +747,13 @@ void launch_gemm_pm(int dtype, hipStream_t s, const void* Xt, const void* Yt, co
       auto kern = gemm_pm_kernel<T, 64, k256>;
       set_max_lds(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, int(G::LDS_BYTES));
       hipLaunchKernelGGL(kern, dim3((unsigned)(ntiles * 2), (unsigned)nslices), dim3(k256), G::LDS_BYTES, s, (const T*)Xt,
-                         (const T*)Yt, (const T*)w, T(wscale), Mp, n, slice_len, (T*)out);
+                         (const T*)Yt, (const T*)w, T(wscale), Mp, n, slice_len, (T*)out, overwrite);
     } else {
       using G = TileGemm<T, kNB, 16, kThreads>;
       auto kern = gemm_pm_kernel<T, kNB, kThreads>;
       set_max_lds(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, int(G::LDS_BYTES));
       hipLaunchKernelGGL(kern, dim3((unsigned)ntiles, (unsigned)nslices), dim3(kThreads), G::LDS_BYTES, s, (const T*)Xt,
-                         (const T*)Yt, (const T*)w, T(wscale), Mp, n, slice_len, (T*)out);
+                         (const T*)Yt, (const T*)w, T(wscale), Mp, n, slice_len, (T*)out, overwrite);
     }
   });
 }

@@ -146,7 +146,9 @@ void launch_abar(int dtype, hipStream_t s, const void* Lqp, const void* C, const
 void launch_solve_t(int dtype, hipStream_t s, const void* S, void* X, void* Xt, int64_t Mp, int64_t ld, int64_t ncols,
                     int num_cus);
 void launch_gemm_pm(int dtype, hipStream_t s, const void* Xt, const void* Yt, const void* w, double wscale, int64_t Mp,
-                    int64_t n, int64_t slice_len, int nslices, void* out);
+                    int64_t n, int64_t slice_len, int nslices, void* out, int overwrite = 0);
+// out (lower 128-tiles) += the sum of `ns` slice partials written by launch_gemm_pm(..., overwrite = 1)
+void launch_sum_slices_lower(int dtype, hipStream_t s, const void* part, int ns, int64_t Mp, void* out);
 void launch_kgrad(int dtype, hipStream_t s, const KernelParams& kp, const void* zs, int64_t Mp, const void* x, int64_t ldx,
                   int64_t xoff, int prescaled, int64_t n, int64_t nvalid, const void* Pt, const void* At, const void* gmu,
                   int64_t slice_len, int nslices, double* rowpart, double* scalpart);
