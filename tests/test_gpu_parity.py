@@ -447,3 +447,44 @@ def test_wrap_device_memory_zero_copy(ctx):
     assert float(xt[0, 0].item()) == x[0, 0] and float(yt[3].item()) == y[3]   # still the caller's, still intact
     up.free()
     model.free()
+
+
+def test_two_contexts_on_two_threads():
+    """SURVEY 8b threading contract: the library is thread-compatible - distinct contexts may be used concurrently (one
+    context is not re-entrant).  Two host threads, each with its own context (own stream, own workspaces), evaluate value and
+    value-and-gradient of different problems at the same time (ctypes drops the GIL during the calls); every result must be
+    bitwise the one the same context produces alone."""
+    import threading
+
+    problems = [(6000, 200, 3, o.KERNEL_SE, np.float64), (9000, 333, 8, o.KERNEL_MATERN52, np.float32)]
+    ctxs = [_ffi.Context(0), _ffi.Context(0)]
+    setups = []
+    for c, (N, M, d, fam, dt) in zip(ctxs, problems):
+        x, y, sva, s2 = o.synth_problem(4000 + M, N, M, d, family=fam, dtype=dt)
+        model = device_model(c, sva, dtype=dt, sigma2=s2)
+        data = _ffi.DeviceData(c, x, y, dt)
+        alone = (model.elbo(data, 0, N, 2.0 * N)[0], model.elbo_grad(data, 0, N, 2.0 * N)[2]["m"].copy())
+        setups.append((model, data, N, alone))
+    errors = []
+
+    def work(i):
+        model, data, N, alone = setups[i]
+        try:
+            for _ in range(25):
+                v = model.elbo(data, 0, N, 2.0 * N)[0]
+                g = model.elbo_grad(data, 0, N, 2.0 * N)[2]["m"]
+                if v != alone[0] or not np.array_equal(g, alone[1]):
+                    errors.append((i, v, alone[0]))
+        except Exception as e:  # noqa: BLE001
+            errors.append((i, repr(e)))
+
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors[:3]
+    for (model, data, _, _), c in zip(setups, ctxs):
+        model.free()
+        data.free()
+        c.close()
