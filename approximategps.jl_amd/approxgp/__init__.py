@@ -9,7 +9,7 @@ from ._ffi import (Context, DeviceData, DeviceModel, DomainError, PosDefExceptio
                    default_context, gausshermite, load_library)
 from .gp import (GP, BernoulliLikelihood, DefaultExpectationMethod, FiniteGP, GaussHermiteExpectation,
                  GaussianLikelihood, LatentFiniteGP, LatentGP, MvNormal, PoissonLikelihood, ExponentialLikelihood,
-                 GammaLikelihood, GenericLikelihood, LogisticLink, NormalCDFLink, ProbitLink)
+                 GammaLikelihood, CallerLikelihood, LogisticLink, NormalCDFLink, ProbitLink)
 from .kernels import (ARDTransform, Matern32Kernel, Matern52Kernel, ScaledKernel, ScaleTransform, SEKernel,
                       SqExponentialKernel, TransformedKernel, with_lengthscale)
 from .sva import (SVGP, ApproxPosteriorGP, Centered, NonCentered, SparseVariationalApproximation, approx_lml, elbo,

@@ -91,32 +91,21 @@ class GammaLikelihood:
     alpha: float = 1.0
 
 
-@dataclass(frozen=True)
-class GenericLikelihood:
-    """A single-latent likelihood the C-ABI does not enumerate (any GPLikelihoods likelihood / link in the reference):
-    log p(y | f) and its f-derivative as vectorised callables (f, y) -> array.  Its expectation under the marginals -
-    SVA:355, the only likelihood-dependent step and O(n) scalar work - is evaluated HERE on the host by Gauss-Hermite, on
-    marginals the device computed (svgp_marginals); the backward pass runs on the device again (svgp_elbo_grad_ext)."""
-    logp: object
-    dlogp: object = None
+class CallerLikelihood:
+    """Base class for a single-latent likelihood the C-ABI does not enumerate (in the reference: any other GPLikelihoods
+    likelihood or link).  It is CALLER code, like the likelihood object a Julia user passes to `elbo`: only SVA:355,
+    expected_loglikelihood(quadrature, lik, q_f, y), depends on it, and that is O(n) scalar work on the marginals.  The
+    library computes marginals(f_post(x)) on the device (svgp_marginals), calls `expectation` below on the host - exactly
+    where the Julia binding calls the reference's own GPLikelihoods method - and runs the backward pass on the device again
+    with the point gradients it returns (svgp_elbo_grad_ext).  This package contains no implementation of it and no host
+    numerics: the enumerated likelihoods never take this route, and there is nothing it falls back from.
 
-    def host_expectation(self, mu, var, y, n_points=20, want_grad=False):
-        """-> (sum_i E_i, dE_i/dmu_i, dE_i/dv_i) with E_i = pi^-1/2 sum_j w_j log p(y_i | sqrt(2 v_i) x_j + mu_i)."""
-        xs, ws = np.polynomial.hermite.hermgauss(int(n_points))
-        ws = ws / np.sqrt(np.pi)
-        sd = np.sqrt(var)
-        f = mu[None, :] + np.sqrt(2.0) * sd[None, :] * xs[:, None]
-        sum_e = float((ws[:, None] * self.logp(f, y[None, :])).sum())
-        if not want_grad:
-            return sum_e, None, None
-        if self.dlogp is None:
-            raise UnsupportedGradient("GenericLikelihood needs dlogp for gradients")
-        dl = self.dlogp(f, y[None, :])
-        return sum_e, (ws[:, None] * dl).sum(axis=0), (ws[:, None] * dl * xs[:, None]).sum(axis=0) / (np.sqrt(2.0) * sd)
+    Subclasses implement
+        expectation(mu, var, y, n_points, want_grad) -> (sum_i E_i, dE_i/dmu_i or None, dE_i/dv_i or None)
+    with E_i = E_{N(mu_i, var_i)}[log p(y_i | f)] and `n_points` the Gauss-Hermite order the caller asked for."""
 
-
-class UnsupportedGradient(RuntimeError):
-    pass
+    def expectation(self, mu, var, y, n_points, want_grad):
+        raise NotImplementedError
 
 
 @dataclass(eq=False)

@@ -10,7 +10,7 @@ import numpy as np
 
 from . import _ffi
 from .gp import (DEFAULT_SIGMA2, BernoulliLikelihood, DefaultExpectationMethod, FiniteGP, GaussHermiteExpectation,
-                 GaussianLikelihood, GenericLikelihood, LatentFiniteGP, MvNormal, NormalCDFLink, LogisticLink, PoissonLikelihood, ExponentialLikelihood,
+                 GaussianLikelihood, CallerLikelihood, LatentFiniteGP, MvNormal, NormalCDFLink, LogisticLink, PoissonLikelihood, ExponentialLikelihood,
                  GammaLikelihood, _as_dn)
 from .kernels import unpack_kernel
 
@@ -115,7 +115,7 @@ def elbo(sva: SparseVariationalApproximation, fx, y, *, num_data=None, quadratur
     if sva.fz.f is not lfx.fx.f:  # SVA:347-351
         raise ValueError("(Latent)FiniteGP prior is not consistent with SparseVariationalApproximation's")
     ctx = ctx or _ffi.default_context()
-    if isinstance(lfx.lik, GenericLikelihood):
+    if isinstance(lfx.lik, CallerLikelihood):
         return _elbo_host_likelihood(sva, lfx, y, num_data, quadrature, ctx, dtype, False)[0]
     desc, keep = _desc(sva, lfx.lik, quadrature, dtype)
     y = np.asarray(y)
@@ -143,7 +143,7 @@ def _elbo_host_likelihood(sva, lfx, y, num_data, quadrature, ctx, dtype, want_gr
     model = _ffi.DeviceModel(ctx, desc, keep)
     try:
         mu, var = model.marginals(data, 0, n)
-        sum_e, gmu, gv = lfx.lik.host_expectation(mu, var, y, qn, want_grad)
+        sum_e, gmu, gv = lfx.lik.expectation(mu, var, y, qn, want_grad)   # the caller's code (SVA:355)
         nd = float(num_data) if num_data is not None else float(n)
         if not want_grad:
             return sum_e * nd / n - model.prior_kl()[0], None
@@ -167,7 +167,7 @@ def elbo_and_gradient(sva: SparseVariationalApproximation, fx, y, *, num_data=No
     if sva.fz.f is not lfx.fx.f:
         raise ValueError("(Latent)FiniteGP prior is not consistent with SparseVariationalApproximation's")
     ctx = ctx or _ffi.default_context()
-    if isinstance(lfx.lik, GenericLikelihood):
+    if isinstance(lfx.lik, CallerLikelihood):
         return _elbo_host_likelihood(sva, lfx, y, num_data, quadrature, ctx, dtype, True)
     desc, keep = _desc(sva, lfx.lik, quadrature, dtype)
     y = np.asarray(y)

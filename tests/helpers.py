@@ -20,3 +20,26 @@ def device_model(ctx, sva, **kw):
 
 def rel(a, b):
     return abs(a - b) / max(abs(b), 1e-300)
+
+
+class GaussHermiteLikelihood:
+    """Test-side CALLER likelihood for the host-evaluated route (approxgp.CallerLikelihood): log p(y | f) and its f-derivative
+    as vectorised callables, expectation by Gauss-Hermite in numpy - the stand-in for the reference's own
+    GPLikelihoods.expected_loglikelihood that the Julia binding calls at this point."""
+
+    def __new__(cls, logp, dlogp=None):
+        import approxgp as ag
+
+        class _L(ag.CallerLikelihood):
+            def expectation(self, mu, var, y, n_points, want_grad):
+                xs, ws = np.polynomial.hermite.hermgauss(int(n_points))
+                ws = ws / np.sqrt(np.pi)
+                sd = np.sqrt(var)
+                f = mu[None, :] + np.sqrt(2.0) * sd[None, :] * xs[:, None]
+                sum_e = float((ws[:, None] * logp(f, y[None, :])).sum())
+                if not want_grad:
+                    return sum_e, None, None
+                dl = dlogp(f, y[None, :])
+                return sum_e, (ws[:, None] * dl).sum(axis=0), (ws[:, None] * dl * xs[:, None]).sum(axis=0) / (np.sqrt(2.0) * sd)
+
+        return _L()

@@ -9,7 +9,7 @@ import pytest
 
 import svgp_oracle as o
 from approxgp import _ffi
-from helpers import device_model, rel
+from helpers import GaussHermiteLikelihood, device_model, rel
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -320,8 +320,8 @@ def test_python_mirror_end_to_end(ctx):
     with pytest.raises(_ffi.UnsupportedError):
         ag.elbo(sva, ag.LatentGP(f, ag.BernoulliLikelihood(object()), 1e-18)(x[:100]), yb, ctx=ctx)
     # a likelihood outside the enumeration goes the host-evaluated route (marginals from the device, SVA:355 on the host);
-    # written as a GenericLikelihood the logistic Bernoulli must reproduce the built-in one, value and gradient
-    gl = ag.GenericLikelihood(lambda ff, yy: -np.logaddexp(0.0, np.where(yy > 0.5, -ff, ff)), lambda ff, yy: yy - 1.0 / (1.0 + np.exp(-ff)))
+    # written as a caller-side likelihood the logistic Bernoulli must reproduce the built-in one, value and gradient
+    gl = GaussHermiteLikelihood(lambda ff, yy: -np.logaddexp(0.0, np.where(yy > 0.5, -ff, ff)), lambda ff, yy: yy - 1.0 / (1.0 + np.exp(-ff)))
     lb, lgen = ag.LatentGP(f, ag.BernoulliLikelihood(), 1e-18)(x[:100]), ag.LatentGP(f, gl, 1e-18)(x[:100])
     vb, gb = ag.elbo_and_gradient(sva, lb, yb, num_data=N, ctx=ctx)
     vg, gg = ag.elbo_and_gradient(sva, lgen, yb, num_data=N, ctx=ctx)
