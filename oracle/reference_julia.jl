@@ -18,6 +18,7 @@
 # It is test infrastructure, never imported by the product.
 using ApproximateGPs, AbstractGPs, KernelFunctions, GPLikelihoods, Distributions, LinearAlgebra
 using PDMats: PDMat
+using StatsFuns: normcdf
 using Zygote
 using NPZ
 
@@ -29,7 +30,8 @@ relerr(a, b) = abs(a - b) / max(abs(b), 1e-300)
 maxrel(a, b) = maximum(abs.(a .- b)) / max(maximum(abs.(b)), 1e-12)
 
 make_lik(lk, p) = lk == 0 ? GaussianLikelihood(p) : lk == 1 ? BernoulliLikelihood() :
-                  lk == 2 ? PoissonLikelihood() : lk == 3 ? ExponentialLikelihood() : GammaLikelihood(p)   # Gamma shape α travels in "sigma2"
+                  lk == 2 ? PoissonLikelihood() : lk == 3 ? ExponentialLikelihood() :
+                  lk == 5 ? BernoulliLikelihood(normcdf) : GammaLikelihood(p)   # Gamma shape α travels in "sigma2"; 5 = NormalCDFLink
 
 # the model as a function of its differentiable parameters (so Zygote sees every dependency)
 function build(T, fam, variance, invl, z, m, A, jitter, c, centered)

@@ -30,6 +30,8 @@ CASES = [
     ("centered_m32_gauss", 9, 160, 24, 2, o.KERNEL_MATERN32, o.LIK_GAUSSIAN, 0, 640.0, True, np.float64),
     ("centered_se_bern", 10, 140, 21, 3, o.KERNEL_SE, o.LIK_BERNOULLI_LOGISTIC, 0, None, True, np.float64),
     ("f32_m52_gauss", 11, 400, 48, 5, o.KERNEL_MATERN52, o.LIK_GAUSSIAN, 0, None, False, np.float32),
+    # BernoulliLikelihood(NormalCDFLink()) - the "other invlink" of examples/c-comparisons/script.jl:33-34 (code 5)
+    ("m52_bern_normcdf", 12, 220, 28, 3, o.KERNEL_MATERN52, o.LIK_BERNOULLI_NORMCDF, 0, 880.0, False, np.float64),
 ]
 
 
