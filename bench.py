@@ -27,6 +27,9 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "approximategps.jl_amd"))
+# multi-process GPU work on this pool: the host driver only supports dmabuf IPC (RCCL fails with hipIpcGetMemHandle otherwise);
+# read by the HSA runtime when it initialises, so it has to be in the environment before the first HIP call
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 # kernel families / likelihood codes of the C-ABI
 SE, M32, M52 = 0, 1, 2

@@ -3,6 +3,8 @@
 import os
 import sys
 
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC for multi-process GPU tests (read at HSA initialisation)
+
 # torch bundles its own copy of the HIP runtime; in a process that uses both torch.cuda and libsvgp_mi355x.so it has to be
 # loaded first (the library then binds to the already loaded runtime; the other order leaves torch without GPUs)
 import torch  # noqa: F401
