@@ -488,3 +488,29 @@ def test_two_contexts_on_two_threads():
         model.free()
         data.free()
         c.close()
+
+
+def test_reference_exact_posterior_equivalence(ctx):
+    """test/SparseVariationalApproximationModule.jl:98-133 through the host mirror, same sizes and constants: with z == x and
+    the closed-form optimal q(u) (test/test_utils.jl:7-17) the Centered SVGP posterior IS the exact GP posterior (and the VFE
+    one): `mean` / `cov` at the reference's own atol 1e-10 (observed 6e-14 although cond(Kuu) ~ 1.5e13 at the reference's default
+    jitter 1e-18), and elbo <= logpdf(fx, y) + 1e-5."""
+    import approxgp as ag
+
+    rng = np.random.default_rng(654321)
+    N = 20
+    x = rng.random(N) * 10
+    y = np.sin(x) + 0.9 * np.cos(x * 1.6) + 0.4 * rng.random(N)
+    z = x.copy()
+    k_init, lik_noise = [0.2, 0.6], 0.1
+    ok = o.make_kernel(k_init)
+    kernel = o.softplus(k_init[0]) * (ag.SqExponentialKernel() @ ag.ScaleTransform(o.softplus(k_init[1])))
+    f = ag.GP(kernel)
+    fx, fz = f(x, lik_noise), f(z)                                            # fz: the default jitter 1e-18
+    m, S = o.optimal_variational_posterior(ok, z, 1e-18, x, lik_noise, y)
+    sva = ag.SparseVariationalApproximation(ag.Centered(), fz, ag.MvNormal(m, S))
+    post = ag.posterior(sva, ctx=ctx)
+    mu_gpr, cov_gpr = o.exact_gp_posterior(ok, x, lik_noise, y, x)
+    np.testing.assert_allclose(post.mean(x), mu_gpr, rtol=0, atol=1e-10)
+    np.testing.assert_allclose(post.cov(x), cov_gpr, rtol=0, atol=1e-10)
+    assert ag.elbo(sva, fx, y, ctx=ctx) <= o.exact_gp_logpdf(ok, x, lik_noise, y) + 1e-5
