@@ -514,3 +514,40 @@ def test_reference_exact_posterior_equivalence(ctx):
     np.testing.assert_allclose(post.mean(x), mu_gpr, rtol=0, atol=1e-10)
     np.testing.assert_allclose(post.cov(x), cov_gpr, rtol=0, atol=1e-10)
     assert ag.elbo(sva, fx, y, ctx=ctx) <= o.exact_gp_logpdf(ok, x, lik_noise, y) + 1e-5
+
+
+@pytest.mark.parametrize("centered", [False, True])
+def test_internal_abstractgps_interface_consistency(ctx, centered):
+    """What AbstractGPs.TestUtils.test_internal_abstractgps_interface checks on the reference's ApproxPosteriorGP
+    (test/SparseVariationalApproximationModule.jl:30-34, :54-58), through the mirror: the predictive methods agree with
+    one another (var = diag cov, cov(x, x) = cov(x), cov(x, y) = cov(y, x)', the *_and_* pairs, symmetry, positive variances)."""
+    import approxgp as ag
+
+    rng = np.random.default_rng(11)
+    d, M = 2, 30
+    X = rng.standard_normal((d, 65))
+    a, b = X[:, :40], X[:, 40:]
+    z = X[:, :M] + 0.01 * rng.standard_normal((d, M))
+    f = ag.GP(0.9 * ag.with_lengthscale(ag.Matern52Kernel(), [0.8, 1.3]))
+    A = np.eye(M) + 0.05 * np.tril(rng.standard_normal((M, M)))
+    q = ag.MvNormal.from_cholesky(0.3 * rng.standard_normal(M), A)
+    sva = ag.SparseVariationalApproximation(ag.Centered() if centered else ag.NonCentered(), f(z, 1e-6), q)
+    post = ag.posterior(sva, ctx=ctx)
+    mean_a, var_a, cov_a = post.mean(a), post.var(a), post.cov(a)
+    assert mean_a.shape == (40,) and var_a.shape == (40,) and cov_a.shape == (40, 40)
+    np.testing.assert_allclose(np.diag(cov_a), var_a, rtol=0, atol=1e-12)
+    np.testing.assert_allclose(cov_a, cov_a.T, rtol=0, atol=1e-13)
+    assert var_a.min() > 0 and np.linalg.eigvalsh(cov_a + 1e-10 * np.eye(40)).min() > 0
+    np.testing.assert_allclose(post.cov(a, a), cov_a, rtol=0, atol=1e-12)
+    cab = post.cov(a, b)
+    assert cab.shape == (40, 25)
+    np.testing.assert_allclose(cab, post.cov(b, a).T, rtol=0, atol=1e-12)
+    m2, v2 = post.mean_and_var(a)
+    m3, c3 = post.mean_and_cov(a)
+    assert np.array_equal(m2, mean_a) and np.array_equal(m3, mean_a)
+    np.testing.assert_allclose(v2, var_a, rtol=0, atol=1e-13)
+    np.testing.assert_allclose(c3, cov_a, rtol=0, atol=1e-13)
+    # the joint covariance of (a, b) is consistent with its blocks
+    joint = post.cov(np.concatenate([a, b], axis=1))
+    np.testing.assert_allclose(joint[:40, 40:], cab, rtol=0, atol=1e-12)
+    assert ag.inducing_points(post) is sva.fz.x or np.array_equal(np.asarray(ag.inducing_points(post)), z)
