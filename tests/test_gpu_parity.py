@@ -551,3 +551,32 @@ def test_internal_abstractgps_interface_consistency(ctx, centered):
     joint = post.cov(np.concatenate([a, b], axis=1))
     np.testing.assert_allclose(joint[:40, 40:], cab, rtol=0, atol=1e-12)
     assert ag.inducing_points(post) is sva.fz.x or np.array_equal(np.asarray(ag.inducing_points(post)), z)
+
+
+def test_reference_elbo_testset(ctx):
+    """The "elbo" testset of test/SparseVariationalApproximationModule.jl:76-97, same sizes and constants, through the mirror:
+    a Real, below logpdf(fx, y), the heteroscedastic-noise ErrorException, and LatentGP + GaussianLikelihood == the FiniteGP
+    method at atol 1e-10."""
+    import approxgp as ag
+
+    rng = np.random.default_rng(654321)
+    N = 20
+    x = rng.random(N) * 10
+    y = np.sin(x) + 0.9 * np.cos(x * 1.6) + 0.4 * rng.random(N)
+    z = x[:5].copy()
+    ok = o.make_kernel([0.2, 0.6])
+    f = ag.GP(o.softplus(0.2) * (ag.SqExponentialKernel() @ ag.ScaleTransform(o.softplus(0.6))))
+    fx, fz = f(x, 0.1), f(z)
+    m, S = o.optimal_variational_posterior(ok, z, 1e-18, x, 0.1, y)
+    sva = ag.SparseVariationalApproximation(fz, ag.MvNormal(m, S))            # two-argument form: NonCentered (SVA:93-95)
+    assert not sva.is_centered
+    val = ag.elbo(sva, fx, y, ctx=ctx)
+    assert isinstance(val, float) and np.isfinite(val)
+    assert val <= o.exact_gp_logpdf(ok, x, 0.1, y)
+    with pytest.raises(RuntimeError, match="homoscedastic"):
+        ag.elbo(sva, f(x, np.full(N, 0.1)), y, ctx=ctx)
+    lfx = ag.LatentGP(f, ag.GaussianLikelihood(0.1), 1e-18)(x)
+    assert ag.elbo(sva, lfx, y, ctx=ctx) == pytest.approx(val, abs=1e-10)
+    # and the value is the oracle's for the same (deliberately mismatched: q_ex is the Centered optimum) model
+    osva = o.SVA(ok, z, m, np.linalg.cholesky(0.5 * (S + S.T)), jitter=1e-18)
+    assert rel(val, o.elbo(osva, x, y, sigma2=0.1)) < 1e-9
