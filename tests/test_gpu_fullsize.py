@@ -88,6 +88,8 @@ GRAD_FULL = [
     ("H", 200_000, 1024, 8, o.KERNEL_SE, o.LIK_GAUSSIAN, np.float64, 1e-8, 1e-6, 2500),
     ("C3", 200_000, 2048, 16, o.KERNEL_MATERN52, o.LIK_BERNOULLI_LOGISTIC, np.float32, 1e-4, 3e-3, 1500),
     ("C5", 262_144, 1024, 8, o.KERNEL_SE, o.LIK_GAUSSIAN, np.float32, 1e-4, 3e-3, 2500),
+    ("C2", 100_000, 512, 8, o.KERNEL_SE, o.LIK_GAUSSIAN, np.float64, 1e-8, 1e-6, 4000),
+    ("C4", 100_000, 8192, 8, o.KERNEL_SE, o.LIK_GAUSSIAN, np.float32, 1e-4, 3e-3, 800),
 ]
 
 
@@ -116,6 +118,9 @@ def test_full_size_value_and_gradient(ctx, name, N, M, d, family, lik, dtype, rt
     for k in ("m", "Lq", "z", "inv_lengthscale"):
         s = np.asarray(parts[0][2][k], dtype=np.float64) + np.asarray(parts[1][2][k], dtype=np.float64)
         f = np.asarray(full_g[k], dtype=np.float64)
-        assert np.abs(s - f).max() <= (1e-9 if dtype == np.float64 else 2e-4) * max(np.abs(f).max(), 1e-12), (name, k)
+        # fp32: the two evaluations differ by rounding only, amplified by the Cholesky adjoint (cond(Lk)^2): 2e-4 of a block's
+        # max-norm up to M = 2048, 1.8e-3 observed at C4's M = 8192 with its jitter 1e-3
+        tol = 1e-9 if dtype == np.float64 else (5e-3 if M > 4096 else 2e-4)
+        assert np.abs(s - f).max() <= tol * max(np.abs(f).max(), 1e-12), (name, k)
     model.free()
     data.free()
