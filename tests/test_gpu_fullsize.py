@@ -124,3 +124,35 @@ def test_full_size_value_and_gradient(ctx, name, N, M, d, family, lik, dtype, rt
         assert np.abs(s - f).max() <= tol * max(np.abs(f).max(), 1e-12), (name, k)
     model.free()
     data.free()
+
+
+PREDICT_FULL = [
+    # name, M, d, family, dtype, atol on mean / var / cov
+    ("H", 1024, 8, o.KERNEL_SE, np.float64, 1e-9),
+    ("C3", 2048, 16, o.KERNEL_MATERN52, np.float32, 2e-3),
+]
+
+
+@pytest.mark.parametrize("name,M,d,family,dtype,atol", PREDICT_FULL)
+@pytest.mark.parametrize("centered", [False, True])
+def test_predictive_api_at_full_m(ctx, name, M, d, family, dtype, atol, centered):
+    """posterior / mean / var / cov / cov(x, y) (SVA:115-264) at the BASELINE models' full M, both parametrisations: 300 + 77
+    test points against the oracle (test_posterior_and_predict covers M = 150)."""
+    x, y, nc, s2 = o.synth_problem(2, 4000, M, d, family=family, dtype=dtype)
+    sva = o.SVA(nc.kernel, nc.z, nc.m + 0.2, 0.6 * nc.Lq, jitter=nc.jitter, mean_const=0.1, centered=True) if centered else nc
+    post = o.posterior(sva)
+    model = device_model(ctx, sva, dtype=dtype, sigma2=s2)
+    Lk, alpha, B = model.posterior()
+    assert np.abs(np.asarray(Lk, dtype=np.float64) - post.Lk).max() <= (1e-9 if dtype == np.float64 else 2e-3) * np.abs(post.Lk).max()
+    xs, xt = x[:, 3000:3300], x[:, 3300:3377]
+    mean, var, cov = model.predict(xs, True, True, True)
+    mu_ref, v_ref = o.mean_and_var(post, xs)
+
+    def close(a, b):   # `atol` of the largest entry: covariances are differences k - A'A + C'C of terms up to ~80 here
+        assert np.abs(np.asarray(a, dtype=np.float64) - b).max() <= atol * max(1.0, np.abs(b).max())
+
+    close(mean, mu_ref)
+    close(var, v_ref)
+    close(cov, o.cov(post, xs))
+    close(model.cross_cov(xs, xt), o.cov(post, xs, xt))
+    model.free()
