@@ -580,3 +580,29 @@ def test_reference_elbo_testset(ctx):
     # and the value is the oracle's for the same (deliberately mismatched: q_ex is the Centered optimum) model
     osva = o.SVA(ok, z, m, np.linalg.cholesky(0.5 * (S + S.T)), jitter=1e-18)
     assert rel(val, o.elbo(osva, x, y, sigma2=0.1)) < 1e-9
+
+
+@pytest.mark.parametrize("dtype,tol,gtol", [(np.float64, F64_RTOL, 1e-6), (np.float32, F32_RTOL, 3e-3)])
+def test_maximum_input_dimension(ctx, dtype, tol, gtol):
+    """d = 32 is the ABI's maximum (the feature rows kept in registers / LDS): value, gradient and Kuf at the limit, and the
+    status one dimension beyond it."""
+    N, M, d = 700, 90, 32
+    x, y, sva, s2 = o.synth_problem(3200, N, M, d, family=o.KERNEL_MATERN32, dtype=dtype)
+    model = device_model(ctx, sva, dtype=dtype, sigma2=s2)
+    data = _ffi.DeviceData(ctx, x, y, dtype)
+    val_ref, g_ref = o.elbo_grad(sva, x, y, sigma2=s2, num_data=5.0 * N)
+    assert rel(model.elbo(data, 0, N, 5.0 * N)[0], val_ref) < tol
+    val, _, g = model.elbo_grad(data, 0, N, 5.0 * N)
+    assert rel(val, val_ref) < tol
+    for k in ("m", "Lq", "inv_lengthscale"):
+        a, b = np.asarray(g[k], dtype=np.float64), np.asarray(g_ref[k])
+        assert np.abs(a - b).max() <= gtol * np.abs(b).max(), k
+    zb = np.asarray(g["z"], dtype=np.float64).reshape(g_ref["z"].shape, order="F")
+    assert np.abs(zb - g_ref["z"]).max() <= gtol * np.abs(g_ref["z"]).max()
+    K = model.kuf(data, 0, N)
+    np.testing.assert_allclose(K, o.kernelmatrix(sva.kernel, sva.z, x), rtol=0, atol=(1e-12 if dtype == np.float64 else 2e-6))
+    model.free()
+    data.free()
+    x33 = np.random.default_rng(0).standard_normal((33, 50))
+    with pytest.raises((ValueError, _ffi.UnsupportedError, _ffi.SvgpError)):
+        _ffi.DeviceData(ctx, x33, np.zeros(50), np.float64)
