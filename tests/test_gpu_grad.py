@@ -362,3 +362,34 @@ def test_host_evaluated_likelihood_across_gradient_chunks(ctx):
         _close(ge[k], gb[k], 1e-10)
     model.free()
     data.free()
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_gradient_layouts_rowvecs_and_vector(ctx, dtype):
+    """The inducing-input gradient comes back in the layout z was given in (ColVecs d x M, RowVecs M x d, Vector M): a RowVecs
+    model on RowVecs data returns the transpose of the ColVecs gradient, bit for bit; d = 1 as a plain vector likewise."""
+    x, y, sva, s2 = o.synth_problem(8400, 500, 45, 3, family=o.KERNEL_MATERN52, dtype=dtype)
+    model = device_model(ctx, sva, dtype=dtype, sigma2=s2)
+    a = _ffi.DeviceData(ctx, x, y, dtype, _ffi.COLVECS)
+    v0, _, g0 = model.elbo_grad(a, 0, 500, 1500.0)
+    desc, keep = _ffi.make_desc(dtype, sva.kernel.family, sva.kernel.variance, sva.kernel.inv_lengthscale, np.ascontiguousarray(sva.z.T),
+                                sva.m, sva.Lq, sva.jitter, lik_sigma2=s2, layout_z=_ffi.ROWVECS)
+    m2 = _ffi.DeviceModel(ctx, desc, keep)
+    b = _ffi.DeviceData(ctx, np.ascontiguousarray(x.T), y, dtype, _ffi.ROWVECS)
+    v1, _, g1 = m2.elbo_grad(b, 0, 500, 1500.0, z_shape=(45, 3))
+    assert v1 == v0
+    assert np.array_equal(np.asarray(g1["z"]), np.asarray(g0["z"]).T)
+    for k in ("m", "Lq", "inv_lengthscale"):
+        assert np.array_equal(np.asarray(g1[k]), np.asarray(g0[k])), k
+    # d = 1: Vector layout for z and x against the 1 x M / 1 x N ColVecs form
+    x1, y1, s1, s21 = o.synth_problem(8401, 400, 30, 1, dtype=dtype)
+    mc = device_model(ctx, s1, dtype=dtype, sigma2=s21)
+    dc = _ffi.DeviceData(ctx, x1, y1, dtype, _ffi.COLVECS)
+    vc, _, gc = mc.elbo_grad(dc, 0, 400, 400.0)
+    desc, keep = _ffi.make_desc(dtype, s1.kernel.family, s1.kernel.variance, s1.kernel.inv_lengthscale, s1.z[0], s1.m, s1.Lq, s1.jitter, lik_sigma2=s21)
+    mv = _ffi.DeviceModel(ctx, desc, keep)
+    dv = _ffi.DeviceData(ctx, x1[0], y1, dtype)
+    vv, _, gv = mv.elbo_grad(dv, 0, 400, 400.0)
+    assert vv == vc and np.array_equal(np.asarray(gv["z"]).ravel(), np.asarray(gc["z"]).ravel())
+    for h in (model, m2, a, b, mc, dc, mv, dv):
+        h.free()
