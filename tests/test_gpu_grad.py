@@ -393,3 +393,22 @@ def test_gradient_layouts_rowvecs_and_vector(ctx, dtype):
     assert vv == vc and np.array_equal(np.asarray(gv["z"]).ravel(), np.asarray(gc["z"]).ravel())
     for h in (model, m2, a, b, mc, dc, mv, dv):
         h.free()
+
+
+@pytest.mark.parametrize("N,M,d", [(1, 1, 1), (1, 5, 2), (3, 130, 1), (2, 257, 4)])
+def test_gradient_degenerate_shapes(ctx, N, M, d):
+    """One point, one inducing point, more inducing points than data, M just over a panel boundary: value and every gradient
+    block against the oracle (fp64), plus the fp32 run within its tolerance."""
+    for dtype, vt, gt in ((np.float64, 1e-9, 1e-6), (np.float32, 1e-4, 5e-3)):
+        x, y, sva, s2 = o.synth_problem(8500 + M, N, M, d, dtype=dtype)   # per dtype: the fp32 recipe carries its own jitter (1e-3)
+        val_ref, g_ref = o.elbo_grad(sva, x, y, sigma2=s2, num_data=10.0)
+        model = device_model(ctx, sva, dtype=dtype, sigma2=s2)
+        data = _ffi.DeviceData(ctx, x, y, dtype)
+        val, t, g = model.elbo_grad(data, 0, N, 10.0)
+        assert rel(val, val_ref) < vt and t.n_points == N
+        for k in ("m", "Lq", "inv_lengthscale"):
+            _close(g[k], g_ref[k], gt)
+        _close(np.asarray(g["z"]).reshape(g_ref["z"].shape, order="F") if d > 1 else np.asarray(g["z"])[None, :], g_ref["z"], gt)
+        assert abs(g["variance"] - g_ref["variance"]) <= gt * max(abs(g_ref["variance"]), 1e-6)
+        model.free()
+        data.free()
