@@ -205,6 +205,19 @@ def test_error_statuses(ctx):
     assert np.isfinite(val) and t.n_neg_var > 0
     with pytest.raises(ValueError):
         model.elbo(data, 4, 100)
+    # the same statuses on the gradient and marginals entry points (both policies)
+    vg, tg, _ = model.elbo_grad(data, 0, 8, 8.0)
+    assert np.isfinite(vg) and tg.n_neg_var == t.n_neg_var and abs(vg - val) <= 1e-12 * abs(val)
+    mu_c, var_c = model.marginals(data)
+    assert var_c.min() == 0.0 and int((var_c == 0.0).sum()) == t.n_neg_var          # clamped
+    strict = device_model(ctx, neg)
+    with pytest.raises(_ffi.DomainError):
+        strict.elbo_grad(data, 0, 8, 8.0)
+    with pytest.raises(_ffi.DomainError):
+        strict.marginals(data)
+    with pytest.raises(_ffi.PosDefException):
+        device_model(ctx, bad).elbo_grad(_ffi.DeviceData(ctx, x, y, np.float64), 0, 100, 100.0)
+    strict.free()
     model.free()
     data.free()
 
