@@ -4,6 +4,8 @@
 
     python bench.py --gpus 1 --steps K --warmup W            # one GPU
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+    python bench.py --gpus N ...        # started plainly with N > 1: launches the line above itself (N fresh children, before
+                                        # this process touches the GPU) and relays rank 0's JSON line
 
 A step is ONE full ELBO evaluation (reference elbo(sva, lfx, y), SVA:340-360) over one batch of synthetic
 data already resident in HBM: Kuu assembly, cholesky(Kuu), diagonal-block inverses / T panels, KL, then the
@@ -95,9 +97,9 @@ def cpu_baseline(p, family, lik, sample, n_full, M):
     if avail >= need and os.environ.get("BENCH_CPU_SAMPLE_ONLY") != "1":
         xs, ys = f64(p["x"]), f64(p["y"])
         t0 = time.perf_counter()
-        o.elbo(sva, xs, ys, lik=lik, sigma2=p["sigma2"])
+        ref = o.elbo(sva, xs, ys, lik=lik, sigma2=p["sigma2"])
         t_full = time.perf_counter() - t0
-        return dict(base, value=1.0 / t_full,
+        return dict(base, value=1.0 / t_full, oracle_elbo=float(ref), oracle_points=int(n_full),
                     sample=f"oracle/svgp_oracle.py (numpy + scipy-OpenBLAS, fp64, {threads} BLAS threads) on ALL {n_full} points, "
                            f"one evaluation = {t_full:.1f} s (no extrapolation)")
     xs, ys = f64(p["x"][:, :sample]), f64(p["y"][:sample])
@@ -109,13 +111,13 @@ def cpu_baseline(p, family, lik, sample, n_full, M):
     ts = []
     for _ in range(3):
         t0 = time.perf_counter()
-        o.elbo(sva, xs, ys, lik=lik, sigma2=p["sigma2"])
+        ref = o.elbo(sva, xs, ys, lik=lik, sigma2=p["sigma2"])
         ts.append(time.perf_counter() - t0)
     t_s, t_2k = float(np.median(ts)), float(min(t_small))
     per_point = max(t_s - t_2k, 1e-9) / max(sample - 2000, 1)    # data-proportional part
     fixed = max(t_2k - 2000 * per_point, 0.0)                    # cholesky(Kuu) etc.
     t_full = fixed + per_point * n_full
-    return dict(base, value=1.0 / t_full,
+    return dict(base, value=1.0 / t_full, oracle_elbo=float(ref), oracle_points=int(sample),
                 sample=f"oracle/svgp_oracle.py (numpy + scipy-OpenBLAS, fp64, {threads} BLAS threads) on {sample} of the {n_full} "
                        f"points (host RAM below 5 M N 8 bytes), median of 3 = {t_s:.2f} s; extrapolated linearly in N to {t_full:.1f} s/eval")
 
@@ -154,6 +156,107 @@ def profile_traffic(config, kernel_prefix):
             return rec
         best = best or rec
     return best
+
+
+def launcher_command(n_gpus, argv, port):
+    """The command `python bench.py --gpus N` (N > 1, not under torchrun) starts: N fresh ranks, one per GPU, rendezvous on
+    127.0.0.1 (the container hostname may not resolve).  `argv` = this invocation's own arguments, passed through."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={int(n_gpus)}",
+            "--master-addr", "127.0.0.1", "--master-port", str(int(port)), os.path.abspath(__file__)] + list(argv)
+
+
+def needs_self_launch(n_gpus, environ):
+    """--gpus N > 1 asks for N ranks; without torchrun's environment (RANK / WORLD_SIZE) this process is not one of them."""
+    return int(n_gpus) > 1 and "RANK" not in environ and int(environ.get("WORLD_SIZE", "1")) <= 1
+
+
+def self_launch(n_gpus, argv):
+    """Runs the N-rank job as CHILD processes (never exec; this parent has not touched HIP or torch at all) and relays rank
+    0's JSON line as the last line of stdout.  Exit code = the launcher's; on failure a JSON line with value null is still
+    printed and the exit code is non-zero."""
+    import socket
+    import subprocess
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = launcher_command(n_gpus, argv, port)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // int(n_gpus))))
+    proc = subprocess.run(cmd, stdout=subprocess.PIPE, env=env, text=True)
+    line = None
+    for ln in proc.stdout.splitlines():
+        ln = ln.strip()
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+        elif ln:
+            print(ln, file=sys.stderr)
+    if line is None:
+        line = json.dumps({"metric": "SVGP ELBO evals/sec at N=1e6, M=1024", "value": None, "unit": "evals/s", "n_gpus": int(n_gpus),
+                           "error": f"the {n_gpus}-rank launch produced no result line (exit code {proc.returncode})",
+                           "launcher": " ".join(cmd)})
+    sys.stdout.write(line + "\n")
+    sys.stdout.flush()
+    if proc.returncode:
+        return proc.returncode
+    return 1 if json.loads(line).get("value") is None else 0
+
+
+def julia_probe():
+    """probe for the reference's own toolchain on the bench host.  Returns (path or None, version string)."""
+    import shutil
+    import subprocess
+
+    exe = shutil.which("julia")
+    if not exe:
+        return None, "absent"
+    try:
+        out = subprocess.run([exe, "--version"], capture_output=True, text=True, timeout=60)
+        return exe, (out.stdout or out.stderr).strip()
+    except Exception as e:  # noqa: BLE001
+        return exe, "present, --version failed: " + repr(e)
+
+
+def julia_reference_baseline(exe, p, family, lik, n_sample):
+    """If Julia AND the reference's packages are installed on this host: time the reference's own elbo (ApproximateGPs.jl) on a
+    bounded sample of the same synthetic inputs (oracle/reference_julia_bench.jl reads them from an .npz).  Any failure is
+    reported, never fatal - the restatement's number is always there."""
+    import subprocess
+    import tempfile
+
+    with tempfile.TemporaryDirectory() as td:
+        path = os.path.join(td, "problem.npz")
+        np.savez(path, x=np.asarray(p["x"][:, :n_sample], dtype=np.float64), y=np.asarray(p["y"][:n_sample], dtype=np.float64),
+                 z=np.asarray(p["z"], dtype=np.float64), m=np.asarray(p["m"], dtype=np.float64), Lq=np.asarray(p["Lq"], dtype=np.float64),
+                 inv_lengthscale=np.asarray(p["inv_l"], dtype=np.float64), variance=float(p["variance"]), sigma2=float(p["sigma2"]),
+                 jitter=float(p["jitter"]), family=int(family), lik=int(lik))
+        try:
+            out = subprocess.run([exe, "-t", "auto", os.path.join(ROOT, "oracle", "reference_julia_bench.jl"), path],
+                                 capture_output=True, text=True, timeout=900)
+        except Exception as e:  # noqa: BLE001
+            return {"error": repr(e)}
+        res = None
+        for ln in out.stdout.splitlines():
+            if ln.startswith("{"):
+                try:
+                    res = json.loads(ln)
+                except ValueError:
+                    pass
+        if res is None:
+            return {"error": "no result line", "rc": out.returncode, "stderr_tail": out.stderr[-400:]}
+        if res.get("elbo") is not None:   # the pin: the oracle against the REAL reference on the very same sample
+            sys.path.insert(0, os.path.join(ROOT, "oracle"))
+            import svgp_oracle as o
+
+            f64 = lambda a: np.asarray(a, dtype=np.float64)
+            sva = o.SVA(o.Kernel(family, p["variance"], p["inv_l"]), f64(p["z"]), f64(p["m"]), f64(p["Lq"]), jitter=p["jitter"])
+            ref = o.elbo(sva, f64(p["x"][:, :n_sample]), f64(p["y"][:n_sample]), lik=lik, sigma2=p["sigma2"])
+            res["oracle_elbo_same_sample"] = float(ref)
+            res["oracle_vs_reference_rel_err"] = abs(float(ref) - res["elbo"]) / abs(res["elbo"])
+        res["kind"] = "reference"
+        res["sample_points"] = int(n_sample)
+        return res
 
 
 def bench_config(args, name, ctx, torch, dist, dev, world, rank, use_dist, steps, warmup, num_data_override=None, host_comm=False):
@@ -242,6 +345,11 @@ def main():
     ap.add_argument("--no-c5", action="store_true")
     args = ap.parse_args()
 
+    # `python bench.py --gpus N` with N > 1, started plainly: become the launcher of N fresh ranks (before torch / HIP are
+    # even imported here), so that an N-GPU line is an N-rank RCCL run however the script was started
+    if needs_self_launch(args.gpus, os.environ):
+        raise SystemExit(self_launch(args.gpus, sys.argv[1:]))
+
     # Everything but the final JSON line goes to stderr: RCCL prints a version banner (and warnings) on the C stdout,
     # which would otherwise surround the one line the driver reads.  fd 1 is restored just before the JSON is written.
     sys.stdout.flush()
@@ -256,7 +364,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the library has no CPU path")
@@ -304,9 +412,29 @@ def main():
                                    f"(library communicator unavailable: {lib_comm_error})"),
                    "elbo": res["elbo"], "timed_region_s": res["elapsed"]},
         "roofline": res["roofline"], "breakdown_ms": res["breakdown_ms"],
+        # what the library itself reports: the size of its RCCL communicator (svgp_ctx_comm_info; 1 = no communicator) and the
+        # number of points the all-reduced evaluation covered (svgp_terms.n_points after the in-library ncclAllReduce)
+        "rccl_world": int(ctx.comm_info()[0]), "n_points_global": res["n_points_global"],
     }
     if use_dist:
         assert res["n_points_global"] == n * world, (res["n_points_global"], n, world)
+        if not host_comm:
+            # cross-check of the in-library collective on this very run: every rank's LOCAL partial sums (svgp_elbo_partial,
+            # never collective) all-reduced by torch.distributed must give the ELBO the library's own ncclAllReduce gave
+            part, kl, err = (0.0, 0.0), 0.0, None
+            try:
+                part = model.elbo_partial(data, 0, n)
+                kl, _ = model.prior_kl()
+            except Exception as e:  # noqa: BLE001 - every rank still reaches the all-reduce below
+                err = repr(e)
+            tt = torch.tensor([part[0], part[1], 0.0 if err is None else 1.0], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt)
+            if float(tt[2].item()) > 0:
+                out["collective_check"] = {"error": err or "a peer rank failed its local evaluation"}
+            else:
+                ref = float(tt[0].item()) * (num_data / float(tt[1].item())) - kl
+                out["collective_check"] = {"library_allreduce_elbo": res["elbo"], "torch_allreduce_of_local_partials": ref,
+                                           "rel_err": abs(res["elbo"] - ref) / abs(ref)}
     tr = profile_traffic(name, "strip_kernel<") if rank == 0 else None
     if tr:
         out["roofline"].update({k: v for k, v in tr.items() if v is not None or k == "traffic_stale"})
@@ -381,9 +509,6 @@ def main():
                                          "ratio_to_forward": 1e3 * tg / res["ms_per_step"], "value": gval}
         except Exception as e:  # noqa: BLE001
             out["value_and_gradient"] = {"error": repr(e)}
-    model.free()
-    data.free()
-
     if name == "H" and not args.no_c5:
         # BASELINE config C5 (8 x MI355X: minibatched ELBO, N = 1e8, per-GPU batch 2^18, M = 1024, fp32) through the same
         # collective path: every rank evaluates its own 2^18-point minibatch per step, scale = 1e8 / (world * 2^18).
@@ -393,32 +518,61 @@ def main():
             c5out = {"workload": c5["workload"] + f"; num_data = {C5_NUM_DATA:.0e}, global minibatch = {world} x 262144",
                      "minibatch_steps_per_s": c5["evals_per_s"] / world, "ms_per_step": c5["ms_per_step"],
                      "points_per_s": c5["points_per_s"], "dtype": "f32", "roofline": c5["roofline"],
-                     "breakdown_ms": c5["breakdown_ms"], "elbo": c5["elbo"]}
+                     "breakdown_ms": c5["breakdown_ms"], "elbo": c5["elbo"], "n_points_global": c5["n_points_global"]}
             if not args.no_grad and not host_comm:
                 m5.elbo_grad(d5, 0, 262144, C5_NUM_DATA)
                 fence()
                 t0 = time.perf_counter()
-                for _ in range(5):
+                reps5 = 10
+                for _ in range(reps5):
                     m5.elbo_grad(d5, 0, 262144, C5_NUM_DATA)
                 fence()
-                tg = (time.perf_counter() - t0) / 5
+                tg = (time.perf_counter() - t0) / reps5
                 if use_dist:
                     tt = torch.tensor([tg], dtype=torch.float64, device=dev)
                     dist.all_reduce(tt, op=dist.ReduceOp.MAX)
                     tg = float(tt.item())
-                c5out["training_step_ms (value + gradient, all-reduced)"] = 1e3 * tg
+                # one training step = value + gradient of the global minibatch ELBO on every rank (svgp_elbo_grad: the batch size
+                # and the gradient blocks all-reduced inside the library), wall clock, max over ranks
+                c5out["training_step_ms"] = 1e3 * tg
+                c5out["training_steps_per_s"] = 1.0 / tg
+                c5out["training_points_per_s"] = world * 262144 / tg
+                c5out["training_step_ratio_to_forward"] = 1e3 * tg / c5["ms_per_step"]
             m5.free()
             d5.free()
             out["c5_minibatch"] = c5out
         except Exception as e:  # noqa: BLE001
             out["c5_minibatch"] = {"error": repr(e)}
 
+    # CPU baseline + parity of the TIMED workload (parity is a gate before any timing counts): the fp64 oracle
+    # evaluates the same inputs on the host cores; its ELBO is compared with the value the timed GPU steps returned, and the
+    # headline `value` is withdrawn (null) when they disagree beyond the tolerance the parity tests use.
+    tol = 1e-8 if dtype == "f64" else 1e-4
+    jl_exe, jl_version = julia_probe() if rank == 0 else (None, "not probed")
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
-            out["cpu_baseline"] = cpu_baseline(p, family, lik, min(args.cpu_sample, n), n, M)
-            out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
+            cb = cpu_baseline(p, family, lik, min(args.cpu_sample, n), n, M)
+            ref, npts = cb.pop("oracle_elbo"), cb.pop("oracle_points")
+            cb["julia"] = jl_version
+            out["cpu_baseline"] = cb
+            out["gpu_over_cpu"] = out["value"] / cb["value"]
+            # the oracle saw the first `npts` points with num_data = npts: the GPU value for exactly that batch
+            gpu_val = res["elbo"] if npts == n else model.elbo(data, 0, npts, float(npts))[0]
+            rel = abs(gpu_val - ref) / abs(ref)
+            out["parity"] = {"oracle_elbo": ref, "gpu_elbo": gpu_val, "rel_err": rel, "tol": tol, "points": npts,
+                             "ok": bool(rel <= tol), "oracle": "oracle/svgp_oracle.py (fp64; parity UNPINNED: no output of the Julia "
+                             "reference has been available to check it against)"}
+            if not out["parity"]["ok"]:
+                out["value_withdrawn"] = out["value"]
+                out["value"] = None
+            if jl_exe:   # the reference itself, when the host has it (never expected on the GPU box: it receives only this repo)
+                jr = julia_reference_baseline(jl_exe, p, family, lik, min(args.cpu_sample, n))
+                out["cpu_baseline_reference_julia"] = jr
         except Exception as e:  # noqa: BLE001
-            out["cpu_baseline"] = {"value": None, "unit": "evals/s", "cores": os.cpu_count(), "kind": "port", "sample": "failed: " + repr(e)}
+            out["cpu_baseline"] = {"value": None, "unit": "evals/s", "cores": os.cpu_count(), "kind": "port", "julia": jl_version,
+                                   "sample": "failed: " + repr(e)}
+    model.free()
+    data.free()
     ctx.close()
     if use_dist:
         dist.barrier()
