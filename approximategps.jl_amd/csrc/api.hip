@@ -738,13 +738,16 @@ int32_t svgp_prior_kl(svgp_ctx* ctx, svgp_model* m, double* kl_out, double* logd
 int32_t svgp_elbo_host(svgp_ctx* ctx, const svgp_model_desc* desc, int32_t layout_x, int64_t n, const void* x_host,
                        const void* y_host, double num_data, double* elbo_out, svgp_terms* terms_out) {
   if (!ctx) return SVGP_INVALID_ARG;
-  if (!desc || !y_host) return fail(ctx, SVGP_INVALID_ARG, "null descriptor or observations");
+  if (!desc || !y_host) {
+    const int rc0 = fail(ctx, SVGP_INVALID_ARG, "null descriptor or observations");
+    return ctx->comm ? elbo_collective(ctx, rc0) : rc0;
+  }
   svgp_model* m = nullptr;
   svgp_data* D = nullptr;
   int rc = svgp_model_create(ctx, desc, &m);
-  if (rc) return rc;
-  rc = svgp_data_upload(ctx, desc->dtype, layout_x, desc->d, n, x_host, y_host, &D);
+  if (rc == SVGP_OK) rc = svgp_data_upload(ctx, desc->dtype, layout_x, desc->d, n, x_host, y_host, &D);
   if (rc == SVGP_OK) rc = svgp_elbo(ctx, m, D, 0, n, num_data, elbo_out, terms_out);
+  else if (ctx->comm) rc = elbo_collective(ctx, rc);   // this rank never reached svgp_elbo: join its peers' all-reduce with the failure flag
   svgp_data_free(ctx, D);
   svgp_model_free(ctx, m);
   return rc;
@@ -931,8 +934,10 @@ int grad_workspace(svgp_ctx* ctx, svgp_model* m, int64_t len, GradWs** out) {
   struct { void** p; size_t b; } req[] = {
       {&w->At, mn}, {&w->Pt, mn}, {&w->gmu, size_t(nc) * es},
       {&w->gv, size_t(nc) * es}, {&w->Lqp, mm}, {&w->S, mm}, {&w->G1, w->g_b}, {&w->G2, mm}, {&w->LkRM, mm},
-      {&w->LbarRM, mm}, {&w->Phi, mm}, {&w->tmp, mm}, {&w->H, mm}, {&w->zbar, size_t(m->M) * m->d * es},
-      {&w->mbar, size_t(m->M) * es}, {&w->Lqbar, size_t(m->M) * m->M * es}, {&w->BbarRM, mm}, {&w->rbar, size_t(Mp) * es},
+      {&w->LbarRM, mm}, {&w->Phi, mm}, {&w->tmp, mm}, {&w->H, mm},
+      // the user-layout blocks hold M d / M / M^2 elements; sized by Mp because the workspace is reused for every model of the
+      // same (dtype, Mp, d), whatever its M (M = 45 then M = 96 on one context overran the smaller buffers)
+      {&w->zbar, size_t(Mp) * m->d * es}, {&w->mbar, size_t(Mp) * es}, {&w->Lqbar, mm}, {&w->BbarRM, mm}, {&w->rbar, size_t(Mp) * es},
       {&w->W2, mm}, {&w->Rcm, mm}, {&w->G1p, mm}, {&w->alpha, size_t(Mp) * es}, {(void**)&w->avec, size_t(Mp) * 8},
       {(void**)&w->rp_uf, w->rp_uf_b},
       {(void**)&w->sp_uf, w->sp_uf_b}, {(void**)&w->rp_uu, w->rp_uu_b}, {(void**)&w->sp_uu, w->sp_uu_b},
@@ -1163,36 +1168,58 @@ int grad_enqueue(svgp_ctx* ctx, svgp_model* m, const svgp_data* data, int64_t of
   return SVGP_OK;
 }
 
-// Opening handshake of a collective value-and-gradient call: ONE all-reduce of {batch length, "I cannot take part"}.
-// It gives every rank the global batch size on the device (the backward pass reads num_data / n_global there) and tells
-// every rank, before anything else is enqueued, whether a peer failed its argument checks or its workspace allocation -
-// failures after which that peer could not join the closing all-reduce of the gradient blocks.  Costs one host
-// synchronisation per call (collective mode only).
-int grad_handshake(svgp_ctx* ctx, GradCall& gc, int64_t len, int pre_rc) {
-  const std::string keep = ctx->err;
-  double h[2] = {pre_rc == SVGP_OK ? double(len) : 0.0, pre_rc == SVGP_OK ? 0.0 : 1.0};
-  int rc = SVGP_OK;
-  if (hipSetDevice(ctx->device) != hipSuccess ||
-      hipMemcpyAsync(ctx->d_coll, h, sizeof h, hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
-      hipStreamSynchronize(ctx->stream) != hipSuccess)
-    rc = SVGP_HIP_ERROR;
-  if (rc == SVGP_OK) rc = comm_allreduce(ctx, ctx->d_coll, 2, SVGP_F64);
-  if (rc == SVGP_OK && (hipMemcpyAsync(h, ctx->d_coll, sizeof h, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
-                        hipStreamSynchronize(ctx->stream) != hipSuccess))
-    rc = SVGP_HIP_ERROR;
-  if (rc != SVGP_OK) {   // the handshake itself broke: nothing sane can follow on this communicator
-    comm_abort(ctx);
-    if (pre_rc != SVGP_OK) ctx->err = keep;
-    return pre_rc != SVGP_OK ? pre_rc : fail(ctx, SVGP_RCCL_ERROR, "the opening all-reduce of svgp_elbo_grad failed");
-  }
-  if (pre_rc != SVGP_OK) {
-    ctx->err = keep;
-    return pre_rc;
-  }
-  if (h[1] > 0.0)
-    return fail(ctx, SVGP_RCCL_ERROR, "a peer rank could not take part in svgp_elbo_grad (argument or allocation failure); abandoned on every rank");
+// Opening all-reduce of a collective value-and-gradient call: the global batch size, summed over the ranks ON THE DEVICE (the
+// strips' phase 3 reads num_data / n_global there).  Asynchronous since round 3: the two values travel as kernel arguments,
+// the 16-byte ncclAllReduce is enqueued behind them, nothing is read back - round 2 synchronised the host twice here to learn
+// of failed peers before enqueueing, which every 5 ms C5 step paid for.  A peer that cannot evaluate now joins BOTH
+// collectives with zero buffers and the failure flag (grad_fail_collective), so the others find out in the closing
+// all-reduce (sums[7]) instead.
+int grad_handshake(svgp_ctx* ctx, GradCall& gc, int64_t len) {
+  if (hipSetDevice(ctx->device) != hipSuccess) return fail(ctx, SVGP_HIP_ERROR, "hipSetDevice failed");
+  launch_set2_f64(ctx->stream, ctx->d_coll, double(len), 0.0);
+  if (hipGetLastError() != hipSuccess) return fail(ctx, SVGP_HIP_ERROR, "launch failed in the opening all-reduce");
+  const int rc = comm_allreduce(ctx, ctx->d_coll, 2, SVGP_F64);
+  if (rc != SVGP_OK) return rc;
   gc.n_global_dev = ctx->d_coll;
   return SVGP_OK;
+}
+
+// A rank of a collective svgp_elbo_grad / svgp_elbo_grad_ext that failed BEFORE anything could be enqueued (argument checks,
+// workspace allocation): it still has to match its peers' two collectives or they wait for it forever.  With a valid model
+// the element counts are known (they depend on M and d only, identical on every rank), so it joins with zero gradient
+// blocks and the failure flag set (its peers return SVGP_RCCL_ERROR).  Without a model, or if even these M^2-sized zeros
+// cannot be allocated, the communicator is aborted: that case is FATAL for the job (ncclCommAbort on one rank does not
+// wake the others; include/svgp_mi355x.h says so).
+int grad_fail_collective(svgp_ctx* ctx, const svgp_model* m, int pre_rc) {
+  const std::string keep = ctx->err;
+  auto give_up = [&]() {
+    comm_abort(ctx);
+    ctx->err = keep;
+    return pre_rc;
+  };
+  if (!m || m->M < 1 || m->d < 1 || hipSetDevice(ctx->device) != hipSuccess) return give_up();
+  const size_t es = m->es, M = size_t(m->M), nz = M * size_t(m->d), nsum = size_t(8 + 1 + grad_dreg(m->d));
+  DevBuf blocks, sums;
+  if (blocks.alloc((nz + M + M * M) * es) != hipSuccess || sums.alloc(nsum * 8) != hipSuccess) return give_up();
+  hipStream_t s = ctx->stream;
+  if (hipMemsetAsync(blocks.p, 0, (nz + M + M * M) * es, s) != hipSuccess || hipMemsetAsync(sums.p, 0, nsum * 8, s) != hipSuccess)
+    return give_up();
+  launch_set2_f64(s, ctx->d_coll, 0.0, 1.0);
+  launch_set_f64(s, static_cast<double*>(sums.p) + 7, 1.0);
+  int rc = comm_allreduce(ctx, ctx->d_coll, 2, SVGP_F64);
+  if (rc == SVGP_OK) rc = comm_group_start(ctx);
+  if (rc == SVGP_OK) {
+    char* b = static_cast<char*>(blocks.p);
+    rc = comm_allreduce(ctx, b, nz, m->dtype);
+    if (rc == SVGP_OK) rc = comm_allreduce(ctx, b + nz * es, M, m->dtype);
+    if (rc == SVGP_OK) rc = comm_allreduce(ctx, b + (nz + M) * es, M * M, m->dtype);
+    if (rc == SVGP_OK) rc = comm_allreduce(ctx, sums.p, nsum, SVGP_F64);
+    const int rce = comm_group_end(ctx);
+    if (rc == SVGP_OK) rc = rce;
+  }
+  if (rc != SVGP_OK || hipStreamSynchronize(s) != hipSuccess) return give_up();   // the buffers die with this scope
+  ctx->err = keep;
+  return pre_rc;
 }
 
 // the gradient's ONE (grouped) all-reduce; a rank whose enqueue failed still takes part with its failure flag set
@@ -1297,8 +1324,14 @@ int elbo_grad_impl(svgp_ctx* ctx, svgp_model* m, const svgp_data* data, int64_t 
   if (rc == SVGP_OK && (!(scale > 0.0) || !(klw >= 0.0))) rc = fail(ctx, SVGP_INVALID_ARG, "scale must be positive and kl_weight non-negative");
   if (rc == SVGP_OK && hipSetDevice(ctx->device) != hipSuccess) rc = fail(ctx, SVGP_HIP_ERROR, "hipSetDevice failed");
   if (rc == SVGP_OK) rc = grad_workspace(ctx, m, len, &gc.w);
-  if (ctx && gc.collective) rc = grad_handshake(ctx, gc, len, rc);
-  if (rc != SVGP_OK) return rc;
+  if (rc != SVGP_OK) return (ctx && gc.collective) ? grad_fail_collective(ctx, m, rc) : rc;
+  if (gc.collective) {
+    rc = grad_handshake(ctx, gc, len);
+    if (rc != SVGP_OK) {   // the opening all-reduce itself could not be issued: nothing sane can follow on this communicator
+      comm_abort(ctx);
+      return rc;
+    }
+  }
   rc = grad_enqueue(ctx, m, data, off, len, gc);
   rc = grad_collective(ctx, m, gc, rc);
   if (rc) return rc;
@@ -1375,13 +1408,8 @@ extern "C" int32_t svgp_elbo_grad_ext(svgp_ctx* ctx, svgp_model* m, const svgp_d
                                       double* elbo_out, svgp_terms* terms_out, svgp_grads* g) {
   if (!ctx) return SVGP_INVALID_ARG;
   if (!g_mu || !g_v) {
-    int rc = fail(ctx, SVGP_INVALID_ARG, "null point gradients");
-    if (ctx->comm) {   // keep the peers' opening handshake matched: they return SVGP_RCCL_ERROR instead of waiting
-      GradCall gc;
-      gc.collective = true;
-      rc = grad_handshake(ctx, gc, len, rc);
-    }
-    return rc;
+    const int rc = fail(ctx, SVGP_INVALID_ARG, "null point gradients");
+    return ctx->comm ? grad_fail_collective(ctx, m, rc) : rc;   // keep the peers' collectives matched: they return SVGP_RCCL_ERROR
   }
   const double scale = len >= 1 ? (num_data > 0 ? num_data : double(len)) / double(len) : 1.0;
   return elbo_grad_impl(ctx, m, data, off, len, scale, 1.0, num_data, true, elbo_out, terms_out, g, g_mu, g_v, sum_e);
@@ -1460,10 +1488,13 @@ int32_t svgp_group_elbo(svgp_group* g, svgp_model* const* models, const svgp_dat
   if (!g || !models || !shards || !offs || !lens) return SVGP_INVALID_ARG;
   const size_t W = g->ctxs.size();
   std::vector<int> rcs(W, SVGP_OK);
+  // one process knows every member: a member that cannot take part is found BEFORE anything is enqueued and nothing touches
+  // the communicator (a failing member used to leave the others' all-reduces waiting for it inside one ncclGroup)
   for (size_t i = 0; i < W; ++i) {
-    rcs[i] = check_batch(g->ctxs[i], models[i], shards[i], offs[i], lens[i], true);
-    if (rcs[i] == SVGP_OK) rcs[i] = elbo_enqueue(g->ctxs[i], models[i], shards[i], offs[i], lens[i]);
+    const int rci = check_batch(g->ctxs[i], models[i], shards[i], offs[i], lens[i], true);
+    if (rci != SVGP_OK) { g->err = svgp_last_error(g->ctxs[i]); return rci; }
   }
+  for (size_t i = 0; i < W; ++i) rcs[i] = elbo_enqueue(g->ctxs[i], models[i], shards[i], offs[i], lens[i]);
   int rc = comm_group_start(g->ctxs[0]);
   if (rc == SVGP_OK) {
     for (size_t i = 0; i < W; ++i) rcs[i] = elbo_collective(g->ctxs[i], rcs[i]);
@@ -1498,14 +1529,21 @@ int32_t svgp_group_elbo_grad(svgp_group* g, svgp_model* const* models, const svg
   if (n_global < 1) return SVGP_INVALID_ARG;
   std::vector<int> rcs(W, SVGP_OK);
   std::vector<GradCall> gcs(W);
+  // validate EVERY member (arguments and gradient workspace) before anything is enqueued: if one cannot join, no member
+  // issues a collective and the error is returned with the communicator untouched (the others used to hang)
+  for (size_t i = 0; i < W; ++i) {
+    int rci = check_batch(g->ctxs[i], models[i], shards[i], offs[i], lens[i], true);
+    if (rci == SVGP_OK && hipSetDevice(g->ctxs[i]->device) != hipSuccess) rci = fail(g->ctxs[i], SVGP_HIP_ERROR, "hipSetDevice failed");
+    if (rci == SVGP_OK) rci = grad_workspace(g->ctxs[i], models[i], lens[i], &gcs[i].w);
+    if (rci != SVGP_OK) { g->err = svgp_last_error(g->ctxs[i]); return rci; }
+  }
   for (size_t i = 0; i < W; ++i) {
     GradCall& gc = gcs[i];
     gc.scale = (num_data > 0 ? num_data : double(n_global)) / double(n_global);
     gc.klw = 1.0 / double(W);
     gc.num_data = num_data;
     gc.collective = false;   // scale known on the host: no batch-size all-reduce
-    rcs[i] = check_batch(g->ctxs[i], models[i], shards[i], offs[i], lens[i], true);
-    if (rcs[i] == SVGP_OK) rcs[i] = grad_enqueue(g->ctxs[i], models[i], shards[i], offs[i], lens[i], gc);
+    rcs[i] = grad_enqueue(g->ctxs[i], models[i], shards[i], offs[i], lens[i], gc);
     gc.collective = true;    // ... but the final reduction and the global bookkeeping of grad_finish apply
   }
   int rc = comm_group_start(g->ctxs[0]);

@@ -95,10 +95,18 @@ struct svgp_group {
   do {                                                                                             \
     hipError_t e_ = (call);                                                                        \
     if (e_ != hipSuccess) {                                                                        \
-      (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e_);                              \
+      (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e_) + svgp::noted();              \
       return (e_ == hipErrorOutOfMemory) ? SVGP_OOM : SVGP_HIP_ERROR;                              \
     }                                                                                              \
   } while (0)
+
+namespace svgp {
+std::string take_note_text();   // prep.hip: the pending host-side diagnosis (device_common.hpp: leave_note), emptied
+inline std::string noted() {
+  const std::string n = take_note_text();
+  return n.empty() ? n : " [" + n + "]";
+}
+}  // namespace svgp
 
 // SVGP_DEBUG_SYNC=1: synchronise and check after every kernel launch, naming the offender.
 inline bool debug_sync() {
@@ -110,7 +118,7 @@ inline bool debug_sync() {
     hipError_t e_ = hipGetLastError();                                                             \
     if (e_ == hipSuccess && debug_sync()) e_ = hipStreamSynchronize((ctx)->stream);                \
     if (e_ != hipSuccess) {                                                                        \
-      (ctx)->err = std::string("kernel ") + name + ": " + hipGetErrorString(e_);                   \
+      (ctx)->err = std::string("kernel ") + name + ": " + hipGetErrorString(e_) + svgp::noted();   \
       return SVGP_HIP_ERROR;                                                                       \
     }                                                                                              \
   } while (0)

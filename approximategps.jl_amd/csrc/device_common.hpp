@@ -7,14 +7,49 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
-#include <stdio.h>
+
+#include <mutex>
+#include <string>
+#include <vector>
 
 namespace svgp {
 
-// allow a kernel to use up to the whole 160 KiB LDS of a CU as dynamic shared memory
+// A note for the next error message of the calling context (the library never prints: include/svgp_mi355x.h).  Host-side
+// helpers that have no context at hand (set_max_lds, the SVGP_DEBUG_SYNC checks of prep.hip) leave their diagnosis here;
+// KCHECK / HIPC in ctx.hpp append it to svgp_last_error() when the launch they guard fails.
+inline std::mutex& note_mutex() { static std::mutex m; return m; }
+inline std::string& note_text() { static std::string s; return s; }
+inline void leave_note(const std::string& s) {
+  std::lock_guard<std::mutex> g(note_mutex());
+  if (note_text().size() < 2048) note_text() += (note_text().empty() ? "" : "; ") + s;
+}
+inline std::string take_note() {
+  std::lock_guard<std::mutex> g(note_mutex());
+  std::string s;
+  s.swap(note_text());
+  return s;
+}
+
+// allow a kernel to use up to the whole 160 KiB LDS of a CU as dynamic shared memory.  hipFuncSetAttribute is issued ONCE
+// per (kernel, device) and size - not on every launch (it takes a lock inside the runtime): the largest size
+// set so far is remembered, a launch that needs no more than that costs one mutex and a short scan.
 inline void set_max_lds(const void* fn, hipFuncAttribute attr, int bytes) {
-  hipError_t e = hipFuncSetAttribute(fn, attr, bytes);
-  if (e != hipSuccess) fprintf(stderr, "[svgp] hipFuncSetAttribute(%d bytes) failed: %s\n", bytes, hipGetErrorString(e));
+  struct Entry { const void* fn; int dev; int bytes; };
+  static std::mutex mu;
+  static std::vector<Entry> seen;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  std::lock_guard<std::mutex> g(mu);
+  for (Entry& e : seen)
+    if (e.fn == fn && e.dev == dev) {
+      if (bytes <= e.bytes) return;
+      if (hipFuncSetAttribute(fn, attr, bytes) == hipSuccess) e.bytes = bytes;
+      else leave_note("hipFuncSetAttribute(" + std::to_string(bytes) + " bytes of LDS) failed");
+      return;
+    }
+  const hipError_t err = hipFuncSetAttribute(fn, attr, bytes);
+  if (err == hipSuccess) seen.push_back(Entry{fn, dev, bytes});
+  else leave_note(std::string("hipFuncSetAttribute(") + std::to_string(bytes) + " bytes of LDS) failed: " + hipGetErrorString(err));
 }
 
 constexpr int kWave = 64;

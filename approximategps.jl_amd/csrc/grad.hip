@@ -64,6 +64,7 @@ __global__ void __launch_bounds__(k256) grad_moments_kernel(LikParams lp, double
 }
 
 __global__ void set_f64_kernel(double* dst, double value) { *dst = value; }
+__global__ void set2_f64_kernel(double* dst, double a, double b) { dst[0] = a; dst[1] = b; }
 __global__ void grad_status_kernel(double* sums, const int* chol_info, double n_points) {
   sums[5] = n_points;
   sums[6] = (chol_info && *chol_info != 0) ? 1.0 : 0.0;
@@ -636,6 +637,7 @@ int grad_dreg(int d) { return d <= 8 ? 8 : (d <= 16 ? 16 : 32); }
 int grad_rowblocks(int d, int64_t Mp) { return int(d <= 16 ? Mp / 128 : Mp / 64); }
 
 void launch_set_f64(hipStream_t s, double* dst, double value) { hipLaunchKernelGGL(set_f64_kernel, dim3(1), dim3(1), 0, s, dst, value); }
+void launch_set2_f64(hipStream_t s, double* dst, double a, double b) { hipLaunchKernelGGL(set2_f64_kernel, dim3(1), dim3(1), 0, s, dst, a, b); }
 void launch_grad_status(hipStream_t s, double* sums, const int* chol_info, double n_points) {
   hipLaunchKernelGGL(grad_status_kernel, dim3(1), dim3(1), 0, s, sums, chol_info, n_points);
 }

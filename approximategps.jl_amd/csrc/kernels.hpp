@@ -139,6 +139,7 @@ void launch_grad_moments(int dtype, hipStream_t s, const LikParams& lp, double s
                          double num_data, const double* mom_mu, const double* mom_var, const void* y, int64_t off,
                          int64_t len, int64_t npad, void* gmu, void* gv, double* partial, double* sums);
 void launch_set_f64(hipStream_t s, double* dst, double value);
+void launch_set2_f64(hipStream_t s, double* dst, double a, double b);   // dst[0] = a, dst[1] = b (values travel as kernel arguments: no host buffer to outlive)
 // sums[5] = n_points, sums[6] = (*chol_info != 0), sums[7] = 0: the status slots of the all-reduced gradient scalars
 void launch_grad_status(hipStream_t s, double* sums, const int* chol_info, double n_points);
 void launch_abar(int dtype, hipStream_t s, const void* Lqp, const void* C, const void* A, const void* mp, const void* gmu,

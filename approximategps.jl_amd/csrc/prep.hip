@@ -9,7 +9,6 @@
 #include "device_common.hpp"
 #include "kernels.hpp"
 
-#include <cstdio>
 #include <cstdlib>
 
 namespace svgp {
@@ -663,7 +662,7 @@ void dbg(const char* name, hipStream_t s) {
   if (!on) return;
   hipError_t e = hipPeekAtLastError();
   if (e == hipSuccess) e = hipStreamSynchronize(s);
-  if (e != hipSuccess) fprintf(stderr, "[svgp debug] %s: %s\n", name, hipGetErrorString(e));
+  if (e != hipSuccess) leave_note(std::string("SVGP_DEBUG_SYNC: ") + name + ": " + hipGetErrorString(e));   // -> svgp_last_error
 }
 
 template <typename T>
@@ -706,6 +705,9 @@ void tpanels_t(hipStream_t s, const T* L, T* Tm, int64_t Mp) {
 }
 
 }  // namespace
+
+// ctx.hpp's error macros (host-only translation units) fetch the pending note through this
+std::string take_note_text() { return take_note(); }
 
 #define SVGP_DISPATCH(dtype, expr_d, expr_f) \
   do {                                       \

@@ -140,8 +140,14 @@ int32_t svgp_last_timing(const svgp_ctx* ctx, svgp_timing* out);
  *
  * One process per GPU: rank 0 calls svgp_comm_unique_id, the host transports the 128 bytes to every rank
  * (MPI / torch.distributed / Distributed.jl), every rank calls svgp_ctx_attach_comm on its own context
- * (collective: ncclCommInitRank).  A rank that fails locally still enters the collective with a failure flag,
- * so its peers return SVGP_RCCL_ERROR instead of waiting for it. */
+ * (collective: ncclCommInitRank).  A rank that fails locally (bad arguments, allocation failure, HIP error) still enters
+ * every collective of the call - with zero contributions and a failure flag - so its peers return SVGP_RCCL_ERROR
+ * instead of waiting for it; svgp_elbo_host does so too when it fails before it reaches svgp_elbo.  The exceptions are
+ * FATAL for the job: a rank that was handed a NULL model (the element counts of the gradient all-reduce are unknown to it)
+ * or that cannot even allocate the zero contributions aborts its communicator (ncclCommAbort), which does NOT wake its
+ * peers - they stay inside the collective and the process group has to be torn down from outside.  The one-process
+ * group calls (svgp_group_elbo / svgp_group_elbo_grad) validate every member before anything is enqueued and return the
+ * first member's error without touching the communicator. */
 #define SVGP_COMM_ID_BYTES 128
 int32_t svgp_comm_unique_id(void* id_out /* SVGP_COMM_ID_BYTES */);
 int32_t svgp_ctx_attach_comm(svgp_ctx* ctx, const void* id, int32_t world_size, int32_t rank);

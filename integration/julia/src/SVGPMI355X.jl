@@ -88,9 +88,24 @@ function ctx()
         dev = parse(Int32, get(ENV, "SVGP_MI355X_DEVICE", "0"))
         st = ccall((:svgp_ctx_create, lib), Int32, (Int32, Ptr{Cvoid}, Ptr{Ptr{Cvoid}}), dev, C_NULL, CTX)
         st == 0 || error("svgp_ctx_create failed with status $st")
-        atexit(() -> ccall((:svgp_ctx_destroy, lib), Int32, (Ptr{Cvoid},), CTX[]))
+        # finalizers of DeviceData / DeviceModel run AFTER atexit hooks: the hook clears CTX[] and they skip a dead context
+        atexit() do
+            c = CTX[]
+            CTX[] = C_NULL
+            c == C_NULL || ccall((:svgp_ctx_destroy, lib), Int32, (Ptr{Cvoid},), c)
+        end
     end
     return CTX[]
+end
+"free a handle on the live context; after the atexit hook destroyed the context the device memory is gone with it"
+free_on_ctx(sym::Symbol, h::Ptr{Cvoid}) = (CTX[] == C_NULL || h == C_NULL) ? Int32(0) :
+    (sym === :data ? ccall((:svgp_data_free, lib), Int32, (Ptr{Cvoid}, Ptr{Cvoid}), CTX[], h) :
+                     ccall((:svgp_model_free, lib), Int32, (Ptr{Cvoid}, Ptr{Cvoid}), CTX[], h))
+"size of the library communicator on the context (1 without one)"
+function comm_world()
+    w = Ref{Int32}(1)
+    ccall((:svgp_ctx_comm_info, lib), Int32, (Ptr{Cvoid}, Ref{Int32}, Ptr{Int32}), ctx(), w, C_NULL)
+    return Int(w[])
 end
 last_error() = unsafe_string(ccall((:svgp_last_error, lib), Cstring, (Ptr{Cvoid},), ctx()))
 
@@ -266,8 +281,12 @@ function elbo_and_grads(sva, lfx, y, num_data, quadrature, want::Bool, config=no
         if p.ext
             # host-evaluated likelihood: marginals from the device, SVA:355 here, the backward pass on the device again
             want && config === nothing && return nothing
+            # data-parallel contexts: the forward value of this route (svgp_marginals + svgp_prior_kl) is this rank's shard only,
+            # while svgp_elbo_grad_ext is collective - value and gradient would disagree; decline (the Julia body runs)
+            comm_world() > 1 && return nothing
             hm, hd = Ref{Ptr{Cvoid}}(C_NULL), Ref{Ptr{Cvoid}}(C_NULL)
             μ, v = zeros(Float64, n), zeros(Float64, n)
+            try   # the user's likelihood / AD may throw: the handles are freed on every path
             st = ccall((:svgp_model_create, lib), Int32, (Ptr{Cvoid}, Ref{ModelDesc}, Ptr{Ptr{Cvoid}}), ctx(), p.desc, hm)
             if st == 0
                 st = ccall((:svgp_data_upload, lib), Int32,
@@ -292,8 +311,10 @@ function elbo_and_grads(sva, lfx, y, num_data, quadrature, want::Bool, config=no
                     out[] = sumE * Float64(num_data) / n - kl[]                       # SVA:357-359
                 end
             end
-            ccall((:svgp_data_free, lib), Int32, (Ptr{Cvoid}, Ptr{Cvoid}), ctx(), hd[])
-            ccall((:svgp_model_free, lib), Int32, (Ptr{Cvoid}, Ptr{Cvoid}), ctx(), hm[])
+            finally
+                free_on_ctx(:data, hd[])
+                free_on_ctx(:model, hm[])
+            end
         elseif !want
             # one-shot entry point: uploads x, y, evaluates, frees (resident handles below avoid the upload in loops)
             st = ccall((:svgp_elbo_host, lib), Int32,
@@ -516,7 +537,7 @@ function DeviceData(x, y::AbstractVector{T}) where {T<:FT}
         (Ptr{Cvoid}, Int32, Int32, Int32, Int64, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Ptr{Cvoid}}),
         ctx(), T === Float64 ? 0 : 1, lx, d, length(yd), Xd, yd, h))
     D = DeviceData(h[], length(yd))
-    finalizer(D -> ccall((:svgp_data_free, lib), Int32, (Ptr{Cvoid}, Ptr{Cvoid}), ctx(), D.h), D)
+    finalizer(D -> free_on_ctx(:data, D.h), D)
     return D
 end
 
@@ -527,7 +548,7 @@ function DeviceModel(p::Packed)
     h = Ref{Ptr{Cvoid}}()
     GC.@preserve p check(ccall((:svgp_model_create, lib), Int32, (Ptr{Cvoid}, Ref{ModelDesc}, Ptr{Ptr{Cvoid}}), ctx(), p.desc, h))
     M = DeviceModel(h[])
-    finalizer(M -> ccall((:svgp_model_free, lib), Int32, (Ptr{Cvoid}, Ptr{Cvoid}), ctx(), M.h), M)
+    finalizer(M -> free_on_ctx(:model, M.h), M)
     return M
 end
 update!(M::DeviceModel, p::Packed) =
@@ -546,7 +567,8 @@ end
 # multi-GPU from ONE Julia process (svgp_group_*): data sharded over the devices, model replicated, the partial sums of
 # SVA:355-359 combined by ONE ncclAllReduce inside the library.  (One process per GPU instead: svgp_comm_unique_id on
 # rank 0, the 128 bytes sent with MPI.jl / Distributed.jl, svgp_ctx_attach_comm on every rank; `try_elbo` is then
-# collective and needs no further change.)
+# collective for the enumerated likelihoods and needs no further change; the host-evaluated-likelihood route declines under a
+# communicator - its forward value would be this rank's shard only.)
 # ---------------------------------------------------------------------------------------------------------
 mutable struct Group
     h::Ptr{Cvoid}; n::Int

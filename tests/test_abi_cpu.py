@@ -113,3 +113,18 @@ def test_struct_layouts_match_the_julia_binding():
     # field order of the Julia struct = field order of the ctypes struct
     jl_fields = re.findall(r"(\w+)::(?:Int32|Int64|Float64|Ptr\{\w+\})", src[src.index("struct ModelDesc"):src.index("mutable struct Terms")])
     assert jl_fields == [f[0] for f in _ffi.ModelDesc._fields_]
+
+
+def test_library_never_prints():
+    """include/svgp_mi355x.h: the library "never throws, aborts, prints or calls back into the host language".  Round 2 still
+    had two fprintf(stderr, "[svgp...") diagnostics; they now travel through svgp_last_error.  Checked on the built .so: no
+    such format string, and no stdio output function among its undefined symbols."""
+    import subprocess
+
+    from approxgp import _ffi
+
+    blob = open(_ffi.LIB_PATH, "rb").read()
+    assert b"[svgp" not in blob
+    nm = subprocess.run(["nm", "-D", "--undefined-only", _ffi.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    used = {ln.split()[-1].split("@")[0] for ln in nm.splitlines() if ln.strip()}
+    assert not (used & {"printf", "fprintf", "puts", "fputs", "perror", "vfprintf", "fwrite", "putchar"}), used

@@ -164,3 +164,69 @@ def test_group_of_one_device_matches_plain_context(dtype):
     for h in (grp2, grp, model, data):
         (h.close if hasattr(h, "close") else h.free)()
     ctx.close()
+
+
+def test_group_member_with_a_bad_window_fails_before_any_collective():
+    """one member of a one-process group failing its local checks used to leave the others' all-reduces waiting
+    inside the same ncclGroup.  Now every member is validated first: the error comes back, nothing was enqueued, and the
+    group is still usable."""
+    for p in (os.path.join(ROOT, "approximategps.jl_amd"), os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    from approxgp import _ffi
+    from helpers import desc_from_oracle
+
+    x, y, sva, s2 = _problem(False)
+    grp = _ffi.Group([0])
+    grp.upload(x, y, np.float64)
+    desc, keep = desc_from_oracle(sva, sigma2=s2)
+    grp.create_model(desc, keep)
+    ref = grp.elbo(num_data=12000.0)[0]
+    gref = grp.elbo_grad(offs=[0], lens=[2000], num_data=12000.0)[0]
+    with pytest.raises((ValueError, _ffi.SvgpError)):
+        grp.elbo(offs=[2900], lens=[500], num_data=12000.0)          # window past the shard
+    with pytest.raises((ValueError, _ffi.SvgpError)):
+        grp.elbo_grad(offs=[2900], lens=[500], num_data=12000.0)
+    with pytest.raises((ValueError, _ffi.SvgpError)):
+        grp.elbo_grad(offs=[0], lens=[0], num_data=12000.0)          # empty batch
+    assert grp.elbo(num_data=12000.0)[0] == ref
+    assert grp.elbo_grad(offs=[0], lens=[2000], num_data=12000.0)[0] == gref
+    grp.close()
+
+
+def test_one_shot_host_entry_keeps_the_collective_matched():
+    """svgp_elbo_host on a context with a communicator returned straight away when the model or the upload failed,
+    leaving its peers in ncclAllReduce.  It now joins the all-reduce with the failure flag; with a world of one the call
+    returns its own error and the communicator stays usable."""
+    for p in (os.path.join(ROOT, "approximategps.jl_amd"), os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import ctypes as C
+
+    import svgp_oracle as o
+    from approxgp import _ffi
+    from helpers import desc_from_oracle, device_model
+
+    x, y, sva, s2 = _problem(False)
+    ctx = _ffi.Context(0)
+    ctx.attach_comm(_ffi.comm_unique_id(), 1, 0)
+    desc, keep = desc_from_oracle(sva, sigma2=s2)
+    lib = ctx.lib
+    out, terms = C.c_double(), _ffi.Terms()
+    xs, ys = np.ascontiguousarray(x.T.ravel()), np.ascontiguousarray(y)   # ColVecs: point-contiguous
+    good = lib.svgp_elbo_host(ctx.h, C.byref(desc), _ffi.COLVECS, x.shape[1], xs.ctypes.data, ys.ctypes.data, 0.0, C.byref(out), C.byref(terms))
+    assert good == _ffi.OK
+    assert abs(out.value - o.elbo(sva, x, y, sigma2=s2)) <= 1e-8 * abs(out.value)
+    desc.kernel = 17                                                      # unsupported family: model creation fails
+    rc = lib.svgp_elbo_host(ctx.h, C.byref(desc), _ffi.COLVECS, x.shape[1], xs.ctypes.data, ys.ctypes.data, 0.0, C.byref(out), C.byref(terms))
+    assert rc == _ffi.UNSUPPORTED
+    desc.kernel = sva.kernel.family
+    again = C.c_double()
+    assert lib.svgp_elbo_host(ctx.h, C.byref(desc), _ffi.COLVECS, x.shape[1], xs.ctypes.data, ys.ctypes.data, 0.0, C.byref(again), C.byref(terms)) == _ffi.OK
+    assert again.value == out.value
+    model = device_model(ctx, sva, sigma2=s2)                             # and the collective calls still work
+    data = _ffi.DeviceData(ctx, x, y, np.float64)
+    assert abs(model.elbo(data, 0, None, 0.0)[0] - out.value) <= 1e-12 * abs(out.value)
+    model.free()
+    data.free()
+    ctx.close()

@@ -412,3 +412,29 @@ def test_gradient_degenerate_shapes(ctx, N, M, d):
         assert abs(g["variance"] - g_ref["variance"]) <= gt * max(abs(g_ref["variance"]), 1e-6)
         model.free()
         data.free()
+
+
+def test_gradient_workspace_reused_across_models_of_different_m(ctx):
+    """the gradient workspace is cached by (dtype, Mp, d); a model with the same Mp but a larger M (40 then 120, both
+    Mp = 128) reused buffers sized for the smaller one.  A fresh context evaluates the small model FIRST, then the large one -
+    its gradient must equal the oracle's and the small model's must be unchanged when re-evaluated afterwards."""
+    c = _ffi.Context(0)
+    try:
+        out = {}
+        for M in (40, 120, 40):
+            x, y, sva, s2 = o.synth_problem(900 + M, 700, M, 3, family=o.KERNEL_MATERN52)
+            val_ref, g_ref = o.elbo_grad(sva, x, y, sigma2=s2, num_data=2000.0)
+            model = device_model(c, sva, sigma2=s2)
+            data = _ffi.DeviceData(c, x, y, np.float64)
+            val, _, g = model.elbo_grad(data, 0, 700, 2000.0)
+            assert rel(val, val_ref) < 1e-8
+            for k in ("m", "Lq", "inv_lengthscale"):
+                _close(g[k], g_ref[k], 1e-6)
+            _close(g["z"].reshape(g_ref["z"].shape, order="F"), g_ref["z"], 1e-6)
+            if M in out:   # the second visit of M = 40 reproduces the first bit for bit
+                assert val == out[M][0] and np.array_equal(np.asarray(g["Lq"]), out[M][1])
+            out[M] = (val, np.asarray(g["Lq"]).copy())
+            model.free()
+            data.free()
+    finally:
+        c.close()
