@@ -5,8 +5,8 @@
     sva = SparseVariationalApproximation(f(z, 1e-5), MvNormal.from_cholesky(m, A))
     elbo(sva, f(x, 0.3), y, num_data=N); posterior(sva).mean_and_var(xs)
 """
-from ._ffi import (Context, DeviceData, DeviceModel, DomainError, PosDefException, SvgpError, UnsupportedError,
-                   default_context, gausshermite, load_library)
+from ._ffi import (Context, DeclinedError, DeviceData, DeviceModel, DomainError, PosDefException, SvgpError, UnsupportedError,
+                   default_context, gausshermite, load_library, offload_advice, offload_work)
 from .gp import (GP, BernoulliLikelihood, DefaultExpectationMethod, FiniteGP, GaussHermiteExpectation,
                  GaussianLikelihood, LatentFiniteGP, LatentGP, MvNormal, PoissonLikelihood, ExponentialLikelihood,
                  GammaLikelihood, CallerLikelihood, LogisticLink, NormalCDFLink, ProbitLink)

@@ -80,6 +80,8 @@ SYMBOLS = {
     "svgp_predict_cross_cov": (C.c_int32, [_P, _P, C.c_int32, C.c_int64, _P, C.c_int64, _P, _P]),
     "svgp_kuf": (C.c_int32, [_P, _P, _P, C.c_int64, C.c_int64, _P]),
     "svgp_gausshermite": (C.c_int32, [C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "svgp_offload_advice": (C.c_int32, [C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_int32]),
+    "svgp_offload_work": (C.c_double, [C.c_int64, C.c_int64, C.c_int32]),
     # multi-GPU
     "svgp_comm_unique_id": (C.c_int32, [_P]),
     "svgp_ctx_attach_comm": (C.c_int32, [_P, _P, C.c_int32, C.c_int32]),
@@ -135,6 +137,20 @@ class PosDefException(SvgpError):
 
 class DomainError(SvgpError):
     pass
+
+
+class DeclinedError(SvgpError):
+    """The problem is below the library's offload threshold (svgp_offload_advice): the Julia hooks return `nothing` here and
+    the reference's own method body runs; the Python mirror has no host path to fall back to and says so."""
+
+
+def offload_advice(n_points: int, M: int, d: int, dtype=F64, want_gradient=False) -> bool:
+    """True when a problem of this size is worth sending to the device (include/svgp_mi355x.h: svgp_offload_advice)."""
+    return bool(load_library().svgp_offload_advice(int(n_points), int(M), int(d), int(dtype), int(bool(want_gradient))))
+
+
+def offload_work(n_points: int, M: int, d: int) -> float:
+    return float(load_library().svgp_offload_work(int(n_points), int(M), int(d)))
 
 
 class UnsupportedError(SvgpError):

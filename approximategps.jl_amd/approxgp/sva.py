@@ -95,8 +95,25 @@ def _desc(sva: SparseVariationalApproximation, lik=None, quadrature=None, dtype=
 # ------------------------------------------------------------------------------------------------
 # elbo / approx_lml
 # ------------------------------------------------------------------------------------------------
+def _decline_if_small(sva, lfx, y, small_problems, want_grad):
+    """The rule of the Julia hooks (try_elbo / the rrule return `nothing` and the reference's own body runs): below the
+    library's offload threshold (svgp_offload_advice; measured crossover, include/svgp_mi355x.h) the device is slower than the
+    host.  The mirror has no host path, so it only applies the rule on request (`small_problems="decline"`) and then raises."""
+    if small_problems == "run":
+        return
+    if small_problems != "decline":
+        raise ValueError('small_problems must be "run" or "decline"')
+    z = np.asarray(sva.fz.x)
+    d, M = (1, z.shape[0]) if z.ndim == 1 else z.shape
+    n = np.asarray(y).shape[0]
+    if not _ffi.offload_advice(n, M, d, want_gradient=want_grad):
+        raise _ffi.DeclinedError(f"n = {n}, M = {M}, d = {d}: work {_ffi.offload_work(n, M, d):.3g} is below the offload "
+                                 "threshold (SVGP_OFFLOAD_MIN_WORK, default 3e6); the Julia binding runs the reference's own "
+                                 "method here")
+
+
 def elbo(sva: SparseVariationalApproximation, fx, y, *, num_data=None, quadrature=None, ctx=None, dtype=None,
-         return_terms=False):
+         return_terms=False, small_problems="run"):
     """elbo(sva, fx::FiniteGP | lfx::LatentFiniteGP, y; num_data=length(y), quadrature=DefaultExpectationMethod())
 
     FiniteGP method (SVA:307-317): Gaussian likelihood with σ² = fx.Σy[1]; non-isotropic noise raises the
@@ -114,6 +131,7 @@ def elbo(sva: SparseVariationalApproximation, fx, y, *, num_data=None, quadratur
         raise TypeError("elbo expects a FiniteGP or a LatentFiniteGP")
     if sva.fz.f is not lfx.fx.f:  # SVA:347-351
         raise ValueError("(Latent)FiniteGP prior is not consistent with SparseVariationalApproximation's")
+    _decline_if_small(sva, lfx, y, small_problems, False)
     ctx = ctx or _ffi.default_context()
     if isinstance(lfx.lik, CallerLikelihood):
         return _elbo_host_likelihood(sva, lfx, y, num_data, quadrature, ctx, dtype, False)[0]
@@ -154,7 +172,8 @@ def _elbo_host_likelihood(sva, lfx, y, num_data, quadrature, ctx, dtype, want_gr
         data.free()
 
 
-def elbo_and_gradient(sva: SparseVariationalApproximation, fx, y, *, num_data=None, quadrature=None, ctx=None, dtype=None):
+def elbo_and_gradient(sva: SparseVariationalApproximation, fx, y, *, num_data=None, quadrature=None, ctx=None, dtype=None,
+                      small_problems="run"):
     """ELBO and its gradient w.r.t. (kernel variance, inverse lengthscales, inducing inputs z, mean(q) m, the lower factor
     Lq of cov(q), Gaussian noise σ², ConstMean) — what `Zygote.gradient(-elbo, ...)` yields for the reference's training
     loops (examples/a-regression/script.jl:188-194); the Julia shim wraps it as a ChainRulesCore.rrule."""
@@ -166,6 +185,7 @@ def elbo_and_gradient(sva: SparseVariationalApproximation, fx, y, *, num_data=No
         lfx = fx
     if sva.fz.f is not lfx.fx.f:
         raise ValueError("(Latent)FiniteGP prior is not consistent with SparseVariationalApproximation's")
+    _decline_if_small(sva, lfx, y, small_problems, True)
     ctx = ctx or _ffi.default_context()
     if isinstance(lfx.lik, CallerLikelihood):
         return _elbo_host_likelihood(sva, lfx, y, num_data, quadrature, ctx, dtype, True)

@@ -519,6 +519,22 @@ int32_t svgp_gausshermite(int32_t n, double* nodes_out, double* weights_out) {
   return gauss_hermite(n, nodes_out, weights_out);
 }
 
+// work(n, M, d) of one evaluation in host flops (2 M^2 n for trsm + trmm, M^3 / 3 for the Cholesky, plus
+// the Kuf assembly and the elementwise reductions the reference materialises, ~ (3 d + 30) per element of Kuf)
+double svgp_offload_work(int64_t n, int64_t M, int32_t d) {
+  if (n < 0 || M < 0 || d < 0) return 0.0;
+  const double nd = double(n), Md = double(M);
+  return nd * Md * (2.0 * Md + 3.0 * double(d) + 30.0) + Md * Md * Md / 3.0;
+}
+
+int32_t svgp_offload_advice(int64_t n, int64_t M, int32_t d, int32_t /*dtype*/, int32_t /*want_gradient*/) {
+  // One threshold for both forms: the device floor of a value-and-gradient call is ~2.5x the forward floor (600 vs 250 us
+  // through the one-shot route), and so is the host's reverse-mode cost (profiles/round3/small_problems.md)
+  const char* e = getenv("SVGP_OFFLOAD_MIN_WORK");   // read on every call: hosts (and the tests) change it at run time
+  const double min_work = e ? atof(e) : 3.0e6;
+  return svgp_offload_work(n, M, d) >= min_work ? 1 : 0;
+}
+
 int32_t svgp_ctx_create(int32_t device_id, void* stream, svgp_ctx** out) {
   if (!out) return SVGP_INVALID_ARG;
   *out = nullptr;

@@ -277,6 +277,19 @@ int32_t svgp_kuf(svgp_ctx* ctx, svgp_model* model, const svgp_data* data, int64_
 /* ---- Gauss–Hermite rule used by GH-n (FastGaussQuadrature.gausshermite) ---------------------- */
 int32_t svgp_gausshermite(int32_t n, double* nodes_out, double* weights_out);
 
+/* ---- small problems: is the device worth calling? -----------------------------------------------
+ * The reference's own workloads are tiny (examples/a-regression/script.jl:33,69,176: N = 10 000, M = 20, minibatch 100;
+ * test/SparseVariationalApproximationModule.jl: N <= 100).  A call into this library has a floor that does not depend on the
+ * problem - measured on MI355X (profiles/round3/small_problems.md): 160-180 us for svgp_elbo on resident data, ~250 us for the
+ * one-shot svgp_elbo_host the un-modified `elbo(sva, lfx, y)` reaches through the hook, ~600 us for value-and-gradient - while
+ * the host path costs about 1e-10 s per unit of  work(n, M, d) = n M (2 M + 3 d + 30) + M^3 / 3.  Returns 1 when
+ * work >= SVGP_OFFLOAD_MIN_WORK (default 3e6: the measured crossover), else 0; the hooks of the Julia binding (try_elbo,
+ * try_posterior, try_predict, the rrule) and the Python mirror decline below it and the pure-Julia method body runs.
+ * The environment variable SVGP_OFFLOAD_MIN_WORK overrides the threshold (0: always offload).  Advice only: the explicit
+ * resident-handle calls (svgp_elbo, svgp_elbo_grad, ...) never refuse a problem for being small.  No context, no GPU needed. */
+int32_t svgp_offload_advice(int64_t n_points, int64_t M, int32_t d, int32_t dtype, int32_t want_gradient);
+double svgp_offload_work(int64_t n_points, int64_t M, int32_t d);
+
 #ifdef __cplusplus
 }
 #endif

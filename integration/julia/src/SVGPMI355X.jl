@@ -101,6 +101,15 @@ end
 free_on_ctx(sym::Symbol, h::Ptr{Cvoid}) = (CTX[] == C_NULL || h == C_NULL) ? Int32(0) :
     (sym === :data ? ccall((:svgp_data_free, lib), Int32, (Ptr{Cvoid}, Ptr{Cvoid}), CTX[], h) :
                      ccall((:svgp_model_free, lib), Int32, (Ptr{Cvoid}, Ptr{Cvoid}), CTX[], h))
+"""
+`worth_offloading(n, M, d; grad=false)`: the library's own small-problem rule (`svgp_offload_advice`, include/svgp_mi355x.h).
+A call has a floor of 160-250 us (forward) / ~600 us (value and gradient) whatever the size (profiles/round3/small_problems.md);
+the reference's own examples (N = 10 000, M = 20, minibatch 100) sit below the crossover, so every hook declines there and the
+pure-Julia method runs.  `ENV["SVGP_OFFLOAD_MIN_WORK"] = "0"` offloads everything.
+"""
+worth_offloading(n::Integer, M::Integer, d::Integer; grad::Bool=false) =
+    ccall((:svgp_offload_advice, lib), Int32, (Int64, Int64, Int32, Int32, Int32), n, M, d, 0, grad ? 1 : 0) == 1
+
 "size of the library communicator on the context (1 without one)"
 function comm_world()
     w = Ref{Int32}(1)
@@ -269,6 +278,7 @@ function elbo_and_grads(sva, lfx, y, num_data, quadrature, want::Bool, config=no
         return nothing
     end
     dx == p.desc.d || return nothing
+    worth_offloading(length(y), length(p.m), Int(p.desc.d); grad=want) || return nothing   # small problems: the Julia body is faster
     Xd, yd = Array{T}(X), Vector{T}(y)
     n = length(yd)
     out, terms = Ref{Float64}(), Terms()
@@ -419,6 +429,7 @@ function MI355XHooks.try_posterior(sva::SparseVariationalApproximation{P}) where
         return nothing
     end
     M = length(p.m)
+    worth_offloading(0, M, Int(p.desc.d)) || return nothing    # posterior(sva) is M-sized work only: M^3 / 3 against the call's floor
     Lk, α, B = Matrix{T}(undef, M, M), Vector{T}(undef, M), Matrix{T}(undef, M, M)
     hm = Ref{Ptr{Cvoid}}(C_NULL)
     st = Int32(0)
@@ -461,6 +472,7 @@ function MI355XHooks.try_predict(f::ApproxPosteriorGP, x::AbstractVector; want_m
     end
     dx == p.desc.d || return nothing
     n = length(x)
+    worth_offloading(n, length(p.m), Int(p.desc.d)) || return nothing
     Xd = Array{T}(X)
     μ = want_mean ? Vector{T}(undef, n) : nothing
     v = want_var ? Vector{T}(undef, n) : nothing
@@ -502,6 +514,7 @@ function MI355XHooks.try_cross_cov(f::ApproxPosteriorGP, x::AbstractVector, y::A
     end
     dx == p.desc.d || return nothing
     nx, ny = length(x), length(y)
+    worth_offloading(nx + ny, length(p.m), Int(p.desc.d)) || return nothing
     Xd, Yd = Array{T}(X), Array{T}(Y)
     C = Matrix{T}(undef, nx, ny)
     hm = Ref{Ptr{Cvoid}}(C_NULL)

@@ -9,6 +9,9 @@ using ApproximateGPs, AbstractGPs, KernelFunctions, GPLikelihoods, Distributions
 using PDMats: PDMat
 using StatsFuns: normcdf
 const MI = ApproximateGPs.SVGPMI355X
+# the problems below are small on purpose (the reference's own test sizes): without this the hooks would decline them all
+# (svgp_offload_advice, the small-problem rule) and every comparison would be Julia against Julia
+ENV["SVGP_OFFLOAD_MIN_WORK"] = "0"
 
 @testset "struct layouts = include/svgp_mi355x.h = approxgp/_ffi.py" begin
     @test sizeof(MI.ModelDesc) == 104 && fieldoffset(MI.ModelDesc, 9) == 32 && fieldoffset(MI.ModelDesc, 17) == 96
@@ -36,6 +39,17 @@ function problem(rng, T; N=400, M=24, d=3, base=SqExponentialKernel(), centered=
         return f, sva
     end
     return x, y, θ, build, lik
+end
+
+@testset "small problems are declined below the measured crossover" begin
+    withenv("SVGP_OFFLOAD_MIN_WORK" => nothing) do
+        @test !MI.worth_offloading(100, 20, 1) && !MI.worth_offloading(100, 20, 1; grad=true)   # examples/a-regression minibatch
+        @test MI.worth_offloading(10_000, 20, 1) && MI.worth_offloading(1000, 32, 1)
+        rng = MersenneTwister(1)
+        x, y, θ, build, lik = problem(rng, Float64; N=100, M=20, d=1)
+        f, sva = build(θ)
+        @test ApproximateGPs.MI355XHooks.try_elbo(sva, LatentGP(f, lik, 1e-18)(x), y, 100, GPLikelihoods.DefaultExpectationMethod()) === nothing
+    end
 end
 
 @testset "elbo / approx_lml: device == reference body ($T, centered = $cen, $(nameof(typeof(lik))))" for

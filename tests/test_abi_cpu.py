@@ -128,3 +128,26 @@ def test_library_never_prints():
     nm = subprocess.run(["nm", "-D", "--undefined-only", _ffi.LIB_PATH], capture_output=True, text=True, check=True).stdout
     used = {ln.split()[-1].split("@")[0] for ln in nm.splitlines() if ln.strip()}
     assert not (used & {"printf", "fprintf", "puts", "fputs", "perror", "vfprintf", "fwrite", "putchar"}), used
+
+
+def test_small_problems_are_declined_below_the_measured_crossover():
+    """the reference's own workloads (examples/a-regression: minibatch 100, M = 20; its tests: N <= 100) sit
+    below the device's per-call floor.  svgp_offload_advice holds the measured rule (profiles/round3/small_problems.md); the Julia
+    hooks return `nothing` below it, the Python mirror raises DeclinedError on request - both without touching a GPU."""
+    assert not approxgp.offload_advice(100, 20, 1)                 # examples/a-regression/script.jl:69,176: minibatch 100, M = 20
+    assert not approxgp.offload_advice(100, 20, 1, want_gradient=True)
+    assert not approxgp.offload_advice(50, 10, 1)                  # the reference's test problems
+    assert approxgp.offload_advice(10_000, 20, 1)                  # the same example, full data set: 273 us here vs 1.5 ms on the host
+    assert approxgp.offload_advice(1000, 32, 1)                    # BASELINE C1: at the crossover (258 vs 285 us)
+    assert approxgp.offload_advice(100_000, 512, 8) and approxgp.offload_advice(0, 1024, 8)   # posterior(sva) alone at M = 1024
+    assert approxgp.offload_work(100, 20, 1) == 100 * 20 * (40 + 3 + 30) + 20 ** 3 / 3
+    f = approxgp.GP(approxgp.SqExponentialKernel())
+    z = np.linspace(0, 1, 20)
+    sva = approxgp.SparseVariationalApproximation(f(z, 1e-6), approxgp.MvNormal(np.zeros(20), np.eye(20)))
+    x = np.linspace(0, 1, 100)
+    with pytest.raises(approxgp.DeclinedError):
+        approxgp.elbo(sva, f(x, 0.1), np.zeros(100), small_problems="decline")
+    with pytest.raises(approxgp.DeclinedError):
+        approxgp.elbo_and_gradient(sva, f(x, 0.1), np.zeros(100), small_problems="decline")
+    src = open(os.path.join(ROOT, "integration", "julia", "src", "SVGPMI355X.jl")).read()
+    assert src.count("worth_offloading(") >= 5                     # elbo / rrule, posterior, predict, cross-cov + the definition
