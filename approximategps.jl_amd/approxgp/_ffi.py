@@ -45,7 +45,7 @@ class Grads(C.Structure):
 class Timing(C.Structure):
     _fields_ = [("ms_total", C.c_double), ("ms_prep", C.c_double), ("ms_strip", C.c_double), ("ms_expect", C.c_double),
                 ("ms_kuf", C.c_double),
-                ("strip_launches", C.c_int64)]
+                ("strip_launches", C.c_int64), ("ms_chol", C.c_double)]
 
 
 # every symbol include/svgp_mi355x.h declares: (restype, argtypes)

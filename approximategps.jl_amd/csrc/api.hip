@@ -177,15 +177,15 @@ KernelParams kparams(const svgp_model* m) {
 int enqueue_prep(svgp_ctx* ctx, svgp_model* m) {
   hipStream_t s = ctx->stream;
   const KernelParams kp = kparams(m);
-  HIPC(ctx, hipMemsetAsync(m->info, 0, sizeof(int), s));
+  HIPC(ctx, hipMemsetAsync(m->info, 0, sizeof(int) * size_t(1 + m->Mp / 128), s));   // info + the factorisation's hand-over counters
   launch_scale_inputs(m->dtype, s, m->z_raw, m->desc.layout_z, m->d, m->M, m->Mp, m->invl, m->zs);
   KCHECK(ctx, "scale_inputs");
   launch_kuu(m->dtype, s, kp, m->zs, m->M, m->Mp, m->desc.jitter, m->L);
   KCHECK(ctx, "kuu");
-  launch_potrf(m->dtype, s, m->L, m->T, m->Mp, m->info);
+  HIPC(ctx, hipEventRecord(ctx->ev_chol[0], s));
+  launch_potrf(m->dtype, s, m->L, m->T, m->Mp, m->info, reinterpret_cast<unsigned*>(m->info + 1));   // T panels included
   KCHECK(ctx, "potrf");
-  launch_tpanels(m->dtype, s, m->L, m->T, m->Mp);
-  KCHECK(ctx, "tpanels");
+  HIPC(ctx, hipEventRecord(ctx->ev_chol[1], s));
   if (m->desc.parametrization == SVGP_NONCENTERED) {
     launch_pack_q(m->dtype, s, m->Lq_raw, m->m_raw, m->M, m->Mp, m->U, m->mp);          // B = Lq      SVA:183-184
     launch_kl_terms(m->dtype, s, m->Lq_raw, m->m_raw, m->L, m->M, m->Mp, m->scal);        // SVA:364-373
@@ -344,7 +344,7 @@ int enqueue_strips(svgp_ctx* ctx, svgp_model* m, const void* x, int64_t ldx, con
   if (o.skip_expect) return SVGP_OK;
   launch_expect(m->dtype, ctx->stream, lp, a.mom_mu, a.mom_var, y, off, len, ctx->partial, ctx->negcnt, o.mu, o.var);
   KCHECK(ctx, "expect");
-  launch_final_reduce(ctx->stream, ctx->partial, ctx->negcnt, expect_blocks(len), m->info, double(len), ctx->d_res);
+  launch_final_reduce(ctx->stream, ctx->partial, ctx->negcnt, expect_blocks(len), m->info, double(len), ctx->d_res, m->scal);
   KCHECK(ctx, "final_reduce");
   ctx->timing.strip_launches = (plan.grid ? 1 : 0) + (plan.nt_tail ? 1 : 0);
   HIPC(ctx, hipGetLastError());
@@ -407,12 +407,12 @@ int elbo_collective(svgp_ctx* ctx, int local_rc) {
 int elbo_finish(svgp_ctx* ctx, svgp_model* m, ElboRead* out) {
   hipStream_t s = ctx->stream;
   HIPC(ctx, hipSetDevice(ctx->device));
-  double res[5];
+  double res[13];   // {sum E, n, n_neg, chol flag, failure flag, 0, 0, 0 | prep scalars (4), chol_info}: one copy
   PrepScalars ps;
   HIPC(ctx, hipMemcpyAsync(res, ctx->d_res, sizeof(res), hipMemcpyDeviceToHost, s));
-  HIPC(ctx, hipMemcpyAsync(ps.scal, m->scal, sizeof(ps.scal), hipMemcpyDeviceToHost, s));
-  HIPC(ctx, hipMemcpyAsync(&ps.info, m->info, sizeof(int), hipMemcpyDeviceToHost, s));
   HIPC(ctx, hipStreamSynchronize(s));
+  for (int q = 0; q < 4; ++q) ps.scal[q] = res[8 + q];
+  ps.info = int(res[12]);
   finish_prep(m, ps);
   float t01 = 0, t12 = 0, t23 = 0;
   (void)hipEventElapsedTime(&t01, ctx->ev[0], ctx->ev[1]);
@@ -423,6 +423,9 @@ int elbo_finish(svgp_ctx* ctx, svgp_model* m, ElboRead* out) {
   ctx->timing.ms_expect = t23;
   ctx->timing.ms_total = t01 + t12 + t23;
   ctx->timing.ms_kuf = 0;
+  float tch = 0;
+  (void)hipEventElapsedTime(&tch, ctx->ev_chol[0], ctx->ev_chol[1]);
+  ctx->timing.ms_chol = tch;
   out->E = res[0];
   out->n_points = res[1];
   out->n_neg = res[2];
@@ -555,7 +558,9 @@ int32_t svgp_ctx_create(int32_t device_id, void* stream, svgp_ctx** out) {
   }
   for (auto& e : c->ev)
     if (hipEventCreate(&e) != hipSuccess) { delete c; return SVGP_HIP_ERROR; }
-  if (hipMalloc(&c->d_res, 8 * sizeof(double)) != hipSuccess || hipMalloc(&c->d_coll, 8 * sizeof(double)) != hipSuccess || hipMalloc(&c->counter, 64) != hipSuccess || hipMalloc(&c->partial, 1024 * sizeof(double)) != hipSuccess ||
+  for (auto& e : c->ev_chol)
+    if (hipEventCreate(&e) != hipSuccess) { delete c; return SVGP_HIP_ERROR; }
+  if (hipMalloc(&c->d_res, 16 * sizeof(double)) != hipSuccess || hipMalloc(&c->d_coll, 8 * sizeof(double)) != hipSuccess || hipMalloc(&c->counter, 64) != hipSuccess || hipMalloc(&c->partial, 1024 * sizeof(double)) != hipSuccess ||
       hipMalloc(&c->negcnt, 1024 * sizeof(unsigned)) != hipSuccess) { delete c; return SVGP_OOM; }
   *out = c;
   return SVGP_OK;
@@ -582,6 +587,8 @@ int32_t svgp_ctx_destroy(svgp_ctx* c) {
   if (c->ext_g) (void)hipFree(c->ext_g);
   if (c->gws) { c->gws->release(); delete c->gws; }
   for (auto& e : c->ev)
+    if (e) (void)hipEventDestroy(e);
+  for (auto& e : c->ev_chol)
     if (e) (void)hipEventDestroy(e);
   if (c->own_stream) (void)hipStreamDestroy(c->stream);
   delete c;
@@ -660,7 +667,7 @@ int32_t svgp_model_create(svgp_ctx* ctx, const svgp_model_desc* desc, svgp_model
   struct { void** p; size_t bytes; } allocs[] = {
       {&m->z_raw, M * m->d * es}, {&m->m_raw, M * es},     {&m->Lq_raw, M * M * es}, {&m->invl, size_t(m->d) * es},
       {&m->zs, Mp * m->d * es},   {&m->L, Mp * Mp * es},   {&m->T, Mp * Mp * es},    {&m->U, Mp * Mp * es},
-      {&m->mp, Mp * es},          {(void**)&m->scal, (8 + Mp) * sizeof(double)},     {(void**)&m->info, sizeof(int)},
+      {&m->mp, Mp * es},          {(void**)&m->scal, (8 + Mp) * sizeof(double)},     {(void**)&m->info, sizeof(int) * (1 + Mp / 128)},
   };
   for (auto& a : allocs)
     if (hipMalloc(a.p, a.bytes) != hipSuccess) {
@@ -947,17 +954,20 @@ int grad_workspace(svgp_ctx* ctx, svgp_model* m, int64_t len, GradWs** out) {
   w->rp_uf_b = size_t(w->ns_uf) * (2 + dreg) * Mp * 8; w->sp_uf_b = size_t(w->ns_uf) * w->rb * (1 + dreg) * 8;
   w->rp_uu_b = size_t(w->ns_uu) * (2 + dreg) * Mp * 8; w->sp_uu_b = size_t(w->ns_uu) * w->rb * (1 + dreg) * 8;
   w->part5_strips = nc / 32 + 2;   // narrowest strips: 32 points
+  // [rp_uf | sp_uf | rp_uu | sp_uu | sums (8) | scal_out (1 + dreg) | prep scalars (4) + info (1)]: one memset, and the tail
+  // [sums .. info] is the ONE fp64 read-back of an evaluation
+  w->zero_b = w->rp_uf_b + w->sp_uf_b + w->rp_uu_b + w->sp_uu_b + size_t(8 + 1 + dreg + 5) * 8;
   struct { void** p; size_t b; } req[] = {
-      {&w->At, mn}, {&w->Pt, mn}, {&w->gmu, size_t(nc) * es},
-      {&w->gv, size_t(nc) * es}, {&w->Lqp, mm}, {&w->S, mm}, {&w->G1, w->g_b}, {&w->G2, mm}, {&w->LkRM, mm},
-      {&w->LbarRM, mm}, {&w->Phi, mm}, {&w->tmp, mm}, {&w->H, mm},
-      // the user-layout blocks hold M d / M / M^2 elements; sized by Mp because the workspace is reused for every model of the
+      {&w->At, mn}, {&w->Pt, mn}, {&w->gmu, 2 * size_t(nc) * es},   // g_mu | g_v contiguous: one memset per chunk
+      {&w->Lqp, mm}, {&w->G1, w->g_b}, {&w->G2, mm}, {&w->LkRM, mm},
+      {&w->LbarRM, mm}, {&w->Phi, mm}, {&w->tmp, mm}, {&w->H, mm}, {&w->LinvRM, mm}, {&w->LinvCM, mm},
+      // the user-layout blocks hold M d + M + M^2 elements; sized by Mp because the workspace is reused for every model of the
       // same (dtype, Mp, d), whatever its M (M = 45 then M = 96 on one context overran the smaller buffers)
-      {&w->zbar, size_t(Mp) * m->d * es}, {&w->mbar, size_t(Mp) * es}, {&w->Lqbar, mm}, {&w->BbarRM, mm}, {&w->rbar, size_t(Mp) * es},
+      {&w->gblk, (size_t(Mp) * m->d + size_t(Mp)) * es + mm}, {&w->BbarRM, mm}, {&w->rbar, size_t(Mp) * es},
       {&w->W2, mm}, {&w->Rcm, mm}, {&w->G1p, mm}, {&w->alpha, size_t(Mp) * es}, {(void**)&w->avec, size_t(Mp) * 8},
-      {(void**)&w->rp_uf, w->rp_uf_b},
-      {(void**)&w->sp_uf, w->sp_uf_b}, {(void**)&w->rp_uu, w->rp_uu_b}, {(void**)&w->sp_uu, w->sp_uu_b},
-      {(void**)&w->partial5, size_t(w->part5_strips) * 5 * 8}, {(void**)&w->apart, size_t(w->part5_strips) * size_t(Mp) * 8}, {(void**)&w->sums, size_t(8 + 1 + dreg) * 8}, {(void**)&w->invl_d, size_t(m->d) * 8},
+      {(void**)&w->gemv_part, size_t(Mp / 128) * size_t(Mp) * 8},
+      {&w->zero_blk, w->zero_b},
+      {(void**)&w->partial5, size_t(w->part5_strips) * 5 * 8}, {(void**)&w->apart, size_t(w->part5_strips) * size_t(Mp) * 8}, {(void**)&w->invl_d, size_t(m->d) * 8},
       {(void**)&w->kred, (size_t(2 + dreg) * size_t(Mp) + size_t(1 + dreg)) * 8}};
   for (auto& r : req) {
     if (hipMalloc(r.p, r.b) != hipSuccess) {
@@ -967,7 +977,24 @@ int grad_workspace(svgp_ctx* ctx, svgp_model* m, int64_t len, GradWs** out) {
     }
     w->all.push_back(*r.p);
   }
+  w->gv = static_cast<char*>(w->gmu) + size_t(nc) * es;
+  {
+    char* z = static_cast<char*>(w->zero_blk);
+    w->rp_uf = reinterpret_cast<double*>(z); z += w->rp_uf_b;
+    w->sp_uf = reinterpret_cast<double*>(z); z += w->sp_uf_b;
+    w->rp_uu = reinterpret_cast<double*>(z); z += w->rp_uu_b;
+    w->sp_uu = reinterpret_cast<double*>(z); z += w->sp_uu_b;
+    w->sums = reinterpret_cast<double*>(z);
+  }
   w->scal_out = w->sums + 8;   // contiguous with sums: the data-parallel path all-reduces [sums | scal_out] in one piece
+  // Linv is written block-lower only and the products skip the tiles above the diagonal, but the stale upper part of a reused
+  // buffer must at least be finite (0 x NaN): start from zeros once
+  for (void* p : {w->LinvRM, w->LinvCM})
+    if (hipMemsetAsync(p, 0, mm, ctx->stream) != hipSuccess) {
+      w->release();
+      delete w;
+      return fail(ctx, SVGP_HIP_ERROR, "memset failed");
+    }
   // the point-major chunk buffers are read beyond the written points of a short last chunk (against g_v = 0): start from zeros
   for (void* p : {w->At, w->Pt})
     if (hipMemsetAsync(p, 0, mn, ctx->stream) != hipSuccess) {
@@ -999,22 +1026,24 @@ struct GradCall {
   double ext_sum_e = 0.0;
 };
 
-// out (lower tiles, pre-zeroed) += Xt' Yt for M x M operands.  One workgroup pair per lower 128-tile is 72 workgroups at
-// M = 1024 for 256 CUs, so the product is split along K into slices whose partials land in `scratch` ([ns][Mp][Mp], here the
-// SYRK's idle slice buffer) and are summed in a fixed order: 110 -> ~50 us per product at M = 1024 (four per gradient).
-void gemm_mm(svgp_ctx* ctx, GradWs* w, int dt, hipStream_t s, const void* Xt, const void* Yt, int64_t Mp, void* out) {
-  const int nP = int(Mp / 128), ntiles = nP * (nP + 1) / 2;
+// out = Xt' Yt for M x M operands ("k-major": Xt[k][r] at Xt[k Mp + r]; a row-major matrix Z is the operand Z, a column-major
+// one is Z').  Lower 128-tiles of the row-major result, or all tiles with kMmFull; kMm?Low / kMm?Up name triangular operands
+// (half the k-steps).  One workgroup pair per tile is 72 (128) workgroups at M = 1024 for 256 CUs, so the product is split
+// along K into slices whose partials land in `scratch` ([ns][Mp][Mp], the SYRK's slice buffer when it is idle) and are summed
+// in a fixed order.  The result OVERWRITES `out` (no pre-zeroing: round 2 spent a memset per product on it).
+void gemm_mm(svgp_ctx* ctx, GradWs* w, int dt, hipStream_t s, const void* Xt, const void* Yt, int64_t Mp, void* out, int flags = 0) {
+  const int nP = int(Mp / 128), ntiles = (flags & kMmFull) ? nP * nP : nP * (nP + 1) / 2;
   int ns = (2 * ctx->num_cus) / (ntiles * (dt == SVGP_F64 ? 2 : 1));   // fill the workgroup slots once (f64: two 128 x 64 halves per tile)
   if (ns > nP) ns = nP;                         // at least 8 k-steps of 16 per slice
   if (ns > w->nslices) ns = w->nslices;         // the scratch is the SYRK's [nslices][Mp][Mp]
   static const int knob = [] { const char* e = getenv("SVGP_GEMM_MM_SPLITK"); return e ? atoi(e) : 1; }();   // A/B knob
   if (ns < 2 || !knob) {
-    launch_gemm_pm(dt, s, Xt, Yt, nullptr, 1.0, Mp, Mp, Mp, 1, out);
+    launch_gemm_pm(dt, s, Xt, Yt, nullptr, 1.0, Mp, Mp, Mp, 1, out, 1, flags);
     return;
   }
   const int64_t sl = ((Mp + ns - 1) / ns + 15) / 16 * 16;
-  launch_gemm_pm(dt, s, Xt, Yt, nullptr, 1.0, Mp, Mp, sl, ns, w->G1, 1);
-  launch_sum_slices_lower(dt, s, w->G1, ns, Mp, out);
+  launch_gemm_pm(dt, s, Xt, Yt, nullptr, 1.0, Mp, Mp, sl, ns, w->G1, 1, flags);
+  launch_sum_slices_lower(dt, s, w->G1, ns, Mp, out, (flags & kMmFull) ? 1 : 0, 1);
 }
 
 int grad_enqueue(svgp_ctx* ctx, svgp_model* m, const svgp_data* data, int64_t off, int64_t len, GradCall& gc) {
@@ -1033,35 +1062,29 @@ int grad_enqueue(svgp_ctx* ctx, svgp_model* m, const svgp_data* data, int64_t of
   const double* n_global_dev = gc.n_global_dev;   // data-parallel: the all-reduced batch size, on the device (grad_handshake)
   const int dt = m->dtype;
   const int64_t Mp = m->Mp, M = m->M, nc = w->nc;
-  const size_t es = m->es, mm = size_t(Mp) * Mp * es;
+  const size_t es = m->es;
   const int dreg = grad_dreg(m->d);
+  // the user-layout gradient blocks of THIS model, contiguous: {z_bar | m_bar | Lq_bar}
+  w->zbar = w->gblk;
+  w->mbar = static_cast<char*>(w->gblk) + size_t(M) * m->d * es;
+  w->Lqbar = static_cast<char*>(w->mbar) + size_t(M) * es;
   HIPC(ctx, hipEventRecord(ctx->ev[0], s));
   rc = enqueue_prep(ctx, m);
   if (rc) return rc;
   HIPC(ctx, hipEventRecord(ctx->ev[1], s));
-  // accumulators (G1, the SYRK's slice buffer, is zeroed after its use as split-K scratch below)
-  HIPC(ctx, hipMemsetAsync(w->G2, 0, mm, s));
-  HIPC(ctx, hipMemsetAsync(w->rp_uf, 0, w->rp_uf_b, s));
-  HIPC(ctx, hipMemsetAsync(w->sp_uf, 0, w->sp_uf_b, s));
-  HIPC(ctx, hipMemsetAsync(w->rp_uu, 0, w->rp_uu_b, s));
-  HIPC(ctx, hipMemsetAsync(w->sp_uu, 0, w->sp_uu_b, s));
-  HIPC(ctx, hipMemsetAsync(w->sums, 0, size_t(8 + 1 + dreg) * 8, s));
-  HIPC(ctx, hipMemsetAsync(w->S, 0, mm, s));
+  HIPC(ctx, hipMemsetAsync(w->zero_blk, 0, w->zero_b, s));   // every accumulator of the evaluation, one fill
   HIPC(ctx, hipMemcpyAsync(w->invl_d, m->invl_host.data(), size_t(m->d) * 8, hipMemcpyHostToDevice, s));
+  // Linv = Lk^-1 (both storage orders): every Lk^-T . below is a GEMM with it (round 2: four blocked substitutions, 0.18 ms each
+  // at M = 1024 whatever the batch size)
+  launch_linv(dt, s, m->L, m->T, Mp, w->LinvRM, w->LinvCM, w->H);
   // the adjoint runs on the whitened problem: (m~, B) are (m, Lq) for NonCentered and (Lk^-1 (m - c), Lk^-1 Lq) for Centered
   const void* Bq = centered ? m->B : w->Lqp;
   if (!centered) launch_pad_lower(dt, s, m->Lq_raw, M, Mp, w->Lqp);
-  launch_sdiag(dt, s, m->T, Mp, w->S);
-  launch_spanels(dt, s, m->L, m->T, w->S, Mp);
   // M-sized operands of the strips' phase 3:  alpha = Lk^-T m~,  R = Lk^-T (B B' - I)  (column-major: the P operand of the GEMM)
-  // alpha as column 0 of an Mp x 64 block through the MFMA panel solve (the one-vector trsv takes 0.7 ms at M = 1024)
-  launch_vec_to_block(dt, s, m->mp, Mp, w->Phi);
-  launch_solve_t(dt, s, w->S, w->Phi, nullptr, Mp, 64, 64, ctx->num_cus);
-  launch_block_to_vec(dt, s, w->Phi, Mp, w->alpha);
-  gemm_mm(ctx, w, dt, s, Bq, Bq, Mp, w->G2);                               // lower tiles of B B' (row-major)
-  HIPC(ctx, hipMemsetAsync(w->G1, 0, w->g_b, s));
-  launch_sym_from_lower(dt, s, w->G2, 1, Mp, 1.0, w->tmp);                 // B B' - I, full
-  launch_solve_t(dt, s, w->S, w->tmp, w->Rcm, Mp, Mp, Mp, ctx->num_cus);   // Lk' \ . ; the transposed copy is R column-major
+  launch_linv_t_gemv(dt, s, w->LinvRM, m->mp, Mp, w->alpha, w->gemv_part);
+  gemm_mm(ctx, w, dt, s, Bq, Bq, Mp, w->G2, kMmXUp | kMmYUp);               // lower tiles of B B' (row-major); B[r][k] = 0 for k > r
+  launch_sym_from_lower(dt, s, w->G2, 1, Mp, 1.0, w->tmp);                 // S = B B' - I, full
+  gemm_mm(ctx, w, dt, s, w->tmp, w->LinvRM, Mp, w->Rcm, kMmFull | kMmYLow); // out[c][r] = sum_k S[k][c] Linv[k][r] = R[r][c]: R column-major
   KCHECK(ctx, "grad prep");
   LikParams lp{};
   lp.lik = m->desc.likelihood;
@@ -1094,8 +1117,7 @@ int grad_enqueue(svgp_ctx* ctx, svgp_model* m, const svgp_data* data, int64_t of
     rc = ensure_scratch(ctx, strip_work_bytes(dt, Mp, nt, grid), 1);
     if (rc) return rc;
     if (nstrips > w->part5_strips) return fail(ctx, SVGP_HIP_ERROR, "internal: strip partial buffer too small");
-    HIPC(ctx, hipMemsetAsync(w->gmu, 0, size_t(ncp) * es, s));
-    HIPC(ctx, hipMemsetAsync(w->gv, 0, size_t(ncp) * es, s));
+    HIPC(ctx, hipMemsetAsync(w->gmu, 0, 2 * size_t(nc) * es, s));   // g_mu | g_v (the SYRK reads g_v over the padded chunk)
     StripArgs a{};
     a.T = m->T; a.U = m->U; a.zs = m->zs; a.mp = m->mp; a.x = data->x; a.work = ctx->work; a.counter = ctx->counter;
     a.At_out = w->At; a.ldx = data->ldx; a.off = off + c0; a.len = clen; a.Mp = Mp; a.M = M; a.kp = kp;
@@ -1132,7 +1154,8 @@ int grad_enqueue(svgp_ctx* ctx, svgp_model* m, const svgp_data* data, int64_t of
     if (kg_overlap) HIPC(ctx, hipEventRecord(ctx->ev_join, sk));
     launch_sum5(s, w->partial5, int(nstrips), w->sums);
     int64_t sl = ((ncp + w->nslices - 1) / w->nslices + 127) / 128 * 128;
-    launch_gemm_pm(dt, s, w->At, w->At, w->gv, 2.0, Mp, ncp, sl, w->nslices, w->G1);   // W += A diag(2 g_v) A' (lower tiles)
+    // W (+)= A diag(2 g_v) A' (lower tiles, split-K slices): the first chunk overwrites, so the slice buffer needs no zeroing
+    launch_gemm_pm(dt, s, w->At, w->At, w->gv, 2.0, Mp, ncp, sl, w->nslices, w->G1, c0 == 0 ? 1 : 0);
     KCHECK(ctx, "syrk");
     if (kg_overlap) HIPC(ctx, hipStreamWaitEvent(s, ctx->ev_join, 0));
   }
@@ -1141,35 +1164,32 @@ int grad_enqueue(svgp_ctx* ctx, svgp_model* m, const svgp_data* data, int64_t of
   // M-sized tail.  With W = A diag(2 g_v) A' and a = A g_mu:
   //   Lq_bar = tril(W B) - klw dKL/dB,   Lk_bar = -tril(alpha a' + R W)     (B = Lq whitened; W, R carry the factors 2)
   launch_sym_from_lower(dt, s, w->G1, w->nslices, Mp, 0.0, w->W2);
-  HIPC(ctx, hipMemsetAsync(w->G1p, 0, mm, s));
-  HIPC(ctx, hipMemsetAsync(w->G2, 0, mm, s));
-  gemm_mm(ctx, w, dt, s, w->W2, m->U, Mp, w->G1p);    // (W B)[r][c] = sum_i W[i][r] B'[c][i]
-  gemm_mm(ctx, w, dt, s, w->Rcm, w->W2, Mp, w->G2);   // (R W)[r][c] = sum_i R[r][i] W[i][c]
+  gemm_mm(ctx, w, dt, s, w->W2, m->U, Mp, w->G1p, kMmYLow);   // (W B)[r][c] = sum_i W[i][r] B[i][c]; B[i][c] = 0 for i < c
+  gemm_mm(ctx, w, dt, s, w->Rcm, w->W2, Mp, w->G2);           // (R W)[r][c] = sum_i R[r][i] W[i][c]
   launch_avec(s, w->rp_uf, w->ns_uf, int64_t(2 + dreg) * Mp, Mp, w->avec);
   launch_finish_mm2(dt, s, w->G1p, w->G2, w->alpha, w->avec, Mp, M, centered ? m->B : m->Lq_raw, centered ? Mp : M, klw, w->Lqbar,
                     centered ? w->BbarRM : nullptr, w->LbarRM);
   KCHECK(ctx, "Lq_bar / Lk_bar");
   if (centered) {
-    // chain through m~ = Lk \ (m - c) and B = Lk \ Lq:  m_bar = Lk^-T m~_bar,  R = Lk^-T B_bar,  Lq_bar = tril(R),
-    // Lk_bar -= tril(m_bar m~') + tril(R B')
+    // chain through m~ = Lk \ (m - c) and B = Lk \ Lq:  m_bar = Lk^-T m~_bar,  Rb = Lk^-T B_bar,  Lq_bar = tril(Rb),
+    // Lk_bar -= tril(m_bar m~') + tril(Rb B')
     launch_mbar(dt, s, w->rp_uf, w->ns_uf, int64_t(2 + dreg) * Mp, m->mp, klw, M, Mp, w->rbar);
-    launch_trsv2(dt, s, m->L, m->T, Mp, 1, w->rbar);
-    launch_solve_t(dt, s, w->S, w->BbarRM, nullptr, Mp, Mp, Mp, ctx->num_cus);
-    launch_rm_tril_to_user(dt, s, w->BbarRM, Mp, M, w->Lqbar);
-    launch_transpose(dt, s, w->BbarRM, Mp, w->tmp);
-    HIPC(ctx, hipMemsetAsync(w->Phi, 0, mm, s));
-    gemm_mm(ctx, w, dt, s, w->tmp, m->B, Mp, w->Phi);
-    launch_lbar_adjust(dt, s, w->LbarRM, w->Phi, w->rbar, m->mp, Mp);
+    launch_linv_t_gemv(dt, s, w->LinvRM, w->rbar, Mp, w->alpha, w->gemv_part);   // alpha is free after finish_mm2: holds m_bar (padded)
+    HIPC(ctx, hipMemcpyAsync(w->mbar, w->alpha, size_t(M) * es, hipMemcpyDeviceToDevice, s));
+    // out[c][r] = sum_i B_bar[i][c] Linv[i][r] = Rb[r][c]: Rb column-major = the k-major operand of Rb B' below
+    gemm_mm(ctx, w, dt, s, w->BbarRM, w->LinvRM, Mp, w->tmp, kMmFull | kMmXLow | kMmYLow);
+    launch_cm_tril_to_user(dt, s, w->tmp, Mp, M, w->Lqbar);
+    gemm_mm(ctx, w, dt, s, w->tmp, m->B, Mp, w->Phi, kMmYUp);   // (Rb B')[r][c] = sum_i Rb[r][i] B[c][i]; B[c][i] = 0 for i > c
+    launch_lbar_adjust(dt, s, w->LbarRM, w->Phi, w->alpha, m->mp, Mp);
     KCHECK(ctx, "centered chain");
   }
+  // Cholesky backward: Kuu_bar = sym(Lk^-T Phi(Lk' Lk_bar) Lk^-1)
   launch_lower_to_rowmajor(dt, s, m->L, Mp, w->LkRM);
-  HIPC(ctx, hipMemsetAsync(w->Phi, 0, mm, s));
-  gemm_mm(ctx, w, dt, s, w->LkRM, w->LbarRM, Mp, w->Phi);
-  launch_phi(dt, s, w->Phi, Mp);
-  launch_solve_t(dt, s, w->S, w->Phi, nullptr, Mp, Mp, Mp, ctx->num_cus);
-  launch_transpose(dt, s, w->Phi, Mp, w->tmp);
-  launch_solve_t(dt, s, w->S, w->tmp, nullptr, Mp, Mp, Mp, ctx->num_cus);
-  launch_symmetrize(dt, s, w->tmp, Mp, w->H);
+  gemm_mm(ctx, w, dt, s, w->LkRM, w->LbarRM, Mp, w->Phi, kMmXLow | kMmYLow);   // (Lk' Lk_bar)[r][c], lower tiles
+  launch_phi(dt, s, w->Phi, Mp);                                               // tril, diagonal halved; zero above
+  gemm_mm(ctx, w, dt, s, w->Phi, w->LinvRM, Mp, w->tmp, kMmFull | kMmXLow | kMmYLow);   // out[c][r] = sum_i Phi[i][c] Linv[i][r] = (Linv' Phi)[r][c]
+  gemm_mm(ctx, w, dt, s, w->tmp, w->LinvRM, Mp, w->G1p, kMmFull | kMmYLow);             // out[r][c] = sum_j (Linv' Phi)[r][j] Linv[j][c]
+  launch_symmetrize(dt, s, w->G1p, Mp, w->H);
   KCHECK(ctx, "chol backward");
   // the Kuu part: the ns_uu slices must cover all M columns (a fixed slice of 128 covered only 1024 of them: the kernel-
   // parameter and z gradients were wrong for M > 1024 until tests/test_gpu_grad.py::test_gradient_large_m_float32_strips)
@@ -1178,7 +1198,8 @@ int grad_enqueue(svgp_ctx* ctx, svgp_model* m, const svgp_data* data, int64_t of
   launch_finish_kgrad(dt, s, m->d, M, Mp, m->zs, w->invl_d, w->rp_uf, w->ns_uf, w->rp_uu, w->ns_uu, w->sp_uf, w->ns_uf * w->rb,
                       w->sp_uu, w->ns_uu * w->rb, m->mp, klw, m->desc.layout_z, m->desc.variance, w->zbar, centered ? nullptr : w->mbar,
                       w->scal_out, w->kred);
-  launch_grad_status(s, w->sums, m->info, double(len));
+  // status slots of the all-reduced scalars + this rank's prep scalars / info behind them: ONE fp64 read-back per evaluation
+  launch_grad_status(s, w->sums, m->info, double(len), m->scal, w->scal_out + 1 + dreg);
   KCHECK(ctx, "kgrad uu / finish");
   HIPC(ctx, hipEventRecord(ctx->ev[3], s));
   return SVGP_OK;
@@ -1225,10 +1246,7 @@ int grad_fail_collective(svgp_ctx* ctx, const svgp_model* m, int pre_rc) {
   int rc = comm_allreduce(ctx, ctx->d_coll, 2, SVGP_F64);
   if (rc == SVGP_OK) rc = comm_group_start(ctx);
   if (rc == SVGP_OK) {
-    char* b = static_cast<char*>(blocks.p);
-    rc = comm_allreduce(ctx, b, nz, m->dtype);
-    if (rc == SVGP_OK) rc = comm_allreduce(ctx, b + nz * es, M, m->dtype);
-    if (rc == SVGP_OK) rc = comm_allreduce(ctx, b + (nz + M) * es, M * M, m->dtype);
+    rc = comm_allreduce(ctx, blocks.p, nz + M + M * M, m->dtype);   // {z_bar | m_bar | Lq_bar}: the same counts as grad_collective
     if (rc == SVGP_OK) rc = comm_allreduce(ctx, sums.p, nsum, SVGP_F64);
     const int rce = comm_group_end(ctx);
     if (rc == SVGP_OK) rc = rce;
@@ -1260,9 +1278,8 @@ int grad_collective(svgp_ctx* ctx, svgp_model* m, GradCall& gc, int local_rc) {
     }
   }
   int rc = comm_group_start(ctx);
-  if (rc == SVGP_OK) rc = comm_allreduce(ctx, w->zbar, size_t(m->M) * m->d, m->dtype);
-  if (rc == SVGP_OK) rc = comm_allreduce(ctx, gc.centered ? w->rbar : w->mbar, size_t(m->M), m->dtype);
-  if (rc == SVGP_OK) rc = comm_allreduce(ctx, w->Lqbar, size_t(m->M) * m->M, m->dtype);
+  // {z_bar | m_bar | Lq_bar} are contiguous for this model's M (grad_enqueue): one all-reduce in the compute dtype, one in fp64
+  if (rc == SVGP_OK) rc = comm_allreduce(ctx, w->gblk, size_t(m->M) * m->d + size_t(m->M) + size_t(m->M) * m->M, m->dtype);
   if (rc == SVGP_OK) rc = comm_allreduce(ctx, w->sums, size_t(8 + 1 + dreg), SVGP_F64);
   const int rce = comm_group_end(ctx);
   if (rc == SVGP_OK) rc = rce;
@@ -1284,19 +1301,22 @@ int grad_finish(svgp_ctx* ctx, svgp_model* m, GradCall& gc, double* elbo_out, sv
   const size_t es = m->es;
   const int dreg = grad_dreg(m->d);
   const bool centered = gc.centered;
-  // read back
-  double sums[8];
-  std::vector<double> sc(1 + dreg);
-  PrepScalars ps;
-  HIPC(ctx, hipMemcpyAsync(sums, w->sums, sizeof sums, hipMemcpyDeviceToHost, s));
-  HIPC(ctx, hipMemcpyAsync(sc.data(), w->scal_out, sc.size() * 8, hipMemcpyDeviceToHost, s));
-  HIPC(ctx, hipMemcpyAsync(ps.scal, m->scal, sizeof(ps.scal), hipMemcpyDeviceToHost, s));
-  HIPC(ctx, hipMemcpyAsync(&ps.info, m->info, sizeof(int), hipMemcpyDeviceToHost, s));
-  if (g->z) HIPC(ctx, hipMemcpyAsync(g->z, w->zbar, size_t(M) * m->d * es, hipMemcpyDeviceToHost, s));
-  std::vector<char> mhost(size_t(M) * es);
-  HIPC(ctx, hipMemcpyAsync(mhost.data(), centered ? w->rbar : w->mbar, size_t(M) * es, hipMemcpyDeviceToHost, s));
-  if (g->Lq) HIPC(ctx, hipMemcpyAsync(g->Lq, w->Lqbar, size_t(M) * M * es, hipMemcpyDeviceToHost, s));
+  // read back: ONE copy of the fp64 block [sums (8) | scal_out (1 + dreg) | prep scalars (4) | chol_info] and ONE of the
+  // gradient blocks {z_bar | m_bar | Lq_bar} (round 2: seven copies, ~20 us of host latency each)
+  std::vector<double> f64blk(size_t(8 + 1 + dreg + 5));
+  const size_t nz = size_t(M) * m->d, nblk = nz + size_t(M) + size_t(M) * M;
+  std::vector<char> gh(nblk * es);
+  HIPC(ctx, hipMemcpyAsync(f64blk.data(), w->sums, f64blk.size() * 8, hipMemcpyDeviceToHost, s));
+  HIPC(ctx, hipMemcpyAsync(gh.data(), w->gblk, gh.size(), hipMemcpyDeviceToHost, s));
   HIPC(ctx, hipStreamSynchronize(s));
+  const double* sums = f64blk.data();
+  const double* sc = sums + 8;
+  PrepScalars ps;
+  for (int q = 0; q < 4; ++q) ps.scal[q] = sums[8 + 1 + dreg + q];
+  ps.info = int(sums[8 + 1 + dreg + 4]);
+  const char* mhost = gh.data() + nz * es;
+  if (g->z) memcpy(g->z, gh.data(), nz * es);
+  if (g->Lq) memcpy(g->Lq, gh.data() + (nz + size_t(M)) * es, size_t(M) * M * es);
   finish_prep(m, ps);
   float t01 = 0, t13 = 0;
   (void)hipEventElapsedTime(&t01, ctx->ev[0], ctx->ev[1]);
@@ -1305,6 +1325,9 @@ int grad_finish(svgp_ctx* ctx, svgp_model* m, GradCall& gc, double* elbo_out, sv
   ctx->timing.ms_prep = t01;
   ctx->timing.ms_strip = t13;
   ctx->timing.ms_total = t01 + t13;
+  float tch = 0;
+  (void)hipEventElapsedTime(&tch, ctx->ev_chol[0], ctx->ev_chol[1]);
+  ctx->timing.ms_chol = tch;
   ElboRead r;
   r.E = sums[0]; r.n_neg = sums[4]; r.n_points = sums[5]; r.bad_chol = gc.collective ? sums[6] : 0.0; r.failed = gc.collective ? sums[7] : 0.0;
   // collective: the sums are global; scale = num_data / n_global (as on the device), and the KL counts once
@@ -1313,10 +1336,10 @@ int grad_finish(svgp_ctx* ctx, svgp_model* m, GradCall& gc, double* elbo_out, sv
   const double elbo = r.E * scale - klw * m->kl;
   g->variance = sc[0] + sums[2];
   g->lik_sigma2 = sums[3];
-  if (g->m) memcpy(g->m, mhost.data(), mhost.size());
+  if (g->m) memcpy(g->m, mhost, size_t(M) * es);
   double msum = 0.0;   // Centered: mean_const also enters through m~ = Lk \\ (m - c)
   if (centered)
-    for (int64_t i = 0; i < M; ++i) msum += (dt == SVGP_F64) ? reinterpret_cast<double*>(mhost.data())[i] : double(reinterpret_cast<float*>(mhost.data())[i]);
+    for (int64_t i = 0; i < M; ++i) msum += (dt == SVGP_F64) ? reinterpret_cast<const double*>(mhost)[i] : double(reinterpret_cast<const float*>(mhost)[i]);
   g->mean_const = sums[1] - msum;
   if (g->inv_lengthscale)
     for (int f = 0; f < m->d; ++f) g->inv_lengthscale[f] = sc[1 + f];

@@ -18,6 +18,7 @@ struct svgp_ctx {
   std::string err;
   svgp_timing timing{};
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};  // start, prep done, strip done, all done
+  hipEvent_t ev_chol[2] = {nullptr, nullptr};               // around the blocked Cholesky inside the prep
   // growable scratch
   void* work = nullptr;       size_t work_bytes = 0;
   double* partial = nullptr;  unsigned* negcnt = nullptr;  // [1024] per-block sums of the expectation kernel
@@ -45,11 +46,18 @@ struct GradWs {
   int64_t Mp = 0, nc = 0;
   std::vector<void*> all;
   void *At = nullptr, *Pt = nullptr, *gmu = nullptr, *gv = nullptr;   // per chunk: A and P = Kuf_bar point-major [nc][Mp], g_mu, g_v
-  void *Lqp = nullptr, *S = nullptr, *G1 = nullptr, *G2 = nullptr, *LkRM = nullptr, *LbarRM = nullptr, *Phi = nullptr,
-       *tmp = nullptr, *H = nullptr, *zbar = nullptr, *mbar = nullptr, *Lqbar = nullptr, *BbarRM = nullptr, *rbar = nullptr;
+  void *Lqp = nullptr, *G1 = nullptr, *G2 = nullptr, *LkRM = nullptr, *LbarRM = nullptr, *Phi = nullptr,
+       *tmp = nullptr, *H = nullptr, *BbarRM = nullptr, *rbar = nullptr;
+  void *LinvRM = nullptr, *LinvCM = nullptr;   // Lk^-1 in both storage orders (launch_linv): every Lk^-T . of the tail is a GEMM with it
   void *W2 = nullptr, *Rcm = nullptr, *G1p = nullptr, *alpha = nullptr;   // W = A diag(2 g_v) A', R = Lk^-T (Lq Lq' - I), 2 W Lq, Lk^-T m
+  // the user-layout gradient blocks {z_bar (M d) | m_bar (M) | Lq_bar (M^2)}: ONE allocation, contiguous for the model's M, so
+  // that the data-parallel sum is one ncclAllReduce and the read-back one copy; zbar / mbar / Lqbar point into it (set per call)
+  void *gblk = nullptr, *zbar = nullptr, *mbar = nullptr, *Lqbar = nullptr;
+  // accumulators zeroed by ONE memset per evaluation: [rp_uf | sp_uf | rp_uu | sp_uu | sums (8) | scal_out (1 + dreg) | prep (5)]
+  void* zero_blk = nullptr;
+  size_t zero_b = 0;
   double *rp_uf = nullptr, *sp_uf = nullptr, *rp_uu = nullptr, *sp_uu = nullptr, *partial5 = nullptr, *sums = nullptr,
-         *invl_d = nullptr, *scal_out = nullptr, *avec = nullptr, *apart = nullptr, *kred = nullptr;
+         *invl_d = nullptr, *scal_out = nullptr, *avec = nullptr, *apart = nullptr, *kred = nullptr, *gemv_part = nullptr;
   int64_t part5_strips = 0;
   size_t rp_uf_b = 0, sp_uf_b = 0, rp_uu_b = 0, sp_uu_b = 0, g_b = 0;
   void release() {

@@ -1,14 +1,16 @@
-// grad.hip — reverse-mode gradient of the NonCentered ELBO (the reference differentiates
-// elbo with Zygote: examples/a-regression/script.jl:188-194, test/SparseVariationalApproximationModule.jl:170-175).
-// Hand-derived adjoint of the forward path (oracle/svgp_oracle.py: elbo_grad is the same derivation):
-//   per point      g_mu = s dE/dmu, g_v = s dE/dv                                   (grad_moments_kernel)
-//   Abar = m g_mu' + 2 (Lq C - A) diag(g_v)        A = Lk \ Kuf, C = Lq'A           (abar_kernel, MFMA)
-//   P    = Lk' \ Abar   (= Kuf_bar)                                                 (solve_t_kernel, MFMA panels)
-//   Lq_bar = tril(2 A diag(g_v) C') - (Lq - diag(1/Lq_ii)),  Lk_bar = -tril(P A')   (gemm_pm_kernel, MFMA)
-//   Kuu_bar = sym(Lk^-T Phi(Lk' Lk_bar) Lk^-1)                                      (gemm_pm + solve_t twice)
-//   kernel parameters / inducing inputs from sum_ij P_ij dK_ij and Kuu_bar_ij dKuu_ij (kgrad_kernel)
-// The data are processed in chunks of columns; per chunk the strip kernel leaves A and C in HBM in both
-// orientations ([Mp][nc] for the panel recurrences, [nc][Mp] for the products contracted over points).
+// grad.hip — reverse-mode gradient of the ELBO (the reference differentiates elbo with Zygote:
+// examples/a-regression/script.jl:188-194, test/SparseVariationalApproximationModule.jl:170-175): the kernels of the parts
+// that are NOT the strip kernel's phase 3.  Hand-derived adjoint of the forward path (oracle/svgp_oracle.py: elbo_grad is
+// the same derivation; api.hip: grad_enqueue is the schedule).  With A = Lk \ Kuf, B the whitened factor, W = A diag(2 g_v) A':
+//   data-sized     W (SYRK over the points, split-K slices)                         gemm_pm_kernel
+//                  kernel-parameter / inducing-input reductions of P o dK           kgrad_kernel
+//   M-sized        Linv = Lk^-1 by recursive doubling (round 3)                     linv_init / linv_step kernels
+//                  alpha = Linv' m~,  R = Linv' (B B' - I)                          linv_t_gemv, gemm_pm (M x M x M form)
+//                  Lq_bar = tril(W B) - dKL/dB,  Lk_bar = -tril(alpha a' + R W)     gemm_pm, finish_mm2
+//                  Kuu_bar = sym(Linv' Phi(Lk' Lk_bar) Linv)                        gemm_pm x 3, phi, symmetrize
+//                  their Kuu part of the kernel-parameter gradients                 kgrad_kernel (uu), kgrad_reduce, finish_kgrad
+// Round 2 applied Lk^-T by blocked substitution (four chains of nP panels, 0.18 ms each at M = 1024 whatever the batch);
+// with the explicit inverse every M-sized step is a GEMM over the whole chip.
 #include <cstdlib>
 
 #include "device_common.hpp"
@@ -18,57 +20,18 @@
 namespace svgp {
 namespace {
 
-template <typename T>
-__global__ void __launch_bounds__(k256) grad_moments_kernel(LikParams lp, double scale, const double* __restrict__ n_global_dev,
-                                                            double num_data, const double* __restrict__ mom_mu,
-                                                            const double* __restrict__ mom_var, const T* __restrict__ y,
-                                                            int64_t off, int64_t len, int64_t npad, T* __restrict__ gmu,
-                                                            T* __restrict__ gv, double* __restrict__ partial) {
-  __shared__ double sh[5][k256];
-  if (n_global_dev) scale = num_data > 0.0 ? num_data / *n_global_dev : 1.0;   // SVA:357-358 with the all-reduced batch size
-  const double log_sigma2 = log(lp.sigma2);
-  double acc[5] = {0, 0, 0, 0, 0};  // E, sum g_mu, sum g_v, dE/dsigma2, n_neg
-  for (int64_t i = int64_t(blockIdx.x) * k256 + threadIdx.x; i < npad; i += int64_t(gridDim.x) * k256) {
-    double a = 0.0, b = 0.0;
-    if (i < len) {
-      const double mu = mom_mu[i];
-      double v = mom_var[i] + kDefaultSigma2;
-      bool bad = v < 0.0;
-      if (bad) {
-        acc[4] += 1.0;
-        if (lp.clamp_neg_var) { v = 0.0; bad = false; }
-      }
-      if (!bad) {
-        const double yv = double(y[off + i]);
-        double gs2;
-        expected_loglik_grad_point(lp, mu, v, yv, a, b, gs2);
-        acc[0] += expected_loglik_point(lp, mu, v, yv, log_sigma2);
-        a *= scale;
-        b *= scale;
-        acc[1] += a;
-        acc[2] += b;
-        acc[3] += gs2 * scale;
-      }
-    }
-    gmu[i] = T(a);
-    gv[i] = T(b);
-  }
-  for (int q = 0; q < 5; ++q) sh[q][threadIdx.x] = acc[q];
-  __syncthreads();
-  for (int w = k256 / 2; w > 0; w >>= 1) {
-    if (int(threadIdx.x) < w)
-      for (int q = 0; q < 5; ++q) sh[q][threadIdx.x] += sh[q][threadIdx.x + w];
-    __syncthreads();
-  }
-  if (threadIdx.x < 5) partial[blockIdx.x * 5 + threadIdx.x] = sh[threadIdx.x][0];
-}
-
 __global__ void set_f64_kernel(double* dst, double value) { *dst = value; }
 __global__ void set2_f64_kernel(double* dst, double a, double b) { dst[0] = a; dst[1] = b; }
-__global__ void grad_status_kernel(double* sums, const int* chol_info, double n_points) {
+// status slots of the (all-reduced) gradient scalars, and - behind the all-reduced region - this rank's own prep scalars
+// {sum Lq^2, m'm, sum log diag Lq, sum log diag Lk} and chol_info, so that one copy brings everything fp64 to the host
+__global__ void grad_status_kernel(double* sums, const int* chol_info, double n_points, const double* prep_scal, double* prep_out) {
   sums[5] = n_points;
   sums[6] = (chol_info && *chol_info != 0) ? 1.0 : 0.0;
   sums[7] = 0.0;
+  if (prep_out) {
+    for (int q = 0; q < 4; ++q) prep_out[q] = prep_scal[q];
+    prep_out[4] = chol_info ? double(*chol_info) : 0.0;
+  }
 }
 
 // out[q] += sum over blocks of partial[b][q]: wave q sums its column (lane l takes blocks l, l + 64, ... in order, then a
@@ -98,27 +61,33 @@ __global__ void __launch_bounds__(k256) apart_reduce_kernel(const double* __rest
 }
 
 // ---- M x M helpers of the fused gradient path (svgp_elbo_grad, api.hip: grad_enqueue) ---------------------------------
-// out (row-major, FULL symmetric) = sum over slices of the lower tiles in G (row-major), minus `eye` on the diagonal
+// out (row-major, FULL symmetric) = sum over slices of the lower triangle of G (row-major; only entries c <= r are read, also
+// inside the diagonal tiles, so the result is exactly symmetric), minus `eye` on the diagonal.  One 32 x 32 tile of the lower
+// triangle per workgroup: the slice sums are read along rows, the mirror image leaves through an LDS transposition, so both
+// the reads and the two writes run along rows (round 2 read the mirror half with stride Mp: 58 us for 7 slices at M = 1024).
 template <typename T>
-__global__ void sym_from_lower_kernel(const T* __restrict__ G, int nslices, int64_t Mp, T eye, T* __restrict__ out) {
-  const int64_t c = int64_t(blockIdx.x) * blockDim.x + threadIdx.x, r = blockIdx.y;
-  if (c >= Mp) return;
-  const int64_t lo = (c <= r) ? r * Mp + c : c * Mp + r;   // element of the lower triangle (tiles on the diagonal are full)
-  T v = T(0);
-  for (int s = 0; s < nslices; ++s) v += G[int64_t(s) * Mp * Mp + lo];
-  out[r * Mp + c] = v - (r == c ? eye : T(0));
-}
-
-// a vector as column 0 of an Mp x 64 k-major block (zeros elsewhere) and back: lets solve_t_kernel do a one-vector solve
-template <typename T>
-__global__ void vec_to_block_kernel(const T* __restrict__ v, int64_t Mp, T* __restrict__ X) {
-  const int64_t e = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
-  if (e < Mp * 64) X[e] = (e % 64 == 0) ? v[e / 64] : T(0);
-}
-template <typename T>
-__global__ void block_to_vec_kernel(const T* __restrict__ X, int64_t Mp, T* __restrict__ v) {
-  const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
-  if (i < Mp) v[i] = X[i * 64];
+__global__ void __launch_bounds__(k256) sym_from_lower_kernel(const T* __restrict__ G, int nslices, int64_t Mp, T eye, T* __restrict__ out) {
+  __shared__ T tile[32][33];
+  int br = 0, b = blockIdx.x;
+  while (b >= br + 1) { b -= br + 1; ++br; }
+  const int bc = b;                                   // bc <= br
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+  for (int q = ty; q < 32; q += 8) {
+    const int64_t r = int64_t(br) * 32 + q, c = int64_t(bc) * 32 + tx;
+    T v = T(0);
+    if (c <= r) {
+      for (int s = 0; s < nslices; ++s) v += G[int64_t(s) * Mp * Mp + r * Mp + c];
+      if (r == c) v -= eye;
+      out[r * Mp + c] = v;
+    }
+    tile[q][tx] = v;
+  }
+  __syncthreads();
+  for (int q = ty; q < 32; q += 8) {
+    // mirror: element (c', r') of the output with c' in the tile's columns, r' in its rows = tile[r' - r0][c' - c0]
+    const int64_t cp = int64_t(bc) * 32 + q, rp = int64_t(br) * 32 + tx;
+    if (cp < rp) out[cp * Mp + rp] = tile[tx][q];
+  }
 }
 
 // avec[c] = sum over slices of rowpart[s][1][c]  ( = (A g_mu)_c, the data part of m_bar )
@@ -148,91 +117,43 @@ __global__ void finish_mm2_kernel(const T* __restrict__ G1, const T* __restrict_
   else if (r < M && c < M) Lq_bar[r + c * M] = v;
 }
 
-// Abar[r][c] = m[r] g_mu[c] + 2 g_v[c] ((Lq C)[r][c] - A[r][c]);  Lq lower triangular, Mp x Mp column-major
-template <typename T, int NT, int NTHR>
-__global__ void __launch_bounds__(NTHR, 2) abar_kernel(const T* __restrict__ Lqp, const T* __restrict__ C,
-                                                        const T* __restrict__ A, const T* __restrict__ mp,
-                                                        const T* __restrict__ gmu, const T* __restrict__ gv,
-                                                        T* __restrict__ Abar, int64_t Mp, int64_t ld) {
-  using G = TileGemm<T, NT, 16, NTHR>;
-  using QRegs = typename G::QRegs;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  T* smem = reinterpret_cast<T*>(smem_raw);
-  const int I = int(gridDim.y) - 1 - int(blockIdx.y);   // long panels first
-  const int64_t c0 = int64_t(blockIdx.x) * NT;
-  typename G::Acc acc;
-  acc.zero();
-  const typename G::QOff qoff = G::q_offsets(ld);
-  auto qload = [&](int t, QRegs& r) { G::load_q(r, C + int64_t(t) * 16 * ld + c0, qoff); };
-  G::template loop_tri<1>(acc, Lqp + int64_t(I) * kNB, Mp, (I + 1) * (kNB / 16), qload, smem);   // last 8 steps: lower-triangular Lq_II
-#pragma unroll
-  for (int i = 0; i < G::MI; ++i)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int64_t row = int64_t(I) * kNB + G::acc_row(i, r);
-      const T mr = mp[row];
-#pragma unroll
-      for (int j = 0; j < G::NJ; ++j) {
-        const int64_t col = c0 + G::acc_col(j);
-        const int64_t idx = row * ld + col;
-        Abar[idx] = mr * gmu[col] + T(2) * gv[col] * (acc.v[i][j][r] - A[idx]);
-      }
-    }
-}
-
-// X := Lk' \ X in place for a k-major X ([Mp][ld]): P_I = S[I,I] X_I + sum_{J>I} S[I,J] P_J, panels in descending
-// order, S[I,I] = inv(L_II)', S[I,J] = -inv(L_II)' L[J,I]'.  One workgroup per 64-column strip.
-template <typename T, int NT>
-__global__ void __launch_bounds__(k256, 2) solve_t_kernel(const T* __restrict__ S, T* __restrict__ X, T* __restrict__ Xt,
-                                                           int64_t Mp, int64_t ld, int64_t nstrips) {
-  using G = TileGemm<T, NT, 16, k256>;
-  using QRegs = typename G::QRegs;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  T* smem = reinterpret_cast<T*>(smem_raw);
-  const int nP = int(Mp / kNB);
-  const typename G::QOff qoff = G::q_offsets(ld);
-  for (int64_t strip = blockIdx.x; strip < nstrips; strip += gridDim.x) {
-    const int64_t c0 = strip * NT;
-    for (int I = nP - 1; I >= 0; --I) {
-      typename G::Acc acc;
-      acc.zero();
-      const T* xq = X + int64_t(I) * kNB * ld + c0;
-      auto qload = [&](int t, QRegs& r) { G::load_q(r, xq + int64_t(t) * 16 * ld, qoff); };
-      G::template loop_tri<-1>(acc, S + int64_t(I) * kNB + int64_t(I) * kNB * Mp, Mp, (nP - I) * (kNB / 16), qload, smem);   // first 8: upper-triangular inv(L_II)'
-#pragma unroll
-      for (int i = 0; i < G::MI; ++i)
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-#pragma unroll
-          for (int j = 0; j < G::NJ; ++j) {
-            const int64_t row = int64_t(I) * kNB + G::acc_row(i, r), col = c0 + G::acc_col(j);
-            X[row * ld + col] = acc.v[i][j][r];
-            if (Xt) Xt[col * Mp + row] = acc.v[i][j][r];
-          }
-      __syncthreads();
-    }
-  }
-}
-
 // out[slice][r][c] += sum_{i in slice} w_i Xt[i][r] Yt[i][c]   (Xt, Yt point-major [n][Mp]; lower tiles only)
 // NT = 128 / 512 threads: one workgroup per 128 x 128 output tile; NT = 64 / 256 threads: two 128 x 64 halves on
 // separate workgroups (the strip kernel's geometry: the two waves of a SIMD belong to different workgroups)
+// flags (round 3, the M x M x M products of the gradient's tail): kMmFull - all nP x nP tiles instead of the lower ones;
+// kMmXLow / kMmYLow - Xt[i][r] (Yt[i][c]) vanishes for i above the diagonal tile of r (c), i.e. the contraction starts at that
+// tile; kMmXUp / kMmYUp - it vanishes BELOW that tile, the contraction ends there (triangular operands: half the k-steps)
 template <typename T, int NT, int NTHR>
 __global__ void __launch_bounds__(NTHR, 2) gemm_pm_kernel(const T* __restrict__ Xt, const T* __restrict__ Yt,
                                                            const T* __restrict__ w, T wscale, int64_t Mp, int64_t n,
-                                                           int64_t slice_len, T* __restrict__ out, int overwrite) {
+                                                           int64_t slice_len, T* __restrict__ out, int overwrite, int flags) {
   using G = TileGemm<T, NT, 16, NTHR>;
   using QRegs = typename G::QRegs;
   constexpr int NCH = kNB / NT;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   T* smem = reinterpret_cast<T*>(smem_raw);
   const int chunk = blockIdx.x % NCH;
-  int ti = 0, b = blockIdx.x / NCH;
-  while (b >= ti + 1) { b -= ti + 1; ++ti; }
-  const int tj = b;
-  const int64_t i0 = int64_t(blockIdx.y) * slice_len;
+  int ti = 0, tj, b = blockIdx.x / NCH;
+  if (flags & kMmFull) {
+    const int nP = int(Mp / kNB);
+    ti = b / nP;
+    tj = b % nP;
+  } else {
+    while (b >= ti + 1) { b -= ti + 1; ++ti; }
+    tj = b;
+  }
+  int64_t i0 = int64_t(blockIdx.y) * slice_len;
   int64_t i1 = i0 + slice_len;
   i1 = i1 < n ? i1 : n;
+  if (flags & (kMmXLow | kMmYLow | kMmXUp | kMmYUp)) {
+    int64_t lo = 0, hi = n;
+    if (flags & kMmXLow) lo = int64_t(ti) * kNB;
+    if ((flags & kMmYLow) && int64_t(tj) * kNB > lo) lo = int64_t(tj) * kNB;
+    if (flags & kMmXUp) hi = int64_t(ti + 1) * kNB;
+    if ((flags & kMmYUp) && int64_t(tj + 1) * kNB < hi) hi = int64_t(tj + 1) * kNB;
+    i0 = i0 > lo ? i0 : lo;
+    i1 = i1 < hi ? i1 : hi;
+  }
   typename G::Acc acc;
   acc.zero();
   if (i1 > i0) {
@@ -265,14 +186,112 @@ __global__ void __launch_bounds__(NTHR, 2) gemm_pm_kernel(const T* __restrict__ 
       }
 }
 
-// out[r][c] += sum_s part[s][r][c] over the lower 128-tiles (the tiles gemm_pm_kernel computes), slices in a fixed order
+// out[r][c] (+)= sum_s part[s][r][c] over the lower 128-tiles (the tiles gemm_pm_kernel computes) or over all of them,
+// slices in a fixed order
 template <typename T>
-__global__ void sum_slices_lower_kernel(const T* __restrict__ part, int ns, int64_t Mp, T* __restrict__ out) {
+__global__ void sum_slices_lower_kernel(const T* __restrict__ part, int ns, int64_t Mp, T* __restrict__ out, int full, int overwrite) {
   const int64_t c = int64_t(blockIdx.x) * blockDim.x + threadIdx.x, r = blockIdx.y;
-  if (c >= Mp || c / kNB > r / kNB) return;
+  if (c >= Mp || (!full && c / kNB > r / kNB)) return;
   T v = T(0);
   for (int s = 0; s < ns; ++s) v += part[int64_t(s) * Mp * Mp + r * Mp + c];
-  out[r * Mp + c] += v;
+  out[r * Mp + c] = overwrite ? v : out[r * Mp + c] + v;
+}
+
+// ---- explicit inverse of the Cholesky factor (round 3) ---------------------------------------------------------------
+// The gradient's tail applied Lk^-T four times by blocked substitution (solve_t_kernel): M / 32 workgroups, each a chain of
+// nP panels at the per-k-step latency - 4 x 0.18 ms of a 3.8 ms training step at M = 1024.  With Linv = Lk^-1 in hand every
+// one of them is a plain (triangular-operand) GEMM over all the chip.  Linv is built by recursive doubling from the 128-blocks
+// potf2 already inverted: for adjacent block ranges lo, hi of s panels,
+//     Linv[hi, lo] = -Linv[hi, hi] (L[hi, lo] Linv[lo, lo])
+// - two launches per level, log2(nP) levels, every tile of a level in parallel.  Both storage orders are kept: LinvRM
+// (row-major: the k-major operand "Xt[k][r] = Linv[k][r]" of the products Linv' X) and LinvCM (column-major: the left
+// operand of step 2).  Numerics: as the blocked substitution it replaces, the products carry a forward error of order
+// eps cond(Lk); the gradient parity tests bound the end result.
+template <typename T>
+__global__ void linv_init_kernel(const T* __restrict__ Tm, int64_t Mp, T* __restrict__ LinvRM, T* __restrict__ LinvCM) {
+  const int64_t o = int64_t(blockIdx.y) * kNB * (Mp + 1);
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < kNB * kNB; e += gridDim.x * blockDim.x) {
+    const int r = e % kNB, c = e / kNB;
+    const T v = Tm[o + r + int64_t(c) * Mp];   // inv(L_II)[r][c], zero above the diagonal
+    LinvCM[o + r + int64_t(c) * Mp] = v;
+    LinvRM[o + c + int64_t(r) * Mp] = v;
+  }
+}
+
+template <typename T, int NT, int STEP>
+__global__ void __launch_bounds__(k256, 2) linv_step_kernel(const T* __restrict__ L, T* __restrict__ LinvRM, T* __restrict__ LinvCM,
+                                                            T* __restrict__ Ytmp, int64_t Mp, int nP, int s) {
+  using G = TileGemm<T, NT, 16, k256>;
+  using QRegs = typename G::QRegs;
+  constexpr int NB = kNB, NCH = NB / NT;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  T* smem = reinterpret_cast<T*>(smem_raw);
+  const int a = int(blockIdx.y) * 2 * s, hi0 = a + s;
+  const int hn = (nP - hi0) < s ? (nP - hi0) : s;
+  const int chunk = blockIdx.x % NCH, tile = blockIdx.x / NCH;
+  const int tr = tile / s, tc = tile % s;
+  if (tr >= hn) return;
+  const int64_t row0 = int64_t(hi0 + tr) * NB, col0 = int64_t(a + tc) * NB + chunk * NT;
+  typename G::Acc acc;
+  acc.zero();
+  const typename G::QOff qoff = G::q_offsets(Mp);
+  if (STEP == 1) {   // Ytmp[hi, lo] = L[hi, lo] Linv[lo, lo]: contraction over the lo rows j >= the column's diagonal tile
+    const T* P = L + row0 + (int64_t(a + tc) * NB) * Mp;                 // element (k, row) at P[k * Mp + row]
+    const T* Q = LinvRM + (int64_t(a + tc) * NB) * Mp + col0;            // element (k, col) at Q[k * Mp + col]
+    auto qload = [&](int t, QRegs& r) { G::load_q(r, Q + int64_t(t) * 16 * Mp, qoff); };
+    G::loop(acc, P, Mp, (s - tc) * (NB / 16), qload, smem);
+  } else {           // Linv[hi, lo] = -Linv[hi, hi] Ytmp[hi, lo]: contraction over the hi columns k <= the row's diagonal tile
+    const T* P = LinvCM + row0 + (int64_t(hi0) * NB) * Mp;
+    const T* Q = Ytmp + (int64_t(hi0) * NB) * Mp + col0;
+    auto qload = [&](int t, QRegs& r) { G::load_q(r, Q + int64_t(t) * 16 * Mp, qoff); };
+    G::loop(acc, P, Mp, (tr + 1) * (NB / 16), qload, smem);
+  }
+#pragma unroll
+  for (int i = 0; i < G::MI; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int j = 0; j < G::NJ; ++j) {
+        const int64_t row = row0 + G::acc_row(i, r), col = col0 + G::acc_col(j);
+        if (STEP == 1) {
+          Ytmp[row * Mp + col] = acc.v[i][j][r];
+        } else {
+          LinvRM[row * Mp + col] = -acc.v[i][j][r];
+          LinvCM[row + col * Mp] = -acc.v[i][j][r];
+        }
+      }
+}
+
+// out[r] = sum_{k >= r} LinvRM[k][r] v[k]  ( = (Lk^-T v)_r ), fp64 accumulation, in two stages: workgroup (bx, by) sums the 128
+// rows k of panel by for its 64 columns r (thread (r, g) takes k = g, g + 4, ...: a row of LinvRM is read contiguously, the
+// loads of a thread are independent), the panel partials are then added in a fixed order.  (One stage with a serial loop over
+// all k per thread ran at the L2 latency: 88 us at M = 1024.)
+template <typename T>
+__global__ void __launch_bounds__(k256) linv_t_gemv_kernel(const T* __restrict__ LinvRM, const T* __restrict__ v, int64_t Mp,
+                                                           double* __restrict__ part) {
+  __shared__ double sh[4][64];
+  const int rl = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const int64_t r = int64_t(blockIdx.x) * 64 + rl, k0 = int64_t(blockIdx.y) * kNB;
+  double acc = 0.0;
+  if (k0 + kNB > int64_t(blockIdx.x) * 64) {   // panels wholly above the diagonal contribute nothing
+#pragma unroll 8
+    for (int kk = g; kk < kNB; kk += 4) {
+      const int64_t k = k0 + kk;
+      const double a = (k >= r) ? double(LinvRM[k * Mp + r]) : 0.0;
+      acc = fma(a, double(v[k]), acc);
+    }
+  }
+  sh[g][rl] = acc;
+  __syncthreads();
+  if (g == 0) part[int64_t(blockIdx.y) * Mp + r] = ((sh[0][rl] + sh[1][rl]) + sh[2][rl]) + sh[3][rl];
+}
+template <typename T>
+__global__ void gemv_finish_kernel(const double* __restrict__ part, int np, int64_t Mp, T* __restrict__ out) {
+  const int64_t r = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (r >= Mp) return;
+  double s = 0.0;
+  for (int q = 0; q < np; ++q) s += part[int64_t(q) * Mp + r];
+  out[r] = T(s);
 }
 
 // kernel value and its derivative w.r.t. r^2 (both including the variance)
@@ -442,39 +461,9 @@ __global__ void lower_to_rowmajor_kernel(const T* __restrict__ L, int64_t Mp, T*
 }
 
 template <typename T>
-__global__ void transpose_kernel(const T* __restrict__ in, int64_t Mp, T* __restrict__ out) {
-  __shared__ T tile[32][33];
-  const int64_t bx = int64_t(blockIdx.x) * 32, by = int64_t(blockIdx.y) * 32;
-  for (int q = threadIdx.y; q < 32; q += blockDim.y) tile[q][threadIdx.x] = in[(by + q) * Mp + bx + threadIdx.x];
-  __syncthreads();
-  for (int q = threadIdx.y; q < 32; q += blockDim.y) out[(bx + q) * Mp + by + threadIdx.x] = tile[threadIdx.x][q];
-}
-
-// out[c][r] = in[r][c]: k-major [Mp][ld] -> point-major [ncols][Mp] (64x64 tiles through LDS, both sides coalesced)
-template <typename T>
-__global__ void __launch_bounds__(k256) to_point_major_kernel(const T* __restrict__ in, int64_t ld, int64_t Mp, T* __restrict__ out) {
-  __shared__ T tile[64][65];
-  const int64_t c0 = int64_t(blockIdx.x) * 64, r0 = int64_t(blockIdx.y) * 64;
-  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-  for (int q = ty; q < 64; q += 4) tile[q][tx] = in[(r0 + q) * ld + c0 + tx];
-  __syncthreads();
-  for (int q = ty; q < 64; q += 4) out[(c0 + q) * Mp + r0 + tx] = tile[tx][q];
-}
-
-template <typename T>
 __global__ void symmetrize_kernel(const T* __restrict__ St, int64_t Mp, T* __restrict__ H) {
   const int64_t c = int64_t(blockIdx.x) * blockDim.x + threadIdx.x, r = blockIdx.y;
   if (c < Mp) H[r * Mp + c] = T(0.5) * (St[r * Mp + c] + St[c * Mp + r]);
-}
-
-// S diagonal blocks: S[I,I] = inv(L_II)' (T holds inv(L_II))
-template <typename T>
-__global__ void sdiag_kernel(const T* __restrict__ Tm, int64_t Mp, T* __restrict__ S) {
-  const int64_t o = int64_t(blockIdx.y) * kNB * (Mp + 1);
-  for (int e = threadIdx.x; e < kNB * kNB; e += blockDim.x) {
-    const int r = e % kNB, c = e / kNB;
-    S[o + r + int64_t(c) * Mp] = Tm[o + c + int64_t(r) * Mp];
-  }
 }
 
 // Phi = tril(X) with the diagonal halved, in place on a row-major Mp x Mp matrix
@@ -485,29 +474,6 @@ __global__ void phi_kernel(T* __restrict__ X, int64_t Mp) {
     const T v = X[r * Mp + c];
     X[r * Mp + c] = c < r ? v : (c == r ? T(0.5) * v : T(0));
   }
-}
-
-// reduce the split-K slices: Lq_bar (user layout, ld M) and Lk_bar row-major (negated, lower)
-template <typename T>
-__global__ void finish_mm_kernel(const T* __restrict__ G1, const T* __restrict__ G2, int nslices, int64_t Mp, int64_t M,
-                                 const T* __restrict__ Lq, int64_t ldq, T klw, T* __restrict__ Lq_bar,
-                                 T* __restrict__ BbarRM, T* __restrict__ LkbarRM) {
-  const int64_t c = int64_t(blockIdx.x) * blockDim.x + threadIdx.x, r = blockIdx.y;
-  if (c >= Mp) return;
-  T g1 = T(0), g2 = T(0);
-  if (c <= r)
-    for (int s = 0; s < nslices; ++s) {
-      g1 += G1[int64_t(s) * Mp * Mp + r * Mp + c];
-      g2 += G2[int64_t(s) * Mp * Mp + r * Mp + c];
-    }
-  LkbarRM[r * Mp + c] = -g2;
-  T v = T(0);
-  if (r < M && c <= r) {
-    const T l = Lq[r + c * ldq];
-    v = g1 - klw * (c == r ? l - T(1) / l : l);   // klw * d KL / d Lq
-  }
-  if (BbarRM) BbarRM[r * Mp + c] = v;                    // Centered: adjoint of B = Lk \ Lq, row-major for the solve
-  else if (r < M && c < M) Lq_bar[r + c * M] = v;
 }
 
 // Centered chain rule helpers ------------------------------------------------------------------------------
@@ -533,11 +499,11 @@ __global__ void lbar_adjust_kernel(T* __restrict__ LkbarRM, const T* __restrict_
   if (c < Mp && c <= r) LkbarRM[r * Mp + c] -= RBt[r * Mp + c] + rbar[r] * mt[c];
 }
 
-// user-layout (column-major, ld M) lower triangle of a row-major Mp x Mp matrix
+// user-layout lower triangle of a matrix held COLUMN-major in an Mp x Mp buffer (element (r, c) at R[c Mp + r])
 template <typename T>
-__global__ void rm_tril_to_user_kernel(const T* __restrict__ R, int64_t Mp, int64_t M, T* __restrict__ out) {
+__global__ void cm_tril_to_user_kernel(const T* __restrict__ R, int64_t Mp, int64_t M, T* __restrict__ out) {
   const int64_t r = int64_t(blockIdx.x) * blockDim.x + threadIdx.x, c = blockIdx.y;
-  if (r < M) out[r + c * M] = (c <= r) ? R[r * Mp + c] : T(0);
+  if (r < M) out[r + c * M] = (c <= r) ? R[c * Mp + r] : T(0);
 }
 
 // Slice partials of the kernel-gradient reductions, summed in a fixed order by many workgroups (a single pass of M threads
@@ -638,18 +604,8 @@ int grad_rowblocks(int d, int64_t Mp) { return int(d <= 16 ? Mp / 128 : Mp / 64)
 
 void launch_set_f64(hipStream_t s, double* dst, double value) { hipLaunchKernelGGL(set_f64_kernel, dim3(1), dim3(1), 0, s, dst, value); }
 void launch_set2_f64(hipStream_t s, double* dst, double a, double b) { hipLaunchKernelGGL(set2_f64_kernel, dim3(1), dim3(1), 0, s, dst, a, b); }
-void launch_grad_status(hipStream_t s, double* sums, const int* chol_info, double n_points) {
-  hipLaunchKernelGGL(grad_status_kernel, dim3(1), dim3(1), 0, s, sums, chol_info, n_points);
-}
-
-void launch_grad_moments(int dtype, hipStream_t s, const LikParams& lp, double scale, const double* n_global_dev,
-                         double num_data, const double* mom_mu, const double* mom_var, const void* y, int64_t off,
-                         int64_t len, int64_t npad, void* gmu, void* gv, double* partial, double* sums) {
-  const int64_t b = (npad + k256 - 1) / k256;
-  const int nb = int(b < 1024 ? b : 1024);
-  GD(dtype, T, hipLaunchKernelGGL(grad_moments_kernel<T>, dim3(nb), dim3(k256), 0, s, lp, scale, n_global_dev, num_data, mom_mu,
-                                  mom_var, (const T*)y, off, len, npad, (T*)gmu, (T*)gv, partial));
-  hipLaunchKernelGGL(sum5_kernel, dim3(1), dim3(320), 0, s, partial, nb, sums);
+void launch_grad_status(hipStream_t s, double* sums, const int* chol_info, double n_points, const double* prep_scal, double* prep_out) {
+  hipLaunchKernelGGL(grad_status_kernel, dim3(1), dim3(1), 0, s, sums, chol_info, n_points, prep_scal, prep_out);
 }
 
 void launch_sum5(hipStream_t s, const double* partial, int nblocks, double* sums) {
@@ -661,15 +617,9 @@ void launch_apart_reduce(hipStream_t s, const double* apart, int nstrips, int64_
 }
 
 void launch_sym_from_lower(int dtype, hipStream_t s, const void* G, int nslices, int64_t Mp, double eye, void* out) {
-  dim3 grid((unsigned)((Mp + 255) / 256), (unsigned)Mp);
-  GD(dtype, T, hipLaunchKernelGGL(sym_from_lower_kernel<T>, grid, dim3(256), 0, s, (const T*)G, nslices, Mp, T(eye), (T*)out));
-}
-
-void launch_vec_to_block(int dtype, hipStream_t s, const void* v, int64_t Mp, void* X) {
-  GD(dtype, T, hipLaunchKernelGGL(vec_to_block_kernel<T>, dim3((unsigned)((Mp * 64 + 255) / 256)), dim3(256), 0, s, (const T*)v, Mp, (T*)X));
-}
-void launch_block_to_vec(int dtype, hipStream_t s, const void* X, int64_t Mp, void* v) {
-  GD(dtype, T, hipLaunchKernelGGL(block_to_vec_kernel<T>, dim3((unsigned)((Mp + 255) / 256)), dim3(256), 0, s, (const T*)X, Mp, (T*)v));
+  const int64_t nb = Mp / 32;
+  GD(dtype, T, hipLaunchKernelGGL(sym_from_lower_kernel<T>, dim3((unsigned)(nb * (nb + 1) / 2)), dim3(k256), 0, s, (const T*)G, nslices, Mp,
+                                  T(eye), (T*)out));
 }
 
 void launch_avec(hipStream_t s, const double* rp_uf, int ns, int64_t stride, int64_t Mp, double* avec) {
@@ -683,63 +633,38 @@ void launch_finish_mm2(int dtype, hipStream_t s, const void* G1, const void* G2,
                                   M, (const T*)Lq, ldq, T(klw), (T*)Lq_bar, (T*)BbarRM, (T*)LkbarRM));
 }
 
-void launch_abar(int dtype, hipStream_t s, const void* Lqp, const void* C, const void* A, const void* mp, const void* gmu,
-                 const void* gv, void* Abar, int64_t Mp, int64_t ld, int64_t ncols) {
-  static const int forced = [] { const char* e = getenv("SVGP_ABAR_NT"); return e ? atoi(e) : 0; }();   // tuning knob
-  const int nt = forced ? forced : 64;   // 128 x 64 tiles on 256 threads: H value-and-gradient 130.2 -> 129.7 ms, H32 72.3 -> 71.9 ms
-  GD(dtype, T, {
-    if (nt == 64) {
-      using G = TileGemm<T, 64, 16, k256>;
-      auto kern = abar_kernel<T, 64, k256>;
-      set_max_lds(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, int(G::LDS_BYTES));
-      hipLaunchKernelGGL(kern, dim3((unsigned)(ncols / 64), (unsigned)(Mp / kNB)), dim3(k256), G::LDS_BYTES, s, (const T*)Lqp,
-                         (const T*)C, (const T*)A, (const T*)mp, (const T*)gmu, (const T*)gv, (T*)Abar, Mp, ld);
-    } else {
-      using G = TileGemm<T, kNB, 16, kThreads>;
-      auto kern = abar_kernel<T, kNB, kThreads>;
-      set_max_lds(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, int(G::LDS_BYTES));
-      hipLaunchKernelGGL(kern, dim3((unsigned)(ncols / kNB), (unsigned)(Mp / kNB)), dim3(kThreads), G::LDS_BYTES, s,
-                         (const T*)Lqp, (const T*)C, (const T*)A, (const T*)mp, (const T*)gmu, (const T*)gv, (T*)Abar, Mp, ld);
-    }
-  });
-}
-
-void launch_sdiag(int dtype, hipStream_t s, const void* Tm, int64_t Mp, void* S) {
-  dim3 grid(1, (unsigned)(Mp / kNB));
-  GD(dtype, T, hipLaunchKernelGGL(sdiag_kernel<T>, grid, dim3(k256), 0, s, (const T*)Tm, Mp, (T*)S));
-}
-
-void launch_solve_t(int dtype, hipStream_t s, const void* S, void* X, void* Xt, int64_t Mp, int64_t ld, int64_t ncols,
-                    int num_cus) {
-  // The panels of a strip are a dependency chain, so the parallelism is the number of column strips: a square M x M right-hand
-  // side has only M / 64 of them (16 at M = 1024 on 256 CUs), hence 32-column strips there (twice the workgroups, half the chain
-  // time each); wide right-hand sides keep the 64-column strips.
-  static const int forced = [] { const char* e = getenv("SVGP_SOLVE_T_NT"); return e ? atoi(e) : 0; }();   // tuning knob
-  const int nt = forced ? forced : (ncols / 64 < num_cus ? 32 : 64);
-  const int64_t nstrips = ncols / nt;
-  const int64_t cap = int64_t(num_cus) * 2;
-  const int grid = int(nstrips < cap ? nstrips : cap);
-  GD(dtype, T, {
-    if (nt == 32) {
-      using G = TileGemm<T, 32, 16, k256>;
-      set_max_lds(reinterpret_cast<const void*>(solve_t_kernel<T, 32>), hipFuncAttributeMaxDynamicSharedMemorySize, int(G::LDS_BYTES));
-      hipLaunchKernelGGL((solve_t_kernel<T, 32>), dim3(grid), dim3(k256), G::LDS_BYTES, s, (const T*)S, (T*)X, (T*)Xt, Mp, ld, nstrips);
-    } else {
-      using G = TileGemm<T, 64, 16, k256>;
-      set_max_lds(reinterpret_cast<const void*>(solve_t_kernel<T, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, int(G::LDS_BYTES));
-      hipLaunchKernelGGL((solve_t_kernel<T, 64>), dim3(grid), dim3(k256), G::LDS_BYTES, s, (const T*)S, (T*)X, (T*)Xt, Mp, ld, nstrips);
-    }
-  });
-}
-
-void launch_sum_slices_lower(int dtype, hipStream_t s, const void* part, int ns, int64_t Mp, void* out) {
+void launch_sum_slices_lower(int dtype, hipStream_t s, const void* part, int ns, int64_t Mp, void* out, int full, int overwrite) {
   dim3 grid((unsigned)((Mp + 255) / 256), (unsigned)Mp);
-  GD(dtype, T, hipLaunchKernelGGL(sum_slices_lower_kernel<T>, grid, dim3(256), 0, s, (const T*)part, ns, Mp, (T*)out));
+  GD(dtype, T, hipLaunchKernelGGL(sum_slices_lower_kernel<T>, grid, dim3(256), 0, s, (const T*)part, ns, Mp, (T*)out, full, overwrite));
+}
+
+void launch_linv(int dtype, hipStream_t s, const void* L, const void* Tm, int64_t Mp, void* LinvRM, void* LinvCM, void* Ytmp) {
+  const int nP = int(Mp / kNB);
+  GD(dtype, T, {
+    constexpr int NT = sizeof(T) == 8 ? 32 : 64, NCH = kNB / NT;   // the latency-bound chunking of the Cholesky tiles
+    using G = TileGemm<T, NT, 16, k256>;
+    set_max_lds(reinterpret_cast<const void*>(linv_step_kernel<T, NT, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, int(G::LDS_BYTES));
+    set_max_lds(reinterpret_cast<const void*>(linv_step_kernel<T, NT, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, int(G::LDS_BYTES));
+    hipLaunchKernelGGL(linv_init_kernel<T>, dim3(16, (unsigned)nP), dim3(k256), 0, s, (const T*)Tm, Mp, (T*)LinvRM, (T*)LinvCM);
+    for (int sz = 1; sz < nP; sz *= 2) {
+      const dim3 grid((unsigned)(sz * sz * NCH), (unsigned)((nP + 2 * sz - 1) / (2 * sz)));
+      hipLaunchKernelGGL((linv_step_kernel<T, NT, 1>), grid, dim3(k256), G::LDS_BYTES, s, (const T*)L, (T*)LinvRM, (T*)LinvCM, (T*)Ytmp, Mp, nP, sz);
+      hipLaunchKernelGGL((linv_step_kernel<T, NT, 2>), grid, dim3(k256), G::LDS_BYTES, s, (const T*)L, (T*)LinvRM, (T*)LinvCM, (T*)Ytmp, Mp, nP, sz);
+    }
+  });
+}
+
+void launch_linv_t_gemv(int dtype, hipStream_t s, const void* LinvRM, const void* v, int64_t Mp, void* out, double* part) {
+  const int nP = int(Mp / kNB);
+  GD(dtype, T, {
+    hipLaunchKernelGGL(linv_t_gemv_kernel<T>, dim3((unsigned)(Mp / 64), (unsigned)nP), dim3(k256), 0, s, (const T*)LinvRM, (const T*)v, Mp, part);
+    hipLaunchKernelGGL(gemv_finish_kernel<T>, dim3((unsigned)((Mp + 255) / 256)), dim3(256), 0, s, part, nP, Mp, (T*)out);
+  });
 }
 
 void launch_gemm_pm(int dtype, hipStream_t s, const void* Xt, const void* Yt, const void* w, double wscale, int64_t Mp,
-                    int64_t n, int64_t slice_len, int nslices, void* out, int overwrite) {
-  const int nP = int(Mp / kNB), ntiles = nP * (nP + 1) / 2;
+                    int64_t n, int64_t slice_len, int nslices, void* out, int overwrite, int flags) {
+  const int nP = int(Mp / kNB), ntiles = (flags & kMmFull) ? nP * nP : nP * (nP + 1) / 2;
   // f64: 128 x 64 halves on 256-thread workgroups (same-box: H value-and-gradient 141.0 -> 138.4 ms); f32: no difference
   static const int forced = [] { const char* e = getenv("SVGP_GEMM_PM_NT"); return e ? atoi(e) : 0; }();   // tuning knob
   const int nt = forced ? forced : (dtype == 0 ? 64 : 128);
@@ -749,13 +674,13 @@ void launch_gemm_pm(int dtype, hipStream_t s, const void* Xt, const void* Yt, co
       auto kern = gemm_pm_kernel<T, 64, k256>;
       set_max_lds(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, int(G::LDS_BYTES));
       hipLaunchKernelGGL(kern, dim3((unsigned)(ntiles * 2), (unsigned)nslices), dim3(k256), G::LDS_BYTES, s, (const T*)Xt,
-                         (const T*)Yt, (const T*)w, T(wscale), Mp, n, slice_len, (T*)out, overwrite);
+                         (const T*)Yt, (const T*)w, T(wscale), Mp, n, slice_len, (T*)out, overwrite, flags);
     } else {
       using G = TileGemm<T, kNB, 16, kThreads>;
       auto kern = gemm_pm_kernel<T, kNB, kThreads>;
       set_max_lds(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, int(G::LDS_BYTES));
       hipLaunchKernelGGL(kern, dim3((unsigned)ntiles, (unsigned)nslices), dim3(kThreads), G::LDS_BYTES, s, (const T*)Xt,
-                         (const T*)Yt, (const T*)w, T(wscale), Mp, n, slice_len, (T*)out, overwrite);
+                         (const T*)Yt, (const T*)w, T(wscale), Mp, n, slice_len, (T*)out, overwrite, flags);
     }
   });
 }
@@ -781,16 +706,6 @@ void launch_lower_to_rowmajor(int dtype, hipStream_t s, const void* L, int64_t M
   GD(dtype, T, hipLaunchKernelGGL(lower_to_rowmajor_kernel<T>, grid, block, 0, s, (const T*)L, Mp, (T*)out));
 }
 
-void launch_transpose(int dtype, hipStream_t s, const void* in, int64_t Mp, void* out) {
-  dim3 grid((unsigned)(Mp / 32), (unsigned)(Mp / 32)), block(32, 8);
-  GD(dtype, T, hipLaunchKernelGGL(transpose_kernel<T>, grid, block, 0, s, (const T*)in, Mp, (T*)out));
-}
-
-void launch_to_point_major(int dtype, hipStream_t s, const void* in, int64_t ld, int64_t Mp, int64_t ncols, void* out) {
-  dim3 grid((unsigned)(ncols / 64), (unsigned)(Mp / 64));
-  GD(dtype, T, hipLaunchKernelGGL(to_point_major_kernel<T>, grid, dim3(k256), 0, s, (const T*)in, ld, Mp, (T*)out));
-}
-
 void launch_symmetrize(int dtype, hipStream_t s, const void* St, int64_t Mp, void* H) {
   dim3 grid((unsigned)((Mp + 255) / 256), (unsigned)Mp);
   GD(dtype, T, hipLaunchKernelGGL(symmetrize_kernel<T>, grid, dim3(256), 0, s, (const T*)St, Mp, (T*)H));
@@ -799,13 +714,6 @@ void launch_symmetrize(int dtype, hipStream_t s, const void* St, int64_t Mp, voi
 void launch_phi(int dtype, hipStream_t s, void* X, int64_t Mp) {
   dim3 grid((unsigned)((Mp + 255) / 256), (unsigned)Mp);
   GD(dtype, T, hipLaunchKernelGGL(phi_kernel<T>, grid, dim3(256), 0, s, (T*)X, Mp));
-}
-
-void launch_finish_mm(int dtype, hipStream_t s, const void* G1, const void* G2, int nslices, int64_t Mp, int64_t M,
-                      const void* Lq, int64_t ldq, double klw, void* Lq_bar, void* BbarRM, void* LkbarRM) {
-  dim3 grid((unsigned)((Mp + 255) / 256), (unsigned)Mp);
-  GD(dtype, T, hipLaunchKernelGGL(finish_mm_kernel<T>, grid, dim3(256), 0, s, (const T*)G1, (const T*)G2, nslices, Mp, M,
-                                  (const T*)Lq, ldq, T(klw), (T*)Lq_bar, (T*)BbarRM, (T*)LkbarRM));
 }
 
 void launch_mbar(int dtype, hipStream_t s, const double* rp_uf, int ns, int64_t stride, const void* mt, double klw, int64_t M,
@@ -820,9 +728,9 @@ void launch_lbar_adjust(int dtype, hipStream_t s, void* LkbarRM, const void* RBt
                                   (const T*)mt, Mp));
 }
 
-void launch_rm_tril_to_user(int dtype, hipStream_t s, const void* R, int64_t Mp, int64_t M, void* out) {
+void launch_cm_tril_to_user(int dtype, hipStream_t s, const void* R, int64_t Mp, int64_t M, void* out) {
   dim3 grid((unsigned)((M + 255) / 256), (unsigned)M);
-  GD(dtype, T, hipLaunchKernelGGL(rm_tril_to_user_kernel<T>, grid, dim3(256), 0, s, (const T*)R, Mp, M, (T*)out));
+  GD(dtype, T, hipLaunchKernelGGL(cm_tril_to_user_kernel<T>, grid, dim3(256), 0, s, (const T*)R, Mp, M, (T*)out));
 }
 
 __global__ void add_f64_kernel(double* p, double v) { *p += v; }

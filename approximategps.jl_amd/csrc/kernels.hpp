@@ -35,11 +35,10 @@ void launch_transpose_colvecs(int dtype, hipStream_t s, const void* x_dn, int d,
 // Kuu (Mp x Mp col-major): k(z_i, z_j) + jitter*[i==j] on the M x M block, identity on the padding.
 void launch_kuu(int dtype, hipStream_t s, const KernelParams& kp, const void* zs, int64_t M, int64_t Mp,
                 double jitter, void* Kuu);
-// Blocked Cholesky in place (lower); T receives the inverted 128x128 diagonal blocks; info = 0 or the
-// 1-based order of the first non-positive pivot.
-void launch_potrf(int dtype, hipStream_t s, void* A, void* T, int64_t Mp, int* info);
-// T[I, <I] = -inv(L_II) * L[I, <I]   (diagonal blocks of T already hold inv(L_II))
-void launch_tpanels(int dtype, hipStream_t s, const void* L, void* T, int64_t Mp);
+// Blocked Cholesky in place (lower).  T receives the inverted 128x128 diagonal blocks AND, since round 3, its panels
+// T[I, <I] = -inv(L_II) * L[I, <I] (computed inside the factorisation's own launches); info = 0 or the 1-based order of the
+// first non-positive pivot; sync: Mp / 128 zeroed counters (device) for the in-kernel hand-over of the next diagonal block.
+void launch_potrf(int dtype, hipStream_t s, void* A, void* T, int64_t Mp, int* info, unsigned* sync);
 // U = Lq' (upper triangular, Mp x Mp col-major, zero padding); also mp[i] = m[i] padded with zeros.
 void launch_pack_q(int dtype, hipStream_t s, const void* Lq, const void* m, int64_t M, int64_t Mp, void* U, void* mp);
 // scal[0] = sum(Lq.^2 lower), scal[1] = m'm, scal[2] = sum log diag Lq, scal[3] = sum log diag Lk (first M)
@@ -117,8 +116,9 @@ void launch_expect(int dtype, hipStream_t s, const LikParams& lp, const double* 
                    void* var_out);
 // out[0..8) = {sum(partial[0..n)), n_points, sum(negcnt), *chol_info != 0, 0, 0, 0, 0} in fixed order (deterministic):
 // the vector a data-parallel evaluation all-reduces
+// out[8..13) (not all-reduced) = this rank's prep scalars prep_scal[0..4) and *chol_info: one read-back per evaluation
 void launch_final_reduce(hipStream_t s, const double* partial, const unsigned* negcnt, int64_t n, const int* chol_info,
-                         double n_points, double* out);
+                         double n_points, double* out, const double* prep_scal);
 // standalone Kuf (M x len col-major, ld = M)
 void launch_kuf(int dtype, hipStream_t s, const KernelParams& kp, const void* zs, int64_t M, int64_t Mp,
                 const void* x, int64_t ldx, int64_t off, int64_t len, void* Kuf);
@@ -131,25 +131,23 @@ void launch_cov_assemble(int dtype, hipStream_t s, const KernelParams& kp, const
 constexpr double kDefaultSigma2 = 1e-18;  // AbstractGPs.default_σ² added by f_post(x) (SVA:354)
 int grad_dreg(int d);
 int grad_rowblocks(int d, int64_t Mp);
-void launch_spanels(int dtype, hipStream_t s, const void* L, const void* T, void* S, int64_t Mp);
-void launch_sdiag(int dtype, hipStream_t s, const void* Tm, int64_t Mp, void* S);
-// scale: num_data / n_batch; with n_global_dev != nullptr (data-parallel: the all-reduced batch size lives on the device)
-// scale = num_data > 0 ? num_data / *n_global_dev : 1
-void launch_grad_moments(int dtype, hipStream_t s, const LikParams& lp, double scale, const double* n_global_dev,
-                         double num_data, const double* mom_mu, const double* mom_var, const void* y, int64_t off,
-                         int64_t len, int64_t npad, void* gmu, void* gv, double* partial, double* sums);
 void launch_set_f64(hipStream_t s, double* dst, double value);
 void launch_set2_f64(hipStream_t s, double* dst, double a, double b);   // dst[0] = a, dst[1] = b (values travel as kernel arguments: no host buffer to outlive)
 // sums[5] = n_points, sums[6] = (*chol_info != 0), sums[7] = 0: the status slots of the all-reduced gradient scalars
-void launch_grad_status(hipStream_t s, double* sums, const int* chol_info, double n_points);
-void launch_abar(int dtype, hipStream_t s, const void* Lqp, const void* C, const void* A, const void* mp, const void* gmu,
-                 const void* gv, void* Abar, int64_t Mp, int64_t ld, int64_t ncols);
-void launch_solve_t(int dtype, hipStream_t s, const void* S, void* X, void* Xt, int64_t Mp, int64_t ld, int64_t ncols,
-                    int num_cus);
+// ... and, behind them, a copy of the prep scalars (4) and chol_info (as a double): prep_out[0..5)
+void launch_grad_status(hipStream_t s, double* sums, const int* chol_info, double n_points, const double* prep_scal, double* prep_out);
+// flags of the M x M x M products (gemm_pm_kernel): all tiles instead of the lower ones; triangular operands (the contraction
+// starts / ends at the diagonal tile of the output row (X) or column (Y))
+enum : int { kMmFull = 1, kMmXLow = 2, kMmYLow = 4, kMmXUp = 8, kMmYUp = 16 };
 void launch_gemm_pm(int dtype, hipStream_t s, const void* Xt, const void* Yt, const void* w, double wscale, int64_t Mp,
-                    int64_t n, int64_t slice_len, int nslices, void* out, int overwrite = 0);
-// out (lower 128-tiles) += the sum of `ns` slice partials written by launch_gemm_pm(..., overwrite = 1)
-void launch_sum_slices_lower(int dtype, hipStream_t s, const void* part, int ns, int64_t Mp, void* out);
+                    int64_t n, int64_t slice_len, int nslices, void* out, int overwrite = 0, int flags = 0);
+// out (lower 128-tiles, or all with full) (+)= the sum of `ns` slice partials written by launch_gemm_pm(..., overwrite = 1)
+void launch_sum_slices_lower(int dtype, hipStream_t s, const void* part, int ns, int64_t Mp, void* out, int full = 0, int overwrite = 0);
+// Linv = Lk^-1 by recursive doubling from the inverted diagonal blocks in T: LinvRM row-major, LinvCM column-major (only
+// the lower block triangle is written / ever read); Ytmp: Mp x Mp scratch
+void launch_linv(int dtype, hipStream_t s, const void* L, const void* Tm, int64_t Mp, void* LinvRM, void* LinvCM, void* Ytmp);
+// out = Lk^-T v = LinvRM' v; part: (Mp / 128) x Mp doubles of scratch
+void launch_linv_t_gemv(int dtype, hipStream_t s, const void* LinvRM, const void* v, int64_t Mp, void* out, double* part);
 void launch_kgrad(int dtype, hipStream_t s, const KernelParams& kp, const void* zs, int64_t Mp, const void* x, int64_t ldx,
                   int64_t xoff, int prescaled, int64_t n, int64_t nvalid, const void* Pt, const void* At, const void* gmu,
                   int64_t slice_len, int nslices, double* rowpart, double* scalpart);
@@ -159,22 +157,16 @@ void launch_sum5(hipStream_t s, const double* partial, int nblocks, double* sums
 // out[i] += sum over strips of apart[strip][i]  (fixed order)
 void launch_apart_reduce(hipStream_t s, const double* apart, int nstrips, int64_t Mp, double* out);
 void launch_sym_from_lower(int dtype, hipStream_t s, const void* G, int nslices, int64_t Mp, double eye, void* out);
-void launch_vec_to_block(int dtype, hipStream_t s, const void* v, int64_t Mp, void* X);   // v -> column 0 of an Mp x 64 block
-void launch_block_to_vec(int dtype, hipStream_t s, const void* X, int64_t Mp, void* v);
 void launch_avec(hipStream_t s, const double* rp_uf, int ns, int64_t stride, int64_t Mp, double* avec);
 void launch_finish_mm2(int dtype, hipStream_t s, const void* G1, const void* G2, const void* alpha, const double* avec, int64_t Mp,
                        int64_t M, const void* Lq, int64_t ldq, double klw, void* Lq_bar, void* BbarRM, void* LkbarRM);
 void launch_lower_to_rowmajor(int dtype, hipStream_t s, const void* L, int64_t Mp, void* out);
-void launch_transpose(int dtype, hipStream_t s, const void* in, int64_t Mp, void* out);
-void launch_to_point_major(int dtype, hipStream_t s, const void* in, int64_t ld, int64_t Mp, int64_t ncols, void* out);
 void launch_symmetrize(int dtype, hipStream_t s, const void* St, int64_t Mp, void* H);
 void launch_phi(int dtype, hipStream_t s, void* X, int64_t Mp);
-void launch_finish_mm(int dtype, hipStream_t s, const void* G1, const void* G2, int nslices, int64_t Mp, int64_t M,
-                      const void* Lq, int64_t ldq, double klw, void* Lq_bar, void* BbarRM, void* LkbarRM);
 void launch_mbar(int dtype, hipStream_t s, const double* rp_uf, int ns, int64_t stride, const void* mt, double klw, int64_t M,
                  int64_t Mp, void* vec);
 void launch_lbar_adjust(int dtype, hipStream_t s, void* LkbarRM, const void* RBt, const void* rbar, const void* mt, int64_t Mp);
-void launch_rm_tril_to_user(int dtype, hipStream_t s, const void* R, int64_t Mp, int64_t M, void* out);
+void launch_cm_tril_to_user(int dtype, hipStream_t s, const void* R, int64_t Mp, int64_t M, void* out);   // R column-major
 void launch_add_f64(hipStream_t s, double* p, double v);   // *p += v
 void launch_finish_kgrad(int dtype, hipStream_t s, int d, int64_t M, int64_t Mp, const void* zs, const double* invl,
                          const double* rp_uf, int ns_uf, const double* rp_uu, int ns_uu, const double* sp_uf, int nsp_uf,

@@ -33,25 +33,47 @@ __global__ void transpose_colvecs_kernel(const T* __restrict__ x, int d, int64_t
   for (int f = 0; f < d; ++f) out[int64_t(f) * ldx + i] = x[i * d + f];
 }
 
-template <typename T>
-__global__ void kuu_kernel(KernelParams kp, const T* __restrict__ zs, int64_t M, int64_t Mp, T jitter,
-                           T* __restrict__ K) {
-  const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
-  const int64_t j = blockIdx.y;
-  if (i >= Mp) return;
-  T v;
-  if (i < M && j < M) {
-    T r2 = T(0);
-    for (int f = 0; f < kp.d; ++f) {
-      const T df = zs[int64_t(f) * Mp + i] - zs[int64_t(f) * Mp + j];
-      r2 = fma(df, df, r2);
-    }
-    v = kappa<T>(kp.family, r2, T(kp.variance));
-    if (i == j) v += jitter;
-  } else {
-    v = (i == j) ? T(1) : T(0);
+// Kuu = k(z, z) + jitter I on the M x M block, identity on the padding.  Only the 128-tiles on and below the diagonal are
+// written: the factorisation (and every later reader of L) never touches the tiles above it.  A thread owns one row i and JB
+// consecutive columns: its scaled z_i stays in registers (d <= 8) and z_j is wave-uniform, so an element costs one pass over the
+// features instead of 2 d loads (round 2: one element per thread, 287 us at M = 8192 fp32 = 0.9 TB/s of stores).
+template <typename T, int DREG>
+__global__ void __launch_bounds__(k256) kuu_kernel(KernelParams kp, const T* __restrict__ zs, int64_t M, int64_t Mp, T jitter,
+                                                   T* __restrict__ K) {
+  constexpr int JB = 16;
+  const int64_t i = int64_t(blockIdx.x) * k256 + threadIdx.x;
+  const int64_t j0 = int64_t(blockIdx.y) * JB;
+  if (i >= Mp || j0 / kNB > (int64_t(blockIdx.x) * k256 + k256 - 1) / kNB) return;   // the whole block lies above the diagonal tiles
+  T zi[DREG > 0 ? DREG : 1];
+  if constexpr (DREG > 0) {
+#pragma unroll
+    for (int f = 0; f < DREG; ++f) zi[f] = (f < kp.d) ? zs[int64_t(f) * Mp + i] : T(0);
   }
-  K[i + j * Mp] = v;
+  for (int jj = 0; jj < JB; ++jj) {
+    const int64_t j = j0 + jj;
+    if (j / kNB > i / kNB) continue;   // tile above the diagonal
+    T v;
+    if (i < M && j < M) {
+      T r2 = T(0);
+      if constexpr (DREG > 0) {
+#pragma unroll
+        for (int f = 0; f < DREG; ++f) {
+          const T df = zi[f] - ((f < kp.d) ? zs[int64_t(f) * Mp + j] : T(0));
+          r2 = fma(df, df, r2);
+        }
+      } else {
+        for (int f = 0; f < kp.d; ++f) {
+          const T df = zs[int64_t(f) * Mp + i] - zs[int64_t(f) * Mp + j];
+          r2 = fma(df, df, r2);
+        }
+      }
+      v = kappa<T>(kp.family, r2, T(kp.variance));
+      if (i == j) v += jitter;
+    } else {
+      v = (i == j) ? T(1) : T(0);
+    }
+    K[i + j * Mp] = v;
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -91,58 +113,97 @@ __device__ __forceinline__ float krsqrt(float d) {
 }
 
 #ifdef SVGP_POTF2_STAMPS   // diagnostic build (tools/build_ablate.sh stamps): s_memtime at the phase boundaries of potf2
-__device__ unsigned long long g_potf2_stamps[64];
+__device__ unsigned long long g_potf2_stamps[128];
 #define SVGP_STAMP(i) do { if (threadIdx.x == 0) g_potf2_stamps[i] = clock64(); } while (0)
+#define SVGP_STAMP1(i) do { if (threadIdx.x == 64) g_potf2_stamps[64 + (i)] = clock64(); } while (0)   // wave 1, a worker
 extern "C" int svgp_debug_potf2_stamps(unsigned long long* out) {
   return int(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_potf2_stamps), sizeof(g_potf2_stamps)));
 }
 #else
 #define SVGP_STAMP(i)
+#define SVGP_STAMP1(i)
 #endif
 
 // wave 0's part of a block step: factor the 16x16 diagonal block at offset o (already updated) and invert it.
-// 16x16 Cholesky AND its inverse in registers, left-looking: lane l15 (every 16-lane group redundantly) owns row l15 of
-// L and column l15 of X = inv(L).  Step j broadcasts row j of L once (v_readlane from lane j) and that one broadcast
-// serves both the column update  L[i][j] = (A[i][j] - sum_s L[i][s] L[j][s]) / L[j][j]  and the inverse row
-// X[j][c] = (delta_jc - sum_k L[j][k] X[k][c]) / L[j][j].  A step is a chain of ~45 dependent VALU operations
-// (~360 cycles; s_memtime stamps): 128 such steps are the critical path of the whole block.
+// 16x16 Cholesky AND its inverse in registers, left-looking: lane l15 (every 16-lane row of the wave redundantly) owns row
+// l15 of L and column l15 of X = inv(L).  Step j needs row j of L in every lane:
+//   L[i][j] = (A[i][j] - sum_k L[i][k] L[j][k]) / L[j][j]      X[j][c] = (delta_jc - sum_k L[j][k] X[k][c]) / L[j][j]
+// Round 3: the broadcast is a DPP row_newbcast (lane j of each 16-lane row to the whole row: v_mov_b32_dpp, pure VALU).  Rounds
+// 1-2 used v_readlane into an SGPR; s_memtime showed 340 cycles per column step whatever the instruction count (43 -> 27
+// instructions changed nothing): the VALU -> SGPR -> VALU round trip of the two readlanes on the dependent chain is what a
+// step costs, and the 128 steps of a block are the critical path of the whole factorisation.  fp32 takes the hardware
+// v_rsq_f32 (1 ulp) as it is; fp64 keeps the Newton refinements (v_rsq_f64 delivers ~26 bits).  No per-step selects: an X
+// lane starts from delta_jc and stays exactly zero above the diagonal; the diagonal entry is t r = sqrt(t) like any other
+// entry of its column; L rows hold unused garbage right of the diagonal.
+#ifndef SVGP_F16_DPP
+#define SVGP_F16_DPP 1   // 0: v_readlane broadcasts (A/B and bisection builds)
+#endif
+template <int J>
+__device__ __forceinline__ float row_bcast(float v) {
+#if SVGP_F16_DPP
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x150 + J, 0xf, 0xf, true));
+#else
+  return readlane_t(v, J);
+#endif
+}
+template <int J>
+__device__ __forceinline__ double row_bcast(double v) {
+#if SVGP_F16_DPP
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x150 + J, 0xf, 0xf, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x150 + J, 0xf, 0xf, true);
+  return __hiloint2double(hi, lo);
+#else
+  return readlane_t(v, J);
+#endif
+}
+__device__ __forceinline__ double pivot_scale(double t, double d, double rj) {
+  double dj = d * rj;
+  dj = fma(fma(-dj, dj, d), 0.5 * rj, dj);              // sqrt(d)
+  const double res = t * rj;
+  return fma(fma(-res, dj, t), rj, res);                // t / sqrt(d)
+}
+__device__ __forceinline__ float pivot_scale(float t, float, float rj) { return t * rj; }
+__device__ __forceinline__ double kpivot_rsqrt(double d) { return krsqrt(d); }
+__device__ __forceinline__ float kpivot_rsqrt(float d) { return __builtin_amdgcn_rsqf(d); }
+
+template <typename T, int J>
+__device__ __forceinline__ void factor16_step(T (&row)[16], T (&x)[16], int l15, int& bad) {
+  T t0 = row[J], t1 = T(0), s0 = x[J], s1 = T(0);
+#pragma unroll
+  for (int k = 0; k < J; ++k) {
+    const T b = row_bcast<J>(row[k]);   // L[J][k], from lane J of this lane's 16-lane row
+    if (k & 1) {
+      t1 = fma(-row[k], b, t1);
+      s1 = fma(-b, x[k], s1);
+    } else {
+      t0 = fma(-row[k], b, t0);
+      s0 = fma(-b, x[k], s0);
+    }
+  }
+  const T t = t0 + t1, sx = s0 + s1;
+  const T d = row_bcast<J>(t);                            // the pivot, in every lane
+  if (!(d > T(0)) && !bad) bad = J + 1;
+  const T rj = kpivot_rsqrt(d);
+  row[J] = pivot_scale(t, d, rj);
+  x[J] = pivot_scale(sx, d, rj);
+}
+
 template <typename T>
 __device__ __forceinline__ int factor16(T* __restrict__ sm, T* __restrict__ dinv, int LD, int DL, int o, int p, int lane) {
   const int l15 = lane & 15;
   T row[16], x[16];
 #pragma unroll
-  for (int c = 0; c < 16; ++c) row[c] = sm[(o + l15) * LD + o + c];
-  int bad = 0;
-#pragma unroll
-  for (int j = 0; j < 16; ++j) {
-    T bj[16];
-#pragma unroll
-    for (int k = 0; k < j; ++k) bj[k] = readlane_t(row[k], j);
-    T t0 = row[j], t1 = T(0), s0 = (l15 == j) ? T(1) : T(0), s1 = T(0);
-#pragma unroll
-    for (int k = 0; k < j; ++k) {
-      if (k & 1) {
-        t1 = fma(-row[k], bj[k], t1);
-        s1 = fma(-bj[k], x[k], s1);
-      } else {
-        t0 = fma(-row[k], bj[k], t0);
-        s0 = fma(-bj[k], x[k], s0);
-      }
-    }
-    const T t = t0 + t1;
-    const T d = readlane_t(t, j);
-    if (!(d > T(0)) && !bad) bad = j + 1;
-    const T rj = krsqrt(d);
-    T dj = d * rj;
-    dj = fma(fma(-dj, dj, d), T(0.5) * rj, dj);           // sqrt(d)
-    T lij = t * rj;
-    lij = fma(fma(-lij, dj, t), rj, lij);                 // t / sqrt(d)
-    const T sx = s0 + s1;
-    T xj = sx * rj;
-    xj = fma(fma(-xj, dj, sx), rj, xj);
-    row[j] = (l15 == j) ? dj : lij;
-    x[j] = (l15 <= j) ? xj : T(0);
+  for (int c = 0; c < 16; ++c) {
+    row[c] = sm[(o + l15) * LD + o + c];
+    x[c] = (l15 == c) ? T(1) : T(0);
   }
+  int bad = 0;
+  factor16_step<T, 0>(row, x, l15, bad);  factor16_step<T, 1>(row, x, l15, bad);  factor16_step<T, 2>(row, x, l15, bad);
+  factor16_step<T, 3>(row, x, l15, bad);  factor16_step<T, 4>(row, x, l15, bad);  factor16_step<T, 5>(row, x, l15, bad);
+  factor16_step<T, 6>(row, x, l15, bad);  factor16_step<T, 7>(row, x, l15, bad);  factor16_step<T, 8>(row, x, l15, bad);
+  factor16_step<T, 9>(row, x, l15, bad);  factor16_step<T, 10>(row, x, l15, bad); factor16_step<T, 11>(row, x, l15, bad);
+  factor16_step<T, 12>(row, x, l15, bad); factor16_step<T, 13>(row, x, l15, bad); factor16_step<T, 14>(row, x, l15, bad);
+  factor16_step<T, 15>(row, x, l15, bad);
   if (lane < 16) {
 #pragma unroll
     for (int c = 0; c < 16; ++c) {
@@ -160,45 +221,78 @@ __device__ __forceinline__ int factor16(T* __restrict__ sm, T* __restrict__ dinv
 // is k-slab r of a B fragment when A is read with k = Mfma16::row(lane, r); X[ti,tj]' lives in the strictly upper block
 // (tj,ti) of the LDS image).  Critical path per block: panel + one tile update + factor16; everything else hides
 // behind the factor (s_memtime: 115k -> ~70k cycles per 128-block).
+// The body is a device function of a 256-thread workgroup (smem_raw: potf2_lds_bytes<T>() of dynamic LDS) so that the
+// trailing-update kernels can run it on the NEXT diagonal block the moment that block is up to date (potrf_t below).
 template <typename T>
-__global__ void __launch_bounds__(k256) potf2_kernel(T* __restrict__ A, T* __restrict__ Tm, int64_t ld,
-                                                      int* __restrict__ info, int pbase) {
-  constexpr int NB = kNB, LD = NB + 1, NBLK = NB / 16, DL = 17;
+constexpr int potf2_ld() { return kNB + (sizeof(T) == 4 ? 4 : 2); }
+template <typename T>
+constexpr size_t potf2_lds_bytes() { return (size_t(kNB) * potf2_ld<T>() + 8 * 16 * 17) * sizeof(T); }
+
+// Workgroup barrier that waits for the wave's LDS traffic only (s_waitcnt lgkmcnt(0)), not for its outstanding global
+// stores: potf2's workers write finished panels out while the block is still being factored, and a __syncthreads() - which
+// also drains vmcnt - made every step wait for a store round trip (s_memtime: +4k cycles per step).  Everything the waves
+// exchange inside potf2 goes through LDS; data loaded from global memory reaches LDS through registers (a data dependence).
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+template <typename T>
+__device__ __forceinline__ void potf2_body(T* __restrict__ A, T* __restrict__ Tm, int64_t ld, int* __restrict__ info, int pbase,
+                                           unsigned char* __restrict__ smem_raw) {
+  // Row stride of the LDS image: an MFMA fragment read touches rows l15 = 0..15 at columns g = 0..3 of a k-slab, i.e. dword
+  // l15 LD + g (fp32) / 2 (l15 LD + g) (f64): with LD = 129 (rounds 1-2) that is bank l15 + g - 19 banks for 64 lanes, a 3-4 way
+  // conflict on every fragment read of the panel solves, the trailing updates and the inverse rows (s_memtime: 1.2k cycles per
+  // 16 x 16 tile update).  LD = 132 (fp32: bank 4 l15 + g) / 130 (f64: bank 4 l15 + 2 g per half wave) are conflict-free.
+  constexpr int NB = kNB, LD = potf2_ld<T>(), NBLK = NB / 16, DL = 17;
   using M16 = Mfma16<T>;
   using acc_t = typename M16::acc_t;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  T* sm = reinterpret_cast<T*>(smem_raw);   // [128][129] row-major block; strictly-upper 16-blocks later hold X'
+  T* sm = reinterpret_cast<T*>(smem_raw);   // [128][LD] row-major block; strictly-upper 16-blocks later hold X'
   T* dinv = sm + NB * LD;                   // [8][16][17]  inverses of the 16x16 diagonal blocks
   __shared__ int failed;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l15 = lane & 15, g = lane >> 4;
   SVGP_STAMP(0);
   if (tid == 0) failed = (*info != 0) ? -1 : 0;
+  // Round 3 (s_memtime, fp32: of 75k cycles per block 5.2k were the load, 5.4k the first 16 x 16 factor, 8.5k the final store):
+  // only the 32 leading columns are loaded before the first factor starts; waves 1-3 bring in the other 96 BESIDE it
+  // (64 elements per thread, unconditional batches of 16 loads in flight).
   {
-    // 64 elements per thread, 16 loads in flight at a time (a plain loop waits for every load before its LDS store)
-    constexpr int U = 16;
-    for (int e0 = tid; e0 < NB * NB; e0 += k256 * U) {
-      T v[U];
+    constexpr int U = 16;   // 128 x 32 elements / 256 threads
+    T v[U];
 #pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const int e = e0 + u * k256;
-        v[u] = A[(e % NB) + int64_t(e / NB) * ld];
-      }
+    for (int u = 0; u < U; ++u) {
+      const int e = tid + u * k256;
+      v[u] = A[(e % NB) + int64_t(e / NB) * ld];
+    }
 #pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const int e = e0 + u * k256;
-        sm[(e % NB) * LD + e / NB] = v[u];
-      }
+    for (int u = 0; u < U; ++u) {
+      const int e = tid + u * k256;
+      sm[(e % NB) * LD + e / NB] = v[u];
     }
   }
-  __syncthreads();
+  lds_barrier();
   if (failed) return;  // an earlier panel already reported the first bad pivot
   SVGP_STAMP(1);
   if (wave == 0) {
     const int bad = factor16(sm, dinv, LD, DL, 0, 0, lane);
     if (bad && lane == 0) failed = pbase + bad;
+    SVGP_STAMP(42);
+  } else {
+    constexpr int U = 16, NW3 = 192;   // 128 x 96 elements / 192 threads = 64
+#pragma unroll 1
+    for (int b = 0; b < 4; ++b) {
+      T v[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int e = 32 * NB + (tid - 64) + (b * U + u) * NW3;
+        v[u] = A[(e % NB) + int64_t(e / NB) * ld];
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int e = 32 * NB + (tid - 64) + (b * U + u) * NW3;
+        sm[(e % NB) * LD + e / NB] = v[u];
+      }
+    }
   }
-  __syncthreads();
+  lds_barrier();
 
   for (int p = 0; p < NBLK; ++p) {
     const int o = 16 * p;
@@ -218,7 +312,7 @@ __global__ void __launch_bounds__(k256) potf2_kernel(T* __restrict__ A, T* __res
 #pragma unroll
       for (int r = 0; r < 4; ++r) sm[(16 * t + M16::row(lane, r)) * LD + o + l15] = acc[r];
     }
-    __syncthreads();
+    lds_barrier();
     SVGP_STAMP(3 + 4 * p);
     auto update_tile = [&](int ti, int tj) {   // A[ti, tj] -= L[ti, p] L[tj, p]'
       const int bi = 16 * ti, bj = 16 * tj;
@@ -231,22 +325,67 @@ __global__ void __launch_bounds__(k256) potf2_kernel(T* __restrict__ A, T* __res
 #pragma unroll
       for (int r = 0; r < 4; ++r) sm[(bi + M16::row(lane, r)) * LD + bj + l15] -= acc[r];
     };
+    // two tiles at a time: their fragment reads and MFMA chains interleave (one tile alone runs at the LDS / MFMA latency)
+    auto update_tile2 = [&](int ti, int tj, int ui, int uj) {
+      const int bi = 16 * ti, bj = 16 * tj, ci = 16 * ui, cj = 16 * uj;
+      T fa[4], fb[4], ga[4], gb[4];
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const int k = o + 4 * s + g;
+        fa[s] = sm[(bi + l15) * LD + k];
+        fb[s] = sm[(bj + l15) * LD + k];
+        ga[s] = sm[(ci + l15) * LD + k];
+        gb[s] = sm[(cj + l15) * LD + k];
+      }
+      acc_t a1 = {0, 0, 0, 0}, a2 = {0, 0, 0, 0};
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        a1 = M16::mma(fa[s], fb[s], a1);
+        a2 = M16::mma(ga[s], gb[s], a2);
+      }
+      T c1[4], c2[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        c1[r] = sm[(bi + M16::row(lane, r)) * LD + bj + l15];
+        c2[r] = sm[(ci + M16::row(lane, r)) * LD + cj + l15];
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        sm[(bi + M16::row(lane, r)) * LD + bj + l15] = c1[r] - a1[r];
+        sm[(ci + M16::row(lane, r)) * LD + cj + l15] = c2[r] - a2[r];
+      }
+    };
     const bool last = (p + 1 == NBLK);          // no next factor: wave 0 joins the inverse-row work
     if (wave == 0 && !last) {
       update_tile(p + 1, p + 1);
+      SVGP_STAMP(44 + 2 * p);
       const int bad = factor16(sm, dinv, LD, DL, o + 16, p + 1, lane);
       if (bad && lane == 0) failed = pbase + o + 16 + bad;
-    } else {
-      // trailing tiles p < tj <= ti except (p+1, p+1), then row p of the block inverse, dealt round-robin to the workers
-      const int nw = last ? 4 : 3, me = last ? wave : wave - 1;
+      SVGP_STAMP(45 + 2 * p);
+    }
+    {
+      // trailing tiles p < tj <= ti except (p+1, p+1), then row p of the block inverse, dealt out statically: the first kHold
+      // items go round-robin to waves 1-3 only - about what wave 0's own tile + factor cost - after that wave 0 takes its share
+      // (with the DPP factor the workers, not the factor, are the longer side of the early steps)
+#ifndef SVGP_POTF2_W0
+#define SVGP_POTF2_W0 1   // 0: wave 0 only factors, the trailing work is dealt to waves 1-3 (A/B and bisection builds)
+#endif
+      constexpr int kHold = SVGP_POTF2_W0 ? (sizeof(T) == 8 ? 15 : 12) : (1 << 30);
+      auto mine = [&](int idx) { return last ? (idx & 3) == wave : (idx < kHold ? 1 + idx % 3 == wave : ((idx - kHold) & 3) == wave); };
       const int n = NBLK - p - 1;
-      int ti = 0, tj = 0, idx = 0;
+      SVGP_STAMP1(4 * p);
+      int ti = 0, tj = 0, idx = 0, hi = -1, hj = -1;
       for (int q = 0; q < n * (n + 1) / 2; ++q) {
-        if (q > 0 && (idx++ % nw) == me) update_tile(p + 1 + ti, p + 1 + tj);
+        if (q > 0 && mine(idx++)) {
+          if (hi < 0) { hi = p + 1 + ti; hj = p + 1 + tj; }
+          else { update_tile2(hi, hj, p + 1 + ti, p + 1 + tj); hi = -1; }
+        }
         if (++tj > ti) { tj = 0; ++ti; }
       }
+      if (hi >= 0) update_tile(hi, hj);
+      SVGP_STAMP1(4 * p + 1);
       for (int tj2 = 0; tj2 < p; ++tj2) {
-        if ((idx++ % nw) != me) continue;
+        if (!mine(idx++)) continue;
         acc_t acc = {0, 0, 0, 0};
         for (int sb = tj2; sb < p; ++sb) {
 #pragma unroll
@@ -263,8 +402,55 @@ __global__ void __launch_bounds__(k256) potf2_kernel(T* __restrict__ A, T* __res
 #pragma unroll
         for (int r = 0; r < 4; ++r) sm[(16 * tj2 + l15) * LD + o + M16::row(lane, r)] = -x[r];
       }
+      SVGP_STAMP1(4 * p + 2);
+      // Results that are final leave NOW, beside wave 0's factor (round 2 wrote everything in a closing pass of 8.5k cycles):
+      // column panel p of L (its diagonal block was factored during the previous step, the rows below it by this step's panel
+      // solve) and row block p-1 of the block inverse (completed by the previous step's workers).  16-byte vectors along the
+      // rows (global memory is column-major), all the LDS reads of a thread before its stores.  Unmasked: the part of a diagonal
+      // 16 x 16 block above its diagonal is the untouched input in L's image (nobody reads it back) and exact zeros in the
+      // inverse's (the X lanes of factor16 never leave zero there) - T's diagonal blocks must be zero above the diagonal.
+      if (wave != 0 || last) {
+        using V = typename Vec16<T>::type;
+        constexpr int VEC = Vec16<T>::N, RV = NB / VEC;           // row vectors per column of the block
+        const int wt = last ? tid : tid - 64, nwt = last ? k256 : 192;
+        constexpr int UL = (16 * RV + 191) / 192;                  // L panel: 16 columns x RV vectors
+        V bl[UL];
+#pragma unroll
+        for (int u = 0; u < UL; ++u) {
+          const int e = wt + u * nwt, c = e & 15, r = ((e >> 4) % RV) * VEC;   // lanes run along the 16 columns: conflict-free LDS reads
+#pragma unroll
+          for (int i = 0; i < VEC; ++i) bl[u][i] = sm[(r + i) * LD + o + c];
+        }
+#pragma unroll
+        for (int u = 0; u < UL; ++u) {
+          const int e = wt + u * nwt, c = e & 15, r = (e >> 4) * VEC;
+          if (e < 16 * RV && r >= o) *reinterpret_cast<V*>(A + r + int64_t(o + c) * ld) = bl[u];
+        }
+        if (p > 0) {
+          const int q0 = 16 * (p - 1);
+          constexpr int CV = 16 / VEC;                              // vectors per column of a 16-row block
+          constexpr int UX = (NB * CV + 191) / 192;
+          V bx[UX];
+#pragma unroll
+          for (int u = 0; u < UX; ++u) {
+            const int e = wt + u * nwt, vi = e % CV, c = (e / CV) & (NB - 1), r = q0 + vi * VEC;
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) {
+              // diagonal block: dinv (which follows sm in LDS: dinv = sm + NB * LD); left of it: X' in the upper part of the image
+              const int idx = (c >= q0) ? NB * LD + (r + i) * DL + ((c - q0) & 15) : c * LD + r + i;
+              bx[u][i] = sm[idx];
+            }
+          }
+#pragma unroll
+          for (int u = 0; u < UX; ++u) {
+            const int e = wt + u * nwt, vi = e % CV, c = e / CV, r = q0 + vi * VEC;
+            if (c < q0 + 16) *reinterpret_cast<V*>(Tm + r + int64_t(c) * ld) = bx[u];
+          }
+        }
+      }
     }
-    __syncthreads();
+    SVGP_STAMP1(4 * p + 3);
+    lds_barrier();
     SVGP_STAMP(4 + 4 * p);
   }
   if (failed) {   // a bad pivot in the last block
@@ -272,31 +458,31 @@ __global__ void __launch_bounds__(k256) potf2_kernel(T* __restrict__ A, T* __res
     return;
   }
   SVGP_STAMP(40);
-  {
-    constexpr int U = 8;
-    for (int e0 = tid; e0 < NB * NB; e0 += k256 * U) {
-      T lv[U], xv[U];
+  {   // the last row block of the inverse (its off-diagonal tiles were computed in the last step)
+    using V = typename Vec16<T>::type;
+    constexpr int VEC = Vec16<T>::N, CV = 16 / VEC, q0 = NB - 16;
+    for (int e = tid; e < NB * CV; e += k256) {
+      const int vi = e % CV, c = e / CV, r = q0 + vi * VEC;
+      V v;
 #pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const int e = e0 + u * k256, r = e % NB, c = e / NB;
-        lv[u] = sm[r * LD + c];
-        xv[u] = ((r >> 4) == (c >> 4)) ? dinv[((r >> 4) * 16 + (r & 15)) * DL + (c & 15)] : sm[c * LD + r];
-      }
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const int e = e0 + u * k256, r = e % NB, c = e / NB;
-        if (r >= c) A[r + int64_t(c) * ld] = lv[u];
-        Tm[r + int64_t(c) * ld] = (r >= c) ? xv[u] : T(0);
-      }
+      for (int i = 0; i < VEC; ++i) v[i] = (c >= q0) ? dinv[(r + i) * DL + (c - q0)] : sm[c * LD + r + i];
+      *reinterpret_cast<V*>(Tm + r + int64_t(c) * ld) = v;
     }
   }
   SVGP_STAMP(41);
 }
 
+template <typename T>
+__global__ void __launch_bounds__(k256) potf2_kernel(T* __restrict__ A, T* __restrict__ Tm, int64_t ld,
+                                                      int* __restrict__ info, int pbase) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  potf2_body<T>(A, Tm, ld, info, pbase, smem_raw);
+}
+
 // ------------------------------------------------------------------------------------------------
-// 128x128 MFMA tile kernels used by the blocked Cholesky and the T panels.
+// MFMA tile kernels of the blocked Cholesky (and of the T panels, which ride in its launches).
 // ------------------------------------------------------------------------------------------------
-enum : int { MODE_TRSM = 0, MODE_SYRK = 1, MODE_TPANEL = 2, MODE_SPANEL = 3 };
+enum : int { MODE_TRSM = 0, MODE_SYRK = 1 };
 
 __device__ __forceinline__ void tri_index(int b, int& i, int& j) {  // b -> (i >= j) in row-major triangle order
   i = 0;
@@ -307,90 +493,23 @@ __device__ __forceinline__ void tri_index(int b, int& i, int& j) {  // b -> (i >
   j = b;
 }
 
-template <typename T, int MODE>
-__global__ void __launch_bounds__(kThreads, 2) tile128_kernel(T* __restrict__ A, T* __restrict__ Tm, int64_t ld, int p,
-                                                               T* __restrict__ Sout = nullptr) {
-  using G = TileGemm<T, kNB, 16>;
-  using QRegs = typename G::QRegs;
-  constexpr int NB = kNB;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  T* smem = reinterpret_cast<T*>(smem_raw);
-  typename G::Acc acc;
-  acc.zero();
-  if (MODE == MODE_TRSM) {
-    // X' = inv(L_pp) * A[i, p]'  ->  L[i, p] = A[i, p] inv(L_pp)'   (row block i = p + 1 + blockIdx.x)
-    const int i = p + 1 + blockIdx.x;
-    const T* P = Tm + int64_t(p) * NB + int64_t(p) * NB * ld;
-    const T* Q = A + int64_t(i) * NB + int64_t(p) * NB * ld;
-    const typename G::QOff qoff = G::q_offsets(ld);
-    auto qload = [&](int t, QRegs& r) { G::load_q(r, Q + int64_t(t) * 16 * ld, qoff); };
-    G::loop(acc, P, ld, NB / 16, qload, smem);
-    T* C = A + int64_t(i) * NB + int64_t(p) * NB * ld;
-#pragma unroll
-    for (int a = 0; a < G::MI; ++a)
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-#pragma unroll
-        for (int b = 0; b < G::NJ; ++b) C[G::acc_col(b) + int64_t(G::acc_row(a, r)) * ld] = acc.v[a][b][r];
-  } else if (MODE == MODE_SYRK) {
-    // A[i, j] -= L[i, p] L[j, p]'  for p < j <= i, computed transposed so stores run along columns of A
-    int ti, tj;
-    tri_index(blockIdx.x, ti, tj);
-    const int i = p + 1 + ti, j = p + 1 + tj;
-    const T* P = A + int64_t(j) * NB + int64_t(p) * NB * ld;
-    const T* Q = A + int64_t(i) * NB + int64_t(p) * NB * ld;
-    const typename G::QOff qoff = G::q_offsets(ld);
-    auto qload = [&](int t, QRegs& r) { G::load_q(r, Q + int64_t(t) * 16 * ld, qoff); };
-    G::loop(acc, P, ld, NB / 16, qload, smem);
-    T* C = A + int64_t(i) * NB + int64_t(j) * NB * ld;
-#pragma unroll
-    for (int a = 0; a < G::MI; ++a)
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-#pragma unroll
-        for (int b = 0; b < G::NJ; ++b) C[G::acc_col(b) + int64_t(G::acc_row(a, r)) * ld] -= acc.v[a][b][r];
-  } else if (MODE == MODE_SPANEL) {
-    // gradient path: S[I, J] = -inv(L_II)' L[J, I]' for J > I, computed as its transpose -L[J, I] inv(L_II);
-    // here `A` is L and `Tm` holds inv(L_II) in its diagonal blocks and receives S in `Sout` (= A2)
-    int ti, tj;
-    tri_index(blockIdx.x, ti, tj);
-    const int J = ti + 1, I = tj;
-    const T* P = A + int64_t(J) * NB + int64_t(I) * NB * ld;
-    const T* Q = Tm + int64_t(I) * NB + int64_t(I) * NB * ld;  // element (k, c) at Q[k + c*ld]
-    auto qload = [&](int t, QRegs& r) { G::load_q_trans(r, Q + int64_t(t) * 16, ld); };
-    G::loop(acc, P, ld, NB / 16, qload, smem);
-    T* C = Sout + int64_t(I) * NB + int64_t(J) * NB * ld;
-#pragma unroll
-    for (int a = 0; a < G::MI; ++a)
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-#pragma unroll
-        for (int b = 0; b < G::NJ; ++b) C[G::acc_col(b) + int64_t(G::acc_row(a, r)) * ld] = -acc.v[a][b][r];
-  } else {
-    // T[I, J] = -inv(L_II) L[I, J],  J < I
-    int ti, tj;
-    tri_index(blockIdx.x, ti, tj);
-    const int I = ti + 1, J = tj;
-    const T* P = Tm + int64_t(I) * NB + int64_t(I) * NB * ld;
-    const T* Q = A + int64_t(I) * NB + int64_t(J) * NB * ld;  // element (k, c) at Q[k + c*ld]
-    auto qload = [&](int t, QRegs& r) { G::load_q_trans(r, Q + int64_t(t) * 16, ld); };
-    G::loop(acc, P, ld, NB / 16, qload, smem);
-    T* C = Tm + int64_t(I) * NB + int64_t(J) * NB * ld;
-#pragma unroll
-    for (int a = 0; a < G::MI; ++a)
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-#pragma unroll
-        for (int b = 0; b < G::NJ; ++b) C[G::acc_row(a, r) + int64_t(G::acc_col(b)) * ld] = -acc.v[a][b][r];
-  }
-}
-
 // Latency-bound small-grid variant of the TRSM / SYRK tiles: one 128x128 f64 tile product is 14 us of MFMA time on a
 // single CU, and a panel step of a small Kuu has only a handful of tiles, so each output tile is split into 128/NT column
 // chunks on 256-thread workgroups (f64: 4 x (128 x 32), f32: 2 x (128 x 64)) that run on different CUs
 // (rocprofv3, M = 1024 f64: TRSM 22.5 -> 11.9 us, SYRK 28 -> 12-19 us per panel step).
-template <typename T, int MODE, int NT>
-__global__ void __launch_bounds__(k256, 2) chol_tile_kernel(T* __restrict__ A, const T* __restrict__ Tm, int64_t ld, int p) {
+// Round 3 - what each launch of the blocked factorisation carries (potrf_t):
+//   MODE_TRSM launch of panel p:  tiles [0, n): L[i, p] = A[i, p] inv(L_pp)' for the n row blocks below the diagonal;
+//                                 tiles [n, n + p): the T panels of block ROW p, T[p, J] = -inv(L_pp) L[p, J] for J < p (they
+//                                 need nothing but inv(L_pp) and the finished row p of L: formerly a launch of their own at the end).
+//   MODE_SYRK launch of panel p:  A[i, j] -= L[i, p] L[j, p]' for p < j <= i; with FUSE the workgroup that completes tile
+//                                 (p+1, p+1) - the last of its NCH column chunks to arrive, counted in sync[p] - goes straight on
+//                                 to factor that diagonal block (potf2_body) while the other workgroups finish the trailing
+//                                 update: the next panel's factorisation no longer waits for the whole update, nor for a launch.
+// (the fused f64 form asks for one workgroup per CU: potf2's LDS image of an f64 block - 146 KiB - allows no second one anyway, and
+// the unrolled DPP factor wants more than the 256 VGPRs a two-workgroup bound leaves it: 282 spilled registers otherwise)
+template <typename T, int MODE, int NT, bool FUSE = false>
+__global__ void __launch_bounds__(k256, (FUSE && sizeof(T) == 8) ? 1 : 2) chol_tile_kernel(T* __restrict__ A, T* __restrict__ Tm, int64_t ld, int p, int n,
+                                                            int* __restrict__ info, unsigned* __restrict__ sync) {
   using G = TileGemm<T, NT, 16, k256>;
   using QRegs = typename G::QRegs;
   constexpr int NB = kNB, NCH = NB / NT;
@@ -399,6 +518,21 @@ __global__ void __launch_bounds__(k256, 2) chol_tile_kernel(T* __restrict__ A, c
   typename G::Acc acc;
   acc.zero();
   const int chunk = blockIdx.x % NCH, tile = blockIdx.x / NCH;
+  if (MODE == MODE_TRSM && tile >= n) {   // T[p, J] = -inv(L_pp) L[p, J]
+    const int J = tile - n;
+    const T* P = Tm + int64_t(p) * NB + int64_t(p) * NB * ld;
+    const T* Q = A + int64_t(p) * NB + (int64_t(J) * NB + chunk * NT) * ld;   // element (k, c) at Q[k + c * ld]
+    auto qload = [&](int t, QRegs& r) { G::load_q_trans(r, Q + int64_t(t) * 16, ld); };
+    G::loop(acc, P, ld, NB / 16, qload, smem);
+    T* C = Tm + int64_t(p) * NB + (int64_t(J) * NB + chunk * NT) * ld;
+#pragma unroll
+    for (int a = 0; a < G::MI; ++a)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int b = 0; b < G::NJ; ++b) C[G::acc_row(a, r) + int64_t(G::acc_col(b)) * ld] = -acc.v[a][b][r];
+    return;
+  }
   int i, j;
   const T* P;
   if (MODE == MODE_TRSM) {       // L[i, p] = A[i, p] inv(L_pp)'  (see tile128_kernel)
@@ -427,6 +561,56 @@ __global__ void __launch_bounds__(k256, 2) chol_tile_kernel(T* __restrict__ A, c
         if (MODE == MODE_TRSM) *dst = acc.v[a][b][r];
         else *dst -= acc.v[a][b][r];
       }
+  if constexpr (FUSE && MODE == MODE_SYRK) {
+    if (tile != 0) return;         // tile 0 = (p+1, p+1): the next diagonal block
+    __shared__ int is_last;
+    __threadfence();               // release: this chunk's stores are visible device-wide before the count goes up
+    __syncthreads();
+    if (threadIdx.x == 0) is_last = (__hip_atomic_fetch_add(&sync[p], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == unsigned(NCH - 1));
+    __syncthreads();
+    if (!is_last) return;
+    __threadfence();               // acquire: the other chunks' stores (other CUs, possibly other XCDs) before the loads below
+    potf2_body<T>(A + int64_t(p + 1) * NB * (ld + 1), Tm + int64_t(p + 1) * NB * (ld + 1), ld, info, (p + 1) * NB, smem_raw);
+  }
+}
+
+// The large-grid form of the trailing update (trailing matrices of >= 256 tiles fill the chip by themselves): whole
+// 128 x 128 tiles on 512-thread workgroups, A[i, j] -= L[i, p] L[j, p]' computed transposed so that stores run along columns
+// of A (half the operand traffic of the chunked form).  FUSE: workgroup 0 owns tile (p+1, p+1) and factors it right after its
+// update.  potf2_body is a 256-thread routine: waves 4-7 leave first (s_barrier only waits for the waves of a workgroup that
+// have not ended).
+template <typename T, bool FUSE>
+__global__ void __launch_bounds__(kThreads, 2) syrk128_kernel(T* __restrict__ A, T* __restrict__ Tm, int64_t ld, int p,
+                                                               int* __restrict__ info) {
+  using G = TileGemm<T, kNB, 16>;
+  using QRegs = typename G::QRegs;
+  constexpr int NB = kNB;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  T* smem = reinterpret_cast<T*>(smem_raw);
+  typename G::Acc acc;
+  acc.zero();
+  int ti, tj;
+  tri_index(blockIdx.x, ti, tj);
+  const int i = p + 1 + ti, j = p + 1 + tj;
+  const T* P = A + int64_t(j) * NB + int64_t(p) * NB * ld;
+  const T* Q = A + int64_t(i) * NB + int64_t(p) * NB * ld;
+  const typename G::QOff qoff = G::q_offsets(ld);
+  auto qload = [&](int t, QRegs& r) { G::load_q(r, Q + int64_t(t) * 16 * ld, qoff); };
+  G::loop(acc, P, ld, NB / 16, qload, smem);
+  T* C = A + int64_t(i) * NB + int64_t(j) * NB * ld;
+#pragma unroll
+  for (int a = 0; a < G::MI; ++a)
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int b = 0; b < G::NJ; ++b) C[G::acc_col(b) + int64_t(G::acc_row(a, r)) * ld] -= acc.v[a][b][r];
+  if constexpr (FUSE) {
+    if (blockIdx.x != 0) return;
+    __threadfence();               // the tile this workgroup just wrote is re-read below (through L2: drop stale L1 lines)
+    __syncthreads();
+    if (threadIdx.x >= k256) return;
+    potf2_body<T>(A + int64_t(p + 1) * NB * (ld + 1), Tm + int64_t(p + 1) * NB * (ld + 1), ld, info, (p + 1) * NB, smem_raw);
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -436,6 +620,11 @@ __global__ void pack_q_kernel(const T* __restrict__ Lq, int64_t ldq, const T* __
   // U[j, k] = Lq[k, j] for k >= j (both < M), else 0.  32x32 LDS transpose keeps both sides coalesced.
   __shared__ T tile[32][33];
   const int64_t bj = int64_t(blockIdx.x) * 32, bk = int64_t(blockIdx.y) * 32;
+  if (mp && blockIdx.y == 0 && threadIdx.y == 0) {
+    const int64_t i = bj + threadIdx.x;
+    mp[i] = (i < M) ? m[i] : T(0);
+  }
+  if (bj / kNB > bk / kNB) return;   // 128-tiles below the diagonal of the upper-triangular U: never read (phase 2 starts at the diagonal block)
   for (int r = threadIdx.y; r < 32; r += blockDim.y) {
     const int64_t k = bk + threadIdx.x, j = bj + r;  // read Lq[k + j*M]: consecutive threads -> consecutive k
     tile[r][threadIdx.x] = (k < M && j < M && k >= j) ? Lq[k + j * ldq] : T(0);
@@ -444,10 +633,6 @@ __global__ void pack_q_kernel(const T* __restrict__ Lq, int64_t ldq, const T* __
   for (int r = threadIdx.y; r < 32; r += blockDim.y) {
     const int64_t j = bj + threadIdx.x, k = bk + r;  // write U[j + k*Mp]: consecutive threads -> consecutive j
     U[j + k * Mp] = tile[threadIdx.x][r];
-  }
-  if (mp && blockIdx.y == 0 && threadIdx.y == 0) {
-    const int64_t i = bj + threadIdx.x;
-    mp[i] = (i < M) ? m[i] : T(0);
   }
 }
 
@@ -666,42 +851,49 @@ void dbg(const char* name, hipStream_t s) {
 }
 
 template <typename T>
-void potrf_t(hipStream_t s, T* A, T* Tm, int64_t Mp, int* info) {
+void potrf_t(hipStream_t s, T* A, T* Tm, int64_t Mp, int* info, unsigned* sync) {
   using G = TileGemm<T, kNB, 16>;
   const int nP = int(Mp / kNB);
-  const size_t lds_potf2 = (size_t(kNB) * (kNB + 1) + 8 * 16 * 17) * sizeof(T);
-  set_max_lds(reinterpret_cast<const void*>(potf2_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds_potf2));
+  constexpr size_t lds_potf2 = potf2_lds_bytes<T>();
   constexpr int CNT = sizeof(T) == 8 ? 32 : 64, NCH = kNB / CNT;
   using GS = TileGemm<T, CNT, 16, k256>;
-  set_max_lds(reinterpret_cast<const void*>(tile128_kernel<T, MODE_SYRK>), hipFuncAttributeMaxDynamicSharedMemorySize, int(G::LDS_BYTES));
+  constexpr size_t lds_fused_s = GS::LDS_BYTES > lds_potf2 ? GS::LDS_BYTES : lds_potf2;
+  constexpr size_t lds_fused_l = G::LDS_BYTES > lds_potf2 ? G::LDS_BYTES : lds_potf2;
+  static const bool fuse_on = [] { const char* e = getenv("SVGP_CHOL_FUSE"); return !e || e[0] != '0'; }();   // A/B knob
+  set_max_lds(reinterpret_cast<const void*>(potf2_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds_potf2));
+  set_max_lds(reinterpret_cast<const void*>(syrk128_kernel<T, false>), hipFuncAttributeMaxDynamicSharedMemorySize, int(G::LDS_BYTES));
+  set_max_lds(reinterpret_cast<const void*>(syrk128_kernel<T, true>), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds_fused_l));
   set_max_lds(reinterpret_cast<const void*>(chol_tile_kernel<T, MODE_TRSM, CNT>), hipFuncAttributeMaxDynamicSharedMemorySize, int(GS::LDS_BYTES));
   set_max_lds(reinterpret_cast<const void*>(chol_tile_kernel<T, MODE_SYRK, CNT>), hipFuncAttributeMaxDynamicSharedMemorySize, int(GS::LDS_BYTES));
-  for (int p = 0; p < nP; ++p) {
-    T* diagA = A + int64_t(p) * kNB * (Mp + 1);
-    T* diagT = Tm + int64_t(p) * kNB * (Mp + 1);
-    hipLaunchKernelGGL(potf2_kernel<T>, dim3(1), dim3(k256), lds_potf2, s, diagA, diagT, Mp, info, p * kNB);
+  set_max_lds(reinterpret_cast<const void*>(chol_tile_kernel<T, MODE_SYRK, CNT, true>), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds_fused_s));
+  auto potf2 = [&](int p) {
+    hipLaunchKernelGGL(potf2_kernel<T>, dim3(1), dim3(k256), lds_potf2, s, A + int64_t(p) * kNB * (Mp + 1), Tm + int64_t(p) * kNB * (Mp + 1), Mp,
+                       info, p * kNB);
     dbg("potf2", s);
+  };
+  potf2(0);
+  for (int p = 0; p < nP; ++p) {
     const int n = nP - p - 1;
-    if (n > 0) {
-      hipLaunchKernelGGL((chol_tile_kernel<T, MODE_TRSM, CNT>), dim3(n * NCH), dim3(k256), GS::LDS_BYTES, s, A, Tm, Mp, p);
-      dbg("chol trsm", s);
-      const int nt = n * (n + 1) / 2;
-      if (nt >= 256)   // a trailing matrix that fills the chip by itself: full 128 x 128 tiles (half the operand traffic)
-        hipLaunchKernelGGL((tile128_kernel<T, MODE_SYRK>), dim3(nt), dim3(kThreads), G::LDS_BYTES, s, A, Tm, Mp, p);
-      else
-        hipLaunchKernelGGL((chol_tile_kernel<T, MODE_SYRK, CNT>), dim3(nt * NCH), dim3(k256), GS::LDS_BYTES, s, A, Tm, Mp, p);
+    if (n + p > 0) {   // the panel below the diagonal and the T panels of block row p
+      hipLaunchKernelGGL((chol_tile_kernel<T, MODE_TRSM, CNT>), dim3((n + p) * NCH), dim3(k256), GS::LDS_BYTES, s, A, Tm, Mp, p, n, info, sync);
+      dbg("chol trsm + T panels", s);
     }
+    if (n == 0) break;
+    const int nt = n * (n + 1) / 2;
+    const bool large = nt >= 256;   // a trailing matrix that fills the chip by itself: full 128 x 128 tiles (half the operand traffic)
+    // the fused f64 form of the large grid would cost the second resident workgroup (potf2's LDS image of an f64 block is 146 KiB)
+    const bool fused = fuse_on && !(large && sizeof(T) == 8);
+    if (fused && large) {
+      hipLaunchKernelGGL((syrk128_kernel<T, true>), dim3(nt), dim3(kThreads), lds_fused_l, s, A, Tm, Mp, p, info);
+    } else if (fused) {
+      hipLaunchKernelGGL((chol_tile_kernel<T, MODE_SYRK, CNT, true>), dim3(nt * NCH), dim3(k256), lds_fused_s, s, A, Tm, Mp, p, n, info, sync);
+    } else {
+      if (large) hipLaunchKernelGGL((syrk128_kernel<T, false>), dim3(nt), dim3(kThreads), G::LDS_BYTES, s, A, Tm, Mp, p, info);
+      else hipLaunchKernelGGL((chol_tile_kernel<T, MODE_SYRK, CNT>), dim3(nt * NCH), dim3(k256), GS::LDS_BYTES, s, A, Tm, Mp, p, n, info, sync);
+      potf2(p + 1);
+    }
+    dbg("chol syrk", s);
   }
-}
-
-template <typename T>
-void tpanels_t(hipStream_t s, const T* L, T* Tm, int64_t Mp) {
-  using G = TileGemm<T, kNB, 16>;
-  const int nP = int(Mp / kNB);
-  set_max_lds(reinterpret_cast<const void*>(tile128_kernel<T, MODE_TPANEL>), hipFuncAttributeMaxDynamicSharedMemorySize, int(G::LDS_BYTES));
-  if (nP > 1)
-    hipLaunchKernelGGL((tile128_kernel<T, MODE_TPANEL>), dim3(nP * (nP - 1) / 2), dim3(kThreads), G::LDS_BYTES, s,
-                       const_cast<T*>(L), Tm, Mp, 0);
 }
 
 }  // namespace
@@ -731,33 +923,20 @@ void launch_transpose_colvecs(int dtype, hipStream_t s, const void* x, int d, in
 
 void launch_kuu(int dtype, hipStream_t s, const KernelParams& kp, const void* zs, int64_t M, int64_t Mp, double jitter,
                 void* Kuu) {
-  dim3 grid((unsigned)((Mp + 255) / 256), (unsigned)Mp);
-  SVGP_DISPATCH(dtype,
-                hipLaunchKernelGGL(kuu_kernel<double>, grid, dim3(256), 0, s, kp, (const double*)zs, M, Mp, jitter, (double*)Kuu),
-                hipLaunchKernelGGL(kuu_kernel<float>, grid, dim3(256), 0, s, kp, (const float*)zs, M, Mp, float(jitter), (float*)Kuu));
+  dim3 grid((unsigned)((Mp + 255) / 256), (unsigned)(Mp / 16));
+  if (kp.d <= 8) {
+    SVGP_DISPATCH(dtype,
+                  hipLaunchKernelGGL((kuu_kernel<double, 8>), grid, dim3(256), 0, s, kp, (const double*)zs, M, Mp, jitter, (double*)Kuu),
+                  hipLaunchKernelGGL((kuu_kernel<float, 8>), grid, dim3(256), 0, s, kp, (const float*)zs, M, Mp, float(jitter), (float*)Kuu));
+  } else {
+    SVGP_DISPATCH(dtype,
+                  hipLaunchKernelGGL((kuu_kernel<double, 0>), grid, dim3(256), 0, s, kp, (const double*)zs, M, Mp, jitter, (double*)Kuu),
+                  hipLaunchKernelGGL((kuu_kernel<float, 0>), grid, dim3(256), 0, s, kp, (const float*)zs, M, Mp, float(jitter), (float*)Kuu));
+  }
 }
 
-void launch_potrf(int dtype, hipStream_t s, void* A, void* T, int64_t Mp, int* info) {
-  SVGP_DISPATCH(dtype, potrf_t<double>(s, (double*)A, (double*)T, Mp, info), potrf_t<float>(s, (float*)A, (float*)T, Mp, info));
-}
-
-template <typename T>
-void spanels_t(hipStream_t s, const T* L, const T* Tm, T* S, int64_t Mp) {
-  using G = TileGemm<T, kNB, 16>;
-  const int nP = int(Mp / kNB);
-  set_max_lds(reinterpret_cast<const void*>(tile128_kernel<T, MODE_SPANEL>), hipFuncAttributeMaxDynamicSharedMemorySize, int(G::LDS_BYTES));
-  if (nP > 1)
-    hipLaunchKernelGGL((tile128_kernel<T, MODE_SPANEL>), dim3(nP * (nP - 1) / 2), dim3(kThreads), G::LDS_BYTES, s,
-                       const_cast<T*>(L), const_cast<T*>(Tm), Mp, 0, S);
-}
-
-void launch_spanels(int dtype, hipStream_t s, const void* L, const void* T, void* S, int64_t Mp) {
-  SVGP_DISPATCH(dtype, spanels_t<double>(s, (const double*)L, (const double*)T, (double*)S, Mp),
-                spanels_t<float>(s, (const float*)L, (const float*)T, (float*)S, Mp));
-}
-
-void launch_tpanels(int dtype, hipStream_t s, const void* L, void* T, int64_t Mp) {
-  SVGP_DISPATCH(dtype, tpanels_t<double>(s, (const double*)L, (double*)T, Mp), tpanels_t<float>(s, (const float*)L, (float*)T, Mp));
+void launch_potrf(int dtype, hipStream_t s, void* A, void* T, int64_t Mp, int* info, unsigned* sync) {
+  SVGP_DISPATCH(dtype, potrf_t<double>(s, (double*)A, (double*)T, Mp, info, sync), potrf_t<float>(s, (float*)A, (float*)T, Mp, info, sync));
 }
 
 void launch_pack_q_ld(int dtype, hipStream_t s, const void* Lq, int64_t ldq, const void* m, int64_t M, int64_t Mp, void* U,

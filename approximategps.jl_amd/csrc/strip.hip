@@ -545,7 +545,8 @@ __global__ void __launch_bounds__(k256) expect_kernel(LikParams lp, const double
 }
 
 __global__ void final_reduce_kernel(const double* __restrict__ partial, const unsigned* __restrict__ negcnt, int64_t n,
-                                    const int* __restrict__ chol_info, double n_points, double* __restrict__ out) {
+                                    const int* __restrict__ chol_info, double n_points, double* __restrict__ out,
+                                    const double* __restrict__ prep_scal) {
   // fixed-order tree: thread t sums elements t, t+256, ... then a fixed LDS tree -> bitwise reproducible.
   // out[0..8) is the vector a data-parallel evaluation all-reduces (comm.hip): {sum E, n_points, n_neg_var, chol flag,
   // failure flag, 0, 0, 0}
@@ -572,6 +573,12 @@ __global__ void final_reduce_kernel(const double* __restrict__ partial, const un
     out[2] = sn[0];
     out[3] = (chol_info && *chol_info != 0) ? 1.0 : 0.0;
     out[4] = out[5] = out[6] = out[7] = 0.0;
+    // behind the all-reduced 8-vector: this rank's prep scalars and chol_info, so that ONE copy brings an evaluation's results
+    // to the host (round 2: three copies, ~20 us of host latency each at the small-problem floor)
+    if (prep_scal) {
+      for (int q = 0; q < 4; ++q) out[8 + q] = prep_scal[q];
+      out[12] = chol_info ? double(*chol_info) : 0.0;
+    }
   }
 }
 
@@ -989,8 +996,8 @@ void launch_expect(int dtype, hipStream_t s, const LikParams& lp, const double* 
 }
 
 void launch_final_reduce(hipStream_t s, const double* partial, const unsigned* negcnt, int64_t n, const int* chol_info,
-                         double n_points, double* out) {
-  hipLaunchKernelGGL(final_reduce_kernel, dim3(1), dim3(k256), 0, s, partial, negcnt, n, chol_info, n_points, out);
+                         double n_points, double* out, const double* prep_scal) {
+  hipLaunchKernelGGL(final_reduce_kernel, dim3(1), dim3(k256), 0, s, partial, negcnt, n, chol_info, n_points, out, prep_scal);
 }
 
 template <typename T, int FAMILY>

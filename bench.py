@@ -292,7 +292,7 @@ def bench_config(args, name, ctx, torch, dist, dev, world, rank, use_dist, steps
 
     for _ in range(warmup):
         step()
-    strip_ms, prep_ms, expect_ms = [], [], []
+    strip_ms, prep_ms, expect_ms, chol_ms = [], [], [], []
     fence()
     t0 = time.perf_counter()
     for _ in range(steps):
@@ -301,6 +301,7 @@ def bench_config(args, name, ctx, torch, dist, dev, world, rank, use_dist, steps
         strip_ms.append(t.ms_strip)
         prep_ms.append(t.ms_prep)
         expect_ms.append(t.ms_expect)
+        chol_ms.append(t.ms_chol)
     fence()
     elapsed = time.perf_counter() - t0
     if use_dist:
@@ -323,7 +324,15 @@ def bench_config(args, name, ctx, torch, dist, dev, world, rank, use_dist, steps
                      "executed_flops_per_launch": 2.0 * 2.0 * 128 * 128 * ((Mp // 128) * (Mp // 128 - 1) / 2 + 0.625 * (Mp // 128))
                      * strip_w * math.ceil(n / strip_w)},
         "breakdown_ms": {"prep (Kuu, cholesky, T panels, KL)": float(np.mean(prep_ms)), "strip": strip_avg_ms,
-                         "expectation + reduce (+ all-reduce)": float(np.mean(expect_ms))},
+                         "expectation + reduce (+ all-reduce)": float(np.mean(expect_ms)), "cholesky alone (inside prep)": float(np.mean(chol_ms))},
+        # BASELINE config 4 / SURVEY Appendix G: "report Cholesky MFMA utilisation separately".  cholesky(Kuu) with its T panels,
+        # HIP events of the library around the factorisation's launches; flops = M^3 / 3 (algorithmic).  Latency-bound by its
+        # panel dependency, not a roofline kernel: the fraction says how far from the matrix peak the serial chain keeps it.
+        "cholesky_roofline": {"kernels": "potf2 (in-kernel hand-over) + chol_tile / syrk128 MFMA tiles", "bound": "mfma (latency-bound chain)",
+                              "flops": M ** 3 / 3.0, "ms": float(np.mean(chol_ms)),
+                              "achieved": (M ** 3 / 3.0) / (float(np.mean(chol_ms)) * 1e-3) / 1e12 if np.mean(chol_ms) > 0 else None,
+                              "peak": PEAK_TFLOPS[dtype], "unit": "TFLOP/s",
+                              "frac": ((M ** 3 / 3.0) / (float(np.mean(chol_ms)) * 1e-3) / 1e12 / PEAK_TFLOPS[dtype]) if np.mean(chol_ms) > 0 else None},
         "workload": f"{name}: N={n} points per GPU, M={M}, d={d}, {['SE', 'Matern32', 'Matern52'][family]}-ARD, "
                     f"{['Gaussian', 'Bernoulli-logistic GH-20', 'Poisson'][lik]}, {dtype}, NonCentered; "
                     "one step = one full elbo(sva, lfx, y) incl. cholesky(Kuu)",
@@ -411,7 +420,7 @@ def main():
                                    f"data-parallel shards x{world}; FALLBACK: host-side all-reduce of the partial sums "
                                    f"(library communicator unavailable: {lib_comm_error})"),
                    "elbo": res["elbo"], "timed_region_s": res["elapsed"]},
-        "roofline": res["roofline"], "breakdown_ms": res["breakdown_ms"],
+        "roofline": res["roofline"], "breakdown_ms": res["breakdown_ms"], "cholesky_roofline": res["cholesky_roofline"],
         # what the library itself reports: the size of its RCCL communicator (svgp_ctx_comm_info; 1 = no communicator) and the
         # number of points the all-reduced evaluation covered (svgp_terms.n_points after the in-library ncclAllReduce)
         "rccl_world": int(ctx.comm_info()[0]), "n_points_global": res["n_points_global"],
@@ -435,6 +444,18 @@ def main():
                 ref = float(tt[0].item()) * (num_data / float(tt[1].item())) - kl
                 out["collective_check"] = {"library_allreduce_elbo": res["elbo"], "torch_allreduce_of_local_partials": ref,
                                            "rel_err": abs(res["elbo"] - ref) / abs(ref)}
+    if rank == 0:   # the Cholesky's MFMA utilisation is a PMC figure: from the committed profile of this configuration, labelled
+        import glob
+        for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "round*", f"{name}_*_pmc.json")), reverse=True):
+            try:
+                agg = json.load(open(path)).get("cholesky_aggregate")
+            except (OSError, ValueError):
+                agg = None
+            if agg and "mfma_busy_frac" in agg and "grad" not in os.path.basename(path):
+                out["cholesky_roofline"].update({"mfma_busy": agg["mfma_busy_frac"], "mfma_busy_source": os.path.relpath(path, ROOT) +
+                                                 " (rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES over every launch of the factorisation; not measured in this run)",
+                                                 "ms_under_rocprof": agg["ms_per_evaluation"]})
+                break
     tr = profile_traffic(name, "strip_kernel<") if rank == 0 else None
     if tr:
         out["roofline"].update({k: v for k, v in tr.items() if v is not None or k == "traffic_stale"})

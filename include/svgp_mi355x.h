@@ -31,7 +31,8 @@
 extern "C" {
 #endif
 
-#define SVGP_ABI_VERSION 3 /* 3 = 2 + svgp_marginals, svgp_elbo_grad_ext, SVGP_LIK_BERNOULLI_NORMCDF (additions only: v2 callers keep working) */
+#define SVGP_ABI_VERSION 4 /* 3 = 2 + svgp_marginals, svgp_elbo_grad_ext, SVGP_LIK_BERNOULLI_NORMCDF; 4 = 3 + svgp_offload_advice /
+                              svgp_offload_work and svgp_timing.ms_chol appended (additions only: v2 / v3 callers keep working) */
 
 /* status codes -> Julia exceptions raised by the shim */
 enum {
@@ -119,6 +120,7 @@ typedef struct svgp_timing {
   double ms_expect;/* marginals + expected log-likelihood + final reduce */
   double ms_kuf;   /* standalone Kuf assembly kernel (svgp_kuf only) */
   int64_t strip_launches;
+  double ms_chol;  /* (v4) cholesky(Kuu) alone - the blocked factorisation with its T panels - inside ms_prep */
 } svgp_timing;
 
 /* ---- library / context ------------------------------------------------------------------- */

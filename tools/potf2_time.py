@@ -26,11 +26,15 @@ print(os.environ.get("SVGP_MI355X_LIB", "default").split("/")[-1], " ".join(out)
 import ctypes
 L = ctypes.CDLL(os.environ.get("SVGP_MI355X_LIB", _ffi.LIB_PATH))
 if hasattr(L, "svgp_debug_potf2_stamps"):
-    buf = (ctypes.c_ulonglong * 64)()
+    buf = (ctypes.c_ulonglong * 128)()
     L.svgp_debug_potf2_stamps(buf)
     s = np.array(list(buf), dtype=np.float64)
     tot = s[41] - s[0]
     print(f"clock64 ticks: total {tot:.0f}; load {s[1]-s[0]:.0f}; first factor {s[2]-s[1]:.0f}; store {s[41]-s[40]:.0f}")
+    print(f"  first 16 x 16 factor alone (wave 0): {s[42]-s[1]:.0f}")
     for p in range(8):
         b = 2 + 4 * p
-        print(f"  block {p}: panel {s[b+1]-s[b]:.0f}  lookahead phase (next factor | trailing + inverse row) {s[b+2]-s[b+1]:.0f}")
+        extra = f"  [wave 0: tile update {s[44+2*p]-s[b+1]:.0f}, factor16 {s[45+2*p]-s[44+2*p]:.0f}, then its share of the tiles {s[b+2]-s[45+2*p]:.0f}]" if p < 7 else ""
+        w = s[64 + 4 * p: 64 + 4 * p + 4]
+        extra += f"  [wave 1: tiles {w[1]-w[0]:.0f}, inverse rows {w[2]-w[1]:.0f}, stores {w[3]-w[2]:.0f}]"
+        print(f"  block {p}: panel {s[b+1]-s[b]:.0f}  lookahead phase (next factor | trailing + inverse row) {s[b+2]-s[b+1]:.0f}" + extra)

@@ -37,6 +37,39 @@ def counters(d):
     return {k: {cn: sum(v) / len(v) for cn, v in c.items()} for k, c in acc.items()}
 
 
+CHOL = ("potf2_kernel", "chol_tile_kernel", "syrk128_kernel")
+
+
+def cholesky_aggregate(src, trace_rows):
+    """BASELINE config 4 / SURVEY Appendix G ask for the Cholesky's MFMA utilisation: all launches of the factorisation's kernels
+    (every panel, not just the largest grid), per evaluation: time from the kernel trace, MFMA busy from the SQ pass."""
+    evals = sum(1 for k, _, _ in trace_rows if k.startswith("kuu_kernel")) or 1
+    per = defaultdict(lambda: [0, 0.0])
+    for k, _, t in trace_rows:
+        if k.startswith(CHOL):
+            per[k][0] += 1
+            per[k][1] += t
+    busy = active = 0.0
+    nsq = 0
+    for f in glob.glob(os.path.join(src, "sq", "**", "*counter_collection.csv"), recursive=True):
+        disp = defaultdict(dict)
+        for r in csv.DictReader(open(f)):
+            if short(r["Kernel_Name"]).startswith(CHOL):
+                disp[r["Dispatch_Id"]][r["Counter_Name"]] = float(r["Counter_Value"])
+        for c in disp.values():
+            if "SQ_VALU_MFMA_BUSY_CYCLES" in c and "GRBM_GUI_ACTIVE" in c:
+                busy += c["SQ_VALU_MFMA_BUSY_CYCLES"]
+                active += c["GRBM_GUI_ACTIVE"] * 1024.0 / 8.0
+                nsq += 1
+    out = {"evaluations_in_trace": evals, "ms_per_evaluation": round(sum(v[1] for v in per.values()) / evals / 1e6, 4),
+           "launches_per_evaluation": round(sum(v[0] for v in per.values()) / evals, 1),
+           "per_kernel": {k: {"launches_per_evaluation": round(v[0] / evals, 1), "ms_per_evaluation": round(v[1] / evals / 1e6, 4)} for k, v in per.items()}}
+    if active > 0:
+        out["mfma_busy_frac"] = round(busy / active, 4)   # busy cycles summed over the chip's 1024 SIMDs / (active cycles x 1024), all launches
+        out["dispatches_counted"] = nsq
+    return out
+
+
 def main():
     src, dst = sys.argv[1], sys.argv[2]
     stats = sorted(glob.glob(os.path.join(src, "stats", "**", "*kernel_stats.csv"), recursive=True), key=os.path.getsize)[-1]
@@ -63,6 +96,7 @@ def main():
     out = {"source": "tools/run_profile.sh: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ_* in three separate passes",
            "kernel_source_sha16": sha,   # bench.py marks the traffic figure stale when strip.hip / device_common.hpp changed since
            "bench_line": json.loads(open(os.path.join(src, "bench_plain.json")).read().strip().splitlines()[-1])}
+    out["cholesky_aggregate"] = cholesky_aggregate(src, rows)
     fetch, write, sq = (counters(os.path.join(src, p)) for p in ("fetch", "write", "sq"))
     for k in sorted(tot, key=tot.get, reverse=True)[:8]:
         e = {"ms_per_launch_rocprof": round(ms[k], 4)}
@@ -88,7 +122,7 @@ def main():
                 e["SQ_WAIT_INST_ANY/SQ_WAVE_CYCLES"] = c.get("SQ_WAIT_INST_ANY", 0.0) / c["SQ_WAVE_CYCLES"]
         out[k] = e
     json.dump(out, open(dst + "_pmc.json", "w"), indent=1)
-    print(json.dumps({k: v for k, v in out.items() if k not in ("source", "bench_line")}, indent=1)[:3000])
+    print(json.dumps({k: v for k, v in out.items() if k not in ("source", "bench_line")}, indent=1)[:4000])
 
 
 if __name__ == "__main__":
