@@ -489,12 +489,15 @@ struct TileGemm {
 #ifndef SVGP_ASYNC_QUAD
 #define SVGP_ASYNC_QUAD 1   // 0: the 256-byte-row tiles (fp32 NT = 64) keep the two-buffer loop (A/B builds)
 #endif
-  static constexpr int QR = (NT * sizeof(T) == 256) ? 4 : 2;
+  // Q k-rows of 1 KiB (f64, NT = 128: the 512-thread strip of the round-3 A/B) are one row per instruction like the P tile's and
+  // get the same +16 padding between rows instead of a swizzle
+  static constexpr bool kRowQ = (NT * sizeof(T) == 1024);
+  static constexpr int QR = kRowQ ? 1 : ((NT * sizeof(T) == 256) ? 4 : 2);
   static constexpr bool kAsync = (SVGP_DMA_P != 0) && (NB * sizeof(T) == 1024 || kPairP) &&
-                                 (NT * sizeof(T) == 512 || (SVGP_ASYNC_QUAD && NT * sizeof(T) == 256)) && BK == 16 &&
-                                 NTHR == 256 && NJ % 2 == 0;
+                                 (NT * sizeof(T) == 512 || (SVGP_ASYNC_QUAD && NT * sizeof(T) == 256) || (kRowQ && NTHR == 512)) &&
+                                 BK == 16 && (NTHR == 256 || (kRowQ && NTHR == 512)) && NJ % 2 == 0;
   static constexpr int NBUF = 3;
-  static constexpr int QPP = QR * NT;                       // one row unit (pair / quad) of the Q tile in LDS (elements) = 1 KiB
+  static constexpr int QPP = kRowQ ? QLD : QR * NT;         // one row unit (row / pair / quad) of the Q tile in LDS (elements)
   static constexpr int QA_TILE = (BK / QR) * QPP;
   static constexpr int QSLAB = (4 / QR) * QPP;              // LDS distance between the k-slabs (4 k-rows) of a Q tile
   static constexpr int PPP = 2 * NB;                        // one row pair of the P tile (pair image)

@@ -115,13 +115,11 @@ __device__ __forceinline__ float krsqrt(float d) {
 #ifdef SVGP_POTF2_STAMPS   // diagnostic build (tools/build_ablate.sh stamps): s_memtime at the phase boundaries of potf2
 __device__ unsigned long long g_potf2_stamps[128];
 #define SVGP_STAMP(i) do { if (threadIdx.x == 0) g_potf2_stamps[i] = clock64(); } while (0)
-#define SVGP_STAMP1(i) do { if (threadIdx.x == 64) g_potf2_stamps[64 + (i)] = clock64(); } while (0)   // wave 1, a worker
 extern "C" int svgp_debug_potf2_stamps(unsigned long long* out) {
   return int(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_potf2_stamps), sizeof(g_potf2_stamps)));
 }
 #else
 #define SVGP_STAMP(i)
-#define SVGP_STAMP1(i)
 #endif
 
 // wave 0's part of a block step: factor the 16x16 diagonal block at offset o (already updated) and invert it.
@@ -129,9 +127,10 @@ extern "C" int svgp_debug_potf2_stamps(unsigned long long* out) {
 // l15 of L and column l15 of X = inv(L).  Step j needs row j of L in every lane:
 //   L[i][j] = (A[i][j] - sum_k L[i][k] L[j][k]) / L[j][j]      X[j][c] = (delta_jc - sum_k L[j][k] X[k][c]) / L[j][j]
 // Round 3: the broadcast is a DPP row_newbcast (lane j of each 16-lane row to the whole row: v_mov_b32_dpp, pure VALU).  Rounds
-// 1-2 used v_readlane into an SGPR; s_memtime showed 340 cycles per column step whatever the instruction count (43 -> 27
-// instructions changed nothing): the VALU -> SGPR -> VALU round trip of the two readlanes on the dependent chain is what a
-// step costs, and the 128 steps of a block are the critical path of the whole factorisation.  fp32 takes the hardware
+// 1-2 used v_readlane into an SGPR: s_memtime showed ~312-340 cycles per column step whatever the instruction count (43 -> 27
+// instructions changed nothing) - the VALU -> SGPR -> VALU round trips on the dependent chain; with DPP a step is 216 cycles
+// (fp32 factor16: 5000 -> 3460 cycles; the 128 steps of a block are the critical path of the whole factorisation; prep at
+// M = 1024, same box: 0.585 -> 0.523 ms f64).  fp32 takes the hardware
 // v_rsq_f32 (1 ulp) as it is; fp64 keeps the Newton refinements (v_rsq_f64 delivers ~26 bits).  No per-step selects: an X
 // lane starts from delta_jc and stays exactly zero above the diagonal; the diagonal entry is t r = sqrt(t) like any other
 // entry of its column; L rows hold unused garbage right of the diagonal.
@@ -221,78 +220,57 @@ __device__ __forceinline__ int factor16(T* __restrict__ sm, T* __restrict__ dinv
 // is k-slab r of a B fragment when A is read with k = Mfma16::row(lane, r); X[ti,tj]' lives in the strictly upper block
 // (tj,ti) of the LDS image).  Critical path per block: panel + one tile update + factor16; everything else hides
 // behind the factor (s_memtime: 115k -> ~70k cycles per 128-block).
+// Round 3, measured and rejected (s_memtime stamps on wave 0 and on a worker wave, fp32, same box): a restructured body - the
+// 32 leading columns loaded first and the rest beside the first factor, finished L panels / inverse rows written out by the
+// workers during the steps (LDS-only barriers), tiles two at a time, wave 0 taking a share of the tiles after its factor, the
+// block inverse accumulated right-looking (no dot-product chains), a conflict-free LDS stride - was SLOWER end to end (prep at
+// M = 1024: 0.595 vs 0.523 ms f64, 0.549 vs 0.507 ms fp32).  The stamps say why: a 4-MFMA 16 x 16 tile update costs ~1000
+// cycles on a worker wave whether tiles are paired or not and whatever the LDS stride (600 when a single wave runs alone), so
+// the workers - ~28 such groups a step in any formulation - need 8-11k cycles per step against the 4k of wave 0's chain, and
+// every store moved into the steps lengthened them further.  What stayed from that session is the factor itself (below).
 // The body is a device function of a 256-thread workgroup (smem_raw: potf2_lds_bytes<T>() of dynamic LDS) so that the
 // trailing-update kernels can run it on the NEXT diagonal block the moment that block is up to date (potrf_t below).
 template <typename T>
-constexpr int potf2_ld() { return kNB + (sizeof(T) == 4 ? 4 : 2); }
-template <typename T>
-constexpr size_t potf2_lds_bytes() { return (size_t(kNB) * potf2_ld<T>() + 8 * 16 * 17) * sizeof(T); }
-
-// Workgroup barrier that waits for the wave's LDS traffic only (s_waitcnt lgkmcnt(0)), not for its outstanding global
-// stores: potf2's workers write finished panels out while the block is still being factored, and a __syncthreads() - which
-// also drains vmcnt - made every step wait for a store round trip (s_memtime: +4k cycles per step).  Everything the waves
-// exchange inside potf2 goes through LDS; data loaded from global memory reaches LDS through registers (a data dependence).
-__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+constexpr size_t potf2_lds_bytes() { return (size_t(kNB) * (kNB + 1) + 8 * 16 * 17) * sizeof(T); }
 
 template <typename T>
 __device__ __forceinline__ void potf2_body(T* __restrict__ A, T* __restrict__ Tm, int64_t ld, int* __restrict__ info, int pbase,
-                                           unsigned char* __restrict__ smem_raw) {
-  // Row stride of the LDS image: an MFMA fragment read touches rows l15 = 0..15 at columns g = 0..3 of a k-slab, i.e. dword
-  // l15 LD + g (fp32) / 2 (l15 LD + g) (f64): with LD = 129 (rounds 1-2) that is bank l15 + g - 19 banks for 64 lanes, a 3-4 way
-  // conflict on every fragment read of the panel solves, the trailing updates and the inverse rows (s_memtime: 1.2k cycles per
-  // 16 x 16 tile update).  LD = 132 (fp32: bank 4 l15 + g) / 130 (f64: bank 4 l15 + 2 g per half wave) are conflict-free.
-  constexpr int NB = kNB, LD = potf2_ld<T>(), NBLK = NB / 16, DL = 17;
+                                              unsigned char* __restrict__ smem_raw) {
+  constexpr int NB = kNB, LD = NB + 1, NBLK = NB / 16, DL = 17;
   using M16 = Mfma16<T>;
   using acc_t = typename M16::acc_t;
-  T* sm = reinterpret_cast<T*>(smem_raw);   // [128][LD] row-major block; strictly-upper 16-blocks later hold X'
+  T* sm = reinterpret_cast<T*>(smem_raw);   // [128][129] row-major block; strictly-upper 16-blocks later hold X'
   T* dinv = sm + NB * LD;                   // [8][16][17]  inverses of the 16x16 diagonal blocks
   __shared__ int failed;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l15 = lane & 15, g = lane >> 4;
   SVGP_STAMP(0);
   if (tid == 0) failed = (*info != 0) ? -1 : 0;
-  // Round 3 (s_memtime, fp32: of 75k cycles per block 5.2k were the load, 5.4k the first 16 x 16 factor, 8.5k the final store):
-  // only the 32 leading columns are loaded before the first factor starts; waves 1-3 bring in the other 96 BESIDE it
-  // (64 elements per thread, unconditional batches of 16 loads in flight).
   {
-    constexpr int U = 16;   // 128 x 32 elements / 256 threads
-    T v[U];
+    // 64 elements per thread, 16 loads in flight at a time (a plain loop waits for every load before its LDS store)
+    constexpr int U = 16;
+    for (int e0 = tid; e0 < NB * NB; e0 += k256 * U) {
+      T v[U];
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int e = tid + u * k256;
-      v[u] = A[(e % NB) + int64_t(e / NB) * ld];
-    }
+      for (int u = 0; u < U; ++u) {
+        const int e = e0 + u * k256;
+        v[u] = A[(e % NB) + int64_t(e / NB) * ld];
+      }
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int e = tid + u * k256;
-      sm[(e % NB) * LD + e / NB] = v[u];
+      for (int u = 0; u < U; ++u) {
+        const int e = e0 + u * k256;
+        sm[(e % NB) * LD + e / NB] = v[u];
+      }
     }
   }
-  lds_barrier();
+  __syncthreads();
   if (failed) return;  // an earlier panel already reported the first bad pivot
   SVGP_STAMP(1);
   if (wave == 0) {
     const int bad = factor16(sm, dinv, LD, DL, 0, 0, lane);
     if (bad && lane == 0) failed = pbase + bad;
-    SVGP_STAMP(42);
-  } else {
-    constexpr int U = 16, NW3 = 192;   // 128 x 96 elements / 192 threads = 64
-#pragma unroll 1
-    for (int b = 0; b < 4; ++b) {
-      T v[U];
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const int e = 32 * NB + (tid - 64) + (b * U + u) * NW3;
-        v[u] = A[(e % NB) + int64_t(e / NB) * ld];
-      }
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const int e = 32 * NB + (tid - 64) + (b * U + u) * NW3;
-        sm[(e % NB) * LD + e / NB] = v[u];
-      }
-    }
   }
-  lds_barrier();
+  __syncthreads();
 
   for (int p = 0; p < NBLK; ++p) {
     const int o = 16 * p;
@@ -312,7 +290,7 @@ __device__ __forceinline__ void potf2_body(T* __restrict__ A, T* __restrict__ Tm
 #pragma unroll
       for (int r = 0; r < 4; ++r) sm[(16 * t + M16::row(lane, r)) * LD + o + l15] = acc[r];
     }
-    lds_barrier();
+    __syncthreads();
     SVGP_STAMP(3 + 4 * p);
     auto update_tile = [&](int ti, int tj) {   // A[ti, tj] -= L[ti, p] L[tj, p]'
       const int bi = 16 * ti, bj = 16 * tj;
@@ -325,67 +303,22 @@ __device__ __forceinline__ void potf2_body(T* __restrict__ A, T* __restrict__ Tm
 #pragma unroll
       for (int r = 0; r < 4; ++r) sm[(bi + M16::row(lane, r)) * LD + bj + l15] -= acc[r];
     };
-    // two tiles at a time: their fragment reads and MFMA chains interleave (one tile alone runs at the LDS / MFMA latency)
-    auto update_tile2 = [&](int ti, int tj, int ui, int uj) {
-      const int bi = 16 * ti, bj = 16 * tj, ci = 16 * ui, cj = 16 * uj;
-      T fa[4], fb[4], ga[4], gb[4];
-#pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        const int k = o + 4 * s + g;
-        fa[s] = sm[(bi + l15) * LD + k];
-        fb[s] = sm[(bj + l15) * LD + k];
-        ga[s] = sm[(ci + l15) * LD + k];
-        gb[s] = sm[(cj + l15) * LD + k];
-      }
-      acc_t a1 = {0, 0, 0, 0}, a2 = {0, 0, 0, 0};
-#pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        a1 = M16::mma(fa[s], fb[s], a1);
-        a2 = M16::mma(ga[s], gb[s], a2);
-      }
-      T c1[4], c2[4];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        c1[r] = sm[(bi + M16::row(lane, r)) * LD + bj + l15];
-        c2[r] = sm[(ci + M16::row(lane, r)) * LD + cj + l15];
-      }
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        sm[(bi + M16::row(lane, r)) * LD + bj + l15] = c1[r] - a1[r];
-        sm[(ci + M16::row(lane, r)) * LD + cj + l15] = c2[r] - a2[r];
-      }
-    };
     const bool last = (p + 1 == NBLK);          // no next factor: wave 0 joins the inverse-row work
     if (wave == 0 && !last) {
       update_tile(p + 1, p + 1);
-      SVGP_STAMP(44 + 2 * p);
       const int bad = factor16(sm, dinv, LD, DL, o + 16, p + 1, lane);
       if (bad && lane == 0) failed = pbase + o + 16 + bad;
-      SVGP_STAMP(45 + 2 * p);
-    }
-    {
-      // trailing tiles p < tj <= ti except (p+1, p+1), then row p of the block inverse, dealt out statically: the first kHold
-      // items go round-robin to waves 1-3 only - about what wave 0's own tile + factor cost - after that wave 0 takes its share
-      // (with the DPP factor the workers, not the factor, are the longer side of the early steps)
-#ifndef SVGP_POTF2_W0
-#define SVGP_POTF2_W0 1   // 0: wave 0 only factors, the trailing work is dealt to waves 1-3 (A/B and bisection builds)
-#endif
-      constexpr int kHold = SVGP_POTF2_W0 ? (sizeof(T) == 8 ? 15 : 12) : (1 << 30);
-      auto mine = [&](int idx) { return last ? (idx & 3) == wave : (idx < kHold ? 1 + idx % 3 == wave : ((idx - kHold) & 3) == wave); };
+    } else {
+      // trailing tiles p < tj <= ti except (p+1, p+1), then row p of the block inverse, dealt round-robin to the workers
+      const int nw = last ? 4 : 3, me = last ? wave : wave - 1;
       const int n = NBLK - p - 1;
-      SVGP_STAMP1(4 * p);
-      int ti = 0, tj = 0, idx = 0, hi = -1, hj = -1;
+      int ti = 0, tj = 0, idx = 0;
       for (int q = 0; q < n * (n + 1) / 2; ++q) {
-        if (q > 0 && mine(idx++)) {
-          if (hi < 0) { hi = p + 1 + ti; hj = p + 1 + tj; }
-          else { update_tile2(hi, hj, p + 1 + ti, p + 1 + tj); hi = -1; }
-        }
+        if (q > 0 && (idx++ % nw) == me) update_tile(p + 1 + ti, p + 1 + tj);
         if (++tj > ti) { tj = 0; ++ti; }
       }
-      if (hi >= 0) update_tile(hi, hj);
-      SVGP_STAMP1(4 * p + 1);
       for (int tj2 = 0; tj2 < p; ++tj2) {
-        if (!mine(idx++)) continue;
+        if ((idx++ % nw) != me) continue;
         acc_t acc = {0, 0, 0, 0};
         for (int sb = tj2; sb < p; ++sb) {
 #pragma unroll
@@ -402,55 +335,8 @@ __device__ __forceinline__ void potf2_body(T* __restrict__ A, T* __restrict__ Tm
 #pragma unroll
         for (int r = 0; r < 4; ++r) sm[(16 * tj2 + l15) * LD + o + M16::row(lane, r)] = -x[r];
       }
-      SVGP_STAMP1(4 * p + 2);
-      // Results that are final leave NOW, beside wave 0's factor (round 2 wrote everything in a closing pass of 8.5k cycles):
-      // column panel p of L (its diagonal block was factored during the previous step, the rows below it by this step's panel
-      // solve) and row block p-1 of the block inverse (completed by the previous step's workers).  16-byte vectors along the
-      // rows (global memory is column-major), all the LDS reads of a thread before its stores.  Unmasked: the part of a diagonal
-      // 16 x 16 block above its diagonal is the untouched input in L's image (nobody reads it back) and exact zeros in the
-      // inverse's (the X lanes of factor16 never leave zero there) - T's diagonal blocks must be zero above the diagonal.
-      if (wave != 0 || last) {
-        using V = typename Vec16<T>::type;
-        constexpr int VEC = Vec16<T>::N, RV = NB / VEC;           // row vectors per column of the block
-        const int wt = last ? tid : tid - 64, nwt = last ? k256 : 192;
-        constexpr int UL = (16 * RV + 191) / 192;                  // L panel: 16 columns x RV vectors
-        V bl[UL];
-#pragma unroll
-        for (int u = 0; u < UL; ++u) {
-          const int e = wt + u * nwt, c = e & 15, r = ((e >> 4) % RV) * VEC;   // lanes run along the 16 columns: conflict-free LDS reads
-#pragma unroll
-          for (int i = 0; i < VEC; ++i) bl[u][i] = sm[(r + i) * LD + o + c];
-        }
-#pragma unroll
-        for (int u = 0; u < UL; ++u) {
-          const int e = wt + u * nwt, c = e & 15, r = (e >> 4) * VEC;
-          if (e < 16 * RV && r >= o) *reinterpret_cast<V*>(A + r + int64_t(o + c) * ld) = bl[u];
-        }
-        if (p > 0) {
-          const int q0 = 16 * (p - 1);
-          constexpr int CV = 16 / VEC;                              // vectors per column of a 16-row block
-          constexpr int UX = (NB * CV + 191) / 192;
-          V bx[UX];
-#pragma unroll
-          for (int u = 0; u < UX; ++u) {
-            const int e = wt + u * nwt, vi = e % CV, c = (e / CV) & (NB - 1), r = q0 + vi * VEC;
-#pragma unroll
-            for (int i = 0; i < VEC; ++i) {
-              // diagonal block: dinv (which follows sm in LDS: dinv = sm + NB * LD); left of it: X' in the upper part of the image
-              const int idx = (c >= q0) ? NB * LD + (r + i) * DL + ((c - q0) & 15) : c * LD + r + i;
-              bx[u][i] = sm[idx];
-            }
-          }
-#pragma unroll
-          for (int u = 0; u < UX; ++u) {
-            const int e = wt + u * nwt, vi = e % CV, c = e / CV, r = q0 + vi * VEC;
-            if (c < q0 + 16) *reinterpret_cast<V*>(Tm + r + int64_t(c) * ld) = bx[u];
-          }
-        }
-      }
     }
-    SVGP_STAMP1(4 * p + 3);
-    lds_barrier();
+    __syncthreads();
     SVGP_STAMP(4 + 4 * p);
   }
   if (failed) {   // a bad pivot in the last block
@@ -458,19 +344,27 @@ __device__ __forceinline__ void potf2_body(T* __restrict__ A, T* __restrict__ Tm
     return;
   }
   SVGP_STAMP(40);
-  {   // the last row block of the inverse (its off-diagonal tiles were computed in the last step)
-    using V = typename Vec16<T>::type;
-    constexpr int VEC = Vec16<T>::N, CV = 16 / VEC, q0 = NB - 16;
-    for (int e = tid; e < NB * CV; e += k256) {
-      const int vi = e % CV, c = e / CV, r = q0 + vi * VEC;
-      V v;
+  {
+    constexpr int U = 8;
+    for (int e0 = tid; e0 < NB * NB; e0 += k256 * U) {
+      T lv[U], xv[U];
 #pragma unroll
-      for (int i = 0; i < VEC; ++i) v[i] = (c >= q0) ? dinv[(r + i) * DL + (c - q0)] : sm[c * LD + r + i];
-      *reinterpret_cast<V*>(Tm + r + int64_t(c) * ld) = v;
+      for (int u = 0; u < U; ++u) {
+        const int e = e0 + u * k256, r = e % NB, c = e / NB;
+        lv[u] = sm[r * LD + c];
+        xv[u] = ((r >> 4) == (c >> 4)) ? dinv[((r >> 4) * 16 + (r & 15)) * DL + (c & 15)] : sm[c * LD + r];
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int e = e0 + u * k256, r = e % NB, c = e / NB;
+        if (r >= c) A[r + int64_t(c) * ld] = lv[u];
+        Tm[r + int64_t(c) * ld] = (r >= c) ? xv[u] : T(0);
+      }
     }
   }
   SVGP_STAMP(41);
 }
+
 
 template <typename T>
 __global__ void __launch_bounds__(k256) potf2_kernel(T* __restrict__ A, T* __restrict__ Tm, int64_t ld,
