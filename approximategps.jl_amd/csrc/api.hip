@@ -104,7 +104,7 @@ int validate_desc(svgp_ctx* ctx, const svgp_model_desc* d) {
   if (d->likelihood < 0 || d->likelihood > SVGP_LIK_BERNOULLI_NORMCDF) return fail(ctx, SVGP_UNSUPPORTED, "unsupported likelihood");
   if (d->parametrization != SVGP_NONCENTERED && d->parametrization != SVGP_CENTERED)
     return fail(ctx, SVGP_INVALID_ARG, "parametrization must be SVGP_NONCENTERED or SVGP_CENTERED");
-  if (d->d < 1 || d->d > 32) return fail(ctx, SVGP_UNSUPPORTED, "input dimension must be in 1..32");
+  if (d->d < 1 || d->d > SVGP_MAX_D) return fail(ctx, SVGP_UNSUPPORTED, "input dimension must be in 1..64");
   if (d->M < 1) return fail(ctx, SVGP_INVALID_ARG, "M must be >= 1");
   if (d->layout_z < 0 || d->layout_z > SVGP_VEC) return fail(ctx, SVGP_INVALID_ARG, "bad layout_z");
   if (d->layout_z == SVGP_VEC && d->d != 1) return fail(ctx, SVGP_INVALID_ARG, "SVGP_VEC layout requires d == 1");
@@ -474,7 +474,7 @@ int make_data(svgp_ctx* ctx, int dtype, int layout, int d, int64_t n, const void
               svgp_data** out) {
   if (!out) return fail(ctx, SVGP_INVALID_ARG, "null out pointer");
   if (dtype != SVGP_F64 && dtype != SVGP_F32) return fail(ctx, SVGP_INVALID_ARG, "bad dtype");
-  if (d < 1 || d > 32 || n < 1 || !x_host) return fail(ctx, SVGP_INVALID_ARG, "bad data shape");
+  if (d < 1 || d > SVGP_MAX_D || n < 1 || !x_host) return fail(ctx, SVGP_INVALID_ARG, "bad data shape");
   if (layout < 0 || layout > SVGP_VEC || (layout == SVGP_VEC && d != 1)) return fail(ctx, SVGP_INVALID_ARG, "bad layout");
   const size_t es = esize(dtype);
   DataGuard guard;
@@ -613,7 +613,7 @@ int32_t svgp_data_upload(svgp_ctx* ctx, int32_t dtype, int32_t layout, int32_t d
 int32_t svgp_data_wrap_device(svgp_ctx* ctx, int32_t dtype, int32_t d, int64_t n, int64_t ldx, const void* x_dev,
                               const void* y_dev, svgp_data** out) {
   if (!ctx) return SVGP_INVALID_ARG;
-  if (!out || !x_dev || d < 1 || d > 32 || n < 1 || ldx < n) return fail(ctx, SVGP_INVALID_ARG, "bad wrap arguments");
+  if (!out || !x_dev || d < 1 || d > SVGP_MAX_D || n < 1 || ldx < n) return fail(ctx, SVGP_INVALID_ARG, "bad wrap arguments");
   if (dtype != SVGP_F64 && dtype != SVGP_F32) return fail(ctx, SVGP_INVALID_ARG, "bad dtype");
   svgp_data* D = new (std::nothrow) svgp_data();
   if (!D) return SVGP_OOM;

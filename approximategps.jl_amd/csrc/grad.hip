@@ -584,9 +584,13 @@ void launch_kgrad_f(hipStream_t s, const KernelParams& kp, const T* zs, int64_t 
     dim3 grid((unsigned)nslices, (unsigned)(Mp / 128));
     hipLaunchKernelGGL((kgrad_kernel<T, 16, 2, FAMILY>), grid, dim3(k256), 0, s, kp, zs, Mp, x, ldx, xoff, prescaled, n, nvalid,
                        Pt, At, gmu, slice_len, rowpart, scalpart);
-  } else {
+  } else if (kp.d <= 32) {
     dim3 grid((unsigned)nslices, (unsigned)(Mp / 64));
     hipLaunchKernelGGL((kgrad_kernel<T, 32, 1, FAMILY>), grid, dim3(k256), 0, s, kp, zs, Mp, x, ldx, xoff, prescaled, n, nvalid,
+                       Pt, At, gmu, slice_len, rowpart, scalpart);
+  } else {   // 32 < d <= 64 (SVGP_MAX_D): the same kernel with 64 feature slots per thread - it spills, and is correct
+    dim3 grid((unsigned)nslices, (unsigned)(Mp / 64));
+    hipLaunchKernelGGL((kgrad_kernel<T, 64, 1, FAMILY>), grid, dim3(k256), 0, s, kp, zs, Mp, x, ldx, xoff, prescaled, n, nvalid,
                        Pt, At, gmu, slice_len, rowpart, scalpart);
   }
 }
@@ -599,7 +603,7 @@ void launch_kgrad_f(hipStream_t s, const KernelParams& kp, const T* zs, int64_t 
     if ((dtype) == 0) { using T = double; __VA_ARGS__; } else { using T = float; __VA_ARGS__; } \
   } while (0)
 
-int grad_dreg(int d) { return d <= 8 ? 8 : (d <= 16 ? 16 : 32); }
+int grad_dreg(int d) { return d <= 8 ? 8 : (d <= 16 ? 16 : (d <= 32 ? 32 : 64)); }
 int grad_rowblocks(int d, int64_t Mp) { return int(d <= 16 ? Mp / 128 : Mp / 64); }
 
 void launch_set_f64(hipStream_t s, double* dst, double value) { hipLaunchKernelGGL(set_f64_kernel, dim3(1), dim3(1), 0, s, dst, value); }

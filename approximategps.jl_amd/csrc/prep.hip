@@ -412,8 +412,14 @@ __global__ void __launch_bounds__(k256, (FUSE && sizeof(T) == 8) ? 1 : 2) chol_t
   typename G::Acc acc;
   acc.zero();
   const int chunk = blockIdx.x % NCH, tile = blockIdx.x / NCH;
-  if (MODE == MODE_TRSM && tile >= n) {   // T[p, J] = -inv(L_pp) L[p, J]
-    const int J = tile - n;
+  if (MODE == MODE_TRSM && (p < 0 || tile >= n)) {   // T[p, J] = -inv(L_pp) L[p, J]
+    int J = tile - n;
+    if (p < 0) {   // all block rows in one launch (large Kuu: potrf_t): tile -> (row I >= 1, column J < I)
+      int ti, tj;
+      tri_index(tile, ti, tj);
+      p = ti + 1;
+      J = tj;
+    }
     const T* P = Tm + int64_t(p) * NB + int64_t(p) * NB * ld;
     const T* Q = A + int64_t(p) * NB + (int64_t(J) * NB + chunk * NT) * ld;   // element (k, c) at Q[k + c * ld]
     auto qload = [&](int t, QRegs& r) { G::load_q_trans(r, Q + int64_t(t) * 16, ld); };
@@ -765,11 +771,15 @@ void potrf_t(hipStream_t s, T* A, T* Tm, int64_t Mp, int* info, unsigned* sync) 
                        info, p * kNB);
     dbg("potf2", s);
   };
+  // The T panels of block row p ride in panel p's TRSM launch while Kuu is small (the launch is latency-bound anyway: M = 1024
+  // saves the 25 us of a launch of their own); from 17 panels on they would lengthen 60-odd serial launches instead (C4: +0.33 ms
+  // in the TRSM launches against the 0.15 ms of one launch over all 2016 tiles at the end), so a large Kuu keeps the one launch.
+  const bool t_inside = nP <= 16;
   potf2(0);
   for (int p = 0; p < nP; ++p) {
-    const int n = nP - p - 1;
-    if (n + p > 0) {   // the panel below the diagonal and the T panels of block row p
-      hipLaunchKernelGGL((chol_tile_kernel<T, MODE_TRSM, CNT>), dim3((n + p) * NCH), dim3(k256), GS::LDS_BYTES, s, A, Tm, Mp, p, n, info, sync);
+    const int n = nP - p - 1, nt_p = t_inside ? p : 0;
+    if (n + nt_p > 0) {   // the panel below the diagonal (and the T panels of block row p)
+      hipLaunchKernelGGL((chol_tile_kernel<T, MODE_TRSM, CNT>), dim3((n + nt_p) * NCH), dim3(k256), GS::LDS_BYTES, s, A, Tm, Mp, p, n, info, sync);
       dbg("chol trsm + T panels", s);
     }
     if (n == 0) break;
@@ -787,6 +797,10 @@ void potrf_t(hipStream_t s, T* A, T* Tm, int64_t Mp, int* info, unsigned* sync) 
       potf2(p + 1);
     }
     dbg("chol syrk", s);
+  }
+  if (!t_inside) {
+    hipLaunchKernelGGL((chol_tile_kernel<T, MODE_TRSM, CNT>), dim3((nP * (nP - 1) / 2) * NCH), dim3(k256), GS::LDS_BYTES, s, A, Tm, Mp, -1, 0, info, sync);
+    dbg("T panels", s);
   }
 }
 

@@ -840,12 +840,34 @@ __global__ void __launch_bounds__(512, 2) kuf_cols_kernel(KernelParams kp, const
   }
 }
 
+// Kuf for 32 < d <= 64 (round 3; the standalone Kuf metric kernels keep their z fragments in registers / LDS for d <= 32):
+// one thread per inducing row and 16 points, direct differences.  Off the ELBO path (svgp_kuf only).
+template <typename T>
+__global__ void __launch_bounds__(k256) kuf_generic_kernel(KernelParams kp, const T* __restrict__ zs, int64_t M, int64_t Mp,
+                                                           const T* __restrict__ x, int64_t ldx, int64_t off, int64_t len,
+                                                           T* __restrict__ K) {
+  const int64_t i = int64_t(blockIdx.x) * k256 + threadIdx.x;
+  const int64_t j0 = int64_t(blockIdx.y) * 16;
+  if (i >= M) return;
+  const T* __restrict__ invl = static_cast<const T*>(kp.invl);
+  for (int jj = 0; jj < 16 && j0 + jj < len; ++jj) {
+    const int64_t j = j0 + jj;
+    T r2 = T(0);
+    for (int f = 0; f < kp.d; ++f) {
+      const T df = zs[int64_t(f) * Mp + i] - x[int64_t(f) * ldx + off + j] * invl[f];
+      r2 = fma(df, df, r2);
+    }
+    K[i + j * M] = kappa<T>(kp.family, r2, T(kp.variance));
+  }
+}
+
 template <typename T, int NT, int BK, int NTHR, int MINW = 2, int PAD = 16, bool GRAD = false, bool EXT = false>
 void launch_strip_t(hipStream_t s, const StripArgs& a, int grid, int64_t nstrips) {
   using G = TileGemm<T, NT, BK, NTHR, PAD>;
-  // the strip's x image (<= 32 feature rows) aliases the staging buffers
+  // the strip's x image (<= 64 feature rows: SVGP_MAX_D) aliases the staging buffers
   const size_t lds = (SVGP_ASYNC && G::kAsync) ? G::ASYNC_LDS_BYTES : G::LDS_BYTES;
-  static_assert(G::LDS_BYTES >= size_t(32) * NT * sizeof(T), "x image must fit the staging buffers");
+  static_assert(G::LDS_BYTES >= size_t(64) * NT * sizeof(T) && (!(SVGP_ASYNC && G::kAsync) || G::ASYNC_LDS_BYTES >= size_t(64) * NT * sizeof(T)),
+                "x image must fit the staging buffers");
   static_assert(G::LDS_BYTES >= size_t(5) * NT * sizeof(double), "the five per-strip sums reuse the staging buffers");
   auto kern = strip_kernel<T, NT, BK, NTHR, MINW, PAD, GRAD, EXT>;
   set_max_lds(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
@@ -1063,6 +1085,11 @@ static void launch_kuf_f(hipStream_t s, const KernelParams& kp, const T* zs, int
 template <typename T>
 static void launch_kuf_t(hipStream_t s, const KernelParams& kp, const T* zs, int64_t M, int64_t Mp, const T* x, int64_t ldx,
                          int64_t off, int64_t len, T* Kuf) {
+  if (kp.d > 32) {
+    hipLaunchKernelGGL(kuf_generic_kernel<T>, dim3((unsigned)((M + 255) / 256), (unsigned)((len + 15) / 16)), dim3(k256), 0, s, kp, zs, M, Mp, x, ldx,
+                       off, len, Kuf);
+    return;
+  }
   if (kp.family == KSE) launch_kuf_f<T, KSE>(s, kp, zs, M, Mp, x, ldx, off, len, Kuf);
   else if (kp.family == KM32) launch_kuf_f<T, KM32>(s, kp, zs, M, Mp, x, ldx, off, len, Kuf);
   else launch_kuf_f<T, KM52>(s, kp, zs, M, Mp, x, ldx, off, len, Kuf);

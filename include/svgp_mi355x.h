@@ -31,6 +31,7 @@
 extern "C" {
 #endif
 
+#define SVGP_MAX_D 64 /* largest input dimension the device path takes (round 3: 32 -> 64); beyond it SVGP_UNSUPPORTED: the host falls back */
 #define SVGP_ABI_VERSION 4 /* 3 = 2 + svgp_marginals, svgp_elbo_grad_ext, SVGP_LIK_BERNOULLI_NORMCDF; 4 = 3 + svgp_offload_advice /
                               svgp_offload_work and svgp_timing.ms_chol appended (additions only: v2 / v3 callers keep working) */
 

@@ -212,7 +212,7 @@ function pack(sva::SparseVariationalApproximation{P}, lik, quadrature, ::Type{T}
     lay = layout(sva.fz.x)
     lay === nothing && throw(Unsupported())
     lz, Z, d = lay
-    (1 <= d <= 32) || throw(Unsupported())
+    (1 <= d <= 64) || throw(Unsupported())       # SVGP_MAX_D
     sva.fz.f isa AbstractGPs.GP || throw(Unsupported())
     sva.q isa MvNormal || throw(Unsupported())
     ku = unpack_kernel(sva.fz.f.kernel, d)

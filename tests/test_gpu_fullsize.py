@@ -86,11 +86,23 @@ def test_c4_large_m_cholesky_dominated(ctx):
 GRAD_FULL = [
     # name, N, M, d, family, lik, dtype, value rtol, gradient tol (of each block's max-norm), sub-batch
     ("H", 200_000, 1024, 8, o.KERNEL_SE, o.LIK_GAUSSIAN, np.float64, 1e-8, 1e-6, 2500),
-    ("C3", 200_000, 2048, 16, o.KERNEL_MATERN52, o.LIK_BERNOULLI_LOGISTIC, np.float32, 1e-4, 3e-3, 1500),
-    ("C5", 262_144, 1024, 8, o.KERNEL_SE, o.LIK_GAUSSIAN, np.float32, 1e-4, 3e-3, 2500),
+    ("C3", 200_000, 2048, 16, o.KERNEL_MATERN52, o.LIK_BERNOULLI_LOGISTIC, np.float32, 1e-4, None, 1500),
+    ("C5", 262_144, 1024, 8, o.KERNEL_SE, o.LIK_GAUSSIAN, np.float32, 1e-4, None, 2500),
     ("C2", 100_000, 512, 8, o.KERNEL_SE, o.LIK_GAUSSIAN, np.float64, 1e-8, 1e-6, 4000),
-    ("C4", 100_000, 8192, 8, o.KERNEL_SE, o.LIK_GAUSSIAN, np.float32, 1e-4, 3e-3, 800),
+    ("C4", 100_000, 8192, 8, o.KERNEL_SE, o.LIK_GAUSSIAN, np.float32, 1e-4, None, 800),
 ]
+
+
+def _one_rounding_gradient(sva, x, y, **kw):
+    """The oracle's fp64 gradient with every kernel-matrix entry (Kuu, Kuf) rounded ONCE to fp32: the smallest perturbation any
+    fp32 evaluation of the path - the reference's own Float32 run included - cannot avoid.  |this - exact| measures how the
+    problem amplifies an eps-sized error (cond(Lk)^2 through the Cholesky adjoint)."""
+    orig = o._kappa
+    o._kappa = lambda k, r2: orig(k, r2).astype(np.float32).astype(np.float64)
+    try:
+        return o.elbo_grad(sva, x, y, **kw)[1]
+    finally:
+        o._kappa = orig
 
 
 @pytest.mark.parametrize("name,N,M,d,family,lik,dtype,rtol,gtol,nb", GRAD_FULL)
@@ -106,10 +118,23 @@ def test_full_size_value_and_gradient(ctx, name, N, M, d, family, lik, dtype, rt
     val_ref, g_ref = o.elbo_grad(sva, x[:, off:off + nb], y[off:off + nb], lik=lik, sigma2=s2, num_data=float(N))
     val, _, g = model.elbo_grad(data, off, nb, float(N))
     assert rel(val, val_ref) < rtol
+    # fp32: no flat tolerance (round 2 used 3e-3 of a block's max-norm everywhere, which hides a 100x regression at M = 512 and is
+    # tight at M = 8192) but a forward-error model: the device error of a block may exceed the error the SAME block suffers from
+    # one fp32 rounding of every kernel-matrix entry by at most 6 sqrt(M) - the M-long fp32 accumulations of the factorisation and
+    # its adjoint, measured 0.7-3.7 sqrt(M) over M = 512 .. 8192 (tests/f32_grad_accuracy.py) - with a floor of 2e-5
+    g_model = None if gtol is not None else _one_rounding_gradient(sva, x[:, off:off + nb], y[off:off + nb], lik=lik, sigma2=s2, num_data=float(N))
+
+    def tol_of(k, ref):
+        if gtol is not None:
+            return gtol
+        delta = np.abs(np.asarray(g_model[k], dtype=np.float64) - ref).max() / max(np.abs(ref).max(), 1e-12)
+        return max(6.0 * np.sqrt(M) * delta, 2e-5)
+
     for k in ("m", "Lq", "inv_lengthscale", "z"):
         a = np.asarray(g[k], dtype=np.float64).reshape(np.shape(g_ref[k]), order="F")
-        assert np.abs(a - g_ref[k]).max() <= gtol * max(np.abs(g_ref[k]).max(), 1e-12), (name, k)
-    assert abs(g["variance"] - g_ref["variance"]) <= gtol * abs(g_ref["variance"])
+        err = np.abs(a - g_ref[k]).max() / max(np.abs(g_ref[k]).max(), 1e-12)
+        assert err <= tol_of(k, np.asarray(g_ref[k], dtype=np.float64)), (name, k, err, tol_of(k, np.asarray(g_ref[k], dtype=np.float64)))
+    assert abs(g["variance"] - g_ref["variance"]) <= tol_of("variance", np.asarray([g_ref["variance"]])) * abs(g_ref["variance"])
     # (ii) shard additivity at full size
     full_v, _, full_g = model.elbo_grad(data, 0, N, float(N))
     cut = N // 2 + 12345

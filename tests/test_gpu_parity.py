@@ -596,11 +596,14 @@ def test_reference_elbo_testset(ctx):
     assert rel(val, o.elbo(osva, x, y, sigma2=0.1)) < 1e-9
 
 
+@pytest.mark.parametrize("d", [32, 33, 48, 64])
 @pytest.mark.parametrize("dtype,tol,gtol", [(np.float64, F64_RTOL, 1e-6), (np.float32, F32_RTOL, 3e-3)])
-def test_maximum_input_dimension(ctx, dtype, tol, gtol):
-    """d = 32 is the ABI's maximum (the feature rows kept in registers / LDS): value, gradient and Kuf at the limit, and the
-    status one dimension beyond it."""
-    N, M, d = 700, 90, 32
+def test_maximum_input_dimension(ctx, dtype, tol, gtol, d):
+    """d = 64 is the ABI's maximum (SVGP_MAX_D; round 2: 32).  Up to 32 the feature rows stay in registers / LDS of the fast
+    kernels; 33..64 take the strip kernel's generic Kuf generation, the generic standalone Kuf kernel and the 64-slot
+    kernel-gradient reductions: value, gradient and Kuf on both sides of 32 and at the limit, and the status one dimension
+    beyond it."""
+    N, M = 700, 90
     x, y, sva, s2 = o.synth_problem(3200, N, M, d, family=o.KERNEL_MATERN32, dtype=dtype)
     model = device_model(ctx, sva, dtype=dtype, sigma2=s2)
     data = _ffi.DeviceData(ctx, x, y, dtype)
@@ -617,6 +620,6 @@ def test_maximum_input_dimension(ctx, dtype, tol, gtol):
     np.testing.assert_allclose(K, o.kernelmatrix(sva.kernel, sva.z, x), rtol=0, atol=(1e-12 if dtype == np.float64 else 2e-6))
     model.free()
     data.free()
-    x33 = np.random.default_rng(0).standard_normal((33, 50))
+    x65 = np.random.default_rng(0).standard_normal((65, 50))
     with pytest.raises((ValueError, _ffi.UnsupportedError, _ffi.SvgpError)):
-        _ffi.DeviceData(ctx, x33, np.zeros(50), np.float64)
+        _ffi.DeviceData(ctx, x65, np.zeros(50), np.float64)
