@@ -249,7 +249,7 @@ struct StripOuts {
   void* At = nullptr;
   void* Ct = nullptr;
   int64_t lda = 0;
-  bool skip_expect = false;   // gradient path: the moments are consumed by grad_moments instead
+  bool skip_expect = false;   // svgp_marginals: the caller wants the moments themselves
 };
 
 // enqueue the fused strip kernel + final reduce over points [off, off+len) of (x, y)
@@ -1012,7 +1012,7 @@ int grad_workspace(svgp_ctx* ctx, svgp_model* m, int64_t len, GradWs** out) {
 namespace {
 // value = scale * sum_i E_i - klw * KL and its gradient over points [off, off + len): three stages like the forward
 // evaluation.  Data-parallel (a communicator on the context, `collective`): every rank uses scale = num_data / n_global
-// with n_global all-reduced on the device BEFORE the backward pass (grad_moments reads it there; no host hop) and
+// with n_global all-reduced on the device BEFORE the backward pass (the strips' phase 3 reads it there; no host hop) and
 // klw = 1 / world, so the plain sum over ranks of (value, gradient) is the global ELBO and its gradient; that sum is ONE
 // grouped ncclAllReduce of {z_bar, m_bar, Lq_bar, [sums | scal_out]} at the end.
 struct GradCall {
@@ -1114,7 +1114,7 @@ int grad_enqueue(svgp_ctx* ctx, svgp_model* m, const svgp_data* data, int64_t of
     const StripPlan plan = strip_plan_single(dt, Mp, clen, ctx->num_cus);
     const int nt = plan.grid ? plan.nt : plan.nt_tail, grid = plan.grid ? plan.grid : plan.grid_tail;
     const int64_t nstrips = plan.grid ? plan.nstrips : plan.nstrips_tail;
-    rc = ensure_scratch(ctx, strip_work_bytes(dt, Mp, nt, grid), 1);
+    rc = ensure_scratch(ctx, 2 * strip_work_bytes(dt, Mp, nt, grid), 1);   // the A strip and, beside it, the Kuf strip
     if (rc) return rc;
     if (nstrips > w->part5_strips) return fail(ctx, SVGP_HIP_ERROR, "internal: strip partial buffer too small");
     HIPC(ctx, hipMemsetAsync(w->gmu, 0, 2 * size_t(nc) * es, s));   // g_mu | g_v (the SYRK reads g_v over the padded chunk)
@@ -1149,7 +1149,7 @@ int grad_enqueue(svgp_ctx* ctx, svgp_model* m, const svgp_data* data, int64_t of
     int64_t ksl = ((clen + w->ns_uf - 1) / w->ns_uf + 127) / 128 * 128;
     if (a_in_strips) launch_apart_reduce(sk, w->apart, int(nstrips), Mp, w->rp_uf + Mp);   // slot 1 of slice 0 of rp_uf
     launch_kgrad(dt, sk, kp, m->zs, Mp, data->x, data->ldx, off + c0, 0, clen, clen, w->Pt, a_in_strips ? nullptr : w->At,
-                 a_in_strips ? nullptr : w->gmu, ksl, w->ns_uf, w->rp_uf, w->sp_uf);
+                 w->gmu, w->gv, w->alpha, ksl, w->ns_uf, w->rp_uf, w->sp_uf);
     KCHECK(ctx, "kgrad uf");
     if (kg_overlap) HIPC(ctx, hipEventRecord(ctx->ev_join, sk));
     launch_sum5(s, w->partial5, int(nstrips), w->sums);
@@ -1194,7 +1194,7 @@ int grad_enqueue(svgp_ctx* ctx, svgp_model* m, const svgp_data* data, int64_t of
   // the Kuu part: the ns_uu slices must cover all M columns (a fixed slice of 128 covered only 1024 of them: the kernel-
   // parameter and z gradients were wrong for M > 1024 until tests/test_gpu_grad.py::test_gradient_large_m_float32_strips)
   const int64_t uu_sl = ((M + w->ns_uu - 1) / w->ns_uu + 127) / 128 * 128;
-  launch_kgrad(dt, s, kp, m->zs, Mp, m->zs, Mp, 0, 1, M, M, w->H, nullptr, nullptr, uu_sl, w->ns_uu, w->rp_uu, w->sp_uu);
+  launch_kgrad(dt, s, kp, m->zs, Mp, m->zs, Mp, 0, 1, M, M, w->H, nullptr, nullptr, nullptr, nullptr, uu_sl, w->ns_uu, w->rp_uu, w->sp_uu);
   launch_finish_kgrad(dt, s, m->d, M, Mp, m->zs, w->invl_d, w->rp_uf, w->ns_uf, w->rp_uu, w->ns_uu, w->sp_uf, w->ns_uf * w->rb,
                       w->sp_uu, w->ns_uu * w->rb, m->mp, klw, m->desc.layout_z, m->desc.variance, w->zbar, centered ? nullptr : w->mbar,
                       w->scal_out, w->kred);

@@ -321,7 +321,8 @@ template <typename T, int DREG, int KV, int FAMILY>
 __global__ void __launch_bounds__(k256) kgrad_kernel(KernelParams kp, const T* __restrict__ zs, int64_t Mp,
                                                      const T* __restrict__ x, int64_t ldx, int64_t xoff, int prescaled,
                                                      int64_t n, int64_t nvalid, const T* __restrict__ Pt,
-                                                     const T* __restrict__ At, const T* __restrict__ gmu, int64_t slice_len,
+                                                     const T* __restrict__ At, const T* __restrict__ gmu, const T* __restrict__ gv,
+                                                     const T* __restrict__ alpha, int64_t slice_len,
                                                      double* __restrict__ rowpart, double* __restrict__ scalpart) {
   constexpr int JB = 128;
   __shared__ T xt[JB * DREG];
@@ -339,6 +340,11 @@ __global__ void __launch_bounds__(k256) kgrad_kernel(KernelParams kp, const T* _
   for (int f = 0; f < DREG; ++f)
 #pragma unroll
     for (int e = 0; e < KV; ++e) z[f][e] = (f < d) ? zs[int64_t(f) * Mp + i + e] : T(0);
+  // data part (round 3): Pt holds the strips' UNSCALED product R A; P_ij = alpha_i g_mu_j + 2 g_v_j (R A)_ij is formed here, by
+  // its one consumer (the strips learn g_v only after their last panel).  Kuu part (alpha == nullptr): Pt is the matrix itself.
+  T al[KV];
+#pragma unroll
+  for (int e = 0; e < KV; ++e) al[e] = alpha ? alpha[i + e] : T(0);
   double R[KV], MB[KV], Q[DREG][KV], IL[DREG], S1 = 0.0;
 #pragma unroll
   for (int e = 0; e < KV; ++e) R[e] = MB[e] = 0.0;
@@ -365,7 +371,7 @@ __global__ void __launch_bounds__(k256) kgrad_kernel(KernelParams kp, const T* _
     // f64 AND in fp32: 5-6 ms of a value-and-gradient evaluation)
     constexpr int U = 4;
     for (int c0w = wave; c0w < JB && jb + c0w < j1; c0w += 4 * U) {
-      T pv[U][KV], av[U][KV], gmv[U];
+      T pv[U][KV], av[U][KV], gmv[U], gvv[U];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const int c = c0w + 4 * u;
@@ -376,7 +382,8 @@ __global__ void __launch_bounds__(k256) kgrad_kernel(KernelParams kp, const T* _
           pv[u][e] = Pt[j * Mp + i + e];
           av[u][e] = At ? At[j * Mp + i + e] : T(0);
         }
-        gmv[u] = (At && gmu) ? gmu[j] : T(0);
+        gmv[u] = gmu ? gmu[j] : T(0);
+        gvv[u] = alpha ? T(2) * gv[j] : T(1);
       }
 #pragma unroll
       for (int u = 0; u < U; ++u) {
@@ -398,11 +405,11 @@ __global__ void __launch_bounds__(k256) kgrad_kernel(KernelParams kp, const T* _
         for (int e = 0; e < KV; ++e) {
           T k, dk;
           kappa_and_d<T, FAMILY>(r2[e], variance, k, dk);
-          const T p = pv[u][e];
+          const T p = fma(gvv[u], pv[u][e], al[e] * gmv[u]);   // alpha == nullptr: 1 * pv + 0
           const double W = double(p) * double(dk);
           S1 += double(p) * double(k);
           R[e] += W;
-          if (At) MB[e] += double(av[u][e]) * double(gmv[u]);
+          if (At) MB[e] += double(av[u][e]) * double(gmv[u]);   // (A g_mu)_i, f64 builds
 #pragma unroll
           for (int f = 0; f < DREG; ++f) {
             Q[f][e] += W * double(xt[c * DREG + f]);
@@ -574,24 +581,24 @@ __global__ void finish_kgrad_kernel(int d, int64_t M, int64_t Mp, const T* __res
 
 template <typename T, int FAMILY>
 void launch_kgrad_f(hipStream_t s, const KernelParams& kp, const T* zs, int64_t Mp, const T* x, int64_t ldx, int64_t xoff,
-                    int prescaled, int64_t n, int64_t nvalid, const T* Pt, const T* At, const T* gmu, int64_t slice_len,
-                    int nslices, double* rowpart, double* scalpart) {
+                    int prescaled, int64_t n, int64_t nvalid, const T* Pt, const T* At, const T* gmu, const T* gv, const T* alpha,
+                    int64_t slice_len, int nslices, double* rowpart, double* scalpart) {
   if (kp.d <= 8) {
     dim3 grid((unsigned)nslices, (unsigned)(Mp / 128));
     hipLaunchKernelGGL((kgrad_kernel<T, 8, 2, FAMILY>), grid, dim3(k256), 0, s, kp, zs, Mp, x, ldx, xoff, prescaled, n, nvalid, Pt,
-                       At, gmu, slice_len, rowpart, scalpart);
+                       At, gmu, gv, alpha, slice_len, rowpart, scalpart);
   } else if (kp.d <= 16) {
     dim3 grid((unsigned)nslices, (unsigned)(Mp / 128));
     hipLaunchKernelGGL((kgrad_kernel<T, 16, 2, FAMILY>), grid, dim3(k256), 0, s, kp, zs, Mp, x, ldx, xoff, prescaled, n, nvalid,
-                       Pt, At, gmu, slice_len, rowpart, scalpart);
+                       Pt, At, gmu, gv, alpha, slice_len, rowpart, scalpart);
   } else if (kp.d <= 32) {
     dim3 grid((unsigned)nslices, (unsigned)(Mp / 64));
     hipLaunchKernelGGL((kgrad_kernel<T, 32, 1, FAMILY>), grid, dim3(k256), 0, s, kp, zs, Mp, x, ldx, xoff, prescaled, n, nvalid,
-                       Pt, At, gmu, slice_len, rowpart, scalpart);
+                       Pt, At, gmu, gv, alpha, slice_len, rowpart, scalpart);
   } else {   // 32 < d <= 64 (SVGP_MAX_D): the same kernel with 64 feature slots per thread - it spills, and is correct
     dim3 grid((unsigned)nslices, (unsigned)(Mp / 64));
     hipLaunchKernelGGL((kgrad_kernel<T, 64, 1, FAMILY>), grid, dim3(k256), 0, s, kp, zs, Mp, x, ldx, xoff, prescaled, n, nvalid,
-                       Pt, At, gmu, slice_len, rowpart, scalpart);
+                       Pt, At, gmu, gv, alpha, slice_len, rowpart, scalpart);
   }
 }
 
@@ -691,17 +698,17 @@ void launch_gemm_pm(int dtype, hipStream_t s, const void* Xt, const void* Yt, co
 
 void launch_kgrad(int dtype, hipStream_t s, const KernelParams& kp, const void* zs, int64_t Mp, const void* x, int64_t ldx,
                   int64_t xoff, int prescaled, int64_t n, int64_t nvalid, const void* Pt, const void* At, const void* gmu,
-                  int64_t slice_len, int nslices, double* rowpart, double* scalpart) {
+                  const void* gv, const void* alpha, int64_t slice_len, int nslices, double* rowpart, double* scalpart) {
   GD(dtype, T, {
     if (kp.family == KSE)
       launch_kgrad_f<T, KSE>(s, kp, (const T*)zs, Mp, (const T*)x, ldx, xoff, prescaled, n, nvalid, (const T*)Pt, (const T*)At,
-                             (const T*)gmu, slice_len, nslices, rowpart, scalpart);
+                             (const T*)gmu, (const T*)gv, (const T*)alpha, slice_len, nslices, rowpart, scalpart);
     else if (kp.family == KM32)
       launch_kgrad_f<T, KM32>(s, kp, (const T*)zs, Mp, (const T*)x, ldx, xoff, prescaled, n, nvalid, (const T*)Pt, (const T*)At,
-                              (const T*)gmu, slice_len, nslices, rowpart, scalpart);
+                              (const T*)gmu, (const T*)gv, (const T*)alpha, slice_len, nslices, rowpart, scalpart);
     else
       launch_kgrad_f<T, KM52>(s, kp, (const T*)zs, Mp, (const T*)x, ldx, xoff, prescaled, n, nvalid, (const T*)Pt, (const T*)At,
-                              (const T*)gmu, slice_len, nslices, rowpart, scalpart);
+                              (const T*)gmu, (const T*)gv, (const T*)alpha, slice_len, nslices, rowpart, scalpart);
   });
 }
 

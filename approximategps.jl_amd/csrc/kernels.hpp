@@ -82,7 +82,7 @@ struct StripArgs {
   // ---- value-and-gradient strips (launch_strip_grad): phase 3 of the same kernel, P = Kuf_bar for the strip's points ----
   const void* R;        // Mp x Mp col-major: Lk^-T (Lq Lq' - I)
   const void* alpha;    // [Mp] Lk^-T m
-  void* Pt_out;         // point-major [n][Mp]: P = alpha g_mu' + 2 (R A) diag(g_v)
+  void* Pt_out;         // point-major [n][Mp]: the UNSCALED product R A (P = alpha g_mu' + 2 (R A) diag(g_v) is formed by kgrad)
   void* gmu_out;        // [n] g_mu = scale dE/dmu (compute dtype), also read by kgrad
   void* gv_out;         // [n] g_v
   const void* y;        // observations of the batch (index off + i)
@@ -148,9 +148,11 @@ void launch_sum_slices_lower(int dtype, hipStream_t s, const void* part, int ns,
 void launch_linv(int dtype, hipStream_t s, const void* L, const void* Tm, int64_t Mp, void* LinvRM, void* LinvCM, void* Ytmp);
 // out = Lk^-T v = LinvRM' v; part: (Mp / 128) x Mp doubles of scratch
 void launch_linv_t_gemv(int dtype, hipStream_t s, const void* LinvRM, const void* v, int64_t Mp, void* out, double* part);
+// data part: Pt = the strips' unscaled R A, P_ij = alpha_i gmu_j + 2 gv_j Pt_ji formed inside (alpha != nullptr); Kuu part: Pt is
+// the matrix itself (alpha = gmu = gv = nullptr); At: (A g_mu) row sums beside it (f64 builds), else nullptr
 void launch_kgrad(int dtype, hipStream_t s, const KernelParams& kp, const void* zs, int64_t Mp, const void* x, int64_t ldx,
                   int64_t xoff, int prescaled, int64_t n, int64_t nvalid, const void* Pt, const void* At, const void* gmu,
-                  int64_t slice_len, int nslices, double* rowpart, double* scalpart);
+                  const void* gv, const void* alpha, int64_t slice_len, int nslices, double* rowpart, double* scalpart);
 // fused gradient path: sums of the per-strip partials, W = A diag(2 g_v) A' from its split-K lower tiles, (A g_mu), and the
 // assembly of Lq_bar / Lk_bar from G1 = 2 W Lq, G2 = 2 R W and the rank-one term alpha (A g_mu)'
 void launch_sum5(hipStream_t s, const double* partial, int nblocks, double* sums);

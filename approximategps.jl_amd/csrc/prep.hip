@@ -435,7 +435,7 @@ __global__ void __launch_bounds__(k256, (FUSE && sizeof(T) == 8) ? 1 : 2) chol_t
   }
   int i, j;
   const T* P;
-  if (MODE == MODE_TRSM) {       // L[i, p] = A[i, p] inv(L_pp)'  (see tile128_kernel)
+  if (MODE == MODE_TRSM) {       // L[i, p] = A[i, p] inv(L_pp)', computed as X' = inv(L_pp) A[i, p]' so that stores run along columns of A
     i = p + 1 + tile;
     j = p;
     P = Tm + int64_t(p) * NB + int64_t(p) * NB * ld;

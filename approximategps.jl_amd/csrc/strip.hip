@@ -197,6 +197,9 @@ __global__ void __launch_bounds__(NTHR, MINW) strip_kernel(StripArgs a, int64_t 
   const T variance = T(a.kp.variance);
   const int nP = int(Mp / NB);
   T* __restrict__ work = static_cast<T*>(a.work) + int64_t(blockIdx.x) * Mp * NT;
+  // GRAD: the generated Kuf block keeps a scratch strip of its own (the A strip goes beside it instead of overwriting it panel by
+  // panel): phase 3's epilogue needs K again for the variance (see below).  Forward builds: one strip, K overwritten in place.
+  T* __restrict__ workK = GRAD ? static_cast<T*>(a.work) + (int64_t(gridDim.x) + blockIdx.x) * Mp * NT : work;
   const int tid = threadIdx.x, lane = tid & 63;
   const typename G::QOff qoff = G::q_offsets(NT);           // per-thread byte offsets inside a scratch-strip tile
 
@@ -251,17 +254,17 @@ __global__ void __launch_bounds__(NTHR, MINW) strip_kernel(StripArgs a, int64_t 
           V out;
 #pragma unroll
           for (int q = 0; q < VEC; ++q) out[q] = (k < M) ? kappa<T>(F, r2[q], variance) : T(0);
-          *reinterpret_cast<V*>(work + int64_t(k) * NT + c) = out;
+          *reinterpret_cast<V*>(workK + int64_t(k) * NT + c) = out;
         }
       };
       if (pre_dl == 8) {
-        if (family == KSE) pregen_mfma<T, NT, NTHR, KSE, 8>(xs, zs, d, Mp, M, a.kp.variance, work);
-        else if (family == KM32) pregen_mfma<T, NT, NTHR, KM32, 8>(xs, zs, d, Mp, M, a.kp.variance, work);
-        else pregen_mfma<T, NT, NTHR, KM52, 8>(xs, zs, d, Mp, M, a.kp.variance, work);
+        if (family == KSE) pregen_mfma<T, NT, NTHR, KSE, 8>(xs, zs, d, Mp, M, a.kp.variance, workK);
+        else if (family == KM32) pregen_mfma<T, NT, NTHR, KM32, 8>(xs, zs, d, Mp, M, a.kp.variance, workK);
+        else pregen_mfma<T, NT, NTHR, KM52, 8>(xs, zs, d, Mp, M, a.kp.variance, workK);
       } else if (pre_dl == 16) {
-        if (family == KSE) pregen_mfma<T, NT, NTHR, KSE, 16>(xs, zs, d, Mp, M, a.kp.variance, work);
-        else if (family == KM32) pregen_mfma<T, NT, NTHR, KM32, 16>(xs, zs, d, Mp, M, a.kp.variance, work);
-        else pregen_mfma<T, NT, NTHR, KM52, 16>(xs, zs, d, Mp, M, a.kp.variance, work);
+        if (family == KSE) pregen_mfma<T, NT, NTHR, KSE, 16>(xs, zs, d, Mp, M, a.kp.variance, workK);
+        else if (family == KM32) pregen_mfma<T, NT, NTHR, KM32, 16>(xs, zs, d, Mp, M, a.kp.variance, workK);
+        else pregen_mfma<T, NT, NTHR, KM52, 16>(xs, zs, d, Mp, M, a.kp.variance, workK);
       } else if (family == KSE) pregen(std::integral_constant<int, KSE>{});
       else if (family == KM32) pregen(std::integral_constant<int, KM32>{});
       else pregen(std::integral_constant<int, KM52>{});
@@ -279,11 +282,12 @@ __global__ void __launch_bounds__(NTHR, MINW) strip_kernel(StripArgs a, int64_t 
       Acc acc;
       acc.zero();
       // the last NB/BK steps multiply the lower-triangular inv(L_II): their zero 16-row tiles are skipped
+      const int tK = I * (NB / BK);   // first k-step of the panel's own (still Kuf) rows
       if constexpr (SVGP_ASYNC && G::kAsync) {
-        auto qsrc = [&](int t) { return work + int64_t(t) * BK * NT; };
+        auto qsrc = [&](int t) { return (t < tK ? work : workK) + int64_t(t) * BK * NT; };
         G::template loop_tri_async<(SVGP_TRI & 1) ? 1 : 0>(acc, Tm + int64_t(I) * NB, Mp, (I + 1) * (NB / BK), qsrc, smem);
       } else {
-        auto qload = [&](int t, QRegs& r) { G::load_q(r, work + int64_t(t) * BK * NT, qoff); };
+        auto qload = [&](int t, QRegs& r) { G::load_q(r, (t < tK ? work : workK) + int64_t(t) * BK * NT, qoff); };
         G::template loop_tri<(BK == 16 && (SVGP_TRI & 1)) ? 1 : 0>(acc, Tm + int64_t(I) * NB, Mp, (I + 1) * (NB / BK), qload, smem);
       }
 
@@ -308,7 +312,7 @@ __global__ void __launch_bounds__(NTHR, MINW) strip_kernel(StripArgs a, int64_t 
             }
 #if !(defined(SVGP_ABLATE) && (SVGP_ABLATE & 16))
             const double dv = double(val);
-            sA[j] = fma(dv, dv, sA[j]);
+            if constexpr (!GRAD) sA[j] = fma(dv, dv, sA[j]);
             sM[j] = fma(dv, mr, sM[j]);
 #else
             sA[j] += double(val) + mr;
@@ -321,7 +325,8 @@ __global__ void __launch_bounds__(NTHR, MINW) strip_kernel(StripArgs a, int64_t 
       SVGP_SSTAMP(4 + 3 * I);
     }
 
-    // ---------------- phase 2: C = B' A ----------------
+    // ---------------- phase 2: C = B' A  (forward builds; the value-and-gradient build gets the variance from phase 3) --------
+    if constexpr (!GRAD)
     for (int J = 0; J < nP; ++J) {
       SVGP_SSTAMP(60 + 2 * J);
       Acc acc;
@@ -350,6 +355,39 @@ __global__ void __launch_bounds__(NTHR, MINW) strip_kernel(StripArgs a, int64_t 
             const double dv = double(val);
             sC[j] = fma(dv, dv, sC[j]);
           }
+    }
+
+    // ---------------- phase 3 (GRAD): R A, panel by panel (dense: every k-step is a full tile) ----------------
+    // Round 3: the value-and-gradient build has NO phase 2.  With S = B B', R = Lk^-T (S - I) and Lk a_j = k_j (column j of Kuf):
+    //   v_j - k(x_j, x_j) = sum C_.j^2 - sum A_.j^2 = a_j' (S - I) a_j = (Lk a_j)' (R a_j) = k_j' (R A)_.j
+    // so the dense product this build needs anyway gives the variance too: the epilogue dots each R A tile with the Kuf tile
+    // (kept in its own scratch strip) - 4 GEMM units per point (trsm 1 + dense 2 + SYRK 1) instead of 5.  The tile leaves
+    // UNSCALED (g_v is only known once all panels are done): P = alpha g_mu' + 2 (R A) diag(g_v) is formed by its one consumer,
+    // kgrad_kernel.  Numerics: same cancellation as the forward formula; emulated in fp32 on posteriors with v down to 4e-4 of
+    // the prior variance the two formulas err alike (3e-6 absolute; 7e-15 in f64).
+    if constexpr (GRAD) {
+      const T* __restrict__ Rm = static_cast<const T*>(a.R);
+      T* __restrict__ Pt = static_cast<T*>(a.Pt_out);
+      for (int I = 0; I < nP; ++I) {
+        Acc acc;
+        acc.zero();
+        if constexpr (SVGP_ASYNC && G::kAsync) {
+          auto qsrc = [&](int t) { return work + int64_t(t) * BK * NT; };
+          G::template loop_tri_async<0>(acc, Rm + int64_t(I) * NB, Mp, nP * (NB / BK), qsrc, smem);
+        } else {
+          auto qload = [&](int t, QRegs& r) { G::load_q(r, work + int64_t(t) * BK * NT, qoff); };
+          G::template loop_tri<0>(acc, Rm + int64_t(I) * NB, Mp, nP * (NB / BK), qload, smem);
+        }
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int64_t row = int64_t(I) * NB + G::acc_row(i, r);
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) sC[j] = fma(double(acc.v[i][j][r]), double(workK[row * NT + G::acc_col(j)]), sC[j]);
+          }
+        store_tile_point_major<G, T, NT, NTHR>(acc, smem, Pt, c0, Mp, I * NB);
+      }
     }
 
     SVGP_SSTAMP(100);
@@ -396,7 +434,7 @@ __global__ void __launch_bounds__(NTHR, MINW) strip_kernel(StripArgs a, int64_t 
           qc += red[(2 * G::WR + w) * NT + tid];
         }
         const double mu = a.mean_const + qm;
-        double v = a.kp.variance - qa + qc + kDefaultSigma2;
+        double v = a.kp.variance + qc + kDefaultSigma2;   // qc = k_j' (R A)_.j  (= sum C^2 - sum A^2; qa is not accumulated in this build)
         const double scale = a.n_global_dev ? (a.num_data > 0.0 ? a.num_data / *a.n_global_dev : 1.0) : a.scale;
         bool bad = v < 0.0;
         if (bad) {
@@ -465,32 +503,6 @@ __global__ void __launch_bounds__(NTHR, MINW) strip_kernel(StripArgs a, int64_t 
           }
         }
       }
-      // ---------------- phase 3: P = alpha g_mu' + 2 (R A) diag(g_v), panel by panel (dense: every k-step is a full tile) ----
-      const T* __restrict__ Rm = static_cast<const T*>(a.R);
-      const T* __restrict__ alpha = static_cast<const T*>(a.alpha);
-      T* __restrict__ Pt = static_cast<T*>(a.Pt_out);
-      for (int I = 0; I < nP; ++I) {
-        Acc acc;
-        acc.zero();
-        if constexpr (SVGP_ASYNC && G::kAsync) {
-          auto qsrc = [&](int t) { return work + int64_t(t) * BK * NT; };
-          G::template loop_tri_async<0>(acc, Rm + int64_t(I) * NB, Mp, nP * (NB / BK), qsrc, smem);
-        } else {
-          auto qload = [&](int t, QRegs& r) { G::load_q(r, work + int64_t(t) * BK * NT, qoff); };
-          G::template loop_tri<0>(acc, Rm + int64_t(I) * NB, Mp, nP * (NB / BK), qload, smem);
-        }
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-          const int col = G::acc_col(j);
-          const T g2 = T(2) * s_gv[col], g1 = s_gmu[col];
-#pragma unroll
-          for (int i = 0; i < MI; ++i)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) acc.v[i][j][r] = fma(g2, acc.v[i][j][r], alpha[I * NB + G::acc_row(i, r)] * g1);
-        }
-        store_tile_point_major<G, T, NT, NTHR>(acc, smem, Pt, c0, Mp, I * NB);
-      }
-      __syncthreads();
     }
     strip = next_strip;
     __syncthreads();

@@ -55,8 +55,9 @@ def test_gradient_matches_oracle(ctx, N, M, d, family, lik, qn, dtype, tol):
     _close([g["mean_const"]], [g_ref["mean_const"]], tol)
     if lik in (o.LIK_GAUSSIAN, o.LIK_GAMMA_EXP):   # the likelihood parameter: sigma^2 / Gamma shape
         _close([g["lik_sigma2"]], [g_ref["lik_sigma2"]], tol)
-    # same value as the forward-only entry point
-    assert rel(val, model.elbo(data, 0, N, 2.5 * N)[0]) < 1e-12
+    # same value as the forward-only entry point (the gradient build takes the variance from its dense product, v - k(x,x) =
+    # k_j' (R A)_j, not from sum C^2 - sum A^2: equal up to rounding in the compute dtype)
+    assert rel(val, model.elbo(data, 0, N, 2.5 * N)[0]) < (1e-12 if dtype == np.float64 else 1e-5)
     model.free()
     data.free()
 
@@ -114,7 +115,7 @@ def test_centered_gradient_matches_oracle(ctx, N, M, d, family, lik, qn, dtype, 
     _close([g["mean_const"]], [g_ref["mean_const"]], tol)
     if lik == o.LIK_GAUSSIAN:
         _close([g["lik_sigma2"]], [g_ref["lik_sigma2"]], tol)
-    assert rel(val, model.elbo(data, 0, N, 1.5 * N)[0]) < 1e-12
+    assert rel(val, model.elbo(data, 0, N, 1.5 * N)[0]) < (1e-12 if dtype == np.float64 else 1e-5)
     model.free()
     data.free()
 
@@ -279,7 +280,7 @@ def test_gradient_more_than_1024_inducing_points_f64(ctx):
 
 
 # ---- likelihoods the ABI does not enumerate: host-evaluated on the device marginals (svgp_marginals / svgp_elbo_grad_ext) ----
-@pytest.mark.parametrize("dtype,vtol,gtol", [(np.float64, 1e-12, 1e-10), (np.float32, 1e-6, 1e-5)])
+@pytest.mark.parametrize("dtype,vtol,gtol", [(np.float64, 1e-12, 1e-10), (np.float32, 1e-5, 5e-5)])   # fp32: the built-in gradient build takes v from k_j'(R A)_j, svgp_marginals from sum C^2 - sum A^2
 @pytest.mark.parametrize("centered", [False, True])
 def test_host_evaluated_likelihood_equals_builtin(ctx, dtype, vtol, gtol, centered):
     """The split path must reproduce the fused one when the host evaluates a likelihood the library also has: marginals ->
