@@ -4,6 +4,8 @@
 // the same derivation; api.hip: grad_enqueue is the schedule).  With A = Lk \ Kuf, B the whitened factor, W = A diag(2 g_v) A':
 //   data-sized     W (SYRK over the points, split-K slices)                         gemm_pm_kernel
 //                  kernel-parameter / inducing-input reductions of P o dK           kgrad_kernel
+//                  (P = alpha g_mu' + 2 (R A) diag(g_v) is formed there from the strips' UNSCALED R A: the strips take the
+//                  variance from the same product, so their phase 2 is gone - 4 GEMM units per point in all: trsm 1 + R A 2 + W 1)
 //   M-sized        Linv = Lk^-1 by recursive doubling (round 3)                     linv_init / linv_step kernels
 //                  alpha = Linv' m~,  R = Linv' (B B' - I)                          linv_t_gemv, gemm_pm (M x M x M form)
 //                  Lq_bar = tril(W B) - dKL/dB,  Lk_bar = -tril(alpha a' + R W)     gemm_pm, finish_mm2
@@ -326,6 +328,7 @@ __global__ void __launch_bounds__(k256) kgrad_kernel(KernelParams kp, const T* _
                                                      double* __restrict__ rowpart, double* __restrict__ scalpart) {
   constexpr int JB = 128;
   __shared__ T xt[JB * DREG];
+  __shared__ T gms[JB], gvs[JB];   // g_mu and 2 g_v of the staged points (1 where P is given as it is): staged with x, read as broadcasts
   __shared__ double red[64 * KV * (2 + DREG)];
   __shared__ double sred[k256];
   const int d = kp.d;
@@ -365,6 +368,12 @@ __global__ void __launch_bounds__(k256) kgrad_kernel(KernelParams kp, const T* _
       if (f < d) v = prescaled ? x[int64_t(f) * ldx + xoff + g] : x[int64_t(f) * ldx + xoff + g] * invl[f];
       xt[e] = v;
     }
+    if (threadIdx.x < JB) {
+      int64_t g = jb + threadIdx.x;
+      g = g < j1 ? g : j1 - 1;
+      gms[threadIdx.x] = gmu ? gmu[g] : T(0);
+      gvs[threadIdx.x] = alpha ? T(2) * gv[g] : T(1);
+    }
     __syncthreads();
     // U points of this wave in flight at a time: the kernel streams P (and A) once from HBM with ONE 1 KiB load per point
     // and wave, and with a single load outstanding per wave it ran at the memory latency (350 us per 65 536-point chunk in
@@ -382,8 +391,8 @@ __global__ void __launch_bounds__(k256) kgrad_kernel(KernelParams kp, const T* _
           pv[u][e] = Pt[j * Mp + i + e];
           av[u][e] = At ? At[j * Mp + i + e] : T(0);
         }
-        gmv[u] = gmu ? gmu[j] : T(0);
-        gvv[u] = alpha ? T(2) * gv[j] : T(1);
+        gmv[u] = gms[ok ? c : c0w];
+        gvv[u] = gvs[ok ? c : c0w];
       }
 #pragma unroll
       for (int u = 0; u < U; ++u) {

@@ -106,8 +106,9 @@ struct StripPlan {       // regular-width launch over the first `points` points,
 StripPlan strip_plan(int dtype, int64_t Mp, int64_t len, int num_cus);
 StripPlan strip_plan_single(int dtype, int64_t Mp, int64_t len, int num_cus);   // never a concurrent tail (paths that write A / C)
 void launch_strip(int dtype, hipStream_t s, const StripArgs& a, int nt, int grid, int64_t nstrips);
-// the value-and-gradient form: phases 1-2 as launch_strip, then the per-point likelihood gradients and phase 3
-// (a dense Mp x Mp GEMM on the strip's A, still in its scratch strip); writes At_out, Pt_out, gmu_out, gv_out, part5
+// the value-and-gradient form: phase 1 as launch_strip, then phase 3 (a dense Mp x Mp GEMM R A on the strip's A, still in its
+// scratch strip, whose epilogue also gives the variance) and the per-point likelihood gradients; writes At_out, Pt_out (R A,
+// unscaled), gmu_out, gv_out, part5.  `work` must hold TWO scratch strips per workgroup (2 x strip_work_bytes).
 void launch_strip_grad(int dtype, hipStream_t s, const StripArgs& a, int nt, int grid, int64_t nstrips);
 // marginals + expected log-likelihood of every point (SVA:354-355): per-block sums into partial/negcnt
 int expect_blocks(int64_t len);

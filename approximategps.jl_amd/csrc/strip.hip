@@ -156,13 +156,14 @@ __device__ __noinline__ PointGrads strip_point_grads(LikParams lp, double mu, do
   return r;
 }
 
-// GRAD: the value-and-gradient form (svgp_elbo_grad).  After phases 1-2 the workgroup knows (mu, v) of its strip's
-// points, so it evaluates the likelihood gradients (g_mu, g_v) = scale dE/d(mu, v) itself and runs
-//   phase 3:  P = Kuf_bar = Lk' \ Abar = alpha g_mu' + 2 (R A) diag(g_v),   R = Lk^-T (Lq Lq' - I),  alpha = Lk^-T m
-// as ONE dense Mp x Mp GEMM on the A strip that is still in its scratch strip (the adjoint's two triangular products
-// Lq (Lq'A) - A and Lk' \ . folded into a precomputed M x M matrix: same flops, no dependence on C, no trip of A / C /
-// Abar through HBM as k-major matrices).  Outputs: A and P point-major (for the products contracted over points: the
-// SYRK W = A diag(g_v) A' and the kernel-gradient reductions), g_mu, g_v, and five per-strip sums.
+// GRAD: the value-and-gradient form (svgp_elbo_grad).  Phase 1 as in the forward build, then - INSTEAD of phase 2 -
+//   phase 3:  R A,   R = Lk^-T (Lq Lq' - I)   (ONE dense Mp x Mp GEMM on the A strip that is still in its scratch strip: the
+//             adjoint's two triangular products Lq (Lq'A) - A and Lk' \ . folded into a precomputed M x M matrix)
+// whose epilogue also yields the variance, v_j - k(x_j, x_j) = k_j' (R A)_j (the Kuf block keeps its own scratch strip for
+// it): 3 GEMM units per point in this kernel instead of 4.  Then the likelihood gradients (g_mu, g_v) = scale dE/d(mu, v).
+// Outputs: A and R A point-major (for the products contracted over points: the SYRK W = A diag(2 g_v) A' and the
+// kernel-gradient reductions, which form P = Kuf_bar = alpha g_mu' + 2 (R A) diag(g_v) themselves), g_mu, g_v, and five
+// per-strip sums.
 template <typename T, int NT, int BK, int NTHR, int MINW = 2, int PAD = 16, bool GRAD = false, bool EXT = false>
 __global__ void __launch_bounds__(NTHR, MINW) strip_kernel(StripArgs a, int64_t nstrips) {
   using G = TileGemm<T, NT, BK, NTHR, PAD>;
