@@ -940,9 +940,22 @@ int grad_workspace(svgp_ctx* ctx, svgp_model* m, int64_t len, GradWs** out) {
   if (!w) return SVGP_OOM;
   w->dtype = m->dtype; w->Mp = Mp; w->d = m->d; w->nc = nc;
   const int nP = int(Mp / 128), ntiles = nP * (nP + 1) / 2;
-  int ns = (2 * ctx->num_cus) / ntiles;   // tiles x slices just under two workgroups' worth per CU: no ragged tail
-  static const int ns_cap = [] { const char* e = getenv("SVGP_GEMM_PM_SLICES_CAP"); return e ? atoi(e) : 64; }();   // tuning knob
-  w->nslices = ns < 1 ? 1 : (ns > ns_cap ? ns_cap : ns);   // (a cap of 16 left C2 - 10 tiles - with 320 workgroups for 512 slots)
+  // Split-K slices of the SYRK: work items = tiles (f64: two 128 x 64 halves each) x slices over 2 workgroup slots per CU.  The
+  // smallest count whose last round of slots is >= 97 % full, else the fullest (H: 72 items, 7 slices = 504 of 512; C3: 136 items,
+  // 11 slices = 1496 of 1536 - the round-2 rule floor(512 / tiles) left C3 with 408 of 512: 175 -> 164 ms), within 2 GiB of slice
+  // buffer and >= 512 points per slice.  Placing the items of a slice on one XCD (they read the same rows of A) was measured
+  // and rejected: H 81.9 -> 85-87 ms - the operand re-reads come out of the Infinity Cache at no cost to the MFMA pipe.
+  static const int ns_forced = [] { const char* e = getenv("SVGP_GEMM_PM_SLICES"); return e ? atoi(e) : 0; }();   // tuning knob
+  const int items = ntiles * (m->dtype == SVGP_F64 ? 2 : 1), slots = 2 * ctx->num_cus;
+  int ns = 1;
+  double best = 0.0;
+  for (int c = 1; c <= 64; ++c) {
+    if (c > 1 && (size_t(c) * size_t(Mp) * size_t(Mp) * es > (size_t(2) << 30) || nc / c < 512)) break;
+    const double wg = double(items) * c, eff = wg / (std::ceil(wg / slots) * slots);
+    if (eff > best + 1e-9) { best = eff; ns = c; }
+    if (eff >= 0.97) break;
+  }
+  w->nslices = ns_forced > 0 ? ns_forced : ns;
   w->rb = grad_rowblocks(m->d, Mp);
   static const int kg_wg = [] { const char* e = getenv("SVGP_KGRAD_WG_PER_CU"); return e ? atoi(e) : 2; }();   // tuning knob
   int nu = (kg_wg * ctx->num_cus + w->rb - 1) / w->rb;
@@ -958,7 +971,7 @@ int grad_workspace(svgp_ctx* ctx, svgp_model* m, int64_t len, GradWs** out) {
   // [sums .. info] is the ONE fp64 read-back of an evaluation
   w->zero_b = w->rp_uf_b + w->sp_uf_b + w->rp_uu_b + w->sp_uu_b + size_t(8 + 1 + dreg + 5) * 8;
   struct { void** p; size_t b; } req[] = {
-      {&w->At, mn}, {&w->Pt, mn}, {&w->gmu, 2 * size_t(nc) * es},   // g_mu | g_v contiguous: one memset per chunk
+      {&w->At, mn}, {&w->Pt, mn}, {&w->gmu, 2 * size_t(nc) * es + 256},   // g_mu | g_v contiguous: one memset per chunk (+ the SYRK's weight DMA reads 256 B at a time)
       {&w->Lqp, mm}, {&w->G1, w->g_b}, {&w->G2, mm}, {&w->LkRM, mm},
       {&w->LbarRM, mm}, {&w->Phi, mm}, {&w->tmp, mm}, {&w->H, mm}, {&w->LinvRM, mm}, {&w->LinvCM, mm},
       // the user-layout blocks hold M d + M + M^2 elements; sized by Mp because the workspace is reused for every model of the
@@ -1153,7 +1166,7 @@ int grad_enqueue(svgp_ctx* ctx, svgp_model* m, const svgp_data* data, int64_t of
     KCHECK(ctx, "kgrad uf");
     if (kg_overlap) HIPC(ctx, hipEventRecord(ctx->ev_join, sk));
     launch_sum5(s, w->partial5, int(nstrips), w->sums);
-    int64_t sl = ((ncp + w->nslices - 1) / w->nslices + 127) / 128 * 128;
+    int64_t sl = ((ncp + w->nslices - 1) / w->nslices + 15) / 16 * 16;   // as even as the 16-point k-step allows
     // W (+)= A diag(2 g_v) A' (lower tiles, split-K slices): the first chunk overwrites, so the slice buffer needs no zeroing
     launch_gemm_pm(dt, s, w->At, w->At, w->gv, 2.0, Mp, ncp, sl, w->nslices, w->G1, c0 == 0 ? 1 : 0);
     KCHECK(ctx, "syrk");

@@ -6,6 +6,7 @@
 //   * the stationary kernel functions of KernelFunctions.jl (SE, Matern-3/2, Matern-5/2).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include <stdint.h>
 
 #include <mutex>
@@ -506,6 +507,11 @@ struct TileGemm {
   static constexpr int DP = kPairP ? (BK / 2) / NW : BK / NW;   // P instructions per wave and tile
   static constexpr int DMA_PER_TILE = DP + DQ;              // DMA instructions per wave and tile
   static constexpr size_t ASYNC_LDS_BYTES = size_t(NBUF) * (PA_TILE + QA_TILE) * sizeof(T);
+  // Optional per-k weights (the SYRK W = A diag(w) A'): the 16 weights of a tile travel by the same DMA path (one
+  // global_load_lds_dword per wave and tile: 256 B, of which the first 16 weights are the tile's; every wave issues it, to the
+  // same slot, so that all waves count the same number of DMAs per tile) and scale the Q fragments as they are read.
+  static constexpr int W_TILE = 256 / int(sizeof(T));   // elements of one weight slot
+  static constexpr size_t ASYNC_W_LDS_BYTES = ASYNC_LDS_BYTES + size_t(NBUF) * 256;
   // dynamic LDS a kernel that may take either loop has to ask for
   static constexpr size_t MAX_LDS_BYTES = (kAsync && ASYNC_LDS_BYTES > LDS_BYTES) ? ASYNC_LDS_BYTES : LDS_BYTES;
 
@@ -538,6 +544,11 @@ struct TileGemm {
 #pragma unroll
     for (int q = 0; q < DQ; ++q) glds16(qsrc, off.q[q], Qb + (wv + q * NW) * QPP);
 #endif
+  }
+  static __device__ __forceinline__ void dma_w(const T* __restrict__ wsrc, T* __restrict__ Wb) {
+    const uint32_t l = uint32_t(uintptr_t((__attribute__((address_space(3))) T*)(Wb)));
+    const uint32_t voff = (threadIdx.x & 63) * 4;
+    asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dword %1, %2" ::"s"(l), "v"(voff), "s"(wsrc) : "memory");
   }
   // all but the wave's N newest vector-memory operations done, every LDS read returned, then the workgroup barrier
   template <int N>
@@ -576,53 +587,90 @@ struct TileGemm {
       }
     }
   }
-  // one k-step on tile t (buffer b, advanced on return); QSrc: t -> wave-uniform pointer to the contiguous Q tile of step t
-  template <int ILO, int IHI, typename QSrc>
+  // one k-step on tile t (buffer b, advanced on return); QSrc: t -> wave-uniform pointer to the contiguous Q tile of step t;
+  // WSrc: NoWeights, or t -> wave-uniform pointer to the 16 weights of step t (>= 64 dwords readable behind it)
+  struct NoWeights { static constexpr bool on = false; __device__ __forceinline__ const T* operator()(int) const { return nullptr; } };
+  template <int KSLAB, bool W>
+  static __device__ __forceinline__ void scale_b(Frag& f, const T* __restrict__ wl) {
+    if constexpr (W) {
+      const T wk = wl[KSLAB * 4];
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) f.b[j] *= wk;
+    }
+  }
+  template <int ILO, int IHI, typename QSrc, typename WSrc>
   static __device__ __forceinline__ void astep(Acc& acc, Frag (&f)[2], const T* __restrict__ Pbase, int64_t pstride,
-                                               const AOff& off, int t, int nsteps, QSrc& qsrc, T* __restrict__ smem,
+                                               const AOff& off, int t, int nsteps, QSrc& qsrc, WSrc& wsrc, T* __restrict__ smem,
                                                int& b, const AFrag& fr) {
     constexpr int KS = BK / 4;
+    constexpr bool W = WSrc::on;
+    constexpr int PER_TILE = DMA_PER_TILE + (W ? 1 : 0);
     static_assert(KS == 4, "written for 16-deep steps");
     const T* fa = fr.a + b * PA_TILE;
     const T* fb0 = fr.b0 + b * QA_TILE;
     const T* fb1 = fr.b1 + b * QA_TILE;
+    T* Ws = smem + NBUF * (PA_TILE + QA_TILE);
+    const T* wl = Ws + b * W_TILE + ((threadIdx.x & 63) >> 4);   // this lane's k-row of slab 0
     load_afrag<1, ILO, IHI>(f[1], fa, fb0, fb1);
     mma_frag<ILO, IHI>(acc, f[0]);
+    scale_b<1, W>(f[1], wl);
     load_afrag<2, ILO, IHI>(f[0], fa, fb0, fb1);
     mma_frag<ILO, IHI>(acc, f[1]);
+    scale_b<2, W>(f[0], wl);
     load_afrag<3, ILO, IHI>(f[1], fa, fb0, fb1);
     mma_frag<ILO, IHI>(acc, f[0]);
+    scale_b<3, W>(f[1], wl);
     if (t + 1 < nsteps) {
       // tile t + 1 must be in LDS for every wave: of this wave's DMAs only the newest group (tile t + 2) may still fly
-      if (t + 2 < nsteps) wait_barrier<DMA_PER_TILE>();
+      if (t + 2 < nsteps) wait_barrier<PER_TILE>();
       else wait_barrier<0>();
       const int bn = (b + 1 == NBUF) ? 0 : b + 1;
       load_afrag<0>(f[0], fr.a + bn * PA_TILE, fr.b0 + bn * QA_TILE, fr.b1 + bn * QA_TILE);   // all tiles: next range unknown here
-      if (t + 3 < nsteps)   // buffer b (tile t) is free now
+      scale_b<0, W>(f[0], Ws + bn * W_TILE + ((threadIdx.x & 63) >> 4));
+      if (t + 3 < nsteps) {   // buffer b (tile t) is free now
         dma_tile(Pbase + int64_t(t + 3) * pstride, qsrc(t + 3), off, smem + b * PA_TILE, smem + NBUF * PA_TILE + b * QA_TILE);
+        if constexpr (W) dma_w(wsrc(t + 3), Ws + b * W_TILE);
+      }
       b = bn;
     }
     mma_frag<ILO, IHI>(acc, f[1]);
   }
-#define SVGP_ASTEP(LO, HI, TT) astep<LO, HI>(acc, f, Pbase, pstride, off, (TT), nsteps, qsrc, smem, b, fr)
+#define SVGP_ASTEP(LO, HI, TT) astep<LO, HI>(acc, f, Pbase, pstride, off, (TT), nsteps, qsrc, wsrc, smem, b, fr)
   template <int TRI, typename QSrc>
   static __device__ __forceinline__ void loop_tri_async(Acc& acc, const T* __restrict__ Pbase, int64_t ldp, int nsteps,
                                                         QSrc&& qsrc, T* __restrict__ smem, int64_t ldq = NT) {
+    NoWeights nw;
+    loop_tri_async_w<TRI>(acc, Pbase, ldp, nsteps, qsrc, nw, smem, ldq);
+  }
+  template <int TRI, typename QSrc, typename WSrc>
+  static __device__ __forceinline__ void loop_tri_async_w(Acc& acc, const T* __restrict__ Pbase, int64_t ldp, int nsteps,
+                                                          QSrc&& qsrc, WSrc&& wsrc, T* __restrict__ smem, int64_t ldq = NT) {
     if (nsteps <= 0) return;
     constexpr int ND = NB / BK;
+    constexpr bool W = std::remove_reference_t<WSrc>::on;
+    constexpr int PER_TILE = DMA_PER_TILE + (W ? 1 : 0);
     static_assert(TRI == 0 || (ND == 8 && MI == 4), "triangular steps are written out for BK = 16, 128-row panels");
     const AOff off = a_offsets(ldp, ldq);
     const int64_t pstride = int64_t(BK) * ldp;
     const AFrag fr = afrag(smem);
     T* Qs = smem + NBUF * PA_TILE;
+    T* Ws = smem + NBUF * (PA_TILE + QA_TILE);
     dma_tile(Pbase, qsrc(0), off, smem, Qs);
-    if (nsteps > 1) dma_tile(Pbase + pstride, qsrc(1), off, smem + PA_TILE, Qs + QA_TILE);
-    if (nsteps > 2) dma_tile(Pbase + 2 * pstride, qsrc(2), off, smem + 2 * PA_TILE, Qs + 2 * QA_TILE);
-    if (nsteps > 2) wait_barrier<2 * DMA_PER_TILE>();
-    else if (nsteps > 1) wait_barrier<DMA_PER_TILE>();
+    if constexpr (W) dma_w(wsrc(0), Ws);
+    if (nsteps > 1) {
+      dma_tile(Pbase + pstride, qsrc(1), off, smem + PA_TILE, Qs + QA_TILE);
+      if constexpr (W) dma_w(wsrc(1), Ws + W_TILE);
+    }
+    if (nsteps > 2) {
+      dma_tile(Pbase + 2 * pstride, qsrc(2), off, smem + 2 * PA_TILE, Qs + 2 * QA_TILE);
+      if constexpr (W) dma_w(wsrc(2), Ws + 2 * W_TILE);
+    }
+    if (nsteps > 2) wait_barrier<2 * PER_TILE>();
+    else if (nsteps > 1) wait_barrier<PER_TILE>();
     else wait_barrier<0>();
     Frag f[2];
     load_afrag<0>(f[0], fr.a, fr.b0, fr.b1);
+    scale_b<0, W>(f[0], Ws + ((threadIdx.x & 63) >> 4));
     int b = 0, t = 0;
     if (TRI < 0) {
       SVGP_ASTEP(0, 0, 0); SVGP_ASTEP(0, 0, 1); SVGP_ASTEP(0, 1, 2); SVGP_ASTEP(0, 1, 3);
@@ -630,7 +678,7 @@ struct TileGemm {
       t = ND;
     }
     const int nreg = (TRI > 0) ? nsteps - ND : nsteps;
-    for (; t < nreg; ++t) astep<0, MI - 1>(acc, f, Pbase, pstride, off, t, nsteps, qsrc, smem, b, fr);
+    for (; t < nreg; ++t) astep<0, MI - 1>(acc, f, Pbase, pstride, off, t, nsteps, qsrc, wsrc, smem, b, fr);
     if (TRI > 0) {
       SVGP_ASTEP(0, 3, nreg + 0); SVGP_ASTEP(0, 3, nreg + 1); SVGP_ASTEP(1, 3, nreg + 2); SVGP_ASTEP(1, 3, nreg + 3);
       SVGP_ASTEP(2, 3, nreg + 4); SVGP_ASTEP(2, 3, nreg + 5); SVGP_ASTEP(3, 3, nreg + 6); SVGP_ASTEP(3, 3, nreg + 7);

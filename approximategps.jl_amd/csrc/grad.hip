@@ -134,8 +134,9 @@ __global__ void __launch_bounds__(NTHR, 2) gemm_pm_kernel(const T* __restrict__ 
   constexpr int NCH = kNB / NT;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   T* smem = reinterpret_cast<T*>(smem_raw);
-  const int chunk = blockIdx.x % NCH;
-  int ti = 0, tj, b = blockIdx.x / NCH;
+  const int item = blockIdx.x, slice = blockIdx.y;   // work item = (tile, K slice)
+  const int chunk = item % NCH;
+  int ti = 0, tj, b = item / NCH;
   if (flags & kMmFull) {
     const int nP = int(Mp / kNB);
     ti = b / nP;
@@ -144,7 +145,7 @@ __global__ void __launch_bounds__(NTHR, 2) gemm_pm_kernel(const T* __restrict__ 
     while (b >= ti + 1) { b -= ti + 1; ++ti; }
     tj = b;
   }
-  int64_t i0 = int64_t(blockIdx.y) * slice_len;
+  int64_t i0 = int64_t(slice) * slice_len;
   int64_t i1 = i0 + slice_len;
   i1 = i1 < n ? i1 : n;
   if (flags & (kMmXLow | kMmYLow | kMmXUp | kMmYUp)) {
@@ -176,7 +177,7 @@ __global__ void __launch_bounds__(NTHR, 2) gemm_pm_kernel(const T* __restrict__ 
     };
     G::loop(acc, Xt + i0 * Mp + int64_t(ti) * kNB, Mp, int((i1 - i0) / 16), qload, smem);
   }
-  T* o = out + int64_t(blockIdx.y) * Mp * Mp + int64_t(ti) * kNB * Mp + int64_t(tj) * kNB + chunk * NT;
+  T* o = out + int64_t(slice) * Mp * Mp + int64_t(ti) * kNB * Mp + int64_t(tj) * kNB + chunk * NT;
 #pragma unroll
   for (int i = 0; i < G::MI; ++i)
 #pragma unroll
@@ -185,6 +186,52 @@ __global__ void __launch_bounds__(NTHR, 2) gemm_pm_kernel(const T* __restrict__ 
       for (int j = 0; j < G::NJ; ++j) {
         T* e = o + int64_t(G::acc_row(i, r)) * Mp + G::acc_col(j);
         *e = overwrite ? acc.v[i][j][r] : *e + acc.v[i][j][r];
+      }
+}
+
+template <typename T>
+struct StepWeights {   // the 16 weights of k-step t
+  static constexpr bool on = true;
+  const T* w0;
+  __device__ __forceinline__ const T* operator()(int t) const { return w0 + t * 16; }
+};
+// The data-sized SYRK on the fully asynchronous loop (device_common.hpp: loop_tri_async_w; round 3): both operand tiles and
+// the 16 weights of a step travel global -> LDS by DMA through three buffers, the weights scale the Q fragments as they are
+// read (2 v_mul per 8 MFMAs in f64).  Same work items, same partial sums layout as gemm_pm_kernel; lower tiles only.
+template <typename T, int NT>
+__global__ void __launch_bounds__(k256, 2) syrk_async_kernel(const T* __restrict__ At, const T* __restrict__ w, T wscale, int64_t Mp, int64_t n,
+                                                             int64_t slice_len, T* __restrict__ out, int overwrite) {
+  using G = TileGemm<T, NT, 16, k256>;
+  static_assert(G::kAsync, "tile shape without an asynchronous loop");
+  constexpr int NCH = kNB / NT;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  T* smem = reinterpret_cast<T*>(smem_raw);
+  const int chunk = blockIdx.x % NCH;
+  int ti = 0, tj, b = blockIdx.x / NCH;
+  while (b >= ti + 1) { b -= ti + 1; ++ti; }
+  tj = b;
+  const int64_t i0 = int64_t(blockIdx.y) * slice_len;
+  int64_t i1 = i0 + slice_len;
+  i1 = i1 < n ? i1 : n;
+  typename G::Acc acc;
+  acc.zero();
+  if (i1 > i0) {
+    const T* yq = At + i0 * Mp + int64_t(tj) * kNB + chunk * NT;
+    const T* w0 = w + i0;
+    auto qsrc = [&](int t) { return yq + int64_t(t) * 16 * Mp; };
+    StepWeights<T> wsrc{w0};
+    G::template loop_tri_async_w<0>(acc, At + i0 * Mp + int64_t(ti) * kNB, Mp, int((i1 - i0) / 16), qsrc, wsrc, smem, Mp);
+  }
+  T* o = out + int64_t(blockIdx.y) * Mp * Mp + int64_t(ti) * kNB * Mp + int64_t(tj) * kNB + chunk * NT;
+#pragma unroll
+  for (int i = 0; i < G::MI; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int j = 0; j < G::NJ; ++j) {
+        T* e = o + int64_t(G::acc_row(i, r)) * Mp + G::acc_col(j);
+        const T v = wscale * acc.v[i][j][r];   // (the gradient's factor 2: exact)
+        *e = overwrite ? v : *e + v;
       }
 }
 
@@ -688,6 +735,19 @@ void launch_gemm_pm(int dtype, hipStream_t s, const void* Xt, const void* Yt, co
   // f64: 128 x 64 halves on 256-thread workgroups (same-box: H value-and-gradient 141.0 -> 138.4 ms); f32: no difference
   static const int forced = [] { const char* e = getenv("SVGP_GEMM_PM_NT"); return e ? atoi(e) : 0; }();   // tuning knob
   const int nt = forced ? forced : (dtype == 0 ? 64 : 128);
+  // the weighted SYRK of the gradient (Xt == Yt, weights 2 g_v folded by the caller into w): asynchronous loop (knob)
+  static const int async_knob = [] { const char* e = getenv("SVGP_SYRK_ASYNC"); return e ? atoi(e) : 1; }();
+  if (async_knob && w && Xt == Yt && flags == 0 && !forced) {
+    GD(dtype, T, {
+      constexpr int NT = sizeof(T) == 8 ? 64 : 128;
+      using G = TileGemm<T, NT, 16, k256>;
+      auto kern = syrk_async_kernel<T, NT>;
+      set_max_lds(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, int(G::ASYNC_W_LDS_BYTES));
+      hipLaunchKernelGGL(kern, dim3((unsigned)(ntiles * (kNB / NT)), (unsigned)nslices), dim3(k256), G::ASYNC_W_LDS_BYTES, s,
+                         (const T*)Xt, (const T*)w, T(wscale), Mp, n, slice_len, (T*)out, overwrite);
+    });
+    return;
+  }
   GD(dtype, T, {
     if (nt == 64) {
       using G = TileGemm<T, 64, 16, k256>;
