@@ -1142,6 +1142,10 @@ int grad_enqueue(svgp_ctx* ctx, svgp_model* m, const svgp_data* data, int64_t of
     // from A beside P as before (same-box three-way A/B, ms, value-and-gradient: H 97.8 -> 95.4 with the kgrad prefetch alone,
     // 99.0 with the in-strip form; H32 53.6 -> 53.0 -> 52.35; C5 16.25 -> 16.2 -> 15.9; C3 208.3 -> 217.2 -> 209.6)
     const bool a_in_strips = (dt == SVGP_F32);
+    // f64, round 3: kgrad evaluates the kernel anyway, so it sums Kuf g_mu and the tail applies Lk^-1 (one gemv with the explicit
+    // inverse): A is then read by the SYRK only, and kgrad streams half the bytes (0.32 -> 0.2 ms per 65 536-point chunk at M = 1024)
+    static const int afk_knob = [] { const char* e = getenv("SVGP_A_FROM_K"); return e ? atoi(e) : 1; }();   // A/B knob
+    const bool a_from_k = !a_in_strips && afk_knob;
     a.part5 = w->partial5; a.apart = a_in_strips ? w->apart : nullptr; a.lp = lpc; a.scale = scale; a.n_global_dev = n_global_dev; a.num_data = gc.num_data;
     HIPC(ctx, hipMemsetAsync(ctx->counter, 0, sizeof(unsigned), s));
     launch_strip_grad(dt, s, a, nt, grid, nstrips);
@@ -1161,8 +1165,8 @@ int grad_enqueue(svgp_ctx* ctx, svgp_model* m, const svgp_data* data, int64_t of
     }
     int64_t ksl = ((clen + w->ns_uf - 1) / w->ns_uf + 127) / 128 * 128;
     if (a_in_strips) launch_apart_reduce(sk, w->apart, int(nstrips), Mp, w->rp_uf + Mp);   // slot 1 of slice 0 of rp_uf
-    launch_kgrad(dt, sk, kp, m->zs, Mp, data->x, data->ldx, off + c0, 0, clen, clen, w->Pt, a_in_strips ? nullptr : w->At,
-                 w->gmu, w->gv, w->alpha, ksl, w->ns_uf, w->rp_uf, w->sp_uf);
+    launch_kgrad(dt, sk, kp, m->zs, Mp, data->x, data->ldx, off + c0, 0, clen, clen, w->Pt, (a_in_strips || a_from_k) ? nullptr : w->At,
+                 w->gmu, w->gv, w->alpha, ksl, w->ns_uf, w->rp_uf, w->sp_uf, a_from_k ? 1 : 0);
     KCHECK(ctx, "kgrad uf");
     if (kg_overlap) HIPC(ctx, hipEventRecord(ctx->ev_join, sk));
     launch_sum5(s, w->partial5, int(nstrips), w->sums);
@@ -1180,13 +1184,18 @@ int grad_enqueue(svgp_ctx* ctx, svgp_model* m, const svgp_data* data, int64_t of
   gemm_mm(ctx, w, dt, s, w->W2, m->U, Mp, w->G1p, kMmYLow);   // (W B)[r][c] = sum_i W[i][r] B[i][c]; B[i][c] = 0 for i < c
   gemm_mm(ctx, w, dt, s, w->Rcm, w->W2, Mp, w->G2);           // (R W)[r][c] = sum_i R[r][i] W[i][c]
   launch_avec(s, w->rp_uf, w->ns_uf, int64_t(2 + dreg) * Mp, Mp, w->avec);
+  {
+    static const int afk_knob = [] { const char* e = getenv("SVGP_A_FROM_K"); return e ? atoi(e) : 1; }();
+    if (dt == SVGP_F64 && afk_knob)   // avec holds Kuf g_mu: A g_mu = Lk^-1 (Kuf g_mu)
+      launch_linv_t_gemv(dt, s, w->LinvCM, w->avec, Mp, w->avec, w->gemv_part, 1);
+  }
   launch_finish_mm2(dt, s, w->G1p, w->G2, w->alpha, w->avec, Mp, M, centered ? m->B : m->Lq_raw, centered ? Mp : M, klw, w->Lqbar,
                     centered ? w->BbarRM : nullptr, w->LbarRM);
   KCHECK(ctx, "Lq_bar / Lk_bar");
   if (centered) {
     // chain through m~ = Lk \ (m - c) and B = Lk \ Lq:  m_bar = Lk^-T m~_bar,  Rb = Lk^-T B_bar,  Lq_bar = tril(Rb),
     // Lk_bar -= tril(m_bar m~') + tril(Rb B')
-    launch_mbar(dt, s, w->rp_uf, w->ns_uf, int64_t(2 + dreg) * Mp, m->mp, klw, M, Mp, w->rbar);
+    launch_mbar(dt, s, w->avec, m->mp, klw, M, Mp, w->rbar);
     launch_linv_t_gemv(dt, s, w->LinvRM, w->rbar, Mp, w->alpha, w->gemv_part);   // alpha is free after finish_mm2: holds m_bar (padded)
     HIPC(ctx, hipMemcpyAsync(w->mbar, w->alpha, size_t(M) * es, hipMemcpyDeviceToDevice, s));
     // out[c][r] = sum_i B_bar[i][c] Linv[i][r] = Rb[r][c]: Rb column-major = the k-major operand of Rb B' below
@@ -1210,7 +1219,7 @@ int grad_enqueue(svgp_ctx* ctx, svgp_model* m, const svgp_data* data, int64_t of
   launch_kgrad(dt, s, kp, m->zs, Mp, m->zs, Mp, 0, 1, M, M, w->H, nullptr, nullptr, nullptr, nullptr, uu_sl, w->ns_uu, w->rp_uu, w->sp_uu);
   launch_finish_kgrad(dt, s, m->d, M, Mp, m->zs, w->invl_d, w->rp_uf, w->ns_uf, w->rp_uu, w->ns_uu, w->sp_uf, w->ns_uf * w->rb,
                       w->sp_uu, w->ns_uu * w->rb, m->mp, klw, m->desc.layout_z, m->desc.variance, w->zbar, centered ? nullptr : w->mbar,
-                      w->scal_out, w->kred);
+                      w->scal_out, w->kred, w->avec);
   // status slots of the all-reduced scalars + this rank's prep scalars / info behind them: ONE fp64 read-back per evaluation
   launch_grad_status(s, w->sums, m->info, double(len), m->scal, w->scal_out + 1 + dreg);
   KCHECK(ctx, "kgrad uu / finish");

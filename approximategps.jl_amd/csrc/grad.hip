@@ -317,16 +317,17 @@ __global__ void __launch_bounds__(k256, 2) linv_step_kernel(const T* __restrict_
 // all k per thread ran at the L2 latency: 88 us at M = 1024.)
 template <typename T>
 __global__ void __launch_bounds__(k256) linv_t_gemv_kernel(const T* __restrict__ LinvRM, const T* __restrict__ v, int64_t Mp,
-                                                           double* __restrict__ part) {
+                                                           double* __restrict__ part, int notrans) {
+  // notrans: the same sum over the COLUMN-major copy, restricted to k <= r:  out[r] = sum_{k <= r} Linv[r][k] v[k] = (Lk^-1 v)_r
   __shared__ double sh[4][64];
   const int rl = threadIdx.x & 63, g = threadIdx.x >> 6;
   const int64_t r = int64_t(blockIdx.x) * 64 + rl, k0 = int64_t(blockIdx.y) * kNB;
   double acc = 0.0;
-  if (k0 + kNB > int64_t(blockIdx.x) * 64) {   // panels wholly above the diagonal contribute nothing
+  if (notrans ? (k0 < int64_t(blockIdx.x + 1) * 64) : (k0 + kNB > int64_t(blockIdx.x) * 64)) {   // panels wholly on the zero side contribute nothing
 #pragma unroll 8
     for (int kk = g; kk < kNB; kk += 4) {
       const int64_t k = k0 + kk;
-      const double a = (k >= r) ? double(LinvRM[k * Mp + r]) : 0.0;
+      const double a = (notrans ? k <= r : k >= r) ? double(LinvRM[k * Mp + r]) : 0.0;
       acc = fma(a, double(v[k]), acc);
     }
   }
@@ -372,7 +373,7 @@ __global__ void __launch_bounds__(k256) kgrad_kernel(KernelParams kp, const T* _
                                                      int64_t n, int64_t nvalid, const T* __restrict__ Pt,
                                                      const T* __restrict__ At, const T* __restrict__ gmu, const T* __restrict__ gv,
                                                      const T* __restrict__ alpha, int64_t slice_len,
-                                                     double* __restrict__ rowpart, double* __restrict__ scalpart) {
+                                                     double* __restrict__ rowpart, double* __restrict__ scalpart, int kmb) {
   constexpr int JB = 128;
   __shared__ T xt[JB * DREG];
   __shared__ T gms[JB], gvs[JB];   // g_mu and 2 g_v of the staged points (1 where P is given as it is): staged with x, read as broadcasts
@@ -425,7 +426,10 @@ __global__ void __launch_bounds__(k256) kgrad_kernel(KernelParams kp, const T* _
     // U points of this wave in flight at a time: the kernel streams P (and A) once from HBM with ONE 1 KiB load per point
     // and wave, and with a single load outstanding per wave it ran at the memory latency (350 us per 65 536-point chunk in
     // f64 AND in fp32: 5-6 ms of a value-and-gradient evaluation)
-    constexpr int U = 4;
+#ifndef SVGP_KGRAD_U
+#define SVGP_KGRAD_U 4
+#endif
+    constexpr int U = SVGP_KGRAD_U;
     for (int c0w = wave; c0w < JB && jb + c0w < j1; c0w += 4 * U) {
       T pv[U][KV], av[U][KV], gmv[U], gvv[U];
 #pragma unroll
@@ -465,7 +469,8 @@ __global__ void __launch_bounds__(k256) kgrad_kernel(KernelParams kp, const T* _
           const double W = double(p) * double(dk);
           S1 += double(p) * double(k);
           R[e] += W;
-          if (At) MB[e] += double(av[u][e]) * double(gmv[u]);   // (A g_mu)_i, f64 builds
+          if (At) MB[e] += double(av[u][e]) * double(gmv[u]);   // (A g_mu)_i from A
+          else if (kmb) MB[e] += double(k) * double(gmv[u]);    // (Kuf g_mu)_i: the caller applies Lk^-1 (f64: A is not read at all)
 #pragma unroll
           for (int f = 0; f < DREG; ++f) {
             Q[f][e] += W * double(xt[c * DREG + f]);
@@ -540,18 +545,13 @@ __global__ void phi_kernel(T* __restrict__ X, int64_t Mp) {
 }
 
 // Centered chain rule helpers ------------------------------------------------------------------------------
-// vec[i] = sum_slices rowpart[s][1][i] - mtilde[i]   (adjoint of the whitened mean), zero padded
+// vec[i] = avec[i] - mtilde[i]   (adjoint of the whitened mean; avec = A g_mu), zero padded
 template <typename T>
-__global__ void mbar_kernel(const double* __restrict__ rp_uf, int ns, int64_t stride, const T* __restrict__ mt, double klw,
-                            int64_t M, int64_t Mp, T* __restrict__ vec) {
+__global__ void mbar_kernel(const double* __restrict__ avec, const T* __restrict__ mt, double klw, int64_t M, int64_t Mp,
+                            T* __restrict__ vec) {
   const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
   if (i >= Mp) return;
-  double s = 0.0;
-  if (i < M) {
-    for (int q = 0; q < ns; ++q) s += rp_uf[q * stride + Mp + i];
-    s -= klw * double(mt[i]);
-  }
-  vec[i] = T(s);
+  vec[i] = (i < M) ? T(avec[i] - klw * double(mt[i])) : T(0);
 }
 
 // LkbarRM[r][c] -= (R B')[r][c] + rbar[r] mtilde[c]  for c <= r
@@ -616,12 +616,12 @@ template <typename T>
 __global__ void finish_kgrad_kernel(int d, int64_t M, int64_t Mp, const T* __restrict__ zs, const double* __restrict__ invl,
                                     const double* __restrict__ red, const double* __restrict__ red_s, const T* __restrict__ m,
                                     double klw, int layout_z, double variance, T* __restrict__ z_bar, T* __restrict__ m_bar,
-                                    double* __restrict__ scal_out) {
+                                    double* __restrict__ scal_out, const double* __restrict__ avec) {
   // scal_out[0] = (sum P K (uf) + sum H K (uu)) / variance, scal_out[1 + f] = il_bar_f
   const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
   if (i < M) {
     const double R = red[i];
-    if (m_bar) m_bar[i] = T(red[Mp + i] - klw * double(m[i]));   // klw * d KL / d m
+    if (m_bar) m_bar[i] = T(avec[i] - klw * double(m[i]));   // A g_mu - klw * d KL / d m
     for (int f = 0; f < d; ++f) {
       const double zf = double(zs[int64_t(f) * Mp + i]);
       const double g = 2.0 * invl[f] * (zf * R - red[(2 + f) * Mp + i]);
@@ -638,23 +638,23 @@ __global__ void finish_kgrad_kernel(int d, int64_t M, int64_t Mp, const T* __res
 template <typename T, int FAMILY>
 void launch_kgrad_f(hipStream_t s, const KernelParams& kp, const T* zs, int64_t Mp, const T* x, int64_t ldx, int64_t xoff,
                     int prescaled, int64_t n, int64_t nvalid, const T* Pt, const T* At, const T* gmu, const T* gv, const T* alpha,
-                    int64_t slice_len, int nslices, double* rowpart, double* scalpart) {
+                    int64_t slice_len, int nslices, double* rowpart, double* scalpart, int kmb) {
   if (kp.d <= 8) {
     dim3 grid((unsigned)nslices, (unsigned)(Mp / 128));
     hipLaunchKernelGGL((kgrad_kernel<T, 8, 2, FAMILY>), grid, dim3(k256), 0, s, kp, zs, Mp, x, ldx, xoff, prescaled, n, nvalid, Pt,
-                       At, gmu, gv, alpha, slice_len, rowpart, scalpart);
+                       At, gmu, gv, alpha, slice_len, rowpart, scalpart, kmb);
   } else if (kp.d <= 16) {
     dim3 grid((unsigned)nslices, (unsigned)(Mp / 128));
     hipLaunchKernelGGL((kgrad_kernel<T, 16, 2, FAMILY>), grid, dim3(k256), 0, s, kp, zs, Mp, x, ldx, xoff, prescaled, n, nvalid,
-                       Pt, At, gmu, gv, alpha, slice_len, rowpart, scalpart);
+                       Pt, At, gmu, gv, alpha, slice_len, rowpart, scalpart, kmb);
   } else if (kp.d <= 32) {
     dim3 grid((unsigned)nslices, (unsigned)(Mp / 64));
     hipLaunchKernelGGL((kgrad_kernel<T, 32, 1, FAMILY>), grid, dim3(k256), 0, s, kp, zs, Mp, x, ldx, xoff, prescaled, n, nvalid,
-                       Pt, At, gmu, gv, alpha, slice_len, rowpart, scalpart);
+                       Pt, At, gmu, gv, alpha, slice_len, rowpart, scalpart, kmb);
   } else {   // 32 < d <= 64 (SVGP_MAX_D): the same kernel with 64 feature slots per thread - it spills, and is correct
     dim3 grid((unsigned)nslices, (unsigned)(Mp / 64));
     hipLaunchKernelGGL((kgrad_kernel<T, 64, 1, FAMILY>), grid, dim3(k256), 0, s, kp, zs, Mp, x, ldx, xoff, prescaled, n, nvalid,
-                       Pt, At, gmu, gv, alpha, slice_len, rowpart, scalpart);
+                       Pt, At, gmu, gv, alpha, slice_len, rowpart, scalpart, kmb);
   }
 }
 
@@ -721,10 +721,10 @@ void launch_linv(int dtype, hipStream_t s, const void* L, const void* Tm, int64_
   });
 }
 
-void launch_linv_t_gemv(int dtype, hipStream_t s, const void* LinvRM, const void* v, int64_t Mp, void* out, double* part) {
+void launch_linv_t_gemv(int dtype, hipStream_t s, const void* LinvRM, const void* v, int64_t Mp, void* out, double* part, int notrans) {
   const int nP = int(Mp / kNB);
   GD(dtype, T, {
-    hipLaunchKernelGGL(linv_t_gemv_kernel<T>, dim3((unsigned)(Mp / 64), (unsigned)nP), dim3(k256), 0, s, (const T*)LinvRM, (const T*)v, Mp, part);
+    hipLaunchKernelGGL(linv_t_gemv_kernel<T>, dim3((unsigned)(Mp / 64), (unsigned)nP), dim3(k256), 0, s, (const T*)LinvRM, (const T*)v, Mp, part, notrans);
     hipLaunchKernelGGL(gemv_finish_kernel<T>, dim3((unsigned)((Mp + 255) / 256)), dim3(256), 0, s, part, nP, Mp, (T*)out);
   });
 }
@@ -767,17 +767,17 @@ void launch_gemm_pm(int dtype, hipStream_t s, const void* Xt, const void* Yt, co
 
 void launch_kgrad(int dtype, hipStream_t s, const KernelParams& kp, const void* zs, int64_t Mp, const void* x, int64_t ldx,
                   int64_t xoff, int prescaled, int64_t n, int64_t nvalid, const void* Pt, const void* At, const void* gmu,
-                  const void* gv, const void* alpha, int64_t slice_len, int nslices, double* rowpart, double* scalpart) {
+                  const void* gv, const void* alpha, int64_t slice_len, int nslices, double* rowpart, double* scalpart, int kmb) {
   GD(dtype, T, {
     if (kp.family == KSE)
       launch_kgrad_f<T, KSE>(s, kp, (const T*)zs, Mp, (const T*)x, ldx, xoff, prescaled, n, nvalid, (const T*)Pt, (const T*)At,
-                             (const T*)gmu, (const T*)gv, (const T*)alpha, slice_len, nslices, rowpart, scalpart);
+                             (const T*)gmu, (const T*)gv, (const T*)alpha, slice_len, nslices, rowpart, scalpart, kmb);
     else if (kp.family == KM32)
       launch_kgrad_f<T, KM32>(s, kp, (const T*)zs, Mp, (const T*)x, ldx, xoff, prescaled, n, nvalid, (const T*)Pt, (const T*)At,
-                              (const T*)gmu, (const T*)gv, (const T*)alpha, slice_len, nslices, rowpart, scalpart);
+                              (const T*)gmu, (const T*)gv, (const T*)alpha, slice_len, nslices, rowpart, scalpart, kmb);
     else
       launch_kgrad_f<T, KM52>(s, kp, (const T*)zs, Mp, (const T*)x, ldx, xoff, prescaled, n, nvalid, (const T*)Pt, (const T*)At,
-                              (const T*)gmu, (const T*)gv, (const T*)alpha, slice_len, nslices, rowpart, scalpart);
+                              (const T*)gmu, (const T*)gv, (const T*)alpha, slice_len, nslices, rowpart, scalpart, kmb);
   });
 }
 
@@ -796,9 +796,8 @@ void launch_phi(int dtype, hipStream_t s, void* X, int64_t Mp) {
   GD(dtype, T, hipLaunchKernelGGL(phi_kernel<T>, grid, dim3(256), 0, s, (T*)X, Mp));
 }
 
-void launch_mbar(int dtype, hipStream_t s, const double* rp_uf, int ns, int64_t stride, const void* mt, double klw, int64_t M,
-                 int64_t Mp, void* vec) {
-  GD(dtype, T, hipLaunchKernelGGL(mbar_kernel<T>, dim3((unsigned)((Mp + 255) / 256)), dim3(256), 0, s, rp_uf, ns, stride,
+void launch_mbar(int dtype, hipStream_t s, const double* avec, const void* mt, double klw, int64_t M, int64_t Mp, void* vec) {
+  GD(dtype, T, hipLaunchKernelGGL(mbar_kernel<T>, dim3((unsigned)((Mp + 255) / 256)), dim3(256), 0, s, avec,
                                   (const T*)mt, klw, M, Mp, (T*)vec));
 }
 
@@ -819,14 +818,14 @@ void launch_add_f64(hipStream_t s, double* p, double v) { hipLaunchKernelGGL(add
 void launch_finish_kgrad(int dtype, hipStream_t s, int d, int64_t M, int64_t Mp, const void* zs, const double* invl,
                          const double* rp_uf, int ns_uf, const double* rp_uu, int ns_uu, const double* sp_uf, int nsp_uf,
                          const double* sp_uu, int nsp_uu, const void* m, double klw, int layout_z, double variance,
-                         void* z_bar, void* m_bar, double* scal_out, double* red) {
+                         void* z_bar, void* m_bar, double* scal_out, double* red, const double* avec) {
   const int dreg = grad_dreg(d);
   double* red_s = red + int64_t(2 + dreg) * Mp;
   hipLaunchKernelGGL(kgrad_reduce_kernel, dim3((unsigned)((Mp + 63) / 64), (unsigned)(3 + dreg)), dim3(256), 0, s, d, dreg, Mp, rp_uf,
                      ns_uf, rp_uu, ns_uu, sp_uf, nsp_uf, sp_uu, nsp_uu, red, red_s);
   dim3 grid((unsigned)((M + 255) / 256));
   GD(dtype, T, hipLaunchKernelGGL(finish_kgrad_kernel<T>, grid, dim3(256), 0, s, d, M, Mp, (const T*)zs, invl, red, red_s,
-                                  (const T*)m, klw, layout_z, variance, (T*)z_bar, (T*)m_bar, scal_out));
+                                  (const T*)m, klw, layout_z, variance, (T*)z_bar, (T*)m_bar, scal_out, avec));
 }
 
 }  // namespace svgp

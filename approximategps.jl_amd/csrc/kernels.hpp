@@ -148,12 +148,12 @@ void launch_sum_slices_lower(int dtype, hipStream_t s, const void* part, int ns,
 // the lower block triangle is written / ever read); Ytmp: Mp x Mp scratch
 void launch_linv(int dtype, hipStream_t s, const void* L, const void* Tm, int64_t Mp, void* LinvRM, void* LinvCM, void* Ytmp);
 // out = Lk^-T v = LinvRM' v; part: (Mp / 128) x Mp doubles of scratch
-void launch_linv_t_gemv(int dtype, hipStream_t s, const void* LinvRM, const void* v, int64_t Mp, void* out, double* part);
+void launch_linv_t_gemv(int dtype, hipStream_t s, const void* LinvRM, const void* v, int64_t Mp, void* out, double* part, int notrans = 0);
 // data part: Pt = the strips' unscaled R A, P_ij = alpha_i gmu_j + 2 gv_j Pt_ji formed inside (alpha != nullptr); Kuu part: Pt is
 // the matrix itself (alpha = gmu = gv = nullptr); At: (A g_mu) row sums beside it (f64 builds), else nullptr
 void launch_kgrad(int dtype, hipStream_t s, const KernelParams& kp, const void* zs, int64_t Mp, const void* x, int64_t ldx,
                   int64_t xoff, int prescaled, int64_t n, int64_t nvalid, const void* Pt, const void* At, const void* gmu,
-                  const void* gv, const void* alpha, int64_t slice_len, int nslices, double* rowpart, double* scalpart);
+                  const void* gv, const void* alpha, int64_t slice_len, int nslices, double* rowpart, double* scalpart, int kmb = 0);
 // fused gradient path: sums of the per-strip partials, W = A diag(2 g_v) A' from its split-K lower tiles, (A g_mu), and the
 // assembly of Lq_bar / Lk_bar from G1 = 2 W Lq, G2 = 2 R W and the rank-one term alpha (A g_mu)'
 void launch_sum5(hipStream_t s, const double* partial, int nblocks, double* sums);
@@ -166,14 +166,13 @@ void launch_finish_mm2(int dtype, hipStream_t s, const void* G1, const void* G2,
 void launch_lower_to_rowmajor(int dtype, hipStream_t s, const void* L, int64_t Mp, void* out);
 void launch_symmetrize(int dtype, hipStream_t s, const void* St, int64_t Mp, void* H);
 void launch_phi(int dtype, hipStream_t s, void* X, int64_t Mp);
-void launch_mbar(int dtype, hipStream_t s, const double* rp_uf, int ns, int64_t stride, const void* mt, double klw, int64_t M,
-                 int64_t Mp, void* vec);
+void launch_mbar(int dtype, hipStream_t s, const double* avec, const void* mt, double klw, int64_t M, int64_t Mp, void* vec);
 void launch_lbar_adjust(int dtype, hipStream_t s, void* LkbarRM, const void* RBt, const void* rbar, const void* mt, int64_t Mp);
 void launch_cm_tril_to_user(int dtype, hipStream_t s, const void* R, int64_t Mp, int64_t M, void* out);   // R column-major
 void launch_add_f64(hipStream_t s, double* p, double v);   // *p += v
 void launch_finish_kgrad(int dtype, hipStream_t s, int d, int64_t M, int64_t Mp, const void* zs, const double* invl,
                          const double* rp_uf, int ns_uf, const double* rp_uu, int ns_uu, const double* sp_uf, int nsp_uf,
                          const double* sp_uu, int nsp_uu, const void* m, double klw, int layout_z, double variance,
-                         void* z_bar, void* m_bar, double* scal_out, double* red);
+                         void* z_bar, void* m_bar, double* scal_out, double* red, const double* avec);
 
 }  // namespace svgp
