@@ -932,6 +932,9 @@ int grad_workspace(svgp_ctx* ctx, svgp_model* m, int64_t len, GradWs** out) {
   int64_t cap = int64_t(cap_bytes / double(Mp * int64_t(es))) / 128 * 128;
   cap = cap < 128 ? 128 : (cap > cap_cols ? cap_cols : cap);
   int64_t nc = (len + 127) / 128 * 128;
+  // a batch of at most two chunks' worth goes as ONE chunk (C2, 1e5 points: 3.7 -> 3.5 ms - one SYRK / kgrad launch, no drain between
+  // the strips of the two chunks); longer batches keep the 65 536-point chunks (H, H32 flat from 32 768 to 262 144; C5 best at 65 536)
+  if (nc > cap && nc <= 2 * cap && double(nc) * double(Mp * int64_t(es)) <= 2.0 * cap_bytes) cap = nc;
   nc = nc < cap ? nc : cap;
   GradWs* w = ctx->gws;
   if (w && w->dtype == m->dtype && w->Mp == Mp && w->d == m->d && w->nc >= nc) { *out = w; return SVGP_OK; }

@@ -92,13 +92,19 @@ __global__ void __launch_bounds__(k256) sym_from_lower_kernel(const T* __restric
   }
 }
 
-// avec[c] = sum over slices of rowpart[s][1][c]  ( = (A g_mu)_c, the data part of m_bar )
-__global__ void avec_kernel(const double* __restrict__ rp_uf, int ns, int64_t stride, int64_t Mp, double* __restrict__ avec) {
-  const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
-  if (i >= Mp) return;
+// avec[c] = sum over slices of rowpart[s][1][c]  ( = (A g_mu)_c or (Kuf g_mu)_c, the data part of m_bar ): 64 columns per
+// workgroup, thread (c, g) sums slices g, g + 4, ... in order, the four groups are combined in a fixed order (one thread per
+// column walking 256 slices ran at the memory latency: 35 us)
+__global__ void __launch_bounds__(k256) avec_kernel(const double* __restrict__ rp_uf, int ns, int64_t stride, int64_t Mp, double* __restrict__ avec) {
+  __shared__ double sh[4][64];
+  const int cl = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const int64_t i = int64_t(blockIdx.x) * 64 + cl;
   double s = 0.0;
-  for (int q = 0; q < ns; ++q) s += rp_uf[q * stride + Mp + i];
-  avec[i] = s;
+  if (i < Mp)
+    for (int q = g; q < ns; q += 4) s += rp_uf[q * stride + Mp + i];
+  sh[g][cl] = s;
+  __syncthreads();
+  if (g == 0 && i < Mp) avec[i] = ((sh[0][cl] + sh[1][cl]) + sh[2][cl]) + sh[3][cl];
 }
 
 // Lq_bar = tril(G1) - klw dKL/dLq  with G1 = 2 W Lq (row-major);  Lk_bar = -tril(G2 + alpha a')  with G2 = 2 R W (row-major)
@@ -690,7 +696,7 @@ void launch_sym_from_lower(int dtype, hipStream_t s, const void* G, int nslices,
 }
 
 void launch_avec(hipStream_t s, const double* rp_uf, int ns, int64_t stride, int64_t Mp, double* avec) {
-  hipLaunchKernelGGL(avec_kernel, dim3((unsigned)((Mp + 255) / 256)), dim3(256), 0, s, rp_uf, ns, stride, Mp, avec);
+  hipLaunchKernelGGL(avec_kernel, dim3((unsigned)((Mp + 63) / 64)), dim3(k256), 0, s, rp_uf, ns, stride, Mp, avec);
 }
 
 void launch_finish_mm2(int dtype, hipStream_t s, const void* G1, const void* G2, const void* alpha, const double* avec, int64_t Mp,

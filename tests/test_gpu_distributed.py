@@ -230,3 +230,26 @@ def test_one_shot_host_entry_keeps_the_collective_matched():
     model.free()
     data.free()
     ctx.close()
+
+
+def _device_count():
+    import torch
+    return torch.cuda.device_count()   # counting devices does not initialise the GPU in this process
+
+
+@pytest.mark.skipif(_device_count() < 2, reason="needs two GPUs (the round's test boxes have one): the real RCCL launch, bench.py --gpus 2")
+def test_bench_two_gpu_launch_runs_two_rccl_ranks():
+    """bench.py --gpus 2 started plainly launches its own two ranks (one per GPU); the line must prove it: rccl_world = 2 from the
+    library's communicator, twice the points from the all-reduced terms, and the library's all-reduce agreeing with a
+    torch.distributed all-reduce of the ranks' local partial sums.  A small config keeps it short."""
+    import json
+    import subprocess
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                        "--config", "C2", "--no-grad", "--no-c5"], capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["rccl_world"] == 2
+    assert line["n_points_global"] == 2 * 100000
+    assert line["value"] is not None and line["value"] > 0
+    assert line["collective_check"]["rel_err"] < 1e-12
