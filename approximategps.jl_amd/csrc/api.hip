@@ -2,6 +2,7 @@
 // number is produced by the HIP kernels in prep.hip / strip.hip; there is no CPU compute path.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -924,9 +925,26 @@ int32_t svgp_predict_cross_cov(svgp_ctx* ctx, svgp_model* m, int32_t layout, int
 
 namespace {
 
-int grad_workspace(svgp_ctx* ctx, svgp_model* m, int64_t len, GradWs** out) {
-  const size_t es = m->es;
+// split-K slice count of the SYRK for a chunk of nc points (the rule: grad_workspace)
+int syrk_slices(const svgp_ctx* ctx, const svgp_model* m, int64_t nc) {
+  static const int ns_forced = [] { const char* e = getenv("SVGP_GEMM_PM_SLICES"); return e ? atoi(e) : 0; }();   // tuning knob
+  if (ns_forced > 0) return ns_forced;
   const int64_t Mp = m->Mp;
+  const int nP = int(Mp / 128), ntiles = nP * (nP + 1) / 2;
+  const int items = ntiles * (m->dtype == SVGP_F64 ? 2 : 1), slots = 2 * ctx->num_cus;
+  int ns = 1;
+  double best = 0.0;
+  for (int c = 1; c <= 64; ++c) {
+    if (c > 1 && (size_t(c) * size_t(Mp) * size_t(Mp) * m->es > (size_t(2) << 30) || nc / c < 512)) break;
+    const double wg = double(items) * c, eff = wg / (std::ceil(wg / slots) * slots);
+    if (eff > best + 1e-9) { best = eff; ns = c; }
+    if (eff >= 0.97) break;
+  }
+  return ns;
+}
+
+// points per chunk of a value-and-gradient evaluation over `len` points (a multiple of 128): the At / Pt buffers hold one chunk
+int64_t grad_chunk_points(int64_t Mp, size_t es, int64_t len) {
   static const int64_t cap_cols = [] { const char* e = getenv("SVGP_GRAD_CHUNK"); return e ? atoll(e) : 65536ll; }();   // tuning knob
   static const double cap_bytes = [] { const char* e = getenv("SVGP_GRAD_CHUNK_BYTES"); return e ? atof(e) : 1.0e9; }();
   int64_t cap = int64_t(cap_bytes / double(Mp * int64_t(es))) / 128 * 128;
@@ -935,30 +953,25 @@ int grad_workspace(svgp_ctx* ctx, svgp_model* m, int64_t len, GradWs** out) {
   // a batch of at most two chunks' worth goes as ONE chunk (C2, 1e5 points: 3.7 -> 3.5 ms - one SYRK / kgrad launch, no drain between
   // the strips of the two chunks); longer batches keep the 65 536-point chunks (H, H32 flat from 32 768 to 262 144; C5 best at 65 536)
   if (nc > cap && nc <= 2 * cap && double(nc) * double(Mp * int64_t(es)) <= 2.0 * cap_bytes) cap = nc;
-  nc = nc < cap ? nc : cap;
+  return nc < cap ? nc : cap;
+}
+
+int grad_workspace(svgp_ctx* ctx, svgp_model* m, int64_t len, GradWs** out) {
+  const size_t es = m->es;
+  const int64_t Mp = m->Mp;
+  const int64_t nc = grad_chunk_points(Mp, es, len);
   GradWs* w = ctx->gws;
   if (w && w->dtype == m->dtype && w->Mp == Mp && w->d == m->d && w->nc >= nc) { *out = w; return SVGP_OK; }
   if (w) { w->release(); delete w; ctx->gws = nullptr; }
   w = new (std::nothrow) GradWs();
   if (!w) return SVGP_OOM;
   w->dtype = m->dtype; w->Mp = Mp; w->d = m->d; w->nc = nc;
-  const int nP = int(Mp / 128), ntiles = nP * (nP + 1) / 2;
   // Split-K slices of the SYRK: work items = tiles (f64: two 128 x 64 halves each) x slices over 2 workgroup slots per CU.  The
   // smallest count whose last round of slots is >= 97 % full, else the fullest (H: 72 items, 7 slices = 504 of 512; C3: 136 items,
   // 11 slices = 1496 of 1536 - the round-2 rule floor(512 / tiles) left C3 with 408 of 512: 175 -> 164 ms), within 2 GiB of slice
   // buffer and >= 512 points per slice.  Placing the items of a slice on one XCD (they read the same rows of A) was measured
   // and rejected: H 81.9 -> 85-87 ms - the operand re-reads come out of the Infinity Cache at no cost to the MFMA pipe.
-  static const int ns_forced = [] { const char* e = getenv("SVGP_GEMM_PM_SLICES"); return e ? atoi(e) : 0; }();   // tuning knob
-  const int items = ntiles * (m->dtype == SVGP_F64 ? 2 : 1), slots = 2 * ctx->num_cus;
-  int ns = 1;
-  double best = 0.0;
-  for (int c = 1; c <= 64; ++c) {
-    if (c > 1 && (size_t(c) * size_t(Mp) * size_t(Mp) * es > (size_t(2) << 30) || nc / c < 512)) break;
-    const double wg = double(items) * c, eff = wg / (std::ceil(wg / slots) * slots);
-    if (eff > best + 1e-9) { best = eff; ns = c; }
-    if (eff >= 0.97) break;
-  }
-  w->nslices = ns_forced > 0 ? ns_forced : ns;
+  w->nslices = syrk_slices(ctx, m, int64_t(1) << 40);   // the buffer holds the count an unbounded chunk would take: a call's count never exceeds it
   w->rb = grad_rowblocks(m->d, Mp);
   static const int kg_wg = [] { const char* e = getenv("SVGP_KGRAD_WG_PER_CU"); return e ? atoi(e) : 2; }();   // tuning knob
   int nu = (kg_wg * ctx->num_cus + w->rb - 1) / w->rb;
@@ -1077,7 +1090,10 @@ int grad_enqueue(svgp_ctx* ctx, svgp_model* m, const svgp_data* data, int64_t of
   const double scale = gc.scale, klw = gc.klw;
   const double* n_global_dev = gc.n_global_dev;   // data-parallel: the all-reduced batch size, on the device (grad_handshake)
   const int dt = m->dtype;
-  const int64_t Mp = m->Mp, M = m->M, nc = w->nc;
+  const int64_t Mp = m->Mp, M = m->M;
+  // this call's chunk (a reused workspace may hold more: the chunking - and with it the summation order - depends on the call only)
+  const int64_t nc = std::min<int64_t>(w->nc, grad_chunk_points(Mp, m->es, len));
+  const int ns_syrk = std::min(w->nslices, syrk_slices(ctx, m, nc));   // the SYRK's slices: a function of the call, like the chunk
   const size_t es = m->es;
   const int dreg = grad_dreg(m->d);
   // the user-layout gradient blocks of THIS model, contiguous: {z_bar | m_bar | Lq_bar}
@@ -1133,7 +1149,7 @@ int grad_enqueue(svgp_ctx* ctx, svgp_model* m, const svgp_data* data, int64_t of
     rc = ensure_scratch(ctx, 2 * strip_work_bytes(dt, Mp, nt, grid), 1);   // the A strip and, beside it, the Kuf strip
     if (rc) return rc;
     if (nstrips > w->part5_strips) return fail(ctx, SVGP_HIP_ERROR, "internal: strip partial buffer too small");
-    HIPC(ctx, hipMemsetAsync(w->gmu, 0, 2 * size_t(nc) * es, s));   // g_mu | g_v (the SYRK reads g_v over the padded chunk)
+    HIPC(ctx, hipMemsetAsync(w->gmu, 0, 2 * size_t(w->nc) * es, s));   // g_mu | g_v, w->nc apart (the SYRK reads g_v over the padded chunk)
     StripArgs a{};
     a.T = m->T; a.U = m->U; a.zs = m->zs; a.mp = m->mp; a.x = data->x; a.work = ctx->work; a.counter = ctx->counter;
     a.At_out = w->At; a.ldx = data->ldx; a.off = off + c0; a.len = clen; a.Mp = Mp; a.M = M; a.kp = kp;
@@ -1173,9 +1189,9 @@ int grad_enqueue(svgp_ctx* ctx, svgp_model* m, const svgp_data* data, int64_t of
     KCHECK(ctx, "kgrad uf");
     if (kg_overlap) HIPC(ctx, hipEventRecord(ctx->ev_join, sk));
     launch_sum5(s, w->partial5, int(nstrips), w->sums);
-    int64_t sl = ((ncp + w->nslices - 1) / w->nslices + 15) / 16 * 16;   // as even as the 16-point k-step allows
+    int64_t sl = ((ncp + ns_syrk - 1) / ns_syrk + 15) / 16 * 16;   // as even as the 16-point k-step allows
     // W (+)= A diag(2 g_v) A' (lower tiles, split-K slices): the first chunk overwrites, so the slice buffer needs no zeroing
-    launch_gemm_pm(dt, s, w->At, w->At, w->gv, 2.0, Mp, ncp, sl, w->nslices, w->G1, c0 == 0 ? 1 : 0);
+    launch_gemm_pm(dt, s, w->At, w->At, w->gv, 2.0, Mp, ncp, sl, ns_syrk, w->G1, c0 == 0 ? 1 : 0);
     KCHECK(ctx, "syrk");
     if (kg_overlap) HIPC(ctx, hipStreamWaitEvent(s, ctx->ev_join, 0));
   }
@@ -1183,7 +1199,7 @@ int grad_enqueue(svgp_ctx* ctx, svgp_model* m, const svgp_data* data, int64_t of
   HIPC(ctx, hipEventRecord(ctx->ev[2], s));
   // M-sized tail.  With W = A diag(2 g_v) A' and a = A g_mu:
   //   Lq_bar = tril(W B) - klw dKL/dB,   Lk_bar = -tril(alpha a' + R W)     (B = Lq whitened; W, R carry the factors 2)
-  launch_sym_from_lower(dt, s, w->G1, w->nslices, Mp, 0.0, w->W2);
+  launch_sym_from_lower(dt, s, w->G1, ns_syrk, Mp, 0.0, w->W2);
   gemm_mm(ctx, w, dt, s, w->W2, m->U, Mp, w->G1p, kMmYLow);   // (W B)[r][c] = sum_i W[i][r] B[i][c]; B[i][c] = 0 for i < c
   gemm_mm(ctx, w, dt, s, w->Rcm, w->W2, Mp, w->G2);           // (R W)[r][c] = sum_i R[r][i] W[i][c]
   launch_avec(s, w->rp_uf, w->ns_uf, int64_t(2 + dreg) * Mp, Mp, w->avec);

@@ -439,3 +439,28 @@ def test_gradient_workspace_reused_across_models_of_different_m(ctx):
             data.free()
     finally:
         c.close()
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_gradient_does_not_depend_on_the_workspace_history(dtype):
+    """The chunking of a value-and-gradient evaluation and the SYRK's split-K slice count are functions of the call (batch length,
+    M, dtype), not of what the context's cached workspace was first sized for: a 1 300-point batch evaluated after a 9 000-point
+    one (workspace sized for the long batch) returns bit for bit what a fresh context returns."""
+    x, y, sva, s2 = o.synth_problem(515, 9000, 150, 4, dtype=dtype, family=o.KERNEL_SE)
+    res = []
+    for first in (9000, None):
+        c = _ffi.Context(0)
+        try:
+            model = device_model(c, sva, dtype=dtype, sigma2=s2)
+            data = _ffi.DeviceData(c, x, y, dtype)
+            if first:
+                model.elbo_grad(data, 0, first, 9000.0)
+            val, _, g = model.elbo_grad(data, 2000, 1300, 9000.0)
+            res.append((val, {k: np.asarray(v).copy() for k, v in g.items() if isinstance(v, np.ndarray) or np.ndim(v)}))
+            model.free()
+            data.free()
+        finally:
+            c.close()
+    assert res[0][0] == res[1][0]
+    for k in res[0][1]:
+        assert np.array_equal(res[0][1][k], res[1][1][k]), k
