@@ -115,11 +115,13 @@ __device__ __forceinline__ float krsqrt(float d) {
 #ifdef SVGP_POTF2_STAMPS   // diagnostic build (tools/build_ablate.sh stamps): s_memtime at the phase boundaries of potf2
 __device__ unsigned long long g_potf2_stamps[128];
 #define SVGP_STAMP(i) do { if (threadIdx.x == 0) g_potf2_stamps[i] = clock64(); } while (0)
+#define SVGP_STAMPW(i) do { if (threadIdx.x == 64) g_potf2_stamps[i] = clock64(); } while (0)   // a worker wave
 extern "C" int svgp_debug_potf2_stamps(unsigned long long* out) {
   return int(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_potf2_stamps), sizeof(g_potf2_stamps)));
 }
 #else
 #define SVGP_STAMP(i)
+#define SVGP_STAMPW(i)
 #endif
 
 // wave 0's part of a block step: factor the 16x16 diagonal block at offset o (already updated) and invert it.
@@ -155,6 +157,33 @@ __device__ __forceinline__ double row_bcast(double v) {
   return readlane_t(v, J);
 #endif
 }
+// acc -= bcast_J(v) * w in ONE instruction: the DP ALU takes a row_newbcast DPP operand directly (v_fmac_f64_dpp, gfx90a+; the
+// 32-bit form since gfx9), so a column of the factor costs two instructions per earlier column instead of four (f64: two
+// v_mov_b32_dpp at 8 cycles each + two FMAs - the broadcasts were 55 % of a column step's issue time).  Inline assembly: the
+// compiler selects the three-operand v_fma_f64, which has no DPP form.  NOP: the hazard recogniser does not look inside inline
+// assembly - a DPP read of a VGPR the previous instructions wrote needs 2 wait states (the k = J - 1 term only).
+template <int J, bool NOP>
+__device__ __forceinline__ void fmac_bcast(double& acc, double v, double w) {
+#if SVGP_F16_DPP == 2   // A/B: one v_mov_b64_dpp + a plain FMA
+  const double zero = 0.0;
+  const double b = __builtin_amdgcn_update_dpp(zero, v, 0x150 + J, 0xf, 0xf, true);
+  acc = fma(-b, w, acc);
+#elif SVGP_F16_DPP
+  if constexpr (NOP) asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %1, -%2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(v), "v"(w), "n"(J));
+  else asm volatile("v_fmac_f64_dpp %0, %1, -%2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(v), "v"(w), "n"(J));
+#else
+  acc = fma(-row_bcast<J>(v), w, acc);
+#endif
+}
+template <int J, bool NOP>
+__device__ __forceinline__ void fmac_bcast(float& acc, float v, float w) {
+#if SVGP_F16_DPP
+  if constexpr (NOP) asm volatile("s_nop 1\n\tv_fmac_f32_dpp %0, %1, -%2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(v), "v"(w), "n"(J));
+  else asm volatile("v_fmac_f32_dpp %0, %1, -%2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(v), "v"(w), "n"(J));
+#else
+  acc = fmaf(-row_bcast<J>(v), w, acc);
+#endif
+}
 __device__ __forceinline__ double pivot_scale(double t, double d, double rj) {
   double dj = d * rj;
   dj = fma(fma(-dj, dj, d), 0.5 * rj, dj);              // sqrt(d)
@@ -165,26 +194,82 @@ __device__ __forceinline__ float pivot_scale(float t, float, float rj) { return 
 __device__ __forceinline__ double kpivot_rsqrt(double d) { return krsqrt(d); }
 __device__ __forceinline__ float kpivot_rsqrt(float d) { return __builtin_amdgcn_rsqf(d); }
 
-template <typename T, int J>
-__device__ __forceinline__ void factor16_step(T (&row)[16], T (&x)[16], int l15, int& bad) {
-  T t0 = row[J], t1 = T(0), s0 = x[J], s1 = T(0);
-#pragma unroll
-  for (int k = 0; k < J; ++k) {
-    const T b = row_bcast<J>(row[k]);   // L[J][k], from lane J of this lane's 16-lane row
-    if (k & 1) {
-      t1 = fma(-row[k], b, t1);
-      s1 = fma(-b, x[k], s1);
-    } else {
-      t0 = fma(-row[k], b, t0);
-      s0 = fma(-b, x[k], s0);
-    }
+// The serial tail of a column step - pivot broadcast -> 1/sqrt -> scale - as numbered stages of one or two independent
+// instructions, so that factor16_step can issue ONE stage between two groups of the next step's dot products: a lone wave issues in
+// order, and left to itself the compiler emits the ~25 dependent f64 operations of the tail back to back (each waiting ~9 cycles
+// for the one before), then the independent work.
+template <typename T>
+struct PivotTail;
+template <>
+struct PivotTail<double> {
+  static constexpr int NST = 13;
+  double t, sx, d, r, u, h, e, dj, rt, rs, c1, c2;
+  template <int J, int S>
+  __device__ __forceinline__ void stage(double (&row)[16], double (&x)[16], int& bad) {
+    if constexpr (S == 0) { d = row_bcast<J>(t); if (!(d > 0.0) && !bad) bad = J + 1; }
+    if constexpr (S == 1) r = __builtin_amdgcn_rsq(d);                      // ~26 bits
+    if constexpr (S == 2 || S == 5) { u = -d * r; h = 0.5 * r; }
+    if constexpr (S == 3 || S == 6) e = fma(u, r, 1.0);
+    if constexpr (S == 4 || S == 7) r = fma(h, e, r);                       // two Newton steps: 1/sqrt(d)
+    if constexpr (S == 8) { dj = d * r; rt = t * r; rs = sx * r; h = 0.5 * r; }
+    if constexpr (S == 9) c1 = fma(-dj, dj, d);
+    if constexpr (S == 10) dj = fma(c1, h, dj);                             // sqrt(d)
+    if constexpr (S == 11) { c1 = fma(-rt, dj, t); c2 = fma(-rs, dj, sx); }
+    if constexpr (S == 12) { row[J] = fma(c1, r, rt); x[J] = fma(c2, r, rs); }   // t / sqrt(d), sx / sqrt(d)
   }
-  const T t = t0 + t1, sx = s0 + s1;
-  const T d = row_bcast<J>(t);                            // the pivot, in every lane
-  if (!(d > T(0)) && !bad) bad = J + 1;
-  const T rj = kpivot_rsqrt(d);
-  row[J] = pivot_scale(t, d, rj);
-  x[J] = pivot_scale(sx, d, rj);
+};
+template <>
+struct PivotTail<float> {
+  static constexpr int NST = 3;
+  float t, sx, d, r;
+  template <int J, int S>
+  __device__ __forceinline__ void stage(float (&row)[16], float (&x)[16], int& bad) {
+    if constexpr (S == 0) { d = row_bcast<J>(t); if (!(d > 0.0f) && !bad) bad = J + 1; }
+    if constexpr (S == 1) r = __builtin_amdgcn_rsqf(d);                     // v_rsq_f32, 1 ulp
+    if constexpr (S == 2) { row[J] = t * r; x[J] = sx * r; }
+  }
+};
+
+// Column step J, software-pipelined by hand: the sums of step J + 1 over the columns k < J (final since step k) are formed
+// BESIDE the serial tail of step J, one tail stage per column k, pinned in that order by scheduling barriers; step J + 1 then
+// only adds its k = J term.  pt / ps carry those partial sums (two accumulators each).
+template <typename T, int J, int K>
+__device__ __forceinline__ void factor16_bulk(T (&row)[16], T (&x)[16], T (&n)[2], T (&m)[2], PivotTail<T>& tail, int& bad) {
+  if constexpr (K < J || K < PivotTail<T>::NST) {
+    if constexpr (K < PivotTail<T>::NST) tail.template stage<J, K>(row, x, bad);
+    if constexpr (K < J && J + 1 < 16) {
+      fmac_bcast<J + 1, false>(n[K & 1], row[K], row[K]);   // n -= L[J+1][K] * row[K]
+      fmac_bcast<J + 1, false>(m[K & 1], row[K], x[K]);     // m -= L[J+1][K] * x[K]
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    factor16_bulk<T, J, K + 1>(row, x, n, m, tail, bad);
+  }
+}
+// Broadcasts: a DPP operand costs 8 cycles of issue in fp32 and ~16 on the DP ALU (a column step of 2J DPP-FMACs + 27 tail
+// instructions takes 307 cycles in f64).  Measured and rejected: finished columns parked in a 16 x 16 LDS buffer and read back as
+// same-address (broadcast) LDS reads for all but the k = J - 1 term - 7.6k instead of 4.9k cycles per factor (f64; 6.0k vs 3.6k
+// fp32): the write -> read round trip of every step lands on the chain.
+template <typename T, int J>
+__device__ __forceinline__ void factor16_step(T (&row)[16], T (&x)[16], T (&pt)[2], T (&ps)[2], int& bad) {
+  T t1 = pt[1], s1 = ps[1];
+  if constexpr (J >= 1) {
+    fmac_bcast<J, true>(t1, row[J - 1], row[J - 1]);   // L[J][J-1] comes from lane J of this lane's 16-lane row
+    fmac_bcast<J, false>(s1, row[J - 1], x[J - 1]);
+  }
+  PivotTail<T> tail;
+  tail.t = pt[0] + t1;
+  tail.sx = ps[0] + s1;
+  T n[2] = {J + 1 < 16 ? row[J + 1 < 16 ? J + 1 : 15] : T(0), T(0)}, m[2] = {J + 1 < 16 ? x[J + 1 < 16 ? J + 1 : 15] : T(0), T(0)};
+  __builtin_amdgcn_sched_barrier(0);
+  factor16_bulk<T, J, 0>(row, x, n, m, tail, bad);
+  pt[0] = n[0]; pt[1] = n[1]; ps[0] = m[0]; ps[1] = m[1];
+  // nothing moves across a column step: left alone the compiler hoists the broadcasts of ALL later steps (row[k] is final from
+  // step k on) - up to 120 live broadcast values, 256 VGPRs + 214 AGPRs, every broadcast parked in an AGPR and fetched back
+  // (700 v_accvgpr moves on the chain of the f64 kernel: 6.8k -> 5.5k cycles per 16 x 16 factor without them)
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int k = 0; k <= J; ++k) asm volatile("" : "+v"(row[k]), "+v"(x[k]));
+  asm volatile("" : "+v"(pt[0]), "+v"(pt[1]), "+v"(ps[0]), "+v"(ps[1]));
 }
 
 template <typename T>
@@ -197,12 +282,13 @@ __device__ __forceinline__ int factor16(T* __restrict__ sm, T* __restrict__ dinv
     x[c] = (l15 == c) ? T(1) : T(0);
   }
   int bad = 0;
-  factor16_step<T, 0>(row, x, l15, bad);  factor16_step<T, 1>(row, x, l15, bad);  factor16_step<T, 2>(row, x, l15, bad);
-  factor16_step<T, 3>(row, x, l15, bad);  factor16_step<T, 4>(row, x, l15, bad);  factor16_step<T, 5>(row, x, l15, bad);
-  factor16_step<T, 6>(row, x, l15, bad);  factor16_step<T, 7>(row, x, l15, bad);  factor16_step<T, 8>(row, x, l15, bad);
-  factor16_step<T, 9>(row, x, l15, bad);  factor16_step<T, 10>(row, x, l15, bad); factor16_step<T, 11>(row, x, l15, bad);
-  factor16_step<T, 12>(row, x, l15, bad); factor16_step<T, 13>(row, x, l15, bad); factor16_step<T, 14>(row, x, l15, bad);
-  factor16_step<T, 15>(row, x, l15, bad);
+  T pt[2] = {row[0], T(0)}, ps[2] = {x[0], T(0)};
+  factor16_step<T, 0>(row, x, pt, ps, bad);  factor16_step<T, 1>(row, x, pt, ps, bad);  factor16_step<T, 2>(row, x, pt, ps, bad);
+  factor16_step<T, 3>(row, x, pt, ps, bad);  factor16_step<T, 4>(row, x, pt, ps, bad);  factor16_step<T, 5>(row, x, pt, ps, bad);
+  factor16_step<T, 6>(row, x, pt, ps, bad);  factor16_step<T, 7>(row, x, pt, ps, bad);  factor16_step<T, 8>(row, x, pt, ps, bad);
+  factor16_step<T, 9>(row, x, pt, ps, bad);  factor16_step<T, 10>(row, x, pt, ps, bad); factor16_step<T, 11>(row, x, pt, ps, bad);
+  factor16_step<T, 12>(row, x, pt, ps, bad); factor16_step<T, 13>(row, x, pt, ps, bad); factor16_step<T, 14>(row, x, pt, ps, bad);
+  factor16_step<T, 15>(row, x, pt, ps, bad);
   if (lane < 16) {
 #pragma unroll
     for (int c = 0; c < 16; ++c) {
@@ -214,22 +300,105 @@ __device__ __forceinline__ int factor16(T* __restrict__ sm, T* __restrict__ dinv
 }
 
 // Block step p, with lookahead: after the panel  L[t,p] = A[t,p] inv(D_p)'  (all waves), wave 0 updates only the next
-// diagonal block and factors it (the serial chain above) WHILE waves 1-3 do the rest of the trailing update
-// A[ti,tj] -= L[ti,p] L[tj,p]'  and row p of the block inverse  X[p,tj] = -inv(D_p) sum_{tj<=s<p} L[p,s] X[s,tj]
+// diagonal block and factors it (the serial chain above) WHILE the other waves work through the step's remaining items - the rest
+// of the trailing update  A[ti,tj] -= L[ti,p] L[tj,p]'  and row p of the block inverse  X[p,tj] = -inv(D_p) sum_{tj<=s<p} L[p,s] X[s,tj]
 // (the accumulator of the sum is fed straight back as the B operand of the second product: register r of a 16x16 result
 // is k-slab r of a B fragment when A is read with k = Mfma16::row(lane, r); X[ti,tj]' lives in the strictly upper block
-// (tj,ti) of the LDS image).  Critical path per block: panel + one tile update + factor16; everything else hides
-// behind the factor (s_memtime: 115k -> ~70k cycles per 128-block).
+// (tj,ti) of the LDS image) - pulled from an LDS counter (potf2_items; wave 0 joins when its factor is done).
+// Round 3, s_memtime stamps (tools/potf2_time.py; cycles per 128-block, f64 / fp32): 97k / 76k -> 84k / 69k.
+//   * the register factor: 6.8k -> 4.9k (f64) per 16 x 16 block - the compiler had hoisted the broadcasts of all later column
+//     steps (256 VGPRs + 214 AGPRs, 700 v_accvgpr moves on the chain: now pinned per step), and the broadcasts fold into
+//     v_fmac_f64_dpp (factor16_step);
+//   * the workers: a static round-robin left wave 0 waiting 1-5k cycles at EVERY step's barrier (early steps: 27 / 20 / 14
+//     trailing tiles; late steps: the inverse rows, up to 8 chained products per tile) - now a work queue, longest items first.
+// What is left per block (f64): 8 x 4.9k factor + 8 x 0.8k diagonal-tile update + 8 x 0.8-1.3k panel + load 7k + store 9k.
 // Round 3, measured and rejected (s_memtime stamps on wave 0 and on a worker wave, fp32, same box): a restructured body - the
 // 32 leading columns loaded first and the rest beside the first factor, finished L panels / inverse rows written out by the
 // workers during the steps (LDS-only barriers), tiles two at a time, wave 0 taking a share of the tiles after its factor, the
 // block inverse accumulated right-looking (no dot-product chains), a conflict-free LDS stride - was SLOWER end to end (prep at
-// M = 1024: 0.595 vs 0.523 ms f64, 0.549 vs 0.507 ms fp32).  The stamps say why: a 4-MFMA 16 x 16 tile update costs ~1000
-// cycles on a worker wave whether tiles are paired or not and whatever the LDS stride (600 when a single wave runs alone), so
-// the workers - ~28 such groups a step in any formulation - need 8-11k cycles per step against the 4k of wave 0's chain, and
-// every store moved into the steps lengthened them further.  What stayed from that session is the factor itself (below).
+// M = 1024: 0.595 vs 0.523 ms f64, 0.549 vs 0.507 ms fp32): every store moved into the steps lengthened them.  Also rejected:
+// 32 loads in flight or a predicate skipping the blocks above the diagonal in the load phase (one CU's share of the memory pipe
+// either way); the software-pipelined column step by itself (the chain is issue-bound: a DPP operand costs 8 / 16 cycles).
 // The body is a device function of a 256-thread workgroup (smem_raw: potf2_lds_bytes<T>() of dynamic LDS) so that the
 // trailing-update kernels can run it on the NEXT diagonal block the moment that block is up to date (potrf_t below).
+// A[ti, tj] -= L[ti, p] L[tj, p]' on the LDS image of the 128-block: every LDS read of the tile first (the old tile is the
+// accumulator's start: no read-modify-write behind the MFMAs)
+template <typename T>
+__device__ __forceinline__ void potf2_update_tile(T* __restrict__ sm, int p, int ti, int tj, int lane) {
+  constexpr int LD = kNB + 1;
+  using M16 = Mfma16<T>;
+  using acc_t = typename M16::acc_t;
+  const int l15 = lane & 15, g = lane >> 4, o = 16 * p, bi = 16 * ti, bj = 16 * tj;
+  T fa[4], fb[4];
+  acc_t acc;
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    const int k = 4 * s + g;
+    fa[s] = -sm[(bi + l15) * LD + o + k];
+    fb[s] = sm[(bj + l15) * LD + o + k];
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) acc[r] = sm[(bi + M16::row(lane, r)) * LD + bj + l15];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) acc = M16::mma(fa[s], fb[s], acc);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) sm[(bi + M16::row(lane, r)) * LD + bj + l15] = acc[r];
+}
+
+// Work items of block step p besides wave 0's chain, longest first: the rows of the block inverse X[p, tj] (tj < p: p - tj + 1 tile
+// products each), then the trailing tiles (one product each).  Pulled from an LDS counter by the workers at once and by wave 0
+// when its factor is done (the round-2 static round-robin left wave 0 waiting 1-5k cycles at every step's barrier: the workers'
+// ~190 tile products per block at 600-950 cycles each exceed wave 0's 8 x 4k chain).  The inverse rows prefetch the operand
+// fragments of the next product before the MFMAs of the current one.
+template <typename T>
+__device__ __forceinline__ void potf2_items(T* __restrict__ sm, T* __restrict__ dinv, int* __restrict__ queue, int p, int lane) {
+  constexpr int NB = kNB, LD = NB + 1, NBLK = NB / 16, DL = 17;
+  using M16 = Mfma16<T>;
+  using acc_t = typename M16::acc_t;
+  const int l15 = lane & 15, g = lane >> 4, o = 16 * p;
+  const bool last = (p + 1 == NBLK);
+  const int n = NBLK - p - 1, ntr = n * (n + 1) / 2 - (last ? 0 : 1), nit = p + ntr;
+  for (;;) {
+    int it = 0;
+    if (lane == 0) it = atomicAdd(queue, 1);
+    it = __builtin_amdgcn_readfirstlane(it);
+    if (it >= nit) break;
+    if (it < p) {   // inverse tile X[p, tj2]
+      const int tj2 = it;
+      T a0[4], b0[4], a1[4], b1[4];   // two operand sets with static names (a runtime-indexed pair lives in scratch memory)
+      auto ld = [&](int sb, T (&a)[4], T (&b)[4]) {
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+          const int k = 4 * s4 + g;
+          a[s4] = sm[(o + l15) * LD + 16 * sb + k];
+          b[s4] = (sb == tj2) ? dinv[(tj2 * 16 + k) * DL + l15] : sm[(16 * tj2 + l15) * LD + 16 * sb + k];
+        }
+      };
+      acc_t acc = {0, 0, 0, 0};
+      ld(tj2, a0, b0);
+      for (int sb = tj2; sb < p; sb += 2) {
+        if (sb + 1 < p) ld(sb + 1, a1, b1);
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) acc = M16::mma(a0[s4], b0[s4], acc);
+        if (sb + 1 < p) {
+          if (sb + 2 < p) ld(sb + 2, a0, b0);
+#pragma unroll
+          for (int s4 = 0; s4 < 4; ++s4) acc = M16::mma(a1[s4], b1[s4], acc);
+        }
+      }
+      acc_t x = {0, 0, 0, 0};
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) x = M16::mma(dinv[(p * 16 + l15) * DL + M16::row(lane, s4)], acc[s4], x);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) sm[(16 * tj2 + l15) * LD + o + M16::row(lane, r)] = -x[r];
+    } else {        // trailing tile number q of the lower triangle of the trailing block ((0, 0) is wave 0's unless last)
+      int q = it - p + (last ? 0 : 1), ti = 0;
+      while (q >= ti + 1) { q -= ti + 1; ++ti; }
+      potf2_update_tile<T>(sm, p, p + 1 + ti, p + 1 + q, lane);
+    }
+  }
+}
+
 template <typename T>
 constexpr size_t potf2_lds_bytes() { return (size_t(kNB) * (kNB + 1) + 8 * 16 * 17) * sizeof(T); }
 
@@ -242,12 +411,15 @@ __device__ __forceinline__ void potf2_body(T* __restrict__ A, T* __restrict__ Tm
   T* sm = reinterpret_cast<T*>(smem_raw);   // [128][129] row-major block; strictly-upper 16-blocks later hold X'
   T* dinv = sm + NB * LD;                   // [8][16][17]  inverses of the 16x16 diagonal blocks
   __shared__ int failed;
+  __shared__ int queue;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l15 = lane & 15, g = lane >> 4;
   SVGP_STAMP(0);
   if (tid == 0) failed = (*info != 0) ? -1 : 0;
   {
-    // 64 elements per thread, 16 loads in flight at a time (a plain loop waits for every load before its LDS store)
+    // 64 elements per thread, 16 loads in flight at a time (a plain loop waits for every load before its LDS store).  32 in flight,
+    // or skipping the 16-blocks above the diagonal with a predicate, are not faster (7.5k cycles of the f64 block's 88k either way:
+    // one CU's share of the memory pipe)
     constexpr int U = 16;
     for (int e0 = tid; e0 < NB * NB; e0 += k256 * U) {
       T v[U];
@@ -269,6 +441,7 @@ __device__ __forceinline__ void potf2_body(T* __restrict__ A, T* __restrict__ Tm
   if (wave == 0) {
     const int bad = factor16(sm, dinv, LD, DL, 0, 0, lane);
     if (bad && lane == 0) failed = pbase + bad;
+    SVGP_STAMP(42);
   }
   __syncthreads();
 
@@ -290,52 +463,20 @@ __device__ __forceinline__ void potf2_body(T* __restrict__ A, T* __restrict__ Tm
 #pragma unroll
       for (int r = 0; r < 4; ++r) sm[(16 * t + M16::row(lane, r)) * LD + o + l15] = acc[r];
     }
+    if (tid == 0) queue = 0;   // the step's item queue
     __syncthreads();
     SVGP_STAMP(3 + 4 * p);
-    auto update_tile = [&](int ti, int tj) {   // A[ti, tj] -= L[ti, p] L[tj, p]'
-      const int bi = 16 * ti, bj = 16 * tj;
-      acc_t acc = {0, 0, 0, 0};
-#pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        const int k = 4 * s + g;
-        acc = M16::mma(sm[(bi + l15) * LD + o + k], sm[(bj + l15) * LD + o + k], acc);
-      }
-#pragma unroll
-      for (int r = 0; r < 4; ++r) sm[(bi + M16::row(lane, r)) * LD + bj + l15] -= acc[r];
-    };
-    const bool last = (p + 1 == NBLK);          // no next factor: wave 0 joins the inverse-row work
+    const bool last = (p + 1 == NBLK);          // no next factor
     if (wave == 0 && !last) {
-      update_tile(p + 1, p + 1);
+      potf2_update_tile<T>(sm, p, p + 1, p + 1, lane);
+      SVGP_STAMP(44 + 2 * p);
       const int bad = factor16(sm, dinv, LD, DL, o + 16, p + 1, lane);
       if (bad && lane == 0) failed = pbase + o + 16 + bad;
-    } else {
-      // trailing tiles p < tj <= ti except (p+1, p+1), then row p of the block inverse, dealt round-robin to the workers
-      const int nw = last ? 4 : 3, me = last ? wave : wave - 1;
-      const int n = NBLK - p - 1;
-      int ti = 0, tj = 0, idx = 0;
-      for (int q = 0; q < n * (n + 1) / 2; ++q) {
-        if (q > 0 && (idx++ % nw) == me) update_tile(p + 1 + ti, p + 1 + tj);
-        if (++tj > ti) { tj = 0; ++ti; }
-      }
-      for (int tj2 = 0; tj2 < p; ++tj2) {
-        if ((idx++ % nw) != me) continue;
-        acc_t acc = {0, 0, 0, 0};
-        for (int sb = tj2; sb < p; ++sb) {
-#pragma unroll
-          for (int s = 0; s < 4; ++s) {
-            const int k = 4 * s + g;
-            const T a = sm[(o + l15) * LD + 16 * sb + k];
-            const T b = (sb == tj2) ? dinv[(tj2 * 16 + k) * DL + l15] : sm[(16 * tj2 + l15) * LD + 16 * sb + k];
-            acc = M16::mma(a, b, acc);
-          }
-        }
-        acc_t x = {0, 0, 0, 0};
-#pragma unroll
-        for (int s = 0; s < 4; ++s) x = M16::mma(dinv[(p * 16 + l15) * DL + M16::row(lane, s)], acc[s], x);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) sm[(16 * tj2 + l15) * LD + o + M16::row(lane, r)] = -x[r];
-      }
+      SVGP_STAMP(45 + 2 * p);
     }
+    SVGP_STAMPW(64 + 4 * p);
+    potf2_items<T>(sm, dinv, &queue, p, lane);
+    SVGP_STAMPW(66 + 4 * p);
     __syncthreads();
     SVGP_STAMP(4 + 4 * p);
   }
@@ -345,7 +486,7 @@ __device__ __forceinline__ void potf2_body(T* __restrict__ A, T* __restrict__ Tm
   }
   SVGP_STAMP(40);
   {
-    constexpr int U = 8;
+    constexpr int U = 16;
     for (int e0 = tid; e0 < NB * NB; e0 += k256 * U) {
       T lv[U], xv[U];
 #pragma unroll
@@ -357,8 +498,10 @@ __device__ __forceinline__ void potf2_body(T* __restrict__ A, T* __restrict__ Tm
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const int e = e0 + u * k256, r = e % NB, c = e / NB;
-        if (r >= c) A[r + int64_t(c) * ld] = lv[u];
-        Tm[r + int64_t(c) * ld] = (r >= c) ? xv[u] : T(0);
+        if (r >= c) {   // Tm is zero above the diagonal on entry and stays so (launch_potrf's contract): nothing to store there
+          A[r + int64_t(c) * ld] = lv[u];
+          Tm[r + int64_t(c) * ld] = xv[u];
+        }
       }
     }
   }
@@ -843,6 +986,8 @@ void launch_kuu(int dtype, hipStream_t s, const KernelParams& kp, const void* zs
   }
 }
 
+// T must be zero above the diagonal on entry (the model's buffer is cleared once at creation): the factorisation writes the
+// lower triangles of the inverted diagonal blocks and the T panels below them only
 void launch_potrf(int dtype, hipStream_t s, void* A, void* T, int64_t Mp, int* info, unsigned* sync) {
   SVGP_DISPATCH(dtype, potrf_t<double>(s, (double*)A, (double*)T, Mp, info, sync), potrf_t<float>(s, (float*)A, (float*)T, Mp, info, sync));
 }

@@ -8,7 +8,7 @@ import bench
 from approxgp import _ffi
 ctx = _ffi.Context(0)
 out = []
-for dt in ("f64", "f32"):
+for dt in os.environ.get("POTF2_DTYPES", "f64,f32").split(","):   # the stamps printed below are those of the LAST dtype
     p = bench.synth(3, 4096, 128, 8, 0, 0, dt)
     desc, keep = _ffi.make_desc(p["np_dt"], 0, p["variance"], p["inv_l"], p["z"], p["m"], p["Lq"], p["jitter"], likelihood=0, lik_sigma2=p["sigma2"], neg_var_policy=_ffi.NEGVAR_CLAMP)
     model = _ffi.DeviceModel(ctx, desc, keep)
@@ -34,7 +34,7 @@ if hasattr(L, "svgp_debug_potf2_stamps"):
     print(f"  first 16 x 16 factor alone (wave 0): {s[42]-s[1]:.0f}")
     for p in range(8):
         b = 2 + 4 * p
-        extra = f"  [wave 0: tile update {s[44+2*p]-s[b+1]:.0f}, factor16 {s[45+2*p]-s[44+2*p]:.0f}, then its share of the tiles {s[b+2]-s[45+2*p]:.0f}]" if p < 7 else ""
+        extra = f"  [wave 0: tile update {s[44+2*p]-s[b+1]:.0f}, factor16 {s[45+2*p]-s[44+2*p]:.0f}, wait at the barrier {s[b+2]-s[45+2*p]:.0f}]" if p < 7 else ""
         w = s[64 + 4 * p: 64 + 4 * p + 4]
-        extra += f"  [wave 1: tiles {w[1]-w[0]:.0f}, inverse rows {w[2]-w[1]:.0f}, stores {w[3]-w[2]:.0f}]"
+        extra += f"  [wave 1: start +{w[0]-s[b+1]:.0f}, items {w[2]-w[0]:.0f}, wait {s[b+2]-w[2]:.0f}]"
         print(f"  block {p}: panel {s[b+1]-s[b]:.0f}  lookahead phase (next factor | trailing + inverse row) {s[b+2]-s[b+1]:.0f}" + extra)
