@@ -320,7 +320,9 @@ __device__ __forceinline__ int factor16(T* __restrict__ sm, T* __restrict__ dinv
 // 32 loads in flight or a predicate skipping the blocks above the diagonal in the load phase (one CU's share of the memory pipe
 // either way); the software-pipelined column step by itself (the chain is issue-bound: a DPP operand costs 8 / 16 cycles);
 // trailing tiles pulled three at a time with their LDS reads and MFMA chains interleaved (a tile still costs ~800 cycles: the
-// coarser items only unbalance the waves - 86k / 72k instead of 84k / 69k cycles per block).
+// coarser items only unbalance the waves - 86k / 72k instead of 84k / 69k cycles per block); moving only the 36 blocks on and
+// below the diagonal in the load and store phases, one block per workgroup pass (load 7.0k -> 6.6k, store 8.8k -> 10.0k: 128-byte
+// segments instead of 512-byte ones cost what the fewer instructions save).
 // The body is a device function of a 256-thread workgroup (smem_raw: potf2_lds_bytes<T>() of dynamic LDS) so that the
 // trailing-update kernels can run it on the NEXT diagonal block the moment that block is up to date (potrf_t below).
 // A[ti, tj] -= L[ti, p] L[tj, p]' on the LDS image of the 128-block: every LDS read of the tile first (the old tile is the
