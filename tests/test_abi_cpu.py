@@ -151,3 +151,15 @@ def test_small_problems_are_declined_below_the_measured_crossover():
         approxgp.elbo_and_gradient(sva, f(x, 0.1), np.zeros(100), small_problems="decline")
     src = open(os.path.join(ROOT, "integration", "julia", "src", "SVGPMI355X.jl")).read()
     assert src.count("worth_offloading(") >= 5                     # elbo / rrule, posterior, predict, cross-cov + the definition
+
+
+def test_inline_assembly_dpp_reads_respect_the_wait_states():
+    """prep.hip folds the register factor's broadcasts into v_fmac_*_dpp through inline assembly, which the compiler's hazard
+    recogniser does not look into: the compiled kernels must keep 2 wait states between a VALU write and a DPP read of the same
+    VGPR (tools/check_dpp_hazard.py scans the gfx950 assembly of the current sources)."""
+    import shutil, subprocess, sys
+    if shutil.which("hipcc") is None:
+        pytest.skip("no hipcc")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_dpp_hazard.py")], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert " 0 with their source written" in r.stdout and not r.stdout.startswith("0 DPP"), r.stdout
