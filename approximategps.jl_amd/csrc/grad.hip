@@ -435,7 +435,24 @@ __global__ void __launch_bounds__(k256) kgrad_kernel(KernelParams kp, const T* _
 #ifndef SVGP_KGRAD_U
 #define SVGP_KGRAD_U 4
 #endif
+#ifndef SVGP_KGRAD_F32_BLOCKS
+#define SVGP_KGRAD_F32_BLOCKS 1   // 0: fp64 accumulation of every entry in the fp32 builds too (A/B builds)
+#endif
     constexpr int U = SVGP_KGRAD_U;
+    // fp32 builds: the 32 points a wave takes of a staged block are summed in fp32 and the block sums added to the fp64 totals
+    // (the per-entry fp64 conversions and FMAs - half the fp32 rate - were most of this VALU-bound kernel: 0.216 ms per 65 536-point
+    // chunk at M = 1024 for 0.27 GB read; a 32-term fp32 sum adds ~3e-7 relative to the one-rounding error of the kernel entries
+    // themselves, which the fp32 gradient tolerances are built on)
+    constexpr bool kBlockF32 = (sizeof(T) == 4) && SVGP_KGRAD_F32_BLOCKS;
+    float Rb[KV], MBb[KV], Qb[DREG][KV], ILb[DREG], S1b = 0.0f;
+#pragma unroll
+    for (int e = 0; e < KV; ++e) Rb[e] = MBb[e] = 0.0f;
+#pragma unroll
+    for (int f = 0; f < DREG; ++f) {
+      ILb[f] = 0.0f;
+#pragma unroll
+      for (int e = 0; e < KV; ++e) Qb[f][e] = 0.0f;
+    }
     for (int c0w = wave; c0w < JB && jb + c0w < j1; c0w += 4 * U) {
       T pv[U][KV], av[U][KV], gmv[U], gvv[U];
 #pragma unroll
@@ -472,6 +489,19 @@ __global__ void __launch_bounds__(k256) kgrad_kernel(KernelParams kp, const T* _
           T k, dk;
           kappa_and_d<T, FAMILY>(r2[e], variance, k, dk);
           const T p = fma(gvv[u], pv[u][e], al[e] * gmv[u]);   // alpha == nullptr: 1 * pv + 0
+          if constexpr (kBlockF32) {
+            const float Wf = float(p) * float(dk);
+            S1b = fmaf(float(p), float(k), S1b);
+            Rb[e] += Wf;
+            if (At) MBb[e] = fmaf(float(av[u][e]), float(gmv[u]), MBb[e]);
+            else if (kmb) MBb[e] = fmaf(float(k), float(gmv[u]), MBb[e]);
+#pragma unroll
+            for (int f = 0; f < DREG; ++f) {
+              Qb[f][e] = fmaf(Wf, float(xt[c * DREG + f]), Qb[f][e]);
+              ILb[f] = fmaf(Wf * float(uu[f][e]), float(uu[f][e]), ILb[f]);
+            }
+            continue;
+          }
           const double W = double(p) * double(dk);
           S1 += double(p) * double(k);
           R[e] += W;
@@ -483,6 +513,20 @@ __global__ void __launch_bounds__(k256) kgrad_kernel(KernelParams kp, const T* _
             IL[f] += W * double(uu[f][e]) * double(uu[f][e]);
           }
         }
+      }
+    }
+    if constexpr (kBlockF32) {
+      S1 += double(S1b);
+#pragma unroll
+      for (int e = 0; e < KV; ++e) {
+        R[e] += double(Rb[e]);
+        MB[e] += double(MBb[e]);
+      }
+#pragma unroll
+      for (int f = 0; f < DREG; ++f) {
+        IL[f] += double(ILb[f]);
+#pragma unroll
+        for (int e = 0; e < KV; ++e) Q[f][e] += double(Qb[f][e]);
       }
     }
   }
