@@ -22,7 +22,7 @@ cnt = int(raw[127])
 s = np.array([float((int(v) - int(raw[0])) % (1 << 64)) / max(cnt, 1) for v in raw[:127]] + [0.0])   # mean offsets from the strip start
 print(f"averaged over {cnt} strips")
 nP = (M + 127) // 128
-print(f"{cfg}: strip total {s[101]-s[0]:.0f} ticks (100 MHz s_memtime: x10 ns); x staging {s[1]-s[0]:.0f}; final moments {s[101]-s[100]:.0f}")
+print(f"{cfg}: strip total {s[101]-s[0]:.0f} ticks (s_memtime counts shader clocks, ~2.3-2.4 GHz: tools/ubench/clock_rate.hip); x staging {s[1]-s[0]:.0f}; final moments {s[101]-s[100]:.0f}")
 l1 = [s[3 + 3 * I] - s[2 + 3 * I] for I in range(nP)]; e1 = [s[4 + 3 * I] - s[3 + 3 * I] for I in range(nP)]
 l2 = [s[61 + 2 * J] - s[60 + 2 * J] for J in range(nP)]
 e2 = [(s[60 + 2 * (J + 1)] if J + 1 < nP else s[100]) - s[61 + 2 * J] for J in range(nP)]
