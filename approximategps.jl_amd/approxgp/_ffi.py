@@ -45,7 +45,9 @@ class Grads(C.Structure):
 class Timing(C.Structure):
     _fields_ = [("ms_total", C.c_double), ("ms_prep", C.c_double), ("ms_strip", C.c_double), ("ms_expect", C.c_double),
                 ("ms_kuf", C.c_double),
-                ("strip_launches", C.c_int64), ("ms_chol", C.c_double)]
+                ("strip_launches", C.c_int64),
+                # appended since ABI v3 (read through svgp_last_timing_sized): v4 ms_chol, v5 ms_overlap
+                ("ms_chol", C.c_double), ("ms_overlap", C.c_double)]
 
 
 # every symbol include/svgp_mi355x.h declares: (restype, argtypes)
@@ -57,6 +59,7 @@ SYMBOLS = {
     "svgp_ctx_destroy": (C.c_int32, [_P]),
     "svgp_last_error": (C.c_char_p, [_P]),
     "svgp_last_timing": (C.c_int32, [_P, C.POINTER(Timing)]),
+    "svgp_last_timing_sized": (C.c_int32, [_P, _P, C.c_int64]),
     "svgp_data_upload": (C.c_int32, [_P, C.c_int32, C.c_int32, C.c_int32, C.c_int64, _P, _P, C.POINTER(_P)]),
     "svgp_data_wrap_device": (C.c_int32, [_P, C.c_int32, C.c_int32, C.c_int64, C.c_int64, _P, _P, C.POINTER(_P)]),
     "svgp_data_free": (C.c_int32, [_P, _P]),
@@ -217,7 +220,7 @@ class Context:
 
     def timing(self) -> Timing:
         t = Timing()
-        self.lib.svgp_last_timing(self.h, C.byref(t))
+        self.lib.svgp_last_timing_sized(self.h, C.byref(t), C.sizeof(Timing))
         return t
 
     # ---- multi-GPU: one process per GPU (include/svgp_mi355x.h "multi-GPU") ----

@@ -95,14 +95,18 @@ def _desc(sva: SparseVariationalApproximation, lik=None, quadrature=None, dtype=
 # ------------------------------------------------------------------------------------------------
 # elbo / approx_lml
 # ------------------------------------------------------------------------------------------------
-def _decline_if_small(sva, lfx, y, small_problems, want_grad):
+def _decline_if_small(sva, lfx, y, small_problems, want_grad, ctx=None):
     """The rule of the Julia hooks (try_elbo / the rrule return `nothing` and the reference's own body runs): below the
     library's offload threshold (svgp_offload_advice; measured crossover, include/svgp_mi355x.h) the device is slower than the
-    host.  The mirror has no host path, so it only applies the rule on request (`small_problems="decline"`) and then raises."""
+    host.  The mirror has no host path, so it only applies the rule on request (`small_problems="decline"`) and then raises.
+    Never under a library communicator: the calls are collective there, and a rule decided on one rank's own shard
+    length would let that rank leave while its peers wait in the all-reduce - every rank of a data-parallel job offloads."""
     if small_problems == "run":
         return
     if small_problems != "decline":
         raise ValueError('small_problems must be "run" or "decline"')
+    if ctx is not None and ctx.comm_info()[0] > 1:
+        return
     z = np.asarray(sva.fz.x)
     d, M = (1, z.shape[0]) if z.ndim == 1 else z.shape
     n = np.asarray(y).shape[0]
@@ -131,7 +135,7 @@ def elbo(sva: SparseVariationalApproximation, fx, y, *, num_data=None, quadratur
         raise TypeError("elbo expects a FiniteGP or a LatentFiniteGP")
     if sva.fz.f is not lfx.fx.f:  # SVA:347-351
         raise ValueError("(Latent)FiniteGP prior is not consistent with SparseVariationalApproximation's")
-    _decline_if_small(sva, lfx, y, small_problems, False)
+    _decline_if_small(sva, lfx, y, small_problems, False, ctx)
     ctx = ctx or _ffi.default_context()
     if isinstance(lfx.lik, CallerLikelihood):
         return _elbo_host_likelihood(sva, lfx, y, num_data, quadrature, ctx, dtype, False)[0]
@@ -185,7 +189,7 @@ def elbo_and_gradient(sva: SparseVariationalApproximation, fx, y, *, num_data=No
         lfx = fx
     if sva.fz.f is not lfx.fx.f:
         raise ValueError("(Latent)FiniteGP prior is not consistent with SparseVariationalApproximation's")
-    _decline_if_small(sva, lfx, y, small_problems, True)
+    _decline_if_small(sva, lfx, y, small_problems, True, ctx)
     ctx = ctx or _ffi.default_context()
     if isinstance(lfx.lik, CallerLikelihood):
         return _elbo_host_likelihood(sva, lfx, y, num_data, quadrature, ctx, dtype, True)

@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstddef>
 #include <cstdlib>
 #include <cstring>
 #include <new>
@@ -475,7 +476,8 @@ int make_data(svgp_ctx* ctx, int dtype, int layout, int d, int64_t n, const void
               svgp_data** out) {
   if (!out) return fail(ctx, SVGP_INVALID_ARG, "null out pointer");
   if (dtype != SVGP_F64 && dtype != SVGP_F32) return fail(ctx, SVGP_INVALID_ARG, "bad dtype");
-  if (d < 1 || d > SVGP_MAX_D || n < 1 || !x_host) return fail(ctx, SVGP_INVALID_ARG, "bad data shape");
+  if (d > SVGP_MAX_D) return fail(ctx, SVGP_UNSUPPORTED, "input dimension beyond SVGP_MAX_D");   // as the model: the host falls back
+  if (d < 1 || n < 1 || !x_host) return fail(ctx, SVGP_INVALID_ARG, "bad data shape");
   if (layout < 0 || layout > SVGP_VEC || (layout == SVGP_VEC && d != 1)) return fail(ctx, SVGP_INVALID_ARG, "bad layout");
   const size_t es = esize(dtype);
   DataGuard guard;
@@ -535,7 +537,13 @@ int32_t svgp_offload_advice(int64_t n, int64_t M, int32_t d, int32_t /*dtype*/, 
   // One threshold for both forms: the device floor of a value-and-gradient call is ~2.5x the forward floor (600 vs 250 us
   // through the one-shot route), and so is the host's reverse-mode cost (profiles/round3/small_problems.md)
   const char* e = getenv("SVGP_OFFLOAD_MIN_WORK");   // read on every call: hosts (and the tests) change it at run time
-  const double min_work = e ? atof(e) : 3.0e6;
+  double min_work = 3.0e6;
+  if (e && *e) {   // a value that does not parse as a non-negative number is ignored (atof gave 0 = "always offload")
+    char* end = nullptr;
+    const double v = strtod(e, &end);
+    while (end && (*end == ' ' || *end == '\t')) ++end;
+    if (end && end != e && *end == '\0' && v >= 0.0 && v == v) min_work = v;
+  }
   return svgp_offload_work(n, M, d) >= min_work ? 1 : 0;
 }
 
@@ -598,9 +606,18 @@ int32_t svgp_ctx_destroy(svgp_ctx* c) {
 
 const char* svgp_last_error(const svgp_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
 
+// the v2 / v3 layout only (48 bytes): a host compiled against an older header sized its buffer for that
 int32_t svgp_last_timing(const svgp_ctx* ctx, svgp_timing* out) {
   if (!ctx || !out) return SVGP_INVALID_ARG;
-  *out = ctx->timing;
+  static_assert(offsetof(svgp_timing, ms_chol) == SVGP_TIMING_V3_BYTES, "the fields appended since v3 start at byte 48");
+  memcpy(out, &ctx->timing, SVGP_TIMING_V3_BYTES);
+  return SVGP_OK;
+}
+
+int32_t svgp_last_timing_sized(const svgp_ctx* ctx, void* out, int64_t out_bytes) {
+  if (!ctx || !out || out_bytes < 0) return SVGP_INVALID_ARG;
+  const size_t n = size_t(out_bytes) < sizeof(svgp_timing) ? size_t(out_bytes) : sizeof(svgp_timing);
+  memcpy(out, &ctx->timing, n);
   return SVGP_OK;
 }
 
@@ -614,7 +631,8 @@ int32_t svgp_data_upload(svgp_ctx* ctx, int32_t dtype, int32_t layout, int32_t d
 int32_t svgp_data_wrap_device(svgp_ctx* ctx, int32_t dtype, int32_t d, int64_t n, int64_t ldx, const void* x_dev,
                               const void* y_dev, svgp_data** out) {
   if (!ctx) return SVGP_INVALID_ARG;
-  if (!out || !x_dev || d < 1 || d > SVGP_MAX_D || n < 1 || ldx < n) return fail(ctx, SVGP_INVALID_ARG, "bad wrap arguments");
+  if (d > SVGP_MAX_D) return fail(ctx, SVGP_UNSUPPORTED, "input dimension beyond SVGP_MAX_D");
+  if (!out || !x_dev || d < 1 || n < 1 || ldx < n) return fail(ctx, SVGP_INVALID_ARG, "bad wrap arguments");
   if (dtype != SVGP_F64 && dtype != SVGP_F32) return fail(ctx, SVGP_INVALID_ARG, "bad dtype");
   svgp_data* D = new (std::nothrow) svgp_data();
   if (!D) return SVGP_OOM;
@@ -679,7 +697,10 @@ int32_t svgp_model_create(svgp_ctx* ctx, const svgp_model_desc* desc, svgp_model
     svgp_model_free(ctx, m);
     return fail(ctx, SVGP_OOM, "hipMalloc failed for model buffers");
   }
-  HIPC(ctx, hipMemsetAsync(m->T, 0, Mp * Mp * es, ctx->stream));
+  if (hipMemsetAsync(m->T, 0, Mp * Mp * es, ctx->stream) != hipSuccess) {   // launch_potrf's contract: T zero above the diagonal
+    svgp_model_free(ctx, m);
+    return fail(ctx, SVGP_HIP_ERROR, "hipMemsetAsync failed for the model's T buffer");
+  }
   rc = upload_params(ctx, m, desc);
   if (rc) {
     svgp_model_free(ctx, m);

@@ -18,14 +18,13 @@ namespace svgp {
 // A note for the next error message of the calling context (the library never prints: include/svgp_mi355x.h).  Host-side
 // helpers that have no context at hand (set_max_lds, the SVGP_DEBUG_SYNC checks of prep.hip) leave their diagnosis here;
 // KCHECK / HIPC in ctx.hpp append it to svgp_last_error() when the launch they guard fails.
-inline std::mutex& note_mutex() { static std::mutex m; return m; }
-inline std::string& note_text() { static std::string s; return s; }
+// Per THREAD (a process-global note left by one context's thread surfaced in an unrelated context's next error): a context
+// is used by one thread at a time, and the launch helper that leaves a note and the macro that collects it run on that thread.
+inline std::string& note_text() { static thread_local std::string s; return s; }
 inline void leave_note(const std::string& s) {
-  std::lock_guard<std::mutex> g(note_mutex());
   if (note_text().size() < 2048) note_text() += (note_text().empty() ? "" : "; ") + s;
 }
 inline std::string take_note() {
-  std::lock_guard<std::mutex> g(note_mutex());
   std::string s;
   s.swap(note_text());
   return s;

@@ -914,7 +914,11 @@ size_t strip_work_bytes(int dtype, int64_t Mp, int nt, int grid) {
 int strip_grid(int dtype, int nt, int64_t nstrips, int num_cus) {
   // two workgroups per CU (measured: a third f32 workgroup fits but is 7 % slower; SVGP_WG_PER_CU overrides)
   const int per_cu = env_int("SVGP_WG_PER_CU", (nt <= 64 || dtype == 1) ? 2 : 1);
-  const int64_t cap = int64_t(num_cus) * per_cu;
+  int64_t cap = int64_t(num_cus) * per_cu;
+  // A/B knob (round 4): fewer workgroups than slots = a scratch working set below the 256 MiB Infinity Cache
+  // (H: 512 workgroups x 512 KiB = exactly 256 MiB); profiles/round4/strip_grid_ab.log
+  static const int forced_grid = env_int("SVGP_STRIP_GRID", 0);
+  if (forced_grid > 0 && forced_grid < cap) cap = forced_grid;
   return int(nstrips < cap ? nstrips : cap);
 }
 

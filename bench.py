@@ -75,7 +75,7 @@ def mem_available_bytes():
     return 0
 
 
-def cpu_baseline(p, family, lik, sample, n_full, M):
+def cpu_baseline(p, family, lik, sample, n_full, M, force_sample=False):
     """The CPU restatement (oracle, reference operation order: materialise Kuf, trsm, trmm, reductions) timed on
     the host cores.  SURVEY §8d: at the FULL workload when the host has room for the reference's M x N temporaries
     (MemAvailable >= 5 M N 8 bytes; one evaluation, ~30 s at H), otherwise on a bounded sample extrapolated linearly in N."""
@@ -94,7 +94,7 @@ def cpu_baseline(p, family, lik, sample, n_full, M):
     base = {"unit": "evals/s", "cores": threads, "kind": "port", "host_cpus": os.cpu_count(),
             "mem_available_GB": round(avail / 1e9, 1), "mem_needed_full_GB": round(need / 1e9, 1)}
     o.elbo(sva, f64(p["x"][:, :2000]), f64(p["y"][:2000]), lik=lik, sigma2=p["sigma2"])  # warm BLAS threads
-    if avail >= need and os.environ.get("BENCH_CPU_SAMPLE_ONLY") != "1":
+    if avail >= need and os.environ.get("BENCH_CPU_SAMPLE_ONLY") != "1" and not force_sample:
         xs, ys = f64(p["x"]), f64(p["y"])
         t0 = time.perf_counter()
         ref = o.elbo(sva, xs, ys, lik=lik, sigma2=p["sigma2"])
@@ -119,7 +119,122 @@ def cpu_baseline(p, family, lik, sample, n_full, M):
     t_full = fixed + per_point * n_full
     return dict(base, value=1.0 / t_full, oracle_elbo=float(ref), oracle_points=int(sample),
                 sample=f"oracle/svgp_oracle.py (numpy + scipy-OpenBLAS, fp64, {threads} BLAS threads) on {sample} of the {n_full} "
-                       f"points (host RAM below 5 M N 8 bytes), median of 3 = {t_s:.2f} s; extrapolated linearly in N to {t_full:.1f} s/eval")
+                       f"points ({'N > 1 ranks: bounded sample of rank 0 shard' if force_sample else 'host RAM below 5 M N 8 bytes'}), "
+                       f"median of 3 = {t_s:.2f} s; extrapolated linearly in N to {t_full:.1f} s/eval")
+
+
+def lib_sha16():
+    """sha256 (first 16 hex digits) of the library this process loaded: profiles/round4/build.log lists the same hash for the .so
+    build.sh produced from the tree's sources."""
+    import hashlib
+    from approxgp import _ffi
+    try:
+        return hashlib.sha256(open(_ffi.LIB_PATH, "rb").read()).hexdigest()[:16]
+    except OSError:
+        return None
+
+
+class GpuTelemetry:
+    """Shader clock and socket power of one GPU, sampled from sysfs (readable without privileges) by a thread while a timed
+    loop runs: /sys/class/drm/card*/device/pp_dpm_sclk (the level marked `*`) and hwmon power1_average / power1_input (uW).
+    Whatever is missing on a box is reported as absent, never guessed."""
+
+    def __init__(self, index=0, period=0.5):
+        import glob
+        self.period, self.samples, self._stop, self._thr = period, [], False, None
+        cards = []
+        for c in sorted(glob.glob("/sys/class/drm/card[0-9]*")):
+            try:
+                if open(os.path.join(c, "device", "vendor")).read().strip() == "0x1002":
+                    cards.append(c)
+            except OSError:
+                pass
+        self.card = cards[index] if index < len(cards) else None
+        self.power_file = None
+        if self.card:
+            for pat in ("device/hwmon/hwmon*/power1_average", "device/hwmon/hwmon*/power1_input"):
+                hits = sorted(glob.glob(os.path.join(self.card, pat)))
+                if hits:
+                    self.power_file = hits[0]
+                    break
+
+    def _read(self):
+        rec = {"t": time.perf_counter()}
+        if self.card:
+            try:
+                for ln in open(os.path.join(self.card, "device", "pp_dpm_sclk")):
+                    if "*" in ln:
+                        rec["sclk_mhz"] = float(ln.split(":")[1].lower().replace("mhz", "").replace("*", "").strip())
+            except (OSError, ValueError, IndexError):
+                pass
+            try:
+                rec["busy_pct"] = float(open(os.path.join(self.card, "device", "gpu_busy_percent")).read())
+            except (OSError, ValueError):
+                pass
+        if self.power_file:
+            try:
+                rec["power_w"] = float(open(self.power_file).read()) / 1e6
+            except (OSError, ValueError):
+                pass
+        return rec
+
+    def start(self):
+        import threading
+
+        def loop():
+            while not self._stop:
+                self.samples.append(self._read())
+                time.sleep(self.period)
+        self._thr = threading.Thread(target=loop, daemon=True)
+        self._thr.start()
+        return self
+
+    def stop(self):
+        self._stop = True
+        if self._thr:
+            self._thr.join(timeout=2.0)
+        return self.samples
+
+    @staticmethod
+    def summarize(samples, t0, t1):
+        sel = [r for r in samples if t0 <= r["t"] <= t1]
+        out = {"samples": len(sel)}
+        for k in ("sclk_mhz", "power_w", "busy_pct"):
+            v = [r[k] for r in sel if k in r]
+            out[k] = ({"mean": float(np.mean(v)), "min": float(np.min(v)), "max": float(np.max(v))} if v else None)
+        return out
+
+
+def sustained_run(step, fence, seconds, ms_per_step, flops_per_step, peak_tflops, device_index=0):
+    """the driver's timed region is K steps (0.7 s at H); this leg runs the SAME step back to back for
+    `seconds` of wall clock and reports evals/s of the first and the last 5 s, with the shader clock and socket power sampled
+    beside it, so that the headline fraction can be read as a sustained figure."""
+    # a FIXED step count from the measured step time (identical on every rank: it comes from the max-reduced timed region), never
+    # a per-rank clock test - with a communicator every step is a collective and the ranks must agree on how many there are
+    nsteps = max(1, int(math.ceil(seconds * 1e3 / ms_per_step)))
+    tel = GpuTelemetry(device_index).start()
+    fence()
+    t_start = time.perf_counter()
+    stamps = []
+    for _ in range(nsteps):
+        step()
+        stamps.append(time.perf_counter())
+    fence()
+    t_end = time.perf_counter()
+    samples = tel.stop()
+    stamps = np.asarray(stamps)
+
+    def window(a, b):
+        k = int(np.sum((stamps > a) & (stamps <= b)))
+        return {"steps": k, "evals_per_s": k / (b - a), "tflops": k * flops_per_step / (b - a) / 1e12,
+                "frac_of_peak_whole_eval": k * flops_per_step / (b - a) / 1e12 / peak_tflops,
+                "telemetry": GpuTelemetry.summarize(samples, a, b)}
+    w = min(5.0, (t_end - t_start) / 2)
+    return {"seconds": t_end - t_start, "steps": int(len(stamps)), "evals_per_s": len(stamps) / (t_end - t_start),
+            "first_window": window(t_start, t_start + w), "last_window": window(t_end - w, t_end), "window_s": w,
+            "telemetry_whole_run": GpuTelemetry.summarize(samples, t_start, t_end),
+            "telemetry_source": {"card": tel.card, "power_file": tel.power_file, "period_s": tel.period},
+            "note": "wall-clock evals/s of back-to-back svgp_elbo calls (prep + strips + reduce + read-back each); flops = 2 M^2 n + M^3/3"}
 
 
 def profile_traffic(config, kernel_prefix):
@@ -259,13 +374,100 @@ def julia_reference_baseline(exe, p, family, lik, n_sample):
         return res
 
 
-def bench_config(args, name, ctx, torch, dist, dev, world, rank, use_dist, steps, warmup, num_data_override=None, host_comm=False):
+def measure_kuf(name, ctx, model, data, torch, dev):
+    """Kuf assembly alone (SVA:216): M x n column-major written once -> HBM-write bound.  Its own launches, its own HIP events
+    (recorded by the library on its stream around the launch), AFTER the ELBO loop so the clocks are up: median and p95 over 32
+    launches; beside it what a plain write-only stream of the same size reaches on this box (report both)."""
+    n, M, d, family, lik, dtype, cid = CONFIGS[name]
+    es = 8 if dtype == "f64" else 4
+    times = []
+    for _ in range(34):
+        model.kuf(data, 0, n, fetch=False)
+        times.append(ctx.timing().ms_kuf)
+    times = times[2:]
+    t_kuf = float(np.median(times))
+    bytes_alg = es * (M * n + n * d + M * d)
+    gbs = bytes_alg / (t_kuf * 1e-3) / 1e9
+    kuf_roofline = {"kernel": "kuf_cols_kernel (kuf_kernel for layouts it does not take)", "bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS,
+                    "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS, "traffic": None,
+                    "bytes_per_launch": bytes_alg, "ms_per_launch": t_kuf, "launches": len(times),
+                    "ms_p95": float(np.percentile(times, 95)), "ms_min": float(np.min(times)),
+                    "GBps_p95_launch": bytes_alg / (float(np.percentile(times, 95)) * 1e-3) / 1e9}
+    if torch is not None:
+        try:
+            buf = torch.empty(M * n, dtype=torch.float64 if dtype == "f64" else torch.float32, device=dev)
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+            ts = []
+            for _ in range(12):
+                ev[0].record()
+                buf.fill_(1.0)
+                ev[1].record()
+                torch.cuda.synchronize()
+                ts.append(ev[0].elapsed_time(ev[1]))
+            t_fill = float(np.median(ts[2:]))
+            kuf_roofline["stream_write_GBps"] = es * M * n / (t_fill * 1e-3) / 1e9
+            kuf_roofline["frac_of_stream_write"] = gbs / kuf_roofline["stream_write_GBps"]
+            del buf
+        except Exception as e:  # noqa: BLE001
+            kuf_roofline["stream_write_GBps"] = None
+            kuf_roofline["stream_write_error"] = repr(e)
+    tk = profile_traffic(name, "kuf_")   # kuf_cols_kernel (the default) or kuf_kernel
+    if tk:
+        kuf_roofline.update({k: v for k, v in tk.items() if k != "hbm_share_note" and (v is not None or k == "traffic_stale")})
+    return kuf_roofline
+
+
+def baseline_and_parity(args, name, p, model, data, res, world, value):
+    """`cpu_baseline` (the fp64 oracle timed on the host cores) and `parity` (its ELBO against the device's on the same inputs).
+    One GPU: the oracle evaluates the TIMED workload itself when the host has the RAM.  N > 1 ranks (rank 0 calls this for its OWN
+    shard): a bounded sample of the shard, extrapolated linearly in N to the shard's size, and the device side through the local
+    svgp_elbo_partial + svgp_prior_kl (svgp_elbo would be collective).  The unit stays evals/s of ONE shard-sized evaluation on
+    the host, so `gpu_over_cpu` divides the per-GPU rate by it."""
+    n, M, d, family, lik, dtype, cid = CONFIGS[name]
+    tol = 1e-8 if dtype == "f64" else 1e-4
+    jl_exe, jl_version = julia_probe()
+    out = {}
+    try:
+        cb = cpu_baseline(p, family, lik, min(args.cpu_sample, n), n, M, force_sample=(world > 1))
+        ref, npts = cb.pop("oracle_elbo"), cb.pop("oracle_points")
+        cb["julia"] = jl_version
+        if world > 1:
+            cb["scope"] = f"rank 0's shard ({n} of the {n * world} global points); value = host evals/s of ONE shard-sized evaluation"
+        out["cpu_baseline"] = cb
+        if value:
+            out["gpu_over_cpu"] = (value / world) / cb["value"]
+        # the oracle saw the first `npts` points with num_data = npts: the GPU value for exactly that batch
+        if world == 1:
+            gpu_val = res["elbo"] if npts == n else model.elbo(data, 0, npts, float(npts))[0]
+            via = "svgp_elbo"
+        else:
+            part = model.elbo_partial(data, 0, npts)
+            gpu_val = float(part[0]) - model.prior_kl()[0]           # scale = num_data / n = 1
+            via = "svgp_elbo_partial + svgp_prior_kl (local calls; rank 0's shard)"
+        rel = abs(gpu_val - ref) / abs(ref)
+        out["parity"] = {"oracle_elbo": ref, "gpu_elbo": gpu_val, "rel_err": rel, "tol": tol, "points": npts, "via": via,
+                         "ok": bool(rel <= tol), "oracle": "oracle/svgp_oracle.py (fp64; parity UNPINNED: no output of the Julia "
+                         "reference has been available to check it against)"}
+        if jl_exe:   # the reference itself, when the host has it (never expected on the GPU box: it receives only this repo)
+            out["cpu_baseline_reference_julia"] = julia_reference_baseline(jl_exe, p, family, lik, min(args.cpu_sample, n))
+    except Exception as e:  # noqa: BLE001
+        out["cpu_baseline"] = {"value": None, "unit": "evals/s", "cores": os.cpu_count(), "kind": "port", "julia": jl_version,
+                               "sample": "failed: " + repr(e)}
+    return out
+
+
+def bench_config(args, name, ctx, torch, dist, dev, world, rank, use_dist, steps, warmup, num_data_override=None, host_comm=False,
+                 resident=None):
     """Times `steps` full elbo evaluations of config `name` (after `warmup`), barrier + synchronize on both sides, MAX over
-    ranks.  Returns (dict of measurements, model, data, p) with the model and data still resident."""
+    ranks.  Returns (dict of measurements, model, data, p) with the model and data still resident.
+    `resident` > n (C5): that many points stay in HBM and step i evaluates the minibatch window
+    [(i mod W) n, (i mod W) n + n), W = resident // n - a different batch every step, as a training loop draws them."""
     from approxgp import _ffi
 
     n, M, d, family, lik, dtype, cid = CONFIGS[name]
-    p = synth(cid, n, M, d, family, lik, dtype, rank)
+    n_res = int(resident) if resident and resident > n else n
+    nwin = n_res // n
+    p = synth(cid, n_res, M, d, family, lik, dtype, rank)
     desc, keep = _ffi.make_desc(p["np_dt"], family, p["variance"], p["inv_l"], p["z"], p["m"], p["Lq"], p["jitter"],
                                 likelihood=lik, lik_sigma2=p["sigma2"])
     model = _ffi.DeviceModel(ctx, desc, keep)
@@ -276,14 +478,18 @@ def bench_config(args, name, ctx, torch, dist, dev, world, rank, use_dist, steps
         from approxgp.distributed import ShardedELBO
         sharded = ShardedELBO(model, data, num_data, device=dev)
 
+    counter = [0]
+
     def step():
         # prep + fused strips + reduce (HIP library); with a communicator on ctx this call is the library's collective:
         # ONE ncclAllReduce of the device-resident 8-vector, every rank gets the global ELBO
+        off = (counter[0] % nwin) * n
+        counter[0] += 1
         if host_comm:   # fallback only: partial sums through torch.distributed
             class _T:
                 n_points = n * world
-            return sharded.step(0, n), _T
-        return model.elbo(data, 0, n, num_data)
+            return sharded.step(off, n), _T
+        return model.elbo(data, off, n, num_data)
 
     def fence():
         if use_dist:
@@ -335,8 +541,9 @@ def bench_config(args, name, ctx, torch, dist, dev, world, rank, use_dist, steps
                               "frac": ((M ** 3 / 3.0) / (float(np.mean(chol_ms)) * 1e-3) / 1e12 / PEAK_TFLOPS[dtype]) if np.mean(chol_ms) > 0 else None},
         "workload": f"{name}: N={n} points per GPU, M={M}, d={d}, {['SE', 'Matern32', 'Matern52'][family]}-ARD, "
                     f"{['Gaussian', 'Bernoulli-logistic GH-20', 'Poisson'][lik]}, {dtype}, NonCentered; "
-                    "one step = one full elbo(sva, lfx, y) incl. cholesky(Kuu)",
-        "num_data": num_data,
+                    "one step = one full elbo(sva, lfx, y) incl. cholesky(Kuu)"
+                    + (f"; {n_res} points resident per GPU, the batch window advances by {n} points every step ({nwin} windows)" if nwin > 1 else ""),
+        "num_data": num_data, "resident_points_per_gpu": n_res, "windows": nwin, "step_fn": step, "fence_fn": fence,
     }
     return res, model, data, p
 
@@ -352,6 +559,12 @@ def main():
     ap.add_argument("--no-kuf", action="store_true")
     ap.add_argument("--no-grad", action="store_true")
     ap.add_argument("--no-c5", action="store_true")
+    # builder-side runs (the driver's --steps / --warmup semantics are untouched): after the K timed steps, keep evaluating back to
+    # back for this many seconds and report first / last 5 s with clock and power
+    ap.add_argument("--min-seconds", type=float, default=0.0)
+    ap.add_argument("--sustained-out", default=None, help="also write the `sustained` object to this JSON file")
+    ap.add_argument("--c5-resident", type=int, default=int(os.environ.get("BENCH_C5_RESIDENT", "12500000")),
+                    help="points resident per GPU for the C5 minibatch leg (SURVEY 8e: 1.25e7); the window moves every step")
     args = ap.parse_args()
 
     # `python bench.py --gpus N` with N > 1, started plainly: become the launcher of N fresh ranks (before torch / HIP are
@@ -463,51 +676,27 @@ def main():
                                            "Infinity-Cache hits of the per-workgroup scratch strips; algorithmic HBM bytes are "
                                            f"{(8 if dtype == 'f64' else 4) * n * (d + 1) + 16 * n} B")
 
-    # Kuf assembly alone (SVA:216): M x n column-major written once -> HBM-write bound.  Its own launches, its own HIP
-    # events (recorded by the library on its stream around the launch), AFTER the ELBO loop so the clocks are up:
-    # median and p95 over 32 launches.
-    if rank == 0 and world == 1 and not args.no_kuf:
-        es = 8 if dtype == "f64" else 4
-        times = []
-        for _ in range(34):
-            model.kuf(data, 0, n, fetch=False)
-            times.append(ctx.timing().ms_kuf)
-        times = times[2:]
-        t_kuf = float(np.median(times))
-        bytes_alg = es * (M * n + n * d + M * d)
-        gbs = bytes_alg / (t_kuf * 1e-3) / 1e9
-        kuf_roofline = {"kernel": "kuf_cols_kernel (kuf_kernel for layouts it does not take)", "bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS,
-                        "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS, "traffic": None,
-                        "bytes_per_launch": bytes_alg, "ms_per_launch": t_kuf, "launches": len(times),
-                        "ms_p95": float(np.percentile(times, 95)), "ms_min": float(np.min(times)),
-                        "GBps_p95_launch": bytes_alg / (float(np.percentile(times, 95)) * 1e-3) / 1e9}
-        # what a plain write-only stream of the same size reaches on this box (report both)
-        try:
-            buf = torch.empty(M * n, dtype=torch.float64 if dtype == "f64" else torch.float32, device=dev)
-            ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
-            ts = []
-            for _ in range(12):
-                ev[0].record()
-                buf.fill_(1.0)
-                ev[1].record()
-                torch.cuda.synchronize()
-                ts.append(ev[0].elapsed_time(ev[1]))
-            t_fill = float(np.median(ts[2:]))
-            kuf_roofline["stream_write_GBps"] = es * M * n / (t_fill * 1e-3) / 1e9
-            kuf_roofline["frac_of_stream_write"] = gbs / kuf_roofline["stream_write_GBps"]
-            del buf
-        except Exception as e:  # noqa: BLE001
-            kuf_roofline["stream_write_GBps"] = None
-            kuf_roofline["stream_write_error"] = repr(e)
-        tk = profile_traffic(name, "kuf_")   # kuf_cols_kernel (the default) or kuf_kernel
-        if tk:
-            kuf_roofline.update({k: v for k, v in tk.items() if k != "hbm_share_note" and (v is not None or k == "traffic_stale")})
-        out["kuf_roofline"] = kuf_roofline
+    # Kuf assembly alone (SVA:216), rank 0 only (a local call: no collective), also on N > 1
+    if rank == 0 and not args.no_kuf:
+        out["kuf_roofline"] = measure_kuf(name, ctx, model, data, torch, dev)
 
     def fence():
         if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
+
+    if args.min_seconds > 0 and not host_comm:
+        flops_eval = 2.0 * M * M * n + M ** 3 / 3.0
+        sus = sustained_run(res["step_fn"], res["fence_fn"], args.min_seconds, res["ms_per_step"], flops_eval, PEAK_TFLOPS[dtype], local_rank)
+        sus["twenty_step_region"] = {"evals_per_s": res["evals_per_s"] / world, "ms_per_step": res["ms_per_step"],
+                                     "strip_frac": res["roofline"]["frac"]}
+        sus["n_gpus"] = world          # evals_per_s above are per rank; every step is one collective evaluation on all ranks
+        out["sustained"] = sus
+        if rank == 0 and args.sustained_out:
+            os.makedirs(os.path.dirname(os.path.abspath(args.sustained_out)), exist_ok=True)
+            json.dump({"workload": res["workload"], "lib_sha16": lib_sha16(), **sus}, open(args.sustained_out, "w"), indent=1)
+    res.pop("step_fn", None)
+    res.pop("fence_fn", None)
 
     if not args.no_grad and not host_comm:
         # value-and-gradient evaluation (svgp_elbo_grad: what a training step costs), same workload, same residency; on N > 1
@@ -535,8 +724,10 @@ def main():
         # collective path: every rank evaluates its own 2^18-point minibatch per step, scale = 1e8 / (world * 2^18).
         try:
             c5, m5, d5, _ = bench_config(args, "C5", ctx, torch, dist, dev, world, rank, use_dist, max(20, args.steps), 5,
-                                         num_data_override=C5_NUM_DATA, host_comm=host_comm)
+                                         num_data_override=C5_NUM_DATA, host_comm=host_comm, resident=args.c5_resident)
+            nwin5 = c5["windows"]
             c5out = {"workload": c5["workload"] + f"; num_data = {C5_NUM_DATA:.0e}, global minibatch = {world} x 262144",
+                     "resident_points_per_gpu": c5["resident_points_per_gpu"], "windows": nwin5,
                      "minibatch_steps_per_s": c5["evals_per_s"] / world, "ms_per_step": c5["ms_per_step"],
                      "points_per_s": c5["points_per_s"], "dtype": "f32", "roofline": c5["roofline"],
                      "breakdown_ms": c5["breakdown_ms"], "elbo": c5["elbo"], "n_points_global": c5["n_points_global"]}
@@ -545,8 +736,8 @@ def main():
                 fence()
                 t0 = time.perf_counter()
                 reps5 = 10
-                for _ in range(reps5):
-                    m5.elbo_grad(d5, 0, 262144, C5_NUM_DATA)
+                for i5 in range(reps5):   # a different resident window every training step
+                    m5.elbo_grad(d5, ((i5 + 1) % nwin5) * 262144, 262144, C5_NUM_DATA)
                 fence()
                 tg = (time.perf_counter() - t0) / reps5
                 if use_dist:
@@ -565,33 +756,14 @@ def main():
         except Exception as e:  # noqa: BLE001
             out["c5_minibatch"] = {"error": repr(e)}
 
-    # CPU baseline + parity of the TIMED workload (parity is a gate before any timing counts): the fp64 oracle
-    # evaluates the same inputs on the host cores; its ELBO is compared with the value the timed GPU steps returned, and the
-    # headline `value` is withdrawn (null) when they disagree beyond the tolerance the parity tests use.
-    tol = 1e-8 if dtype == "f64" else 1e-4
-    jl_exe, jl_version = julia_probe() if rank == 0 else (None, "not probed")
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        try:
-            cb = cpu_baseline(p, family, lik, min(args.cpu_sample, n), n, M)
-            ref, npts = cb.pop("oracle_elbo"), cb.pop("oracle_points")
-            cb["julia"] = jl_version
-            out["cpu_baseline"] = cb
-            out["gpu_over_cpu"] = out["value"] / cb["value"]
-            # the oracle saw the first `npts` points with num_data = npts: the GPU value for exactly that batch
-            gpu_val = res["elbo"] if npts == n else model.elbo(data, 0, npts, float(npts))[0]
-            rel = abs(gpu_val - ref) / abs(ref)
-            out["parity"] = {"oracle_elbo": ref, "gpu_elbo": gpu_val, "rel_err": rel, "tol": tol, "points": npts,
-                             "ok": bool(rel <= tol), "oracle": "oracle/svgp_oracle.py (fp64; parity UNPINNED: no output of the Julia "
-                             "reference has been available to check it against)"}
-            if not out["parity"]["ok"]:
-                out["value_withdrawn"] = out["value"]
-                out["value"] = None
-            if jl_exe:   # the reference itself, when the host has it (never expected on the GPU box: it receives only this repo)
-                jr = julia_reference_baseline(jl_exe, p, family, lik, min(args.cpu_sample, n))
-                out["cpu_baseline_reference_julia"] = jr
-        except Exception as e:  # noqa: BLE001
-            out["cpu_baseline"] = {"value": None, "unit": "evals/s", "cores": os.cpu_count(), "kind": "port", "julia": jl_version,
-                                   "sample": "failed: " + repr(e)}
+    # CPU baseline + parity of the TIMED workload (parity is a gate before any timing counts), rank 0 only, on
+    # N > 1 too (its own shard, through the LOCAL svgp_elbo_partial: the other ranks wait at the closing barrier meanwhile)
+    if rank == 0 and not args.no_cpu_baseline:
+        out.update(baseline_and_parity(args, name, p, model, data, res, world, out["value"]))
+        if out.get("parity") and not out["parity"]["ok"]:
+            out["value_withdrawn"] = out["value"]
+            out["value"] = None
+    out["lib_sha16"] = lib_sha16()
     model.free()
     data.free()
     ctx.close()

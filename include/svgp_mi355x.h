@@ -31,9 +31,12 @@
 extern "C" {
 #endif
 
-#define SVGP_MAX_D 64 /* largest input dimension the device path takes (round 3: 32 -> 64); beyond it SVGP_UNSUPPORTED: the host falls back */
-#define SVGP_ABI_VERSION 4 /* 3 = 2 + svgp_marginals, svgp_elbo_grad_ext, SVGP_LIK_BERNOULLI_NORMCDF; 4 = 3 + svgp_offload_advice /
-                              svgp_offload_work and svgp_timing.ms_chol appended (additions only: v2 / v3 callers keep working) */
+#define SVGP_MAX_D 64 /* largest input dimension the device path takes (round 3: 32 -> 64); beyond it SVGP_UNSUPPORTED from every entry
+                         point that takes a dimension (model, data upload / wrap): the host falls back */
+#define SVGP_ABI_VERSION 5 /* 3 = 2 + svgp_marginals, svgp_elbo_grad_ext, SVGP_LIK_BERNOULLI_NORMCDF; 4 = 3 + svgp_offload_advice /
+                              svgp_offload_work and svgp_timing.ms_chol; 5 = 4 + svgp_last_timing_sized: svgp_last_timing writes the
+                              48-byte v2 / v3 layout again (v4 let it write 56 bytes into a buffer a v3 host sized at 48), the
+                              fields appended since are read through the sized call.  Additions only: v2 / v3 callers keep working */
 
 /* status codes -> Julia exceptions raised by the shim */
 enum {
@@ -121,8 +124,11 @@ typedef struct svgp_timing {
   double ms_expect;/* marginals + expected log-likelihood + final reduce */
   double ms_kuf;   /* standalone Kuf assembly kernel (svgp_kuf only) */
   int64_t strip_launches;
+  /* ---- end of the v2 / v3 layout (SVGP_TIMING_V3_BYTES = 48): svgp_last_timing writes exactly the fields above ---- */
   double ms_chol;  /* (v4) cholesky(Kuu) alone - the blocked factorisation with its T panels - inside ms_prep */
+  double ms_overlap; /* (v5) part of ms_prep that ran BESIDE the strips (flag-gated strips on the second stream); 0 when serial */
 } svgp_timing;
+#define SVGP_TIMING_V3_BYTES 48
 
 /* ---- library / context ------------------------------------------------------------------- */
 int32_t svgp_version(void);
@@ -132,7 +138,11 @@ int32_t svgp_ctx_create(int32_t device_id, void* stream, svgp_ctx** out);
 int32_t svgp_ctx_destroy(svgp_ctx* ctx);
 /* text of the last error on ctx (owned by the library, valid until the next call on ctx) */
 const char* svgp_last_error(const svgp_ctx* ctx);
+/* writes the first SVGP_TIMING_V3_BYTES of the timing struct: the layout every ABI version shares */
 int32_t svgp_last_timing(const svgp_ctx* ctx, svgp_timing* out);
+/* (v5) writes the first min(out_bytes, size of svgp_timing) bytes: a host passes the size of the struct IT was compiled against, so the
+ * struct can grow without the library ever writing past the caller's buffer */
+int32_t svgp_last_timing_sized(const svgp_ctx* ctx, void* out, int64_t out_bytes);
 
 /* ---- multi-GPU: data-parallel shards of the sum over points (SVA:355-359), SURVEY §8e ----------
  * The expectation term is a plain sum over data points, so each rank holds a shard of (x, y) in its own HBM,

@@ -278,7 +278,11 @@ function elbo_and_grads(sva, lfx, y, num_data, quadrature, want::Bool, config=no
         return nothing
     end
     dx == p.desc.d || return nothing
-    worth_offloading(length(y), length(p.m), Int(p.desc.d); grad=want) || return nothing   # small problems: the Julia body is faster
+    # small problems: the Julia body is faster.  NOT under a library communicator: svgp_elbo_host / svgp_elbo_grad are collective
+    # there, and a rule decided on this rank's own shard length (or on a rank-local ENV value) would let one rank run the Julia
+    # body - and return a shard-local ELBO - while its peers wait in ncclAllReduce (uneven shards, a short last shard).  Every
+    # rank of a data-parallel job therefore offloads, whatever its shard's size.
+    (comm_world() > 1 || worth_offloading(length(y), length(p.m), Int(p.desc.d); grad=want)) || return nothing
     Xd, yd = Array{T}(X), Vector{T}(y)
     n = length(yd)
     out, terms = Ref{Float64}(), Terms()

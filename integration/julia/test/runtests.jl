@@ -17,7 +17,7 @@ ENV["SVGP_OFFLOAD_MIN_WORK"] = "0"
     @test sizeof(MI.ModelDesc) == 104 && fieldoffset(MI.ModelDesc, 9) == 32 && fieldoffset(MI.ModelDesc, 17) == 96
     @test sizeof(MI.Terms) == 64 && fieldoffset(MI.Terms, 8) == 56
     @test sizeof(MI.Grads) == 56 && fieldoffset(MI.Grads, 4) == 24
-    @test ccall((:svgp_version, MI.lib), Int32, ()) == 4
+    @test ccall((:svgp_version, MI.lib), Int32, ()) == 5
 end
 
 on(f) = (MI.enable!(true); f())

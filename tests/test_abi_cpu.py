@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(lib, name), f"{name} declared in the header but not exported"
     assert declared == set(_ffi.SYMBOLS), "ctypes table and header disagree"
-    assert lib.svgp_version() == 4
+    assert lib.svgp_version() == 5
 
 
 def test_gausshermite_matches_numpy():

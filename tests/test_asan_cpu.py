@@ -19,7 +19,7 @@ import ctypes as C, sys
 sys.path.insert(0, %r)
 from approxgp import _ffi
 lib = _ffi.load_library()
-assert lib.svgp_version() == 4
+assert lib.svgp_version() == 5
 for n in (1, 2, 7, 20, 64, 200):
     xs, ws = (C.c_double * n)(), (C.c_double * n)()
     assert lib.svgp_gausshermite(n, xs, ws) == 0

@@ -49,3 +49,50 @@ def test_plain_multi_gpu_start_spawns_ranks_and_reports_failure_loudly():
     assert out["value"] is None and out["n_gpus"] == 2
     assert "--nproc-per-node=2" in out["launcher"]
     assert "bench.py needs a GPU" in r.stderr                                # the children really ran bench.py as ranks
+
+
+def test_multi_rank_line_carries_baseline_parity_and_kuf():
+    """for world > 1 rank 0 used to drop `cpu_baseline`, `parity` and `kuf_roofline`.  The helpers that produce
+    them are exercised here for a 2-rank job on a GPU-less box with a stand-in for the device handles (the stand-in answers
+    svgp_elbo_partial / svgp_prior_kl from the oracle: test infrastructure, this file only): the three keys are present, the parity
+    figure is the local-partial one and the baseline says whose shard it timed."""
+    import types
+
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import svgp_oracle as o
+
+    b = _bench()
+    b.CONFIGS["T"] = (3000, 48, 2, b.SE, b.GAUSS, "f64", 9)
+    n, M, d, family, lik, dtype, cid = b.CONFIGS["T"]
+    p = b.synth(cid, n, M, d, family, lik, dtype, 0)
+    sva = o.SVA(o.Kernel(family, p["variance"], p["inv_l"]), p["z"], p["m"], p["Lq"], jitter=p["jitter"])
+
+    class Model:
+        def elbo_partial(self, data, off, length):
+            e = o.elbo(sva, p["x"][:, off:off + length], p["y"][off:off + length], lik=lik, sigma2=p["sigma2"], num_data=float(length))
+            return np.array([e + o.prior_kl(sva), float(length), 0.0, 0.0])
+
+        def prior_kl(self):
+            return o.prior_kl(sva), 0.0
+
+        def elbo(self, *a):
+            raise AssertionError("svgp_elbo is collective under a communicator: rank 0 must not call it alone")
+
+        def kuf(self, data, off, length, fetch=True):
+            return None
+
+    ctx = types.SimpleNamespace(timing=lambda: types.SimpleNamespace(ms_kuf=0.5))
+    args = types.SimpleNamespace(cpu_sample=2500)
+    got = b.baseline_and_parity(args, "T", p, Model(), None, {"elbo": 0.0}, 2, 40.0)
+    assert {"cpu_baseline", "parity", "gpu_over_cpu"} <= set(got), got
+    assert got["parity"]["ok"] and got["parity"]["rel_err"] < 1e-10 and "svgp_elbo_partial" in got["parity"]["via"]
+    assert got["cpu_baseline"]["value"] > 0 and "rank 0's shard" in got["cpu_baseline"]["scope"]
+    assert got["gpu_over_cpu"] == (40.0 / 2) / got["cpu_baseline"]["value"]
+    kr = b.measure_kuf("T", ctx, Model(), None, None, None)
+    assert kr["bound"] == "hbm" and kr["achieved"] > 0 and kr["bytes_per_launch"] == 8 * (M * n + n * d + M * d)
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    main_src = src[src.index("def main():"):]
+    # main() attaches all three on rank 0 whatever the world size
+    assert 'if rank == 0 and not args.no_kuf:' in main_src and 'if rank == 0 and not args.no_cpu_baseline:' in main_src
+    assert "world == 1 and not args.no_kuf" not in main_src and "world == 1 and not args.no_cpu_baseline" not in main_src
