@@ -1160,6 +1160,18 @@ int grad_enqueue(svgp_ctx* ctx, svgp_model* m, const svgp_data* data, int64_t of
     HIPC(ctx, hipMemcpyAsync(ctx->ext_g, gc.ext_gmu, size_t(len) * 8, hipMemcpyHostToDevice, s));
     HIPC(ctx, hipMemcpyAsync(ctx->ext_g + ctx->ext_cap, gc.ext_gv, size_t(len) * 8, hipMemcpyHostToDevice, s));
   }
+  // Who evaluates the likelihood gradients (strip.hip: kPgPost): round 4 - a small kernel behind the strips, for both likelihood
+  // routes; SVGP_GRAD_POST=0 keeps the round-3 in-kernel forms (A/B).  In-kernel fp32 builds also form A g_mu per strip (`apart`).
+  const char* post_env = getenv("SVGP_GRAD_POST");   // read per call: the equivalence test toggles it inside one process
+  const bool post = post_env ? atoi(post_env) != 0 : true;
+  // A g_mu (the data part of m_bar): in-kernel fp32 - per strip inside the strip kernel, so that kgrad streams P only; otherwise
+  // kgrad, which evaluates the kernel anyway, sums Kuf g_mu and the tail applies Lk^-1 (one gemv with the explicit inverse): A is
+  // then read by the SYRK only (round 3, f64: 0.32 -> 0.2 ms per 65 536-point chunk at M = 1024); SVGP_A_FROM_K=0: kgrad reads A
+  // beside P.  (Round-2 three-way A/B, ms: H 97.8 -> 95.4 with the kgrad prefetch alone, 99.0 with the in-strip form; H32 53.6 ->
+  // 53.0 -> 52.35; C5 16.25 -> 16.2 -> 15.9; C3 208.3 -> 217.2 -> 209.6.)
+  static const int afk_knob = [] { const char* e = getenv("SVGP_A_FROM_K"); return e ? atoi(e) : 1; }();   // A/B knob
+  const bool a_in_strips = (dt == SVGP_F32) && !post;
+  const bool a_from_k = !a_in_strips && afk_knob;
   for (int64_t c0 = 0; c0 < len; c0 += nc) {
     const int64_t clen = (len - c0 < nc) ? len - c0 : nc;
     const int64_t ncp = (clen + 127) / 128 * 128;
@@ -1167,7 +1179,7 @@ int grad_enqueue(svgp_ctx* ctx, svgp_model* m, const svgp_data* data, int64_t of
     const StripPlan plan = strip_plan_single(dt, Mp, clen, ctx->num_cus);
     const int nt = plan.grid ? plan.nt : plan.nt_tail, grid = plan.grid ? plan.grid : plan.grid_tail;
     const int64_t nstrips = plan.grid ? plan.nstrips : plan.nstrips_tail;
-    rc = ensure_scratch(ctx, 2 * strip_work_bytes(dt, Mp, nt, grid), 1);   // the A strip and, beside it, the Kuf strip
+    rc = ensure_scratch(ctx, 2 * strip_work_bytes(dt, Mp, nt, grid), size_t(nc));   // the A strip and, beside it, the Kuf strip; the chunk's moments
     if (rc) return rc;
     if (nstrips > w->part5_strips) return fail(ctx, SVGP_HIP_ERROR, "internal: strip partial buffer too small");
     HIPC(ctx, hipMemsetAsync(w->gmu, 0, 2 * size_t(w->nc) * es, s));   // g_mu | g_v, w->nc apart (the SYRK reads g_v over the padded chunk)
@@ -1175,21 +1187,20 @@ int grad_enqueue(svgp_ctx* ctx, svgp_model* m, const svgp_data* data, int64_t of
     a.T = m->T; a.U = m->U; a.zs = m->zs; a.mp = m->mp; a.x = data->x; a.work = ctx->work; a.counter = ctx->counter;
     a.At_out = w->At; a.ldx = data->ldx; a.off = off + c0; a.len = clen; a.Mp = Mp; a.M = M; a.kp = kp;
     a.mean_const = m->desc.mean_const;
+    a.mom_mu = ctx->mom; a.mom_var = ctx->mom + ctx->mom_cap;   // post: the strips' (mu, v), read by launch_point_grads
     a.R = w->Rcm; a.alpha = w->alpha; a.Pt_out = w->Pt; a.gmu_out = w->gmu; a.gv_out = w->gv; a.y = data->y;
     LikParams lpc = lp;
     if (gc.ext_gmu) { lpc.lik = kLikExternal; lpc.gh_x = ctx->ext_g + c0; lpc.gh_w = ctx->ext_g + ctx->ext_cap + c0; a.y = nullptr; }
-    // A g_mu (the data part of m_bar): fp32 - per strip inside the strip kernel, so that kgrad streams P only; f64 - by kgrad
-    // from A beside P as before (same-box three-way A/B, ms, value-and-gradient: H 97.8 -> 95.4 with the kgrad prefetch alone,
-    // 99.0 with the in-strip form; H32 53.6 -> 53.0 -> 52.35; C5 16.25 -> 16.2 -> 15.9; C3 208.3 -> 217.2 -> 209.6)
-    const bool a_in_strips = (dt == SVGP_F32);
-    // f64, round 3: kgrad evaluates the kernel anyway, so it sums Kuf g_mu and the tail applies Lk^-1 (one gemv with the explicit
-    // inverse): A is then read by the SYRK only, and kgrad streams half the bytes (0.32 -> 0.2 ms per 65 536-point chunk at M = 1024)
-    static const int afk_knob = [] { const char* e = getenv("SVGP_A_FROM_K"); return e ? atoi(e) : 1; }();   // A/B knob
-    const bool a_from_k = !a_in_strips && afk_knob;
     a.part5 = w->partial5; a.apart = a_in_strips ? w->apart : nullptr; a.lp = lpc; a.scale = scale; a.n_global_dev = n_global_dev; a.num_data = gc.num_data;
     HIPC(ctx, hipMemsetAsync(ctx->counter, 0, sizeof(unsigned), s));
-    launch_strip_grad(dt, s, a, nt, grid, nstrips);
+    launch_strip_grad(dt, s, a, nt, grid, nstrips, post);
     KCHECK(ctx, "strip (value and gradient)");
+    int n5 = int(nstrips);   // rows of partial5: per strip (in-kernel forms) or per 256-point block (post)
+    if (post) {
+      launch_point_grads(dt, s, lpc, a.mom_mu, a.mom_var, a.y, off + c0, clen, scale, n_global_dev, gc.num_data, w->gmu, w->gv, w->partial5);
+      KCHECK(ctx, "point gradients");
+      n5 = point_grad_blocks(clen);
+    }
     // Knob (off): the kernel-gradient reductions (f64 VALU, latency-bound, no MFMA) on the second stream BESIDE the SYRK
     // (MFMA-bound); both only read this chunk's A / P / g, the join comes before the next chunk's strips overwrite them.
     // Measured and not adopted: H 97.8-98.3 vs 98.2-98.4 ms, C5 16.5-16.6 vs 16.6-16.7 ms (same box) - the SYRK's 504
@@ -1209,7 +1220,7 @@ int grad_enqueue(svgp_ctx* ctx, svgp_model* m, const svgp_data* data, int64_t of
                  w->gmu, w->gv, w->alpha, ksl, w->ns_uf, w->rp_uf, w->sp_uf, a_from_k ? 1 : 0);
     KCHECK(ctx, "kgrad uf");
     if (kg_overlap) HIPC(ctx, hipEventRecord(ctx->ev_join, sk));
-    launch_sum5(s, w->partial5, int(nstrips), w->sums);
+    launch_sum5(s, w->partial5, n5, w->sums);
     int64_t sl = ((ncp + ns_syrk - 1) / ns_syrk + 15) / 16 * 16;   // as even as the 16-point k-step allows
     // W (+)= A diag(2 g_v) A' (lower tiles, split-K slices): the first chunk overwrites, so the slice buffer needs no zeroing
     launch_gemm_pm(dt, s, w->At, w->At, w->gv, 2.0, Mp, ncp, sl, ns_syrk, w->G1, c0 == 0 ? 1 : 0);
@@ -1224,11 +1235,8 @@ int grad_enqueue(svgp_ctx* ctx, svgp_model* m, const svgp_data* data, int64_t of
   gemm_mm(ctx, w, dt, s, w->W2, m->U, Mp, w->G1p, kMmYLow);   // (W B)[r][c] = sum_i W[i][r] B[i][c]; B[i][c] = 0 for i < c
   gemm_mm(ctx, w, dt, s, w->Rcm, w->W2, Mp, w->G2);           // (R W)[r][c] = sum_i R[r][i] W[i][c]
   launch_avec(s, w->rp_uf, w->ns_uf, int64_t(2 + dreg) * Mp, Mp, w->avec);
-  {
-    static const int afk_knob = [] { const char* e = getenv("SVGP_A_FROM_K"); return e ? atoi(e) : 1; }();
-    if (dt == SVGP_F64 && afk_knob)   // avec holds Kuf g_mu: A g_mu = Lk^-1 (Kuf g_mu)
-      launch_linv_t_gemv(dt, s, w->LinvCM, w->avec, Mp, w->avec, w->gemv_part, 1);
-  }
+  if (a_from_k)   // avec holds Kuf g_mu: A g_mu = Lk^-1 (Kuf g_mu)
+    launch_linv_t_gemv(dt, s, w->LinvCM, w->avec, Mp, w->avec, w->gemv_part, 1);
   launch_finish_mm2(dt, s, w->G1p, w->G2, w->alpha, w->avec, Mp, M, centered ? m->B : m->Lq_raw, centered ? Mp : M, klw, w->Lqbar,
                     centered ? w->BbarRM : nullptr, w->LbarRM);
   KCHECK(ctx, "Lq_bar / Lk_bar");

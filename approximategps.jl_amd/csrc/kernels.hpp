@@ -109,7 +109,15 @@ void launch_strip(int dtype, hipStream_t s, const StripArgs& a, int nt, int grid
 // the value-and-gradient form: phase 1 as launch_strip, then phase 3 (a dense Mp x Mp GEMM R A on the strip's A, still in its
 // scratch strip, whose epilogue also gives the variance) and the per-point likelihood gradients; writes At_out, Pt_out (R A,
 // unscaled), gmu_out, gv_out, part5.  `work` must hold TWO scratch strips per workgroup (2 x strip_work_bytes).
-void launch_strip_grad(int dtype, hipStream_t s, const StripArgs& a, int nt, int grid, int64_t nstrips);
+// post = true (round 4): the strips leave their moments in mom_mu / mom_var (like launch_strip) and write no gmu / gv / part5 -
+// launch_point_grads, next on the stream, produces those from the moments.  post = false: the round-3 in-kernel forms.
+void launch_strip_grad(int dtype, hipStream_t s, const StripArgs& a, int nt, int grid, int64_t nstrips, bool post);
+// marginals, expected log-likelihood and d E / d (mu, v) (x scale) of the points [off, off + len) of y from their moments: gmu_out /
+// gv_out (compute dtype, [len]) and part5[point_grad_blocks(len)][5] = per-block {E, sum g_mu, sum g_v, dE/dsigma2, n_neg}
+int point_grad_blocks(int64_t len);
+void launch_point_grads(int dtype, hipStream_t s, const LikParams& lp, const double* mom_mu, const double* mom_var, const void* y,
+                        int64_t off, int64_t len, double scale, const double* n_global_dev, double num_data, void* gmu_out,
+                        void* gv_out, double* part5);
 // marginals + expected log-likelihood of every point (SVA:354-355): per-block sums into partial/negcnt
 int expect_blocks(int64_t len);
 void launch_expect(int dtype, hipStream_t s, const LikParams& lp, const double* mom_mu, const double* mom_var,

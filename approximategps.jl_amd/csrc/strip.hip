@@ -38,7 +38,13 @@ namespace {
 template <typename T, int NT, int NTHR, int F, int DL>
 __device__ __forceinline__ void pregen_mfma(const T* __restrict__ xs, const T* __restrict__ zs, int d, int64_t Mp, int64_t M,
                                             double variance_d, T* __restrict__ work) {
+  // DL <= 16: the strip's x fragments stay in registers for the whole pass (JT x KS values).  DL = 32 / 64 (round 4: d in (16, 64]
+  // used to fall off the MFMA path onto a scalar per-feature loop): the distance chain runs over the 16-feature chunks with the x
+  // fragment of each MFMA read from the LDS image as it is needed (one conflict-free ds_read per MFMA: 16 lanes x consecutive
+  // points of one feature row) - JT x KS fragments would be 128 VGPRs at d = 64; the z fragments of a 16-row block (KS values)
+  // are fetched once per block as before.
   constexpr int KS = DL / 4, JT = NT / 16, NW = NTHR / 64;
+  constexpr bool XREG = (DL <= 16);
   using M16 = Mfma16<T>;
   using acc_t = typename M16::acc_t;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l15 = lane & 15, g = lane >> 4;
@@ -46,14 +52,15 @@ __device__ __forceinline__ void pregen_mfma(const T* __restrict__ xs, const T* _
   const T c1 = (F == KSE) ? T(-0.5) : T(1);
   const T c0 = (F == KSE) ? T(log(variance_d)) : T(0);
   const T ascale = (F == KSE) ? T(1) : T(-2);
-  T xb[JT][KS], xn[JT];
+  T xb[XREG ? JT : 1][XREG ? KS : 1], xn[JT];
+  const T* __restrict__ xl = xs + g * NT + l15;   // this lane's element of slab 0, column tile 0
 #pragma unroll
   for (int jt = 0; jt < JT; ++jt) {
     T s = T(0);
 #pragma unroll
     for (int q = 0; q < KS; ++q) {
-      const T v = xs[(4 * q + g) * NT + jt * 16 + l15];
-      xb[jt][q] = v;
+      const T v = xl[(4 * q) * NT + jt * 16];
+      if constexpr (XREG) xb[jt][q] = v;
       s = fma(v, v, s);
     }
     s += __shfl_xor(s, 16);
@@ -82,8 +89,21 @@ __device__ __forceinline__ void pregen_mfma(const T* __restrict__ xs, const T* _
       acc_t acc;
 #pragma unroll
       for (int r = 0; r < 4; ++r) acc[r] = xn[jt] + zn[r];
+      if constexpr (XREG) {
 #pragma unroll
-      for (int q = 0; q < KS; ++q) acc = M16::mma(za[q], xb[jt][q], acc);
+        for (int q = 0; q < KS; ++q) acc = M16::mma(za[q], xb[jt][q], acc);
+      } else {
+        // two independent chains (even / odd feature slabs), summed at the end: halves the dependent-MFMA latency of the 8 / 16 steps
+        acc_t acc2 = {0, 0, 0, 0};
+        __builtin_amdgcn_sched_barrier(0);   // keep the LDS reads of a tile with its MFMAs: hoisted across tiles they are 128 VGPRs
+#pragma unroll
+        for (int q = 0; q < KS; q += 2) {
+          acc = M16::mma(za[q], xl[(4 * q) * NT + jt * 16], acc);
+          acc2 = M16::mma(za[q + 1], xl[(4 * q + 4) * NT + jt * 16], acc2);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[r] += acc2[r];
+      }
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int64_t k = k0 + M16::row(lane, r);
@@ -164,8 +184,21 @@ __device__ __noinline__ PointGrads strip_point_grads(LikParams lp, double mu, do
 // Outputs: A and R A point-major (for the products contracted over points: the SYRK W = A diag(2 g_v) A' and the
 // kernel-gradient reductions, which form P = Kuf_bar = alpha g_mu' + 2 (R A) diag(g_v) themselves), g_mu, g_v, and five
 // per-strip sums.
-template <typename T, int NT, int BK, int NTHR, int MINW = 2, int PAD = 16, bool GRAD = false, bool EXT = false>
+// PG (value-and-gradient builds): who turns the strip's (mu, v) into likelihood gradients.
+//   kPgPost (round 4, the default): nobody in here - the strip leaves its moments in mom_mu / mom_var exactly like a forward strip and
+//            point_grad_kernel evaluates SVA:354-355 and their adjoint afterwards (as expect_kernel does for the forward path).
+//            Since phase 3 moved in FRONT of the likelihood gradients nothing in the strip consumes g_mu / g_v (the fp32 `apart`
+//            row sums excepted), and the non-inlined call was all that separated the f64 kernel (256 VGPRs + 72 spilled, 336 B of
+//            scratch) from the spill-free shape of the host-evaluated build: one kernel now serves both.
+//   kPgBuiltin / kPgExternal: the round-3 in-kernel forms (strip_point_grads / two loads of the host's point gradients), kept
+//            for the fp32 `apart` path and as A/B builds (SVGP_GRAD_POST=0).
+enum : int { kPgBuiltin = 0, kPgExternal = 1, kPgPost = 2 };
+// BIGD (round 4): the instantiation for 16 < d <= 64.  A separate kernel, not a branch: with the 32- / 64-feature pre-generation
+// bodies inside, the register allocation of the WHOLE kernel changed (the headline f64 kernel went from 0 to 335 spilled VGPRs) -
+// so the d <= 16 kernels stay bit for bit what they were and the wide-input kernels hold only the wide bodies.
+template <typename T, int NT, int BK, int NTHR, int MINW = 2, int PAD = 16, bool GRAD = false, int PG = kPgBuiltin, bool BIGD = false>
 __global__ void __launch_bounds__(NTHR, MINW) strip_kernel(StripArgs a, int64_t nstrips) {
+  constexpr bool EXT = (PG == kPgExternal);
   using G = TileGemm<T, NT, BK, NTHR, PAD>;
   using Acc = typename G::Acc;
   using QRegs = typename G::QRegs;
@@ -184,7 +217,8 @@ __global__ void __launch_bounds__(NTHR, MINW) strip_kernel(StripArgs a, int64_t 
   // 37.9 to 34.3 ms; moving the generation out of the loop altogether, onto MFMA distances, gave 34.0 ms (f64) and
   // H32 18.9 -> 17.45, C3 73.0 -> 68.4, C5 5.20 -> 4.83 ms (fp32, whose VALU work co-executes with the partner
   // workgroup's MFMAs).
-  const int pre_dl = a.kp.d <= 8 ? 8 : a.kp.d <= 16 ? 16 : 0;   // MFMA pre-generation: xs zero padded to 8 / 16 feature rows
+  // MFMA pre-generation: xs zero padded to 8 / 16 feature rows (BIGD: 32 / 64 - SVGP_MAX_D = 64, every dimension the library takes)
+  const int pre_dl = BIGD ? (a.kp.d <= 32 ? 32 : 64) : (a.kp.d <= 8 ? 8 : a.kp.d <= 16 ? 16 : 0);
   const int dl = pre_dl ? pre_dl : a.kp.d;                      // feature rows of xs
 
   const T* __restrict__ Tm = static_cast<const T*>(a.T);
@@ -208,7 +242,7 @@ __global__ void __launch_bounds__(NTHR, MINW) strip_kernel(StripArgs a, int64_t 
   // of the launch take more strips, which removes most of the ragged last round (C2: 3.05 rounds of strips).
   // Which workgroup evaluates a strip does not change its arithmetic, so results stay bitwise reproducible.
   __shared__ unsigned next_strip;
-  __shared__ T s_gmu[GRAD ? NT : 1], s_gv[GRAD ? NT : 1];   // the strip's likelihood gradients, read by phase 3's epilogue
+  __shared__ T s_gmu[(GRAD && PG != kPgPost) ? NT : 1], s_gv[(GRAD && PG != kPgPost) ? NT : 1];   // the strip's likelihood gradients (fp32 `apart` row sums)
 #ifdef SVGP_STRIP_STAMPS
   int strips_done = 0;
   if (threadIdx.x < 128) s_strip_stamps[threadIdx.x] = 0;
@@ -258,7 +292,17 @@ __global__ void __launch_bounds__(NTHR, MINW) strip_kernel(StripArgs a, int64_t 
           *reinterpret_cast<V*>(workK + int64_t(k) * NT + c) = out;
         }
       };
-      if (pre_dl == 8) {
+      if constexpr (BIGD) {
+        if (pre_dl == 32) {
+          if (family == KSE) pregen_mfma<T, NT, NTHR, KSE, 32>(xs, zs, d, Mp, M, a.kp.variance, workK);
+          else if (family == KM32) pregen_mfma<T, NT, NTHR, KM32, 32>(xs, zs, d, Mp, M, a.kp.variance, workK);
+          else pregen_mfma<T, NT, NTHR, KM52, 32>(xs, zs, d, Mp, M, a.kp.variance, workK);
+        } else {
+          if (family == KSE) pregen_mfma<T, NT, NTHR, KSE, 64>(xs, zs, d, Mp, M, a.kp.variance, workK);
+          else if (family == KM32) pregen_mfma<T, NT, NTHR, KM32, 64>(xs, zs, d, Mp, M, a.kp.variance, workK);
+          else pregen_mfma<T, NT, NTHR, KM52, 64>(xs, zs, d, Mp, M, a.kp.variance, workK);
+        }
+      } else if (pre_dl == 8) {
         if (family == KSE) pregen_mfma<T, NT, NTHR, KSE, 8>(xs, zs, d, Mp, M, a.kp.variance, workK);
         else if (family == KM32) pregen_mfma<T, NT, NTHR, KM32, 8>(xs, zs, d, Mp, M, a.kp.variance, workK);
         else pregen_mfma<T, NT, NTHR, KM52, 8>(xs, zs, d, Mp, M, a.kp.variance, workK);
@@ -266,7 +310,7 @@ __global__ void __launch_bounds__(NTHR, MINW) strip_kernel(StripArgs a, int64_t 
         if (family == KSE) pregen_mfma<T, NT, NTHR, KSE, 16>(xs, zs, d, Mp, M, a.kp.variance, workK);
         else if (family == KM32) pregen_mfma<T, NT, NTHR, KM32, 16>(xs, zs, d, Mp, M, a.kp.variance, workK);
         else pregen_mfma<T, NT, NTHR, KM52, 16>(xs, zs, d, Mp, M, a.kp.variance, workK);
-      } else if (family == KSE) pregen(std::integral_constant<int, KSE>{});
+      } else if (family == KSE) pregen(std::integral_constant<int, KSE>{});   // d > 16 in a kernel without the wide bodies (A/B builds)
       else if (family == KM32) pregen(std::integral_constant<int, KM32>{});
       else pregen(std::integral_constant<int, KM52>{});
       __syncthreads();
@@ -409,7 +453,7 @@ __global__ void __launch_bounds__(NTHR, MINW) strip_kernel(StripArgs a, int64_t 
       }
     }
     __syncthreads();
-    if constexpr (!GRAD) {
+    if constexpr (!GRAD || PG == kPgPost) {
       if (tid < NT && c0 + tid < a.len) {
         double qa = 0, qm = 0, qc = 0;
 #pragma unroll
@@ -419,6 +463,7 @@ __global__ void __launch_bounds__(NTHR, MINW) strip_kernel(StripArgs a, int64_t 
           qc += red[(2 * G::WR + w) * NT + tid];
         }
         a.mom_mu[c0 + tid] = a.mean_const + qm;
+        // GRAD: qc = k_j' (R A)_.j = sum C^2 - sum A^2 (qa is not accumulated in that build, it stays 0)
         a.mom_var[c0 + tid] = a.kp.variance - qa + qc;
       }
       __syncthreads();
@@ -555,6 +600,57 @@ __global__ void __launch_bounds__(k256) expect_kernel(LikParams lp, const double
     partial[blockIdx.x] = sh[0];
     negcnt[blockIdx.x] = sn[0];
   }
+}
+
+// ---------------------------------------------------------------------------------------------
+// value-and-gradient path (round 4): marginals + expected log-likelihood AND its adjoint d E / d (mu, v) of every point of a
+// chunk, from the moments the strips left (SVA:354-355; the likelihood's own parameter gradient too).  One point per thread;
+// per-block sums {E, sum g_mu, sum g_v, dE/dsigma2, n_neg} in a fixed order (LDS tree), summed over blocks by sum5_kernel.
+// lp.lik == kLikExternal: the host evaluated the likelihood on svgp_marginals; lp.gh_x / lp.gh_w hold its (unscaled) point
+// gradients of this chunk and E is the host's.
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(k256) point_grad_kernel(LikParams lp, const double* __restrict__ mom_mu,
+                                                          const double* __restrict__ mom_var, const T* __restrict__ y, int64_t off,
+                                                          int64_t len, double scale_host, const double* __restrict__ n_global_dev,
+                                                          double num_data, T* __restrict__ gmu_out, T* __restrict__ gv_out,
+                                                          double* __restrict__ part5) {
+  __shared__ double sh[5][k256];
+  const int64_t i = int64_t(blockIdx.x) * k256 + threadIdx.x;
+  double e5[5] = {0, 0, 0, 0, 0};
+  if (i < len) {
+    const double scale = n_global_dev ? (num_data > 0.0 ? num_data / *n_global_dev : 1.0) : scale_host;
+    const double mu = mom_mu[i];
+    double v = mom_var[i] + kDefaultSigma2;                 // FiniteGP(f_post, x, 1e-18) -> marginals
+    bool bad = v < 0.0;
+    if (bad) {
+      e5[4] = 1.0;
+      if (lp.clamp_neg_var) { v = 0.0; bad = false; }
+    }
+    double gm = 0.0, gvv = 0.0;
+    if (!bad) {
+      if (lp.lik == kLikExternal) {
+        e5[1] = gm = lp.gh_x[i] * scale;
+        e5[2] = gvv = lp.gh_w[i] * scale;
+      } else {
+        const PointGrads pg = strip_point_grads(lp, mu, v, double(y[off + i]), scale);
+        e5[0] = pg.e; e5[1] = gm = pg.gmu; e5[2] = gvv = pg.gv; e5[3] = pg.gs2;
+      }
+    }
+    gmu_out[i] = T(gm);
+    gv_out[i] = T(gvv);
+  }
+#pragma unroll
+  for (int q = 0; q < 5; ++q) sh[q][threadIdx.x] = e5[q];
+  __syncthreads();
+  for (int w = k256 / 2; w > 0; w >>= 1) {
+    if (int(threadIdx.x) < w) {
+#pragma unroll
+      for (int q = 0; q < 5; ++q) sh[q][threadIdx.x] += sh[q][threadIdx.x + w];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x < 5) part5[int64_t(blockIdx.x) * 5 + threadIdx.x] = sh[threadIdx.x][0];
 }
 
 __global__ void final_reduce_kernel(const double* __restrict__ partial, const unsigned* __restrict__ negcnt, int64_t n,
@@ -874,7 +970,7 @@ __global__ void __launch_bounds__(k256) kuf_generic_kernel(KernelParams kp, cons
   }
 }
 
-template <typename T, int NT, int BK, int NTHR, int MINW = 2, int PAD = 16, bool GRAD = false, bool EXT = false>
+template <typename T, int NT, int BK, int NTHR, int MINW = 2, int PAD = 16, bool GRAD = false, int PG = kPgBuiltin, bool BIGD = false>
 void launch_strip_t(hipStream_t s, const StripArgs& a, int grid, int64_t nstrips) {
   using G = TileGemm<T, NT, BK, NTHR, PAD>;
   // the strip's x image (<= 64 feature rows: SVGP_MAX_D) aliases the staging buffers
@@ -882,9 +978,18 @@ void launch_strip_t(hipStream_t s, const StripArgs& a, int grid, int64_t nstrips
   static_assert(G::LDS_BYTES >= size_t(64) * NT * sizeof(T) && (!(SVGP_ASYNC && G::kAsync) || G::ASYNC_LDS_BYTES >= size_t(64) * NT * sizeof(T)),
                 "x image must fit the staging buffers");
   static_assert(G::LDS_BYTES >= size_t(5) * NT * sizeof(double), "the five per-strip sums reuse the staging buffers");
-  auto kern = strip_kernel<T, NT, BK, NTHR, MINW, PAD, GRAD, EXT>;
+  auto kern = strip_kernel<T, NT, BK, NTHR, MINW, PAD, GRAD, PG, BIGD>;
   set_max_lds(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
   hipLaunchKernelGGL(kern, dim3(grid), dim3(NTHR), lds, s, a, nstrips);
+}
+
+// the product shapes (256 threads): d <= 16 -> the round-3 kernel, 16 < d <= 64 -> its wide-input twin (SVGP_PREGEN_MFMA_BIGD=0:
+// the scalar per-feature generation inside the d <= 16 kernel, as round 3 - A/B knob)
+template <typename T, int NT, bool GRAD, int PG>
+void launch_strip_d(hipStream_t s, const StripArgs& a, int grid, int64_t nstrips) {
+  static const bool bigd_on = [] { const char* e = getenv("SVGP_PREGEN_MFMA_BIGD"); return !e || e[0] != '0'; }();
+  if (a.kp.d > 16 && bigd_on) launch_strip_t<T, NT, 16, 256, 2, 16, GRAD, PG, true>(s, a, grid, nstrips);
+  else launch_strip_t<T, NT, 16, 256, 2, 16, GRAD, PG, false>(s, a, grid, nstrips);
 }
 
 }  // namespace
@@ -978,14 +1083,14 @@ StripPlan strip_plan_single(int dtype, int64_t Mp, int64_t len, int num_cus) {
 void launch_strip(int dtype, hipStream_t s, const StripArgs& a, int nt, int grid, int64_t nstrips) {
   static const bool bk32 = env_int("SVGP_STRIP_BK", 16) == 32;
   if (nt == 32 && dtype == 0) {
-    launch_strip_t<double, 32, 16, 256>(s, a, grid, nstrips);
+    launch_strip_d<double, 32, false, kPgBuiltin>(s, a, grid, nstrips);
   } else if (nt == 32) {
-    launch_strip_t<float, 32, 16, 256>(s, a, grid, nstrips);
+    launch_strip_d<float, 32, false, kPgBuiltin>(s, a, grid, nstrips);
   } else if (nt == 64) {
-    if (dtype == 0) launch_strip_t<double, 64, 16, 256>(s, a, grid, nstrips);
-    else launch_strip_t<float, 64, 16, 256>(s, a, grid, nstrips);   // BK = 32 measured identical
+    if (dtype == 0) launch_strip_d<double, 64, false, kPgBuiltin>(s, a, grid, nstrips);
+    else launch_strip_d<float, 64, false, kPgBuiltin>(s, a, grid, nstrips);   // BK = 32 measured identical
   } else if (dtype == 1 && env_int("SVGP_F32_THREADS", 256) == 256) {
-    launch_strip_t<float, 128, 16, 256>(s, a, grid, nstrips);
+    launch_strip_d<float, 128, false, kPgBuiltin>(s, a, grid, nstrips);
   } else if (dtype == 0) {
     if (bk32 && a.kp.d <= 8) launch_strip_t<double, 128, 32, 512>(s, a, grid, nstrips);
     else launch_strip_t<double, 128, 16, 512>(s, a, grid, nstrips);
@@ -995,15 +1100,26 @@ void launch_strip(int dtype, hipStream_t s, const StripArgs& a, int nt, int grid
   }
 }
 
-void launch_strip_grad(int dtype, hipStream_t s, const StripArgs& a, int nt, int grid, int64_t nstrips) {
+void launch_strip_grad(int dtype, hipStream_t s, const StripArgs& a, int nt, int grid, int64_t nstrips, bool post) {
+  if (post) {   // the strips leave (mu, v); launch_point_grads follows (both likelihood routes, one instantiation per shape)
+    if (dtype == 0) {
+      if (nt == 32) launch_strip_d<double, 32, true, kPgPost>(s, a, grid, nstrips);
+      else launch_strip_d<double, 64, true, kPgPost>(s, a, grid, nstrips);
+    } else {
+      if (nt == 32) launch_strip_d<float, 32, true, kPgPost>(s, a, grid, nstrips);
+      else if (nt == 64) launch_strip_d<float, 64, true, kPgPost>(s, a, grid, nstrips);
+      else launch_strip_d<float, 128, true, kPgPost>(s, a, grid, nstrips);
+    }
+    return;
+  }
   if (a.lp.lik == kLikExternal) {   // the host-evaluated-likelihood build: a separate instantiation, so the enumerated one
     if (dtype == 0) {               // is bit for bit the kernel it was (its register allocation is that sensitive)
-      if (nt == 32) launch_strip_t<double, 32, 16, 256, 2, 16, true, true>(s, a, grid, nstrips);
-      else launch_strip_t<double, 64, 16, 256, 2, 16, true, true>(s, a, grid, nstrips);
+      if (nt == 32) launch_strip_t<double, 32, 16, 256, 2, 16, true, kPgExternal>(s, a, grid, nstrips);
+      else launch_strip_t<double, 64, 16, 256, 2, 16, true, kPgExternal>(s, a, grid, nstrips);
     } else {
-      if (nt == 32) launch_strip_t<float, 32, 16, 256, 2, 16, true, true>(s, a, grid, nstrips);
-      else if (nt == 64) launch_strip_t<float, 64, 16, 256, 2, 16, true, true>(s, a, grid, nstrips);
-      else launch_strip_t<float, 128, 16, 256, 2, 16, true, true>(s, a, grid, nstrips);
+      if (nt == 32) launch_strip_t<float, 32, 16, 256, 2, 16, true, kPgExternal>(s, a, grid, nstrips);
+      else if (nt == 64) launch_strip_t<float, 64, 16, 256, 2, 16, true, kPgExternal>(s, a, grid, nstrips);
+      else launch_strip_t<float, 128, 16, 256, 2, 16, true, kPgExternal>(s, a, grid, nstrips);
     }
     return;
   }
@@ -1015,6 +1131,20 @@ void launch_strip_grad(int dtype, hipStream_t s, const StripArgs& a, int nt, int
     else if (nt == 64) launch_strip_t<float, 64, 16, 256, 2, 16, true>(s, a, grid, nstrips);
     else launch_strip_t<float, 128, 16, 256, 2, 16, true>(s, a, grid, nstrips);
   }
+}
+
+int point_grad_blocks(int64_t len) { return int((len + k256 - 1) / k256); }
+
+void launch_point_grads(int dtype, hipStream_t s, const LikParams& lp, const double* mom_mu, const double* mom_var, const void* y,
+                        int64_t off, int64_t len, double scale, const double* n_global_dev, double num_data, void* gmu_out,
+                        void* gv_out, double* part5) {
+  const int nb = point_grad_blocks(len);
+  if (dtype == 0)
+    hipLaunchKernelGGL(point_grad_kernel<double>, dim3(nb), dim3(k256), 0, s, lp, mom_mu, mom_var, (const double*)y, off, len, scale,
+                       n_global_dev, num_data, (double*)gmu_out, (double*)gv_out, part5);
+  else
+    hipLaunchKernelGGL(point_grad_kernel<float>, dim3(nb), dim3(k256), 0, s, lp, mom_mu, mom_var, (const float*)y, off, len, scale,
+                       n_global_dev, num_data, (float*)gmu_out, (float*)gv_out, part5);
 }
 
 int expect_blocks(int64_t len) {

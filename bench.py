@@ -47,6 +47,12 @@ CONFIGS = {
     "C3": (1_000_000, 2048, 16, M52, BERN, "f32", 3),
     "C4": (100_000, 8192, 8, SE, GAUSS, "f32", 4),
     "C5": (262_144, 1024, 8, SE, GAUSS, "f32", 5),        # per-GPU minibatch of the 8-GPU config
+    # wide inputs (round 4): the headline shape at d = 32 / 64, both precisions
+    "Hd32": (1_000_000, 1024, 32, SE, GAUSS, "f64", 6), "Hd64": (1_000_000, 1024, 64, SE, GAUSS, "f64", 6),
+    "H32d32": (1_000_000, 1024, 32, SE, GAUSS, "f32", 6), "H32d64": (1_000_000, 1024, 64, SE, GAUSS, "f32", 6),
+    "Hd17": (1_000_000, 1024, 17, SE, GAUSS, "f64", 6),
+    # minibatch shapes of the verdict's prep-overlap targets
+    "MB16k": (16_384, 1024, 8, SE, GAUSS, "f64", 7), "MB4k": (4_096, 512, 8, SE, GAUSS, "f64", 7),
 }
 C5_NUM_DATA = 1.0e8
 PEAK_TFLOPS = {"f64": 78.6, "f32": 157.3}  # MI355X dense matrix peaks (AMD spec; MI355X_MICROARCH.md for f32)
@@ -139,7 +145,7 @@ class GpuTelemetry:
     loop runs: /sys/class/drm/card*/device/pp_dpm_sclk (the level marked `*`) and hwmon power1_average / power1_input (uW).
     Whatever is missing on a box is reported as absent, never guessed."""
 
-    def __init__(self, index=0, period=0.5):
+    def __init__(self, index=0, period=0.5, pci_bus_id=None):
         import glob
         self.period, self.samples, self._stop, self._thr = period, [], False, None
         cards = []
@@ -149,7 +155,18 @@ class GpuTelemetry:
                     cards.append(c)
             except OSError:
                 pass
-        self.card = cards[index] if index < len(cards) else None
+        self.card = None
+        if pci_bus_id:   # the card whose PCI address is the HIP device's (a box may expose more cards than the one we were given)
+            want = pci_bus_id.lower()
+            for c in cards:
+                try:
+                    if os.path.basename(os.path.realpath(os.path.join(c, "device"))).lower() == want:
+                        self.card = c
+                except OSError:
+                    pass
+        self.card_matched_by_pci = self.card is not None
+        if self.card is None:
+            self.card = cards[index] if index < len(cards) else None
         self.power_file = None
         if self.card:
             for pat in ("device/hwmon/hwmon*/power1_average", "device/hwmon/hwmon*/power1_input"):
@@ -205,14 +222,14 @@ class GpuTelemetry:
         return out
 
 
-def sustained_run(step, fence, seconds, ms_per_step, flops_per_step, peak_tflops, device_index=0):
+def sustained_run(step, fence, seconds, ms_per_step, flops_per_step, peak_tflops, device_index=0, pci_bus_id=None):
     """the driver's timed region is K steps (0.7 s at H); this leg runs the SAME step back to back for
     `seconds` of wall clock and reports evals/s of the first and the last 5 s, with the shader clock and socket power sampled
     beside it, so that the headline fraction can be read as a sustained figure."""
     # a FIXED step count from the measured step time (identical on every rank: it comes from the max-reduced timed region), never
     # a per-rank clock test - with a communicator every step is a collective and the ranks must agree on how many there are
     nsteps = max(1, int(math.ceil(seconds * 1e3 / ms_per_step)))
-    tel = GpuTelemetry(device_index).start()
+    tel = GpuTelemetry(device_index, pci_bus_id=pci_bus_id).start()
     fence()
     t_start = time.perf_counter()
     stamps = []
@@ -233,7 +250,8 @@ def sustained_run(step, fence, seconds, ms_per_step, flops_per_step, peak_tflops
     return {"seconds": t_end - t_start, "steps": int(len(stamps)), "evals_per_s": len(stamps) / (t_end - t_start),
             "first_window": window(t_start, t_start + w), "last_window": window(t_end - w, t_end), "window_s": w,
             "telemetry_whole_run": GpuTelemetry.summarize(samples, t_start, t_end),
-            "telemetry_source": {"card": tel.card, "power_file": tel.power_file, "period_s": tel.period},
+            "telemetry_source": {"card": tel.card, "matched_by_pci_bus_id": tel.card_matched_by_pci, "pci_bus_id": pci_bus_id,
+                                 "power_file": tel.power_file, "period_s": tel.period},
             "note": "wall-clock evals/s of back-to-back svgp_elbo calls (prep + strips + reduce + read-back each); flops = 2 M^2 n + M^3/3"}
 
 
@@ -687,7 +705,12 @@ def main():
 
     if args.min_seconds > 0 and not host_comm:
         flops_eval = 2.0 * M * M * n + M ** 3 / 3.0
-        sus = sustained_run(res["step_fn"], res["fence_fn"], args.min_seconds, res["ms_per_step"], flops_eval, PEAK_TFLOPS[dtype], local_rank)
+        try:
+            pr = torch.cuda.get_device_properties(local_rank)
+            pci = f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0"
+        except Exception:  # noqa: BLE001
+            pci = None
+        sus = sustained_run(res["step_fn"], res["fence_fn"], args.min_seconds, res["ms_per_step"], flops_eval, PEAK_TFLOPS[dtype], local_rank, pci)
         sus["twenty_step_region"] = {"evals_per_s": res["evals_per_s"] / world, "ms_per_step": res["ms_per_step"],
                                      "strip_frac": res["roofline"]["frac"]}
         sus["n_gpus"] = world          # evals_per_s above are per rank; every step is one collective evaluation on all ranks

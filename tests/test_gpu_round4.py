@@ -1,0 +1,144 @@
+"""GPU tests of what round 4 added: inputs of 17..64 dimensions on the MFMA-distance pre-generation (every kernel family, value
+and gradient), the post-strip point-gradient kernel against the round-3 in-kernel forms, and the device-side halves of the
+ADVICE r3 fixes.  Everything goes through the C-ABI (ctypes)."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import svgp_oracle as o
+from approxgp import _ffi
+from helpers import GaussHermiteLikelihood, device_model, rel
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = _ffi.Context(0)
+    yield c
+    c.close()
+
+
+@pytest.mark.parametrize("d", [17, 24, 32, 40, 64])
+@pytest.mark.parametrize("family", [o.KERNEL_SE, o.KERNEL_MATERN32, o.KERNEL_MATERN52])
+@pytest.mark.parametrize("dtype,tol,mtol,gtol", [(np.float64, 1e-8, 1e-10, 1e-6), (np.float32, 1e-4, 2e-4, 3e-3)])
+def test_wide_inputs_on_the_mfma_pregeneration(ctx, dtype, tol, mtol, gtol, family, d):
+    """cov(f.prior, z, x) is dimension-agnostic in the reference (SVA:216); the device's strips used to leave the
+    MFMA-distance path at d = 17.  16 < d <= 64 now run the 32- / 64-feature bodies of pregen_mfma (strip.hip): ELBO, the
+    per-point marginals (a stricter check than one scalar) and the gradient, M not a multiple of 128, ragged batch."""
+    N, M = 1237, 150
+    x, y, sva, s2 = o.synth_problem(4100 + d, N, M, d, family=family, dtype=dtype)
+    model = device_model(ctx, sva, dtype=dtype, sigma2=s2)
+    data = _ffi.DeviceData(ctx, x, y, dtype)
+    val_ref, g_ref = o.elbo_grad(sva, x, y, sigma2=s2, num_data=3.0 * N)
+    assert rel(model.elbo(data, 0, N, 3.0 * N)[0], val_ref) < tol
+    mu, var = model.marginals(data, 0, N)
+    mu_ref, var_ref = o.mean_and_var(o.posterior(sva), x)
+    assert np.abs(mu - mu_ref).max() < mtol * max(1.0, np.abs(mu_ref).max())
+    assert np.abs(var - (var_ref + 1e-18)).max() < mtol * sva.kernel.variance
+    val, _, g = model.elbo_grad(data, 0, N, 3.0 * N)
+    assert rel(val, val_ref) < tol
+    for k in ("m", "Lq", "inv_lengthscale"):
+        a, b = np.asarray(g[k], dtype=np.float64), np.asarray(g_ref[k])
+        assert np.abs(a - b).max() <= gtol * np.abs(b).max(), k
+    zb = np.asarray(g["z"], dtype=np.float64).reshape(g_ref["z"].shape, order="F")
+    assert np.abs(zb - g_ref["z"]).max() <= gtol * np.abs(g_ref["z"]).max()
+    model.free()
+    data.free()
+
+
+@pytest.mark.parametrize("dtype,vtol,gtol", [(np.float64, 1e-13, 1e-11), (np.float32, 2e-6, 2e-4)])
+@pytest.mark.parametrize("lik,qn", [(o.LIK_GAUSSIAN, 0), (o.LIK_BERNOULLI_LOGISTIC, 0), (o.LIK_POISSON_EXP, 0), (o.LIK_GAMMA_EXP, 7)])
+def test_point_gradient_kernel_equals_the_in_kernel_forms(ctx, dtype, vtol, gtol, lik, qn):
+    """Round 4 moved the likelihood gradients out of the value-and-gradient strips into point_grad_kernel (strip.hip, kPgPost).
+    Per point it is the same arithmetic on the same moments; only the order of the per-block sums differs.  SVGP_GRAD_POST=0
+    selects the round-3 in-kernel build: both must agree to rounding in the compute dtype, on a batch spanning several strips and
+    a ragged end, with the oracle between them."""
+    N, M, d = 2900, 140, 5
+    x, y, sva, s2 = o.synth_problem(5200, N, M, d, family=o.KERNEL_MATERN52, lik=lik, dtype=dtype)
+    model = device_model(ctx, sva, dtype=dtype, lik=lik, sigma2=s2, quadrature_n=qn)
+    data = _ffi.DeviceData(ctx, x, y, dtype)
+    old = os.environ.get("SVGP_GRAD_POST")
+    try:
+        os.environ["SVGP_GRAD_POST"] = "1"
+        v1, _, g1 = model.elbo_grad(data, 0, N, 2.0 * N)
+        os.environ["SVGP_GRAD_POST"] = "0"
+        v0, _, g0 = model.elbo_grad(data, 0, N, 2.0 * N)
+    finally:
+        if old is None:
+            os.environ.pop("SVGP_GRAD_POST", None)
+        else:
+            os.environ["SVGP_GRAD_POST"] = old
+    assert rel(v1, v0) < vtol
+    for k in ("z", "m", "Lq", "inv_lengthscale"):
+        a, b = np.asarray(g1[k], dtype=np.float64), np.asarray(g0[k], dtype=np.float64)
+        assert np.abs(a - b).max() <= gtol * max(np.abs(b).max(), 1e-30), k
+    for k in ("variance", "lik_sigma2", "mean_const"):
+        assert abs(g1[k] - g0[k]) <= gtol * max(abs(g0[k]), 1e-12) + (0 if dtype == np.float64 else 1e-6), k
+    val_ref, _ = o.elbo_grad(sva, x, y, lik=lik, sigma2=s2, num_data=2.0 * N, quadrature_n=qn)
+    assert rel(v1, val_ref) < (1e-8 if dtype == np.float64 else 1e-4)
+    model.free()
+    data.free()
+
+
+def test_host_evaluated_route_through_the_point_gradient_kernel(ctx):
+    """svgp_elbo_grad_ext: the host's (dE/dmu, dE/dv) now enter through point_grad_kernel too (one strip instantiation for both
+    likelihood routes): a Gaussian evaluated on the host reproduces the built-in likelihood, across two gradient chunks' worth
+    of strips and with negative-variance clamping off."""
+    N, M, d = 3001, 96, 3
+    x, y, sva, s2 = o.synth_problem(5300, N, M, d)
+    model = device_model(ctx, sva, sigma2=s2)
+    data = _ffi.DeviceData(ctx, x, y, np.float64)
+    vb, _, gb = model.elbo_grad(data, 0, N, 4.0 * N)
+    mu, var = model.marginals(data, 0, N)
+    sum_e = float(np.sum(-0.5 * (np.log(2 * np.pi) + np.log(s2) + ((y - mu) ** 2 + var) / s2)))
+    gmu, gv = (y - mu) / s2, np.full(N, -0.5 / s2)
+    ve, _, ge = model.elbo_grad(data, 0, N, 4.0 * N, ext=(sum_e, gmu, gv))
+    assert rel(ve, vb) < 1e-12
+    for k in ("z", "m", "Lq", "inv_lengthscale"):
+        assert np.abs(np.asarray(ge[k]) - np.asarray(gb[k])).max() <= 1e-9 * np.abs(np.asarray(gb[k])).max(), k
+    model.free()
+    data.free()
+
+
+def test_timing_calls_respect_the_callers_buffer(ctx):
+    """svgp_last_timing writes the 48-byte v2 / v3 layout and not a byte more; svgp_last_timing_sized writes
+    what the caller says it has (and carries ms_chol, the v4 field)."""
+    x, y, sva, s2 = o.synth_problem(5400, 600, 130, 2)
+    model = device_model(ctx, sva, sigma2=s2)
+    data = _ffi.DeviceData(ctx, x, y, np.float64)
+    model.elbo(data, 0, 600, 600.0)
+    lib = ctx.lib
+    buf = (C.c_ubyte * 80)(*([0xAB] * 80))
+    assert lib.svgp_last_timing(ctx.h, C.cast(buf, C.POINTER(_ffi.Timing))) == _ffi.OK
+    assert bytes(buf[48:]) == b"\xab" * 32, "svgp_last_timing wrote past the v3 layout"
+    t3 = _ffi.Timing.from_buffer_copy(bytes(buf[:64]))
+    assert t3.ms_total > 0 and t3.ms_prep > 0 and t3.strip_launches >= 1
+    for nbytes in (0, 8, 48, 56, 64, 80):
+        buf = (C.c_ubyte * 80)(*([0xCD] * 80))
+        assert lib.svgp_last_timing_sized(ctx.h, buf, nbytes) == _ffi.OK
+        wrote = min(nbytes, C.sizeof(_ffi.Timing))
+        assert bytes(buf[wrote:]) == b"\xcd" * (80 - wrote), nbytes
+    t = ctx.timing()
+    assert t.ms_chol > 0 and t.ms_chol <= t.ms_prep and t.ms_total == t3.ms_total
+    assert lib.svgp_last_timing_sized(ctx.h, buf, -1) == _ffi.INVALID_ARG
+    model.free()
+    data.free()
+
+
+def test_dimension_beyond_the_maximum_is_unsupported_everywhere(ctx):
+    """ADVICE r3 (low, 3): the header promises SVGP_UNSUPPORTED for d > SVGP_MAX_D (the host falls back); the data entry points
+    answered SVGP_INVALID_ARG (an ArgumentError in the binding)."""
+    lib = ctx.lib
+    x65 = np.zeros((65, 10))
+    h = C.c_void_p()
+    rc = lib.svgp_data_upload(ctx.h, _ffi.F64, _ffi.COLVECS, 65, 10, x65.ctypes.data_as(C.c_void_p), None, C.byref(h))
+    assert rc == _ffi.UNSUPPORTED
+    rc = lib.svgp_data_wrap_device(ctx.h, _ffi.F64, 65, 10, 10, C.c_void_p(0x1000), None, C.byref(h))
+    assert rc == _ffi.UNSUPPORTED
+    with pytest.raises(_ffi.UnsupportedError):
+        _ffi.DeviceData(ctx, x65, np.zeros(10), np.float64)
+    rc = lib.svgp_data_upload(ctx.h, _ffi.F64, _ffi.COLVECS, 0, 10, x65.ctypes.data_as(C.c_void_p), None, C.byref(h))
+    assert rc == _ffi.INVALID_ARG
