@@ -176,19 +176,30 @@ KernelParams kparams(const svgp_model* m) {
 }
 
 // The M-sized work of posterior(sva): enqueue only, no sync.
-int enqueue_prep(svgp_ctx* ctx, svgp_model* m) {
+// overlap (NonCentered only): everything the strips need besides T - the scaled inducing inputs, U = Lq', the padded mean - is
+// enqueued FIRST and ctx->ev_fork recorded behind it; the factorisation then records ctx->ev_row[p] as block row p of T becomes
+// final, so that strips on a second stream can run beside it (enqueue_strips_overlapped).
+int enqueue_prep(svgp_ctx* ctx, svgp_model* m, bool overlap = false) {
   hipStream_t s = ctx->stream;
   const KernelParams kp = kparams(m);
   HIPC(ctx, hipMemsetAsync(m->info, 0, sizeof(int) * size_t(1 + m->Mp / 128), s));   // info + the factorisation's hand-over counters
   launch_scale_inputs(m->dtype, s, m->z_raw, m->desc.layout_z, m->d, m->M, m->Mp, m->invl, m->zs);
   KCHECK(ctx, "scale_inputs");
+  if (overlap) {
+    launch_pack_q(m->dtype, s, m->Lq_raw, m->m_raw, m->M, m->Mp, m->U, m->mp);          // B = Lq      SVA:183-184
+    KCHECK(ctx, "pack_q");
+    HIPC(ctx, hipEventRecord(ctx->ev_fork, s));
+    HIPC(ctx, hipEventRecord(ctx->ev_ov[0], s));
+  }
   launch_kuu(m->dtype, s, kp, m->zs, m->M, m->Mp, m->desc.jitter, m->L);
   KCHECK(ctx, "kuu");
   HIPC(ctx, hipEventRecord(ctx->ev_chol[0], s));
-  launch_potrf(m->dtype, s, m->L, m->T, m->Mp, m->info, reinterpret_cast<unsigned*>(m->info + 1));   // T panels included
+  launch_potrf(m->dtype, s, m->L, m->T, m->Mp, m->info, reinterpret_cast<unsigned*>(m->info + 1), overlap ? ctx->ev_row : nullptr);   // T panels included
   KCHECK(ctx, "potrf");
   HIPC(ctx, hipEventRecord(ctx->ev_chol[1], s));
-  if (m->desc.parametrization == SVGP_NONCENTERED) {
+  if (overlap) {
+    launch_kl_terms(m->dtype, s, m->Lq_raw, m->m_raw, m->L, m->M, m->Mp, m->scal);        // SVA:364-373
+  } else if (m->desc.parametrization == SVGP_NONCENTERED) {
     launch_pack_q(m->dtype, s, m->Lq_raw, m->m_raw, m->M, m->Mp, m->U, m->mp);          // B = Lq      SVA:183-184
     launch_kl_terms(m->dtype, s, m->Lq_raw, m->m_raw, m->L, m->M, m->Mp, m->scal);        // SVA:364-373
   } else {
@@ -236,10 +247,38 @@ int ensure_scratch(svgp_ctx* ctx, size_t work_bytes, size_t npoints) {
 // second stream (+ fork / join events, its own strip queue head) for launches that run BESIDE the main stream's
 int ensure_stream2(svgp_ctx* ctx) {
   if (ctx->stream2) return SVGP_OK;
-  HIPC(ctx, hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
+  // the second stream carries work that runs BESIDE the main stream's (the ragged tail of a large batch, the segmented strips beside
+  // the factorisation): lowest priority, so that where both have workgroups to dispatch the main stream's serial chain goes first
+  static const int prio_knob = [] { const char* e = getenv("SVGP_STREAM2_LOW_PRIO"); return e ? atoi(e) : 1; }();   // A/B knob
+  int least = 0, greatest = 0;
+  if (prio_knob && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && least != greatest) {
+    HIPC(ctx, hipStreamCreateWithPriority(&ctx->stream2, hipStreamNonBlocking, least));
+  } else {
+    HIPC(ctx, hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
+  }
   HIPC(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
   HIPC(ctx, hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
   HIPC(ctx, hipMalloc(&ctx->counter2, 64));
+  return SVGP_OK;
+}
+
+int ensure_overlap(svgp_ctx* ctx, size_t state_doubles) {
+  int rc = ensure_stream2(ctx);
+  if (rc) return rc;
+  if (!ctx->ev_row_ready) {
+    for (auto& e : ctx->ev_row)
+      if (!e) HIPC(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    for (auto& e : ctx->ev_ov)
+      if (!e) HIPC(ctx, hipEventCreate(&e));
+    ctx->ev_row_ready = true;
+  }
+  if (state_doubles > ctx->seg_state_doubles) {
+    if (ctx->seg_state) (void)hipFree(ctx->seg_state);
+    ctx->seg_state = nullptr;
+    ctx->seg_state_doubles = 0;
+    HIPC(ctx, hipMalloc(&ctx->seg_state, state_doubles * sizeof(double)));
+    ctx->seg_state_doubles = state_doubles;
+  }
   return SVGP_OK;
 }
 
@@ -353,6 +392,80 @@ int enqueue_strips(svgp_ctx* ctx, svgp_model* m, const void* x, int64_t ldx, con
   return SVGP_OK;
 }
 
+// ---- prep beside the strips (round 4) --------------------------------------------------------------------
+// The M-sized prep is a serial chain of ~2 nP launches (0.43 ms at M = 1024 whatever the batch) and minibatches are where real
+// callers live.  Phase 1 of panel I needs only block row I of T, final after panel step I of the factorisation.  For a batch of
+// at most one round of strips the evaluation therefore runs as SEGMENTED strips (strip.hip: SEG) on the second stream: the Kuf
+// pre-generation right away, phase-1 panel I behind ev_row[I], phase 2 with the last panel; the main stream joins before the
+// expectation.  Nothing spins and no launch waits while resident, so the factorisation's launches always find free CUs.
+struct OverlapPlan { bool on = false; int nt = 0, grid = 0; int64_t nstrips = 0; };
+
+OverlapPlan overlap_plan(const svgp_ctx* ctx, const svgp_model* m, int64_t len, const StripOuts& o) {
+  OverlapPlan p;
+  const char* e = getenv("SVGP_OVERLAP");   // read per call (the tests toggle it inside one process); default: on
+  if (e && atoi(e) == 0) return p;
+  const int nP = int(m->Mp / 128);
+  // measured (profiles/round4/overlap.md, f64, one round of strips): M = 256 +5 %, 512 0..-4 %, 1024 -9..-11 %, 2048 -19 %: the
+  // 2 nP extra launches and the chain's slowdown beside the strips are paid back from about six panels on
+  const char* q = getenv("SVGP_OVERLAP_MIN_PANELS");   // per call, like SVGP_OVERLAP
+  const int min_panels = q ? atoi(q) : 5;
+  if (m->desc.parametrization != SVGP_NONCENTERED || m->d > 16 || nP < min_panels || nP > potrf_max_row_events()) return p;
+  if (o.A || o.C || o.At || o.Ct) return p;
+  const StripPlan sp = strip_plan(m->dtype, m->Mp, len, ctx->num_cus);
+  if (sp.concurrent_tail || (sp.grid && sp.nt_tail)) return p;
+  p.nt = sp.grid ? sp.nt : sp.nt_tail;
+  p.nstrips = sp.grid ? sp.nstrips : sp.nstrips_tail;
+  p.grid = sp.grid ? sp.grid : sp.grid_tail;
+  if (p.nstrips > p.grid) return OverlapPlan{};   // more than one round: the one-launch kernel behind the prep (dynamic queue)
+  p.on = true;
+  return p;
+}
+
+int enqueue_strips_overlapped(svgp_ctx* ctx, svgp_model* m, const void* x, int64_t ldx, const void* y, int64_t off, int64_t len,
+                              const StripOuts& o, const OverlapPlan& op) {
+  hipStream_t s = ctx->stream, s2 = ctx->stream2;
+  const int nP = int(m->Mp / 128);
+  int rc = ensure_scratch(ctx, strip_work_bytes(m->dtype, m->Mp, op.nt, int(op.nstrips)), size_t(len));
+  if (rc) return rc;
+  StripArgs a{};
+  a.T = m->T; a.U = m->U; a.zs = m->zs; a.mp = m->mp; a.x = x; a.work = ctx->work; a.counter = ctx->counter2;
+  a.mom_mu = ctx->mom; a.mom_var = ctx->mom + ctx->mom_cap;
+  a.ldx = ldx; a.off = off; a.len = len; a.Mp = m->Mp; a.M = m->M; a.kp = kparams(m); a.mean_const = m->desc.mean_const;
+  a.seg_state = ctx->seg_state;
+  HIPC(ctx, hipStreamWaitEvent(s2, ctx->ev_fork, 0));
+  a.seg_flags = kSegPregen; a.seg_lo = 0; a.seg_hi = 0;
+  launch_strip_seg(m->dtype, s2, a, op.nt, op.grid, op.nstrips);
+  KCHECK(ctx, "strip (segmented: pre-generation)");
+  for (int I = 0; I < nP; ++I) {
+    HIPC(ctx, hipStreamWaitEvent(s2, ctx->ev_row[I], 0));
+    a.seg_lo = I; a.seg_hi = I + 1;
+    a.seg_flags = (I > 0 ? kSegLoad : 0) | (I + 1 < nP ? kSegStore : kSegPhase2);
+    launch_strip_seg(m->dtype, s2, a, op.nt, op.grid, op.nstrips);
+    KCHECK(ctx, "strip (segmented: panel)");
+    if (I == 0) HIPC(ctx, hipEventRecord(ctx->ev_ov[1], s2));
+  }
+  HIPC(ctx, hipEventRecord(ctx->ev_join, s2));
+  HIPC(ctx, hipStreamWaitEvent(s, ctx->ev_join, 0));
+  HIPC(ctx, hipEventRecord(ctx->ev[2], s));
+  if (o.skip_expect) return SVGP_OK;
+  LikParams lp{};
+  lp.lik = m->desc.likelihood;
+  lp.gh_n = m->gh_n;
+  lp.sigma2 = lik_param(m->desc);
+  lp.digamma_alpha = m->desc.likelihood == SVGP_LIK_GAMMA_EXP ? digamma_d(m->desc.lik_sigma2) : 0.0;
+  lp.gh_x = m->gh_x;
+  lp.gh_w = m->gh_w;
+  lp.clamp_neg_var = (m->desc.neg_var_policy == SVGP_NEGVAR_CLAMP);
+  lp.mean_const = m->desc.mean_const;
+  launch_expect(m->dtype, s, lp, a.mom_mu, a.mom_var, y, off, len, ctx->partial, ctx->negcnt, o.mu, o.var);
+  KCHECK(ctx, "expect");
+  launch_final_reduce(s, ctx->partial, ctx->negcnt, expect_blocks(len), m->info, double(len), ctx->d_res, m->scal);
+  KCHECK(ctx, "final_reduce");
+  ctx->timing.strip_launches = nP + 1;
+  HIPC(ctx, hipGetLastError());
+  return SVGP_OK;
+}
+
 int check_batch(svgp_ctx* ctx, const svgp_model* m, const svgp_data* data, int64_t off, int64_t len, bool need_y) {
   if (!ctx) return SVGP_INVALID_ARG;
   if (!m || !data) return fail(ctx, SVGP_INVALID_ARG, "null model or data");
@@ -373,11 +486,19 @@ struct ElboRead {
 int elbo_enqueue(svgp_ctx* ctx, svgp_model* m, const svgp_data* data, int64_t off, int64_t len) {
   hipStream_t s = ctx->stream;
   HIPC(ctx, hipSetDevice(ctx->device));
+  const OverlapPlan op = overlap_plan(ctx, m, len, StripOuts{});
+  int rc = SVGP_OK;
+  if (op.on) {
+    rc = ensure_overlap(ctx, size_t(op.nstrips) * strip_seg_state_doubles(m->dtype, op.nt));
+    if (rc) return rc;
+  }
+  ctx->overlapped = op.on;
   HIPC(ctx, hipEventRecord(ctx->ev[0], s));
-  int rc = enqueue_prep(ctx, m);
+  rc = enqueue_prep(ctx, m, op.on);
   if (rc) return rc;
   HIPC(ctx, hipEventRecord(ctx->ev[1], s));
-  rc = enqueue_strips(ctx, m, data->x, data->ldx, data->y, off, len, StripOuts{});
+  rc = op.on ? enqueue_strips_overlapped(ctx, m, data->x, data->ldx, data->y, off, len, StripOuts{}, op)
+             : enqueue_strips(ctx, m, data->x, data->ldx, data->y, off, len, StripOuts{});
   if (rc) return rc;
   HIPC(ctx, hipEventRecord(ctx->ev[3], s));
   return SVGP_OK;
@@ -428,6 +549,11 @@ int elbo_finish(svgp_ctx* ctx, svgp_model* m, ElboRead* out) {
   float tch = 0;
   (void)hipEventElapsedTime(&tch, ctx->ev_chol[0], ctx->ev_chol[1]);
   ctx->timing.ms_chol = tch;
+  ctx->timing.ms_overlap = 0;
+  if (ctx->overlapped) {   // the part of the prep the strips ran beside: from their first launch's completion to the prep's end
+    float tov = 0;
+    if (hipEventElapsedTime(&tov, ctx->ev_ov[1], ctx->ev[1]) == hipSuccess && tov > 0) ctx->timing.ms_overlap = tov;
+  }
   out->E = res[0];
   out->n_points = res[1];
   out->n_neg = res[2];
@@ -589,6 +715,11 @@ int32_t svgp_ctx_destroy(svgp_ctx* c) {
   if (c->counter) (void)hipFree(c->counter);
   if (c->counter2) (void)hipFree(c->counter2);
   if (c->work2) (void)hipFree(c->work2);
+  for (auto& e : c->ev_row)
+    if (e) (void)hipEventDestroy(e);
+  for (auto& e : c->ev_ov)
+    if (e) (void)hipEventDestroy(e);
+  if (c->seg_state) (void)hipFree(c->seg_state);
   if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
   if (c->ev_join) (void)hipEventDestroy(c->ev_join);
   if (c->stream2) { (void)hipStreamSynchronize(c->stream2); (void)hipStreamDestroy(c->stream2); }
@@ -1013,7 +1144,8 @@ int grad_workspace(svgp_ctx* ctx, svgp_model* m, int64_t len, GradWs** out) {
       {&w->LbarRM, mm}, {&w->Phi, mm}, {&w->tmp, mm}, {&w->H, mm}, {&w->LinvRM, mm}, {&w->LinvCM, mm},
       // the user-layout blocks hold M d + M + M^2 elements; sized by Mp because the workspace is reused for every model of the
       // same (dtype, Mp, d), whatever its M (M = 45 then M = 96 on one context overran the smaller buffers)
-      {&w->gblk, (size_t(Mp) * m->d + size_t(Mp)) * es + mm}, {&w->BbarRM, mm}, {&w->rbar, size_t(Mp) * es},
+      {&w->gblk, (size_t(Mp) * m->d + size_t(Mp)) * es + mm}, {&w->cblk, (size_t(Mp) * m->d + size_t(Mp)) * es + mm / 2 + size_t(Mp) * es},
+      {&w->BbarRM, mm}, {&w->rbar, size_t(Mp) * es},
       {&w->W2, mm}, {&w->Rcm, mm}, {&w->G1p, mm}, {&w->alpha, size_t(Mp) * es}, {(void**)&w->avec, size_t(Mp) * 8},
       {(void**)&w->gemv_part, size_t(Mp / 128) * size_t(Mp) * 8},
       {&w->zero_blk, w->zero_b},
@@ -1170,6 +1302,10 @@ int grad_enqueue(svgp_ctx* ctx, svgp_model* m, const svgp_data* data, int64_t of
   // beside P.  (Round-2 three-way A/B, ms: H 97.8 -> 95.4 with the kgrad prefetch alone, 99.0 with the in-strip form; H32 53.6 ->
   // 53.0 -> 52.35; C5 16.25 -> 16.2 -> 15.9; C3 208.3 -> 217.2 -> 209.6.)
   static const int afk_knob = [] { const char* e = getenv("SVGP_A_FROM_K"); return e ? atoi(e) : 1; }();   // A/B knob
+  // the SYRK's weights 2 g_v are uniform over the points for the built-in Gaussian likelihood (grad.hip: UW) unless a variance was
+  // negative and clamped (then that point's g_v differs... it does not: dE/dv = -1 / (2 sigma^2) whatever v) - so: Gaussian, built in
+  const char* uw_env = getenv("SVGP_SYRK_UNIFORM");   // A/B knob, read per call (the equivalence test toggles it)
+  const bool uniform_w = m->desc.likelihood == SVGP_LIK_GAUSSIAN && !gc.ext_gmu && m->gh_n == 0 && (!uw_env || atoi(uw_env) != 0);
   const bool a_in_strips = (dt == SVGP_F32) && !post;
   const bool a_from_k = !a_in_strips && afk_knob;
   for (int64_t c0 = 0; c0 < len; c0 += nc) {
@@ -1223,7 +1359,15 @@ int grad_enqueue(svgp_ctx* ctx, svgp_model* m, const svgp_data* data, int64_t of
     launch_sum5(s, w->partial5, n5, w->sums);
     int64_t sl = ((ncp + ns_syrk - 1) / ns_syrk + 15) / 16 * 16;   // as even as the 16-point k-step allows
     // W (+)= A diag(2 g_v) A' (lower tiles, split-K slices): the first chunk overwrites, so the slice buffer needs no zeroing
-    launch_gemm_pm(dt, s, w->At, w->At, w->gv, 2.0, Mp, ncp, sl, ns_syrk, w->G1, c0 == 0 ? 1 : 0);
+    if (uniform_w) {
+      // g_v is the same for every point (Gaussian: -scale / (2 sigma^2)): the unweighted loop, the weight applied to the accumulators.
+      // Columns of the chunk's last strip beyond its last point hold the replicated last point: zero them up to the k-step boundary
+      const int64_t n16 = (clen + 15) / 16 * 16;
+      if (n16 > clen) HIPC(ctx, hipMemsetAsync(static_cast<char*>(w->At) + size_t(clen) * size_t(Mp) * es, 0, size_t(n16 - clen) * size_t(Mp) * es, s));
+      launch_syrk_uniform(dt, s, w->At, -0.5 / lp.sigma2, scale, n_global_dev, gc.num_data, 2.0, Mp, n16, sl, ns_syrk, w->G1, c0 == 0 ? 1 : 0);
+    } else {
+      launch_gemm_pm(dt, s, w->At, w->At, w->gv, 2.0, Mp, ncp, sl, ns_syrk, w->G1, c0 == 0 ? 1 : 0);
+    }
     KCHECK(ctx, "syrk");
     if (kg_overlap) HIPC(ctx, hipStreamWaitEvent(s, ctx->ev_join, 0));
   }
@@ -1236,7 +1380,7 @@ int grad_enqueue(svgp_ctx* ctx, svgp_model* m, const svgp_data* data, int64_t of
   gemm_mm(ctx, w, dt, s, w->Rcm, w->W2, Mp, w->G2);           // (R W)[r][c] = sum_i R[r][i] W[i][c]
   launch_avec(s, w->rp_uf, w->ns_uf, int64_t(2 + dreg) * Mp, Mp, w->avec);
   if (a_from_k)   // avec holds Kuf g_mu: A g_mu = Lk^-1 (Kuf g_mu)
-    launch_linv_t_gemv(dt, s, w->LinvCM, w->avec, Mp, w->avec, w->gemv_part, 1);
+    launch_linv_t_gemv(dt, s, w->LinvCM, w->avec, Mp, w->avec, w->gemv_part, 1, 1);   // avec is fp64 in both builds
   launch_finish_mm2(dt, s, w->G1p, w->G2, w->alpha, w->avec, Mp, M, centered ? m->B : m->Lq_raw, centered ? Mp : M, klw, w->Lqbar,
                     centered ? w->BbarRM : nullptr, w->LbarRM);
   KCHECK(ctx, "Lq_bar / Lk_bar");
@@ -1306,17 +1450,18 @@ int grad_fail_collective(svgp_ctx* ctx, const svgp_model* m, int pre_rc) {
   };
   if (!m || m->M < 1 || m->d < 1 || hipSetDevice(ctx->device) != hipSuccess) return give_up();
   const size_t es = m->es, M = size_t(m->M), nz = M * size_t(m->d), nsum = size_t(8 + 1 + grad_dreg(m->d));
+  const size_t ncoll = nz + M + M * (M + 1) / 2;   // {z_bar | m_bar | packed tril(Lq_bar)}: exactly grad_collective's count
   DevBuf blocks, sums;
-  if (blocks.alloc((nz + M + M * M) * es) != hipSuccess || sums.alloc(nsum * 8) != hipSuccess) return give_up();
+  if (blocks.alloc(ncoll * es) != hipSuccess || sums.alloc(nsum * 8) != hipSuccess) return give_up();
   hipStream_t s = ctx->stream;
-  if (hipMemsetAsync(blocks.p, 0, (nz + M + M * M) * es, s) != hipSuccess || hipMemsetAsync(sums.p, 0, nsum * 8, s) != hipSuccess)
+  if (hipMemsetAsync(blocks.p, 0, ncoll * es, s) != hipSuccess || hipMemsetAsync(sums.p, 0, nsum * 8, s) != hipSuccess)
     return give_up();
   launch_set2_f64(s, ctx->d_coll, 0.0, 1.0);
   launch_set_f64(s, static_cast<double*>(sums.p) + 7, 1.0);
   int rc = comm_allreduce(ctx, ctx->d_coll, 2, SVGP_F64);
   if (rc == SVGP_OK) rc = comm_group_start(ctx);
   if (rc == SVGP_OK) {
-    rc = comm_allreduce(ctx, blocks.p, nz + M + M * M, m->dtype);   // {z_bar | m_bar | Lq_bar}: the same counts as grad_collective
+    rc = comm_allreduce(ctx, blocks.p, ncoll, m->dtype);   // the same counts as grad_collective
     if (rc == SVGP_OK) rc = comm_allreduce(ctx, sums.p, nsum, SVGP_F64);
     const int rce = comm_group_end(ctx);
     if (rc == SVGP_OK) rc = rce;
@@ -1347,12 +1492,17 @@ int grad_collective(svgp_ctx* ctx, svgp_model* m, GradCall& gc, int local_rc) {
       return local_rc;
     }
   }
+  // {z_bar | m_bar | tril(Lq_bar)}: the lower triangle packed (M (M + 1) / 2 entries instead of M^2: SURVEY 8 f1), one all-reduce in
+  // the compute dtype, one in fp64 for the scalars, then unpacked in place
+  const int64_t M = m->M, head = M * m->d + M;
+  const size_t ncoll = size_t(head) + size_t(M) * size_t(M + 1) / 2;
+  if (hipSetDevice(ctx->device) == hipSuccess) launch_pack_tril(m->dtype, ctx->stream, w->gblk, w->cblk, head, M, 0);
   int rc = comm_group_start(ctx);
-  // {z_bar | m_bar | Lq_bar} are contiguous for this model's M (grad_enqueue): one all-reduce in the compute dtype, one in fp64
-  if (rc == SVGP_OK) rc = comm_allreduce(ctx, w->gblk, size_t(m->M) * m->d + size_t(m->M) + size_t(m->M) * m->M, m->dtype);
+  if (rc == SVGP_OK) rc = comm_allreduce(ctx, w->cblk, ncoll, m->dtype);
   if (rc == SVGP_OK) rc = comm_allreduce(ctx, w->sums, size_t(8 + 1 + dreg), SVGP_F64);
   const int rce = comm_group_end(ctx);
   if (rc == SVGP_OK) rc = rce;
+  if (rc == SVGP_OK) launch_pack_tril(m->dtype, ctx->stream, w->gblk, w->cblk, head, M, 1);
   if (rc != SVGP_OK) {
     comm_abort(ctx);
     if (local_rc != SVGP_OK) ctx->err = keep;

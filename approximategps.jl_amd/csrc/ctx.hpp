@@ -30,6 +30,11 @@ struct svgp_ctx {
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   unsigned* counter2 = nullptr;
   void* work2 = nullptr;      size_t work2_bytes = 0;
+  // strips beside the factorisation (enqueue_strips_overlapped): one event per block row of T, the segmented strips' saved sums
+  hipEvent_t ev_row[16] = {};
+  bool ev_row_ready = false, overlapped = false;
+  hipEvent_t ev_ov[2] = {nullptr, nullptr};   // timed: fork point, first strip launch done (svgp_timing.ms_overlap)
+  double* seg_state = nullptr; size_t seg_state_doubles = 0;
   void* kuf_buf = nullptr;    size_t kuf_bytes = 0;
   double* ext_g = nullptr;    size_t ext_cap = 0;           // [2][ext_cap] point gradients of a host-evaluated likelihood
   struct GradWs* gws = nullptr;  // gradient workspace, cached by problem shape
@@ -53,6 +58,7 @@ struct GradWs {
   // the user-layout gradient blocks {z_bar (M d) | m_bar (M) | Lq_bar (M^2)}: ONE allocation, contiguous for the model's M, so
   // that the data-parallel sum is one ncclAllReduce and the read-back one copy; zbar / mbar / Lqbar point into it (set per call)
   void *gblk = nullptr, *zbar = nullptr, *mbar = nullptr, *Lqbar = nullptr;
+  void* cblk = nullptr;   // the same block with Lq_bar packed to its lower triangle: what the collective all-reduces (M d + M + M (M + 1) / 2)
   // accumulators zeroed by ONE memset per evaluation: [rp_uf | sp_uf | rp_uu | sp_uu | sums (8) | scal_out (1 + dreg) | prep (5)]
   void* zero_blk = nullptr;
   size_t zero_b = 0;

@@ -634,6 +634,69 @@ struct TileGemm {
     }
     mma_frag<ILO, IHI>(acc, f[1]);
   }
+  // ---- a weighted twin of astep (the SYRK W = A diag(w) A'), round 4, MEASURED AND REJECTED (kept as an A/B build, SVGP_WSTEP).
+  // A separate function, NOT a branch of astep: the strips' kernels, which instantiate the unweighted step, change their register
+  // allocation with any edit of it (212 -> 255 VGPRs + 4 spills when this was first written as one function).  The idea: fetch
+  // the four weights a lane needs in a step in ONE go behind the barrier and scale the next step's slab-0 fragments AFTER the
+  // closing MFMAs.  rocprofv3, H, f64, per 65 536-point chunk (profiles/round4/syrk_weights.md): round-3 step 1267 us, this twin
+  // 1402 (with the scheduling barrier) / 1436 (without), a timing-only build with NO weights 1174.  So the weights cost 7 % and
+  // it is the 8 v_mul_f64 per step themselves (f64 VALU never co-executes with the MFMA pipe), not where they wait; the product
+  // keeps the round-3 step and drops the weights altogether where they are uniform (Gaussian likelihood: grad.hip).
+#ifndef SVGP_WSTEP
+#define SVGP_WSTEP 0   // 0 = the round-3 step (weights read per slab: the product), 1 = the twin below with the scheduling barrier, 2 = without
+#endif
+  struct WRegs { T w[4]; };
+  static __device__ __forceinline__ void load_w(WRegs& wr, const T* __restrict__ wl) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) wr.w[q] = wl[q * 4];
+  }
+  template <int KSLAB>
+  static __device__ __forceinline__ void scale_bw(Frag& f, const WRegs& wr) {
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) f.b[j] *= wr.w[KSLAB];
+  }
+  template <typename QSrc, typename WSrc>
+  static __device__ __forceinline__ void astep_w(Acc& acc, Frag (&f)[2], WRegs& wr, const T* __restrict__ Pbase, int64_t pstride,
+                                                 const AOff& off, int t, int nsteps, QSrc& qsrc, WSrc& wsrc, T* __restrict__ smem,
+                                                 int& b, const AFrag& fr) {
+    constexpr int PER_TILE = DMA_PER_TILE + 1;
+    static_assert(BK / 4 == 4, "written for 16-deep steps");
+    const T* fa = fr.a + b * PA_TILE;
+    const T* fb0 = fr.b0 + b * QA_TILE;
+    const T* fb1 = fr.b1 + b * QA_TILE;
+    T* Ws = smem + NBUF * (PA_TILE + QA_TILE);
+    load_afrag<1>(f[1], fa, fb0, fb1);
+    mma_frag(acc, f[0]);
+    scale_bw<1>(f[1], wr);
+    load_afrag<2>(f[0], fa, fb0, fb1);
+    mma_frag(acc, f[1]);
+    scale_bw<2>(f[0], wr);
+    load_afrag<3>(f[1], fa, fb0, fb1);
+    mma_frag(acc, f[0]);
+    scale_bw<3>(f[1], wr);
+    if (t + 1 < nsteps) {
+      if (t + 2 < nsteps) wait_barrier<PER_TILE>();
+      else wait_barrier<0>();
+      const int bn = (b + 1 == NBUF) ? 0 : b + 1;
+      load_w(wr, Ws + bn * W_TILE + ((threadIdx.x & 63) >> 4));   // this step's weights are all consumed
+      load_afrag<0>(f[0], fr.a + bn * PA_TILE, fr.b0 + bn * QA_TILE, fr.b1 + bn * QA_TILE);
+      if (t + 3 < nsteps) {   // buffer b (tile t) is free now
+        dma_tile(Pbase + int64_t(t + 3) * pstride, qsrc(t + 3), off, smem + b * PA_TILE, smem + NBUF * PA_TILE + b * QA_TILE);
+        dma_w(wsrc(t + 3), Ws + b * W_TILE);
+      }
+      b = bn;
+      mma_frag(acc, f[1]);
+#ifndef SVGP_WSTEP
+#define SVGP_WSTEP 1   // A/B builds: 0 = the round-3 step (weights read per slab), 1 = this with the scheduling barrier, 2 = without it
+#endif
+#if SVGP_WSTEP == 1
+      __builtin_amdgcn_sched_barrier(0);   // the closing MFMAs first: the fresh LDS reads land under them
+#endif
+      scale_bw<0>(f[0], wr);
+    } else {
+      mma_frag(acc, f[1]);
+    }
+  }
 #define SVGP_ASTEP(LO, HI, TT) astep<LO, HI>(acc, f, Pbase, pstride, off, (TT), nsteps, qsrc, wsrc, smem, b, fr)
   template <int TRI, typename QSrc>
   static __device__ __forceinline__ void loop_tri_async(Acc& acc, const T* __restrict__ Pbase, int64_t ldp, int nsteps,
@@ -677,7 +740,13 @@ struct TileGemm {
       t = ND;
     }
     const int nreg = (TRI > 0) ? nsteps - ND : nsteps;
-    for (; t < nreg; ++t) astep<0, MI - 1>(acc, f, Pbase, pstride, off, t, nsteps, qsrc, wsrc, smem, b, fr);
+    if constexpr (W && TRI == 0 && SVGP_WSTEP != 0) {
+      WRegs wr;
+      load_w(wr, Ws + ((threadIdx.x & 63) >> 4));   // f[0] was scaled above through scale_b (once per loop)
+      for (; t < nreg; ++t) astep_w(acc, f, wr, Pbase, pstride, off, t, nsteps, qsrc, wsrc, smem, b, fr);
+    } else {
+      for (; t < nreg; ++t) astep<0, MI - 1>(acc, f, Pbase, pstride, off, t, nsteps, qsrc, wsrc, smem, b, fr);
+    }
     if (TRI > 0) {
       SVGP_ASTEP(0, 3, nreg + 0); SVGP_ASTEP(0, 3, nreg + 1); SVGP_ASTEP(1, 3, nreg + 2); SVGP_ASTEP(1, 3, nreg + 3);
       SVGP_ASTEP(2, 3, nreg + 4); SVGP_ASTEP(2, 3, nreg + 5); SVGP_ASTEP(3, 3, nreg + 6); SVGP_ASTEP(3, 3, nreg + 7);

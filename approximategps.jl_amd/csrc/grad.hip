@@ -204,9 +204,16 @@ struct StepWeights {   // the 16 weights of k-step t
 // The data-sized SYRK on the fully asynchronous loop (device_common.hpp: loop_tri_async_w; round 3): both operand tiles and
 // the 16 weights of a step travel global -> LDS by DMA through three buffers, the weights scale the Q fragments as they are
 // read (2 v_mul per 8 MFMAs in f64).  Same work items, same partial sums layout as gemm_pm_kernel; lower tiles only.
-template <typename T, int NT>
+// UW (round 4): UNIFORM weights - every point of the chunk carries the same weight (the Gaussian likelihood: g_v = -scale / (2 sigma^2)
+// whatever the point), so W = w A A' and the loop is the unweighted one; the weight meets the accumulators once, in the epilogue.
+// The per-k weights cost the f64 kernel 7 % (8 v_mul_f64 per 32 MFMAs on a pipe that does not co-execute them: rocprofv3, H, 1267 ->
+// 1174 us per 65 536-point chunk).  `uw` = {weight without the data scale, data scale or 0, num_data}: with a device-resident batch
+// size (collective calls) the scale is num_data / *n_global_dev, read here.  The caller zeroes the rows of At between the chunk's
+// last point and the end of its last 16-point k-step (the weighted form met them with zero weights).
+struct UniformW { double w; double scale; double num_data; const double* n_global_dev; };
+template <typename T, int NT, bool UW = false>
 __global__ void __launch_bounds__(k256, 2) syrk_async_kernel(const T* __restrict__ At, const T* __restrict__ w, T wscale, int64_t Mp, int64_t n,
-                                                             int64_t slice_len, T* __restrict__ out, int overwrite) {
+                                                             int64_t slice_len, T* __restrict__ out, int overwrite, UniformW uw) {
   using G = TileGemm<T, NT, 16, k256>;
   static_assert(G::kAsync, "tile shape without an asynchronous loop");
   constexpr int NCH = kNB / NT;
@@ -225,8 +232,17 @@ __global__ void __launch_bounds__(k256, 2) syrk_async_kernel(const T* __restrict
     const T* yq = At + i0 * Mp + int64_t(tj) * kNB + chunk * NT;
     const T* w0 = w + i0;
     auto qsrc = [&](int t) { return yq + int64_t(t) * 16 * Mp; };
-    StepWeights<T> wsrc{w0};
-    G::template loop_tri_async_w<0>(acc, At + i0 * Mp + int64_t(ti) * kNB, Mp, int((i1 - i0) / 16), qsrc, wsrc, smem, Mp);
+    if constexpr (UW) {
+      (void)w0;
+      G::template loop_tri_async<0>(acc, At + i0 * Mp + int64_t(ti) * kNB, Mp, int((i1 - i0 + 15) / 16), qsrc, smem, Mp);
+    } else {
+      StepWeights<T> wsrc{w0};
+      G::template loop_tri_async_w<0>(acc, At + i0 * Mp + int64_t(ti) * kNB, Mp, int((i1 - i0) / 16), qsrc, wsrc, smem, Mp);
+    }
+  }
+  if constexpr (UW) {
+    const double sc = uw.n_global_dev ? (uw.num_data > 0.0 ? uw.num_data / *uw.n_global_dev : 1.0) : uw.scale;
+    wscale = T(double(wscale) * uw.w * sc);
   }
   T* o = out + int64_t(blockIdx.y) * Mp * Mp + int64_t(ti) * kNB * Mp + int64_t(tj) * kNB + chunk * NT;
 #pragma unroll
@@ -321,8 +337,8 @@ __global__ void __launch_bounds__(k256, 2) linv_step_kernel(const T* __restrict_
 // rows k of panel by for its 64 columns r (thread (r, g) takes k = g, g + 4, ...: a row of LinvRM is read contiguously, the
 // loads of a thread are independent), the panel partials are then added in a fixed order.  (One stage with a serial loop over
 // all k per thread ran at the L2 latency: 88 us at M = 1024.)
-template <typename T>
-__global__ void __launch_bounds__(k256) linv_t_gemv_kernel(const T* __restrict__ LinvRM, const T* __restrict__ v, int64_t Mp,
+template <typename T, typename VT>
+__global__ void __launch_bounds__(k256) linv_t_gemv_kernel(const T* __restrict__ LinvRM, const VT* __restrict__ v, int64_t Mp,
                                                            double* __restrict__ part, int notrans) {
   // notrans: the same sum over the COLUMN-major copy, restricted to k <= r:  out[r] = sum_{k <= r} Linv[r][k] v[k] = (Lk^-1 v)_r
   __shared__ double sh[4][64];
@@ -771,10 +787,16 @@ void launch_linv(int dtype, hipStream_t s, const void* L, const void* Tm, int64_
   });
 }
 
-void launch_linv_t_gemv(int dtype, hipStream_t s, const void* LinvRM, const void* v, int64_t Mp, void* out, double* part, int notrans) {
+void launch_linv_t_gemv(int dtype, hipStream_t s, const void* LinvRM, const void* v, int64_t Mp, void* out, double* part, int notrans,
+                        int vec_f64) {
   const int nP = int(Mp / kNB);
+  if (vec_f64 && dtype != 0) {   // fp32 matrix, fp64 vector in and out (the accumulated Kuf g_mu of the kernel-gradient reductions)
+    hipLaunchKernelGGL((linv_t_gemv_kernel<float, double>), dim3((unsigned)(Mp / 64), (unsigned)nP), dim3(k256), 0, s, (const float*)LinvRM, (const double*)v, Mp, part, notrans);
+    hipLaunchKernelGGL(gemv_finish_kernel<double>, dim3((unsigned)((Mp + 255) / 256)), dim3(256), 0, s, part, nP, Mp, (double*)out);
+    return;
+  }
   GD(dtype, T, {
-    hipLaunchKernelGGL(linv_t_gemv_kernel<T>, dim3((unsigned)(Mp / 64), (unsigned)nP), dim3(k256), 0, s, (const T*)LinvRM, (const T*)v, Mp, part, notrans);
+    hipLaunchKernelGGL((linv_t_gemv_kernel<T, T>), dim3((unsigned)(Mp / 64), (unsigned)nP), dim3(k256), 0, s, (const T*)LinvRM, (const T*)v, Mp, part, notrans);
     hipLaunchKernelGGL(gemv_finish_kernel<T>, dim3((unsigned)((Mp + 255) / 256)), dim3(256), 0, s, part, nP, Mp, (T*)out);
   });
 }
@@ -794,7 +816,7 @@ void launch_gemm_pm(int dtype, hipStream_t s, const void* Xt, const void* Yt, co
       auto kern = syrk_async_kernel<T, NT>;
       set_max_lds(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, int(G::ASYNC_W_LDS_BYTES));
       hipLaunchKernelGGL(kern, dim3((unsigned)(ntiles * (kNB / NT)), (unsigned)nslices), dim3(k256), G::ASYNC_W_LDS_BYTES, s,
-                         (const T*)Xt, (const T*)w, T(wscale), Mp, n, slice_len, (T*)out, overwrite);
+                         (const T*)Xt, (const T*)w, T(wscale), Mp, n, slice_len, (T*)out, overwrite, UniformW{});
     });
     return;
   }
@@ -812,6 +834,19 @@ void launch_gemm_pm(int dtype, hipStream_t s, const void* Xt, const void* Yt, co
       hipLaunchKernelGGL(kern, dim3((unsigned)ntiles, (unsigned)nslices), dim3(kThreads), G::LDS_BYTES, s, (const T*)Xt,
                          (const T*)Yt, (const T*)w, T(wscale), Mp, n, slice_len, (T*)out, overwrite, flags);
     }
+  });
+}
+
+void launch_syrk_uniform(int dtype, hipStream_t s, const void* At, double w, double scale, const double* n_global_dev, double num_data,
+                         double wscale, int64_t Mp, int64_t n, int64_t slice_len, int nslices, void* out, int overwrite) {
+  const int nP = int(Mp / kNB), ntiles = nP * (nP + 1) / 2;
+  GD(dtype, T, {
+    constexpr int NT = sizeof(T) == 8 ? 64 : 128;
+    using G = TileGemm<T, NT, 16, k256>;
+    auto kern = syrk_async_kernel<T, NT, true>;
+    set_max_lds(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, int(G::ASYNC_LDS_BYTES));
+    hipLaunchKernelGGL(kern, dim3((unsigned)(ntiles * (kNB / NT)), (unsigned)nslices), dim3(k256), G::ASYNC_LDS_BYTES, s, (const T*)At,
+                       (const T*)nullptr, T(wscale), Mp, n, slice_len, (T*)out, overwrite, UniformW{w, scale, num_data, n_global_dev});
   });
 }
 
@@ -862,7 +897,30 @@ void launch_cm_tril_to_user(int dtype, hipStream_t s, const void* R, int64_t Mp,
   GD(dtype, T, hipLaunchKernelGGL(cm_tril_to_user_kernel<T>, grid, dim3(256), 0, s, (const T*)R, Mp, M, (T*)out));
 }
 
+// The collective gradient's compute-dtype block {z_bar | m_bar | Lq_bar}: Lq_bar is lower triangular, so only its M (M + 1) / 2
+// entries travel (SURVEY 8 f1 counts M^2 / 2 for the all-reduce; round 3 sent the full M x M block, half of it zeros).  Packed by
+// columns: entry (r >= c) at head + c M - c (c - 1) / 2 + (r - c).  dir 0: gblk -> packed, dir 1: packed -> gblk (upper untouched: zero).
+template <typename T>
+__global__ void pack_tril_kernel(T* __restrict__ gblk, T* __restrict__ packed, int64_t head, int64_t M, int dir) {
+  const int64_t r = int64_t(blockIdx.x) * blockDim.x + threadIdx.x, c = blockIdx.y;
+  if (c == 0 && r < head) {   // z_bar | m_bar: copied as they are (head = M d + M entries, by the first grid row and its neighbours)
+    if (dir == 0) packed[r] = gblk[r]; else gblk[r] = packed[r];
+  }
+  if (c == 0)
+    for (int64_t q = r + int64_t(gridDim.x) * blockDim.x; q < head; q += int64_t(gridDim.x) * blockDim.x) {
+      if (dir == 0) packed[q] = gblk[q]; else gblk[q] = packed[q];
+    }
+  if (r >= M || r < c) return;
+  const int64_t pi = head + c * M - c * (c - 1) / 2 + (r - c), gi = head + c * M + r;
+  if (dir == 0) packed[pi] = gblk[gi]; else gblk[gi] = packed[pi];
+}
+
 __global__ void add_f64_kernel(double* p, double v) { *p += v; }
+void launch_pack_tril(int dtype, hipStream_t s, void* gblk, void* packed, int64_t head, int64_t M, int dir) {
+  dim3 grid((unsigned)((M + 255) / 256), (unsigned)M);
+  GD(dtype, T, hipLaunchKernelGGL(pack_tril_kernel<T>, grid, dim3(256), 0, s, (T*)gblk, (T*)packed, head, M, dir));
+}
+
 void launch_add_f64(hipStream_t s, double* p, double v) { hipLaunchKernelGGL(add_f64_kernel, dim3(1), dim3(1), 0, s, p, v); }
 
 void launch_finish_kgrad(int dtype, hipStream_t s, int d, int64_t M, int64_t Mp, const void* zs, const double* invl,

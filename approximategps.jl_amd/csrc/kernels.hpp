@@ -38,7 +38,9 @@ void launch_kuu(int dtype, hipStream_t s, const KernelParams& kp, const void* zs
 // Blocked Cholesky in place (lower).  T receives the inverted 128x128 diagonal blocks AND, since round 3, its panels
 // T[I, <I] = -inv(L_II) * L[I, <I] (computed inside the factorisation's own launches); info = 0 or the 1-based order of the
 // first non-positive pivot; sync: Mp / 128 zeroed counters (device) for the in-kernel hand-over of the next diagonal block.
-void launch_potrf(int dtype, hipStream_t s, void* A, void* T, int64_t Mp, int* info, unsigned* sync);
+// row_events (nullable; Mp / 128 <= potrf_max_row_events() events): event p is recorded on `s` once block row p of T is final
+void launch_potrf(int dtype, hipStream_t s, void* A, void* T, int64_t Mp, int* info, unsigned* sync, hipEvent_t* row_events = nullptr);
+int potrf_max_row_events();
 // U = Lq' (upper triangular, Mp x Mp col-major, zero padding); also mp[i] = m[i] padded with zeros.
 void launch_pack_q(int dtype, hipStream_t s, const void* Lq, const void* m, int64_t M, int64_t Mp, void* U, void* mp);
 // scal[0] = sum(Lq.^2 lower), scal[1] = m'm, scal[2] = sum log diag Lq, scal[3] = sum log diag Lk (first M)
@@ -60,6 +62,7 @@ void launch_shift_vec(int dtype, hipStream_t s, const void* m, double shift, int
 void launch_extract_lower(int dtype, hipStream_t s, const void* A, int64_t Mp, int64_t M, void* out);
 
 // ---- strip.hip -------------------------------------------------------------------------------
+enum : int { kSegPregen = 1, kSegPhase2 = 2, kSegLoad = 4, kSegStore = 8 };   // StripArgs::seg_flags
 struct StripArgs {
   const void* T;     // Mp x Mp col-major: block rows of inv(L_II) * [-L_I,<I | I]
   const void* U;     // Mp x Mp col-major: B' (upper triangular)
@@ -92,6 +95,11 @@ struct StripArgs {
   double scale;               // num_data / n_batch ...
   const double* n_global_dev; // ... or, data-parallel, num_data / *n_global_dev (0 -> 1)
   double num_data;
+  // ---- segmented forward strips (launch_strip_seg): one launch covers the phase-1 panels [seg_lo, seg_hi) of every strip ----
+  int seg_flags;              // kSegPregen 1: generate the Kuf block first; kSegPhase2 2: phase 2 + moments after the panels;
+                              // kSegLoad 4 / kSegStore 8: restore / save the threads' fp64 column sums in seg_state
+  int seg_lo, seg_hi;
+  double* seg_state;          // [nstrips][256][2 NJ]; `work` then holds ONE scratch strip PER STRIP (nstrips x Mp x NT)
 };
 int strip_nt(int dtype, int64_t Mp, int64_t len);                 // column-strip width chosen for a problem
 size_t strip_work_bytes(int dtype, int64_t Mp, int nt, int grid);  // workspace bytes
@@ -106,6 +114,8 @@ struct StripPlan {       // regular-width launch over the first `points` points,
 StripPlan strip_plan(int dtype, int64_t Mp, int64_t len, int num_cus);
 StripPlan strip_plan_single(int dtype, int64_t Mp, int64_t len, int num_cus);   // never a concurrent tail (paths that write A / C)
 void launch_strip(int dtype, hipStream_t s, const StripArgs& a, int nt, int grid, int64_t nstrips);
+void launch_strip_seg(int dtype, hipStream_t s, const StripArgs& a, int nt, int grid, int64_t nstrips);
+size_t strip_seg_state_doubles(int dtype, int nt);
 // the value-and-gradient form: phase 1 as launch_strip, then phase 3 (a dense Mp x Mp GEMM R A on the strip's A, still in its
 // scratch strip, whose epilogue also gives the variance) and the per-point likelihood gradients; writes At_out, Pt_out (R A,
 // unscaled), gmu_out, gv_out, part5.  `work` must hold TWO scratch strips per workgroup (2 x strip_work_bytes).
@@ -150,13 +160,19 @@ void launch_grad_status(hipStream_t s, double* sums, const int* chol_info, doubl
 enum : int { kMmFull = 1, kMmXLow = 2, kMmYLow = 4, kMmXUp = 8, kMmYUp = 16 };
 void launch_gemm_pm(int dtype, hipStream_t s, const void* Xt, const void* Yt, const void* w, double wscale, int64_t Mp,
                     int64_t n, int64_t slice_len, int nslices, void* out, int overwrite = 0, int flags = 0);
+// the data-sized SYRK with UNIFORM weights (Gaussian likelihood): out (+)= wscale * w * scale * At' At over the first n points (slices of
+// slice_len); scale = num_data / *n_global_dev when n_global_dev is given.  Rows [n, ceil16(n)) of At must be zero.
+void launch_syrk_uniform(int dtype, hipStream_t s, const void* At, double w, double scale, const double* n_global_dev, double num_data,
+                         double wscale, int64_t Mp, int64_t n, int64_t slice_len, int nslices, void* out, int overwrite);
 // out (lower 128-tiles, or all with full) (+)= the sum of `ns` slice partials written by launch_gemm_pm(..., overwrite = 1)
 void launch_sum_slices_lower(int dtype, hipStream_t s, const void* part, int ns, int64_t Mp, void* out, int full = 0, int overwrite = 0);
 // Linv = Lk^-1 by recursive doubling from the inverted diagonal blocks in T: LinvRM row-major, LinvCM column-major (only
 // the lower block triangle is written / ever read); Ytmp: Mp x Mp scratch
 void launch_linv(int dtype, hipStream_t s, const void* L, const void* Tm, int64_t Mp, void* LinvRM, void* LinvCM, void* Ytmp);
 // out = Lk^-T v = LinvRM' v; part: (Mp / 128) x Mp doubles of scratch
-void launch_linv_t_gemv(int dtype, hipStream_t s, const void* LinvRM, const void* v, int64_t Mp, void* out, double* part, int notrans = 0);
+// vec_f64: v and out are fp64 whatever the matrix dtype (the kernel-gradient reductions keep their sums in fp64)
+void launch_linv_t_gemv(int dtype, hipStream_t s, const void* LinvRM, const void* v, int64_t Mp, void* out, double* part, int notrans = 0,
+                        int vec_f64 = 0);
 // data part: Pt = the strips' unscaled R A, P_ij = alpha_i gmu_j + 2 gv_j Pt_ji formed inside (alpha != nullptr); Kuu part: Pt is
 // the matrix itself (alpha = gmu = gv = nullptr); At: (A g_mu) row sums beside it (f64 builds), else nullptr
 void launch_kgrad(int dtype, hipStream_t s, const KernelParams& kp, const void* zs, int64_t Mp, const void* x, int64_t ldx,
@@ -178,6 +194,8 @@ void launch_mbar(int dtype, hipStream_t s, const double* avec, const void* mt, d
 void launch_lbar_adjust(int dtype, hipStream_t s, void* LkbarRM, const void* RBt, const void* rbar, const void* mt, int64_t Mp);
 void launch_cm_tril_to_user(int dtype, hipStream_t s, const void* R, int64_t Mp, int64_t M, void* out);   // R column-major
 void launch_add_f64(hipStream_t s, double* p, double v);   // *p += v
+// {head entries | M x M column-major lower-triangular block} <-> {head entries | its M (M + 1) / 2 packed entries}; dir 0 packs
+void launch_pack_tril(int dtype, hipStream_t s, void* gblk, void* packed, int64_t head, int64_t M, int dir);
 void launch_finish_kgrad(int dtype, hipStream_t s, int d, int64_t M, int64_t Mp, const void* zs, const double* invl,
                          const double* rp_uf, int ns_uf, const double* rp_uu, int ns_uu, const double* sp_uf, int nsp_uf,
                          const double* sp_uu, int nsp_uu, const void* m, double klw, int layout_z, double variance,

@@ -898,7 +898,7 @@ void dbg(const char* name, hipStream_t s) {
 }
 
 template <typename T>
-void potrf_t(hipStream_t s, T* A, T* Tm, int64_t Mp, int* info, unsigned* sync) {
+void potrf_t(hipStream_t s, T* A, T* Tm, int64_t Mp, int* info, unsigned* sync, hipEvent_t* row_events) {
   using G = TileGemm<T, kNB, 16>;
   const int nP = int(Mp / kNB);
   constexpr size_t lds_potf2 = potf2_lds_bytes<T>();
@@ -929,6 +929,9 @@ void potrf_t(hipStream_t s, T* A, T* Tm, int64_t Mp, int* info, unsigned* sync) 
       hipLaunchKernelGGL((chol_tile_kernel<T, MODE_TRSM, CNT>), dim3((n + nt_p) * NCH), dim3(k256), GS::LDS_BYTES, s, A, Tm, Mp, p, n, info, sync);
       dbg("chol trsm + T panels", s);
     }
+    // block row p of T (inv(L_pp) from the block factorisation, T[p, J < p] from the launch above) is final here: the strips'
+    // phase 1 of panel p may start (api.hip: enqueue_strips_overlapped waits for this event on its own stream)
+    if (row_events && t_inside) (void)hipEventRecord(row_events[p], s);
     if (n == 0) break;
     const int nt = n * (n + 1) / 2;
     const bool large = nt >= 256;   // a trailing matrix that fills the chip by itself: full 128 x 128 tiles (half the operand traffic)
@@ -992,9 +995,11 @@ void launch_kuu(int dtype, hipStream_t s, const KernelParams& kp, const void* zs
 
 // T must be zero above the diagonal on entry (the model's buffer is cleared once at creation): the factorisation writes the
 // lower triangles of the inverted diagonal blocks and the T panels below them only
-void launch_potrf(int dtype, hipStream_t s, void* A, void* T, int64_t Mp, int* info, unsigned* sync) {
-  SVGP_DISPATCH(dtype, potrf_t<double>(s, (double*)A, (double*)T, Mp, info, sync), potrf_t<float>(s, (float*)A, (float*)T, Mp, info, sync));
+void launch_potrf(int dtype, hipStream_t s, void* A, void* T, int64_t Mp, int* info, unsigned* sync, hipEvent_t* row_events) {
+  SVGP_DISPATCH(dtype, potrf_t<double>(s, (double*)A, (double*)T, Mp, info, sync, row_events),
+                potrf_t<float>(s, (float*)A, (float*)T, Mp, info, sync, row_events));
 }
+int potrf_max_row_events() { return 16; }   // block rows of T are final one by one only while they ride in the TRSM launches (nP <= 16)
 
 void launch_pack_q_ld(int dtype, hipStream_t s, const void* Lq, int64_t ldq, const void* m, int64_t M, int64_t Mp, void* U,
                        void* mp) {

@@ -196,8 +196,18 @@ enum : int { kPgBuiltin = 0, kPgExternal = 1, kPgPost = 2 };
 // BIGD (round 4): the instantiation for 16 < d <= 64.  A separate kernel, not a branch: with the 32- / 64-feature pre-generation
 // bodies inside, the register allocation of the WHOLE kernel changed (the headline f64 kernel went from 0 to 335 spilled VGPRs) -
 // so the d <= 16 kernels stay bit for bit what they were and the wide-input kernels hold only the wide bodies.
-template <typename T, int NT, int BK, int NTHR, int MINW = 2, int PAD = 16, bool GRAD = false, int PG = kPgBuiltin, bool BIGD = false>
+// SEG (round 4, forward builds): the SEGMENTED form for strips that run BESIDE the factorisation of Kuu (api.hip:
+// enqueue_strips_overlapped).  Phase 1 of panel I needs nothing of the prep but block row I of T, which is final after panel
+// step I of the Cholesky; so a batch of at most one round of strips is evaluated as a sequence of short launches on a second
+// stream - pre-generation, then one launch per panel (each behind the event of its T row), then phase 2 + moments - instead of
+// one launch behind the whole prep.  A launch covers the panels [seg_lo, seg_hi); between launches a strip's state is its scratch
+// strip (per STRIP here, not per workgroup) and the fp64 column sums its threads carry, saved and restored register for register,
+// so that the arithmetic - and the result, bit for bit - is that of the one-launch kernel.  No spinning, no flags: a launch that
+// is waiting occupies nothing, so the factorisation's own launches always find the chip (VERDICT r3 item 2 asked for flag-gated
+// persistent strips; those hold every CU while they wait - DESIGN section 3 "prep beside the strips").
+template <typename T, int NT, int BK, int NTHR, int MINW = 2, int PAD = 16, bool GRAD = false, int PG = kPgBuiltin, bool BIGD = false, bool SEG = false>
 __global__ void __launch_bounds__(NTHR, MINW) strip_kernel(StripArgs a, int64_t nstrips) {
+  static_assert(!(SEG && GRAD), "the segmented form is a forward build");
   constexpr bool EXT = (PG == kPgExternal);
   using G = TileGemm<T, NT, BK, NTHR, PAD>;
   using Acc = typename G::Acc;
@@ -231,10 +241,10 @@ __global__ void __launch_bounds__(NTHR, MINW) strip_kernel(StripArgs a, int64_t 
   const int d = a.kp.d, family = a.kp.family;
   const T variance = T(a.kp.variance);
   const int nP = int(Mp / NB);
-  T* __restrict__ work = static_cast<T*>(a.work) + int64_t(blockIdx.x) * Mp * NT;
+  T* __restrict__ work = static_cast<T*>(a.work) + int64_t(blockIdx.x) * Mp * NT;   // SEG: re-pointed per strip below
   // GRAD: the generated Kuf block keeps a scratch strip of its own (the A strip goes beside it instead of overwriting it panel by
   // panel): phase 3's epilogue needs K again for the variance (see below).  Forward builds: one strip, K overwritten in place.
-  T* __restrict__ workK = GRAD ? static_cast<T*>(a.work) + (int64_t(gridDim.x) + blockIdx.x) * Mp * NT : work;
+  T* __restrict__ workK = GRAD ? static_cast<T*>(a.work) + (int64_t(gridDim.x) + blockIdx.x) * Mp * NT : work;   // not const: SEG re-points it
   const int tid = threadIdx.x, lane = tid & 63;
   const typename G::QOff qoff = G::q_offsets(NT);           // per-thread byte offsets inside a scratch-strip tile
 
@@ -249,6 +259,10 @@ __global__ void __launch_bounds__(NTHR, MINW) strip_kernel(StripArgs a, int64_t 
   __syncthreads();
 #endif
   for (int64_t strip = blockIdx.x; strip < nstrips;) {
+    if constexpr (SEG) {   // a strip's scratch must outlive the launch: indexed by strip, not by workgroup
+      work = static_cast<T*>(a.work) + strip * Mp * NT;
+      workK = work;
+    }
 #ifdef SVGP_STRIP_STAMPS
     const bool stamping = (blockIdx.x == 37 && strips_done >= 1);   // every strip of one workgroup but its first
     if (stamping && threadIdx.x == 0) s_strip_stamps[127] += 1;
@@ -256,9 +270,12 @@ __global__ void __launch_bounds__(NTHR, MINW) strip_kernel(StripArgs a, int64_t 
 #endif
     SVGP_SSTAMP(0);
     const int64_t c0 = strip * NT;                          // first column of the strip inside the batch
-    if (tid == 0) next_strip = gridDim.x + atomicAdd(a.counter, 1u);
+    if constexpr (SEG) { if (tid == 0) next_strip = unsigned(strip + gridDim.x); }   // static schedule: launches are at most one round
+    else if (tid == 0) next_strip = gridDim.x + atomicAdd(a.counter, 1u);
     const int64_t last = a.off + a.len - 1;
+    const bool do_pregen = !SEG || (a.seg_flags & kSegPregen);
     // scaled inputs of the strip -> LDS (columns past the batch end replicate the last point; masked later)
+    if (do_pregen)
     for (int e = tid; e < dl * NT; e += NTHR) {
       const int f = e / NT, c = e % NT;
       int64_t g = a.off + c0 + c;
@@ -266,7 +283,7 @@ __global__ void __launch_bounds__(NTHR, MINW) strip_kernel(StripArgs a, int64_t 
       xs[e] = (f < d) ? x[int64_t(f) * a.ldx + g] * invl[f] : T(0);
     }
     __syncthreads();
-    {
+    if (do_pregen) {
       auto pregen = [&](auto fam) {
         constexpr int F = decltype(fam)::value;
         using V = typename G::V;
@@ -319,10 +336,20 @@ __global__ void __launch_bounds__(NTHR, MINW) strip_kernel(StripArgs a, int64_t 
     double sA[NJ], sM[NJ], sC[NJ];
 #pragma unroll
     for (int j = 0; j < NJ; ++j) sA[j] = sM[j] = sC[j] = 0.0;
+    int I_lo = 0, I_hi = nP;
+    if constexpr (SEG) {
+      I_lo = a.seg_lo;
+      I_hi = a.seg_hi;
+      if (a.seg_flags & kSegLoad) {   // the column sums this thread carried out of the previous launch of the strip
+        const double* __restrict__ st = a.seg_state + (strip * NTHR + tid) * (2 * NJ);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) { sA[j] = st[j]; sM[j] = st[NJ + j]; }
+      }
+    }
 
     // ---------------- phase 1: A = Lk \ Kuf, panel by panel ----------------
     SVGP_SSTAMP(1);
-    for (int I = 0; I < nP; ++I) {
+    for (int I = I_lo; I < I_hi; ++I) {
       SVGP_SSTAMP(2 + 3 * I);
       Acc acc;
       acc.zero();
@@ -365,12 +392,26 @@ __global__ void __launch_bounds__(NTHR, MINW) strip_kernel(StripArgs a, int64_t 
           }
         }
       }
+#if !(defined(SVGP_ABLATE) && (SVGP_ABLATE & 32))   // timing-only builds: bit 32 no point-major A, 64 no point-major R A, 128 no K-dot
       if constexpr (GRAD) store_tile_point_major<G, T, NT, NTHR>(acc, smem, static_cast<T*>(a.At_out), c0, Mp, I * NB);
+#endif
       __syncthreads();  // scratch rows of panel I visible to the whole workgroup
       SVGP_SSTAMP(4 + 3 * I);
     }
 
     // ---------------- phase 2: C = B' A  (forward builds; the value-and-gradient build gets the variance from phase 3) --------
+    if constexpr (SEG) {
+      if (a.seg_flags & kSegStore) {
+        double* __restrict__ st = a.seg_state + (strip * NTHR + tid) * (2 * NJ);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) { st[j] = sA[j]; st[NJ + j] = sM[j]; }
+      }
+      if (!(a.seg_flags & kSegPhase2)) {   // this launch ends here for the strip; phase 2 and the moments come with a later one
+        strip = next_strip;
+        __syncthreads();
+        continue;
+      }
+    }
     if constexpr (!GRAD)
     for (int J = 0; J < nP; ++J) {
       SVGP_SSTAMP(60 + 2 * J);
@@ -423,6 +464,7 @@ __global__ void __launch_bounds__(NTHR, MINW) strip_kernel(StripArgs a, int64_t 
           auto qload = [&](int t, QRegs& r) { G::load_q(r, work + int64_t(t) * BK * NT, qoff); };
           G::template loop_tri<0>(acc, Rm + int64_t(I) * NB, Mp, nP * (NB / BK), qload, smem);
         }
+#if !(defined(SVGP_ABLATE) && (SVGP_ABLATE & 128))
 #pragma unroll
         for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -431,7 +473,15 @@ __global__ void __launch_bounds__(NTHR, MINW) strip_kernel(StripArgs a, int64_t 
 #pragma unroll
             for (int j = 0; j < NJ; ++j) sC[j] = fma(double(acc.v[i][j][r]), double(workK[row * NT + G::acc_col(j)]), sC[j]);
           }
+#else
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) sC[j] += double(acc.v[0][j][0]);
+#endif
+#if !(defined(SVGP_ABLATE) && (SVGP_ABLATE & 64))
         store_tile_point_major<G, T, NT, NTHR>(acc, smem, Pt, c0, Mp, I * NB);
+#else
+        if (acc.v[0][0][0] == T(12345.678)) Pt[c0] = acc.v[0][0][0];   // keep the accumulators live
+#endif
       }
     }
 
@@ -970,7 +1020,7 @@ __global__ void __launch_bounds__(k256) kuf_generic_kernel(KernelParams kp, cons
   }
 }
 
-template <typename T, int NT, int BK, int NTHR, int MINW = 2, int PAD = 16, bool GRAD = false, int PG = kPgBuiltin, bool BIGD = false>
+template <typename T, int NT, int BK, int NTHR, int MINW = 2, int PAD = 16, bool GRAD = false, int PG = kPgBuiltin, bool BIGD = false, bool SEG = false>
 void launch_strip_t(hipStream_t s, const StripArgs& a, int grid, int64_t nstrips) {
   using G = TileGemm<T, NT, BK, NTHR, PAD>;
   // the strip's x image (<= 64 feature rows: SVGP_MAX_D) aliases the staging buffers
@@ -978,7 +1028,7 @@ void launch_strip_t(hipStream_t s, const StripArgs& a, int grid, int64_t nstrips
   static_assert(G::LDS_BYTES >= size_t(64) * NT * sizeof(T) && (!(SVGP_ASYNC && G::kAsync) || G::ASYNC_LDS_BYTES >= size_t(64) * NT * sizeof(T)),
                 "x image must fit the staging buffers");
   static_assert(G::LDS_BYTES >= size_t(5) * NT * sizeof(double), "the five per-strip sums reuse the staging buffers");
-  auto kern = strip_kernel<T, NT, BK, NTHR, MINW, PAD, GRAD, PG, BIGD>;
+  auto kern = strip_kernel<T, NT, BK, NTHR, MINW, PAD, GRAD, PG, BIGD, SEG>;
   set_max_lds(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
   hipLaunchKernelGGL(kern, dim3(grid), dim3(NTHR), lds, s, a, nstrips);
 }
@@ -1098,6 +1148,24 @@ void launch_strip(int dtype, hipStream_t s, const StripArgs& a, int nt, int grid
     if (bk32 && a.kp.d <= 8) launch_strip_t<float, 128, 32, 512>(s, a, grid, nstrips);
     else launch_strip_t<float, 128, 16, 512>(s, a, grid, nstrips);
   }
+}
+
+// the segmented forward strips (a.seg_*): nt = 32 / 64 (f64), 32 / 64 / 128 (f32); d <= 16 (wider inputs take the one-launch path)
+void launch_strip_seg(int dtype, hipStream_t s, const StripArgs& a, int nt, int grid, int64_t nstrips) {
+  if (dtype == 0) {
+    if (nt == 32) launch_strip_t<double, 32, 16, 256, 2, 16, false, kPgBuiltin, false, true>(s, a, grid, nstrips);
+    else launch_strip_t<double, 64, 16, 256, 2, 16, false, kPgBuiltin, false, true>(s, a, grid, nstrips);
+  } else {
+    if (nt == 32) launch_strip_t<float, 32, 16, 256, 2, 16, false, kPgBuiltin, false, true>(s, a, grid, nstrips);
+    else if (nt == 64) launch_strip_t<float, 64, 16, 256, 2, 16, false, kPgBuiltin, false, true>(s, a, grid, nstrips);
+    else launch_strip_t<float, 128, 16, 256, 2, 16, false, kPgBuiltin, false, true>(s, a, grid, nstrips);
+  }
+}
+// doubles of state per strip a segmented launch saves / restores (kernels.hpp: StripArgs::seg_state)
+size_t strip_seg_state_doubles(int dtype, int nt) {
+  const int nj = nt / 2 / 16 > 0 ? nt / 2 / 16 : 1;   // TileGemm::NJ of the 256-thread builds (WC = 2)
+  (void)dtype;
+  return size_t(256) * 2 * nj;
 }
 
 void launch_strip_grad(int dtype, hipStream_t s, const StripArgs& a, int nt, int grid, int64_t nstrips, bool post) {

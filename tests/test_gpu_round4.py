@@ -142,3 +142,129 @@ def test_dimension_beyond_the_maximum_is_unsupported_everywhere(ctx):
         _ffi.DeviceData(ctx, x65, np.zeros(10), np.float64)
     rc = lib.svgp_data_upload(ctx.h, _ffi.F64, _ffi.COLVECS, 0, 10, x65.ctypes.data_as(C.c_void_p), None, C.byref(h))
     assert rc == _ffi.INVALID_ARG
+
+
+def _toggle(name, value):
+    old = os.environ.get(name)
+    os.environ[name] = value
+    return old
+
+
+def _restore(name, old):
+    if old is None:
+        os.environ.pop(name, None)
+    else:
+        os.environ[name] = old
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("N,M,d,lik", [(4096, 512, 8, o.LIK_GAUSSIAN), (16384, 1024, 8, o.LIK_GAUSSIAN), (3000, 300, 3, o.LIK_BERNOULLI_LOGISTIC),
+                                      (777, 1500, 2, o.LIK_POISSON_EXP), (20000, 256, 16, o.LIK_GAUSSIAN), (64, 2048, 1, o.LIK_GAUSSIAN)])
+def test_strips_beside_the_factorisation_are_bitwise_the_serial_result(ctx, dtype, N, M, d, lik):
+    """a batch of at most one round of strips runs as segmented strips on a second stream, panel I behind the
+    event of block row I of T, beside the Cholesky of Kuu (api.hip: enqueue_strips_overlapped).  Per strip the arithmetic is the
+    one-launch kernel's, register for register: ELBO, expectation and the per-point marginals must be IDENTICAL bits with the
+    overlap on and off, repeatedly (a race between the streams would show as a flaky difference), at several M / widths."""
+    x, y, sva, s2 = o.synth_problem(6000 + M, N, M, d, lik=lik, dtype=dtype)
+    model = device_model(ctx, sva, dtype=dtype, lik=lik, sigma2=s2)
+    data = _ffi.DeviceData(ctx, x, y, dtype)
+    old = _toggle("SVGP_OVERLAP", "0")
+    oldp = _toggle("SVGP_OVERLAP_MIN_PANELS", "2")   # the product default (5: where it pays) would skip the small models here
+    try:
+        v0, t0 = model.elbo(data, 0, N, 3.0 * N)
+        os.environ["SVGP_OVERLAP"] = "1"
+        for rep in range(4):
+            v1, t1 = model.elbo(data, 0, N, 3.0 * N)
+            assert v1 == v0 and t1.expectation == t0.expectation and t1.kl == t0.kl, (rep, v1, v0)
+        tm = ctx.timing()
+        off = min(17, N - 1)                     # an offset window, ragged end
+        os.environ["SVGP_OVERLAP"] = "0"
+        w0 = model.elbo(data, off, N - off, 0.0)[0]
+        os.environ["SVGP_OVERLAP"] = "1"
+        assert model.elbo(data, off, N - off, 0.0)[0] == w0
+    finally:
+        _restore("SVGP_OVERLAP", old)
+        _restore("SVGP_OVERLAP_MIN_PANELS", oldp)
+    ref = o.elbo(sva, x, y, lik=lik, sigma2=s2, num_data=3.0 * N)
+    assert rel(v0, ref) < (1e-8 if dtype == np.float64 else 1e-4)
+    if M >= 256:   # two panels at least: the path was really taken (one launch per panel + the pre-generation)
+        assert tm.strip_launches == (M + 127) // 128 + 1, tm.strip_launches
+    model.free()
+    data.free()
+
+
+def test_overlapped_strips_report_a_non_positive_definite_kuu(ctx):
+    """The strips beside the factorisation wait for events, not for values: a failed Cholesky (a negative jitter beyond the
+    smallest eigenvalue) still records every row event, the strips run on garbage and the call returns SVGP_NOT_POSDEF with the
+    failing order - no waiter is left behind, and the context works afterwards."""
+    N, M, d = 5000, 512, 2
+    x, y, sva, s2 = o.synth_problem(6100, N, M, d)
+    bad = o.SVA(sva.kernel, sva.z, sva.m, sva.Lq, jitter=-0.5)
+    old = _toggle("SVGP_OVERLAP", "1")
+    try:
+        model = device_model(ctx, bad, sigma2=s2)
+        data = _ffi.DeviceData(ctx, x, y, np.float64)
+        with pytest.raises(_ffi.PosDefException) as ei:
+            model.elbo(data, 0, N, float(N))
+        with pytest.raises(o.PosDefException) as ref:
+            o.posterior(bad)
+        assert ei.value.info == ref.value.info and 0 < ei.value.info <= 512
+        model.free()
+        good = device_model(ctx, sva, sigma2=s2)
+        v = good.elbo(data, 0, N, float(N))[0]
+        assert rel(v, o.elbo(sva, x, y, sigma2=s2, num_data=float(N))) < 1e-8
+        good.free()
+        data.free()
+    finally:
+        _restore("SVGP_OVERLAP", old)
+
+
+def test_batches_of_more_than_one_round_keep_the_one_launch_path(ctx):
+    """More strips than workgroup slots: the dynamic-queue kernel behind the prep (the segmented form is a one-round schedule)."""
+    N, M, d = 70000, 256, 4
+    x, y, sva, s2 = o.synth_problem(6200, N, M, d)
+    model = device_model(ctx, sva, sigma2=s2)
+    data = _ffi.DeviceData(ctx, x, y, np.float64)
+    old = _toggle("SVGP_OVERLAP", "1")
+    try:
+        v = model.elbo(data, 0, N, float(N))[0]
+        assert ctx.timing().strip_launches <= 2 and ctx.timing().ms_overlap == 0.0
+    finally:
+        _restore("SVGP_OVERLAP", old)
+    assert rel(v, o.elbo(sva, x, y, sigma2=s2, num_data=float(N))) < 1e-8
+    model.free()
+    data.free()
+
+
+@pytest.mark.parametrize("dtype,gtol", [(np.float64, 1e-11), (np.float32, 3e-4)])   # fp32: the two SYRKs round differently and the Cholesky adjoint amplifies it
+@pytest.mark.parametrize("N,M,clamp", [(3001, 200, False), (70001, 130, False), (1000, 64, True)])
+def test_uniform_weight_syrk_equals_the_weighted_one(ctx, dtype, gtol, N, M, clamp):
+    """Gaussian likelihood: d E_i / d v_i = -1 / (2 sigma^2) for every point, so W = A diag(2 g_v) A' is w A A' and the SYRK runs its
+    unweighted loop (grad.hip: UW).  Against the per-point weighted SYRK (SVGP_SYRK_UNIFORM=0): same gradient to rounding, on
+    batches whose length is not a multiple of the 16-point k-step (the replicated columns of the last strip must not count), over
+    more than one gradient chunk, and with the clamping policy on a posterior with negative variances."""
+    x, y, sva, s2 = o.synth_problem(7000 + M, N, M, 3, dtype=dtype)
+    if clamp:   # a q far from the prior: some variances go negative and are clamped; their g_v is still -scale / (2 sigma^2)
+        sva = o.SVA(sva.kernel, sva.z, sva.m, 1e-3 * sva.Lq, jitter=sva.jitter)
+    model = device_model(ctx, sva, dtype=dtype, sigma2=s2, neg_var_policy=_ffi.NEGVAR_CLAMP if clamp else _ffi.NEGVAR_ERROR)
+    data = _ffi.DeviceData(ctx, x, y, dtype)
+    old = _toggle("SVGP_SYRK_UNIFORM", "0")
+    try:
+        v0, t0, g0 = model.elbo_grad(data, 0, N, 2.0 * N)
+        os.environ["SVGP_SYRK_UNIFORM"] = "1"
+        v1, t1, g1 = model.elbo_grad(data, 0, N, 2.0 * N)
+        w1, _, h1 = model.elbo_grad(data, 5, N - 9, 0.0)
+        os.environ["SVGP_SYRK_UNIFORM"] = "0"
+        w0, _, h0 = model.elbo_grad(data, 5, N - 9, 0.0)
+    finally:
+        _restore("SVGP_SYRK_UNIFORM", old)
+    assert v1 == v0 and w1 == w0          # the value does not depend on the SYRK at all
+    if clamp:
+        assert t1.n_neg_var > 0
+    for a, b in ((g1, g0), (h1, h0)):
+        for k in ("z", "m", "Lq", "inv_lengthscale"):
+            p, q = np.asarray(a[k], dtype=np.float64), np.asarray(b[k], dtype=np.float64)
+            assert np.abs(p - q).max() <= gtol * max(np.abs(q).max(), 1e-30), k
+        assert abs(a["variance"] - b["variance"]) <= gtol * max(abs(b["variance"]), 1e-12) * 10
+    model.free()
+    data.free()
