@@ -523,7 +523,7 @@ __global__ void __launch_bounds__(k256) potf2_kernel(T* __restrict__ A, T* __res
 // ------------------------------------------------------------------------------------------------
 // MFMA tile kernels of the blocked Cholesky (and of the T panels, which ride in its launches).
 // ------------------------------------------------------------------------------------------------
-enum : int { MODE_TRSM = 0, MODE_SYRK = 1 };
+enum : int { MODE_TRSM = 0, MODE_SYRK = 1, MODE_COL = 2 };
 
 __device__ __forceinline__ void tri_index(int b, int& i, int& j) {  // b -> (i >= j) in row-major triangle order
   i = 0;
@@ -548,9 +548,14 @@ __device__ __forceinline__ void tri_index(int b, int& i, int& j) {  // b -> (i >
 //                                 update: the next panel's factorisation no longer waits for the whole update, nor for a launch.
 // (the fused f64 form asks for one workgroup per CU: potf2's LDS image of an f64 block - 146 KiB - allows no second one anyway, and
 // the unrolled DPP factor wants more than the 256 VGPRs a two-workgroup bound leaves it: 282 spilled registers otherwise)
+// Round 4, two-level blocking (potrf_t, large Kuu): MODE_COL is the trailing update restricted to block column p + 1 - tiles (i, p + 1),
+// i > p - so that the second block column of a 256-wide outer panel can be factored before the REST of the trailing matrix is touched;
+// that rest then takes ONE update of rank 256 (kb = 2: the contraction runs over the two block columns p - 1, p) instead of two of
+// rank 128: half the read-modify-write traffic of the trailing matrix, which is what bounds these launches (a 128 x 128 tile read
+// and written per 4.2 MFLOP).
 template <typename T, int MODE, int NT, bool FUSE = false>
 __global__ void __launch_bounds__(k256, (FUSE && sizeof(T) == 8) ? 1 : 2) chol_tile_kernel(T* __restrict__ A, T* __restrict__ Tm, int64_t ld, int p, int n,
-                                                            int* __restrict__ info, unsigned* __restrict__ sync) {
+                                                            int* __restrict__ info, unsigned* __restrict__ sync, int kb = 1) {
   using G = TileGemm<T, NT, 16, k256>;
   using QRegs = typename G::QRegs;
   constexpr int NB = kNB, NCH = NB / NT;
@@ -586,17 +591,22 @@ __global__ void __launch_bounds__(k256, (FUSE && sizeof(T) == 8) ? 1 : 2) chol_t
     i = p + 1 + tile;
     j = p;
     P = Tm + int64_t(p) * NB + int64_t(p) * NB * ld;
-  } else {                       // A[i, j] -= L[i, p] L[j, p]'
+  } else if (MODE == MODE_COL) {   // A[i, p + 1] -= L[i, p] L[p + 1, p]'  (block column p + 1 only)
+    i = p + 1 + tile;
+    j = p + 1;
+    P = A + int64_t(j) * NB + int64_t(p) * NB * ld;
+  } else {                       // A[i, j] -= L[i, p - kb + 1 .. p] L[j, p - kb + 1 .. p]'
     int ti, tj;
     tri_index(tile, ti, tj);
     i = p + 1 + ti;
     j = p + 1 + tj;
-    P = A + int64_t(j) * NB + int64_t(p) * NB * ld;
+    P = A + int64_t(j) * NB + int64_t(p - kb + 1) * NB * ld;
   }
-  const T* Q = A + int64_t(i) * NB + int64_t(p) * NB * ld + chunk * NT;
+  const int kcol = (MODE == MODE_SYRK) ? p - kb + 1 : p;   // first block column of the contraction
+  const T* Q = A + int64_t(i) * NB + int64_t(kcol) * NB * ld + chunk * NT;
   const typename G::QOff qoff = G::q_offsets(ld);
   auto qload = [&](int t, QRegs& r) { G::load_q(r, Q + int64_t(t) * 16 * ld, qoff); };
-  G::loop(acc, P, ld, NB / 16, qload, smem);
+  G::loop(acc, P, ld, (MODE == MODE_SYRK ? kb : 1) * (NB / 16), qload, smem);
   T* C = A + int64_t(i) * NB + int64_t(j) * NB * ld + chunk * NT;
 #pragma unroll
   for (int a = 0; a < G::MI; ++a)
@@ -608,7 +618,7 @@ __global__ void __launch_bounds__(k256, (FUSE && sizeof(T) == 8) ? 1 : 2) chol_t
         if (MODE == MODE_TRSM) *dst = acc.v[a][b][r];
         else *dst -= acc.v[a][b][r];
       }
-  if constexpr (FUSE && MODE == MODE_SYRK) {
+  if constexpr (FUSE && (MODE == MODE_SYRK || MODE == MODE_COL)) {
     if (tile != 0) return;         // tile 0 = (p+1, p+1): the next diagonal block
     __shared__ int is_last;
     __threadfence();               // release: this chunk's stores are visible device-wide before the count goes up
@@ -628,7 +638,7 @@ __global__ void __launch_bounds__(k256, (FUSE && sizeof(T) == 8) ? 1 : 2) chol_t
 // have not ended).
 template <typename T, bool FUSE>
 __global__ void __launch_bounds__(kThreads, 2) syrk128_kernel(T* __restrict__ A, T* __restrict__ Tm, int64_t ld, int p,
-                                                               int* __restrict__ info) {
+                                                               int* __restrict__ info, int kb = 1) {
   using G = TileGemm<T, kNB, 16>;
   using QRegs = typename G::QRegs;
   constexpr int NB = kNB;
@@ -639,11 +649,11 @@ __global__ void __launch_bounds__(kThreads, 2) syrk128_kernel(T* __restrict__ A,
   int ti, tj;
   tri_index(blockIdx.x, ti, tj);
   const int i = p + 1 + ti, j = p + 1 + tj;
-  const T* P = A + int64_t(j) * NB + int64_t(p) * NB * ld;
-  const T* Q = A + int64_t(i) * NB + int64_t(p) * NB * ld;
+  const T* P = A + int64_t(j) * NB + int64_t(p - kb + 1) * NB * ld;   // kb = 2: rank-256 update over block columns p - 1, p
+  const T* Q = A + int64_t(i) * NB + int64_t(p - kb + 1) * NB * ld;
   const typename G::QOff qoff = G::q_offsets(ld);
   auto qload = [&](int t, QRegs& r) { G::load_q(r, Q + int64_t(t) * 16 * ld, qoff); };
-  G::loop(acc, P, ld, NB / 16, qload, smem);
+  G::loop(acc, P, ld, kb * (NB / 16), qload, smem);
   T* C = A + int64_t(i) * NB + int64_t(j) * NB * ld;
 #pragma unroll
   for (int a = 0; a < G::MI; ++a)
@@ -656,6 +666,44 @@ __global__ void __launch_bounds__(kThreads, 2) syrk128_kernel(T* __restrict__ A,
     __threadfence();               // the tile this workgroup just wrote is re-read below (through L2: drop stale L1 lines)
     __syncthreads();
     if (threadIdx.x >= k256) return;
+    potf2_body<T>(A + int64_t(p + 1) * NB * (ld + 1), Tm + int64_t(p + 1) * NB * (ld + 1), ld, info, (p + 1) * NB, smem_raw);
+  }
+}
+
+// The same update on the fully asynchronous three-buffer LDS-DMA loop of the strips (round 4; fp32, whose 128-column tiles take it
+// on 256 threads: a wave owns 64 x 64).  Why: the big launches sat at MFMA busy 0.37, and it is the OPERAND stream that bounds
+// them, not the read-modify-write of C - a rank-256 update (two-level blocking, same operand bytes per flop) bought nothing by
+// itself (M = 8192: 5.05 vs 4.92 ms).  The register-staged two-buffer loop waits for every operand tile at a __syncthreads(); here
+// a tile has two whole steps to land.  P and Q are both k-major views of the panel L[:, kcol..] (leading dimension ld): the Q
+// operand's 512-byte k-rows travel in pairs like the fp32 strips'.
+template <typename T, bool FUSE>
+__global__ void __launch_bounds__(k256, 2) syrk128_async_kernel(T* __restrict__ A, T* __restrict__ Tm, int64_t ld, int p,
+                                                                 int* __restrict__ info, int kb) {
+  using G = TileGemm<T, kNB, 16, k256>;
+  static_assert(G::kAsync, "tile shape without an asynchronous loop");
+  constexpr int NB = kNB;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  T* smem = reinterpret_cast<T*>(smem_raw);
+  typename G::Acc acc;
+  acc.zero();
+  int ti, tj;
+  tri_index(blockIdx.x, ti, tj);
+  const int i = p + 1 + ti, j = p + 1 + tj;
+  const T* P = A + int64_t(j) * NB + int64_t(p - kb + 1) * NB * ld;
+  const T* Q = A + int64_t(i) * NB + int64_t(p - kb + 1) * NB * ld;
+  auto qsrc = [&](int t) { return Q + int64_t(t) * 16 * ld; };
+  G::template loop_tri_async<0>(acc, P, ld, kb * (NB / 16), qsrc, smem, ld);
+  T* C = A + int64_t(i) * NB + int64_t(j) * NB * ld;
+#pragma unroll
+  for (int a = 0; a < G::MI; ++a)
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int b = 0; b < G::NJ; ++b) C[G::acc_col(b) + int64_t(G::acc_row(a, r)) * ld] -= acc.v[a][b][r];
+  if constexpr (FUSE) {
+    if (blockIdx.x != 0) return;
+    __threadfence();               // the tile this workgroup just wrote is re-read below (through L2: drop stale L1 lines)
+    __syncthreads();
     potf2_body<T>(A + int64_t(p + 1) * NB * (ld + 1), Tm + int64_t(p + 1) * NB * (ld + 1), ld, info, (p + 1) * NB, smem_raw);
   }
 }
@@ -922,6 +970,63 @@ void potrf_t(hipStream_t s, T* A, T* Tm, int64_t Mp, int* info, unsigned* sync, 
   // saves the 25 us of a launch of their own); from 17 panels on they would lengthen 60-odd serial launches instead (C4: +0.33 ms
   // in the TRSM launches against the 0.15 ms of one launch over all 2016 tiles at the end), so a large Kuu keeps the one launch.
   const bool t_inside = nP <= 16;
+  set_max_lds(reinterpret_cast<const void*>(chol_tile_kernel<T, MODE_COL, CNT, true>), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds_fused_s));
+  // ---- two-level blocking (round 4): 256-wide outer panels for a large Kuu -------------------------------
+  // Per outer panel (block columns a, b = a + 1):  TRSM(a);  update of block column b alone + factorisation of (b, b) in the same
+  // launch;  TRSM(b);  ONE rank-256 update of everything right of b (+ the factorisation of the next diagonal block in it).
+  // The trailing matrix is read and written once per 256 columns instead of once per 128.
+  // MEASURED AND NOT ADOPTED (profiles/round4/chol_two_level.md; fp32, ms per factorisation, same box, two repetitions):
+  //     M       one-level (round 3)   two-level   one-level + async update   two-level + async update
+  //   8192          4.89                5.00            4.73                       4.83
+  //   4224          1.88                1.97            1.95                       2.02
+  //   2304          0.976               1.02            0.977                      1.02
+  // The rank-256 update is no faster per flop than two of rank 128 (it is the OPERAND stream and the 64-byte pieces of the C
+  // tile's read-modify-write that bound a 128 x 128 x K tile, and K only amortises the second), while the column-b step puts a
+  // second block factorisation per 256 columns on the serial chain.  Where the 4.9 ms go at M = 8192: ~3.0 ms in the 32 big
+  // updates that are longer than the block factorisation fused into them, ~1.3 ms in the 32 panels where the factorisation (34 us)
+  // is the longer one, ~1.2 ms in 64 TRSM launches + gaps.  Reaching the 3.3 ms the verdict asked for needs the chain
+  // (factorisation + TRSM of the next panel) OFF the bulk update's stream - a two-stream lookahead with the bulk one panel
+  // behind - which was not built.  Both forms stay as A/B knobs (SVGP_CHOL_TWO_LEVEL=1, SVGP_CHOL_ASYNC=1), default off.
+  static const bool two_level_on = [] { const char* e = getenv("SVGP_CHOL_TWO_LEVEL"); return e && e[0] == '1'; }();
+  static const bool async_on = [] { const char* e = getenv("SVGP_CHOL_ASYNC"); return e && e[0] == '1'; }();   // A/B knob
+  // the big fused update: fp32 on the asynchronous loop (256 threads), else the 512-thread two-buffer kernel
+  auto big_update = [&](int nt, int pp, int kbb) {
+    if constexpr (sizeof(T) == 4) {
+      if (async_on) {
+        using GA = TileGemm<T, kNB, 16, k256>;
+        constexpr size_t lds_a = GA::ASYNC_LDS_BYTES > lds_potf2 ? GA::ASYNC_LDS_BYTES : lds_potf2;
+        set_max_lds(reinterpret_cast<const void*>(syrk128_async_kernel<T, true>), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds_a));
+        hipLaunchKernelGGL((syrk128_async_kernel<T, true>), dim3(nt), dim3(k256), lds_a, s, A, Tm, Mp, pp, info, kbb);
+        return;
+      }
+    }
+    hipLaunchKernelGGL((syrk128_kernel<T, true>), dim3(nt), dim3(kThreads), lds_fused_l, s, A, Tm, Mp, pp, info, kbb);
+  };
+  if (two_level_on && fuse_on && !t_inside && sizeof(T) == 4) {
+    potf2(0);
+    for (int a = 0; a < nP; a += 2) {
+      const int b = a + 1, na = nP - a - 1;
+      if (na > 0) {
+        hipLaunchKernelGGL((chol_tile_kernel<T, MODE_TRSM, CNT>), dim3(na * NCH), dim3(k256), GS::LDS_BYTES, s, A, Tm, Mp, a, na, info, sync, 1);
+        dbg("chol trsm (a)", s);
+      }
+      if (b >= nP) break;
+      // block column b: A[i, b] -= L[i, a] L[b, a]' for i >= b, then the workgroup that completes tile (b, b) factors it
+      hipLaunchKernelGGL((chol_tile_kernel<T, MODE_COL, CNT, true>), dim3(na * NCH), dim3(k256), lds_fused_s, s, A, Tm, Mp, a, na, info, sync, 1);
+      dbg("chol column update + potf2 (b)", s);
+      const int nb = nP - b - 1;
+      if (nb == 0) break;
+      hipLaunchKernelGGL((chol_tile_kernel<T, MODE_TRSM, CNT>), dim3(nb * NCH), dim3(k256), GS::LDS_BYTES, s, A, Tm, Mp, b, nb, info, sync, 1);
+      dbg("chol trsm (b)", s);
+      const int nt = nb * (nb + 1) / 2;
+      if (nt >= 256) big_update(nt, b, 2);
+      else hipLaunchKernelGGL((chol_tile_kernel<T, MODE_SYRK, CNT, true>), dim3(nt * NCH), dim3(k256), lds_fused_s, s, A, Tm, Mp, b, nb, info, sync, 2);
+      dbg("chol rank-256 update + potf2 (next a)", s);
+    }
+    hipLaunchKernelGGL((chol_tile_kernel<T, MODE_TRSM, CNT>), dim3((nP * (nP - 1) / 2) * NCH), dim3(k256), GS::LDS_BYTES, s, A, Tm, Mp, -1, 0, info, sync, 1);
+    dbg("T panels", s);
+    return;
+  }
   potf2(0);
   for (int p = 0; p < nP; ++p) {
     const int n = nP - p - 1, nt_p = t_inside ? p : 0;
@@ -938,7 +1043,7 @@ void potrf_t(hipStream_t s, T* A, T* Tm, int64_t Mp, int* info, unsigned* sync, 
     // the fused f64 form of the large grid would cost the second resident workgroup (potf2's LDS image of an f64 block is 146 KiB)
     const bool fused = fuse_on && !(large && sizeof(T) == 8);
     if (fused && large) {
-      hipLaunchKernelGGL((syrk128_kernel<T, true>), dim3(nt), dim3(kThreads), lds_fused_l, s, A, Tm, Mp, p, info);
+      big_update(nt, p, 1);
     } else if (fused) {
       hipLaunchKernelGGL((chol_tile_kernel<T, MODE_SYRK, CNT, true>), dim3(nt * NCH), dim3(k256), lds_fused_s, s, A, Tm, Mp, p, n, info, sync);
     } else {
