@@ -270,6 +270,7 @@ int ensure_overlap(svgp_ctx* ctx, size_t state_doubles) {
       if (!e) HIPC(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
     for (auto& e : ctx->ev_ov)
       if (!e) HIPC(ctx, hipEventCreate(&e));
+    if (!ctx->ev_R) HIPC(ctx, hipEventCreateWithFlags(&ctx->ev_R, hipEventDisableTiming));
     ctx->ev_row_ready = true;
   }
   if (state_doubles > ctx->seg_state_doubles) {
@@ -719,6 +720,7 @@ int32_t svgp_ctx_destroy(svgp_ctx* c) {
     if (e) (void)hipEventDestroy(e);
   for (auto& e : c->ev_ov)
     if (e) (void)hipEventDestroy(e);
+  if (c->ev_R) (void)hipEventDestroy(c->ev_R);
   if (c->seg_state) (void)hipFree(c->seg_state);
   if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
   if (c->ev_join) (void)hipEventDestroy(c->ev_join);
@@ -1253,8 +1255,28 @@ int grad_enqueue(svgp_ctx* ctx, svgp_model* m, const svgp_data* data, int64_t of
   w->zbar = w->gblk;
   w->mbar = static_cast<char*>(w->gblk) + size_t(M) * m->d * es;
   w->Lqbar = static_cast<char*>(w->mbar) + size_t(M) * es;
+  // Strips beside the factorisation (round 4): a one-chunk, one-round batch runs its phase 1 as segmented strips on the second
+  // stream - panel I behind the event of block row I of T - and its phase 3 behind the M-sized gradient prep (Linv, alpha, R) that
+  // the main stream computes meanwhile.  Same conditions as the forward path (overlap_plan), plus: the whole batch is one chunk.
+  OverlapPlan gop;
+  if (len <= nc && centered == false) {
+    gop = overlap_plan(ctx, m, len, StripOuts{});
+    if (gop.on) {   // the gradient's strips: the single-launch plan's geometry (no concurrent tail there)
+      const StripPlan sp = strip_plan_single(dt, Mp, len, ctx->num_cus);
+      gop.nt = sp.grid ? sp.nt : sp.nt_tail;
+      gop.grid = sp.grid ? sp.grid : sp.grid_tail;
+      gop.nstrips = sp.grid ? sp.nstrips : sp.nstrips_tail;
+      if (gop.nstrips > gop.grid || (sp.grid && sp.nt_tail)) gop.on = false;
+    }
+    if (gop.on) {
+      rc = ensure_overlap(ctx, size_t(gop.nstrips) * strip_seg_state_doubles(dt, gop.nt));
+      if (rc == SVGP_OK) rc = ensure_scratch(ctx, 2 * strip_work_bytes(dt, Mp, gop.nt, int(gop.nstrips)), size_t(nc));
+      if (rc) return rc;
+    }
+  }
+  ctx->overlapped = gop.on;
   HIPC(ctx, hipEventRecord(ctx->ev[0], s));
-  rc = enqueue_prep(ctx, m);
+  rc = enqueue_prep(ctx, m, gop.on);
   if (rc) return rc;
   HIPC(ctx, hipEventRecord(ctx->ev[1], s));
   HIPC(ctx, hipMemsetAsync(w->zero_blk, 0, w->zero_b, s));   // every accumulator of the evaluation, one fill
@@ -1271,6 +1293,7 @@ int grad_enqueue(svgp_ctx* ctx, svgp_model* m, const svgp_data* data, int64_t of
   launch_sym_from_lower(dt, s, w->G2, 1, Mp, 1.0, w->tmp);                 // S = B B' - I, full
   gemm_mm(ctx, w, dt, s, w->tmp, w->LinvRM, Mp, w->Rcm, kMmFull | kMmYLow); // out[c][r] = sum_k S[k][c] Linv[k][r] = R[r][c]: R column-major
   KCHECK(ctx, "grad prep");
+  if (gop.on) HIPC(ctx, hipEventRecord(ctx->ev_R, s));   // R and alpha are final: the segmented strips' closing launch (phase 3) may run
   LikParams lp{};
   lp.lik = m->desc.likelihood;
   lp.gh_n = m->gh_n;
@@ -1295,7 +1318,7 @@ int grad_enqueue(svgp_ctx* ctx, svgp_model* m, const svgp_data* data, int64_t of
   // Who evaluates the likelihood gradients (strip.hip: kPgPost): round 4 - a small kernel behind the strips, for both likelihood
   // routes; SVGP_GRAD_POST=0 keeps the round-3 in-kernel forms (A/B).  In-kernel fp32 builds also form A g_mu per strip (`apart`).
   const char* post_env = getenv("SVGP_GRAD_POST");   // read per call: the equivalence test toggles it inside one process
-  const bool post = post_env ? atoi(post_env) != 0 : true;
+  const bool post = gop.on || (post_env ? atoi(post_env) != 0 : true);   // the segmented strips exist in the post form only
   // A g_mu (the data part of m_bar): in-kernel fp32 - per strip inside the strip kernel, so that kgrad streams P only; otherwise
   // kgrad, which evaluates the kernel anyway, sums Kuf g_mu and the tail applies Lk^-1 (one gemv with the explicit inverse): A is
   // then read by the SYRK only (round 3, f64: 0.32 -> 0.2 ms per 65 536-point chunk at M = 1024); SVGP_A_FROM_K=0: kgrad reads A
@@ -1328,9 +1351,33 @@ int grad_enqueue(svgp_ctx* ctx, svgp_model* m, const svgp_data* data, int64_t of
     LikParams lpc = lp;
     if (gc.ext_gmu) { lpc.lik = kLikExternal; lpc.gh_x = ctx->ext_g + c0; lpc.gh_w = ctx->ext_g + ctx->ext_cap + c0; a.y = nullptr; }
     a.part5 = w->partial5; a.apart = a_in_strips ? w->apart : nullptr; a.lp = lpc; a.scale = scale; a.n_global_dev = n_global_dev; a.num_data = gc.num_data;
-    HIPC(ctx, hipMemsetAsync(ctx->counter, 0, sizeof(unsigned), s));
-    launch_strip_grad(dt, s, a, nt, grid, nstrips, post);
-    KCHECK(ctx, "strip (value and gradient)");
+    if (gop.on) {   // (single chunk) segmented strips on the second stream; the main stream joins before the point gradients
+      hipStream_t s2 = ctx->stream2;
+      const int nPn = int(Mp / 128);
+      a.seg_state = ctx->seg_state;
+      a.counter = ctx->counter2;
+      HIPC(ctx, hipStreamWaitEvent(s2, ctx->ev_fork, 0));
+      a.seg_flags = kSegPregen; a.seg_lo = 0; a.seg_hi = 0;
+      launch_strip_seg(dt, s2, a, nt, grid, nstrips, true);
+      for (int I = 0; I < nPn; ++I) {
+        HIPC(ctx, hipStreamWaitEvent(s2, ctx->ev_row[I], 0));
+        a.seg_lo = I; a.seg_hi = I + 1;
+        a.seg_flags = (I > 0 ? kSegLoad : 0) | kSegStore;
+        launch_strip_seg(dt, s2, a, nt, grid, nstrips, true);
+        if (I == 0) HIPC(ctx, hipEventRecord(ctx->ev_ov[1], s2));
+      }
+      HIPC(ctx, hipStreamWaitEvent(s2, ctx->ev_R, 0));
+      a.seg_lo = a.seg_hi = nPn;
+      a.seg_flags = kSegLoad | kSegPhase2;
+      launch_strip_seg(dt, s2, a, nt, grid, nstrips, true);
+      KCHECK(ctx, "strip (value and gradient, segmented)");
+      HIPC(ctx, hipEventRecord(ctx->ev_join, s2));
+      HIPC(ctx, hipStreamWaitEvent(s, ctx->ev_join, 0));
+    } else {
+      HIPC(ctx, hipMemsetAsync(ctx->counter, 0, sizeof(unsigned), s));
+      launch_strip_grad(dt, s, a, nt, grid, nstrips, post);
+      KCHECK(ctx, "strip (value and gradient)");
+    }
     int n5 = int(nstrips);   // rows of partial5: per strip (in-kernel forms) or per 256-point block (post)
     if (post) {
       launch_point_grads(dt, s, lpc, a.mom_mu, a.mom_var, a.y, off + c0, clen, scale, n_global_dev, gc.num_data, w->gmu, w->gv, w->partial5);

@@ -33,6 +33,7 @@ struct svgp_ctx {
   // strips beside the factorisation (enqueue_strips_overlapped): one event per block row of T, the segmented strips' saved sums
   hipEvent_t ev_row[16] = {};
   bool ev_row_ready = false, overlapped = false;
+  hipEvent_t ev_R = nullptr;                  // the gradient's M-sized prep (Linv, alpha, R) is final: phase 3 of the segmented strips
   hipEvent_t ev_ov[2] = {nullptr, nullptr};   // timed: fork point, first strip launch done (svgp_timing.ms_overlap)
   double* seg_state = nullptr; size_t seg_state_doubles = 0;
   void* kuf_buf = nullptr;    size_t kuf_bytes = 0;

@@ -114,7 +114,7 @@ struct StripPlan {       // regular-width launch over the first `points` points,
 StripPlan strip_plan(int dtype, int64_t Mp, int64_t len, int num_cus);
 StripPlan strip_plan_single(int dtype, int64_t Mp, int64_t len, int num_cus);   // never a concurrent tail (paths that write A / C)
 void launch_strip(int dtype, hipStream_t s, const StripArgs& a, int nt, int grid, int64_t nstrips);
-void launch_strip_seg(int dtype, hipStream_t s, const StripArgs& a, int nt, int grid, int64_t nstrips);
+void launch_strip_seg(int dtype, hipStream_t s, const StripArgs& a, int nt, int grid, int64_t nstrips, bool grad = false);
 size_t strip_seg_state_doubles(int dtype, int nt);
 // the value-and-gradient form: phase 1 as launch_strip, then phase 3 (a dense Mp x Mp GEMM R A on the strip's A, still in its
 // scratch strip, whose epilogue also gives the variance) and the per-point likelihood gradients; writes At_out, Pt_out (R A,

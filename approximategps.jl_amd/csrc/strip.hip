@@ -196,7 +196,7 @@ enum : int { kPgBuiltin = 0, kPgExternal = 1, kPgPost = 2 };
 // BIGD (round 4): the instantiation for 16 < d <= 64.  A separate kernel, not a branch: with the 32- / 64-feature pre-generation
 // bodies inside, the register allocation of the WHOLE kernel changed (the headline f64 kernel went from 0 to 335 spilled VGPRs) -
 // so the d <= 16 kernels stay bit for bit what they were and the wide-input kernels hold only the wide bodies.
-// SEG (round 4, forward builds): the SEGMENTED form for strips that run BESIDE the factorisation of Kuu (api.hip:
+// SEG (round 4): the SEGMENTED form for strips that run BESIDE the factorisation of Kuu (api.hip:
 // enqueue_strips_overlapped).  Phase 1 of panel I needs nothing of the prep but block row I of T, which is final after panel
 // step I of the Cholesky; so a batch of at most one round of strips is evaluated as a sequence of short launches on a second
 // stream - pre-generation, then one launch per panel (each behind the event of its T row), then phase 2 + moments - instead of
@@ -207,7 +207,7 @@ enum : int { kPgBuiltin = 0, kPgExternal = 1, kPgPost = 2 };
 // persistent strips; those hold every CU while they wait - DESIGN section 3 "prep beside the strips").
 template <typename T, int NT, int BK, int NTHR, int MINW = 2, int PAD = 16, bool GRAD = false, int PG = kPgBuiltin, bool BIGD = false, bool SEG = false>
 __global__ void __launch_bounds__(NTHR, MINW) strip_kernel(StripArgs a, int64_t nstrips) {
-  static_assert(!(SEG && GRAD), "the segmented form is a forward build");
+  static_assert(!(SEG && GRAD) || PG == kPgPost, "segmented value-and-gradient strips leave their moments to point_grad_kernel");
   constexpr bool EXT = (PG == kPgExternal);
   using G = TileGemm<T, NT, BK, NTHR, PAD>;
   using Acc = typename G::Acc;
@@ -261,7 +261,7 @@ __global__ void __launch_bounds__(NTHR, MINW) strip_kernel(StripArgs a, int64_t 
   for (int64_t strip = blockIdx.x; strip < nstrips;) {
     if constexpr (SEG) {   // a strip's scratch must outlive the launch: indexed by strip, not by workgroup
       work = static_cast<T*>(a.work) + strip * Mp * NT;
-      workK = work;
+      workK = GRAD ? static_cast<T*>(a.work) + (nstrips + strip) * Mp * NT : work;   // GRAD: the Kuf strips behind the A strips
     }
 #ifdef SVGP_STRIP_STAMPS
     const bool stamping = (blockIdx.x == 37 && strips_done >= 1);   // every strip of one workgroup but its first
@@ -406,7 +406,7 @@ __global__ void __launch_bounds__(NTHR, MINW) strip_kernel(StripArgs a, int64_t 
 #pragma unroll
         for (int j = 0; j < NJ; ++j) { st[j] = sA[j]; st[NJ + j] = sM[j]; }
       }
-      if (!(a.seg_flags & kSegPhase2)) {   // this launch ends here for the strip; phase 2 and the moments come with a later one
+      if (!(a.seg_flags & kSegPhase2)) {   // this launch ends here for the strip; phase 2 (GRAD: phase 3) and the moments come with a later one
         strip = next_strip;
         __syncthreads();
         continue;
@@ -1150,8 +1150,21 @@ void launch_strip(int dtype, hipStream_t s, const StripArgs& a, int nt, int grid
   }
 }
 
-// the segmented forward strips (a.seg_*): nt = 32 / 64 (f64), 32 / 64 / 128 (f32); d <= 16 (wider inputs take the one-launch path)
-void launch_strip_seg(int dtype, hipStream_t s, const StripArgs& a, int nt, int grid, int64_t nstrips) {
+// the segmented strips (a.seg_*): nt = 32 / 64 (f64), 32 / 64 / 128 (f32); d <= 16 (wider inputs take the one-launch path).
+// grad: the value-and-gradient build (phase 1 per panel with the point-major A, then phase 3 + moments in the closing launch;
+// `work` holds 2 x nstrips scratch strips: A, then Kuf)
+void launch_strip_seg(int dtype, hipStream_t s, const StripArgs& a, int nt, int grid, int64_t nstrips, bool grad) {
+  if (grad) {
+    if (dtype == 0) {
+      if (nt == 32) launch_strip_t<double, 32, 16, 256, 2, 16, true, kPgPost, false, true>(s, a, grid, nstrips);
+      else launch_strip_t<double, 64, 16, 256, 2, 16, true, kPgPost, false, true>(s, a, grid, nstrips);
+    } else {
+      if (nt == 32) launch_strip_t<float, 32, 16, 256, 2, 16, true, kPgPost, false, true>(s, a, grid, nstrips);
+      else if (nt == 64) launch_strip_t<float, 64, 16, 256, 2, 16, true, kPgPost, false, true>(s, a, grid, nstrips);
+      else launch_strip_t<float, 128, 16, 256, 2, 16, true, kPgPost, false, true>(s, a, grid, nstrips);
+    }
+    return;
+  }
   if (dtype == 0) {
     if (nt == 32) launch_strip_t<double, 32, 16, 256, 2, 16, false, kPgBuiltin, false, true>(s, a, grid, nstrips);
     else launch_strip_t<double, 64, 16, 256, 2, 16, false, kPgBuiltin, false, true>(s, a, grid, nstrips);

@@ -268,3 +268,38 @@ def test_uniform_weight_syrk_equals_the_weighted_one(ctx, dtype, gtol, N, M, cla
         assert abs(a["variance"] - b["variance"]) <= gtol * max(abs(b["variance"]), 1e-12) * 10
     model.free()
     data.free()
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("N,M,d,lik", [(8192, 1024, 8, o.LIK_GAUSSIAN), (3000, 700, 3, o.LIK_BERNOULLI_LOGISTIC), (16384, 640, 8, o.LIK_POISSON_EXP),
+                                      (500, 1300, 2, o.LIK_GAUSSIAN)])
+def test_gradient_strips_beside_the_factorisation_are_bitwise_the_serial_result(ctx, dtype, N, M, d, lik):
+    """The training step's strips run their phase 1 beside the factorisation too (segmented, panel I behind the event of block row
+    I of T) and their phase 3 behind the M-sized gradient prep (Linv, alpha, R) that the main stream computes meanwhile: value and
+    EVERY gradient block must be identical bits with SVGP_OVERLAP on and off, repeatedly."""
+    x, y, sva, s2 = o.synth_problem(8000 + M, N, M, d, lik=lik, dtype=dtype)
+    model = device_model(ctx, sva, dtype=dtype, lik=lik, sigma2=s2)
+    data = _ffi.DeviceData(ctx, x, y, dtype)
+    old = _toggle("SVGP_OVERLAP", "0")
+    oldp = _toggle("SVGP_OVERLAP_MIN_PANELS", "2")
+    try:
+        v0, t0, g0 = model.elbo_grad(data, 0, N, 2.0 * N)
+        os.environ["SVGP_OVERLAP"] = "1"
+        for rep in range(3):
+            v1, t1, g1 = model.elbo_grad(data, 0, N, 2.0 * N)
+            assert v1 == v0, (rep, v1, v0)
+            for k in ("z", "m", "Lq", "inv_lengthscale"):
+                assert np.array_equal(np.asarray(g1[k]), np.asarray(g0[k])), (rep, k)
+            for k in ("variance", "lik_sigma2", "mean_const"):
+                assert g1[k] == g0[k], (rep, k)
+        # the forward entry point between two gradient calls (shared scratch, shared events)
+        f1 = model.elbo(data, 0, N, 2.0 * N)[0]
+        os.environ["SVGP_OVERLAP"] = "0"
+        assert model.elbo(data, 0, N, 2.0 * N)[0] == f1
+    finally:
+        _restore("SVGP_OVERLAP", old)
+        _restore("SVGP_OVERLAP_MIN_PANELS", oldp)
+    val_ref, g_ref = o.elbo_grad(sva, x, y, lik=lik, sigma2=s2, num_data=2.0 * N)
+    assert rel(v0, val_ref) < (1e-8 if dtype == np.float64 else 1e-4)
+    model.free()
+    data.free()
