@@ -1126,7 +1126,7 @@ int grad_workspace(svgp_ctx* ctx, svgp_model* m, int64_t len, GradWs** out) {
   // buffer and >= 512 points per slice.  Placing the items of a slice on one XCD (they read the same rows of A) was measured
   // and rejected: H 81.9 -> 85-87 ms - the operand re-reads come out of the Infinity Cache at no cost to the MFMA pipe.
   w->nslices = syrk_slices(ctx, m, int64_t(1) << 40);   // the buffer holds the count an unbounded chunk would take: a call's count never exceeds it
-  w->rb = grad_rowblocks(m->d, Mp);
+  w->rb = grad_rowblocks(m->dtype, m->d, Mp);
   static const int kg_wg = [] { const char* e = getenv("SVGP_KGRAD_WG_PER_CU"); return e ? atoi(e) : 2; }();   // tuning knob
   int nu = (kg_wg * ctx->num_cus + w->rb - 1) / w->rb;
   w->ns_uf = nu < 1 ? 1 : (nu > 256 ? 256 : nu);

@@ -580,6 +580,148 @@ __global__ void __launch_bounds__(k256) kgrad_kernel(KernelParams kp, const T* _
   }
 }
 
+// ---- wide inputs: 16 < d <= 64 (round 4) ------------------------------------------------------------------------------------
+// kgrad_kernel keeps a row's d feature slots (z, Q, IL) in the registers of ONE thread: 32 slots still fit, 64 spill by the hundred
+// (an H-sized value-and-gradient evaluation at d = 64 took 590 ms against 78 at d = 8).  Here LPR = 2 / 4 adjacent lanes share a
+// row, 16 features each: the squared distance is completed by LPR - 1 xor-shuffles per (row, point), every lane evaluates the
+// kernel function for itself (no broadcast to wait for) and accumulates only its own features' sums; the row-level sums (R, the
+// m_bar column, sum P K) are kept by the first lane of the group.  Same interface, same partial-sum layout, same fixed-order
+// reductions as kgrad_kernel (rows per workgroup: 64 / LPR).
+template <typename T, int LPR, int FAMILY>
+__global__ void __launch_bounds__(k256) kgrad_wide_kernel(KernelParams kp, const T* __restrict__ zs, int64_t Mp,
+                                                          const T* __restrict__ x, int64_t ldx, int64_t xoff, int prescaled,
+                                                          int64_t n, int64_t nvalid, const T* __restrict__ Pt,
+                                                          const T* __restrict__ At, const T* __restrict__ gmu, const T* __restrict__ gv,
+                                                          const T* __restrict__ alpha, int64_t slice_len,
+                                                          double* __restrict__ rowpart, double* __restrict__ scalpart, int kmb) {
+  constexpr int JB = 128, FL = 16, DL = FL * LPR, RPW = 64 / LPR, U = 4;
+  constexpr bool kF32 = (sizeof(T) == 4);
+  using B = std::conditional_t<kF32, float, double>;   // per-staged-block accumulators (fp32 builds: 32 terms in fp32, then fp64 totals)
+  __shared__ T xt[JB * DL];
+  __shared__ T gms[JB], gvs[JB];
+  __shared__ double red[64 * (2 + FL)];
+  __shared__ double sred[k256];
+  const int d = kp.d;
+  const T* __restrict__ invl = static_cast<const T*>(kp.invl);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, rowl = lane / LPR, fg = lane % LPR;
+  const bool lead = (fg == 0);
+  const int64_t i = int64_t(blockIdx.y) * RPW + rowl;
+  const int64_t j0 = int64_t(blockIdx.x) * slice_len;
+  int64_t j1 = j0 + slice_len;
+  j1 = j1 < n ? j1 : n;
+  T z[FL];
+#pragma unroll
+  for (int f = 0; f < FL; ++f) z[f] = (FL * fg + f < d) ? zs[int64_t(FL * fg + f) * Mp + i] : T(0);
+  const T al = alpha ? alpha[i] : T(0);
+  double R = 0.0, MB = 0.0, S1 = 0.0, Q[FL], IL[FL];
+#pragma unroll
+  for (int f = 0; f < FL; ++f) Q[f] = IL[f] = 0.0;
+  const T variance = T(kp.variance);
+  for (int64_t jb = j0; jb < j1; jb += JB) {
+    __syncthreads();
+    for (int e = threadIdx.x; e < JB * DL; e += k256) {
+      const int c = e / DL, f = e % DL;
+      int64_t g = jb + c;
+      g = g < nvalid ? g : nvalid - 1;
+      T v = T(0);
+      if (f < d) v = prescaled ? x[int64_t(f) * ldx + xoff + g] : x[int64_t(f) * ldx + xoff + g] * invl[f];
+      xt[e] = v;
+    }
+    if (threadIdx.x < JB) {
+      int64_t g = jb + threadIdx.x;
+      g = g < j1 ? g : j1 - 1;
+      gms[threadIdx.x] = gmu ? gmu[g] : T(0);
+      gvs[threadIdx.x] = alpha ? T(2) * gv[g] : T(1);
+    }
+    __syncthreads();
+    B Rb = 0, MBb = 0, S1b = 0, Qb[FL], ILb[FL];
+#pragma unroll
+    for (int f = 0; f < FL; ++f) Qb[f] = ILb[f] = 0;
+    for (int c0w = wave; c0w < JB && jb + c0w < j1; c0w += 4 * U) {
+      T pv[U], av[U], gmv[U], gvv[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int c = c0w + 4 * u;
+        const bool ok = c < JB && jb + c < j1;
+        const int64_t j = ok ? jb + c : jb + c0w;
+        pv[u] = Pt[j * Mp + i];
+        av[u] = At ? At[j * Mp + i] : T(0);
+        gmv[u] = gms[ok ? c : c0w];
+        gvv[u] = gvs[ok ? c : c0w];
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int c = c0w + 4 * u;
+        if (!(c < JB && jb + c < j1)) break;   // wave-uniform
+        const T* __restrict__ xc = xt + c * DL + FL * fg;
+        T uu[FL], r2 = T(0);
+#pragma unroll
+        for (int f = 0; f < FL; ++f) {
+          uu[f] = z[f] - xc[f];
+          r2 = fma(uu[f], uu[f], r2);
+        }
+        r2 += __shfl_xor(r2, 1);
+        if (LPR == 4) r2 += __shfl_xor(r2, 2);
+        T k, dk;
+        kappa_and_d<T, FAMILY>(r2, variance, k, dk);
+        const T p = fma(gvv[u], pv[u], al * gmv[u]);   // alpha == nullptr: 1 * pv + 0
+        const B W = B(p) * B(dk);
+        if (lead) {
+          S1b = fma(B(p), B(k), S1b);
+          Rb += W;
+          if (At) MBb = fma(B(av[u]), B(gmv[u]), MBb);
+          else if (kmb) MBb = fma(B(k), B(gmv[u]), MBb);
+        }
+#pragma unroll
+        for (int f = 0; f < FL; ++f) {
+          Qb[f] = fma(W, B(xc[f]), Qb[f]);
+          ILb[f] = fma(W * B(uu[f]), B(uu[f]), ILb[f]);
+        }
+      }
+    }
+    S1 += double(S1b); R += double(Rb); MB += double(MBb);
+#pragma unroll
+    for (int f = 0; f < FL; ++f) { Q[f] += double(Qb[f]); IL[f] += double(ILb[f]); }
+  }
+  // combine the four waves (same rows) in a fixed order, then add into this (slice, row-block)'s partials
+  constexpr int NV = 2 + FL;
+  for (int w = 0; w < 4; ++w) {
+    __syncthreads();
+    if (wave == w) {
+      double* rr = red + lane * NV;
+      rr[0] = (w ? rr[0] : 0.0) + R;
+      rr[1] = (w ? rr[1] : 0.0) + MB;
+#pragma unroll
+      for (int f = 0; f < FL; ++f) rr[2 + f] = (w ? rr[2 + f] : 0.0) + Q[f];
+    }
+  }
+  __syncthreads();
+  double* rp = rowpart + int64_t(blockIdx.x) * (2 + DL) * Mp;
+  for (int t = threadIdx.x; t < 64 * NV; t += k256) {
+    const int ln = t / NV, q = t % NV, rl = ln / LPR, g = ln % LPR;
+    const int64_t row = int64_t(blockIdx.y) * RPW + rl;
+    if (q < 2) { if (g == 0) rp[int64_t(q) * Mp + row] += red[t]; }
+    else rp[int64_t(2 + FL * g + (q - 2)) * Mp + row] += red[t];
+  }
+  double* sp = scalpart + (int64_t(blockIdx.x) * gridDim.y + blockIdx.y) * (1 + DL);
+  for (int q = 0; q <= DL; ++q) {
+    __syncthreads();
+    double v = 0.0;
+    if (q == 0) v = S1;
+    else if ((q - 1) / FL == fg) {
+#pragma unroll
+      for (int f = 0; f < FL; ++f) v = ((q - 1) % FL == f) ? IL[f] : v;
+    }
+    sred[threadIdx.x] = v;
+    __syncthreads();
+    for (int w = k256 / 2; w > 0; w >>= 1) {
+      if (int(threadIdx.x) < w) sred[threadIdx.x] += sred[threadIdx.x + w];
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) sp[q] += sred[0];
+  }
+}
+
 // ---- small M x M helpers -------------------------------------------------------------------------------------
 template <typename T>
 __global__ void lower_to_rowmajor_kernel(const T* __restrict__ L, int64_t Mp, T* __restrict__ out) {
@@ -713,11 +855,15 @@ void launch_kgrad_f(hipStream_t s, const KernelParams& kp, const T* zs, int64_t 
     dim3 grid((unsigned)nslices, (unsigned)(Mp / 128));
     hipLaunchKernelGGL((kgrad_kernel<T, 16, 2, FAMILY>), grid, dim3(k256), 0, s, kp, zs, Mp, x, ldx, xoff, prescaled, n, nvalid,
                        Pt, At, gmu, gv, alpha, slice_len, rowpart, scalpart, kmb);
-  } else if (kp.d <= 32) {
-    dim3 grid((unsigned)nslices, (unsigned)(Mp / 64));
-    hipLaunchKernelGGL((kgrad_kernel<T, 32, 1, FAMILY>), grid, dim3(k256), 0, s, kp, zs, Mp, x, ldx, xoff, prescaled, n, nvalid,
+  } else if (kp.d <= 32) {   // two lanes per row, 16 features each (round 3: 32 slots in one thread)
+    dim3 grid((unsigned)nslices, (unsigned)(Mp / 32));
+    hipLaunchKernelGGL((kgrad_wide_kernel<T, 2, FAMILY>), grid, dim3(k256), 0, s, kp, zs, Mp, x, ldx, xoff, prescaled, n, nvalid,
                        Pt, At, gmu, gv, alpha, slice_len, rowpart, scalpart, kmb);
-  } else {   // 32 < d <= 64 (SVGP_MAX_D): the same kernel with 64 feature slots per thread - it spills, and is correct
+  } else if (sizeof(T) == 8) {   // 32 < d <= 64 (SVGP_MAX_D), f64: four lanes per row (round 3: 64 slots in one thread - it spilled by the hundred)
+    dim3 grid((unsigned)nslices, (unsigned)(Mp / 16));
+    hipLaunchKernelGGL((kgrad_wide_kernel<T, 4, FAMILY>), grid, dim3(k256), 0, s, kp, zs, Mp, x, ldx, xoff, prescaled, n, nvalid,
+                       Pt, At, gmu, gv, alpha, slice_len, rowpart, scalpart, kmb);
+  } else {   // fp32: the 64-slot thread still wins (H-sized value-and-gradient at d = 64: 73.6 ms against 98.5 with four lanes per row)
     dim3 grid((unsigned)nslices, (unsigned)(Mp / 64));
     hipLaunchKernelGGL((kgrad_kernel<T, 64, 1, FAMILY>), grid, dim3(k256), 0, s, kp, zs, Mp, x, ldx, xoff, prescaled, n, nvalid,
                        Pt, At, gmu, gv, alpha, slice_len, rowpart, scalpart, kmb);
@@ -733,7 +879,8 @@ void launch_kgrad_f(hipStream_t s, const KernelParams& kp, const T* zs, int64_t 
   } while (0)
 
 int grad_dreg(int d) { return d <= 8 ? 8 : (d <= 16 ? 16 : (d <= 32 ? 32 : 64)); }
-int grad_rowblocks(int d, int64_t Mp) { return int(d <= 16 ? Mp / 128 : Mp / 64); }
+// workgroups along the rows, exactly launch_kgrad_f's grid: 128 rows (d <= 16), 32 (two lanes per row), 16 (f64, four lanes per row) or 64 (fp32, d > 32)
+int grad_rowblocks(int dtype, int d, int64_t Mp) { return int(d <= 16 ? Mp / 128 : (d <= 32 ? Mp / 32 : (dtype == 0 ? Mp / 16 : Mp / 64))); }
 
 void launch_set_f64(hipStream_t s, double* dst, double value) { hipLaunchKernelGGL(set_f64_kernel, dim3(1), dim3(1), 0, s, dst, value); }
 void launch_set2_f64(hipStream_t s, double* dst, double a, double b) { hipLaunchKernelGGL(set2_f64_kernel, dim3(1), dim3(1), 0, s, dst, a, b); }

@@ -149,7 +149,7 @@ void launch_cov_assemble(int dtype, hipStream_t s, const KernelParams& kp, const
 // ---- grad.hip (reverse-mode gradient of the NonCentered ELBO) -------------------------------------------
 constexpr double kDefaultSigma2 = 1e-18;  // AbstractGPs.default_σ² added by f_post(x) (SVA:354)
 int grad_dreg(int d);
-int grad_rowblocks(int d, int64_t Mp);
+int grad_rowblocks(int dtype, int d, int64_t Mp);
 void launch_set_f64(hipStream_t s, double* dst, double value);
 void launch_set2_f64(hipStream_t s, double* dst, double a, double b);   // dst[0] = a, dst[1] = b (values travel as kernel arguments: no host buffer to outlive)
 // sums[5] = n_points, sums[6] = (*chol_info != 0), sums[7] = 0: the status slots of the all-reduced gradient scalars

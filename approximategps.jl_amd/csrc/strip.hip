@@ -755,11 +755,15 @@ __global__ void final_reduce_kernel(const double* __restrict__ partial, const un
 // Rounding: |x|^2 + |z|^2 - 2 x.z carries an absolute error of a few ulp of (|x|^2 + |z|^2) in r2, i.e. of that size
 // relative in K — parity with kernelmatrix() is tested at 1e-12 (f64) / 2e-5 (f32).
 // ---------------------------------------------------------------------------------------------
-template <typename T, int DREG, int FAMILY>
+// NBLK: 16-row blocks per wave (a wave owns 16 NBLK inducing rows, a workgroup 64 NBLK).  4 by default; the 64-feature build
+// (32 < d <= 64, round 4: those dimensions used to take a scalar one-thread-per-row kernel at 0.16 TB/s) keeps its z fragments in
+// registers too, KS = 16 values per block, and therefore owns fewer rows per wave: NBLK = VEC (2 in f64, 4 in fp32).
+template <typename T, int DREG, int FAMILY, int NBLK = 4>
 __global__ void __launch_bounds__(k256, 2) kuf_kernel(KernelParams kp, const T* __restrict__ zs, int64_t M, int64_t Mp,
                                                     const T* __restrict__ x, int64_t ldx, int64_t off, int64_t len,
                                                     T* __restrict__ K) {
-  constexpr int VEC = Vec16<T>::N, NBLK = 4, JB = 256, XLD = JB + 16, KS = DREG / 4;
+  constexpr int VEC = Vec16<T>::N, JB = 256, XLD = JB + 16, KS = DREG / 4, WROWS = 16 * NBLK;
+  static_assert(NBLK % VEC == 0, "a lane stores VEC consecutive rows");
   using V = typename Vec16<T>::type;
   using acc_t = typename Mfma16<T>::acc_t;
   static_assert(JB == k256, "one staged point per thread");
@@ -770,9 +774,9 @@ __global__ void __launch_bounds__(k256, 2) kuf_kernel(KernelParams kp, const T* 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c = lane & 15, kq = lane >> 4;
   // consecutive workgroups walk down the inducing rows of the same JB columns: the workgroups in flight write whole
   // columns, i.e. one contiguous region of Kuf, instead of a 1-2 KB piece out of every column
-  const int nI = int((M + 255) / 256);
+  const int nI = int((M + 4 * WROWS - 1) / (4 * WROWS));
   const int64_t j0 = int64_t(blockIdx.x / nI) * JB;
-  const int64_t ibase = (int64_t(blockIdx.x % nI) * 4 + wave) * 64;
+  const int64_t ibase = (int64_t(blockIdx.x % nI) * 4 + wave) * WROWS;
   const T variance = T(kp.variance);
   const T c1 = (FAMILY == KSE) ? T(-0.5) : T(1);
   const T c0 = (FAMILY == KSE) ? T(log(kp.variance)) : T(0);
@@ -1261,11 +1265,17 @@ static void launch_kuf_f(hipStream_t s, const KernelParams& kp, const T* zs, int
   // persistent structure (f64; f32 with d > 8) and the column fits one 8 KiB piece; the light f32 d <= 8 case is purely
   // store-bound in both and the block kernel's higher residency wins by a few per cent.
   static const int forced_v = env_int("SVGP_KUF_V1", -1);   // A/B knob: 1 = block kernel, 0 = column-owning kernel
-  const bool v1 = forced_v >= 0 ? forced_v != 0 : (size_t(M) * sizeof(T) > 8192 || (sizeof(T) == 4 && kp.d <= 8));
+  const bool v1 = kp.d > 32 || (forced_v >= 0 ? forced_v != 0 : (size_t(M) * sizeof(T) > 8192 || (sizeof(T) == 4 && kp.d <= 8)));
   if (v1) {
     const dim3 grid((unsigned)(((len + 255) / 256) * ((M + 255) / 256)));
 #define SVGP_KUF_LAUNCH(DREG) \
   hipLaunchKernelGGL((kuf_kernel<T, DREG, FAMILY>), grid, dim3(k256), 0, s, kp, zs, M, Mp, x, ldx, off, len, Kuf)
+    if (kp.d > 32) {   // 64 feature rows: VEC blocks of 16 rows per wave
+      constexpr int NB64 = Vec16<T>::N, WGROWS = 64 * NB64;
+      const dim3 g64((unsigned)(((len + 255) / 256) * ((M + WGROWS - 1) / WGROWS)));
+      hipLaunchKernelGGL((kuf_kernel<T, 64, FAMILY, NB64>), g64, dim3(k256), 0, s, kp, zs, M, Mp, x, ldx, off, len, Kuf);
+      return;
+    }
     if (kp.d <= 4) SVGP_KUF_LAUNCH(4);
     else if (kp.d <= 8) SVGP_KUF_LAUNCH(8);
     else if (kp.d <= 16) SVGP_KUF_LAUNCH(16);
@@ -1313,7 +1323,8 @@ static void launch_kuf_f(hipStream_t s, const KernelParams& kp, const T* zs, int
 template <typename T>
 static void launch_kuf_t(hipStream_t s, const KernelParams& kp, const T* zs, int64_t M, int64_t Mp, const T* x, int64_t ldx,
                          int64_t off, int64_t len, T* Kuf) {
-  if (kp.d > 32) {
+  static const bool generic_knob = [] { const char* e = getenv("SVGP_KUF_GENERIC"); return e && e[0] == '1'; }();   // A/B: the round-3 path for d > 32
+  if (kp.d > 32 && generic_knob) {
     hipLaunchKernelGGL(kuf_generic_kernel<T>, dim3((unsigned)((M + 255) / 256), (unsigned)((len + 15) / 16)), dim3(k256), 0, s, kp, zs, M, Mp, x, ldx,
                        off, len, Kuf);
     return;

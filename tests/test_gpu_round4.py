@@ -244,8 +244,10 @@ def test_uniform_weight_syrk_equals_the_weighted_one(ctx, dtype, gtol, N, M, cla
     batches whose length is not a multiple of the 16-point k-step (the replicated columns of the last strip must not count), over
     more than one gradient chunk, and with the clamping policy on a posterior with negative variances."""
     x, y, sva, s2 = o.synth_problem(7000 + M, N, M, 3, dtype=dtype)
-    if clamp:   # a q far from the prior: some variances go negative and are clamped; their g_v is still -scale / (2 sigma^2)
-        sva = o.SVA(sva.kernel, sva.z, sva.m, 1e-3 * sva.Lq, jitter=sva.jitter)
+    if clamp:   # a small NEGATIVE jitter and a tiny cov(q): at the points next to an inducing input k - sum A^2 dips below zero and is
+        # clamped (tests/test_gpu_parity.py::test_error_statuses builds its case the same way); their g_v is still -scale / (2 sigma^2)
+        x = np.concatenate([np.asarray(sva.z), x[:, : N - M]], axis=1).astype(dtype)
+        sva = o.SVA(o.Kernel(o.KERNEL_SE, 1.0, [6.0, 6.0, 6.0]), sva.z, np.zeros(M), 1e-3 * np.eye(M), jitter=-1e-3)
     model = device_model(ctx, sva, dtype=dtype, sigma2=s2, neg_var_policy=_ffi.NEGVAR_CLAMP if clamp else _ffi.NEGVAR_ERROR)
     data = _ffi.DeviceData(ctx, x, y, dtype)
     old = _toggle("SVGP_SYRK_UNIFORM", "0")
