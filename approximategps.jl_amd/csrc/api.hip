@@ -292,16 +292,18 @@ struct StripOuts {
   void* Ct = nullptr;
   int64_t lda = 0;
   bool skip_expect = false;   // svgp_marginals: the caller wants the moments themselves
+  int64_t mom_shift = 0;      // the batch's moments start at this index of the context's moment arrays (a batch evaluated in two parts)
+  bool no_ctail = false;      // never a concurrent tail launch (the second stream is taken: segmented head)
 };
 
 // enqueue the fused strip kernel + final reduce over points [off, off+len) of (x, y)
 int enqueue_strips(svgp_ctx* ctx, svgp_model* m, const void* x, int64_t ldx, const void* y, int64_t off, int64_t len,
                    const StripOuts& o) {
   StripPlan plan = strip_plan(m->dtype, m->Mp, len, ctx->num_cus);
-  if (plan.concurrent_tail && (o.A || o.C || o.At || o.Ct)) plan = strip_plan_single(m->dtype, m->Mp, len, ctx->num_cus);
+  if (plan.concurrent_tail && (o.A || o.C || o.At || o.Ct || o.no_ctail)) plan = strip_plan_single(m->dtype, m->Mp, len, ctx->num_cus);
   const size_t wb_main = plan.grid ? strip_work_bytes(m->dtype, m->Mp, plan.nt, plan.grid) : 0;
   const size_t wb_tail = plan.nt_tail ? strip_work_bytes(m->dtype, m->Mp, plan.nt_tail, plan.grid_tail) : 0;
-  int rc = ensure_scratch(ctx, plan.concurrent_tail ? wb_main : (wb_main > wb_tail ? wb_main : wb_tail), size_t(len));
+  int rc = ensure_scratch(ctx, plan.concurrent_tail ? wb_main : (wb_main > wb_tail ? wb_main : wb_tail), size_t(len + o.mom_shift));
   if (rc) return rc;
   if (plan.concurrent_tail) {
     rc = ensure_stream2(ctx);
@@ -322,8 +324,8 @@ int enqueue_strips(svgp_ctx* ctx, svgp_model* m, const void* x, int64_t ldx, con
   a.x = x;
   a.work = ctx->work;
   a.counter = ctx->counter;
-  a.mom_mu = ctx->mom;
-  a.mom_var = ctx->mom + ctx->mom_cap;
+  a.mom_mu = ctx->mom + o.mom_shift;
+  a.mom_var = ctx->mom + ctx->mom_cap + o.mom_shift;
   a.A_out = o.A;
   a.C_out = o.C;
   a.At_out = o.At;
@@ -382,13 +384,14 @@ int enqueue_strips(svgp_ctx* ctx, svgp_model* m, const void* x, int64_t ldx, con
       KCHECK(ctx, "strip tail");
     }
   }
+  ctx->timing.strip_launches = (plan.grid ? 1 : 0) + (plan.nt_tail ? 1 : 0);
+  if (o.mom_shift) return SVGP_OK;   // the second part of a batch: the caller joins the parts and runs the expectation over both
   HIPC(ctx, hipEventRecord(ctx->ev[2], ctx->stream));
   if (o.skip_expect) return SVGP_OK;
   launch_expect(m->dtype, ctx->stream, lp, a.mom_mu, a.mom_var, y, off, len, ctx->partial, ctx->negcnt, o.mu, o.var);
   KCHECK(ctx, "expect");
   launch_final_reduce(ctx->stream, ctx->partial, ctx->negcnt, expect_blocks(len), m->info, double(len), ctx->d_res, m->scal);
   KCHECK(ctx, "final_reduce");
-  ctx->timing.strip_launches = (plan.grid ? 1 : 0) + (plan.nt_tail ? 1 : 0);
   HIPC(ctx, hipGetLastError());
   return SVGP_OK;
 }
@@ -399,7 +402,7 @@ int enqueue_strips(svgp_ctx* ctx, svgp_model* m, const void* x, int64_t ldx, con
 // at most one round of strips the evaluation therefore runs as SEGMENTED strips (strip.hip: SEG) on the second stream: the Kuf
 // pre-generation right away, phase-1 panel I behind ev_row[I], phase 2 with the last panel; the main stream joins before the
 // expectation.  Nothing spins and no launch waits while resident, so the factorisation's launches always find free CUs.
-struct OverlapPlan { bool on = false; int nt = 0, grid = 0; int64_t nstrips = 0; };
+struct OverlapPlan { bool on = false; int nt = 0, grid = 0; int64_t nstrips = 0, head_points = 0; };
 
 OverlapPlan overlap_plan(const svgp_ctx* ctx, const svgp_model* m, int64_t len, const StripOuts& o) {
   OverlapPlan p;
@@ -410,14 +413,29 @@ OverlapPlan overlap_plan(const svgp_ctx* ctx, const svgp_model* m, int64_t len, 
   // 2 nP extra launches and the chain's slowdown beside the strips are paid back from about six panels on
   const char* q = getenv("SVGP_OVERLAP_MIN_PANELS");   // per call, like SVGP_OVERLAP
   const int min_panels = q ? atoi(q) : 5;
-  if (m->desc.parametrization != SVGP_NONCENTERED || m->d > 16 || nP < min_panels || nP > potrf_max_row_events()) return p;
+  if (m->desc.parametrization != SVGP_NONCENTERED || m->d > 16 || nP < 2 || nP > potrf_max_row_events()) return p;
   if (o.A || o.C || o.At || o.Ct) return p;
-  const StripPlan sp = strip_plan(m->dtype, m->Mp, len, ctx->num_cus);
-  if (sp.concurrent_tail || (sp.grid && sp.nt_tail)) return p;
+  const StripPlan sp = strip_plan_single(m->dtype, m->Mp, len, ctx->num_cus);
+  if (sp.grid && sp.nt_tail) return p;
   p.nt = sp.grid ? sp.nt : sp.nt_tail;
   p.nstrips = sp.grid ? sp.nstrips : sp.nstrips_tail;
   p.grid = sp.grid ? sp.grid : sp.grid_tail;
-  if (p.nstrips > p.grid) return OverlapPlan{};   // more than one round: the one-launch kernel behind the prep (dynamic queue)
+  if (p.nstrips <= p.grid && nP < min_panels) return p;   // one round: pays from about five panels on (multi-round heads: below)
+  p.head_points = len;
+  if (p.nstrips > p.grid) {
+    // More than one round of strips (C5: 4, C2: 3): a SEGMENTED HEAD - the first round's worth of strips runs beside the
+    // factorisation like a one-round batch, the rest as the one-launch kernel behind the prep on the main stream (its dynamic queue
+    // intact), the two joined before the expectation.  The head's phase 1 fills the chip while the chain would have had it alone.
+    // MEASURED, default OFF (profiles/round4/overlap.md): C5 (4 rounds of fp32 strips) 5.02 -> 4.91 ms wall, C2 (3 rounds, M = 512) 1.339
+    // -> 1.340, H32 / C3 unchanged - the head's panel launches are long (a full round of full-width strips) and the factorisation
+    // waits for their CUs (C5 prep 0.48 -> 0.84 ms), which gives back most of what the head gains.  SVGP_OVERLAP_HEAD=1 enables it.
+    const char* hq = getenv("SVGP_OVERLAP_HEAD");   // per call
+    const char* mq = getenv("SVGP_OVERLAP_HEAD_MIN_PANELS");
+    const int64_t rounds = (p.nstrips + p.grid - 1) / p.grid;
+    if (!(hq && atoi(hq) == 1) || !sp.grid || nP < (mq ? atoi(mq) : 4) || rounds > 8) return OverlapPlan{};
+    p.nstrips = p.grid;
+    p.head_points = int64_t(p.grid) * p.nt;
+  }
   p.on = true;
   return p;
 }
@@ -426,12 +444,31 @@ int enqueue_strips_overlapped(svgp_ctx* ctx, svgp_model* m, const void* x, int64
                               const StripOuts& o, const OverlapPlan& op) {
   hipStream_t s = ctx->stream, s2 = ctx->stream2;
   const int nP = int(m->Mp / 128);
-  int rc = ensure_scratch(ctx, strip_work_bytes(m->dtype, m->Mp, op.nt, int(op.nstrips)), size_t(len));
+  const int64_t head = op.head_points < len ? op.head_points : len;
+  // the segmented strips' scratch is per STRIP and lives beside the main launch's per-workgroup scratch (a segmented head runs
+  // concurrently with the rest of its batch): its own buffer
+  const size_t wb = strip_work_bytes(m->dtype, m->Mp, op.nt, int(op.nstrips));
+  if (wb > ctx->work_seg_bytes) {
+    if (ctx->work_seg) (void)hipFree(ctx->work_seg);
+    ctx->work_seg = nullptr;
+    ctx->work_seg_bytes = 0;
+    HIPC(ctx, hipMalloc(&ctx->work_seg, wb));
+    ctx->work_seg_bytes = wb;
+  }
+  int rc = ensure_scratch(ctx, 0, size_t(len));
   if (rc) return rc;
+  StripOuts rest = o;   // the part behind the head: sized and allocated BEFORE anything is enqueued (ensure_scratch may reallocate)
+  if (head < len) {
+    const StripPlan rp = strip_plan_single(m->dtype, m->Mp, len - head, ctx->num_cus);
+    const size_t w1 = rp.grid ? strip_work_bytes(m->dtype, m->Mp, rp.nt, rp.grid) : 0;
+    const size_t w2 = rp.nt_tail ? strip_work_bytes(m->dtype, m->Mp, rp.nt_tail, rp.grid_tail) : 0;
+    rc = ensure_scratch(ctx, w1 > w2 ? w1 : w2, size_t(len));
+    if (rc) return rc;
+  }
   StripArgs a{};
-  a.T = m->T; a.U = m->U; a.zs = m->zs; a.mp = m->mp; a.x = x; a.work = ctx->work; a.counter = ctx->counter2;
+  a.T = m->T; a.U = m->U; a.zs = m->zs; a.mp = m->mp; a.x = x; a.work = ctx->work_seg; a.counter = ctx->counter2;
   a.mom_mu = ctx->mom; a.mom_var = ctx->mom + ctx->mom_cap;
-  a.ldx = ldx; a.off = off; a.len = len; a.Mp = m->Mp; a.M = m->M; a.kp = kparams(m); a.mean_const = m->desc.mean_const;
+  a.ldx = ldx; a.off = off; a.len = head; a.Mp = m->Mp; a.M = m->M; a.kp = kparams(m); a.mean_const = m->desc.mean_const;
   a.seg_state = ctx->seg_state;
   HIPC(ctx, hipStreamWaitEvent(s2, ctx->ev_fork, 0));
   a.seg_flags = kSegPregen; a.seg_lo = 0; a.seg_hi = 0;
@@ -446,8 +483,18 @@ int enqueue_strips_overlapped(svgp_ctx* ctx, svgp_model* m, const void* x, int64
     if (I == 0) HIPC(ctx, hipEventRecord(ctx->ev_ov[1], s2));
   }
   HIPC(ctx, hipEventRecord(ctx->ev_join, s2));
+  int launches = nP + 1;
+  if (head < len) {   // the rest of the batch: the one-launch kernel behind the prep, on the main stream, beside the head's tail
+    rest.mom_shift = head;
+    rest.no_ctail = true;
+    rest.skip_expect = true;
+    rc = enqueue_strips(ctx, m, x, ldx, y, off + head, len - head, rest);
+    if (rc) return rc;
+    launches += int(ctx->timing.strip_launches);
+  }
   HIPC(ctx, hipStreamWaitEvent(s, ctx->ev_join, 0));
   HIPC(ctx, hipEventRecord(ctx->ev[2], s));
+  ctx->timing.strip_launches = launches;
   if (o.skip_expect) return SVGP_OK;
   LikParams lp{};
   lp.lik = m->desc.likelihood;
@@ -462,7 +509,6 @@ int enqueue_strips_overlapped(svgp_ctx* ctx, svgp_model* m, const void* x, int64
   KCHECK(ctx, "expect");
   launch_final_reduce(s, ctx->partial, ctx->negcnt, expect_blocks(len), m->info, double(len), ctx->d_res, m->scal);
   KCHECK(ctx, "final_reduce");
-  ctx->timing.strip_launches = nP + 1;
   HIPC(ctx, hipGetLastError());
   return SVGP_OK;
 }
@@ -722,6 +768,7 @@ int32_t svgp_ctx_destroy(svgp_ctx* c) {
     if (e) (void)hipEventDestroy(e);
   if (c->ev_R) (void)hipEventDestroy(c->ev_R);
   if (c->seg_state) (void)hipFree(c->seg_state);
+  if (c->work_seg) (void)hipFree(c->work_seg);
   if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
   if (c->ev_join) (void)hipEventDestroy(c->ev_join);
   if (c->stream2) { (void)hipStreamSynchronize(c->stream2); (void)hipStreamDestroy(c->stream2); }
@@ -1266,7 +1313,7 @@ int grad_enqueue(svgp_ctx* ctx, svgp_model* m, const svgp_data* data, int64_t of
       gop.nt = sp.grid ? sp.nt : sp.nt_tail;
       gop.grid = sp.grid ? sp.grid : sp.grid_tail;
       gop.nstrips = sp.grid ? sp.nstrips : sp.nstrips_tail;
-      if (gop.nstrips > gop.grid || (sp.grid && sp.nt_tail)) gop.on = false;
+      if (gop.head_points < len || gop.nstrips > gop.grid || (sp.grid && sp.nt_tail)) gop.on = false;   // one chunk, one round only
     }
     if (gop.on) {
       rc = ensure_overlap(ctx, size_t(gop.nstrips) * strip_seg_state_doubles(dt, gop.nt));
