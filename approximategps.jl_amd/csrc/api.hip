@@ -251,7 +251,17 @@ int ensure_stream2(svgp_ctx* ctx) {
   // the factorisation): lowest priority, so that where both have workgroups to dispatch the main stream's serial chain goes first
   static const int prio_knob = [] { const char* e = getenv("SVGP_STREAM2_LOW_PRIO"); return e ? atoi(e) : 1; }();   // A/B knob
   int least = 0, greatest = 0;
-  if (prio_knob && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && least != greatest) {
+  // A/B knob (round 4): keep SVGP_STREAM2_RESERVE CUs out of the second stream's reach (hipExtStreamCreateWithCUMask), so that the
+  // factorisation's launches always find free CUs beside the segmented strips
+  static const int reserve = [] { const char* e = getenv("SVGP_STREAM2_RESERVE"); return e ? atoi(e) : 0; }();
+  if (reserve > 0 && reserve < ctx->num_cus) {
+    std::vector<uint32_t> mask(size_t((ctx->num_cus + 31) / 32), 0xffffffffu);
+    for (int c = 0; c < reserve; ++c) {   // spread the reserved CUs: one every num_cus / reserve
+      const int cu = int((int64_t(c) * ctx->num_cus) / reserve);
+      mask[size_t(cu / 32)] &= ~(1u << (cu % 32));
+    }
+    HIPC(ctx, hipExtStreamCreateWithCUMask(&ctx->stream2, uint32_t(mask.size()), mask.data()));
+  } else if (prio_knob && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && least != greatest) {
     HIPC(ctx, hipStreamCreateWithPriority(&ctx->stream2, hipStreamNonBlocking, least));
   } else {
     HIPC(ctx, hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
@@ -447,7 +457,13 @@ int enqueue_strips_overlapped(svgp_ctx* ctx, svgp_model* m, const void* x, int64
   const int64_t head = op.head_points < len ? op.head_points : len;
   // the segmented strips' scratch is per STRIP and lives beside the main launch's per-workgroup scratch (a segmented head runs
   // concurrently with the rest of its batch): its own buffer
-  const size_t wb = strip_work_bytes(m->dtype, m->Mp, op.nt, int(op.nstrips));
+  // ... twice: the A strips, then the parked phase-2 accumulator tiles (checkpointed phase 2: strip.hip kSegP2)
+  const size_t wb1 = strip_work_bytes(m->dtype, m->Mp, op.nt, int(op.nstrips)), wb = 2 * wb1;
+  // Checkpointed phase 2: bitwise-tested, MEASURED, default OFF (profiles/round4/overlap.md): the factorisation slows by what the
+  // strips' extra work beside it occupies (16 384 / 1024 f64: prep 0.60 -> 0.78 ms, rest 0.38 -> 0.23: 1.046 -> 1.06-1.07 ms; M = 2048
+  // 1.94 -> 2.11).  The chain is latency-bound and every CU a strip launch holds delays it.  SVGP_OVERLAP_P2CKPT=1 enables it.
+  const char* ckq = getenv("SVGP_OVERLAP_P2CKPT");   // per call; A/B knob
+  const bool ckpt = (ckq && atoi(ckq) == 1) && nP >= 4;
   if (wb > ctx->work_seg_bytes) {
     if (ctx->work_seg) (void)hipFree(ctx->work_seg);
     ctx->work_seg = nullptr;
@@ -474,10 +490,20 @@ int enqueue_strips_overlapped(svgp_ctx* ctx, svgp_model* m, const void* x, int64
   a.seg_flags = kSegPregen; a.seg_lo = 0; a.seg_hi = 0;
   launch_strip_seg(m->dtype, s2, a, op.nt, op.grid, op.nstrips);
   KCHECK(ctx, "strip (segmented: pre-generation)");
+  a.seg_cacc = static_cast<char*>(ctx->work_seg) + wb1;
+  const int ck[3] = {nP / 2, (3 * nP) / 4, nP};   // phase-2 checkpoints: after panels ck[.] - 1
+  int ck_prev = 0;
   for (int I = 0; I < nP; ++I) {
     HIPC(ctx, hipStreamWaitEvent(s2, ctx->ev_row[I], 0));
     a.seg_lo = I; a.seg_hi = I + 1;
     a.seg_flags = (I > 0 ? kSegLoad : 0) | (I + 1 < nP ? kSegStore : kSegPhase2);
+    a.seg_p2_lo = a.seg_p2_hi = 0;
+    if (ckpt) {
+      a.seg_flags |= kSegP2;
+      if (I + 1 == ck[0] || I + 1 == ck[1] || I + 1 == ck[2]) {
+        if (I + 1 > ck_prev) { a.seg_p2_lo = ck_prev; a.seg_p2_hi = I + 1; ck_prev = I + 1; }
+      }
+    }
     launch_strip_seg(m->dtype, s2, a, op.nt, op.grid, op.nstrips);
     KCHECK(ctx, "strip (segmented: panel)");
     if (I == 0) HIPC(ctx, hipEventRecord(ctx->ev_ov[1], s2));
@@ -544,6 +570,17 @@ int elbo_enqueue(svgp_ctx* ctx, svgp_model* m, const svgp_data* data, int64_t of
   rc = enqueue_prep(ctx, m, op.on);
   if (rc) return rc;
   HIPC(ctx, hipEventRecord(ctx->ev[1], s));
+  {   // diagnostic (SVGP_OVERLAP_DRY=1): the overlap's prep - reordered, with its row events recorded - but the strips behind it as usual:
+      // what the events alone cost the chain
+    const char* dq = getenv("SVGP_OVERLAP_DRY");
+    if (op.on && dq && atoi(dq) == 1) {
+      ctx->overlapped = false;   // ev_ov[1] is not recorded on this path
+      rc = enqueue_strips(ctx, m, data->x, data->ldx, data->y, off, len, StripOuts{});
+      if (rc) return rc;
+      HIPC(ctx, hipEventRecord(ctx->ev[3], s));
+      return SVGP_OK;
+    }
+  }
   rc = op.on ? enqueue_strips_overlapped(ctx, m, data->x, data->ldx, data->y, off, len, StripOuts{}, op)
              : enqueue_strips(ctx, m, data->x, data->ldx, data->y, off, len, StripOuts{});
   if (rc) return rc;

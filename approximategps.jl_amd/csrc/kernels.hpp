@@ -62,7 +62,7 @@ void launch_shift_vec(int dtype, hipStream_t s, const void* m, double shift, int
 void launch_extract_lower(int dtype, hipStream_t s, const void* A, int64_t Mp, int64_t M, void* out);
 
 // ---- strip.hip -------------------------------------------------------------------------------
-enum : int { kSegPregen = 1, kSegPhase2 = 2, kSegLoad = 4, kSegStore = 8 };   // StripArgs::seg_flags
+enum : int { kSegPregen = 1, kSegPhase2 = 2, kSegLoad = 4, kSegStore = 8, kSegP2 = 16 };   // StripArgs::seg_flags
 struct StripArgs {
   const void* T;     // Mp x Mp col-major: block rows of inv(L_II) * [-L_I,<I | I]
   const void* U;     // Mp x Mp col-major: B' (upper triangular)
@@ -100,6 +100,10 @@ struct StripArgs {
                               // kSegLoad 4 / kSegStore 8: restore / save the threads' fp64 column sums in seg_state
   int seg_lo, seg_hi;
   double* seg_state;          // [nstrips][256][2 NJ]; `work` then holds ONE scratch strip PER STRIP (nstrips x Mp x NT)
+  // kSegP2 (forward): checkpointed phase 2 - this launch advances the accumulators of the panels J < seg_p2_hi over the k-blocks
+  // [max(J, seg_p2_lo), seg_p2_hi) and parks them in seg_cacc (nstrips x Mp x NT elements, register layout); seg_p2_hi == Mp / 128 closes
+  int seg_p2_lo, seg_p2_hi;
+  void* seg_cacc;
 };
 int strip_nt(int dtype, int64_t Mp, int64_t len);                 // column-strip width chosen for a problem
 size_t strip_work_bytes(int dtype, int64_t Mp, int nt, int grid);  // workspace bytes

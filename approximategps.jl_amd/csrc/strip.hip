@@ -400,11 +400,70 @@ __global__ void __launch_bounds__(NTHR, MINW) strip_kernel(StripArgs a, int64_t 
     }
 
     // ---------------- phase 2: C = B' A  (forward builds; the value-and-gradient build gets the variance from phase 3) --------
+    [[maybe_unused]] bool p2_complete = false;
     if constexpr (SEG) {
       if (a.seg_flags & kSegStore) {
         double* __restrict__ st = a.seg_state + (strip * NTHR + tid) * (2 * NJ);
 #pragma unroll
         for (int j = 0; j < NJ; ++j) { st[j] = sA[j]; st[NJ + j] = sM[j]; }
+      }
+      // Checkpointed phase 2 (forward builds, kSegP2): every C_J = sum_{I >= J} U[J, I] A_I needs the LAST panel of A, so a phase 2
+      // that starts behind phase 1 leaves all of it behind the factorisation.  But the contraction runs over ascending I, and
+      // splitting a K loop into two invocations changes no arithmetic: at a checkpoint launch (after panel p2_hi - 1) every panel
+      // J < p2_hi advances its accumulator over the k-blocks [max(J, p2_lo), p2_hi) - resuming from the tile it parked in `seg_cacc`
+      // at the previous checkpoint, in the threads' own register layout - and parks it again; the closing launch finishes all of
+      // them.  Same operations on every accumulator in the same order: bitwise the one-launch result.  Three checkpoints
+      // (nP / 2, 3 nP / 4, nP): 20 tile transfers per strip instead of 64 for one per panel.
+      if constexpr (!GRAD) {
+        const int p2_lo = a.seg_p2_lo, p2_hi = a.seg_p2_hi;
+        if ((a.seg_flags & kSegP2) && p2_hi > p2_lo) {
+          constexpr int PT = MI * NJ * 4;   // accumulator values per thread and tile
+          using acc_t = typename G::acc_t;
+          T* __restrict__ cacc = static_cast<T*>(a.seg_cacc) + strip * Mp * NT;
+          const bool last = (p2_hi == nP);
+          for (int J = 0; J < p2_hi; ++J) {
+            Acc acc;
+            T* __restrict__ ct = cacc + (int64_t(J) * NTHR + tid) * PT;
+            const int kb0 = J > p2_lo ? J : p2_lo;   // first k-block of panel J in this launch
+            if (J < p2_lo) {
+#pragma unroll
+              for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) acc.v[i][j] = *reinterpret_cast<const acc_t*>(ct + (i * NJ + j) * 4);
+            } else {
+              acc.zero();
+            }
+            const int nst = (p2_hi - kb0) * (NB / BK);
+            const T* Pb = U + int64_t(J) * NB + int64_t(kb0) * NB * Mp;
+            const T* wq = work + int64_t(kb0) * NB * NT;
+            if constexpr (SVGP_ASYNC && G::kAsync) {
+              auto qsrc = [&](int t) { return wq + int64_t(t) * BK * NT; };
+              if (kb0 == J) G::template loop_tri_async<(SVGP_TRI & 2) ? -1 : 0>(acc, Pb, Mp, nst, qsrc, smem);
+              else G::template loop_tri_async<0>(acc, Pb, Mp, nst, qsrc, smem);
+            } else {
+              auto qload = [&](int t, QRegs& r) { G::load_q(r, wq + int64_t(t) * BK * NT, qoff); };
+              if (kb0 == J) G::template loop_tri<(BK == 16 && (SVGP_TRI & 2)) ? -1 : 0>(acc, Pb, Mp, nst, qload, smem);
+              else G::template loop_tri<0>(acc, Pb, Mp, nst, qload, smem);
+            }
+            if (!last) {
+#pragma unroll
+              for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) *reinterpret_cast<acc_t*>(ct + (i * NJ + j) * 4) = acc.v[i][j];
+            } else {   // C_J is complete: its column sums, panels in ascending order as in the one-launch kernel
+#pragma unroll
+              for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                  for (int j = 0; j < NJ; ++j) {
+                    const double dv = double(acc.v[i][j][r]);
+                    sC[j] = fma(dv, dv, sC[j]);
+                  }
+            }
+          }
+          p2_complete = last;
+        }
       }
       if (!(a.seg_flags & kSegPhase2)) {   // this launch ends here for the strip; phase 2 (GRAD: phase 3) and the moments come with a later one
         strip = next_strip;
@@ -413,7 +472,7 @@ __global__ void __launch_bounds__(NTHR, MINW) strip_kernel(StripArgs a, int64_t 
       }
     }
     if constexpr (!GRAD)
-    for (int J = 0; J < nP; ++J) {
+    for (int J = (SEG && p2_complete) ? nP : 0; J < nP; ++J) {   // (segmented builds: the checkpoints may have covered phase 2)
       SVGP_SSTAMP(60 + 2 * J);
       Acc acc;
       acc.zero();
