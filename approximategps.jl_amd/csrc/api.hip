@@ -583,7 +583,11 @@ int elbo_enqueue(svgp_ctx* ctx, svgp_model* m, const svgp_data* data, int64_t of
   }
   rc = op.on ? enqueue_strips_overlapped(ctx, m, data->x, data->ldx, data->y, off, len, StripOuts{}, op)
              : enqueue_strips(ctx, m, data->x, data->ldx, data->y, off, len, StripOuts{});
-  if (rc) return rc;
+  if (rc) {   // a failure between the fork and the join leaves work on the second stream that the main stream never waited for: drain it,
+              // so that the next call on this context cannot meet it in the shared scratch
+    if (op.on && ctx->stream2) (void)hipStreamSynchronize(ctx->stream2);
+    return rc;
+  }
   HIPC(ctx, hipEventRecord(ctx->ev[3], s));
   return SVGP_OK;
 }
@@ -1314,7 +1318,16 @@ void gemm_mm(svgp_ctx* ctx, GradWs* w, int dt, hipStream_t s, const void* Xt, co
   launch_sum_slices_lower(dt, s, w->G1, ns, Mp, out, (flags & kMmFull) ? 1 : 0, 1);
 }
 
+int grad_enqueue_impl(svgp_ctx* ctx, svgp_model* m, const svgp_data* data, int64_t off, int64_t len, GradCall& gc);
 int grad_enqueue(svgp_ctx* ctx, svgp_model* m, const svgp_data* data, int64_t off, int64_t len, GradCall& gc) {
+  const int rc = grad_enqueue_impl(ctx, m, data, off, len, gc);
+  // a failure between the fork and the join of the segmented strips leaves work on the second stream that the main stream never
+  // waited for: drain it, so that the next call on this context cannot meet it in the shared scratch
+  if (rc != SVGP_OK && ctx->overlapped && ctx->stream2) (void)hipStreamSynchronize(ctx->stream2);
+  return rc;
+}
+
+int grad_enqueue_impl(svgp_ctx* ctx, svgp_model* m, const svgp_data* data, int64_t off, int64_t len, GradCall& gc) {
   const bool centered = gc.centered = (m->desc.parametrization == SVGP_CENTERED);
   HIPC(ctx, hipSetDevice(ctx->device));
   hipStream_t s = ctx->stream;

@@ -35,9 +35,30 @@ namespace {
 // here with z as the A operand so that a lane's 16-lane group writes 16 consecutive points of one row.  xs: the strip's
 // scaled inputs in LDS, [DL][NT], zero padded to DL feature rows.  A wave owns every (NTHR/64)-th block of 16 rows; the
 // x fragments and column norms are fetched once per strip, the row norms travel by two xor-shuffles and one index shuffle.
+#ifndef SVGP_PREGEN_EXPTAB
+#define SVGP_PREGEN_EXPTAB 1   // the f64 SE pre-generation takes exp from a 64-entry table of 2^(j/64) in LDS + a degree-5 polynomial (0: kexp; A/B builds)
+#endif
+// exp(v), v <= 0: v = (64 m + j) ln2 / 64 + r, |r| <= ln2 / 128: 2^m * tab[j] * (1 + r + ... + r^5 / 120) (truncation 3.5e-17): ~15 VALU
+// instructions and one LDS read against kexp's ~20 - the pre-generation is VALU-bound and f64 VALU blocks the MFMA pipe of the
+// partner workgroup too (s_memtime stamps: 140-158k of a forward strip's 2230k ticks).  Same box, three repetitions, H strip ms:
+// 33.44 / 33.41 / 33.57 with kexp, 33.35 / 33.33 / 33.27 with the table (C2 1.13 vs 1.13): -0.5 %, parity tests unchanged; 212 VGPRs either way
+__device__ __forceinline__ double kexp_tab(double v, const double* __restrict__ tab) {
+  const double nd = rint(v * 92.332482616893658);               // 64 / ln2
+  const int n = int(nd);
+  double r = fma(nd, -1.08304246932675596327e-02, v);           // ln2_hi / 64 (kexp's split, exact in binary)
+  r = fma(nd, -2.98158582698529328128e-12, r);                  // ln2_lo / 64
+  const double t = tab[n & 63];
+  double p = fma(r, 8.333333333333333e-03, 4.1666666666666664e-02);
+  p = fma(p, r, 1.6666666666666666e-01);
+  p = fma(p, r, 0.5);
+  p = fma(p, r, 1.0);
+  p *= r;                                                       // exp(r) - 1
+  return ldexp(fma(t, p, t), n >> 6);
+}
+
 template <typename T, int NT, int NTHR, int F, int DL>
 __device__ __forceinline__ void pregen_mfma(const T* __restrict__ xs, const T* __restrict__ zs, int d, int64_t Mp, int64_t M,
-                                            double variance_d, T* __restrict__ work) {
+                                            double variance_d, T* __restrict__ work, const double* __restrict__ exptab = nullptr) {
   // DL <= 16: the strip's x fragments stay in registers for the whole pass (JT x KS values).  DL = 32 / 64 (round 4: d in (16, 64]
   // used to fall off the MFMA path onto a scalar per-feature loop): the distance chain runs over the 16-feature chunks with the x
   // fragment of each MFMA read from the LDS image as it is needed (one conflict-free ds_read per MFMA: 16 lanes x consecutive
@@ -108,7 +129,9 @@ __device__ __forceinline__ void pregen_mfma(const T* __restrict__ xs, const T* _
       for (int r = 0; r < 4; ++r) {
         const int64_t k = k0 + M16::row(lane, r);
         const T v = acc[r];
-        const T out = (F == KSE) ? kexp(v < c0 ? v : c0) : kappa<T>(F, v > T(0) ? v : T(0), variance);
+        T out;
+        if constexpr (SVGP_PREGEN_EXPTAB && F == KSE && sizeof(T) == 8) out = T(kexp_tab(double(v < c0 ? v : c0), exptab));
+        else out = (F == KSE) ? kexp(v < c0 ? v : c0) : kappa<T>(F, v > T(0) ? v : T(0), variance);
         work[k * NT + jt * 16 + l15] = (k < M) ? out : T(0);
       }
     }
@@ -121,6 +144,12 @@ __shared__ unsigned long long s_strip_stamps[128];   // accumulated in LDS (a gl
 #define SVGP_SSTAMP(i) do { if (stamping && threadIdx.x == 0) s_strip_stamps[i] += clock64(); } while (0)   // sums over strips
 extern "C" int svgp_debug_strip_stamps(unsigned long long* out) {
   return int(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_strip_stamps), sizeof(g_strip_stamps)));
+}
+// per-workgroup timeline of the LAST launch: for workgroups 0, 37, 74, ... (16 of them) the clock at the start of each of its first
+// 10 strips, at its end (slot 10), and its XCC id (slot 11): first-strip cost, lockstep, spread over the chip
+__device__ unsigned long long g_wg_times[16][12];
+extern "C" int svgp_debug_wg_times(unsigned long long* out) {
+  return int(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wg_times), sizeof(g_wg_times)));
 }
 #else
 #define SVGP_SSTAMP(i)
@@ -252,6 +281,13 @@ __global__ void __launch_bounds__(NTHR, MINW) strip_kernel(StripArgs a, int64_t 
   // of the launch take more strips, which removes most of the ragged last round (C2: 3.05 rounds of strips).
   // Which workgroup evaluates a strip does not change its arithmetic, so results stay bitwise reproducible.
   __shared__ unsigned next_strip;
+#if SVGP_PREGEN_EXPTAB
+  __shared__ double s_exptab[64];
+  if (sizeof(T) == 8 && threadIdx.x < 64) s_exptab[threadIdx.x] = exp2(double(threadIdx.x) * 0.015625);
+  const double* exptab = s_exptab;
+#else
+  const double* exptab = nullptr;
+#endif
   __shared__ T s_gmu[(GRAD && PG != kPgPost) ? NT : 1], s_gv[(GRAD && PG != kPgPost) ? NT : 1];   // the strip's likelihood gradients (fp32 `apart` row sums)
 #ifdef SVGP_STRIP_STAMPS
   int strips_done = 0;
@@ -266,6 +302,7 @@ __global__ void __launch_bounds__(NTHR, MINW) strip_kernel(StripArgs a, int64_t 
 #ifdef SVGP_STRIP_STAMPS
     const bool stamping = (blockIdx.x == 37 && strips_done >= 1);   // every strip of one workgroup but its first
     if (stamping && threadIdx.x == 0) s_strip_stamps[127] += 1;
+    if (threadIdx.x == 0 && blockIdx.x % 37 == 0 && blockIdx.x / 37 < 16 && strips_done < 10) g_wg_times[blockIdx.x / 37][strips_done] = clock64();
     ++strips_done;
 #endif
     SVGP_SSTAMP(0);
@@ -311,20 +348,20 @@ __global__ void __launch_bounds__(NTHR, MINW) strip_kernel(StripArgs a, int64_t 
       };
       if constexpr (BIGD) {
         if (pre_dl == 32) {
-          if (family == KSE) pregen_mfma<T, NT, NTHR, KSE, 32>(xs, zs, d, Mp, M, a.kp.variance, workK);
+          if (family == KSE) pregen_mfma<T, NT, NTHR, KSE, 32>(xs, zs, d, Mp, M, a.kp.variance, workK, exptab);
           else if (family == KM32) pregen_mfma<T, NT, NTHR, KM32, 32>(xs, zs, d, Mp, M, a.kp.variance, workK);
           else pregen_mfma<T, NT, NTHR, KM52, 32>(xs, zs, d, Mp, M, a.kp.variance, workK);
         } else {
-          if (family == KSE) pregen_mfma<T, NT, NTHR, KSE, 64>(xs, zs, d, Mp, M, a.kp.variance, workK);
+          if (family == KSE) pregen_mfma<T, NT, NTHR, KSE, 64>(xs, zs, d, Mp, M, a.kp.variance, workK, exptab);
           else if (family == KM32) pregen_mfma<T, NT, NTHR, KM32, 64>(xs, zs, d, Mp, M, a.kp.variance, workK);
           else pregen_mfma<T, NT, NTHR, KM52, 64>(xs, zs, d, Mp, M, a.kp.variance, workK);
         }
       } else if (pre_dl == 8) {
-        if (family == KSE) pregen_mfma<T, NT, NTHR, KSE, 8>(xs, zs, d, Mp, M, a.kp.variance, workK);
+        if (family == KSE) pregen_mfma<T, NT, NTHR, KSE, 8>(xs, zs, d, Mp, M, a.kp.variance, workK, exptab);
         else if (family == KM32) pregen_mfma<T, NT, NTHR, KM32, 8>(xs, zs, d, Mp, M, a.kp.variance, workK);
         else pregen_mfma<T, NT, NTHR, KM52, 8>(xs, zs, d, Mp, M, a.kp.variance, workK);
       } else if (pre_dl == 16) {
-        if (family == KSE) pregen_mfma<T, NT, NTHR, KSE, 16>(xs, zs, d, Mp, M, a.kp.variance, workK);
+        if (family == KSE) pregen_mfma<T, NT, NTHR, KSE, 16>(xs, zs, d, Mp, M, a.kp.variance, workK, exptab);
         else if (family == KM32) pregen_mfma<T, NT, NTHR, KM32, 16>(xs, zs, d, Mp, M, a.kp.variance, workK);
         else pregen_mfma<T, NT, NTHR, KM52, 16>(xs, zs, d, Mp, M, a.kp.variance, workK);
       } else if (family == KSE) pregen(std::integral_constant<int, KSE>{});   // d > 16 in a kernel without the wide bodies (A/B builds)
@@ -514,6 +551,7 @@ __global__ void __launch_bounds__(NTHR, MINW) strip_kernel(StripArgs a, int64_t 
       const T* __restrict__ Rm = static_cast<const T*>(a.R);
       T* __restrict__ Pt = static_cast<T*>(a.Pt_out);
       for (int I = 0; I < nP; ++I) {
+        SVGP_SSTAMP(26 + 4 * I);   // (diagnostic builds, nP <= 8) phase 3: loop start / loop end / after the K-dot / after the point-major store
         Acc acc;
         acc.zero();
         if constexpr (SVGP_ASYNC && G::kAsync) {
@@ -523,6 +561,7 @@ __global__ void __launch_bounds__(NTHR, MINW) strip_kernel(StripArgs a, int64_t 
           auto qload = [&](int t, QRegs& r) { G::load_q(r, work + int64_t(t) * BK * NT, qoff); };
           G::template loop_tri<0>(acc, Rm + int64_t(I) * NB, Mp, nP * (NB / BK), qload, smem);
         }
+        SVGP_SSTAMP(27 + 4 * I);
 #if !(defined(SVGP_ABLATE) && (SVGP_ABLATE & 128))
 #pragma unroll
         for (int i = 0; i < MI; ++i)
@@ -536,11 +575,13 @@ __global__ void __launch_bounds__(NTHR, MINW) strip_kernel(StripArgs a, int64_t 
 #pragma unroll
         for (int j = 0; j < NJ; ++j) sC[j] += double(acc.v[0][j][0]);
 #endif
+        SVGP_SSTAMP(28 + 4 * I);
 #if !(defined(SVGP_ABLATE) && (SVGP_ABLATE & 64))
         store_tile_point_major<G, T, NT, NTHR>(acc, smem, Pt, c0, Mp, I * NB);
 #else
         if (acc.v[0][0][0] == T(12345.678)) Pt[c0] = acc.v[0][0][0];   // keep the accumulators live
 #endif
+        SVGP_SSTAMP(29 + 4 * I);
       }
     }
 
@@ -665,6 +706,11 @@ __global__ void __launch_bounds__(NTHR, MINW) strip_kernel(StripArgs a, int64_t 
   }
 #ifdef SVGP_STRIP_STAMPS
   if (blockIdx.x == 37 && threadIdx.x < 128) g_strip_stamps[threadIdx.x] = s_strip_stamps[threadIdx.x];
+  if (threadIdx.x == 0 && blockIdx.x % 37 == 0 && blockIdx.x / 37 < 16) {
+    g_wg_times[blockIdx.x / 37][10] = clock64();
+    g_wg_times[blockIdx.x / 37][11] = (unsigned long long)(__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) & 0xf) | ((unsigned long long)strips_done << 8);   // HW_REG_XCC_ID
+    for (int q = strips_done; q < 10; ++q) g_wg_times[blockIdx.x / 37][q] = 0;
+  }
 #endif
 }
 

@@ -1,0 +1,42 @@
+"""Soak of the strips-beside-the-factorisation path (a script like tests/soak.py, not a pytest file): 300 evaluations alternating
+forward / value-and-gradient, model updates in between, every result compared bit for bit with the same call behind the prep
+(SVGP_OVERLAP=0).  A race between the two streams (scratch reuse, events of consecutive evaluations) would show as a difference.
+usage (GPU box): python tests/soak_overlap.py [reps]"""
+import os, sys
+R = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(R, "..", "approximategps.jl_amd")); sys.path.insert(0, os.path.join(R, "..", "oracle")); sys.path.insert(0, R)
+import numpy as np
+import svgp_oracle as o
+from approxgp import _ffi
+from helpers import desc_from_oracle
+
+reps = int(sys.argv[1]) if len(sys.argv) > 1 else 300
+ctx = _ffi.Context(0)
+rng = np.random.default_rng(0)
+bad = 0
+for dtype, N, M, d in ((np.float64, 9000, 1024, 4), (np.float32, 20000, 700, 8)):
+    x, y, sva, s2 = o.synth_problem(9100, N, M, d, dtype=dtype)
+    desc, keep = desc_from_oracle(sva, dtype=dtype, sigma2=s2)
+    model = _ffi.DeviceModel(ctx, desc, keep)
+    data = _ffi.DeviceData(ctx, x, y, dtype)
+    for rep in range(reps // 2):
+        # new parameter values every few steps (a training loop): m and the kernel variance move
+        if rep % 3 == 0:
+            sva.m = (sva.m + 0.01 * rng.standard_normal(M)).astype(np.float64)
+            sva.kernel = o.Kernel(sva.kernel.family, sva.kernel.variance * (1.0 + 0.01 * rng.standard_normal()), sva.kernel.inv_lengthscale)
+            desc, keep = desc_from_oracle(sva, dtype=dtype, sigma2=s2)
+            model.update(desc, keep)
+        off = int(rng.integers(0, 64)); n = N - off - int(rng.integers(0, 64))
+        res = {}
+        for k in ("1", "0"):
+            os.environ["SVGP_OVERLAP"] = k
+            v = model.elbo(data, off, n, float(N))[0]
+            vg, _, g = model.elbo_grad(data, off, n, float(N))
+            res[k] = (v, vg, g)
+        same = res["1"][0] == res["0"][0] and res["1"][1] == res["0"][1] and all(
+            np.array_equal(np.asarray(res["1"][2][q]), np.asarray(res["0"][2][q])) for q in ("z", "m", "Lq", "inv_lengthscale"))
+        bad += 0 if same else 1
+    print(f"{np.dtype(dtype).name} N={N} M={M}: {reps // 2} rounds of (forward, gradient) x (beside, behind): mismatches so far {bad}", flush=True)
+    model.free(); data.free()
+print("SOAK", "FAILED" if bad else "OK")
+sys.exit(1 if bad else 0)
