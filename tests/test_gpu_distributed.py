@@ -253,6 +253,10 @@ def test_bench_two_gpu_launch_runs_two_rccl_ranks():
     assert line["n_points_global"] == 2 * 100000
     assert line["value"] is not None and line["value"] > 0
     assert line["collective_check"]["rel_err"] < 1e-12
+    # round 4: the N > 1 line is self-contained - rank 0's baseline, parity of its shard and the Kuf figure
+    assert line["cpu_baseline"]["value"] > 0 and "rank 0's shard" in line["cpu_baseline"]["scope"]
+    assert line["parity"]["ok"] and "svgp_elbo_partial" in line["parity"]["via"]
+    assert line["kuf_roofline"]["achieved"] > 0
 
 
 # ---- two real GPUs: skipped on the one-GPU boxes of this build; the transport-level checks a reader with a
