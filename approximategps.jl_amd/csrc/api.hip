@@ -182,7 +182,7 @@ KernelParams kparams(const svgp_model* m) {
 int enqueue_prep(svgp_ctx* ctx, svgp_model* m, bool overlap = false) {
   hipStream_t s = ctx->stream;
   const KernelParams kp = kparams(m);
-  HIPC(ctx, hipMemsetAsync(m->info, 0, sizeof(int) * size_t(1 + m->Mp / 128), s));   // info + the factorisation's hand-over counters
+  HIPC(ctx, hipMemsetAsync(m->info, 0, sizeof(int) * size_t(1 + 2 * (m->Mp / 128)), s));   // info + the factorisation's hand-over counters and flags
   launch_scale_inputs(m->dtype, s, m->z_raw, m->desc.layout_z, m->d, m->M, m->Mp, m->invl, m->zs);
   KCHECK(ctx, "scale_inputs");
   if (overlap) {
@@ -907,7 +907,7 @@ int32_t svgp_model_create(svgp_ctx* ctx, const svgp_model_desc* desc, svgp_model
   struct { void** p; size_t bytes; } allocs[] = {
       {&m->z_raw, M * m->d * es}, {&m->m_raw, M * es},     {&m->Lq_raw, M * M * es}, {&m->invl, size_t(m->d) * es},
       {&m->zs, Mp * m->d * es},   {&m->L, Mp * Mp * es},   {&m->T, Mp * Mp * es},    {&m->U, Mp * Mp * es},
-      {&m->mp, Mp * es},          {(void**)&m->scal, (8 + Mp) * sizeof(double)},     {(void**)&m->info, sizeof(int) * (1 + Mp / 128)},
+      {&m->mp, Mp * es},          {(void**)&m->scal, (8 + Mp) * sizeof(double)},     {(void**)&m->info, sizeof(int) * (1 + 2 * (Mp / 128))},
   };
   for (auto& a : allocs)
     if (hipMalloc(a.p, a.bytes) != hipSuccess) {

@@ -631,6 +631,113 @@ __global__ void __launch_bounds__(k256, (FUSE && sizeof(T) == 8) ? 1 : 2) chol_t
   }
 }
 
+// Round 4, one launch per panel of a small Kuu (the factorisation chain is what a minibatch step waits for).
+// Launch p of the chain =  trailing update of panel p  +  factorisation of block (q, q), q = p + 1  +  the TRSM of panel q  +  the
+// T panels of block row q.  The round-3 form needed two launches for this (update + factorisation; TRSM + T panels) and paid the
+// launch boundary between them (~8 us of the ~54 us a panel costs at M = 1024) for a dependency that is much narrower than "the whole
+// previous launch": the TRSM of rows [c NT, (c + 1) NT) of tile (i, q) reads exactly the rows the SAME workgroup has just updated, plus
+// inv(L_qq).  So every workgroup that updated a chunk of block column q keeps going: it waits for flag[q] (set by the workgroup that
+// factored block (q, q), the last arriver of tile 0's chunks as in the round-3 fused kernel) and runs its own rows' TRSM; q * NCH
+// further workgroups of the launch wait for the same flag and write the T panels.
+//   Residency: waiting workgroups hold a CU slot, so the launch must fit the chip at once - potrf_t checks (nt + q) NCH against the
+// slots (one workgroup per CU for f64: potf2's LDS image) and falls back to the two-launch form otherwise.  The only thing anybody
+// waits for is the factorisation, whose workgroup is one of blockIdx 0 .. NCH - 1 (dispatched first) and waits for nothing but those
+// NCH workgroups: no cycle.  A wait that outlasts 0.2 s (never seen; a guard against a wedged box, not a protocol step) gives up
+// and reports through info.  NOT ADOPTED (see potrf_t): correct and bitwise equal to the two-launch form, but no faster.
+// sync layout (unsigned words): [p] hand-over counter of tile (p + 1, p + 1)  |  [nP + q] flag: block (q, q) factored and stored.
+template <typename T, int NT>
+__global__ void __launch_bounds__(k256, sizeof(T) == 8 ? 1 : 2) chol_chain_kernel(T* __restrict__ A, T* __restrict__ Tm, int64_t ld, int p, int n,
+                                                                                   int nP, int* __restrict__ info, unsigned* __restrict__ sync) {
+  using G = TileGemm<T, NT, 16, k256>;
+  using QRegs = typename G::QRegs;
+  constexpr int NB = kNB, NCH = NB / NT;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  T* smem = reinterpret_cast<T*>(smem_raw);
+  const int chunk = blockIdx.x % NCH, tile = blockIdx.x / NCH;
+  const int nt = n * (n + 1) / 2, q = p + 1;
+  unsigned* flag = sync + nP + q;
+  int ti = 0, tj = 0;
+  if (tile < nt) {   // ---- trailing update: A[i, j] -= L[i, p] L[j, p]' ----
+    tri_index(tile, ti, tj);
+    const int i = q + ti, j = q + tj;
+    typename G::Acc acc;
+    acc.zero();
+    const T* P = A + int64_t(j) * NB + int64_t(p) * NB * ld;
+    const T* Q = A + int64_t(i) * NB + int64_t(p) * NB * ld + chunk * NT;
+    const typename G::QOff qoff = G::q_offsets(ld);
+    auto qload = [&](int t, QRegs& r) { G::load_q(r, Q + int64_t(t) * 16 * ld, qoff); };
+    G::loop(acc, P, ld, NB / 16, qload, smem);
+    T* C = A + int64_t(i) * NB + int64_t(j) * NB * ld + chunk * NT;
+#pragma unroll
+    for (int a = 0; a < G::MI; ++a)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int b = 0; b < G::NJ; ++b) {
+          T* dst = C + G::acc_col(b) + int64_t(G::acc_row(a, r)) * ld;
+          *dst -= acc.v[a][b][r];
+        }
+    if (tj != 0) return;           // not a tile of block column q: nothing more to do here
+    if (ti == 0) {                 // tile (q, q): hand over to the factorisation as in chol_tile_kernel<FUSE>
+      __shared__ int is_last;
+      __threadfence();
+      __syncthreads();
+      if (threadIdx.x == 0) is_last = (__hip_atomic_fetch_add(&sync[p], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == unsigned(NCH - 1));
+      __syncthreads();
+      if (!is_last) return;
+      __threadfence();
+      potf2_body<T>(A + int64_t(q) * NB * (ld + 1), Tm + int64_t(q) * NB * (ld + 1), ld, info, q * NB, smem_raw);
+      __threadfence();             // release: L_qq and inv(L_qq) device-wide before the flag (also on the failure returns of potf2_body)
+      __syncthreads();
+      if (threadIdx.x == 0) __hip_atomic_store(flag, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      return;
+    }
+  }
+  // ---- wait for block (q, q) ----
+  if (threadIdx.x == 0) {
+    const uint64_t t0 = wall_clock64();   // 100 MHz
+    // relaxed polls (an acquire here would invalidate caches a hundred times a microsecond across the chip); ONE acquire fence below
+    while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+      __builtin_amdgcn_s_sleep(16);
+      if (wall_clock64() - t0 > 20000000ull) {
+        atomicCAS(info, 0, 0x7ffffffe);
+        break;
+      }
+    }
+  }
+  __syncthreads();
+  __threadfence();                 // acquire: the factorisation's stores (another CU, possibly another XCD) before the loads below
+  typename G::Acc acc;
+  acc.zero();
+  const T* P = Tm + int64_t(q) * NB * (ld + 1);   // inv(L_qq)
+  if (tile >= nt) {   // T[q, J] = -inv(L_qq) L[q, J]
+    const int J = tile - nt;
+    const T* Q = A + int64_t(q) * NB + (int64_t(J) * NB + chunk * NT) * ld;
+    auto qload = [&](int t, QRegs& r) { G::load_q_trans(r, Q + int64_t(t) * 16, ld); };
+    G::loop(acc, P, ld, NB / 16, qload, smem);
+    T* C = Tm + int64_t(q) * NB + (int64_t(J) * NB + chunk * NT) * ld;
+#pragma unroll
+    for (int a = 0; a < G::MI; ++a)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int b = 0; b < G::NJ; ++b) C[G::acc_row(a, r) + int64_t(G::acc_col(b)) * ld] = -acc.v[a][b][r];
+    return;
+  }
+  // L[i, q] = A[i, q] inv(L_qq)' on the rows this workgroup has just updated
+  const int i = q + ti;
+  T* C = A + int64_t(i) * NB + int64_t(q) * NB * ld + chunk * NT;
+  const typename G::QOff qoff = G::q_offsets(ld);
+  auto qload = [&](int t, QRegs& r) { G::load_q(r, C + int64_t(t) * 16 * ld, qoff); };
+  G::loop(acc, P, ld, NB / 16, qload, smem);
+#pragma unroll
+  for (int a = 0; a < G::MI; ++a)
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int b = 0; b < G::NJ; ++b) C[G::acc_col(b) + int64_t(G::acc_row(a, r)) * ld] = acc.v[a][b][r];
+}
+
 // The large-grid form of the trailing update (trailing matrices of >= 256 tiles fill the chip by themselves): whole
 // 128 x 128 tiles on 512-thread workgroups, A[i, j] -= L[i, p] L[j, p]' computed transposed so that stores run along columns
 // of A (half the operand traffic of the chunked form).  FUSE: workgroup 0 owns tile (p+1, p+1) and factors it right after its
@@ -1027,10 +1134,24 @@ void potrf_t(hipStream_t s, T* A, T* Tm, int64_t Mp, int* info, unsigned* sync, 
     dbg("T panels", s);
     return;
   }
+  // one launch per panel (chol_chain_kernel) where the whole launch is resident at once.  MEASURED AND NOT ADOPTED
+  // (profiles/round4/chol_chain.md): bitwise the same factor, but no faster - M = 1024 f64 0.558-0.561 ms of prep against 0.553-0.561,
+  // fp32 0.580-0.588 against 0.552-0.560.  The kernel trace says why: the TRSM launch already starts the instant the fused
+  // update + factorisation launch ends (0.0 us between them), so the flag hand-over (57 us per chain launch against 46.4 + 8.8)
+  // replaces a boundary that cost nothing; the 5.4 us gap sits in front of every update launch in either form.  A/B knob, default off.
+  static const bool chain_on = [] { const char* e = getenv("SVGP_CHOL_CHAIN"); return e && e[0] == '1'; }();
+  static const int chain_slots = [] {
+    hipDeviceProp_t prop;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
+    return prop.multiProcessorCount * (sizeof(T) == 8 ? 1 : 2);
+  }();
+  set_max_lds(reinterpret_cast<const void*>(chol_chain_kernel<T, CNT>), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds_fused_s));
+  bool trsm_done = false;   // panel p's TRSM and T panels rode in the previous chain launch
   potf2(0);
   for (int p = 0; p < nP; ++p) {
     const int n = nP - p - 1, nt_p = t_inside ? p : 0;
-    if (n + nt_p > 0) {   // the panel below the diagonal (and the T panels of block row p)
+    if (!trsm_done && n + nt_p > 0) {   // the panel below the diagonal (and the T panels of block row p)
       hipLaunchKernelGGL((chol_tile_kernel<T, MODE_TRSM, CNT>), dim3((n + nt_p) * NCH), dim3(k256), GS::LDS_BYTES, s, A, Tm, Mp, p, n, info, sync);
       dbg("chol trsm + T panels", s);
     }
@@ -1042,7 +1163,11 @@ void potrf_t(hipStream_t s, T* A, T* Tm, int64_t Mp, int* info, unsigned* sync, 
     const bool large = nt >= 256;   // a trailing matrix that fills the chip by itself: full 128 x 128 tiles (half the operand traffic)
     // the fused f64 form of the large grid would cost the second resident workgroup (potf2's LDS image of an f64 block is 146 KiB)
     const bool fused = fuse_on && !(large && sizeof(T) == 8);
-    if (fused && large) {
+    trsm_done = false;
+    if (fused && !large && chain_on && t_inside && (nt + p + 1) * NCH <= chain_slots) {
+      hipLaunchKernelGGL((chol_chain_kernel<T, CNT>), dim3((nt + p + 1) * NCH), dim3(k256), lds_fused_s, s, A, Tm, Mp, p, n, nP, info, sync);
+      trsm_done = true;
+    } else if (fused && large) {
       big_update(nt, p, 1);
     } else if (fused) {
       hipLaunchKernelGGL((chol_tile_kernel<T, MODE_SYRK, CNT, true>), dim3(nt * NCH), dim3(k256), lds_fused_s, s, A, Tm, Mp, p, n, info, sync);

@@ -14,4 +14,4 @@ for name, fn in (("elbo", lambda: model.elbo(data, 0, n, float(n))[0]), ("elbo_g
     fn(); ts = []
     for _ in range(3):
         t0 = time.perf_counter(); v = fn(); ts.append(time.perf_counter() - t0)
-    print(f"{cfg} {name}: {min(ts)*1e3:.1f} ms  value {v:.6f}")
+    print(f"{cfg} {name}: {min(ts)*1e3:.3f} ms  value {v:.6f}")
