@@ -179,7 +179,7 @@ KernelParams kparams(const svgp_model* m) {
 // overlap (NonCentered only): everything the strips need besides T - the scaled inducing inputs, U = Lq', the padded mean - is
 // enqueued FIRST and ctx->ev_fork recorded behind it; the factorisation then records ctx->ev_row[p] as block row p of T becomes
 // final, so that strips on a second stream can run beside it (enqueue_strips_overlapped).
-int enqueue_prep(svgp_ctx* ctx, svgp_model* m, bool overlap = false) {
+int enqueue_prep(svgp_ctx* ctx, svgp_model* m, bool overlap = false, const RowHook* hook = nullptr) {
   hipStream_t s = ctx->stream;
   const KernelParams kp = kparams(m);
   HIPC(ctx, hipMemsetAsync(m->info, 0, sizeof(int) * size_t(1 + 2 * (m->Mp / 128)), s));   // info + the factorisation's hand-over counters and flags
@@ -190,11 +190,13 @@ int enqueue_prep(svgp_ctx* ctx, svgp_model* m, bool overlap = false) {
     KCHECK(ctx, "pack_q");
     HIPC(ctx, hipEventRecord(ctx->ev_fork, s));
     HIPC(ctx, hipEventRecord(ctx->ev_ov[0], s));
+    if (hook && hook->fn) hook->fn(hook->user, -1);   // the strips' pre-generation: behind the fork, before the chain is enqueued
   }
   launch_kuu(m->dtype, s, kp, m->zs, m->M, m->Mp, m->desc.jitter, m->L);
   KCHECK(ctx, "kuu");
   HIPC(ctx, hipEventRecord(ctx->ev_chol[0], s));
-  launch_potrf(m->dtype, s, m->L, m->T, m->Mp, m->info, reinterpret_cast<unsigned*>(m->info + 1), overlap ? ctx->ev_row : nullptr);   // T panels included
+  launch_potrf(m->dtype, s, m->L, m->T, m->Mp, m->info, reinterpret_cast<unsigned*>(m->info + 1), overlap ? ctx->ev_row : nullptr,
+               overlap ? hook : nullptr);   // T panels included
   KCHECK(ctx, "potrf");
   HIPC(ctx, hipEventRecord(ctx->ev_chol[1], s));
   if (overlap) {
@@ -450,9 +452,60 @@ OverlapPlan overlap_plan(const svgp_ctx* ctx, const svgp_model* m, int64_t len, 
   return p;
 }
 
-int enqueue_strips_overlapped(svgp_ctx* ctx, svgp_model* m, const void* x, int64_t ldx, const void* y, int64_t off, int64_t len,
-                              const StripOuts& o, const OverlapPlan& op) {
-  hipStream_t s = ctx->stream, s2 = ctx->stream2;
+// The segmented strips of ONE evaluation.  Their launches wait for events the factorisation records panel by panel, and a wait can
+// only be enqueued BEHIND its record - so they are enqueued from inside the factorisation's launch loop (RowHook), each right behind
+// the record it waits for.  (Until late in round 4 they were enqueued after the whole prep: the host needs 5-10 us per launch, the ~25
+// launches of the prep took it longer than the device needed to start the chain, and the strips' first panel reached the second stream
+// when the chain was already a third - in the gradient, where the M-sized adjoint prep is enqueued first as well, completely - done.)
+struct SegRun {
+  svgp_ctx* ctx = nullptr;
+  svgp_model* m = nullptr;
+  StripArgs a{};
+  OverlapPlan op;
+  bool grad = false, ckpt = false;
+  int nP = 0, ck[3] = {0, 0, 0}, ck_prev = 0, rc = SVGP_OK;
+  size_t wb1 = 0;
+  int64_t head = 0;
+};
+
+// row -1: the Kuf pre-generation (behind ev_fork); row I >= 0: phase-1 panel I (behind ev_row[I]); the forward's last panel carries
+// phase 2, the gradient's closing launch (phase 2 + 3, behind ev_R) is enqueued by grad_enqueue_impl
+int seg_enqueue_row(SegRun& r, int row) {
+  svgp_ctx* ctx = r.ctx;
+  hipStream_t s2 = ctx->stream2;
+  StripArgs& a = r.a;
+  const int dt = r.m->dtype;
+  if (row < 0) {
+    HIPC(ctx, hipStreamWaitEvent(s2, ctx->ev_fork, 0));
+    a.seg_flags = kSegPregen; a.seg_lo = 0; a.seg_hi = 0;
+    launch_strip_seg(dt, s2, a, r.op.nt, r.op.grid, r.op.nstrips, r.grad);
+    KCHECK(ctx, "strip (segmented: pre-generation)");
+    return SVGP_OK;
+  }
+  const int I = row, nP = r.nP;
+  HIPC(ctx, hipStreamWaitEvent(s2, ctx->ev_row[I], 0));
+  a.seg_lo = I; a.seg_hi = I + 1;
+  a.seg_flags = (I > 0 ? kSegLoad : 0) | ((r.grad || I + 1 < nP) ? kSegStore : kSegPhase2);
+  a.seg_p2_lo = a.seg_p2_hi = 0;
+  if (r.ckpt) {
+    a.seg_flags |= kSegP2;
+    if (I + 1 == r.ck[0] || I + 1 == r.ck[1] || I + 1 == r.ck[2]) {
+      if (I + 1 > r.ck_prev) { a.seg_p2_lo = r.ck_prev; a.seg_p2_hi = I + 1; r.ck_prev = I + 1; }
+    }
+  }
+  launch_strip_seg(dt, s2, a, r.op.nt, r.op.grid, r.op.nstrips, r.grad);
+  KCHECK(ctx, "strip (segmented: panel)");
+  if (I == 0) HIPC(ctx, hipEventRecord(ctx->ev_ov[1], s2));
+  return SVGP_OK;
+}
+
+void seg_row_hook(void* user, int row) {
+  SegRun& r = *static_cast<SegRun*>(user);
+  if (r.rc == SVGP_OK) r.rc = seg_enqueue_row(r, row);
+}
+
+// forward evaluation, stage 1 (BEFORE the prep is enqueued): every allocation and the strips' arguments
+int seg_prepare_forward(svgp_ctx* ctx, svgp_model* m, const void* x, int64_t ldx, int64_t off, int64_t len, const OverlapPlan& op, SegRun& r) {
   const int nP = int(m->Mp / 128);
   const int64_t head = op.head_points < len ? op.head_points : len;
   // the segmented strips' scratch is per STRIP and lives beside the main launch's per-workgroup scratch (a segmented head runs
@@ -463,7 +516,6 @@ int enqueue_strips_overlapped(svgp_ctx* ctx, svgp_model* m, const void* x, int64
   // strips' extra work beside it occupies (16 384 / 1024 f64: prep 0.60 -> 0.78 ms, rest 0.38 -> 0.23: 1.046 -> 1.06-1.07 ms; M = 2048
   // 1.94 -> 2.11).  The chain is latency-bound and every CU a strip launch holds delays it.  SVGP_OVERLAP_P2CKPT=1 enables it.
   const char* ckq = getenv("SVGP_OVERLAP_P2CKPT");   // per call; A/B knob
-  const bool ckpt = (ckq && atoi(ckq) == 1) && nP >= 4;
   if (wb > ctx->work_seg_bytes) {
     if (ctx->work_seg) (void)hipFree(ctx->work_seg);
     ctx->work_seg = nullptr;
@@ -473,48 +525,39 @@ int enqueue_strips_overlapped(svgp_ctx* ctx, svgp_model* m, const void* x, int64
   }
   int rc = ensure_scratch(ctx, 0, size_t(len));
   if (rc) return rc;
-  StripOuts rest = o;   // the part behind the head: sized and allocated BEFORE anything is enqueued (ensure_scratch may reallocate)
-  if (head < len) {
+  if (head < len) {   // the part behind the head: sized and allocated BEFORE anything is enqueued (ensure_scratch may reallocate)
     const StripPlan rp = strip_plan_single(m->dtype, m->Mp, len - head, ctx->num_cus);
     const size_t w1 = rp.grid ? strip_work_bytes(m->dtype, m->Mp, rp.nt, rp.grid) : 0;
     const size_t w2 = rp.nt_tail ? strip_work_bytes(m->dtype, m->Mp, rp.nt_tail, rp.grid_tail) : 0;
     rc = ensure_scratch(ctx, w1 > w2 ? w1 : w2, size_t(len));
     if (rc) return rc;
   }
-  StripArgs a{};
+  r.ctx = ctx; r.m = m; r.op = op; r.grad = false; r.nP = nP; r.wb1 = wb1; r.head = head;
+  r.ckpt = (ckq && atoi(ckq) == 1) && nP >= 4;
+  r.ck[0] = nP / 2; r.ck[1] = (3 * nP) / 4; r.ck[2] = nP;   // phase-2 checkpoints: after panels ck[.] - 1
+  StripArgs& a = r.a;
   a.T = m->T; a.U = m->U; a.zs = m->zs; a.mp = m->mp; a.x = x; a.work = ctx->work_seg; a.counter = ctx->counter2;
   a.mom_mu = ctx->mom; a.mom_var = ctx->mom + ctx->mom_cap;
   a.ldx = ldx; a.off = off; a.len = head; a.Mp = m->Mp; a.M = m->M; a.kp = kparams(m); a.mean_const = m->desc.mean_const;
   a.seg_state = ctx->seg_state;
-  HIPC(ctx, hipStreamWaitEvent(s2, ctx->ev_fork, 0));
-  a.seg_flags = kSegPregen; a.seg_lo = 0; a.seg_hi = 0;
-  launch_strip_seg(m->dtype, s2, a, op.nt, op.grid, op.nstrips);
-  KCHECK(ctx, "strip (segmented: pre-generation)");
   a.seg_cacc = static_cast<char*>(ctx->work_seg) + wb1;
-  const int ck[3] = {nP / 2, (3 * nP) / 4, nP};   // phase-2 checkpoints: after panels ck[.] - 1
-  int ck_prev = 0;
-  for (int I = 0; I < nP; ++I) {
-    HIPC(ctx, hipStreamWaitEvent(s2, ctx->ev_row[I], 0));
-    a.seg_lo = I; a.seg_hi = I + 1;
-    a.seg_flags = (I > 0 ? kSegLoad : 0) | (I + 1 < nP ? kSegStore : kSegPhase2);
-    a.seg_p2_lo = a.seg_p2_hi = 0;
-    if (ckpt) {
-      a.seg_flags |= kSegP2;
-      if (I + 1 == ck[0] || I + 1 == ck[1] || I + 1 == ck[2]) {
-        if (I + 1 > ck_prev) { a.seg_p2_lo = ck_prev; a.seg_p2_hi = I + 1; ck_prev = I + 1; }
-      }
-    }
-    launch_strip_seg(m->dtype, s2, a, op.nt, op.grid, op.nstrips);
-    KCHECK(ctx, "strip (segmented: panel)");
-    if (I == 0) HIPC(ctx, hipEventRecord(ctx->ev_ov[1], s2));
-  }
+  return SVGP_OK;
+}
+
+// forward evaluation, stage 2 (AFTER the prep, whose launch loop enqueued the segments): the rest of the batch, the join, the expectation
+int seg_finish_forward(svgp_ctx* ctx, svgp_model* m, const void* x, int64_t ldx, const void* y, int64_t off, int64_t len,
+                       const StripOuts& o, SegRun& r) {
+  hipStream_t s = ctx->stream, s2 = ctx->stream2;
+  if (r.rc) return r.rc;
+  const int64_t head = r.head;
   HIPC(ctx, hipEventRecord(ctx->ev_join, s2));
-  int launches = nP + 1;
+  int launches = r.nP + 1;
   if (head < len) {   // the rest of the batch: the one-launch kernel behind the prep, on the main stream, beside the head's tail
+    StripOuts rest = o;
     rest.mom_shift = head;
     rest.no_ctail = true;
     rest.skip_expect = true;
-    rc = enqueue_strips(ctx, m, x, ldx, y, off + head, len - head, rest);
+    const int rc = enqueue_strips(ctx, m, x, ldx, y, off + head, len - head, rest);
     if (rc) return rc;
     launches += int(ctx->timing.strip_launches);
   }
@@ -531,7 +574,7 @@ int enqueue_strips_overlapped(svgp_ctx* ctx, svgp_model* m, const void* x, int64
   lp.gh_w = m->gh_w;
   lp.clamp_neg_var = (m->desc.neg_var_policy == SVGP_NEGVAR_CLAMP);
   lp.mean_const = m->desc.mean_const;
-  launch_expect(m->dtype, s, lp, a.mom_mu, a.mom_var, y, off, len, ctx->partial, ctx->negcnt, o.mu, o.var);
+  launch_expect(m->dtype, s, lp, r.a.mom_mu, r.a.mom_var, y, off, len, ctx->partial, ctx->negcnt, o.mu, o.var);
   KCHECK(ctx, "expect");
   launch_final_reduce(s, ctx->partial, ctx->negcnt, expect_blocks(len), m->info, double(len), ctx->d_res, m->scal);
   KCHECK(ctx, "final_reduce");
@@ -566,25 +609,33 @@ int elbo_enqueue(svgp_ctx* ctx, svgp_model* m, const svgp_data* data, int64_t of
     if (rc) return rc;
   }
   ctx->overlapped = op.on;
-  HIPC(ctx, hipEventRecord(ctx->ev[0], s));
-  rc = enqueue_prep(ctx, m, op.on);
-  if (rc) return rc;
-  HIPC(ctx, hipEventRecord(ctx->ev[1], s));
-  {   // diagnostic (SVGP_OVERLAP_DRY=1): the overlap's prep - reordered, with its row events recorded - but the strips behind it as usual:
-      // what the events alone cost the chain
-    const char* dq = getenv("SVGP_OVERLAP_DRY");
-    if (op.on && dq && atoi(dq) == 1) {
-      ctx->overlapped = false;   // ev_ov[1] is not recorded on this path
-      rc = enqueue_strips(ctx, m, data->x, data->ldx, data->y, off, len, StripOuts{});
-      if (rc) return rc;
-      HIPC(ctx, hipEventRecord(ctx->ev[3], s));
-      return SVGP_OK;
-    }
+  const char* dq = getenv("SVGP_OVERLAP_DRY");   // diagnostic: the overlap's prep - reordered, with its row events recorded - but the strips
+  const bool dry = op.on && dq && atoi(dq) == 1;  // behind it as usual: what the events alone cost the chain
+  SegRun seg;
+  RowHook hook{seg_row_hook, &seg};
+  if (op.on && !dry) {
+    rc = seg_prepare_forward(ctx, m, data->x, data->ldx, off, len, op, seg);
+    if (rc) return rc;
   }
-  rc = op.on ? enqueue_strips_overlapped(ctx, m, data->x, data->ldx, data->y, off, len, StripOuts{}, op)
-             : enqueue_strips(ctx, m, data->x, data->ldx, data->y, off, len, StripOuts{});
+  HIPC(ctx, hipEventRecord(ctx->ev[0], s));
+  rc = enqueue_prep(ctx, m, op.on, (op.on && !dry) ? &hook : nullptr);
+  if (rc == SVGP_OK && op.on && !dry) rc = seg.rc;
   if (rc) {   // a failure between the fork and the join leaves work on the second stream that the main stream never waited for: drain it,
               // so that the next call on this context cannot meet it in the shared scratch
+    if (op.on && ctx->stream2) (void)hipStreamSynchronize(ctx->stream2);
+    return rc;
+  }
+  HIPC(ctx, hipEventRecord(ctx->ev[1], s));
+  if (dry) {
+    ctx->overlapped = false;   // ev_ov[1] is not recorded on this path
+    rc = enqueue_strips(ctx, m, data->x, data->ldx, data->y, off, len, StripOuts{});
+    if (rc) return rc;
+    HIPC(ctx, hipEventRecord(ctx->ev[3], s));
+    return SVGP_OK;
+  }
+  rc = op.on ? seg_finish_forward(ctx, m, data->x, data->ldx, data->y, off, len, StripOuts{}, seg)
+             : enqueue_strips(ctx, m, data->x, data->ldx, data->y, off, len, StripOuts{});
+  if (rc) {
     if (op.on && ctx->stream2) (void)hipStreamSynchronize(ctx->stream2);
     return rc;
   }
@@ -810,6 +861,9 @@ int32_t svgp_ctx_destroy(svgp_ctx* c) {
   if (c->ev_R) (void)hipEventDestroy(c->ev_R);
   if (c->seg_state) (void)hipFree(c->seg_state);
   if (c->work_seg) (void)hipFree(c->work_seg);
+  if (c->hstage) (void)hipHostFree(c->hstage);
+  for (auto& e : c->ev_piece)
+    if (e) (void)hipEventDestroy(e);
   if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
   if (c->ev_join) (void)hipEventDestroy(c->ev_join);
   if (c->stream2) { (void)hipStreamSynchronize(c->stream2); (void)hipStreamDestroy(c->stream2); }
@@ -1367,30 +1421,11 @@ int grad_enqueue_impl(svgp_ctx* ctx, svgp_model* m, const svgp_data* data, int64
     }
     if (gop.on) {
       rc = ensure_overlap(ctx, size_t(gop.nstrips) * strip_seg_state_doubles(dt, gop.nt));
-      if (rc == SVGP_OK) rc = ensure_scratch(ctx, 2 * strip_work_bytes(dt, Mp, gop.nt, int(gop.nstrips)), size_t(nc));
+      // the size the chunk loop below asks for (per workgroup >= per strip here): nothing may reallocate once segments are enqueued
+      if (rc == SVGP_OK) rc = ensure_scratch(ctx, 2 * strip_work_bytes(dt, Mp, gop.nt, gop.grid > int(gop.nstrips) ? gop.grid : int(gop.nstrips)), size_t(nc));
       if (rc) return rc;
     }
   }
-  ctx->overlapped = gop.on;
-  HIPC(ctx, hipEventRecord(ctx->ev[0], s));
-  rc = enqueue_prep(ctx, m, gop.on);
-  if (rc) return rc;
-  HIPC(ctx, hipEventRecord(ctx->ev[1], s));
-  HIPC(ctx, hipMemsetAsync(w->zero_blk, 0, w->zero_b, s));   // every accumulator of the evaluation, one fill
-  HIPC(ctx, hipMemcpyAsync(w->invl_d, m->invl_host.data(), size_t(m->d) * 8, hipMemcpyHostToDevice, s));
-  // Linv = Lk^-1 (both storage orders): every Lk^-T . below is a GEMM with it (round 2: four blocked substitutions, 0.18 ms each
-  // at M = 1024 whatever the batch size)
-  launch_linv(dt, s, m->L, m->T, Mp, w->LinvRM, w->LinvCM, w->H);
-  // the adjoint runs on the whitened problem: (m~, B) are (m, Lq) for NonCentered and (Lk^-1 (m - c), Lk^-1 Lq) for Centered
-  const void* Bq = centered ? m->B : w->Lqp;
-  if (!centered) launch_pad_lower(dt, s, m->Lq_raw, M, Mp, w->Lqp);
-  // M-sized operands of the strips' phase 3:  alpha = Lk^-T m~,  R = Lk^-T (B B' - I)  (column-major: the P operand of the GEMM)
-  launch_linv_t_gemv(dt, s, w->LinvRM, m->mp, Mp, w->alpha, w->gemv_part);
-  gemm_mm(ctx, w, dt, s, Bq, Bq, Mp, w->G2, kMmXUp | kMmYUp);               // lower tiles of B B' (row-major); B[r][k] = 0 for k > r
-  launch_sym_from_lower(dt, s, w->G2, 1, Mp, 1.0, w->tmp);                 // S = B B' - I, full
-  gemm_mm(ctx, w, dt, s, w->tmp, w->LinvRM, Mp, w->Rcm, kMmFull | kMmYLow); // out[c][r] = sum_k S[k][c] Linv[k][r] = R[r][c]: R column-major
-  KCHECK(ctx, "grad prep");
-  if (gop.on) HIPC(ctx, hipEventRecord(ctx->ev_R, s));   // R and alpha are final: the segmented strips' closing launch (phase 3) may run
   LikParams lp{};
   lp.lik = m->desc.likelihood;
   lp.gh_n = m->gh_n;
@@ -1428,6 +1463,53 @@ int grad_enqueue_impl(svgp_ctx* ctx, svgp_model* m, const svgp_data* data, int64
   const bool uniform_w = m->desc.likelihood == SVGP_LIK_GAUSSIAN && !gc.ext_gmu && m->gh_n == 0 && (!uw_env || atoi(uw_env) != 0);
   const bool a_in_strips = (dt == SVGP_F32) && !post;
   const bool a_from_k = !a_in_strips && afk_knob;
+  // the strips' arguments for the chunk [c0, c0 + clen) (scratch / moment pointers: read after the ensure_scratch of the caller)
+  auto strip_args = [&](int64_t c0, int64_t clen, LikParams& lpc) -> StripArgs {
+    StripArgs a{};
+    a.T = m->T; a.U = m->U; a.zs = m->zs; a.mp = m->mp; a.x = data->x; a.work = ctx->work; a.counter = ctx->counter;
+    a.At_out = w->At; a.ldx = data->ldx; a.off = off + c0; a.len = clen; a.Mp = Mp; a.M = M; a.kp = kp;
+    a.mean_const = m->desc.mean_const;
+    a.mom_mu = ctx->mom; a.mom_var = ctx->mom + ctx->mom_cap;   // post: the strips' (mu, v), read by launch_point_grads
+    a.R = w->Rcm; a.alpha = w->alpha; a.Pt_out = w->Pt; a.gmu_out = w->gmu; a.gv_out = w->gv; a.y = data->y;
+    lpc = lp;
+    if (gc.ext_gmu) { lpc.lik = kLikExternal; lpc.gh_x = ctx->ext_g + c0; lpc.gh_w = ctx->ext_g + ctx->ext_cap + c0; a.y = nullptr; }
+    a.part5 = w->partial5; a.apart = a_in_strips ? w->apart : nullptr; a.lp = lpc; a.scale = scale; a.n_global_dev = n_global_dev; a.num_data = gc.num_data;
+    return a;
+  };
+  // segmented strips (gop.on): enqueued panel by panel from inside the factorisation's launch loop (SegRun), so built before the prep
+  SegRun gseg;
+  RowHook ghook{seg_row_hook, &gseg};
+  LikParams lpc_seg{};
+  if (gop.on) {
+    gseg.ctx = ctx; gseg.m = m; gseg.op = gop; gseg.grad = true; gseg.nP = int(Mp / 128);
+    gseg.a = strip_args(0, len, lpc_seg);
+    gseg.a.seg_state = ctx->seg_state;
+    gseg.a.counter = ctx->counter2;
+  }
+  ctx->overlapped = gop.on;
+  HIPC(ctx, hipEventRecord(ctx->ev[0], s));
+  rc = enqueue_prep(ctx, m, gop.on, gop.on ? &ghook : nullptr);
+  if (rc == SVGP_OK && gop.on) rc = gseg.rc;
+  if (rc) {
+    if (gop.on && ctx->stream2) (void)hipStreamSynchronize(ctx->stream2);   // segments already enqueued: drain before the scratch is reused
+    return rc;
+  }
+  HIPC(ctx, hipEventRecord(ctx->ev[1], s));
+  HIPC(ctx, hipMemsetAsync(w->zero_blk, 0, w->zero_b, s));   // every accumulator of the evaluation, one fill
+  HIPC(ctx, hipMemcpyAsync(w->invl_d, m->invl_host.data(), size_t(m->d) * 8, hipMemcpyHostToDevice, s));
+  // Linv = Lk^-1 (both storage orders): every Lk^-T . below is a GEMM with it (round 2: four blocked substitutions, 0.18 ms each
+  // at M = 1024 whatever the batch size)
+  launch_linv(dt, s, m->L, m->T, Mp, w->LinvRM, w->LinvCM, w->H);
+  // the adjoint runs on the whitened problem: (m~, B) are (m, Lq) for NonCentered and (Lk^-1 (m - c), Lk^-1 Lq) for Centered
+  const void* Bq = centered ? m->B : w->Lqp;
+  if (!centered) launch_pad_lower(dt, s, m->Lq_raw, M, Mp, w->Lqp);
+  // M-sized operands of the strips' phase 3:  alpha = Lk^-T m~,  R = Lk^-T (B B' - I)  (column-major: the P operand of the GEMM)
+  launch_linv_t_gemv(dt, s, w->LinvRM, m->mp, Mp, w->alpha, w->gemv_part);
+  gemm_mm(ctx, w, dt, s, Bq, Bq, Mp, w->G2, kMmXUp | kMmYUp);               // lower tiles of B B' (row-major); B[r][k] = 0 for k > r
+  launch_sym_from_lower(dt, s, w->G2, 1, Mp, 1.0, w->tmp);                 // S = B B' - I, full
+  gemm_mm(ctx, w, dt, s, w->tmp, w->LinvRM, Mp, w->Rcm, kMmFull | kMmYLow); // out[c][r] = sum_k S[k][c] Linv[k][r] = R[r][c]: R column-major
+  KCHECK(ctx, "grad prep");
+  if (gop.on) HIPC(ctx, hipEventRecord(ctx->ev_R, s));   // R and alpha are final: the segmented strips' closing launch (phase 3) may run
   for (int64_t c0 = 0; c0 < len; c0 += nc) {
     const int64_t clen = (len - c0 < nc) ? len - c0 : nc;
     const int64_t ncp = (clen + 127) / 128 * 128;
@@ -1439,30 +1521,14 @@ int grad_enqueue_impl(svgp_ctx* ctx, svgp_model* m, const svgp_data* data, int64
     if (rc) return rc;
     if (nstrips > w->part5_strips) return fail(ctx, SVGP_HIP_ERROR, "internal: strip partial buffer too small");
     HIPC(ctx, hipMemsetAsync(w->gmu, 0, 2 * size_t(w->nc) * es, s));   // g_mu | g_v, w->nc apart (the SYRK reads g_v over the padded chunk)
-    StripArgs a{};
-    a.T = m->T; a.U = m->U; a.zs = m->zs; a.mp = m->mp; a.x = data->x; a.work = ctx->work; a.counter = ctx->counter;
-    a.At_out = w->At; a.ldx = data->ldx; a.off = off + c0; a.len = clen; a.Mp = Mp; a.M = M; a.kp = kp;
-    a.mean_const = m->desc.mean_const;
-    a.mom_mu = ctx->mom; a.mom_var = ctx->mom + ctx->mom_cap;   // post: the strips' (mu, v), read by launch_point_grads
-    a.R = w->Rcm; a.alpha = w->alpha; a.Pt_out = w->Pt; a.gmu_out = w->gmu; a.gv_out = w->gv; a.y = data->y;
-    LikParams lpc = lp;
-    if (gc.ext_gmu) { lpc.lik = kLikExternal; lpc.gh_x = ctx->ext_g + c0; lpc.gh_w = ctx->ext_g + ctx->ext_cap + c0; a.y = nullptr; }
-    a.part5 = w->partial5; a.apart = a_in_strips ? w->apart : nullptr; a.lp = lpc; a.scale = scale; a.n_global_dev = n_global_dev; a.num_data = gc.num_data;
-    if (gop.on) {   // (single chunk) segmented strips on the second stream; the main stream joins before the point gradients
+    LikParams lpc{};
+    StripArgs a = gop.on ? gseg.a : strip_args(c0, clen, lpc);
+    if (gop.on) lpc = lpc_seg;
+    if (gop.on) {   // (single chunk) the segments are on the second stream already; the closing launch (phase 2 + 3) waits for R and alpha,
+                    // and the main stream joins before the point gradients
       hipStream_t s2 = ctx->stream2;
       const int nPn = int(Mp / 128);
-      a.seg_state = ctx->seg_state;
-      a.counter = ctx->counter2;
-      HIPC(ctx, hipStreamWaitEvent(s2, ctx->ev_fork, 0));
-      a.seg_flags = kSegPregen; a.seg_lo = 0; a.seg_hi = 0;
-      launch_strip_seg(dt, s2, a, nt, grid, nstrips, true);
-      for (int I = 0; I < nPn; ++I) {
-        HIPC(ctx, hipStreamWaitEvent(s2, ctx->ev_row[I], 0));
-        a.seg_lo = I; a.seg_hi = I + 1;
-        a.seg_flags = (I > 0 ? kSegLoad : 0) | kSegStore;
-        launch_strip_seg(dt, s2, a, nt, grid, nstrips, true);
-        if (I == 0) HIPC(ctx, hipEventRecord(ctx->ev_ov[1], s2));
-      }
+      if (a.work != ctx->work || a.mom_mu != ctx->mom) return fail(ctx, SVGP_HIP_ERROR, "internal: scratch moved under the segmented strips");
       HIPC(ctx, hipStreamWaitEvent(s2, ctx->ev_R, 0));
       a.seg_lo = a.seg_hi = nPn;
       a.seg_flags = kSegLoad | kSegPhase2;
@@ -1665,22 +1731,50 @@ int grad_finish(svgp_ctx* ctx, svgp_model* m, GradCall& gc, double* elbo_out, sv
   const size_t es = m->es;
   const int dreg = grad_dreg(m->d);
   const bool centered = gc.centered;
-  // read back: ONE copy of the fp64 block [sums (8) | scal_out (1 + dreg) | prep scalars (4) | chol_info] and ONE of the
-  // gradient blocks {z_bar | m_bar | Lq_bar} (round 2: seven copies, ~20 us of host latency each)
-  std::vector<double> f64blk(size_t(8 + 1 + dreg + 5));
+  // Read back: the fp64 block [sums (8) | scal_out (1 + dreg) | prep scalars (4) | chol_info] and the gradient blocks
+  // {z_bar | m_bar | Lq_bar}, contiguous on the device (round 2: seven copies, ~20 us of host latency each).  Lq_bar is M^2 elements -
+  // 8.4 MB at M = 1024 f64, 33.5 MB at M = 2048 - and a minibatch step is 1-3 ms of device time: until late in round 4 this went through a
+  // fresh std::vector per call (page faults + zero fill), a pageable device-to-host copy and a second host copy into the caller's
+  // buffers (M = 2048: 6.6 ms of an 11.7 ms call).  Now: a pinned staging buffer kept by the context, the copy issued in up to 8
+  // pieces with an event behind each, and the host copy of piece i into the caller's buffers running while piece i + 1 is on the bus.
   const size_t nz = size_t(M) * m->d, nblk = nz + size_t(M) + size_t(M) * M;
-  std::vector<char> gh(nblk * es);
-  HIPC(ctx, hipMemcpyAsync(f64blk.data(), w->sums, f64blk.size() * 8, hipMemcpyDeviceToHost, s));
-  HIPC(ctx, hipMemcpyAsync(gh.data(), w->gblk, gh.size(), hipMemcpyDeviceToHost, s));
+  const size_t f64n = size_t(8 + 1 + dreg + 5), f64b = (f64n * 8 + 255) / 256 * 256, gbytes = nblk * es;
+  if (f64b + gbytes > ctx->hstage_bytes) {
+    if (ctx->hstage) (void)hipHostFree(ctx->hstage);
+    ctx->hstage = nullptr;
+    ctx->hstage_bytes = 0;
+    HIPC(ctx, hipHostMalloc(&ctx->hstage, f64b + gbytes, hipHostMallocDefault));
+    ctx->hstage_bytes = f64b + gbytes;
+  }
+  for (auto& e : ctx->ev_piece)
+    if (!e) HIPC(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  double* f64blk = static_cast<double*>(ctx->hstage);
+  char* gh = static_cast<char*>(ctx->hstage) + f64b;
+  HIPC(ctx, hipMemcpyAsync(f64blk, w->sums, f64n * 8, hipMemcpyDeviceToHost, s));
+  const int npiece = int(std::min<size_t>(8, std::max<size_t>(1, gbytes >> 20)));   // >= 1 MiB per piece
+  const size_t piece = ((gbytes + npiece - 1) / npiece + 255) / 256 * 256;
+  for (int q = 0; q < npiece; ++q) {
+    const size_t lo = std::min(gbytes, size_t(q) * piece), hi = std::min(gbytes, lo + piece);
+    if (hi > lo) HIPC(ctx, hipMemcpyAsync(gh + lo, static_cast<const char*>(w->gblk) + lo, hi - lo, hipMemcpyDeviceToHost, s));
+    HIPC(ctx, hipEventRecord(ctx->ev_piece[q], s));
+  }
+  struct Dst { size_t lo, hi; void* p; };
+  const Dst dst[3] = {{0, nz * es, g->z}, {nz * es, (nz + size_t(M)) * es, g->m}, {(nz + size_t(M)) * es, gbytes, g->Lq}};
+  for (int q = 0; q < npiece; ++q) {
+    HIPC(ctx, hipEventSynchronize(ctx->ev_piece[q]));
+    const size_t lo = std::min(gbytes, size_t(q) * piece), hi = std::min(gbytes, lo + piece);
+    for (const Dst& d : dst) {
+      const size_t a = std::max(lo, d.lo), b = std::min(hi, d.hi);
+      if (d.p && b > a) memcpy(static_cast<char*>(d.p) + (a - d.lo), gh + a, b - a);
+    }
+  }
   HIPC(ctx, hipStreamSynchronize(s));
-  const double* sums = f64blk.data();
+  const double* sums = f64blk;
   const double* sc = sums + 8;
   PrepScalars ps;
   for (int q = 0; q < 4; ++q) ps.scal[q] = sums[8 + 1 + dreg + q];
   ps.info = int(sums[8 + 1 + dreg + 4]);
-  const char* mhost = gh.data() + nz * es;
-  if (g->z) memcpy(g->z, gh.data(), nz * es);
-  if (g->Lq) memcpy(g->Lq, gh.data() + (nz + size_t(M)) * es, size_t(M) * M * es);
+  const char* mhost = gh + nz * es;
   finish_prep(m, ps);
   float t01 = 0, t13 = 0;
   (void)hipEventElapsedTime(&t01, ctx->ev[0], ctx->ev[1]);
@@ -1700,7 +1794,6 @@ int grad_finish(svgp_ctx* ctx, svgp_model* m, GradCall& gc, double* elbo_out, sv
   const double elbo = r.E * scale - klw * m->kl;
   g->variance = sc[0] + sums[2];
   g->lik_sigma2 = sums[3];
-  if (g->m) memcpy(g->m, mhost, size_t(M) * es);
   double msum = 0.0;   // Centered: mean_const also enters through m~ = Lk \\ (m - c)
   if (centered)
     for (int64_t i = 0; i < M; ++i) msum += (dt == SVGP_F64) ? reinterpret_cast<const double*>(mhost)[i] : double(reinterpret_cast<const float*>(mhost)[i]);

@@ -37,6 +37,8 @@ struct svgp_ctx {
   hipEvent_t ev_ov[2] = {nullptr, nullptr};   // timed: fork point, first strip launch done (svgp_timing.ms_overlap)
   double* seg_state = nullptr; size_t seg_state_doubles = 0;
   void* work_seg = nullptr;    size_t work_seg_bytes = 0;   // per-strip scratch of the segmented strips
+  void* hstage = nullptr;      size_t hstage_bytes = 0;     // pinned host staging of the gradient read-back (api.hip: grad_finish)
+  hipEvent_t ev_piece[8] = {};                               // one behind each piece of that read-back
   void* kuf_buf = nullptr;    size_t kuf_bytes = 0;
   double* ext_g = nullptr;    size_t ext_cap = 0;           // [2][ext_cap] point gradients of a host-evaluated likelihood
   struct GradWs* gws = nullptr;  // gradient workspace, cached by problem shape

@@ -39,7 +39,11 @@ void launch_kuu(int dtype, hipStream_t s, const KernelParams& kp, const void* zs
 // T[I, <I] = -inv(L_II) * L[I, <I] (computed inside the factorisation's own launches); info = 0 or the 1-based order of the
 // first non-positive pivot; sync: Mp / 128 zeroed counters (device) for the in-kernel hand-over of the next diagonal block.
 // row_events (nullable; Mp / 128 <= potrf_max_row_events() events): event p is recorded on `s` once block row p of T is final
-void launch_potrf(int dtype, hipStream_t s, void* A, void* T, int64_t Mp, int* info, unsigned* sync, hipEvent_t* row_events = nullptr);
+// row hook: called on the host right after row_events[p] is recorded (p = block row of T that has just become final), so that the
+// caller can enqueue the work that waits for that event BEHIND the record and still AHEAD of the device (api.hip: SegRun)
+struct RowHook { void (*fn)(void* user, int row) = nullptr; void* user = nullptr; };
+void launch_potrf(int dtype, hipStream_t s, void* A, void* T, int64_t Mp, int* info, unsigned* sync, hipEvent_t* row_events = nullptr,
+                  const RowHook* hook = nullptr);
 int potrf_max_row_events();
 // U = Lq' (upper triangular, Mp x Mp col-major, zero padding); also mp[i] = m[i] padded with zeros.
 void launch_pack_q(int dtype, hipStream_t s, const void* Lq, const void* m, int64_t M, int64_t Mp, void* U, void* mp);

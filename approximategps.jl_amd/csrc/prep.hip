@@ -1053,7 +1053,7 @@ void dbg(const char* name, hipStream_t s) {
 }
 
 template <typename T>
-void potrf_t(hipStream_t s, T* A, T* Tm, int64_t Mp, int* info, unsigned* sync, hipEvent_t* row_events) {
+void potrf_t(hipStream_t s, T* A, T* Tm, int64_t Mp, int* info, unsigned* sync, hipEvent_t* row_events, const RowHook* hook) {
   using G = TileGemm<T, kNB, 16>;
   const int nP = int(Mp / kNB);
   constexpr size_t lds_potf2 = potf2_lds_bytes<T>();
@@ -1157,7 +1157,10 @@ void potrf_t(hipStream_t s, T* A, T* Tm, int64_t Mp, int* info, unsigned* sync, 
     }
     // block row p of T (inv(L_pp) from the block factorisation, T[p, J < p] from the launch above) is final here: the strips'
     // phase 1 of panel p may start (api.hip: enqueue_strips_overlapped waits for this event on its own stream)
-    if (row_events && t_inside) (void)hipEventRecord(row_events[p], s);
+    if (row_events && t_inside) {
+      (void)hipEventRecord(row_events[p], s);
+      if (hook && hook->fn) hook->fn(hook->user, p);   // the waiters of this row are enqueued now, not after the whole chain (host time)
+    }
     if (n == 0) break;
     const int nt = n * (n + 1) / 2;
     const bool large = nt >= 256;   // a trailing matrix that fills the chip by itself: full 128 x 128 tiles (half the operand traffic)
@@ -1225,9 +1228,10 @@ void launch_kuu(int dtype, hipStream_t s, const KernelParams& kp, const void* zs
 
 // T must be zero above the diagonal on entry (the model's buffer is cleared once at creation): the factorisation writes the
 // lower triangles of the inverted diagonal blocks and the T panels below them only
-void launch_potrf(int dtype, hipStream_t s, void* A, void* T, int64_t Mp, int* info, unsigned* sync, hipEvent_t* row_events) {
-  SVGP_DISPATCH(dtype, potrf_t<double>(s, (double*)A, (double*)T, Mp, info, sync, row_events),
-                potrf_t<float>(s, (float*)A, (float*)T, Mp, info, sync, row_events));
+void launch_potrf(int dtype, hipStream_t s, void* A, void* T, int64_t Mp, int* info, unsigned* sync, hipEvent_t* row_events,
+                  const RowHook* hook) {
+  SVGP_DISPATCH(dtype, potrf_t<double>(s, (double*)A, (double*)T, Mp, info, sync, row_events, hook),
+                potrf_t<float>(s, (float*)A, (float*)T, Mp, info, sync, row_events, hook));
 }
 int potrf_max_row_events() { return 16; }   // block rows of T are final one by one only while they ride in the TRSM launches (nP <= 16)
 

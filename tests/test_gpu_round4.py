@@ -312,3 +312,35 @@ def test_gradient_strips_beside_the_factorisation_are_bitwise_the_serial_result(
     assert rel(v0, val_ref) < (1e-8 if dtype == np.float64 else 1e-4)
     model.free()
     data.free()
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("M,d", [(130, 3), (1100, 8)])   # gradient blocks below one piece of the read-back, and of several pieces
+def test_gradient_read_back_in_pieces_and_into_reused_buffers(ctx, dtype, M, d):
+    """svgp_elbo_grad returns M^2 elements of Lq_bar to host memory every step: the read-back goes through a pinned staging buffer in up
+    to 8 pieces whose host copies overlap the bus (api.hip: grad_finish).  Piece boundaries fall anywhere inside z_bar | m_bar | Lq_bar:
+    every block must equal a one-piece reference (models of different sizes sharing the context's staging buffer), and a second call
+    into the SAME host arrays (`out=`) must overwrite them with identical bits."""
+    N = 2000
+    x, y, sva, s2 = o.synth_problem(4100 + M, N, M, d, dtype=dtype)
+    model = device_model(ctx, sva, dtype=dtype, sigma2=s2)
+    data = _ffi.DeviceData(ctx, x, y, dtype)
+    v0, _, g0 = model.elbo_grad(data, 0, N, float(N))
+    val_ref, g_ref = o.elbo_grad(sva, x, y, sigma2=s2, num_data=float(N))
+    assert rel(v0, val_ref) < (1e-8 if dtype == np.float64 else 1e-4)
+    tol = 1e-7 if dtype == np.float64 else 5e-3
+    for k in ("z", "m", "Lq"):
+        a = np.asarray(g0[k], dtype=np.float64).reshape(np.shape(g_ref[k]), order="F")
+        assert np.abs(a - g_ref[k]).max() <= tol * max(np.abs(g_ref[k]).max(), 1e-12), k
+    assert not np.any(np.triu(np.asarray(g0["Lq"]), 1))          # Lq_bar is lower triangular in the caller's buffer
+    keep = {k: np.array(g0[k], copy=True) for k in ("z", "m", "Lq", "inv_lengthscale")}
+    for k in ("z", "m", "Lq", "inv_lengthscale"):
+        g0[k][...] = 7                                             # stale contents must not survive
+    v1, _, g1 = model.elbo_grad(data, 0, N, float(N), out=g0)
+    assert v1 == v0 and g1["Lq"] is g0["Lq"] and g1["z"] is g0["z"]
+    for k in keep:
+        assert np.array_equal(np.asarray(g1[k]), keep[k]), k
+    with pytest.raises(ValueError):
+        model.elbo_grad(data, 0, N, float(N), out=dict(g0, Lq=np.zeros((M, M + 1), dtype=dtype, order="F")))
+    model.free()
+    data.free()

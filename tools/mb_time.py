@@ -1,0 +1,25 @@
+"""Median wall clock of svgp_elbo and svgp_elbo_grad over minibatch shapes, one process (process-wide knobs such as
+SVGP_STREAM2_RESERVE are read once): tools/mb_time.py [f64|f32]"""
+import os, sys, time
+R = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(R, "..")); sys.path.insert(0, os.path.join(R, "..", "approximategps.jl_amd"))
+import numpy as np, bench
+from approxgp import _ffi
+dtype = sys.argv[1] if len(sys.argv) > 1 else "f64"
+shapes = [(8192, 1024), (16384, 1024), (32768, 1024), (4096, 2048), (16384, 2048)] if dtype == "f64" else [(16384, 1024), (65536, 1024), (32768, 2048)]
+ctx = _ffi.Context(0)
+out = []
+for n, M in shapes:
+    p = bench.synth(7, n, M, 8, bench.SE, bench.GAUSS, dtype)
+    desc, keep = _ffi.make_desc(p["np_dt"], bench.SE, p["variance"], p["inv_l"], p["z"], p["m"], p["Lq"], p["jitter"], lik_sigma2=p["sigma2"])
+    model = _ffi.DeviceModel(ctx, desc, keep); data = _ffi.DeviceData(ctx, p["x"], p["y"], p["np_dt"])
+    row = []
+    for fn in (lambda: model.elbo(data, 0, n, float(n))[0], lambda: model.elbo_grad(data, 0, n, float(n))[0]):
+        for _ in range(4): fn()
+        ts = []
+        for _ in range(30):
+            t0 = time.perf_counter(); fn(); ts.append(time.perf_counter() - t0)
+        row.append(np.median(ts) * 1e3)
+    out.append(f"{n}/{M}: {row[0]:.3f} {row[1]:.3f}")
+    model.free(); data.free()
+print(dtype, " | ".join(out))
