@@ -178,7 +178,7 @@ KernelParams kparams(const svgp_model* m) {
 // The M-sized work of posterior(sva): enqueue only, no sync.
 // overlap (NonCentered only): everything the strips need besides T - the scaled inducing inputs, U = Lq', the padded mean - is
 // enqueued FIRST and ctx->ev_fork recorded behind it; the factorisation then records ctx->ev_row[p] as block row p of T becomes
-// final, so that strips on a second stream can run beside it (enqueue_strips_overlapped).
+// final, so that strips on a second stream can run beside it (SegRun: seg_enqueue_row).
 int enqueue_prep(svgp_ctx* ctx, svgp_model* m, bool overlap = false, const RowHook* hook = nullptr) {
   hipStream_t s = ctx->stream;
   const KernelParams kp = kparams(m);

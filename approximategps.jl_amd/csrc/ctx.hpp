@@ -30,7 +30,7 @@ struct svgp_ctx {
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   unsigned* counter2 = nullptr;
   void* work2 = nullptr;      size_t work2_bytes = 0;
-  // strips beside the factorisation (enqueue_strips_overlapped): one event per block row of T, the segmented strips' saved sums
+  // strips beside the factorisation (api.hip: SegRun): one event per block row of T, the segmented strips' saved sums
   hipEvent_t ev_row[16] = {};
   bool ev_row_ready = false, overlapped = false;
   hipEvent_t ev_R = nullptr;                  // the gradient's M-sized prep (Linv, alpha, R) is final: phase 3 of the segmented strips

@@ -1156,7 +1156,7 @@ void potrf_t(hipStream_t s, T* A, T* Tm, int64_t Mp, int* info, unsigned* sync, 
       dbg("chol trsm + T panels", s);
     }
     // block row p of T (inv(L_pp) from the block factorisation, T[p, J < p] from the launch above) is final here: the strips'
-    // phase 1 of panel p may start (api.hip: enqueue_strips_overlapped waits for this event on its own stream)
+    // phase 1 of panel p may start (api.hip: SegRun - the row hook below enqueues the waiter on its own stream)
     if (row_events && t_inside) {
       (void)hipEventRecord(row_events[p], s);
       if (hook && hook->fn) hook->fn(hook->user, p);   // the waiters of this row are enqueued now, not after the whole chain (host time)

@@ -164,7 +164,7 @@ def _restore(name, old):
                                       (100000, 512, 8, o.LIK_GAUSSIAN), (70001, 650, 4, o.LIK_BERNOULLI_LOGISTIC), (150000, 300, 2, o.LIK_GAUSSIAN)])
 def test_strips_beside_the_factorisation_are_bitwise_the_serial_result(ctx, dtype, N, M, d, lik):
     """a batch of at most one round of strips runs as segmented strips on a second stream, panel I behind the
-    event of block row I of T, beside the Cholesky of Kuu (api.hip: enqueue_strips_overlapped).  Per strip the arithmetic is the
+    event of block row I of T, beside the Cholesky of Kuu (api.hip: SegRun).  Per strip the arithmetic is the
     one-launch kernel's, register for register: ELBO, expectation and the per-point marginals must be IDENTICAL bits with the
     overlap on and off, repeatedly (a race between the streams would show as a flaky difference), at several M / widths."""
     x, y, sva, s2 = o.synth_problem(6000 + M, N, M, d, lik=lik, dtype=dtype)
