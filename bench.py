@@ -392,6 +392,35 @@ def julia_reference_baseline(exe, p, family, lik, n_sample):
         return res
 
 
+def measure_host_step(ctx, n=16384, M=1024, d=8, reps=20):
+    """One minibatch TRAINING STEP as a host optimiser sees it (reference: examples/a-regression/script.jl:176-194 - new parameters
+    every step, gradients consumed on the host): svgp_model_update from host memory (z, m, the M x M Lq) + svgp_elbo_grad with the
+    gradients (the M x M Lq_bar among them) back in host memory.  Wall clock, median; `ms_device` is the same step's HIP-event time."""
+    from approxgp import _ffi
+    p = synth(7, n, M, d, SE, GAUSS, "f64")
+    desc, keep = _ffi.make_desc(p["np_dt"], SE, p["variance"], p["inv_l"], p["z"], p["m"], p["Lq"], p["jitter"], lik_sigma2=p["sigma2"])
+    model = _ffi.DeviceModel(ctx, desc, keep)
+    data = _ffi.DeviceData(ctx, p["x"], p["y"], p["np_dt"])
+    tu, tg, td, g = [], [], [], None
+    try:
+        for it in range(reps + 4):
+            t0 = time.perf_counter()
+            model.update(desc, keep)
+            t1 = time.perf_counter()
+            _, _, g = model.elbo_grad(data, 0, n, float(n), **({"out": g} if g is not None else {}))
+            t2 = time.perf_counter()
+            if it >= 4:
+                tu.append(t1 - t0), tg.append(t2 - t1), td.append(ctx.timing().ms_total)
+    finally:
+        model.free()
+        data.free()
+    step = float(np.median(np.add(tu, tg))) * 1e3
+    return {"workload": f"minibatch of {n} points, M={M}, d={d}, SE-ARD, Gaussian, f64; parameters from host memory every step, "
+                        "gradients to host memory (pinned staging, reused host arrays)",
+            "ms_step": step, "steps_per_s": 1e3 / step, "ms_model_update": float(np.median(tu)) * 1e3,
+            "ms_elbo_grad": float(np.median(tg)) * 1e3, "ms_device": float(np.median(td)), "pcie_bytes_per_step": 2 * 8 * (M * M + M * d + M)}
+
+
 def measure_kuf(name, ctx, model, data, torch, dev):
     """Kuf assembly alone (SVA:216): M x n column-major written once -> HBM-write bound.  Its own launches, its own HIP events
     (recorded by the library on its stream around the launch), AFTER the ELBO loop so the clocks are up: median and p95 over 32
@@ -726,12 +755,12 @@ def main():
         # GPUs the library's collective form (batch size all-reduced on the device, one grouped gradient all-reduce).
         # Reported beside the headline, never part of it; a failure here must not cost the main line.
         try:
-            model.elbo_grad(data, 0, n, num_data)
+            _, _, gout = model.elbo_grad(data, 0, n, num_data)
             fence()
             t0 = time.perf_counter()
             reps = 3
-            for _ in range(reps):
-                gval, _, _ = model.elbo_grad(data, 0, n, num_data)
+            for _ in range(reps):   # out=: the gradient lands in the previous step's host arrays, as in a training loop
+                gval, _, gout = model.elbo_grad(data, 0, n, num_data, out=gout)
             fence()
             tg = (time.perf_counter() - t0) / reps
             if use_dist:
@@ -742,6 +771,11 @@ def main():
                                          "ratio_to_forward": 1e3 * tg / res["ms_per_step"], "value": gval}
         except Exception as e:  # noqa: BLE001
             out["value_and_gradient"] = {"error": repr(e)}
+    if name == "H" and world == 1 and not args.no_grad and not host_comm:
+        try:
+            out["host_training_step"] = measure_host_step(ctx)
+        except Exception as e:  # noqa: BLE001
+            out["host_training_step"] = {"error": repr(e)}
     if name == "H" and not args.no_c5:
         # BASELINE config C5 (8 x MI355X: minibatched ELBO, N = 1e8, per-GPU batch 2^18, M = 1024, fp32) through the same
         # collective path: every rank evaluates its own 2^18-point minibatch per step, scale = 1e8 / (world * 2^18).
@@ -755,12 +789,12 @@ def main():
                      "points_per_s": c5["points_per_s"], "dtype": "f32", "roofline": c5["roofline"],
                      "breakdown_ms": c5["breakdown_ms"], "elbo": c5["elbo"], "n_points_global": c5["n_points_global"]}
             if not args.no_grad and not host_comm:
-                m5.elbo_grad(d5, 0, 262144, C5_NUM_DATA)
+                _, _, g5 = m5.elbo_grad(d5, 0, 262144, C5_NUM_DATA)
                 fence()
                 t0 = time.perf_counter()
                 reps5 = 10
                 for i5 in range(reps5):   # a different resident window every training step
-                    m5.elbo_grad(d5, ((i5 + 1) % nwin5) * 262144, 262144, C5_NUM_DATA)
+                    _, _, g5 = m5.elbo_grad(d5, ((i5 + 1) % nwin5) * 262144, 262144, C5_NUM_DATA, out=g5)
                 fence()
                 tg = (time.perf_counter() - t0) / reps5
                 if use_dist:
