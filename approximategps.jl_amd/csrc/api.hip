@@ -274,6 +274,28 @@ int ensure_stream2(svgp_ctx* ctx) {
   return SVGP_OK;
 }
 
+// split closing launch of small batches (kernels.hpp: seg_split): at most kSegSplitSlots workgroups, each leaving 3 x NT <= 384 doubles;
+// then one counter per strip
+constexpr size_t kSegSplitSlots = 512, kSegSplitPart = 384, kSegSplitDoubles = kSegSplitSlots * kSegSplitPart + kSegSplitSlots;
+// S = the largest power of two with S <= nP and nstrips S <= kSegSplitSlots - if that is at least 4: two workgroups per strip do not
+// pay for the extra launch (measured, profiles/round4/minibatch_step.md: 8192 points / M = 1024 f64 forward 0.84 -> 0.87 ms, gradient
+// 2.29 -> 2.28; 4096 points 0.81 -> 0.78 / 2.13 -> 2.00; 1024 points 0.80 -> 0.71 / 2.05 -> 1.78).  SVGP_SEG_SPLIT=0 (per call): never split
+int seg_split_factor(int nP, int64_t nstrips) {
+  const char* sq = getenv("SVGP_SEG_SPLIT");
+  int S = 1;
+  if (!(sq && atoi(sq) == 0))
+    while (2 * S <= nP && int64_t(2 * S) * nstrips <= int64_t(kSegSplitSlots)) S *= 2;
+  return S >= 4 ? S : 1;
+}
+// points the split closing launch at its partials and counters (behind the saved sums) and zeroes the counters on the second stream
+int seg_split_setup(svgp_ctx* ctx, StripArgs& a, int S, int64_t nstrips) {
+  double* extra = ctx->seg_state + (ctx->seg_state_doubles - kSegSplitDoubles);
+  a.seg_split = S;
+  a.seg_part = extra;
+  a.seg_cnt = reinterpret_cast<unsigned*>(extra + kSegSplitSlots * kSegSplitPart);
+  HIPC(ctx, hipMemsetAsync(a.seg_cnt, 0, size_t(nstrips) * sizeof(unsigned), ctx->stream2));
+  return SVGP_OK;
+}
 int ensure_overlap(svgp_ctx* ctx, size_t state_doubles) {
   int rc = ensure_stream2(ctx);
   if (rc) return rc;
@@ -285,6 +307,7 @@ int ensure_overlap(svgp_ctx* ctx, size_t state_doubles) {
     if (!ctx->ev_R) HIPC(ctx, hipEventCreateWithFlags(&ctx->ev_R, hipEventDisableTiming));
     ctx->ev_row_ready = true;
   }
+  state_doubles += kSegSplitDoubles;   // behind the saved sums: the split closing launch's partials and its per-strip counters
   if (state_doubles > ctx->seg_state_doubles) {
     if (ctx->seg_state) (void)hipFree(ctx->seg_state);
     ctx->seg_state = nullptr;
@@ -463,6 +486,7 @@ struct SegRun {
   StripArgs a{};
   OverlapPlan op;
   bool grad = false, ckpt = false;
+  int split = 1;   // forward: phase 2 in a closing launch of its own, `split` workgroups per strip (small batches; kernels.hpp: seg_split)
   int nP = 0, ck[3] = {0, 0, 0}, ck_prev = 0, rc = SVGP_OK;
   size_t wb1 = 0;
   int64_t head = 0;
@@ -485,7 +509,7 @@ int seg_enqueue_row(SegRun& r, int row) {
   const int I = row, nP = r.nP;
   HIPC(ctx, hipStreamWaitEvent(s2, ctx->ev_row[I], 0));
   a.seg_lo = I; a.seg_hi = I + 1;
-  a.seg_flags = (I > 0 ? kSegLoad : 0) | ((r.grad || I + 1 < nP) ? kSegStore : kSegPhase2);
+  a.seg_flags = (I > 0 ? kSegLoad : 0) | ((r.grad || r.split > 1 || I + 1 < nP) ? kSegStore : kSegPhase2);
   a.seg_p2_lo = a.seg_p2_hi = 0;
   if (r.ckpt) {
     a.seg_flags |= kSegP2;
@@ -535,6 +559,9 @@ int seg_prepare_forward(svgp_ctx* ctx, svgp_model* m, const void* x, int64_t ldx
   r.ctx = ctx; r.m = m; r.op = op; r.grad = false; r.nP = nP; r.wb1 = wb1; r.head = head;
   r.ckpt = (ckq && atoi(ckq) == 1) && nP >= 4;
   r.ck[0] = nP / 2; r.ck[1] = (3 * nP) / 4; r.ck[2] = nP;   // phase-2 checkpoints: after panels ck[.] - 1
+  // A small batch (fewer strips than workgroup slots; not a segmented head): phase 2 - one panel C_J after the other inside a strip's
+  // workgroup - is latency-bound on the few CUs it reaches, and its panels are independent: a closing launch with S workgroups per strip
+  r.split = (r.ckpt || head < len) ? 1 : seg_split_factor(nP, op.nstrips);
   StripArgs& a = r.a;
   a.T = m->T; a.U = m->U; a.zs = m->zs; a.mp = m->mp; a.x = x; a.work = ctx->work_seg; a.counter = ctx->counter2;
   a.mom_mu = ctx->mom; a.mom_var = ctx->mom + ctx->mom_cap;
@@ -550,8 +577,19 @@ int seg_finish_forward(svgp_ctx* ctx, svgp_model* m, const void* x, int64_t ldx,
   hipStream_t s = ctx->stream, s2 = ctx->stream2;
   if (r.rc) return r.rc;
   const int64_t head = r.head;
-  HIPC(ctx, hipEventRecord(ctx->ev_join, s2));
   int launches = r.nP + 1;
+  if (r.split > 1) {   // phase 2 + moments, r.split workgroups per strip
+    StripArgs& a = r.a;
+    const int rcs = seg_split_setup(ctx, a, r.split, r.op.nstrips);
+    if (rcs) return rcs;
+    a.seg_lo = a.seg_hi = r.nP;
+    a.seg_flags = kSegLoad | kSegPhase2;
+    a.seg_p2_lo = a.seg_p2_hi = 0;
+    launch_strip_seg(m->dtype, s2, a, r.op.nt, int(r.op.nstrips) * r.split, r.op.nstrips, false);
+    KCHECK(ctx, "strip (segmented: split phase 2)");
+    ++launches;
+  }
+  HIPC(ctx, hipEventRecord(ctx->ev_join, s2));
   if (head < len) {   // the rest of the batch: the one-launch kernel behind the prep, on the main stream, beside the head's tail
     StripOuts rest = o;
     rest.mom_shift = head;
@@ -1529,10 +1567,22 @@ int grad_enqueue_impl(svgp_ctx* ctx, svgp_model* m, const svgp_data* data, int64
       hipStream_t s2 = ctx->stream2;
       const int nPn = int(Mp / 128);
       if (a.work != ctx->work || a.mom_mu != ctx->mom) return fail(ctx, SVGP_HIP_ERROR, "internal: scratch moved under the segmented strips");
+      // A small batch has fewer strips than the chip has workgroup slots and phase 3 - 2 M^2 flops per point, one panel after the other
+      // inside a strip's workgroup - is latency-bound on the few CUs it reaches (1024 points, M = 1024: 32 workgroups, 340 us for 27 us
+      // of MFMA work).  Its output panels are independent: the closing launch runs S workgroups per strip (strip.hip: seg_split).
+      // SVGP_SEG_SPLIT=0 (per call): the unsplit launch, whose result is bitwise the serial kernel's (the split one differs in the
+      // variance's summation order).
+      const int S = seg_split_factor(nPn, nstrips);
+      int cgrid = grid;
+      if (S > 1) {
+        rc = seg_split_setup(ctx, a, S, nstrips);
+        if (rc) return rc;
+        cgrid = int(nstrips) * S;
+      }
       HIPC(ctx, hipStreamWaitEvent(s2, ctx->ev_R, 0));
       a.seg_lo = a.seg_hi = nPn;
       a.seg_flags = kSegLoad | kSegPhase2;
-      launch_strip_seg(dt, s2, a, nt, grid, nstrips, true);
+      launch_strip_seg(dt, s2, a, nt, cgrid, nstrips, true);
       KCHECK(ctx, "strip (value and gradient, segmented)");
       HIPC(ctx, hipEventRecord(ctx->ev_join, s2));
       HIPC(ctx, hipStreamWaitEvent(s, ctx->ev_join, 0));

@@ -108,6 +108,15 @@ struct StripArgs {
   // [max(J, seg_p2_lo), seg_p2_hi) and parks them in seg_cacc (nstrips x Mp x NT elements, register layout); seg_p2_hi == Mp / 128 closes
   int seg_p2_lo, seg_p2_hi;
   void* seg_cacc;
+  // Split closing launch (segmented strips of a SMALL batch: fewer strips than workgroup slots).  The output panels of phase 3 (value and
+  // gradient: dense) and of phase 2 (forward: C_J = sum_{I >= J} U[J, I] A_I) are independent, so the closing launch runs seg_split
+  // workgroups per strip - workgroup (strip, part) = blockIdx (part * nstrips + strip) takes the panels [part nP / S, (part + 1) nP / S)
+  // of phase 3, or J = part, part + S, .. of phase 2 - and the parts' column sums meet in seg_part ([S][nstrips][3][NT] doubles: sum A^2,
+  // mean, variance term); the last part to arrive (seg_cnt[strip], zeroed by the host) adds them in part order and writes the moments.
+  // Run-to-run bitwise reproducible; against the unsplit kernel the variance differs by summation order.
+  int seg_split;
+  double* seg_part;
+  unsigned* seg_cnt;
 };
 int strip_nt(int dtype, int64_t Mp, int64_t len);                 // column-strip width chosen for a problem
 size_t strip_work_bytes(int dtype, int64_t Mp, int nt, int grid);  // workspace bytes

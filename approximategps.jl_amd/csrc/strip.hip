@@ -294,7 +294,11 @@ __global__ void __launch_bounds__(NTHR, MINW) strip_kernel(StripArgs a, int64_t 
   if (threadIdx.x < 128) s_strip_stamps[threadIdx.x] = 0;
   __syncthreads();
 #endif
-  for (int64_t strip = blockIdx.x; strip < nstrips;) {
+  [[maybe_unused]] int part = 0, nsplit = 1;   // split closing launch (kernels.hpp: seg_split)
+  if constexpr (SEG) {
+    if (a.seg_split > 1) { nsplit = a.seg_split; part = int(blockIdx.x / nstrips); }
+  }
+  for (int64_t strip = (nsplit > 1) ? int64_t(blockIdx.x % nstrips) : int64_t(blockIdx.x); strip < nstrips;) {
     if constexpr (SEG) {   // a strip's scratch must outlive the launch: indexed by strip, not by workgroup
       work = static_cast<T*>(a.work) + strip * Mp * NT;
       workK = GRAD ? static_cast<T*>(a.work) + (nstrips + strip) * Mp * NT : work;   // GRAD: the Kuf strips behind the A strips
@@ -377,7 +381,7 @@ __global__ void __launch_bounds__(NTHR, MINW) strip_kernel(StripArgs a, int64_t 
     if constexpr (SEG) {
       I_lo = a.seg_lo;
       I_hi = a.seg_hi;
-      if (a.seg_flags & kSegLoad) {   // the column sums this thread carried out of the previous launch of the strip
+      if ((a.seg_flags & kSegLoad) && part == 0) {   // the column sums this thread carried out of the previous launch of the strip
         const double* __restrict__ st = a.seg_state + (strip * NTHR + tid) * (2 * NJ);
 #pragma unroll
         for (int j = 0; j < NJ; ++j) { sA[j] = st[j]; sM[j] = st[NJ + j]; }
@@ -509,7 +513,9 @@ __global__ void __launch_bounds__(NTHR, MINW) strip_kernel(StripArgs a, int64_t 
       }
     }
     if constexpr (!GRAD)
-    for (int J = (SEG && p2_complete) ? nP : 0; J < nP; ++J) {   // (segmented builds: the checkpoints may have covered phase 2)
+    // (segmented builds: the checkpoints may have covered phase 2; a split closing launch deals the panels round-robin - C_J costs
+    // nP - J block products - to the strip's nsplit workgroups)
+    for (int J = (SEG && p2_complete) ? nP : (SEG ? part : 0); J < nP; J += (SEG ? nsplit : 1)) {
       SVGP_SSTAMP(60 + 2 * J);
       Acc acc;
       acc.zero();
@@ -550,7 +556,9 @@ __global__ void __launch_bounds__(NTHR, MINW) strip_kernel(StripArgs a, int64_t 
     if constexpr (GRAD) {
       const T* __restrict__ Rm = static_cast<const T*>(a.R);
       T* __restrict__ Pt = static_cast<T*>(a.Pt_out);
-      for (int I = 0; I < nP; ++I) {
+      int p3_lo = 0, p3_hi = nP;
+      if constexpr (SEG) { p3_lo = (part * nP) / nsplit; p3_hi = ((part + 1) * nP) / nsplit; }
+      for (int I = p3_lo; I < p3_hi; ++I) {
         SVGP_SSTAMP(26 + 4 * I);   // (diagnostic builds, nP <= 8) phase 3: loop start / loop end / after the K-dot / after the point-major store
         Acc acc;
         acc.zero();
@@ -604,6 +612,46 @@ __global__ void __launch_bounds__(NTHR, MINW) strip_kernel(StripArgs a, int64_t 
     }
     __syncthreads();
     if constexpr (!GRAD || PG == kPgPost) {
+      bool split_done = false;
+      if constexpr (SEG) {
+        if (nsplit > 1) {   // this part's column sums -> seg_part; the last part of the strip to arrive adds them in part order
+          __shared__ int s_last_part;
+          if (tid < NT) {
+            double qa = 0, qm = 0, qc = 0;
+#pragma unroll
+            for (int w = 0; w < G::WR; ++w) {
+              qa += red[(0 * G::WR + w) * NT + tid];
+              qm += red[(1 * G::WR + w) * NT + tid];
+              qc += red[(2 * G::WR + w) * NT + tid];
+            }
+            double* __restrict__ pp = a.seg_part + ((int64_t(part) * nstrips + strip) * 3) * NT;
+            pp[tid] = qa;
+            pp[NT + tid] = qm;
+            pp[2 * NT + tid] = qc;
+          }
+          __threadfence();   // release: the partials device-wide before the count goes up
+          __syncthreads();
+          if (tid == 0) s_last_part = (__hip_atomic_fetch_add(&a.seg_cnt[strip], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == unsigned(nsplit - 1));
+          __syncthreads();
+          if (s_last_part) {
+            __threadfence();   // acquire: the other parts' partials (other CUs, possibly other XCDs)
+            if (tid < NT && c0 + tid < a.len) {
+              double qa = 0, qm = 0, qc = 0;   // (qa, qm: part 0 alone carries the sums of phase 1; the others add zeros)
+              for (int q = 0; q < nsplit; ++q) {
+                const double* __restrict__ pp = a.seg_part + ((int64_t(q) * nstrips + strip) * 3) * NT;
+                qa += __builtin_nontemporal_load(pp + tid);
+                qm += __builtin_nontemporal_load(pp + NT + tid);
+                qc += __builtin_nontemporal_load(pp + 2 * NT + tid);
+              }
+              a.mom_mu[c0 + tid] = a.mean_const + qm;
+              a.mom_var[c0 + tid] = a.kp.variance - qa + qc;
+            }
+          }
+          __syncthreads();
+          split_done = true;
+        }
+      }
+      if (!split_done) {
       if (tid < NT && c0 + tid < a.len) {
         double qa = 0, qm = 0, qc = 0;
 #pragma unroll
@@ -617,6 +665,7 @@ __global__ void __launch_bounds__(NTHR, MINW) strip_kernel(StripArgs a, int64_t 
         a.mom_var[c0 + tid] = a.kp.variance - qa + qc;
       }
       __syncthreads();
+      }
     } else {
       // ---- marginals + d E[log p] / d (mu, v) of the strip's points (SVA:354-355 and their adjoint), one thread per point
       double e5[5] = {0, 0, 0, 0, 0};   // E, sum g_mu, sum g_v, dE/dsigma2, n_neg

@@ -174,6 +174,7 @@ def test_strips_beside_the_factorisation_are_bitwise_the_serial_result(ctx, dtyp
     oldp = _toggle("SVGP_OVERLAP_MIN_PANELS", "2")   # the product default (5: where it pays) would skip the small models here
     oldh = _toggle("SVGP_OVERLAP_HEAD", "1")         # ... and the segmented head of a multi-round batch is off by default
     oldhp = _toggle("SVGP_OVERLAP_HEAD_MIN_PANELS", "2")
+    olds = _toggle("SVGP_SEG_SPLIT", "0")            # small batches: the split closing launch sums the variance in another order (below)
     try:
         v0, t0 = model.elbo(data, 0, N, 3.0 * N)
         os.environ["SVGP_OVERLAP"] = "1"
@@ -181,6 +182,13 @@ def test_strips_beside_the_factorisation_are_bitwise_the_serial_result(ctx, dtyp
             v1, t1 = model.elbo(data, 0, N, 3.0 * N)
             assert v1 == v0 and t1.expectation == t0.expectation and t1.kl == t0.kl, (rep, v1, v0)
         tm = ctx.timing()
+        # the product default: phase 2 of a batch of fewer strips than workgroup slots in a closing launch of its own, several
+        # workgroups per strip - identical bits run to run, rounding-level agreement with the unsplit launch
+        os.environ["SVGP_SEG_SPLIT"] = "1"
+        vs = model.elbo(data, 0, N, 3.0 * N)[0]
+        assert model.elbo(data, 0, N, 3.0 * N)[0] == vs
+        assert rel(vs, v0) < (1e-13 if dtype == np.float64 else 1e-6), (vs, v0)
+        os.environ["SVGP_SEG_SPLIT"] = "0"
         off = min(17, N - 1)                     # an offset window, ragged end
         os.environ["SVGP_OVERLAP"] = "0"
         w0 = model.elbo(data, off, N - off, 0.0)[0]
@@ -191,6 +199,7 @@ def test_strips_beside_the_factorisation_are_bitwise_the_serial_result(ctx, dtyp
         _restore("SVGP_OVERLAP_MIN_PANELS", oldp)
         _restore("SVGP_OVERLAP_HEAD", oldh)
         _restore("SVGP_OVERLAP_HEAD_MIN_PANELS", oldhp)
+        _restore("SVGP_SEG_SPLIT", olds)
     ref = o.elbo(sva, x, y, lik=lik, sigma2=s2, num_data=3.0 * N)
     assert rel(v0, ref) < (1e-8 if dtype == np.float64 else 1e-4)
     if M >= 256:   # two panels at least: the path was really taken (one launch per panel + the pre-generation [+ the rest of the batch])
@@ -291,6 +300,7 @@ def test_gradient_strips_beside_the_factorisation_are_bitwise_the_serial_result(
     data = _ffi.DeviceData(ctx, x, y, dtype)
     old = _toggle("SVGP_OVERLAP", "0")
     oldp = _toggle("SVGP_OVERLAP_MIN_PANELS", "2")
+    olds = _toggle("SVGP_SEG_SPLIT", "0")   # the split closing launch of small batches sums the variance in another order (test below)
     try:
         v0, t0, g0 = model.elbo_grad(data, 0, N, 2.0 * N)
         os.environ["SVGP_OVERLAP"] = "1"
@@ -301,6 +311,20 @@ def test_gradient_strips_beside_the_factorisation_are_bitwise_the_serial_result(
                 assert np.array_equal(np.asarray(g1[k]), np.asarray(g0[k])), (rep, k)
             for k in ("variance", "lik_sigma2", "mean_const"):
                 assert g1[k] == g0[k], (rep, k)
+        # Split closing launch (the default for batches of fewer strips than workgroup slots): S workgroups per strip share phase 3's
+        # output panels, the variance is summed per part and then over the parts - same operations, another association.  Run-to-run
+        # identical bits; against the unsplit launch: rounding-level agreement.
+        os.environ["SVGP_SEG_SPLIT"] = "1"
+        vs, _, gs = model.elbo_grad(data, 0, N, 2.0 * N)
+        vs2, _, gs2 = model.elbo_grad(data, 0, N, 2.0 * N)
+        assert vs2 == vs
+        rt, gt = (1e-13, 1e-10) if dtype == np.float64 else (1e-6, 2e-4)
+        assert rel(vs, v0) < rt, (vs, v0)
+        for k in ("z", "m", "Lq", "inv_lengthscale"):
+            a, b, c = np.asarray(gs[k], dtype=np.float64), np.asarray(g0[k], dtype=np.float64), np.asarray(gs2[k], dtype=np.float64)
+            assert np.array_equal(a, c), k
+            assert np.abs(a - b).max() <= gt * max(np.abs(b).max(), 1e-300), (k, np.abs(a - b).max(), np.abs(b).max())
+        os.environ["SVGP_SEG_SPLIT"] = "0"
         # the forward entry point between two gradient calls (shared scratch, shared events)
         f1 = model.elbo(data, 0, N, 2.0 * N)[0]
         os.environ["SVGP_OVERLAP"] = "0"
@@ -308,6 +332,7 @@ def test_gradient_strips_beside_the_factorisation_are_bitwise_the_serial_result(
     finally:
         _restore("SVGP_OVERLAP", old)
         _restore("SVGP_OVERLAP_MIN_PANELS", oldp)
+        _restore("SVGP_SEG_SPLIT", olds)
     val_ref, g_ref = o.elbo_grad(sva, x, y, lik=lik, sigma2=s2, num_data=2.0 * N)
     assert rel(v0, val_ref) < (1e-8 if dtype == np.float64 else 1e-4)
     model.free()
