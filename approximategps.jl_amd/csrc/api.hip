@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <functional>
 #include <cmath>
 #include <cstdio>
 #include <cstddef>
@@ -305,6 +306,7 @@ int ensure_overlap(svgp_ctx* ctx, size_t state_doubles) {
     for (auto& e : ctx->ev_ov)
       if (!e) HIPC(ctx, hipEventCreate(&e));
     if (!ctx->ev_R) HIPC(ctx, hipEventCreateWithFlags(&ctx->ev_R, hipEventDisableTiming));
+    if (!ctx->ev_S) HIPC(ctx, hipEventCreateWithFlags(&ctx->ev_S, hipEventDisableTiming));
     ctx->ev_row_ready = true;
   }
   state_doubles += kSegSplitDoubles;   // behind the saved sums: the split closing launch's partials and its per-strip counters
@@ -490,6 +492,7 @@ struct SegRun {
   int nP = 0, ck[3] = {0, 0, 0}, ck_prev = 0, rc = SVGP_OK;
   size_t wb1 = 0;
   int64_t head = 0;
+  std::function<int()>* pre = nullptr;   // work for the second stream ahead of the pre-generation (the gradient's chain-independent prep)
 };
 
 // row -1: the Kuf pre-generation (behind ev_fork); row I >= 0: phase-1 panel I (behind ev_row[I]); the forward's last panel carries
@@ -501,6 +504,10 @@ int seg_enqueue_row(SegRun& r, int row) {
   const int dt = r.m->dtype;
   if (row < 0) {
     HIPC(ctx, hipStreamWaitEvent(s2, ctx->ev_fork, 0));
+    if (r.pre) {
+      const int rcp = (*r.pre)();
+      if (rcp) return rcp;
+    }
     a.seg_flags = kSegPregen; a.seg_lo = 0; a.seg_hi = 0;
     launch_strip_seg(dt, s2, a, r.op.nt, r.op.grid, r.op.nstrips, r.grad);
     KCHECK(ctx, "strip (segmented: pre-generation)");
@@ -897,6 +904,7 @@ int32_t svgp_ctx_destroy(svgp_ctx* c) {
   for (auto& e : c->ev_ov)
     if (e) (void)hipEventDestroy(e);
   if (c->ev_R) (void)hipEventDestroy(c->ev_R);
+  if (c->ev_S) (void)hipEventDestroy(c->ev_S);
   if (c->seg_state) (void)hipFree(c->seg_state);
   if (c->work_seg) (void)hipFree(c->work_seg);
   if (c->hstage) (void)hipHostFree(c->hstage);
@@ -1514,6 +1522,27 @@ int grad_enqueue_impl(svgp_ctx* ctx, svgp_model* m, const svgp_data* data, int64
     a.part5 = w->partial5; a.apart = a_in_strips ? w->apart : nullptr; a.lp = lpc; a.scale = scale; a.n_global_dev = n_global_dev; a.num_data = gc.num_data;
     return a;
   };
+  // The M-sized work of the adjoint that does NOT depend on the factorisation: the cleared accumulators, the inverse lengthscales for
+  // the kernel-gradient kernels, S = B B' - I (B = the padded Lq: NonCentered) - ~60 us of small launches.  Serial path: behind the
+  // prep on the main stream.  Strips beside the factorisation: on the second stream AHEAD of the pre-generation (that stream has
+  // nothing to do until block row 0 of T exists, ~130 us into the chain), the main stream waits for ev_S before it forms R.
+  // the adjoint runs on the whitened problem: (m~, B) are (m, Lq) for NonCentered and (Lk^-1 (m - c), Lk^-1 Lq) for Centered
+  const void* Bq = centered ? m->B : w->Lqp;
+  auto grad_pre_chain = [&](hipStream_t st) -> int {
+    HIPC(ctx, hipMemsetAsync(w->zero_blk, 0, w->zero_b, st));   // every accumulator of the evaluation, one fill
+    HIPC(ctx, hipMemcpyAsync(w->invl_d, m->invl_host.data(), size_t(m->d) * 8, hipMemcpyHostToDevice, st));
+    if (!centered) launch_pad_lower(dt, st, m->Lq_raw, M, Mp, w->Lqp);
+    gemm_mm(ctx, w, dt, st, Bq, Bq, Mp, w->G2, kMmXUp | kMmYUp);   // lower tiles of B B' (row-major); B[r][k] = 0 for k > r
+    launch_sym_from_lower(dt, st, w->G2, 1, Mp, 1.0, w->tmp);     // S = B B' - I, full
+    KCHECK(ctx, "grad prep (S)");
+    return SVGP_OK;
+  };
+  std::function<int()> seg_pre = [&]() -> int {
+    const int rcp = grad_pre_chain(ctx->stream2);
+    if (rcp) return rcp;
+    HIPC(ctx, hipEventRecord(ctx->ev_S, ctx->stream2));
+    return SVGP_OK;
+  };
   // segmented strips (gop.on): enqueued panel by panel from inside the factorisation's launch loop (SegRun), so built before the prep
   SegRun gseg;
   RowHook ghook{seg_row_hook, &gseg};
@@ -1523,6 +1552,7 @@ int grad_enqueue_impl(svgp_ctx* ctx, svgp_model* m, const svgp_data* data, int64
     gseg.a = strip_args(0, len, lpc_seg);
     gseg.a.seg_state = ctx->seg_state;
     gseg.a.counter = ctx->counter2;
+    gseg.pre = &seg_pre;
   }
   ctx->overlapped = gop.on;
   HIPC(ctx, hipEventRecord(ctx->ev[0], s));
@@ -1533,21 +1563,21 @@ int grad_enqueue_impl(svgp_ctx* ctx, svgp_model* m, const svgp_data* data, int64
     return rc;
   }
   HIPC(ctx, hipEventRecord(ctx->ev[1], s));
-  HIPC(ctx, hipMemsetAsync(w->zero_blk, 0, w->zero_b, s));   // every accumulator of the evaluation, one fill
-  HIPC(ctx, hipMemcpyAsync(w->invl_d, m->invl_host.data(), size_t(m->d) * 8, hipMemcpyHostToDevice, s));
+  if (!gop.on) {
+    rc = grad_pre_chain(s);
+    if (rc) return rc;
+  } else {
+    HIPC(ctx, hipStreamWaitEvent(s, ctx->ev_S, 0));   // S = B B' - I and the cleared accumulators: done on the second stream beside the chain
+  }
   // Linv = Lk^-1 (both storage orders): every Lk^-T . below is a GEMM with it (round 2: four blocked substitutions, 0.18 ms each
   // at M = 1024 whatever the batch size)
   launch_linv(dt, s, m->L, m->T, Mp, w->LinvRM, w->LinvCM, w->H);
-  // the adjoint runs on the whitened problem: (m~, B) are (m, Lq) for NonCentered and (Lk^-1 (m - c), Lk^-1 Lq) for Centered
-  const void* Bq = centered ? m->B : w->Lqp;
-  if (!centered) launch_pad_lower(dt, s, m->Lq_raw, M, Mp, w->Lqp);
-  // M-sized operands of the strips' phase 3:  alpha = Lk^-T m~,  R = Lk^-T (B B' - I)  (column-major: the P operand of the GEMM)
-  launch_linv_t_gemv(dt, s, w->LinvRM, m->mp, Mp, w->alpha, w->gemv_part);
-  gemm_mm(ctx, w, dt, s, Bq, Bq, Mp, w->G2, kMmXUp | kMmYUp);               // lower tiles of B B' (row-major); B[r][k] = 0 for k > r
-  launch_sym_from_lower(dt, s, w->G2, 1, Mp, 1.0, w->tmp);                 // S = B B' - I, full
+  // M-sized operands of the strips' phase 3:  R = Lk^-T (B B' - I)  (column-major: the P operand of the GEMM); then, for the
+  // kernel-gradient reductions behind the strips, alpha = Lk^-T m~ (no strip reads it: it follows ev_R)
   gemm_mm(ctx, w, dt, s, w->tmp, w->LinvRM, Mp, w->Rcm, kMmFull | kMmYLow); // out[c][r] = sum_k S[k][c] Linv[k][r] = R[r][c]: R column-major
   KCHECK(ctx, "grad prep");
-  if (gop.on) HIPC(ctx, hipEventRecord(ctx->ev_R, s));   // R and alpha are final: the segmented strips' closing launch (phase 3) may run
+  if (gop.on) HIPC(ctx, hipEventRecord(ctx->ev_R, s));   // R is final: the segmented strips' closing launch (phase 3) may run
+  launch_linv_t_gemv(dt, s, w->LinvRM, m->mp, Mp, w->alpha, w->gemv_part);
   for (int64_t c0 = 0; c0 < len; c0 += nc) {
     const int64_t clen = (len - c0 < nc) ? len - c0 : nc;
     const int64_t ncp = (clen + 127) / 128 * 128;
