@@ -20,6 +20,17 @@
 
 using namespace svgp;
 
+// (no query of events that were never recorded: it would leave a sticky "invalid resource handle" on the context's device)
+inline hipError_t elapsed_ms(const svgp_ctx* ctx, float* ms, hipEvent_t a, hipEvent_t b) {
+  if (!ctx->timing_on) { *ms = 0.0f; return hipErrorNotReady; }
+  return hipEventElapsedTime(ms, a, b);
+}
+// timing events (ms_prep / ms_strip / ms_chol / ms_overlap of svgp_last_timing): recorded unless the context was created with SVGP_TIMING=0
+#define TREC(ctx, ev, stream)                            \
+  do {                                                   \
+    if ((ctx)->timing_on) HIPC(ctx, hipEventRecord(ev, stream)); \
+  } while (0)
+
 namespace {
 
 size_t esize(int dtype) { return dtype == SVGP_F64 ? 8 : 4; }
@@ -190,16 +201,16 @@ int enqueue_prep(svgp_ctx* ctx, svgp_model* m, bool overlap = false, const RowHo
     launch_pack_q(m->dtype, s, m->Lq_raw, m->m_raw, m->M, m->Mp, m->U, m->mp);          // B = Lq      SVA:183-184
     KCHECK(ctx, "pack_q");
     HIPC(ctx, hipEventRecord(ctx->ev_fork, s));
-    HIPC(ctx, hipEventRecord(ctx->ev_ov[0], s));
+    TREC(ctx, ctx->ev_ov[0], s);
     if (hook && hook->fn) hook->fn(hook->user, -1);   // the strips' pre-generation: behind the fork, before the chain is enqueued
   }
   launch_kuu(m->dtype, s, kp, m->zs, m->M, m->Mp, m->desc.jitter, m->L);
   KCHECK(ctx, "kuu");
-  HIPC(ctx, hipEventRecord(ctx->ev_chol[0], s));
+  TREC(ctx, ctx->ev_chol[0], s);
   launch_potrf(m->dtype, s, m->L, m->T, m->Mp, m->info, reinterpret_cast<unsigned*>(m->info + 1), overlap ? ctx->ev_row : nullptr,
                overlap ? hook : nullptr);   // T panels included
   KCHECK(ctx, "potrf");
-  HIPC(ctx, hipEventRecord(ctx->ev_chol[1], s));
+  TREC(ctx, ctx->ev_chol[1], s);
   if (overlap) {
     launch_kl_terms(m->dtype, s, m->Lq_raw, m->m_raw, m->L, m->M, m->Mp, m->scal);        // SVA:364-373
   } else if (m->desc.parametrization == SVGP_NONCENTERED) {
@@ -423,7 +434,7 @@ int enqueue_strips(svgp_ctx* ctx, svgp_model* m, const void* x, int64_t ldx, con
   }
   ctx->timing.strip_launches = (plan.grid ? 1 : 0) + (plan.nt_tail ? 1 : 0);
   if (o.mom_shift) return SVGP_OK;   // the second part of a batch: the caller joins the parts and runs the expectation over both
-  HIPC(ctx, hipEventRecord(ctx->ev[2], ctx->stream));
+  TREC(ctx, ctx->ev[2], ctx->stream);
   if (o.skip_expect) return SVGP_OK;
   launch_expect(m->dtype, ctx->stream, lp, a.mom_mu, a.mom_var, y, off, len, ctx->partial, ctx->negcnt, o.mu, o.var);
   KCHECK(ctx, "expect");
@@ -526,7 +537,7 @@ int seg_enqueue_row(SegRun& r, int row) {
   }
   launch_strip_seg(dt, s2, a, r.op.nt, r.op.grid, r.op.nstrips, r.grad);
   KCHECK(ctx, "strip (segmented: panel)");
-  if (I == 0) HIPC(ctx, hipEventRecord(ctx->ev_ov[1], s2));
+  if (I == 0) TREC(ctx, ctx->ev_ov[1], s2);
   return SVGP_OK;
 }
 
@@ -607,7 +618,7 @@ int seg_finish_forward(svgp_ctx* ctx, svgp_model* m, const void* x, int64_t ldx,
     launches += int(ctx->timing.strip_launches);
   }
   HIPC(ctx, hipStreamWaitEvent(s, ctx->ev_join, 0));
-  HIPC(ctx, hipEventRecord(ctx->ev[2], s));
+  TREC(ctx, ctx->ev[2], s);
   ctx->timing.strip_launches = launches;
   if (o.skip_expect) return SVGP_OK;
   LikParams lp{};
@@ -662,7 +673,7 @@ int elbo_enqueue(svgp_ctx* ctx, svgp_model* m, const svgp_data* data, int64_t of
     rc = seg_prepare_forward(ctx, m, data->x, data->ldx, off, len, op, seg);
     if (rc) return rc;
   }
-  HIPC(ctx, hipEventRecord(ctx->ev[0], s));
+  TREC(ctx, ctx->ev[0], s);
   rc = enqueue_prep(ctx, m, op.on, (op.on && !dry) ? &hook : nullptr);
   if (rc == SVGP_OK && op.on && !dry) rc = seg.rc;
   if (rc) {   // a failure between the fork and the join leaves work on the second stream that the main stream never waited for: drain it,
@@ -670,12 +681,12 @@ int elbo_enqueue(svgp_ctx* ctx, svgp_model* m, const svgp_data* data, int64_t of
     if (op.on && ctx->stream2) (void)hipStreamSynchronize(ctx->stream2);
     return rc;
   }
-  HIPC(ctx, hipEventRecord(ctx->ev[1], s));
+  TREC(ctx, ctx->ev[1], s);
   if (dry) {
     ctx->overlapped = false;   // ev_ov[1] is not recorded on this path
     rc = enqueue_strips(ctx, m, data->x, data->ldx, data->y, off, len, StripOuts{});
     if (rc) return rc;
-    HIPC(ctx, hipEventRecord(ctx->ev[3], s));
+    TREC(ctx, ctx->ev[3], s);
     return SVGP_OK;
   }
   rc = op.on ? seg_finish_forward(ctx, m, data->x, data->ldx, data->y, off, len, StripOuts{}, seg)
@@ -684,7 +695,7 @@ int elbo_enqueue(svgp_ctx* ctx, svgp_model* m, const svgp_data* data, int64_t of
     if (op.on && ctx->stream2) (void)hipStreamSynchronize(ctx->stream2);
     return rc;
   }
-  HIPC(ctx, hipEventRecord(ctx->ev[3], s));
+  TREC(ctx, ctx->ev[3], s);
   return SVGP_OK;
 }
 
@@ -722,21 +733,21 @@ int elbo_finish(svgp_ctx* ctx, svgp_model* m, ElboRead* out) {
   ps.info = int(res[12]);
   finish_prep(m, ps);
   float t01 = 0, t12 = 0, t23 = 0;
-  (void)hipEventElapsedTime(&t01, ctx->ev[0], ctx->ev[1]);
-  (void)hipEventElapsedTime(&t12, ctx->ev[1], ctx->ev[2]);
-  (void)hipEventElapsedTime(&t23, ctx->ev[2], ctx->ev[3]);
+  (void)elapsed_ms(ctx, &t01, ctx->ev[0], ctx->ev[1]);
+  (void)elapsed_ms(ctx, &t12, ctx->ev[1], ctx->ev[2]);
+  (void)elapsed_ms(ctx, &t23, ctx->ev[2], ctx->ev[3]);
   ctx->timing.ms_prep = t01;
   ctx->timing.ms_strip = t12;
   ctx->timing.ms_expect = t23;
   ctx->timing.ms_total = t01 + t12 + t23;
   ctx->timing.ms_kuf = 0;
   float tch = 0;
-  (void)hipEventElapsedTime(&tch, ctx->ev_chol[0], ctx->ev_chol[1]);
+  (void)elapsed_ms(ctx, &tch, ctx->ev_chol[0], ctx->ev_chol[1]);
   ctx->timing.ms_chol = tch;
   ctx->timing.ms_overlap = 0;
   if (ctx->overlapped) {   // the part of the prep the strips ran beside: from their first launch's completion to the prep's end
     float tov = 0;
-    if (hipEventElapsedTime(&tov, ctx->ev_ov[1], ctx->ev[1]) == hipSuccess && tov > 0) ctx->timing.ms_overlap = tov;
+    if (elapsed_ms(ctx, &tov, ctx->ev_ov[1], ctx->ev[1]) == hipSuccess && tov > 0) ctx->timing.ms_overlap = tov;
   }
   out->E = res[0];
   out->n_points = res[1];
@@ -866,6 +877,7 @@ int32_t svgp_ctx_create(int32_t device_id, void* stream, svgp_ctx** out) {
   svgp_ctx* c = new (std::nothrow) svgp_ctx();
   if (!c) return SVGP_OOM;
   c->device = device_id;
+  { const char* tq = getenv("SVGP_TIMING"); c->timing_on = !(tq && tq[0] == '0'); }
   if (hipSetDevice(device_id) != hipSuccess) { delete c; return SVGP_HIP_ERROR; }
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device_id) == hipSuccess) c->num_cus = prop.multiProcessorCount;
@@ -1133,14 +1145,14 @@ int32_t svgp_kuf(svgp_ctx* ctx, svgp_model* m, const svgp_data* data, int64_t of
     ctx->kuf_bytes = bytes;
   }
   launch_scale_inputs(m->dtype, s, m->z_raw, m->desc.layout_z, m->d, m->M, m->Mp, m->invl, m->zs);
-  HIPC(ctx, hipEventRecord(ctx->ev[0], s));
+  TREC(ctx, ctx->ev[0], s);
   launch_kuf(m->dtype, s, kparams(m), m->zs, m->M, m->Mp, data->x, data->ldx, off, len, ctx->kuf_buf);
-  HIPC(ctx, hipEventRecord(ctx->ev[1], s));
+  TREC(ctx, ctx->ev[1], s);
   HIPC(ctx, hipGetLastError());
   if (Kuf_out_host) HIPC(ctx, hipMemcpyAsync(Kuf_out_host, ctx->kuf_buf, bytes, hipMemcpyDeviceToHost, s));
   HIPC(ctx, hipStreamSynchronize(s));
   float t = 0;
-  (void)hipEventElapsedTime(&t, ctx->ev[0], ctx->ev[1]);
+  (void)elapsed_ms(ctx, &t, ctx->ev[0], ctx->ev[1]);
   ctx->timing = svgp_timing{};
   ctx->timing.ms_kuf = t;
   ctx->timing.ms_total = t;
@@ -1555,14 +1567,14 @@ int grad_enqueue_impl(svgp_ctx* ctx, svgp_model* m, const svgp_data* data, int64
     gseg.pre = &seg_pre;
   }
   ctx->overlapped = gop.on;
-  HIPC(ctx, hipEventRecord(ctx->ev[0], s));
+  TREC(ctx, ctx->ev[0], s);
   rc = enqueue_prep(ctx, m, gop.on, gop.on ? &ghook : nullptr);
   if (rc == SVGP_OK && gop.on) rc = gseg.rc;
   if (rc) {
     if (gop.on && ctx->stream2) (void)hipStreamSynchronize(ctx->stream2);   // segments already enqueued: drain before the scratch is reused
     return rc;
   }
-  HIPC(ctx, hipEventRecord(ctx->ev[1], s));
+  TREC(ctx, ctx->ev[1], s);
   if (!gop.on) {
     rc = grad_pre_chain(s);
     if (rc) return rc;
@@ -1662,7 +1674,7 @@ int grad_enqueue_impl(svgp_ctx* ctx, svgp_model* m, const svgp_data* data, int64
     if (kg_overlap) HIPC(ctx, hipStreamWaitEvent(s, ctx->ev_join, 0));
   }
   if (gc.ext_gmu) launch_add_f64(s, w->sums, gc.ext_sum_e);   // sums[0] = sum E: the host's, before any collective
-  HIPC(ctx, hipEventRecord(ctx->ev[2], s));
+  TREC(ctx, ctx->ev[2], s);
   // M-sized tail.  With W = A diag(2 g_v) A' and a = A g_mu:
   //   Lq_bar = tril(W B) - klw dKL/dB,   Lk_bar = -tril(alpha a' + R W)     (B = Lq whitened; W, R carry the factors 2)
   launch_sym_from_lower(dt, s, w->G1, ns_syrk, Mp, 0.0, w->W2);
@@ -1705,7 +1717,7 @@ int grad_enqueue_impl(svgp_ctx* ctx, svgp_model* m, const svgp_data* data, int64
   // status slots of the all-reduced scalars + this rank's prep scalars / info behind them: ONE fp64 read-back per evaluation
   launch_grad_status(s, w->sums, m->info, double(len), m->scal, w->scal_out + 1 + dreg);
   KCHECK(ctx, "kgrad uu / finish");
-  HIPC(ctx, hipEventRecord(ctx->ev[3], s));
+  TREC(ctx, ctx->ev[3], s);
   return SVGP_OK;
 }
 
@@ -1857,14 +1869,14 @@ int grad_finish(svgp_ctx* ctx, svgp_model* m, GradCall& gc, double* elbo_out, sv
   const char* mhost = gh + nz * es;
   finish_prep(m, ps);
   float t01 = 0, t13 = 0;
-  (void)hipEventElapsedTime(&t01, ctx->ev[0], ctx->ev[1]);
-  (void)hipEventElapsedTime(&t13, ctx->ev[1], ctx->ev[3]);
+  (void)elapsed_ms(ctx, &t01, ctx->ev[0], ctx->ev[1]);
+  (void)elapsed_ms(ctx, &t13, ctx->ev[1], ctx->ev[3]);
   ctx->timing = svgp_timing{};
   ctx->timing.ms_prep = t01;
   ctx->timing.ms_strip = t13;
   ctx->timing.ms_total = t01 + t13;
   float tch = 0;
-  (void)hipEventElapsedTime(&tch, ctx->ev_chol[0], ctx->ev_chol[1]);
+  (void)elapsed_ms(ctx, &tch, ctx->ev_chol[0], ctx->ev_chol[1]);
   ctx->timing.ms_chol = tch;
   ElboRead r;
   r.E = sums[0]; r.n_neg = sums[4]; r.n_points = sums[5]; r.bad_chol = gc.collective ? sums[6] : 0.0; r.failed = gc.collective ? sums[7] : 0.0;
@@ -1943,10 +1955,10 @@ extern "C" int32_t svgp_marginals(svgp_ctx* ctx, svgp_model* m, const svgp_data*
   if (!mean_out || !var_out) return fail(ctx, SVGP_INVALID_ARG, "null output");
   hipStream_t s = ctx->stream;
   HIPC(ctx, hipSetDevice(ctx->device));
-  HIPC(ctx, hipEventRecord(ctx->ev[0], s));
+  TREC(ctx, ctx->ev[0], s);
   rc = enqueue_prep(ctx, m);
   if (rc) return rc;
-  HIPC(ctx, hipEventRecord(ctx->ev[1], s));
+  TREC(ctx, ctx->ev[1], s);
   StripOuts so;
   so.skip_expect = true;
   rc = enqueue_strips(ctx, m, data->x, data->ldx, nullptr, off, len, so);
@@ -1959,8 +1971,8 @@ extern "C" int32_t svgp_marginals(svgp_ctx* ctx, svgp_model* m, const svgp_data*
   HIPC(ctx, hipStreamSynchronize(s));
   finish_prep(m, ps);
   float t01 = 0, t12 = 0;
-  (void)hipEventElapsedTime(&t01, ctx->ev[0], ctx->ev[1]);
-  (void)hipEventElapsedTime(&t12, ctx->ev[1], ctx->ev[2]);
+  (void)elapsed_ms(ctx, &t01, ctx->ev[0], ctx->ev[1]);
+  (void)elapsed_ms(ctx, &t12, ctx->ev[1], ctx->ev[2]);
   ctx->timing = svgp_timing{};
   ctx->timing.ms_prep = t01;
   ctx->timing.ms_strip = t12;

@@ -33,6 +33,7 @@ struct svgp_ctx {
   // strips beside the factorisation (api.hip: SegRun): one event per block row of T, the segmented strips' saved sums
   hipEvent_t ev_row[16] = {};
   bool ev_row_ready = false, overlapped = false;
+  bool timing_on = true;   // SVGP_TIMING=0 at context creation: no timing events on the stream (each record costs the stream ~5 us); svgp_last_timing then reports zeros
   hipEvent_t ev_S = nullptr;                  // the chain-independent part of the gradient's prep (S = B B' - I, cleared accumulators), second stream
   hipEvent_t ev_R = nullptr;                  // the gradient's M-sized prep (Linv, alpha, R) is final: phase 3 of the segmented strips
   hipEvent_t ev_ov[2] = {nullptr, nullptr};   // timed: fork point, first strip launch done (svgp_timing.ms_overlap)

@@ -369,3 +369,36 @@ def test_gradient_read_back_in_pieces_and_into_reused_buffers(ctx, dtype, M, d):
         model.elbo_grad(data, 0, N, float(N), out=dict(g0, Lq=np.zeros((M, M + 1), dtype=dtype, order="F")))
     model.free()
     data.free()
+
+
+def test_context_without_timing_events():
+    """SVGP_TIMING=0 at context creation: no timing events on the stream (each record costs the stream ~5 us: 3 % of a 1024-point
+    forward call).  Same results bit for bit, svgp_last_timing reports zeros, and nothing is left behind in the HIP error state
+    (querying an event that was never recorded would be a sticky error)."""
+    x, y, sva, s2 = o.synth_problem(5150, 3000, 700, 3, dtype=np.float64)
+    ref_ctx = _ffi.Context(0)
+    old = _toggle("SVGP_TIMING", "0")
+    try:
+        quiet = _ffi.Context(0)
+    finally:
+        _restore("SVGP_TIMING", old)
+    out = []
+    for c in (ref_ctx, quiet):
+        model = device_model(c, sva, dtype=np.float64, sigma2=s2)
+        data = _ffi.DeviceData(c, x, y, np.float64)
+        v = model.elbo(data, 0, 3000, 3000.0)[0]
+        tf = c.timing()
+        vg, _, g = model.elbo_grad(data, 0, 3000, 3000.0)
+        tg = c.timing()
+        mu, var = model.marginals(data, 0, 3000)
+        out.append((v, vg, g, mu, var, tf, tg))
+        model.free()
+        data.free()
+    a, b = out
+    assert a[0] == b[0] and a[1] == b[1] and np.array_equal(a[3], b[3]) and np.array_equal(a[4], b[4])
+    for k in ("z", "m", "Lq", "inv_lengthscale"):
+        assert np.array_equal(np.asarray(a[2][k]), np.asarray(b[2][k])), k
+    assert a[5].ms_total > 0 and a[6].ms_total > 0
+    assert b[5].ms_total == 0 and b[5].ms_prep == 0 and b[5].ms_chol == 0 and b[6].ms_total == 0
+    quiet.close()
+    ref_ctx.close()
