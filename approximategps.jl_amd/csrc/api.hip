@@ -20,6 +20,16 @@
 
 using namespace svgp;
 
+// Events between the context's own streams and for device-side timing need no system-scope fence (the cache write-back and invalidation
+// that makes device memory visible to the HOST): a record then costs the stream ~1 instead of ~5 us (profiles/round4/minibatch_step.md
+// section 7).  Everything the host reads comes through hipMemcpy + a stream / event synchronisation of DEFAULT events (ev_piece).
+// SVGP_EVENT_FENCE=1 (process-wide, A/B): default events everywhere.
+inline unsigned event_flags(bool timing) {
+  static const bool fence = [] { const char* e = getenv("SVGP_EVENT_FENCE"); return e && e[0] == '1'; }();
+  return (timing ? 0u : unsigned(hipEventDisableTiming)) | (fence ? 0u : unsigned(hipEventDisableSystemFence));
+}
+#define kSyncEvent event_flags(false)
+#define kTimingEvent event_flags(true)
 // (no query of events that were never recorded: it would leave a sticky "invalid resource handle" on the context's device)
 inline hipError_t elapsed_ms(const svgp_ctx* ctx, float* ms, hipEvent_t a, hipEvent_t b) {
   if (!ctx->timing_on) { *ms = 0.0f; return hipErrorNotReady; }
@@ -280,8 +290,8 @@ int ensure_stream2(svgp_ctx* ctx) {
   } else {
     HIPC(ctx, hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
   }
-  HIPC(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
-  HIPC(ctx, hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
+  HIPC(ctx, hipEventCreateWithFlags(&ctx->ev_fork, kSyncEvent));
+  HIPC(ctx, hipEventCreateWithFlags(&ctx->ev_join, kSyncEvent));
   HIPC(ctx, hipMalloc(&ctx->counter2, 64));
   return SVGP_OK;
 }
@@ -313,11 +323,11 @@ int ensure_overlap(svgp_ctx* ctx, size_t state_doubles) {
   if (rc) return rc;
   if (!ctx->ev_row_ready) {
     for (auto& e : ctx->ev_row)
-      if (!e) HIPC(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+      if (!e) HIPC(ctx, hipEventCreateWithFlags(&e, kSyncEvent));
     for (auto& e : ctx->ev_ov)
-      if (!e) HIPC(ctx, hipEventCreate(&e));
-    if (!ctx->ev_R) HIPC(ctx, hipEventCreateWithFlags(&ctx->ev_R, hipEventDisableTiming));
-    if (!ctx->ev_S) HIPC(ctx, hipEventCreateWithFlags(&ctx->ev_S, hipEventDisableTiming));
+      if (!e) HIPC(ctx, hipEventCreateWithFlags(&e, kTimingEvent));
+    if (!ctx->ev_R) HIPC(ctx, hipEventCreateWithFlags(&ctx->ev_R, kSyncEvent));
+    if (!ctx->ev_S) HIPC(ctx, hipEventCreateWithFlags(&ctx->ev_S, kSyncEvent));
     ctx->ev_row_ready = true;
   }
   state_doubles += kSegSplitDoubles;   // behind the saved sums: the split closing launch's partials and its per-strip counters
@@ -515,10 +525,6 @@ int seg_enqueue_row(SegRun& r, int row) {
   const int dt = r.m->dtype;
   if (row < 0) {
     HIPC(ctx, hipStreamWaitEvent(s2, ctx->ev_fork, 0));
-    if (r.pre) {
-      const int rcp = (*r.pre)();
-      if (rcp) return rcp;
-    }
     a.seg_flags = kSegPregen; a.seg_lo = 0; a.seg_hi = 0;
     launch_strip_seg(dt, s2, a, r.op.nt, r.op.grid, r.op.nstrips, r.grad);
     KCHECK(ctx, "strip (segmented: pre-generation)");
@@ -538,6 +544,13 @@ int seg_enqueue_row(SegRun& r, int row) {
   launch_strip_seg(dt, s2, a, r.op.nt, r.op.grid, r.op.nstrips, r.grad);
   KCHECK(ctx, "strip (segmented: panel)");
   if (I == 0) TREC(ctx, ctx->ev_ov[1], s2);
+  // The gradient's chain-independent prep goes behind the strips of panel 1: its ~10 launches are ~55 us of HOST time, and enqueued
+  // any earlier (it sat in front of the pre-generation at first) they kept the host from enqueueing the factorisation's first launches -
+  // the main stream idled for 45 us waiting for its Kuu kernel (kernel trace, profiles/round4/minibatch_step.md section 7)
+  if (I == 1 && r.pre) {
+    const int rcp = (*r.pre)();
+    if (rcp) return rcp;
+  }
   return SVGP_OK;
 }
 
@@ -888,9 +901,9 @@ int32_t svgp_ctx_create(int32_t device_id, void* stream, svgp_ctx** out) {
     c->own_stream = true;
   }
   for (auto& e : c->ev)
-    if (hipEventCreate(&e) != hipSuccess) { delete c; return SVGP_HIP_ERROR; }
+    if (hipEventCreateWithFlags(&e, kTimingEvent) != hipSuccess) { delete c; return SVGP_HIP_ERROR; }
   for (auto& e : c->ev_chol)
-    if (hipEventCreate(&e) != hipSuccess) { delete c; return SVGP_HIP_ERROR; }
+    if (hipEventCreateWithFlags(&e, kTimingEvent) != hipSuccess) { delete c; return SVGP_HIP_ERROR; }
   if (hipMalloc(&c->d_res, 16 * sizeof(double)) != hipSuccess || hipMalloc(&c->d_coll, 8 * sizeof(double)) != hipSuccess || hipMalloc(&c->counter, 64) != hipSuccess || hipMalloc(&c->partial, 1024 * sizeof(double)) != hipSuccess ||
       hipMalloc(&c->negcnt, 1024 * sizeof(unsigned)) != hipSuccess) { delete c; return SVGP_OOM; }
   *out = c;
@@ -1542,7 +1555,9 @@ int grad_enqueue_impl(svgp_ctx* ctx, svgp_model* m, const svgp_data* data, int64
   const void* Bq = centered ? m->B : w->Lqp;
   auto grad_pre_chain = [&](hipStream_t st) -> int {
     HIPC(ctx, hipMemsetAsync(w->zero_blk, 0, w->zero_b, st));   // every accumulator of the evaluation, one fill
-    HIPC(ctx, hipMemcpyAsync(w->invl_d, m->invl_host.data(), size_t(m->d) * 8, hipMemcpyHostToDevice, st));
+    // (as kernel arguments: a hipMemcpyAsync from pageable memory blocks the host until the stream gets there - on the second stream
+    // that was ~45 us during which the main stream's Kuu launch was not even enqueued)
+    launch_setvec_f64(st, w->invl_d, m->invl_host.data(), m->d);
     if (!centered) launch_pad_lower(dt, st, m->Lq_raw, M, Mp, w->Lqp);
     gemm_mm(ctx, w, dt, st, Bq, Bq, Mp, w->G2, kMmXUp | kMmYUp);   // lower tiles of B B' (row-major); B[r][k] = 0 for k > r
     launch_sym_from_lower(dt, st, w->G2, 1, Mp, 1.0, w->tmp);     // S = B B' - I, full

@@ -883,6 +883,17 @@ int grad_dreg(int d) { return d <= 8 ? 8 : (d <= 16 ? 16 : (d <= 32 ? 32 : 64));
 int grad_rowblocks(int dtype, int d, int64_t Mp) { return int(d <= 16 ? Mp / 128 : (d <= 32 ? Mp / 32 : (dtype == 0 ? Mp / 16 : Mp / 64))); }
 
 void launch_set_f64(hipStream_t s, double* dst, double value) { hipLaunchKernelGGL(set_f64_kernel, dim3(1), dim3(1), 0, s, dst, value); }
+struct Vec64 { double v[64]; };
+__global__ void setvec_f64_kernel(double* __restrict__ dst, Vec64 vals, int n) {
+  if (int(threadIdx.x) < n) dst[threadIdx.x] = vals.v[threadIdx.x];
+}
+// dst[0 .. n) = vals (n <= 64), the values travelling as kernel arguments: unlike a hipMemcpyAsync from pageable host memory this
+// does not block the enqueueing thread until the stream gets there
+void launch_setvec_f64(hipStream_t s, double* dst, const double* vals, int n) {
+  Vec64 v{};
+  for (int i = 0; i < n && i < 64; ++i) v.v[i] = vals[i];
+  hipLaunchKernelGGL(setvec_f64_kernel, dim3(1), dim3(64), 0, s, dst, v, n < 64 ? n : 64);
+}
 void launch_set2_f64(hipStream_t s, double* dst, double a, double b) { hipLaunchKernelGGL(set2_f64_kernel, dim3(1), dim3(1), 0, s, dst, a, b); }
 void launch_grad_status(hipStream_t s, double* sums, const int* chol_info, double n_points, const double* prep_scal, double* prep_out) {
   hipLaunchKernelGGL(grad_status_kernel, dim3(1), dim3(1), 0, s, sums, chol_info, n_points, prep_scal, prep_out);

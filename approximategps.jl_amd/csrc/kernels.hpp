@@ -168,6 +168,7 @@ constexpr double kDefaultSigma2 = 1e-18;  // AbstractGPs.default_σ² added by f
 int grad_dreg(int d);
 int grad_rowblocks(int dtype, int d, int64_t Mp);
 void launch_set_f64(hipStream_t s, double* dst, double value);
+void launch_setvec_f64(hipStream_t s, double* dst, const double* vals, int n);   // dst[0 .. n) = vals, n <= 64, as kernel arguments (never blocks the host)
 void launch_set2_f64(hipStream_t s, double* dst, double a, double b);   // dst[0] = a, dst[1] = b (values travel as kernel arguments: no host buffer to outlive)
 // sums[5] = n_points, sums[6] = (*chol_info != 0), sums[7] = 0: the status slots of the all-reduced gradient scalars
 // ... and, behind them, a copy of the prep scalars (4) and chol_info (as a double): prep_out[0..5)
