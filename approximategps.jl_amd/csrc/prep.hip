@@ -9,6 +9,7 @@
 #include "device_common.hpp"
 #include "kernels.hpp"
 
+#include <hip/hip_ext.h>
 #include <cstdlib>
 
 namespace svgp {
@@ -1151,14 +1152,26 @@ void potrf_t(hipStream_t s, T* A, T* Tm, int64_t Mp, int* info, unsigned* sync, 
   potf2(0);
   for (int p = 0; p < nP; ++p) {
     const int n = nP - p - 1, nt_p = t_inside ? p : 0;
+    // block row p of T (inv(L_pp) from the block factorisation, T[p, J < p] from the TRSM launch) is final behind that launch: the
+    // strips' phase 1 of panel p may start (api.hip: SegRun - the row hook below enqueues the waiter on its own stream).  The event
+    // rides on the launch itself (hipExtLaunchKernelGGL's stop event = the dispatch packet's own completion signal): a separate
+    // hipEventRecord is a barrier packet of its own, ~5 us of the chain per panel (kernel traces, minibatch_step.md section 8).
+    // SVGP_ROW_EVENT_EXT=0: the separate record (A/B).
+    static const bool ev_ext = [] { const char* e = getenv("SVGP_ROW_EVENT_EXT"); return !e || e[0] != '0'; }();
+    const bool want_ev = row_events && t_inside;
+    bool ev_done = false;
     if (!trsm_done && n + nt_p > 0) {   // the panel below the diagonal (and the T panels of block row p)
-      hipLaunchKernelGGL((chol_tile_kernel<T, MODE_TRSM, CNT>), dim3((n + nt_p) * NCH), dim3(k256), GS::LDS_BYTES, s, A, Tm, Mp, p, n, info, sync);
+      if (want_ev && ev_ext) {
+        hipExtLaunchKernelGGL((chol_tile_kernel<T, MODE_TRSM, CNT>), dim3((n + nt_p) * NCH), dim3(k256), GS::LDS_BYTES, s, nullptr, row_events[p], 0,
+                              A, Tm, Mp, p, n, info, sync, 1);
+        ev_done = true;
+      } else {
+        hipLaunchKernelGGL((chol_tile_kernel<T, MODE_TRSM, CNT>), dim3((n + nt_p) * NCH), dim3(k256), GS::LDS_BYTES, s, A, Tm, Mp, p, n, info, sync);
+      }
       dbg("chol trsm + T panels", s);
     }
-    // block row p of T (inv(L_pp) from the block factorisation, T[p, J < p] from the launch above) is final here: the strips'
-    // phase 1 of panel p may start (api.hip: SegRun - the row hook below enqueues the waiter on its own stream)
-    if (row_events && t_inside) {
-      (void)hipEventRecord(row_events[p], s);
+    if (want_ev) {
+      if (!ev_done) (void)hipEventRecord(row_events[p], s);
       if (hook && hook->fn) hook->fn(hook->user, p);   // the waiters of this row are enqueued now, not after the whole chain (host time)
     }
     if (n == 0) break;
