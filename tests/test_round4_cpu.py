@@ -95,3 +95,16 @@ def test_timing_struct_growth_is_safe_for_old_hosts():
     api = open(os.path.join(ROOT, "approximategps.jl_amd", "csrc", "api.hip")).read()
     body = api[api.index("int32_t svgp_last_timing(const svgp_ctx* ctx, svgp_timing* out)"):api.index("int32_t svgp_last_timing_sized")]
     assert "SVGP_TIMING_V3_BYTES" in body and "*out = ctx->timing" not in body
+
+
+def test_every_environment_knob_is_documented():
+    """Every SVGP_* environment variable the library (or its Python mirror) reads has a row in INTEGRATION.md's table."""
+    import glob
+    import re
+    names = set()
+    for f in glob.glob(os.path.join(ROOT, "approximategps.jl_amd", "csrc", "*.h*")) + glob.glob(os.path.join(ROOT, "approximategps.jl_amd", "approxgp", "*.py")):
+        names |= set(re.findall(r'(?:getenv|env_int|environ\.get|environ\[)\(?\s*"(SVGP_[A-Z0-9_]+)"', open(f).read()))
+    assert len(names) > 30, names
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    missing = sorted(n for n in names if f"`{n}`" not in doc)
+    assert not missing, missing
