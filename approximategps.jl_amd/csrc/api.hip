@@ -201,10 +201,13 @@ KernelParams kparams(const svgp_model* m) {
 // overlap (NonCentered only): everything the strips need besides T - the scaled inducing inputs, U = Lq', the padded mean - is
 // enqueued FIRST and ctx->ev_fork recorded behind it; the factorisation then records ctx->ev_row[p] as block row p of T becomes
 // final, so that strips on a second stream can run beside it (SegRun: seg_enqueue_row).
+// info + the factorisation's hand-over counters and flags: 1 + 2 nP ints, rounded up to 256 bytes - a memset whose size is not a
+// multiple of 16 bytes becomes TWO fill kernels (aligned body + tail), ~5 us of every call's prologue
+inline size_t info_bytes(int64_t Mp) { return (sizeof(int) * size_t(1 + 2 * (Mp / 128)) + 255) / 256 * 256; }
 int enqueue_prep(svgp_ctx* ctx, svgp_model* m, bool overlap = false, const RowHook* hook = nullptr) {
   hipStream_t s = ctx->stream;
   const KernelParams kp = kparams(m);
-  HIPC(ctx, hipMemsetAsync(m->info, 0, sizeof(int) * size_t(1 + 2 * (m->Mp / 128)), s));   // info + the factorisation's hand-over counters and flags
+  HIPC(ctx, hipMemsetAsync(m->info, 0, info_bytes(m->Mp), s));   // info + the factorisation's hand-over counters and flags
   launch_scale_inputs(m->dtype, s, m->z_raw, m->desc.layout_z, m->d, m->M, m->Mp, m->invl, m->zs);
   KCHECK(ctx, "scale_inputs");
   if (overlap) {
@@ -1032,7 +1035,7 @@ int32_t svgp_model_create(svgp_ctx* ctx, const svgp_model_desc* desc, svgp_model
   struct { void** p; size_t bytes; } allocs[] = {
       {&m->z_raw, M * m->d * es}, {&m->m_raw, M * es},     {&m->Lq_raw, M * M * es}, {&m->invl, size_t(m->d) * es},
       {&m->zs, Mp * m->d * es},   {&m->L, Mp * Mp * es},   {&m->T, Mp * Mp * es},    {&m->U, Mp * Mp * es},
-      {&m->mp, Mp * es},          {(void**)&m->scal, (8 + Mp) * sizeof(double)},     {(void**)&m->info, sizeof(int) * (1 + 2 * (Mp / 128))},
+      {&m->mp, Mp * es},          {(void**)&m->scal, (8 + Mp) * sizeof(double)},     {(void**)&m->info, info_bytes(Mp)},
   };
   for (auto& a : allocs)
     if (hipMalloc(a.p, a.bytes) != hipSuccess) {
