@@ -525,6 +525,9 @@ __global__ void __launch_bounds__(k256) potf2_kernel(T* __restrict__ A, T* __res
 // MFMA tile kernels of the blocked Cholesky (and of the T panels, which ride in its launches).
 // ------------------------------------------------------------------------------------------------
 enum : int { MODE_TRSM = 0, MODE_SYRK = 1, MODE_COL = 2 };
+#ifndef SVGP_CHOL_TILE_ASYNC
+#define SVGP_CHOL_TILE_ASYNC 1
+#endif
 
 __device__ __forceinline__ void tri_index(int b, int& i, int& j) {  // b -> (i >= j) in row-major triangle order
   i = 0;
@@ -605,9 +608,19 @@ __global__ void __launch_bounds__(k256, (FUSE && sizeof(T) == 8) ? 1 : 2) chol_t
   }
   const int kcol = (MODE == MODE_SYRK) ? p - kb + 1 : p;   // first block column of the contraction
   const T* Q = A + int64_t(i) * NB + int64_t(kcol) * NB * ld + chunk * NT;
-  const typename G::QOff qoff = G::q_offsets(ld);
-  auto qload = [&](int t, QRegs& r) { G::load_q(r, Q + int64_t(t) * 16 * ld, qoff); };
-  G::loop(acc, P, ld, (MODE == MODE_SYRK ? kb : 1) * (NB / 16), qload, smem);
+  // SVGP_CHOL_TILE_ASYNC (build-time A/B, default 1): both operands global -> LDS by DMA through three buffers (the strips' loop) instead
+  // of the two-buffer register-staged loop: these 8-step products run at the latency of their loads.  fp32 (64-column chunks): prep
+  // M = 512 0.252 -> 0.245 ms, 2048 1.09 -> 1.06, 4096 1.89 -> 1.77 (same box, three runs).  The f64 tile shape (four 32-column chunks: one
+  // column tile per wave) has no asynchronous loop and keeps the two-buffer one; two 64-column f64 chunks ON the asynchronous loop were
+  // measured too: M = 1024 0.535 -> 0.615 ms, 4096 2.23 -> 2.48 - half the workgroups per tile costs more than the deeper pipeline gives.
+  if constexpr (SVGP_CHOL_TILE_ASYNC && G::kAsync) {
+    auto qsrc = [&](int t) { return Q + int64_t(t) * 16 * ld; };
+    G::template loop_tri_async<0>(acc, P, ld, (MODE == MODE_SYRK ? kb : 1) * (NB / 16), qsrc, smem, ld);
+  } else {
+    const typename G::QOff qoff = G::q_offsets(ld);
+    auto qload = [&](int t, QRegs& r) { G::load_q(r, Q + int64_t(t) * 16 * ld, qoff); };
+    G::loop(acc, P, ld, (MODE == MODE_SYRK ? kb : 1) * (NB / 16), qload, smem);
+  }
   T* C = A + int64_t(i) * NB + int64_t(j) * NB * ld + chunk * NT;
 #pragma unroll
   for (int a = 0; a < G::MI; ++a)
@@ -1060,14 +1073,15 @@ void potrf_t(hipStream_t s, T* A, T* Tm, int64_t Mp, int* info, unsigned* sync, 
   constexpr size_t lds_potf2 = potf2_lds_bytes<T>();
   constexpr int CNT = sizeof(T) == 8 ? 32 : 64, NCH = kNB / CNT;
   using GS = TileGemm<T, CNT, 16, k256>;
-  constexpr size_t lds_fused_s = GS::LDS_BYTES > lds_potf2 ? GS::LDS_BYTES : lds_potf2;
+  constexpr size_t lds_tile = (SVGP_CHOL_TILE_ASYNC && GS::kAsync) ? (GS::ASYNC_LDS_BYTES > GS::LDS_BYTES ? GS::ASYNC_LDS_BYTES : GS::LDS_BYTES) : GS::LDS_BYTES;
+  constexpr size_t lds_fused_s = lds_tile > lds_potf2 ? lds_tile : lds_potf2;
   constexpr size_t lds_fused_l = G::LDS_BYTES > lds_potf2 ? G::LDS_BYTES : lds_potf2;
   static const bool fuse_on = [] { const char* e = getenv("SVGP_CHOL_FUSE"); return !e || e[0] != '0'; }();   // A/B knob
   set_max_lds(reinterpret_cast<const void*>(potf2_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds_potf2));
   set_max_lds(reinterpret_cast<const void*>(syrk128_kernel<T, false>), hipFuncAttributeMaxDynamicSharedMemorySize, int(G::LDS_BYTES));
   set_max_lds(reinterpret_cast<const void*>(syrk128_kernel<T, true>), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds_fused_l));
-  set_max_lds(reinterpret_cast<const void*>(chol_tile_kernel<T, MODE_TRSM, CNT>), hipFuncAttributeMaxDynamicSharedMemorySize, int(GS::LDS_BYTES));
-  set_max_lds(reinterpret_cast<const void*>(chol_tile_kernel<T, MODE_SYRK, CNT>), hipFuncAttributeMaxDynamicSharedMemorySize, int(GS::LDS_BYTES));
+  set_max_lds(reinterpret_cast<const void*>(chol_tile_kernel<T, MODE_TRSM, CNT>), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds_tile));
+  set_max_lds(reinterpret_cast<const void*>(chol_tile_kernel<T, MODE_SYRK, CNT>), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds_tile));
   set_max_lds(reinterpret_cast<const void*>(chol_tile_kernel<T, MODE_SYRK, CNT, true>), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds_fused_s));
   auto potf2 = [&](int p) {
     hipLaunchKernelGGL(potf2_kernel<T>, dim3(1), dim3(k256), lds_potf2, s, A + int64_t(p) * kNB * (Mp + 1), Tm + int64_t(p) * kNB * (Mp + 1), Mp,
@@ -1115,7 +1129,7 @@ void potrf_t(hipStream_t s, T* A, T* Tm, int64_t Mp, int* info, unsigned* sync, 
     for (int a = 0; a < nP; a += 2) {
       const int b = a + 1, na = nP - a - 1;
       if (na > 0) {
-        hipLaunchKernelGGL((chol_tile_kernel<T, MODE_TRSM, CNT>), dim3(na * NCH), dim3(k256), GS::LDS_BYTES, s, A, Tm, Mp, a, na, info, sync, 1);
+        hipLaunchKernelGGL((chol_tile_kernel<T, MODE_TRSM, CNT>), dim3(na * NCH), dim3(k256), lds_tile, s, A, Tm, Mp, a, na, info, sync, 1);
         dbg("chol trsm (a)", s);
       }
       if (b >= nP) break;
@@ -1124,14 +1138,14 @@ void potrf_t(hipStream_t s, T* A, T* Tm, int64_t Mp, int* info, unsigned* sync, 
       dbg("chol column update + potf2 (b)", s);
       const int nb = nP - b - 1;
       if (nb == 0) break;
-      hipLaunchKernelGGL((chol_tile_kernel<T, MODE_TRSM, CNT>), dim3(nb * NCH), dim3(k256), GS::LDS_BYTES, s, A, Tm, Mp, b, nb, info, sync, 1);
+      hipLaunchKernelGGL((chol_tile_kernel<T, MODE_TRSM, CNT>), dim3(nb * NCH), dim3(k256), lds_tile, s, A, Tm, Mp, b, nb, info, sync, 1);
       dbg("chol trsm (b)", s);
       const int nt = nb * (nb + 1) / 2;
       if (nt >= 256) big_update(nt, b, 2);
       else hipLaunchKernelGGL((chol_tile_kernel<T, MODE_SYRK, CNT, true>), dim3(nt * NCH), dim3(k256), lds_fused_s, s, A, Tm, Mp, b, nb, info, sync, 2);
       dbg("chol rank-256 update + potf2 (next a)", s);
     }
-    hipLaunchKernelGGL((chol_tile_kernel<T, MODE_TRSM, CNT>), dim3((nP * (nP - 1) / 2) * NCH), dim3(k256), GS::LDS_BYTES, s, A, Tm, Mp, -1, 0, info, sync, 1);
+    hipLaunchKernelGGL((chol_tile_kernel<T, MODE_TRSM, CNT>), dim3((nP * (nP - 1) / 2) * NCH), dim3(k256), lds_tile, s, A, Tm, Mp, -1, 0, info, sync, 1);
     dbg("T panels", s);
     return;
   }
@@ -1162,11 +1176,11 @@ void potrf_t(hipStream_t s, T* A, T* Tm, int64_t Mp, int* info, unsigned* sync, 
     bool ev_done = false;
     if (!trsm_done && n + nt_p > 0) {   // the panel below the diagonal (and the T panels of block row p)
       if (want_ev && ev_ext) {
-        hipExtLaunchKernelGGL((chol_tile_kernel<T, MODE_TRSM, CNT>), dim3((n + nt_p) * NCH), dim3(k256), GS::LDS_BYTES, s, nullptr, row_events[p], 0,
+        hipExtLaunchKernelGGL((chol_tile_kernel<T, MODE_TRSM, CNT>), dim3((n + nt_p) * NCH), dim3(k256), lds_tile, s, nullptr, row_events[p], 0,
                               A, Tm, Mp, p, n, info, sync, 1);
         ev_done = true;
       } else {
-        hipLaunchKernelGGL((chol_tile_kernel<T, MODE_TRSM, CNT>), dim3((n + nt_p) * NCH), dim3(k256), GS::LDS_BYTES, s, A, Tm, Mp, p, n, info, sync);
+        hipLaunchKernelGGL((chol_tile_kernel<T, MODE_TRSM, CNT>), dim3((n + nt_p) * NCH), dim3(k256), lds_tile, s, A, Tm, Mp, p, n, info, sync);
       }
       dbg("chol trsm + T panels", s);
     }
@@ -1189,13 +1203,13 @@ void potrf_t(hipStream_t s, T* A, T* Tm, int64_t Mp, int* info, unsigned* sync, 
       hipLaunchKernelGGL((chol_tile_kernel<T, MODE_SYRK, CNT, true>), dim3(nt * NCH), dim3(k256), lds_fused_s, s, A, Tm, Mp, p, n, info, sync);
     } else {
       if (large) hipLaunchKernelGGL((syrk128_kernel<T, false>), dim3(nt), dim3(kThreads), G::LDS_BYTES, s, A, Tm, Mp, p, info);
-      else hipLaunchKernelGGL((chol_tile_kernel<T, MODE_SYRK, CNT>), dim3(nt * NCH), dim3(k256), GS::LDS_BYTES, s, A, Tm, Mp, p, n, info, sync);
+      else hipLaunchKernelGGL((chol_tile_kernel<T, MODE_SYRK, CNT>), dim3(nt * NCH), dim3(k256), lds_tile, s, A, Tm, Mp, p, n, info, sync);
       potf2(p + 1);
     }
     dbg("chol syrk", s);
   }
   if (!t_inside) {
-    hipLaunchKernelGGL((chol_tile_kernel<T, MODE_TRSM, CNT>), dim3((nP * (nP - 1) / 2) * NCH), dim3(k256), GS::LDS_BYTES, s, A, Tm, Mp, -1, 0, info, sync);
+    hipLaunchKernelGGL((chol_tile_kernel<T, MODE_TRSM, CNT>), dim3((nP * (nP - 1) / 2) * NCH), dim3(k256), lds_tile, s, A, Tm, Mp, -1, 0, info, sync);
     dbg("T panels", s);
   }
 }
