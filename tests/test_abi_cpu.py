@@ -163,3 +163,97 @@ def test_inline_assembly_dpp_reads_respect_the_wait_states():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_dpp_hazard.py")], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout + r.stderr
     assert " 0 with their source written" in r.stdout and not r.stdout.startswith("0 DPP"), r.stdout
+
+
+def _c_class(ctype: str) -> str:
+    """Argument class of a C parameter / return type: what a ccall type must agree with (pointer, or the integer / float width)."""
+    t = ctype.strip()
+    if "*" in t or "[" in t:   # `double out[4]` as a parameter is a pointer
+        return "ptr"
+    t = re.sub(r"\b(const|struct)\b", "", t).split()
+    t = t[0] if t else "void"
+    return {"int32_t": "i32", "int64_t": "i64", "double": "f64", "void": "void", "float": "f32", "uint32_t": "u32", "uint64_t": "u64",
+            "size_t": "u64"}[t]
+
+
+def _jl_class(jtype: str) -> str:
+    t = jtype.strip()
+    if t.startswith(("Ptr{", "Ref{")) or t in ("Cstring", "Ptr"):
+        return "ptr"
+    return {"Int32": "i32", "Cint": "i32", "Int64": "i64", "Float64": "f64", "Cdouble": "f64", "Cvoid": "void", "Nothing": "void",
+            "Float32": "f32", "UInt32": "u32", "UInt64": "u64", "Csize_t": "u64"}[t]
+
+
+def _split_top(s: str):
+    """Split at top-level commas (Julia type parameters nest braces, tuples nest parentheses)."""
+    out, depth, cur = [], 0, ""
+    for ch in s:
+        if ch in "({[":
+            depth += 1
+        elif ch in ")}]":
+            depth -= 1
+        if ch == "," and depth == 0:
+            out.append(cur)
+            cur = ""
+        else:
+            cur += ch
+    if cur.strip():
+        out.append(cur)
+    return [p.strip() for p in out if p.strip()]
+
+
+def _header_prototypes():
+    hdr = open(os.path.join(ROOT, "include", "svgp_mi355x.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", " ", hdr, flags=re.S)
+    hdr = re.sub(r"//[^\n]*", " ", hdr)
+    protos = {}
+    for ret, name, args in re.findall(r"\b(const char\s*\*|svgp_ctx\s*\*|int32_t|int64_t|double|void)\s*(svgp_[a-z_0-9]+)\s*\(([^;{]*?)\)\s*;", hdr, flags=re.S):
+        args = " ".join(args.split())
+        params = [] if args in ("", "void") else [a if (a.rstrip().endswith("*") or "[" in a) else a.rsplit(" ", 1)[0] for a in _split_top(args)]
+        protos[name] = (_c_class(ret), [_c_class(p) for p in params])
+    return protos
+
+
+def _julia_ccalls(src: str):
+    """Every `ccall((:svgp_x, lib), Ret, (Args...), values...)` of the binding: (symbol, line, Ret, [Args], n_values)."""
+    calls = []
+    for mt in re.finditer(r"ccall\(\(:(svgp_[a-z_0-9]+), lib\),", src):
+        i, depth = mt.end(), 1          # inside `ccall(` at depth 1
+        while depth and i < len(src):
+            depth += src[i] in "([{"
+            depth -= src[i] in ")]}"
+            i += 1
+        parts = _split_top(src[mt.end():i - 1])
+        ret, argt, vals = parts[0], parts[1], parts[2:]
+        assert argt.startswith("(") and argt.endswith(")"), argt
+        calls.append((mt.group(1), src.count("\n", 0, mt.start()) + 1, ret, _split_top(argt[1:-1]), len(vals)))
+    return calls
+
+
+def test_every_julia_ccall_matches_its_header_prototype():
+    """the Julia binding cannot be executed in this image, so its 41 `ccall` signatures are linted against
+    include/svgp_mi355x.h: arity, pointer vs integer vs float class and integer width of every argument and of the return type,
+    and as many values as declared argument types.  A Julia `Int` (64 bit) passed where the header says int32_t - or the reverse -
+    corrupts the argument registers silently; this keeps the count of such mismatches at zero."""
+    protos = _header_prototypes()
+    assert set(protos) == set(_ffi.SYMBOLS), set(protos) ^ set(_ffi.SYMBOLS)
+    src = open(os.path.join(ROOT, "integration", "julia", "src", "SVGPMI355X.jl")).read()
+    calls = _julia_ccalls(src)
+    assert len(calls) >= 41
+    bad = []
+    for sym, line, ret, argt, nvals in calls:
+        want_ret, want_args = protos[sym]
+        got_ret, got_args = _jl_class(ret), [_jl_class(a) for a in argt]
+        if got_ret != want_ret or got_args != want_args or nvals != len(argt):
+            bad.append(f"{sym} (SVGPMI355X.jl:{line}): ccall {got_ret}({', '.join(got_args)}) with {nvals} values; header {want_ret}({', '.join(want_args)})")
+    assert not bad, "\n".join(bad)
+    # the ctypes mirror the GPU tests call through declares the same classes (so what is tested is what Julia passes)
+    lib = _ffi.load_library()
+    cmap = {C.c_int32: "i32", C.c_int64: "i64", C.c_double: "f64", C.c_char_p: "ptr", C.c_void_p: "ptr", None: "void"}
+    for sym, (want_ret, want_args) in protos.items():
+        fn = getattr(lib, sym)
+        if fn.argtypes is None:
+            continue
+        got = [cmap.get(t, "ptr") for t in fn.argtypes]
+        assert got == want_args, (sym, got, want_args)
+        assert cmap.get(fn.restype, "ptr") == want_ret, (sym, fn.restype, want_ret)
