@@ -894,6 +894,17 @@ int32_t svgp_ctx_create(int32_t device_id, void* stream, svgp_ctx** out) {
   if (!c) return SVGP_OOM;
   c->device = device_id;
   { const char* tq = getenv("SVGP_TIMING"); c->timing_on = !(tq && tq[0] == '0'); }
+  {   // chunk pipeline of the value-and-gradient evaluation (ensure_pipe): read ONCE per context
+    const char* e = getenv("SVGP_GRAD_PIPELINE");   // 0 / 1: serial chunks; n >= 2: n buffer sets
+    c->pipe_lanes = e ? atoi(e) : 3;
+    c->pipe_lanes = c->pipe_lanes < 2 ? 1 : (c->pipe_lanes > 4 ? 4 : c->pipe_lanes);
+    const char* st = getenv("SVGP_GRAD_PIPE_STREAMS");
+    c->pipe_streams = st ? atoi(st) : 2;
+    c->pipe_streams = c->pipe_streams < 1 ? 1 : (c->pipe_streams > 2 ? 2 : c->pipe_streams);
+    if (c->pipe_streams > c->pipe_lanes) c->pipe_streams = c->pipe_lanes;
+    const char* pr = getenv("SVGP_GRAD_PIPE_PRIO");   // -1 / 0 / 1: lowest / default / highest stream priority for the strips' streams
+    c->pipe_prio = pr ? atoi(pr) : 0;
+  }
   if (hipSetDevice(device_id) != hipSuccess) { delete c; return SVGP_HIP_ERROR; }
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device_id) == hipSuccess) c->num_cus = prop.multiProcessorCount;
@@ -943,6 +954,12 @@ int32_t svgp_ctx_destroy(svgp_ctx* c) {
   if (c->stream2) { (void)hipStreamSynchronize(c->stream2); (void)hipStreamDestroy(c->stream2); }
   if (c->kuf_buf) (void)hipFree(c->kuf_buf);
   if (c->ext_g) (void)hipFree(c->ext_g);
+  for (auto& st : c->pst)
+    if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
+  if (c->ev_pipe_prep) (void)hipEventDestroy(c->ev_pipe_prep);
+  if (c->pwork) (void)hipFree(c->pwork);
+  if (c->pcounter) (void)hipFree(c->pcounter);
+  if (c->pmom) (void)hipFree(c->pmom);
   if (c->gws) { c->gws->release(); delete c->gws; }
   for (auto& e : c->ev)
     if (e) (void)hipEventDestroy(e);
@@ -1407,6 +1424,68 @@ int grad_workspace(svgp_ctx* ctx, svgp_model* m, int64_t len, GradWs** out) {
   return SVGP_OK;
 }
 
+// ---- chunk pipeline of a value-and-gradient evaluation (round 5) -----------------------------------------------
+// A batch of more than one chunk used to run strictly serially on one stream: strips(k) [MFMA, ragged end: the last 13 % of a launch
+// run one workgroup per CU] -> point gradients -> kernel-gradient reductions(k) [f64 VALU, no MFMA] -> SYRK(k) [MFMA] -> strips(k + 1)
+// [starts in its MFMA-free pre-generation] ...  Now the per-chunk arrays (A, P point-major, g_mu | g_v, the point-gradient partials)
+// exist in `lanes` sets; the strips + point gradients of chunk k run on a pipeline stream (chunk k on stream k mod `streams`), the
+// consumers of chunk k (reductions, sum5, SYRK) on the main stream behind ev_strips[lane], and the strips of chunk k + lanes wait for
+// ev_done[lane].  Every accumulation (slice buffer, row partials, sums) stays on the main stream in chunk order, so the result is
+// bitwise the serial one.
+struct PipeCfg { int lanes = 1, streams = 1, prio = 0; };
+PipeCfg pipe_cfg(const svgp_ctx* ctx) { return PipeCfg{ctx->pipe_lanes, ctx->pipe_streams, ctx->pipe_prio}; }
+
+int ensure_pipe(svgp_ctx* ctx, GradWs* w, const svgp_model* m, const PipeCfg& pc, size_t work_bytes, size_t nc) {
+  const size_t es = m->es;
+  for (int q = 0; q < pc.streams; ++q) {
+    if (ctx->pst[q]) continue;
+    int least = 0, greatest = 0;
+    if (pc.prio != 0 && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && least != greatest)
+      HIPC(ctx, hipStreamCreateWithPriority(&ctx->pst[q], hipStreamNonBlocking, pc.prio < 0 ? least : greatest));
+    else
+      HIPC(ctx, hipStreamCreateWithFlags(&ctx->pst[q], hipStreamNonBlocking));
+  }
+  if (!ctx->ev_pipe_prep) HIPC(ctx, hipEventCreateWithFlags(&ctx->ev_pipe_prep, kSyncEvent));
+  if (pc.streams > 1) {   // the second pipeline stream's strips: their own scratch strips, queue head and moments
+    if (work_bytes > ctx->pwork_bytes) {
+      if (ctx->pwork) (void)hipFree(ctx->pwork);
+      ctx->pwork = nullptr; ctx->pwork_bytes = 0;
+      HIPC(ctx, hipMalloc(&ctx->pwork, work_bytes));
+      ctx->pwork_bytes = work_bytes;
+    }
+    if (nc > ctx->pmom_cap) {
+      if (ctx->pmom) (void)hipFree(ctx->pmom);
+      ctx->pmom = nullptr; ctx->pmom_cap = 0;
+      HIPC(ctx, hipMalloc(&ctx->pmom, 2 * nc * sizeof(double)));
+      ctx->pmom_cap = nc;
+    }
+    if (!ctx->pcounter) HIPC(ctx, hipMalloc(&ctx->pcounter, 64));
+  }
+  if (w->lanes.empty()) {
+    GradWs::Lane l0;
+    l0.At = w->At; l0.Pt = w->Pt; l0.gmu = w->gmu; l0.gv = w->gv; l0.partial5 = w->partial5;
+    w->lanes.push_back(l0);
+  }
+  const size_t mn = size_t(w->Mp) * size_t(w->nc) * es;
+  while (int(w->lanes.size()) < pc.lanes) {
+    GradWs::Lane l;
+    struct { void** p; size_t b; bool zero; } req[] = {
+        {&l.At, mn, true}, {&l.Pt, mn, true}, {&l.gmu, 2 * size_t(w->nc) * es + 256, false}, {(void**)&l.partial5, size_t(w->part5_strips) * 5 * 8, false}};
+    for (auto& r : req) {
+      if (hipMalloc(r.p, r.b) != hipSuccess) return fail(ctx, SVGP_OOM, "hipMalloc failed for the gradient pipeline");
+      w->all.push_back(*r.p);
+      if (r.zero) HIPC(ctx, hipMemsetAsync(*r.p, 0, r.b, ctx->stream));   // read beyond the written points of a short last chunk (against g_v = 0)
+    }
+    l.gv = static_cast<char*>(l.gmu) + size_t(w->nc) * es;
+    w->lanes.push_back(l);
+  }
+  for (GradWs::Lane& l : w->lanes) {
+    if (!l.ev_strips) HIPC(ctx, hipEventCreateWithFlags(&l.ev_strips, kSyncEvent));
+    if (!l.ev_done) HIPC(ctx, hipEventCreateWithFlags(&l.ev_done, kSyncEvent));
+  }
+  return SVGP_OK;
+}
+
 }  // namespace
 
 namespace {
@@ -1452,6 +1531,9 @@ int grad_enqueue(svgp_ctx* ctx, svgp_model* m, const svgp_data* data, int64_t of
   // a failure between the fork and the join of the segmented strips leaves work on the second stream that the main stream never
   // waited for: drain it, so that the next call on this context cannot meet it in the shared scratch
   if (rc != SVGP_OK && ctx->overlapped && ctx->stream2) (void)hipStreamSynchronize(ctx->stream2);
+  if (rc != SVGP_OK && ctx->pipelined)   // likewise the chunk pipeline's streams
+    for (hipStream_t st : ctx->pst)
+      if (st) (void)hipStreamSynchronize(st);
   return rc;
 }
 
@@ -1608,20 +1690,58 @@ int grad_enqueue_impl(svgp_ctx* ctx, svgp_model* m, const svgp_data* data, int64
   KCHECK(ctx, "grad prep");
   if (gop.on) HIPC(ctx, hipEventRecord(ctx->ev_R, s));   // R is final: the segmented strips' closing launch (phase 3) may run
   launch_linv_t_gemv(dt, s, w->LinvRM, m->mp, Mp, w->alpha, w->gemv_part);
-  for (int64_t c0 = 0; c0 < len; c0 += nc) {
+  // the strips' scratch (the A strip and, beside it, the Kuf strip) and the chunk's moments, sized for every chunk of the call BEFORE
+  // anything of the loop is enqueued (ensure_scratch may reallocate): the full chunks and the shorter last one may plan differently
+  auto chunk_plan = [&](int64_t clen, int& nt, int& grid, int64_t& nstrips) {
+    const StripPlan plan = strip_plan_single(dt, Mp, clen, ctx->num_cus);
+    nt = plan.grid ? plan.nt : plan.nt_tail;
+    grid = plan.grid ? plan.grid : plan.grid_tail;
+    nstrips = plan.grid ? plan.nstrips : plan.nstrips_tail;
+  };
+  size_t wb_max = 0;
+  const int64_t nchunks = (len + nc - 1) / nc;
+  for (int64_t clen : {std::min(len, nc), len - (nchunks - 1) * nc}) {
+    int nt, grid; int64_t nstrips;
+    chunk_plan(clen, nt, grid, nstrips);
+    wb_max = std::max(wb_max, 2 * strip_work_bytes(dt, Mp, nt, grid));
+    if (nstrips > w->part5_strips) return fail(ctx, SVGP_HIP_ERROR, "internal: strip partial buffer too small");
+  }
+  rc = ensure_scratch(ctx, wb_max, size_t(nc));
+  if (rc) return rc;
+  // chunk pipeline (ensure_pipe): needs the post form of the point gradients (the in-kernel forms write per-strip partials the lanes do not hold)
+  static const int kg_overlap = [] { const char* e = getenv("SVGP_KGRAD_OVERLAP"); return e ? atoi(e) : 0; }();
+  const PipeCfg pc = pipe_cfg(ctx);
+  const bool pipe = !gop.on && post && !kg_overlap && nchunks >= 2 && pc.lanes >= 2;
+  ctx->pipelined = pipe;
+  if (pipe) {
+    rc = ensure_pipe(ctx, w, m, pc, wb_max, size_t(nc));
+    if (rc) return rc;
+    HIPC(ctx, hipEventRecord(ctx->ev_pipe_prep, s));   // R, alpha, the cleared accumulators: everything the strips read
+  }
+  for (int64_t c0 = 0, kc = 0; c0 < len; c0 += nc, ++kc) {
     const int64_t clen = (len - c0 < nc) ? len - c0 : nc;
     const int64_t ncp = (clen + 127) / 128 * 128;
     // forward strips + likelihood gradients + phase 3 in ONE launch: leaves A, P point-major and g_mu, g_v of the chunk
-    const StripPlan plan = strip_plan_single(dt, Mp, clen, ctx->num_cus);
-    const int nt = plan.grid ? plan.nt : plan.nt_tail, grid = plan.grid ? plan.grid : plan.grid_tail;
-    const int64_t nstrips = plan.grid ? plan.nstrips : plan.nstrips_tail;
-    rc = ensure_scratch(ctx, 2 * strip_work_bytes(dt, Mp, nt, grid), size_t(nc));   // the A strip and, beside it, the Kuf strip; the chunk's moments
-    if (rc) return rc;
-    if (nstrips > w->part5_strips) return fail(ctx, SVGP_HIP_ERROR, "internal: strip partial buffer too small");
-    HIPC(ctx, hipMemsetAsync(w->gmu, 0, 2 * size_t(w->nc) * es, s));   // g_mu | g_v, w->nc apart (the SYRK reads g_v over the padded chunk)
+    int nt, grid; int64_t nstrips;
+    chunk_plan(clen, nt, grid, nstrips);
+    // this chunk's buffer set and the stream of its strips (serial path: lane 0 = the workspace's own arrays, the main stream)
+    const int lane = pipe ? int(kc % pc.lanes) : 0, pq = pipe ? int(kc % pc.streams) : 0;
+    GradWs::Lane L;
+    if (pipe) L = w->lanes[size_t(lane)];
+    else { L.At = w->At; L.Pt = w->Pt; L.gmu = w->gmu; L.gv = w->gv; L.partial5 = w->partial5; }
+    hipStream_t ss = pipe ? ctx->pst[pq] : s;
+    if (pipe) {
+      if (kc < pc.streams) HIPC(ctx, hipStreamWaitEvent(ss, ctx->ev_pipe_prep, 0));
+      if (kc >= pc.lanes) HIPC(ctx, hipStreamWaitEvent(ss, L.ev_done, 0));   // the lane's previous chunk has been consumed
+    }
+    HIPC(ctx, hipMemsetAsync(L.gmu, 0, 2 * size_t(w->nc) * es, ss));   // g_mu | g_v, w->nc apart (the SYRK reads g_v over the padded chunk)
     LikParams lpc{};
     StripArgs a = gop.on ? gseg.a : strip_args(c0, clen, lpc);
     if (gop.on) lpc = lpc_seg;
+    if (!gop.on) {
+      a.At_out = L.At; a.Pt_out = L.Pt; a.gmu_out = L.gmu; a.gv_out = L.gv; a.part5 = L.partial5;
+      if (pipe && pq == 1) { a.work = ctx->pwork; a.counter = ctx->pcounter; a.mom_mu = ctx->pmom; a.mom_var = ctx->pmom + ctx->pmom_cap; }
+    }
     if (gop.on) {   // (single chunk) the segments are on the second stream already; the closing launch (phase 2 + 3) waits for R and alpha,
                     // and the main stream joins before the point gradients
       hipStream_t s2 = ctx->stream2;
@@ -1647,21 +1767,24 @@ int grad_enqueue_impl(svgp_ctx* ctx, svgp_model* m, const svgp_data* data, int64
       HIPC(ctx, hipEventRecord(ctx->ev_join, s2));
       HIPC(ctx, hipStreamWaitEvent(s, ctx->ev_join, 0));
     } else {
-      HIPC(ctx, hipMemsetAsync(ctx->counter, 0, sizeof(unsigned), s));
-      launch_strip_grad(dt, s, a, nt, grid, nstrips, post);
+      HIPC(ctx, hipMemsetAsync(a.counter, 0, sizeof(unsigned), ss));
+      launch_strip_grad(dt, ss, a, nt, grid, nstrips, post);
       KCHECK(ctx, "strip (value and gradient)");
     }
     int n5 = int(nstrips);   // rows of partial5: per strip (in-kernel forms) or per 256-point block (post)
     if (post) {
-      launch_point_grads(dt, s, lpc, a.mom_mu, a.mom_var, a.y, off + c0, clen, scale, n_global_dev, gc.num_data, w->gmu, w->gv, w->partial5);
+      launch_point_grads(dt, ss, lpc, a.mom_mu, a.mom_var, a.y, off + c0, clen, scale, n_global_dev, gc.num_data, L.gmu, L.gv, L.partial5);
       KCHECK(ctx, "point gradients");
       n5 = point_grad_blocks(clen);
+    }
+    if (pipe) {   // the consumers of this chunk: on the main stream, behind the chunk's strips
+      HIPC(ctx, hipEventRecord(L.ev_strips, ss));
+      HIPC(ctx, hipStreamWaitEvent(s, L.ev_strips, 0));
     }
     // Knob (off): the kernel-gradient reductions (f64 VALU, latency-bound, no MFMA) on the second stream BESIDE the SYRK
     // (MFMA-bound); both only read this chunk's A / P / g, the join comes before the next chunk's strips overwrite them.
     // Measured and not adopted: H 97.8-98.3 vs 98.2-98.4 ms, C5 16.5-16.6 vs 16.6-16.7 ms (same box) - the SYRK's 504
     // workgroups leave kgrad no room to run beside them.
-    static const int kg_overlap = [] { const char* e = getenv("SVGP_KGRAD_OVERLAP"); return e ? atoi(e) : 0; }();
     hipStream_t sk = s;
     if (kg_overlap) {
       rc = ensure_stream2(ctx);
@@ -1672,24 +1795,25 @@ int grad_enqueue_impl(svgp_ctx* ctx, svgp_model* m, const svgp_data* data, int64
     }
     int64_t ksl = ((clen + w->ns_uf - 1) / w->ns_uf + 127) / 128 * 128;
     if (a_in_strips) launch_apart_reduce(sk, w->apart, int(nstrips), Mp, w->rp_uf + Mp);   // slot 1 of slice 0 of rp_uf
-    launch_kgrad(dt, sk, kp, m->zs, Mp, data->x, data->ldx, off + c0, 0, clen, clen, w->Pt, (a_in_strips || a_from_k) ? nullptr : w->At,
-                 w->gmu, w->gv, w->alpha, ksl, w->ns_uf, w->rp_uf, w->sp_uf, a_from_k ? 1 : 0);
+    launch_kgrad(dt, sk, kp, m->zs, Mp, data->x, data->ldx, off + c0, 0, clen, clen, L.Pt, (a_in_strips || a_from_k) ? nullptr : L.At,
+                 L.gmu, L.gv, w->alpha, ksl, w->ns_uf, w->rp_uf, w->sp_uf, a_from_k ? 1 : 0);
     KCHECK(ctx, "kgrad uf");
     if (kg_overlap) HIPC(ctx, hipEventRecord(ctx->ev_join, sk));
-    launch_sum5(s, w->partial5, n5, w->sums);
+    launch_sum5(s, L.partial5, n5, w->sums);
     int64_t sl = ((ncp + ns_syrk - 1) / ns_syrk + 15) / 16 * 16;   // as even as the 16-point k-step allows
     // W (+)= A diag(2 g_v) A' (lower tiles, split-K slices): the first chunk overwrites, so the slice buffer needs no zeroing
     if (uniform_w) {
       // g_v is the same for every point (Gaussian: -scale / (2 sigma^2)): the unweighted loop, the weight applied to the accumulators.
       // Columns of the chunk's last strip beyond its last point hold the replicated last point: zero them up to the k-step boundary
       const int64_t n16 = (clen + 15) / 16 * 16;
-      if (n16 > clen) HIPC(ctx, hipMemsetAsync(static_cast<char*>(w->At) + size_t(clen) * size_t(Mp) * es, 0, size_t(n16 - clen) * size_t(Mp) * es, s));
-      launch_syrk_uniform(dt, s, w->At, -0.5 / lp.sigma2, scale, n_global_dev, gc.num_data, 2.0, Mp, n16, sl, ns_syrk, w->G1, c0 == 0 ? 1 : 0);
+      if (n16 > clen) HIPC(ctx, hipMemsetAsync(static_cast<char*>(L.At) + size_t(clen) * size_t(Mp) * es, 0, size_t(n16 - clen) * size_t(Mp) * es, s));
+      launch_syrk_uniform(dt, s, L.At, -0.5 / lp.sigma2, scale, n_global_dev, gc.num_data, 2.0, Mp, n16, sl, ns_syrk, w->G1, c0 == 0 ? 1 : 0);
     } else {
-      launch_gemm_pm(dt, s, w->At, w->At, w->gv, 2.0, Mp, ncp, sl, ns_syrk, w->G1, c0 == 0 ? 1 : 0);
+      launch_gemm_pm(dt, s, L.At, L.At, L.gv, 2.0, Mp, ncp, sl, ns_syrk, w->G1, c0 == 0 ? 1 : 0);
     }
     KCHECK(ctx, "syrk");
     if (kg_overlap) HIPC(ctx, hipStreamWaitEvent(s, ctx->ev_join, 0));
+    if (pipe) HIPC(ctx, hipEventRecord(L.ev_done, s));
   }
   if (gc.ext_gmu) launch_add_f64(s, w->sums, gc.ext_sum_e);   // sums[0] = sum E: the host's, before any collective
   TREC(ctx, ctx->ev[2], s);

@@ -41,6 +41,15 @@ struct svgp_ctx {
   void* work_seg = nullptr;    size_t work_seg_bytes = 0;   // per-strip scratch of the segmented strips
   void* hstage = nullptr;      size_t hstage_bytes = 0;     // pinned host staging of the gradient read-back (api.hip: grad_finish)
   hipEvent_t ev_piece[8] = {};                               // one behind each piece of that read-back
+  // chunk pipeline of a value-and-gradient evaluation (api.hip: grad_enqueue_impl): up to two streams that carry the chunks' strips
+  // beside the main stream's SYRK / kernel-gradient launches of the chunks before; the second one has its own scratch, queue head, moments
+  hipStream_t pst[2] = {nullptr, nullptr};
+  hipEvent_t ev_pipe_prep = nullptr;
+  void* pwork = nullptr;       size_t pwork_bytes = 0;
+  unsigned* pcounter = nullptr;
+  double* pmom = nullptr;      size_t pmom_cap = 0;
+  bool pipelined = false;      // the last value-and-gradient call enqueued work on pst[]
+  int pipe_lanes = 3, pipe_streams = 2, pipe_prio = 0;   // SVGP_GRAD_PIPELINE / _PIPE_STREAMS / _PIPE_PRIO at context creation
   void* kuf_buf = nullptr;    size_t kuf_bytes = 0;
   double* ext_g = nullptr;    size_t ext_cap = 0;           // [2][ext_cap] point gradients of a host-evaluated likelihood
   struct GradWs* gws = nullptr;  // gradient workspace, cached by problem shape
@@ -72,10 +81,23 @@ struct GradWs {
          *invl_d = nullptr, *scal_out = nullptr, *avec = nullptr, *apart = nullptr, *kred = nullptr, *gemv_part = nullptr;
   int64_t part5_strips = 0;
   size_t rp_uf_b = 0, sp_uf_b = 0, rp_uu_b = 0, sp_uu_b = 0, g_b = 0;
+  // chunk pipeline: buffer sets ("lanes") of the per-chunk arrays; lane 0 is {At, Pt, gmu, gv, partial5} above, the others are
+  // allocated the first time a call has more than one chunk
+  struct Lane {
+    void *At = nullptr, *Pt = nullptr, *gmu = nullptr, *gv = nullptr;
+    double* partial5 = nullptr;
+    hipEvent_t ev_strips = nullptr, ev_done = nullptr;   // the chunk's A / P / g are complete; its SYRK and reductions have read them
+  };
+  std::vector<Lane> lanes;
   void release() {
     for (void* p : all)
       if (p) (void)hipFree(p);
     all.clear();
+    for (Lane& l : lanes) {
+      if (l.ev_strips) (void)hipEventDestroy(l.ev_strips);
+      if (l.ev_done) (void)hipEventDestroy(l.ev_done);
+    }
+    lanes.clear();
   }
 };
 

@@ -137,6 +137,9 @@ extern "C" int svgp_debug_potf2_stamps(unsigned long long* out) {
 // v_rsq_f32 (1 ulp) as it is; fp64 keeps the Newton refinements (v_rsq_f64 delivers ~26 bits).  No per-step selects: an X
 // lane starts from delta_jc and stays exactly zero above the diagonal; the diagonal entry is t r = sqrt(t) like any other
 // entry of its column; L rows hold unused garbage right of the diagonal.
+#ifndef SVGP_F16_BULK_SGPR
+#define SVGP_F16_BULK_SGPR 0
+#endif
 #ifndef SVGP_F16_DPP
 #define SVGP_F16_DPP 1   // 0: v_readlane broadcasts (A/B and bisection builds)
 #endif
@@ -239,8 +242,14 @@ __device__ __forceinline__ void factor16_bulk(T (&row)[16], T (&x)[16], T (&n)[2
   if constexpr (K < J || K < PivotTail<T>::NST) {
     if constexpr (K < PivotTail<T>::NST) tail.template stage<J, K>(row, x, bad);
     if constexpr (K < J && J + 1 < 16) {
+#if SVGP_F16_BULK_SGPR   // experiment (round 5): the bulk terms' broadcast through an SGPR - two v_readlane + two plain FMAs instead of two DPP FMACs
+      const T bc = readlane_t(row[K], J + 1);
+      n[K & 1] = fma(-bc, row[K], n[K & 1]);
+      m[K & 1] = fma(-bc, x[K], m[K & 1]);
+#else
       fmac_bcast<J + 1, false>(n[K & 1], row[K], row[K]);   // n -= L[J+1][K] * row[K]
       fmac_bcast<J + 1, false>(m[K & 1], row[K], x[K]);     // m -= L[J+1][K] * x[K]
+#endif
     }
     __builtin_amdgcn_sched_barrier(0);
     factor16_bulk<T, J, K + 1>(row, x, n, m, tail, bad);
