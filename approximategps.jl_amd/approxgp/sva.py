@@ -105,7 +105,11 @@ def _decline_if_small(sva, lfx, y, small_problems, want_grad, ctx=None):
         return
     if small_problems != "decline":
         raise ValueError('small_problems must be "run" or "decline"')
-    if ctx is not None and ctx.comm_info()[0] > 1:
+    # ctx=None means the default context (elbo / elbo_and_gradient resolve it after this check): a communicator initialised on THAT
+    # context counts too (with it skipped, one rank could decline while its peers sat in the all-reduce).  Peeked at, never
+    # created here: the rule itself must work without a GPU.
+    c = ctx if ctx is not None else _ffi._default_ctx
+    if c is not None and c.comm_info()[0] > 1:
         return
     z = np.asarray(sva.fz.x)
     d, M = (1, z.shape[0]) if z.ndim == 1 else z.shape

@@ -16,6 +16,7 @@
 #include "../../include/svgp_mi355x.h"
 #include "ctx.hpp"
 #include "kernels.hpp"
+#include "knobs.hpp"
 #include "lik.hpp"
 
 using namespace svgp;
@@ -23,9 +24,9 @@ using namespace svgp;
 // Events between the context's own streams and for device-side timing need no system-scope fence (the cache write-back and invalidation
 // that makes device memory visible to the HOST): a record then costs the stream ~1 instead of ~5 us (profiles/round4/minibatch_step.md
 // section 7).  Everything the host reads comes through hipMemcpy + a stream / event synchronisation of DEFAULT events (ev_piece).
-// SVGP_EVENT_FENCE=1 (process-wide, A/B): default events everywhere.
+// SVGP_EVENT_FENCE=1 (experiments build, process-wide, A/B): default events everywhere.
 inline unsigned event_flags(bool timing) {
-  static const bool fence = [] { const char* e = getenv("SVGP_EVENT_FENCE"); return e && e[0] == '1'; }();
+  static const bool fence = exp_int("SVGP_EVENT_FENCE", 0) == 1;   // experiments build: A/B
   return (timing ? 0u : unsigned(hipEventDisableTiming)) | (fence ? 0u : unsigned(hipEventDisableSystemFence));
 }
 #define kSyncEvent event_flags(false)
@@ -276,11 +277,11 @@ int ensure_stream2(svgp_ctx* ctx) {
   if (ctx->stream2) return SVGP_OK;
   // the second stream carries work that runs BESIDE the main stream's (the ragged tail of a large batch, the segmented strips beside
   // the factorisation): lowest priority, so that where both have workgroups to dispatch the main stream's serial chain goes first
-  static const int prio_knob = [] { const char* e = getenv("SVGP_STREAM2_LOW_PRIO"); return e ? atoi(e) : 1; }();   // A/B knob
+  static const int prio_knob = exp_int("SVGP_STREAM2_LOW_PRIO", 1);   // A/B knob (experiments build)
   int least = 0, greatest = 0;
   // A/B knob (round 4): keep SVGP_STREAM2_RESERVE CUs out of the second stream's reach (hipExtStreamCreateWithCUMask), so that the
   // factorisation's launches always find free CUs beside the segmented strips
-  static const int reserve = [] { const char* e = getenv("SVGP_STREAM2_RESERVE"); return e ? atoi(e) : 0; }();
+  static const int reserve = exp_int("SVGP_STREAM2_RESERVE", 0);
   if (reserve > 0 && reserve < ctx->num_cus) {
     std::vector<uint32_t> mask(size_t((ctx->num_cus + 31) / 32), 0xffffffffu);
     for (int c = 0; c < reserve; ++c) {   // spread the reserved CUs: one every num_cus / reserve
@@ -304,11 +305,10 @@ int ensure_stream2(svgp_ctx* ctx) {
 constexpr size_t kSegSplitSlots = 512, kSegSplitPart = 384, kSegSplitDoubles = kSegSplitSlots * kSegSplitPart + kSegSplitSlots;
 // S = the largest power of two with S <= nP and nstrips S <= kSegSplitSlots - if that is at least 4: two workgroups per strip do not
 // pay for the extra launch (measured, profiles/round4/minibatch_step.md: 8192 points / M = 1024 f64 forward 0.84 -> 0.87 ms, gradient
-// 2.29 -> 2.28; 4096 points 0.81 -> 0.78 / 2.13 -> 2.00; 1024 points 0.80 -> 0.71 / 2.05 -> 1.78).  SVGP_SEG_SPLIT=0 (per call): never split
-int seg_split_factor(int nP, int64_t nstrips) {
-  const char* sq = getenv("SVGP_SEG_SPLIT");
+// 2.29 -> 2.28; 4096 points 0.81 -> 0.78 / 2.13 -> 2.00; 1024 points 0.80 -> 0.71 / 2.05 -> 1.78).  SVGP_SEG_SPLIT=0 (at context creation): never split
+int seg_split_factor(const svgp_ctx* ctx, int nP, int64_t nstrips) {
   int S = 1;
-  if (!(sq && atoi(sq) == 0))
+  if (ctx->kn.seg_split)
     while (2 * S <= nP && int64_t(2 * S) * nstrips <= int64_t(kSegSplitSlots)) S *= 2;
   return S >= 4 ? S : 1;
 }
@@ -467,13 +467,11 @@ struct OverlapPlan { bool on = false; int nt = 0, grid = 0; int64_t nstrips = 0,
 
 OverlapPlan overlap_plan(const svgp_ctx* ctx, const svgp_model* m, int64_t len, const StripOuts& o) {
   OverlapPlan p;
-  const char* e = getenv("SVGP_OVERLAP");   // read per call (the tests toggle it inside one process); default: on
-  if (e && atoi(e) == 0) return p;
+  if (!ctx->kn.overlap) return p;   // SVGP_OVERLAP=0 at context creation
   const int nP = int(m->Mp / 128);
   // measured (profiles/round4/overlap.md, f64, one round of strips): M = 256 +5 %, 512 0..-4 %, 1024 -9..-11 %, 2048 -19 %: the
   // 2 nP extra launches and the chain's slowdown beside the strips are paid back from about six panels on
-  const char* q = getenv("SVGP_OVERLAP_MIN_PANELS");   // per call, like SVGP_OVERLAP
-  const int min_panels = q ? atoi(q) : 5;
+  const int min_panels = ctx->kn.overlap_min_panels;   // 5 (SVGP_OVERLAP_MIN_PANELS in the experiments build)
   if (m->desc.parametrization != SVGP_NONCENTERED || m->d > 16 || nP < 2 || nP > potrf_max_row_events()) return p;
   if (o.A || o.C || o.At || o.Ct) return p;
   const StripPlan sp = strip_plan_single(m->dtype, m->Mp, len, ctx->num_cus);
@@ -481,6 +479,9 @@ OverlapPlan overlap_plan(const svgp_ctx* ctx, const svgp_model* m, int64_t len, 
   p.nt = sp.grid ? sp.nt : sp.nt_tail;
   p.nstrips = sp.grid ? sp.nstrips : sp.nstrips_tail;
   p.grid = sp.grid ? sp.grid : sp.grid_tail;
+  // the segmented kernels exist for 32- / 64-point strips (f64) and 32 / 64 / 128 (f32) on 256 threads (launch_strip_seg); a wider plan -
+  // only an experiments build can ask for one (SVGP_STRIP_NT=128) - keeps the one-launch path
+  if (p.nt > (m->dtype == SVGP_F64 ? 64 : 128)) return p;
   if (p.nstrips <= p.grid && nP < min_panels) return p;   // one round: pays from about five panels on (multi-round heads: below)
   p.head_points = len;
   if (p.nstrips > p.grid) {
@@ -489,11 +490,10 @@ OverlapPlan overlap_plan(const svgp_ctx* ctx, const svgp_model* m, int64_t len, 
     // intact), the two joined before the expectation.  The head's phase 1 fills the chip while the chain would have had it alone.
     // MEASURED, default OFF (profiles/round4/overlap.md): C5 (4 rounds of fp32 strips) 5.02 -> 4.91 ms wall, C2 (3 rounds, M = 512) 1.339
     // -> 1.340, H32 / C3 unchanged - the head's panel launches are long (a full round of full-width strips) and the factorisation
-    // waits for their CUs (C5 prep 0.48 -> 0.84 ms), which gives back most of what the head gains.  SVGP_OVERLAP_HEAD=1 enables it.
-    const char* hq = getenv("SVGP_OVERLAP_HEAD");   // per call
-    const char* mq = getenv("SVGP_OVERLAP_HEAD_MIN_PANELS");
+    // waits for their CUs (C5 prep 0.48 -> 0.84 ms), which gives back most of what the head gains.  SVGP_OVERLAP_HEAD=1 enables it
+    // in the experiments build; the product build never takes this branch.
     const int64_t rounds = (p.nstrips + p.grid - 1) / p.grid;
-    if (!(hq && atoi(hq) == 1) || !sp.grid || nP < (mq ? atoi(mq) : 4) || rounds > 8) return OverlapPlan{};
+    if (!ctx->kn.overlap_head || !sp.grid || nP < ctx->kn.overlap_head_min_panels || rounds > 8) return OverlapPlan{};
     p.nstrips = p.grid;
     p.head_points = int64_t(p.grid) * p.nt;
   }
@@ -572,8 +572,7 @@ int seg_prepare_forward(svgp_ctx* ctx, svgp_model* m, const void* x, int64_t ldx
   const size_t wb1 = strip_work_bytes(m->dtype, m->Mp, op.nt, int(op.nstrips)), wb = 2 * wb1;
   // Checkpointed phase 2: bitwise-tested, MEASURED, default OFF (profiles/round4/overlap.md): the factorisation slows by what the
   // strips' extra work beside it occupies (16 384 / 1024 f64: prep 0.60 -> 0.78 ms, rest 0.38 -> 0.23: 1.046 -> 1.06-1.07 ms; M = 2048
-  // 1.94 -> 2.11).  The chain is latency-bound and every CU a strip launch holds delays it.  SVGP_OVERLAP_P2CKPT=1 enables it.
-  const char* ckq = getenv("SVGP_OVERLAP_P2CKPT");   // per call; A/B knob
+  // 1.94 -> 2.11).  The chain is latency-bound and every CU a strip launch holds delays it.  SVGP_OVERLAP_P2CKPT=1 (experiments build) enables it.
   if (wb > ctx->work_seg_bytes) {
     if (ctx->work_seg) (void)hipFree(ctx->work_seg);
     ctx->work_seg = nullptr;
@@ -591,11 +590,11 @@ int seg_prepare_forward(svgp_ctx* ctx, svgp_model* m, const void* x, int64_t ldx
     if (rc) return rc;
   }
   r.ctx = ctx; r.m = m; r.op = op; r.grad = false; r.nP = nP; r.wb1 = wb1; r.head = head;
-  r.ckpt = (ckq && atoi(ckq) == 1) && nP >= 4;
+  r.ckpt = ctx->kn.overlap_p2ckpt && nP >= 4;   // experiments build only
   r.ck[0] = nP / 2; r.ck[1] = (3 * nP) / 4; r.ck[2] = nP;   // phase-2 checkpoints: after panels ck[.] - 1
   // A small batch (fewer strips than workgroup slots; not a segmented head): phase 2 - one panel C_J after the other inside a strip's
   // workgroup - is latency-bound on the few CUs it reaches, and its panels are independent: a closing launch with S workgroups per strip
-  r.split = (r.ckpt || head < len) ? 1 : seg_split_factor(nP, op.nstrips);
+  r.split = (r.ckpt || head < len) ? 1 : seg_split_factor(ctx, nP, op.nstrips);
   StripArgs& a = r.a;
   a.T = m->T; a.U = m->U; a.zs = m->zs; a.mp = m->mp; a.x = x; a.work = ctx->work_seg; a.counter = ctx->counter2;
   a.mom_mu = ctx->mom; a.mom_var = ctx->mom + ctx->mom_cap;
@@ -681,8 +680,9 @@ int elbo_enqueue(svgp_ctx* ctx, svgp_model* m, const svgp_data* data, int64_t of
     if (rc) return rc;
   }
   ctx->overlapped = op.on;
-  const char* dq = getenv("SVGP_OVERLAP_DRY");   // diagnostic: the overlap's prep - reordered, with its row events recorded - but the strips
-  const bool dry = op.on && dq && atoi(dq) == 1;  // behind it as usual: what the events alone cost the chain
+  // (experiments build) diagnostic: the overlap's prep - reordered, with its row events recorded - but the strips behind it as usual:
+  // what the events alone cost the chain
+  const bool dry = op.on && ctx->kn.overlap_dry == 1;
   SegRun seg;
   RowHook hook{seg_row_hook, &seg};
   if (op.on && !dry) {
@@ -884,6 +884,11 @@ int32_t svgp_offload_advice(int64_t n, int64_t M, int32_t d, int32_t /*dtype*/, 
   return svgp_offload_work(n, M, d) >= min_work ? 1 : 0;
 }
 
+#ifdef SVGP_EXPERIMENTS
+// only the experiments build (tools/build_experiments.sh) exports this: tools and tests tell the two libraries apart by it
+int svgp_debug_experiments(void) { return 1; }
+#endif
+
 int32_t svgp_ctx_create(int32_t device_id, void* stream, svgp_ctx** out) {
   if (!out) return SVGP_INVALID_ARG;
   *out = nullptr;
@@ -893,18 +898,8 @@ int32_t svgp_ctx_create(int32_t device_id, void* stream, svgp_ctx** out) {
   svgp_ctx* c = new (std::nothrow) svgp_ctx();
   if (!c) return SVGP_OOM;
   c->device = device_id;
-  { const char* tq = getenv("SVGP_TIMING"); c->timing_on = !(tq && tq[0] == '0'); }
-  {   // chunk pipeline of the value-and-gradient evaluation (ensure_pipe): read ONCE per context
-    const char* e = getenv("SVGP_GRAD_PIPELINE");   // 0 / 1: serial chunks; n >= 2: n buffer sets
-    c->pipe_lanes = e ? atoi(e) : 3;
-    c->pipe_lanes = c->pipe_lanes < 2 ? 1 : (c->pipe_lanes > 4 ? 4 : c->pipe_lanes);
-    const char* st = getenv("SVGP_GRAD_PIPE_STREAMS");
-    c->pipe_streams = st ? atoi(st) : 2;
-    c->pipe_streams = c->pipe_streams < 1 ? 1 : (c->pipe_streams > 2 ? 2 : c->pipe_streams);
-    if (c->pipe_streams > c->pipe_lanes) c->pipe_streams = c->pipe_lanes;
-    const char* pr = getenv("SVGP_GRAD_PIPE_PRIO");   // -1 / 0 / 1: lowest / default / highest stream priority for the strips' streams
-    c->pipe_prio = pr ? atoi(pr) : 0;
-  }
+  read_knobs(c->kn);   // the operational variables (knobs.hpp), once per context
+  c->timing_on = c->kn.timing != 0;
   if (hipSetDevice(device_id) != hipSuccess) { delete c; return SVGP_HIP_ERROR; }
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device_id) == hipSuccess) c->num_cus = prop.multiProcessorCount;
@@ -1314,7 +1309,7 @@ namespace {
 
 // split-K slice count of the SYRK for a chunk of nc points (the rule: grad_workspace)
 int syrk_slices(const svgp_ctx* ctx, const svgp_model* m, int64_t nc) {
-  static const int ns_forced = [] { const char* e = getenv("SVGP_GEMM_PM_SLICES"); return e ? atoi(e) : 0; }();   // tuning knob
+  static const int ns_forced = exp_int("SVGP_GEMM_PM_SLICES", 0);   // tuning knob (experiments build)
   if (ns_forced > 0) return ns_forced;
   const int64_t Mp = m->Mp;
   const int nP = int(Mp / 128), ntiles = nP * (nP + 1) / 2;
@@ -1332,8 +1327,8 @@ int syrk_slices(const svgp_ctx* ctx, const svgp_model* m, int64_t nc) {
 
 // points per chunk of a value-and-gradient evaluation over `len` points (a multiple of 128): the At / Pt buffers hold one chunk
 int64_t grad_chunk_points(int64_t Mp, size_t es, int64_t len) {
-  static const int64_t cap_cols = [] { const char* e = getenv("SVGP_GRAD_CHUNK"); return e ? atoll(e) : 65536ll; }();   // tuning knob
-  static const double cap_bytes = [] { const char* e = getenv("SVGP_GRAD_CHUNK_BYTES"); return e ? atof(e) : 1.0e9; }();
+  static const int64_t cap_cols = exp_ll("SVGP_GRAD_CHUNK", 65536ll);   // tuning knobs (experiments build)
+  static const double cap_bytes = exp_double("SVGP_GRAD_CHUNK_BYTES", 1.0e9);
   int64_t cap = int64_t(cap_bytes / double(Mp * int64_t(es))) / 128 * 128;
   cap = cap < 128 ? 128 : (cap > cap_cols ? cap_cols : cap);
   int64_t nc = (len + 127) / 128 * 128;
@@ -1360,7 +1355,7 @@ int grad_workspace(svgp_ctx* ctx, svgp_model* m, int64_t len, GradWs** out) {
   // and rejected: H 81.9 -> 85-87 ms - the operand re-reads come out of the Infinity Cache at no cost to the MFMA pipe.
   w->nslices = syrk_slices(ctx, m, int64_t(1) << 40);   // the buffer holds the count an unbounded chunk would take: a call's count never exceeds it
   w->rb = grad_rowblocks(m->dtype, m->d, Mp);
-  static const int kg_wg = [] { const char* e = getenv("SVGP_KGRAD_WG_PER_CU"); return e ? atoi(e) : 2; }();   // tuning knob
+  static const int kg_wg = exp_int("SVGP_KGRAD_WG_PER_CU", 2);   // tuning knob (experiments build)
   int nu = (kg_wg * ctx->num_cus + w->rb - 1) / w->rb;
   w->ns_uf = nu < 1 ? 1 : (nu > 256 ? 256 : nu);
   w->ns_uu = 8;
@@ -1433,7 +1428,7 @@ int grad_workspace(svgp_ctx* ctx, svgp_model* m, int64_t len, GradWs** out) {
 // ev_done[lane].  Every accumulation (slice buffer, row partials, sums) stays on the main stream in chunk order, so the result is
 // bitwise the serial one.
 struct PipeCfg { int lanes = 1, streams = 1, prio = 0; };
-PipeCfg pipe_cfg(const svgp_ctx* ctx) { return PipeCfg{ctx->pipe_lanes, ctx->pipe_streams, ctx->pipe_prio}; }
+PipeCfg pipe_cfg(const svgp_ctx* ctx) { return PipeCfg{ctx->kn.pipe_lanes, ctx->kn.pipe_streams, ctx->kn.pipe_prio}; }
 
 int ensure_pipe(svgp_ctx* ctx, GradWs* w, const svgp_model* m, const PipeCfg& pc, size_t work_bytes, size_t nc) {
   const size_t es = m->es;
@@ -1499,6 +1494,7 @@ struct GradCall {
   const double* n_global_dev = nullptr;
   double scale = 1.0, klw = 1.0, num_data = 0.0;
   bool collective = false, centered = false;
+  bool packed = false;   // w->cblk already holds {z_bar | m_bar | packed tril(Lq_bar)} (the collective's all-reduced block)
   int64_t len = 0;
   // host-evaluated likelihood (svgp_elbo_grad_ext): per-point dE/dmu, dE/dv (host, fp64, [len] each) and the host's sum E
   const double *ext_gmu = nullptr, *ext_gv = nullptr;
@@ -1515,7 +1511,7 @@ void gemm_mm(svgp_ctx* ctx, GradWs* w, int dt, hipStream_t s, const void* Xt, co
   int ns = (2 * ctx->num_cus) / (ntiles * (dt == SVGP_F64 ? 2 : 1));   // fill the workgroup slots once (f64: two 128 x 64 halves per tile)
   if (ns > nP) ns = nP;                         // at least 8 k-steps of 16 per slice
   if (ns > w->nslices) ns = w->nslices;         // the scratch is the SYRK's [nslices][Mp][Mp]
-  static const int knob = [] { const char* e = getenv("SVGP_GEMM_MM_SPLITK"); return e ? atoi(e) : 1; }();   // A/B knob
+  static const int knob = exp_int("SVGP_GEMM_MM_SPLITK", 1);   // A/B knob (experiments build)
   if (ns < 2 || !knob) {
     launch_gemm_pm(dt, s, Xt, Yt, nullptr, 1.0, Mp, Mp, Mp, 1, out, 1, flags);
     return;
@@ -1605,18 +1601,16 @@ int grad_enqueue_impl(svgp_ctx* ctx, svgp_model* m, const svgp_data* data, int64
   }
   // Who evaluates the likelihood gradients (strip.hip: kPgPost): round 4 - a small kernel behind the strips, for both likelihood
   // routes; SVGP_GRAD_POST=0 keeps the round-3 in-kernel forms (A/B).  In-kernel fp32 builds also form A g_mu per strip (`apart`).
-  const char* post_env = getenv("SVGP_GRAD_POST");   // read per call: the equivalence test toggles it inside one process
-  const bool post = gop.on || (post_env ? atoi(post_env) != 0 : true);   // the segmented strips exist in the post form only
+  const bool post = gop.on || ctx->kn.grad_post;   // always in the product build; the segmented strips exist in the post form only
   // A g_mu (the data part of m_bar): in-kernel fp32 - per strip inside the strip kernel, so that kgrad streams P only; otherwise
   // kgrad, which evaluates the kernel anyway, sums Kuf g_mu and the tail applies Lk^-1 (one gemv with the explicit inverse): A is
   // then read by the SYRK only (round 3, f64: 0.32 -> 0.2 ms per 65 536-point chunk at M = 1024); SVGP_A_FROM_K=0: kgrad reads A
   // beside P.  (Round-2 three-way A/B, ms: H 97.8 -> 95.4 with the kgrad prefetch alone, 99.0 with the in-strip form; H32 53.6 ->
   // 53.0 -> 52.35; C5 16.25 -> 16.2 -> 15.9; C3 208.3 -> 217.2 -> 209.6.)
-  static const int afk_knob = [] { const char* e = getenv("SVGP_A_FROM_K"); return e ? atoi(e) : 1; }();   // A/B knob
+  static const int afk_knob = exp_int("SVGP_A_FROM_K", 1);   // A/B knob (experiments build)
   // the SYRK's weights 2 g_v are uniform over the points for the built-in Gaussian likelihood (grad.hip: UW) unless a variance was
   // negative and clamped (then that point's g_v differs... it does not: dE/dv = -1 / (2 sigma^2) whatever v) - so: Gaussian, built in
-  const char* uw_env = getenv("SVGP_SYRK_UNIFORM");   // A/B knob, read per call (the equivalence test toggles it)
-  const bool uniform_w = m->desc.likelihood == SVGP_LIK_GAUSSIAN && !gc.ext_gmu && m->gh_n == 0 && (!uw_env || atoi(uw_env) != 0);
+  const bool uniform_w = m->desc.likelihood == SVGP_LIK_GAUSSIAN && !gc.ext_gmu && m->gh_n == 0 && ctx->kn.syrk_uniform;   // (knob: experiments build)
   const bool a_in_strips = (dt == SVGP_F32) && !post;
   const bool a_from_k = !a_in_strips && afk_knob;
   // the strips' arguments for the chunk [c0, c0 + clen) (scratch / moment pointers: read after the ensure_scratch of the caller)
@@ -1709,14 +1703,18 @@ int grad_enqueue_impl(svgp_ctx* ctx, svgp_model* m, const svgp_data* data, int64
   rc = ensure_scratch(ctx, wb_max, size_t(nc));
   if (rc) return rc;
   // chunk pipeline (ensure_pipe): needs the post form of the point gradients (the in-kernel forms write per-strip partials the lanes do not hold)
-  static const int kg_overlap = [] { const char* e = getenv("SVGP_KGRAD_OVERLAP"); return e ? atoi(e) : 0; }();
+  static const int kg_overlap = exp_int("SVGP_KGRAD_OVERLAP", 0);   // experiments build
   const PipeCfg pc = pipe_cfg(ctx);
-  const bool pipe = !gop.on && post && !kg_overlap && nchunks >= 2 && pc.lanes >= 2;
-  ctx->pipelined = pipe;
-  if (pipe) {
-    rc = ensure_pipe(ctx, w, m, pc, wb_max, size_t(nc));
+  const bool pipe_any = !gop.on && post && !kg_overlap && nchunks >= 2 && pc.lanes >= 2;
+  const bool pipe = pipe_any && ctx->kn.pipe_mode != 2;   // mode 1: strips(k + 1) on a pipeline stream beside the consumers of chunk k
+  const bool trail = pipe_any && ctx->kn.pipe_mode == 2;  // mode 2: everything on the main stream but kgrad(k), which trails on a pipeline stream beside SYRK(k) and strips(k + 1)
+  ctx->pipelined = pipe_any;
+  if (pipe_any) {
+    PipeCfg pcc = pc;
+    if (trail) pcc.streams = 1;
+    rc = ensure_pipe(ctx, w, m, pcc, wb_max, size_t(nc));
     if (rc) return rc;
-    HIPC(ctx, hipEventRecord(ctx->ev_pipe_prep, s));   // R, alpha, the cleared accumulators: everything the strips read
+    if (pipe) HIPC(ctx, hipEventRecord(ctx->ev_pipe_prep, s));   // R, alpha, the cleared accumulators: everything the strips read
   }
   for (int64_t c0 = 0, kc = 0; c0 < len; c0 += nc, ++kc) {
     const int64_t clen = (len - c0 < nc) ? len - c0 : nc;
@@ -1725,15 +1723,16 @@ int grad_enqueue_impl(svgp_ctx* ctx, svgp_model* m, const svgp_data* data, int64
     int nt, grid; int64_t nstrips;
     chunk_plan(clen, nt, grid, nstrips);
     // this chunk's buffer set and the stream of its strips (serial path: lane 0 = the workspace's own arrays, the main stream)
-    const int lane = pipe ? int(kc % pc.lanes) : 0, pq = pipe ? int(kc % pc.streams) : 0;
+    const int lane = pipe_any ? int(kc % pc.lanes) : 0, pq = pipe ? int(kc % pc.streams) : 0;
     GradWs::Lane L;
-    if (pipe) L = w->lanes[size_t(lane)];
+    if (pipe_any) L = w->lanes[size_t(lane)];
     else { L.At = w->At; L.Pt = w->Pt; L.gmu = w->gmu; L.gv = w->gv; L.partial5 = w->partial5; }
     hipStream_t ss = pipe ? ctx->pst[pq] : s;
     if (pipe) {
       if (kc < pc.streams) HIPC(ctx, hipStreamWaitEvent(ss, ctx->ev_pipe_prep, 0));
       if (kc >= pc.lanes) HIPC(ctx, hipStreamWaitEvent(ss, L.ev_done, 0));   // the lane's previous chunk has been consumed
     }
+    if (trail && kc >= pc.lanes) HIPC(ctx, hipStreamWaitEvent(s, L.ev_done, 0));   // the reductions of the lane's previous chunk have read P / g
     HIPC(ctx, hipMemsetAsync(L.gmu, 0, 2 * size_t(w->nc) * es, ss));   // g_mu | g_v, w->nc apart (the SYRK reads g_v over the padded chunk)
     LikParams lpc{};
     StripArgs a = gop.on ? gseg.a : strip_args(c0, clen, lpc);
@@ -1752,7 +1751,7 @@ int grad_enqueue_impl(svgp_ctx* ctx, svgp_model* m, const svgp_data* data, int64
       // of MFMA work).  Its output panels are independent: the closing launch runs S workgroups per strip (strip.hip: seg_split).
       // SVGP_SEG_SPLIT=0 (per call): the unsplit launch, whose result is bitwise the serial kernel's (the split one differs in the
       // variance's summation order).
-      const int S = seg_split_factor(nPn, nstrips);
+      const int S = seg_split_factor(ctx, nPn, nstrips);
       int cgrid = grid;
       if (S > 1) {
         rc = seg_split_setup(ctx, a, S, nstrips);
@@ -1781,11 +1780,15 @@ int grad_enqueue_impl(svgp_ctx* ctx, svgp_model* m, const svgp_data* data, int64
       HIPC(ctx, hipEventRecord(L.ev_strips, ss));
       HIPC(ctx, hipStreamWaitEvent(s, L.ev_strips, 0));
     }
+    if (trail) {
+      HIPC(ctx, hipEventRecord(L.ev_strips, s));
+      HIPC(ctx, hipStreamWaitEvent(ctx->pst[0], L.ev_strips, 0));
+    }
     // Knob (off): the kernel-gradient reductions (f64 VALU, latency-bound, no MFMA) on the second stream BESIDE the SYRK
     // (MFMA-bound); both only read this chunk's A / P / g, the join comes before the next chunk's strips overwrite them.
     // Measured and not adopted: H 97.8-98.3 vs 98.2-98.4 ms, C5 16.5-16.6 vs 16.6-16.7 ms (same box) - the SYRK's 504
     // workgroups leave kgrad no room to run beside them.
-    hipStream_t sk = s;
+    hipStream_t sk = trail ? ctx->pst[0] : s;
     if (kg_overlap) {
       rc = ensure_stream2(ctx);
       if (rc) return rc;
@@ -1799,6 +1802,7 @@ int grad_enqueue_impl(svgp_ctx* ctx, svgp_model* m, const svgp_data* data, int64
                  L.gmu, L.gv, w->alpha, ksl, w->ns_uf, w->rp_uf, w->sp_uf, a_from_k ? 1 : 0);
     KCHECK(ctx, "kgrad uf");
     if (kg_overlap) HIPC(ctx, hipEventRecord(ctx->ev_join, sk));
+    if (trail) HIPC(ctx, hipEventRecord(L.ev_done, sk));
     launch_sum5(s, L.partial5, n5, w->sums);
     int64_t sl = ((ncp + ns_syrk - 1) / ns_syrk + 15) / 16 * 16;   // as even as the 16-point k-step allows
     // W (+)= A diag(2 g_v) A' (lower tiles, split-K slices): the first chunk overwrites, so the slice buffer needs no zeroing
@@ -1815,6 +1819,8 @@ int grad_enqueue_impl(svgp_ctx* ctx, svgp_model* m, const svgp_data* data, int64
     if (kg_overlap) HIPC(ctx, hipStreamWaitEvent(s, ctx->ev_join, 0));
     if (pipe) HIPC(ctx, hipEventRecord(L.ev_done, s));
   }
+  if (trail)   // join: the trailing reductions of the last chunks
+    for (int64_t q = 0; q < std::min<int64_t>(nchunks, pc.lanes); ++q) HIPC(ctx, hipStreamWaitEvent(s, w->lanes[size_t(q)].ev_done, 0));
   if (gc.ext_gmu) launch_add_f64(s, w->sums, gc.ext_sum_e);   // sums[0] = sum E: the host's, before any collective
   TREC(ctx, ctx->ev[2], s);
   // M-sized tail.  With W = A diag(2 g_v) A' and a = A g_mu:
@@ -1946,7 +1952,8 @@ int grad_collective(svgp_ctx* ctx, svgp_model* m, GradCall& gc, int local_rc) {
   if (rc == SVGP_OK) rc = comm_allreduce(ctx, w->sums, size_t(8 + 1 + dreg), SVGP_F64);
   const int rce = comm_group_end(ctx);
   if (rc == SVGP_OK) rc = rce;
-  if (rc == SVGP_OK) launch_pack_tril(m->dtype, ctx->stream, w->gblk, w->cblk, head, M, 1);
+  // (the reduced block stays packed: grad_finish reads {z_bar | m_bar | packed tril(Lq_bar)} back as it is)
+  if (rc == SVGP_OK) gc.packed = true;
   if (rc != SVGP_OK) {
     comm_abort(ctx);
     if (local_rc != SVGP_OK) ctx->err = keep;
@@ -1969,10 +1976,15 @@ int grad_finish(svgp_ctx* ctx, svgp_model* m, GradCall& gc, double* elbo_out, sv
   // {z_bar | m_bar | Lq_bar}, contiguous on the device (round 2: seven copies, ~20 us of host latency each).  Lq_bar is M^2 elements -
   // 8.4 MB at M = 1024 f64, 33.5 MB at M = 2048 - and a minibatch step is 1-3 ms of device time: until late in round 4 this went through a
   // fresh std::vector per call (page faults + zero fill), a pageable device-to-host copy and a second host copy into the caller's
-  // buffers (M = 2048: 6.6 ms of an 11.7 ms call).  Now: a pinned staging buffer kept by the context, the copy issued in up to 8
+  // buffers (M = 2048: 6.6 ms of an 11.7 ms call).  Round 4: a pinned staging buffer kept by the context, the copy issued in up to 8
   // pieces with an event behind each, and the host copy of piece i into the caller's buffers running while piece i + 1 is on the bus.
-  const size_t nz = size_t(M) * m->d, nblk = nz + size_t(M) + size_t(M) * M;
+  // Round 5: Lq_bar is lower triangular, so only its M (M + 1) / 2 entries cross the bus - packed by columns on the
+  // device (pack_tril_kernel, the all-reduce's layout) and scattered into the caller's dense column-major M x M array by the host
+  // copy, which also writes the zeros above the diagonal.  The C-ABI keeps its dense Lq_bar.
+  const size_t nz = size_t(M) * m->d, head = nz + size_t(M), tri = size_t(M) * size_t(M + 1) / 2, nblk = head + tri;
   const size_t f64n = size_t(8 + 1 + dreg + 5), f64b = (f64n * 8 + 255) / 256 * 256, gbytes = nblk * es;
+  if (!gc.packed) launch_pack_tril(dt, s, w->gblk, w->cblk, int64_t(head), M, 0);
+  KCHECK(ctx, "pack Lq_bar");
   if (f64b + gbytes > ctx->hstage_bytes) {
     if (ctx->hstage) (void)hipHostFree(ctx->hstage);
     ctx->hstage = nullptr;
@@ -1989,17 +2001,33 @@ int grad_finish(svgp_ctx* ctx, svgp_model* m, GradCall& gc, double* elbo_out, sv
   const size_t piece = ((gbytes + npiece - 1) / npiece + 255) / 256 * 256;
   for (int q = 0; q < npiece; ++q) {
     const size_t lo = std::min(gbytes, size_t(q) * piece), hi = std::min(gbytes, lo + piece);
-    if (hi > lo) HIPC(ctx, hipMemcpyAsync(gh + lo, static_cast<const char*>(w->gblk) + lo, hi - lo, hipMemcpyDeviceToHost, s));
+    if (hi > lo) HIPC(ctx, hipMemcpyAsync(gh + lo, static_cast<const char*>(w->cblk) + lo, hi - lo, hipMemcpyDeviceToHost, s));
     HIPC(ctx, hipEventRecord(ctx->ev_piece[q], s));
   }
   struct Dst { size_t lo, hi; void* p; };
-  const Dst dst[3] = {{0, nz * es, g->z}, {nz * es, (nz + size_t(M)) * es, g->m}, {(nz + size_t(M)) * es, gbytes, g->Lq}};
+  const Dst dst[2] = {{0, nz * es, g->z}, {nz * es, head * es, g->m}};
+  int64_t col = 0;   // column of Lq_bar the packed stream has reached (pieces arrive in order)
   for (int q = 0; q < npiece; ++q) {
     HIPC(ctx, hipEventSynchronize(ctx->ev_piece[q]));
     const size_t lo = std::min(gbytes, size_t(q) * piece), hi = std::min(gbytes, lo + piece);
     for (const Dst& d : dst) {
       const size_t a = std::max(lo, d.lo), b = std::min(hi, d.hi);
       if (d.p && b > a) memcpy(static_cast<char*>(d.p) + (a - d.lo), gh + a, b - a);
+    }
+    // packed entries [e_lo, e_hi) of the triangle (piece boundaries are multiples of 256 bytes, hence of the element size):
+    // column c holds the rows c .. M - 1 at st(c) = c M - c (c - 1) / 2; its part above the diagonal is zeroed as the column begins
+    if (g->Lq && hi > head * es && hi > lo) {
+      const int64_t e_lo = int64_t((std::max(lo, head * es) - head * es) / es), e_hi = int64_t((hi - head * es) / es);
+      auto st = [M](int64_t c) { return c * M - c * (c - 1) / 2; };
+      char* Lq = static_cast<char*>(g->Lq);
+      const char* pk = gh + head * es;
+      while (col + 1 < M && st(col + 1) <= e_lo) ++col;
+      for (int64_t c = col; c < M && st(c) < e_hi; ++c) {
+        const int64_t a = std::max(e_lo, st(c)), b = std::min(e_hi, st(c + 1));
+        if (a == st(c) && c > 0) memset(Lq + size_t(c) * size_t(M) * es, 0, size_t(c) * es);
+        if (b > a) memcpy(Lq + (size_t(c) * size_t(M) + size_t(c + (a - st(c)))) * es, pk + size_t(a) * es, size_t(b - a) * es);
+        col = c;
+      }
     }
   }
   HIPC(ctx, hipStreamSynchronize(s));

@@ -8,6 +8,7 @@
 #include <vector>
 
 #include "../../include/svgp_mi355x.h"
+#include "knobs.hpp"
 
 // ------------------------------------------------------------------------------------------------
 struct svgp_ctx {
@@ -15,6 +16,7 @@ struct svgp_ctx {
   hipStream_t stream = nullptr;
   bool own_stream = false;
   int num_cus = 256;
+  svgp::Knobs kn;   // environment settings, read once at context creation (knobs.hpp)
   std::string err;
   svgp_timing timing{};
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};  // start, prep done, strip done, all done
@@ -49,7 +51,6 @@ struct svgp_ctx {
   unsigned* pcounter = nullptr;
   double* pmom = nullptr;      size_t pmom_cap = 0;
   bool pipelined = false;      // the last value-and-gradient call enqueued work on pst[]
-  int pipe_lanes = 3, pipe_streams = 2, pipe_prio = 0;   // SVGP_GRAD_PIPELINE / _PIPE_STREAMS / _PIPE_PRIO at context creation
   void* kuf_buf = nullptr;    size_t kuf_bytes = 0;
   double* ext_g = nullptr;    size_t ext_cap = 0;           // [2][ext_cap] point gradients of a host-evaluated likelihood
   struct GradWs* gws = nullptr;  // gradient workspace, cached by problem shape

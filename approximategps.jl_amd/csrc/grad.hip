@@ -17,6 +17,7 @@
 
 #include "device_common.hpp"
 #include "kernels.hpp"
+#include "knobs.hpp"
 #include "lik.hpp"
 
 namespace svgp {
@@ -963,10 +964,10 @@ void launch_gemm_pm(int dtype, hipStream_t s, const void* Xt, const void* Yt, co
                     int64_t n, int64_t slice_len, int nslices, void* out, int overwrite, int flags) {
   const int nP = int(Mp / kNB), ntiles = (flags & kMmFull) ? nP * nP : nP * (nP + 1) / 2;
   // f64: 128 x 64 halves on 256-thread workgroups (same-box: H value-and-gradient 141.0 -> 138.4 ms); f32: no difference
-  static const int forced = [] { const char* e = getenv("SVGP_GEMM_PM_NT"); return e ? atoi(e) : 0; }();   // tuning knob
+  static const int forced = exp_int("SVGP_GEMM_PM_NT", 0);   // tuning knob (experiments build)
   const int nt = forced ? forced : (dtype == 0 ? 64 : 128);
   // the weighted SYRK of the gradient (Xt == Yt, weights 2 g_v folded by the caller into w): asynchronous loop (knob)
-  static const int async_knob = [] { const char* e = getenv("SVGP_SYRK_ASYNC"); return e ? atoi(e) : 1; }();
+  static const int async_knob = exp_int("SVGP_SYRK_ASYNC", 1);   // (experiments build)
   if (async_knob && w && Xt == Yt && flags == 0 && !forced) {
     GD(dtype, T, {
       constexpr int NT = sizeof(T) == 8 ? 64 : 128;

@@ -8,6 +8,7 @@
 // Everything is padded to Mp = ceil(M/128)*128 with an identity block so no kernel needs edge tiles.
 #include "device_common.hpp"
 #include "kernels.hpp"
+#include "knobs.hpp"
 
 #include <hip/hip_ext.h>
 #include <cstdlib>
@@ -137,9 +138,6 @@ extern "C" int svgp_debug_potf2_stamps(unsigned long long* out) {
 // v_rsq_f32 (1 ulp) as it is; fp64 keeps the Newton refinements (v_rsq_f64 delivers ~26 bits).  No per-step selects: an X
 // lane starts from delta_jc and stays exactly zero above the diagonal; the diagonal entry is t r = sqrt(t) like any other
 // entry of its column; L rows hold unused garbage right of the diagonal.
-#ifndef SVGP_F16_BULK_SGPR
-#define SVGP_F16_BULK_SGPR 0
-#endif
 #ifndef SVGP_F16_DPP
 #define SVGP_F16_DPP 1   // 0: v_readlane broadcasts (A/B and bisection builds)
 #endif
@@ -242,14 +240,8 @@ __device__ __forceinline__ void factor16_bulk(T (&row)[16], T (&x)[16], T (&n)[2
   if constexpr (K < J || K < PivotTail<T>::NST) {
     if constexpr (K < PivotTail<T>::NST) tail.template stage<J, K>(row, x, bad);
     if constexpr (K < J && J + 1 < 16) {
-#if SVGP_F16_BULK_SGPR   // experiment (round 5): the bulk terms' broadcast through an SGPR - two v_readlane + two plain FMAs instead of two DPP FMACs
-      const T bc = readlane_t(row[K], J + 1);
-      n[K & 1] = fma(-bc, row[K], n[K & 1]);
-      m[K & 1] = fma(-bc, x[K], m[K & 1]);
-#else
       fmac_bcast<J + 1, false>(n[K & 1], row[K], row[K]);   // n -= L[J+1][K] * row[K]
       fmac_bcast<J + 1, false>(m[K & 1], row[K], x[K]);     // m -= L[J+1][K] * x[K]
-#endif
     }
     __builtin_amdgcn_sched_barrier(0);
     factor16_bulk<T, J, K + 1>(row, x, n, m, tail, bad);
@@ -258,7 +250,10 @@ __device__ __forceinline__ void factor16_bulk(T (&row)[16], T (&x)[16], T (&n)[2
 // Broadcasts: a DPP operand costs 8 cycles of issue in fp32 and ~16 on the DP ALU (a column step of 2J DPP-FMACs + 27 tail
 // instructions takes 307 cycles in f64).  Measured and rejected: finished columns parked in a 16 x 16 LDS buffer and read back as
 // same-address (broadcast) LDS reads for all but the k = J - 1 term - 7.6k instead of 4.9k cycles per factor (f64; 6.0k vs 3.6k
-// fp32): the write -> read round trip of every step lands on the chain.
+// fp32): the write -> read round trip of every step lands on the chain.  Round 5, measured and rejected: the BULK terms' broadcast through
+// an SGPR (two v_readlane_b32 + two plain v_fma_f64 with an SGPR-pair operand instead of two DPP FMACs; the k = J - 1 term stays DPP):
+// fp32 factor16 3.6k -> 4.3k cycles, prep at M = 128 66-68 -> 72-74 us f64, 62 -> 65-73 us fp32 (profiles/round5/potf2_sgpr.log) - the
+// v_readlane -> SGPR -> VALU round trip costs more than the DPP operand's 8 / 16 issue cycles even off the dependent chain.
 template <typename T, int J>
 __device__ __forceinline__ void factor16_step(T (&row)[16], T (&x)[16], T (&pt)[2], T (&ps)[2], int& bad) {
   T t1 = pt[1], s1 = ps[1];
@@ -668,6 +663,7 @@ __global__ void __launch_bounds__(k256, (FUSE && sizeof(T) == 8) ? 1 : 2) chol_t
 // NCH workgroups: no cycle.  A wait that outlasts 0.2 s (never seen; a guard against a wedged box, not a protocol step) gives up
 // and reports through info.  NOT ADOPTED (see potrf_t): correct and bitwise equal to the two-launch form, but no faster.
 // sync layout (unsigned words): [p] hand-over counter of tile (p + 1, p + 1)  |  [nP + q] flag: block (q, q) factored and stored.
+#ifdef SVGP_EXPERIMENTS
 template <typename T, int NT>
 __global__ void __launch_bounds__(k256, sizeof(T) == 8 ? 1 : 2) chol_chain_kernel(T* __restrict__ A, T* __restrict__ Tm, int64_t ld, int p, int n,
                                                                                    int nP, int* __restrict__ info, unsigned* __restrict__ sync) {
@@ -760,6 +756,7 @@ __global__ void __launch_bounds__(k256, sizeof(T) == 8 ? 1 : 2) chol_chain_kerne
 #pragma unroll
       for (int b = 0; b < G::NJ; ++b) C[G::acc_col(b) + int64_t(G::acc_row(a, r)) * ld] = acc.v[a][b][r];
 }
+#endif   // SVGP_EXPERIMENTS
 
 // The large-grid form of the trailing update (trailing matrices of >= 256 tiles fill the chip by themselves): whole
 // 128 x 128 tiles on 512-thread workgroups, A[i, j] -= L[i, p] L[j, p]' computed transposed so that stores run along columns
@@ -806,6 +803,7 @@ __global__ void __launch_bounds__(kThreads, 2) syrk128_kernel(T* __restrict__ A,
 // itself (M = 8192: 5.05 vs 4.92 ms).  The register-staged two-buffer loop waits for every operand tile at a __syncthreads(); here
 // a tile has two whole steps to land.  P and Q are both k-major views of the panel L[:, kcol..] (leading dimension ld): the Q
 // operand's 512-byte k-rows travel in pairs like the fp32 strips'.
+#ifdef SVGP_EXPERIMENTS
 template <typename T, bool FUSE>
 __global__ void __launch_bounds__(k256, 2) syrk128_async_kernel(T* __restrict__ A, T* __restrict__ Tm, int64_t ld, int p,
                                                                  int* __restrict__ info, int kb) {
@@ -837,6 +835,7 @@ __global__ void __launch_bounds__(k256, 2) syrk128_async_kernel(T* __restrict__ 
     potf2_body<T>(A + int64_t(p + 1) * NB * (ld + 1), Tm + int64_t(p + 1) * NB * (ld + 1), ld, info, (p + 1) * NB, smem_raw);
   }
 }
+#endif   // SVGP_EXPERIMENTS
 
 // ------------------------------------------------------------------------------------------------
 template <typename T>
@@ -1085,7 +1084,7 @@ void potrf_t(hipStream_t s, T* A, T* Tm, int64_t Mp, int* info, unsigned* sync, 
   constexpr size_t lds_tile = (SVGP_CHOL_TILE_ASYNC && GS::kAsync) ? (GS::ASYNC_LDS_BYTES > GS::LDS_BYTES ? GS::ASYNC_LDS_BYTES : GS::LDS_BYTES) : GS::LDS_BYTES;
   constexpr size_t lds_fused_s = lds_tile > lds_potf2 ? lds_tile : lds_potf2;
   constexpr size_t lds_fused_l = G::LDS_BYTES > lds_potf2 ? G::LDS_BYTES : lds_potf2;
-  static const bool fuse_on = [] { const char* e = getenv("SVGP_CHOL_FUSE"); return !e || e[0] != '0'; }();   // A/B knob
+  static const bool fuse_on = exp_int("SVGP_CHOL_FUSE", 1) != 0;   // A/B knob (experiments build)
   set_max_lds(reinterpret_cast<const void*>(potf2_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds_potf2));
   set_max_lds(reinterpret_cast<const void*>(syrk128_kernel<T, false>), hipFuncAttributeMaxDynamicSharedMemorySize, int(G::LDS_BYTES));
   set_max_lds(reinterpret_cast<const void*>(syrk128_kernel<T, true>), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds_fused_l));
@@ -1101,7 +1100,6 @@ void potrf_t(hipStream_t s, T* A, T* Tm, int64_t Mp, int* info, unsigned* sync, 
   // saves the 25 us of a launch of their own); from 17 panels on they would lengthen 60-odd serial launches instead (C4: +0.33 ms
   // in the TRSM launches against the 0.15 ms of one launch over all 2016 tiles at the end), so a large Kuu keeps the one launch.
   const bool t_inside = nP <= 16;
-  set_max_lds(reinterpret_cast<const void*>(chol_tile_kernel<T, MODE_COL, CNT, true>), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds_fused_s));
   // ---- two-level blocking (round 4): 256-wide outer panels for a large Kuu -------------------------------
   // Per outer panel (block columns a, b = a + 1):  TRSM(a);  update of block column b alone + factorisation of (b, b) in the same
   // launch;  TRSM(b);  ONE rank-256 update of everything right of b (+ the factorisation of the next diagonal block in it).
@@ -1118,10 +1116,11 @@ void potrf_t(hipStream_t s, T* A, T* Tm, int64_t Mp, int* info, unsigned* sync, 
   // is the longer one, ~1.2 ms in 64 TRSM launches + gaps.  Reaching the 3.3 ms the verdict asked for needs the chain
   // (factorisation + TRSM of the next panel) OFF the bulk update's stream - a two-stream lookahead with the bulk one panel
   // behind - which was not built.  Both forms stay as A/B knobs (SVGP_CHOL_TWO_LEVEL=1, SVGP_CHOL_ASYNC=1), default off.
-  static const bool two_level_on = [] { const char* e = getenv("SVGP_CHOL_TWO_LEVEL"); return e && e[0] == '1'; }();
-  static const bool async_on = [] { const char* e = getenv("SVGP_CHOL_ASYNC"); return e && e[0] == '1'; }();   // A/B knob
-  // the big fused update: fp32 on the asynchronous loop (256 threads), else the 512-thread two-buffer kernel
+  // (experiments build only: SVGP_CHOL_TWO_LEVEL=1, SVGP_CHOL_ASYNC=1, SVGP_CHOL_CHAIN=1; the product build compiles none of them)
+  // the big fused update: the 512-thread two-buffer kernel (experiments build: fp32 on the asynchronous loop, 256 threads)
   auto big_update = [&](int nt, int pp, int kbb) {
+#ifdef SVGP_EXPERIMENTS
+    static const bool async_on = exp_int("SVGP_CHOL_ASYNC", 0) == 1;   // A/B knob
     if constexpr (sizeof(T) == 4) {
       if (async_on) {
         using GA = TileGemm<T, kNB, 16, k256>;
@@ -1131,8 +1130,12 @@ void potrf_t(hipStream_t s, T* A, T* Tm, int64_t Mp, int* info, unsigned* sync, 
         return;
       }
     }
+#endif
     hipLaunchKernelGGL((syrk128_kernel<T, true>), dim3(nt), dim3(kThreads), lds_fused_l, s, A, Tm, Mp, pp, info, kbb);
   };
+#ifdef SVGP_EXPERIMENTS
+  static const bool two_level_on = exp_int("SVGP_CHOL_TWO_LEVEL", 0) == 1;
+  set_max_lds(reinterpret_cast<const void*>(chol_tile_kernel<T, MODE_COL, CNT, true>), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds_fused_s));
   if (two_level_on && fuse_on && !t_inside && sizeof(T) == 4) {
     potf2(0);
     for (int a = 0; a < nP; a += 2) {
@@ -1158,12 +1161,14 @@ void potrf_t(hipStream_t s, T* A, T* Tm, int64_t Mp, int* info, unsigned* sync, 
     dbg("T panels", s);
     return;
   }
+#endif
   // one launch per panel (chol_chain_kernel) where the whole launch is resident at once.  MEASURED AND NOT ADOPTED
   // (profiles/round4/chol_chain.md): bitwise the same factor, but no faster - M = 1024 f64 0.558-0.561 ms of prep against 0.553-0.561,
   // fp32 0.580-0.588 against 0.552-0.560.  The kernel trace says why: the TRSM launch already starts the instant the fused
   // update + factorisation launch ends (0.0 us between them), so the flag hand-over (57 us per chain launch against 46.4 + 8.8)
   // replaces a boundary that cost nothing; the 5.4 us gap sits in front of every update launch in either form.  A/B knob, default off.
-  static const bool chain_on = [] { const char* e = getenv("SVGP_CHOL_CHAIN"); return e && e[0] == '1'; }();
+#ifdef SVGP_EXPERIMENTS
+  static const bool chain_on = exp_int("SVGP_CHOL_CHAIN", 0) == 1;
   static const int chain_slots = [] {
     hipDeviceProp_t prop;
     int dev = 0;
@@ -1171,6 +1176,7 @@ void potrf_t(hipStream_t s, T* A, T* Tm, int64_t Mp, int* info, unsigned* sync, 
     return prop.multiProcessorCount * (sizeof(T) == 8 ? 1 : 2);
   }();
   set_max_lds(reinterpret_cast<const void*>(chol_chain_kernel<T, CNT>), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds_fused_s));
+#endif
   bool trsm_done = false;   // panel p's TRSM and T panels rode in the previous chain launch
   potf2(0);
   for (int p = 0; p < nP; ++p) {
@@ -1180,7 +1186,7 @@ void potrf_t(hipStream_t s, T* A, T* Tm, int64_t Mp, int* info, unsigned* sync, 
     // rides on the launch itself (hipExtLaunchKernelGGL's stop event = the dispatch packet's own completion signal): a separate
     // hipEventRecord is a barrier packet of its own, ~5 us of the chain per panel (kernel traces, minibatch_step.md section 8).
     // SVGP_ROW_EVENT_EXT=0: the separate record (A/B).
-    static const bool ev_ext = [] { const char* e = getenv("SVGP_ROW_EVENT_EXT"); return !e || e[0] != '0'; }();
+    static const bool ev_ext = exp_int("SVGP_ROW_EVENT_EXT", 1) != 0;   // (experiments build)
     const bool want_ev = row_events && t_inside;
     bool ev_done = false;
     if (!trsm_done && n + nt_p > 0) {   // the panel below the diagonal (and the T panels of block row p)
@@ -1203,10 +1209,13 @@ void potrf_t(hipStream_t s, T* A, T* Tm, int64_t Mp, int* info, unsigned* sync, 
     // the fused f64 form of the large grid would cost the second resident workgroup (potf2's LDS image of an f64 block is 146 KiB)
     const bool fused = fuse_on && !(large && sizeof(T) == 8);
     trsm_done = false;
+#ifdef SVGP_EXPERIMENTS
     if (fused && !large && chain_on && t_inside && (nt + p + 1) * NCH <= chain_slots) {
       hipLaunchKernelGGL((chol_chain_kernel<T, CNT>), dim3((nt + p + 1) * NCH), dim3(k256), lds_fused_s, s, A, Tm, Mp, p, n, nP, info, sync);
       trsm_done = true;
-    } else if (fused && large) {
+    } else
+#endif
+    if (fused && large) {
       big_update(nt, p, 1);
     } else if (fused) {
       hipLaunchKernelGGL((chol_tile_kernel<T, MODE_SYRK, CNT, true>), dim3(nt * NCH), dim3(k256), lds_fused_s, s, A, Tm, Mp, p, n, info, sync);

@@ -14,6 +14,7 @@
 // Roofline: MFMA-bound (2 Mp² flops per point); algorithmic HBM bytes are only x, y.
 #include "device_common.hpp"
 #include "kernels.hpp"
+#include "knobs.hpp"
 #include "lik.hpp"
 
 #ifndef SVGP_ASYNC
@@ -455,6 +456,7 @@ __global__ void __launch_bounds__(NTHR, MINW) strip_kernel(StripArgs a, int64_t 
       // at the previous checkpoint, in the threads' own register layout - and parks it again; the closing launch finishes all of
       // them.  Same operations on every accumulator in the same order: bitwise the one-launch result.  Three checkpoints
       // (nP / 2, 3 nP / 4, nP): 20 tile transfers per strip instead of 64 for one per panel.
+#ifdef SVGP_EXPERIMENTS   // (measured, not adopted: SVGP_OVERLAP_P2CKPT=1 - the product build's segmented kernels do not carry it)
       if constexpr (!GRAD) {
         const int p2_lo = a.seg_p2_lo, p2_hi = a.seg_p2_hi;
         if ((a.seg_flags & kSegP2) && p2_hi > p2_lo) {
@@ -506,6 +508,7 @@ __global__ void __launch_bounds__(NTHR, MINW) strip_kernel(StripArgs a, int64_t 
           p2_complete = last;
         }
       }
+#endif
       if (!(a.seg_flags & kSegPhase2)) {   // this launch ends here for the strip; phase 2 (GRAD: phase 3) and the moments come with a later one
         strip = next_strip;
         __syncthreads();
@@ -1195,7 +1198,7 @@ void launch_strip_t(hipStream_t s, const StripArgs& a, int grid, int64_t nstrips
 // the scalar per-feature generation inside the d <= 16 kernel, as round 3 - A/B knob)
 template <typename T, int NT, bool GRAD, int PG>
 void launch_strip_d(hipStream_t s, const StripArgs& a, int grid, int64_t nstrips) {
-  static const bool bigd_on = [] { const char* e = getenv("SVGP_PREGEN_MFMA_BIGD"); return !e || e[0] != '0'; }();
+  static const bool bigd_on = exp_int("SVGP_PREGEN_MFMA_BIGD", 1) != 0;   // experiments build: A/B
   if (a.kp.d > 16 && bigd_on) launch_strip_t<T, NT, 16, 256, 2, 16, GRAD, PG, true>(s, a, grid, nstrips);
   else launch_strip_t<T, NT, 16, 256, 2, 16, GRAD, PG, false>(s, a, grid, nstrips);
 }
@@ -1206,10 +1209,8 @@ void launch_strip_d(hipStream_t s, const StripArgs& a, int grid, int64_t nstrips
 // waves on a SIMD belong to different workgroups and do not park at the same barrier.
 // SVGP_STRIP_NT=128 selects the 128-point / 512-thread build, SVGP_STRIP_BK=32 the 32-deep k-step (tuning knobs).
 // Measured and rejected for f64: 64 x 64 per wave on one workgroup per CU (1 wave/SIMD): 54.9 ms vs 42.1 ms at H.
-static int env_int(const char* name, int dflt) {
-  const char* e = getenv(name);
-  return e ? atoi(e) : dflt;
-}
+// (every knob below is a constant - its default - in the product build: knobs.hpp)
+static int env_int(const char* name, int dflt) { return exp_int(name, dflt); }
 
 int strip_nt(int dtype, int64_t Mp, int64_t /*len*/) {
   // f64: 64-point strips; f32: 128-point strips (a wave then owns 64 x 64 = 16 MFMA tiles, the same 64 accumulator
@@ -1299,13 +1300,21 @@ void launch_strip(int dtype, hipStream_t s, const StripArgs& a, int nt, int grid
     else launch_strip_d<float, 64, false, kPgBuiltin>(s, a, grid, nstrips);   // BK = 32 measured identical
   } else if (dtype == 1 && env_int("SVGP_F32_THREADS", 256) == 256) {
     launch_strip_d<float, 128, false, kPgBuiltin>(s, a, grid, nstrips);
-  } else if (dtype == 0) {
+  }
+#ifdef SVGP_EXPERIMENTS   // the 512-thread, 128-point builds (SVGP_STRIP_NT=128 / SVGP_F32_THREADS=512): measured and rejected, round 1-3
+  else if (dtype == 0) {
     if (bk32 && a.kp.d <= 8) launch_strip_t<double, 128, 32, 512>(s, a, grid, nstrips);
     else launch_strip_t<double, 128, 16, 512>(s, a, grid, nstrips);
   } else {
     if (bk32 && a.kp.d <= 8) launch_strip_t<float, 128, 32, 512>(s, a, grid, nstrips);
     else launch_strip_t<float, 128, 16, 512>(s, a, grid, nstrips);
   }
+#else
+  else {
+    (void)bk32;
+    leave_note("internal: no strip kernel for this (dtype, width)");   // unreachable: strip_nt() only plans the widths above
+  }
+#endif
 }
 
 // the segmented strips (a.seg_*): nt = 32 / 64 (f64), 32 / 64 / 128 (f32); d <= 16 (wider inputs take the one-launch path).
@@ -1351,6 +1360,7 @@ void launch_strip_grad(int dtype, hipStream_t s, const StripArgs& a, int nt, int
     }
     return;
   }
+#ifdef SVGP_EXPERIMENTS   // the round-3 in-kernel likelihood-gradient forms (SVGP_GRAD_POST=0): five of them spill at occupancy 1
   if (a.lp.lik == kLikExternal) {   // the host-evaluated-likelihood build: a separate instantiation, so the enumerated one
     if (dtype == 0) {               // is bit for bit the kernel it was (its register allocation is that sensitive)
       if (nt == 32) launch_strip_t<double, 32, 16, 256, 2, 16, true, kPgExternal>(s, a, grid, nstrips);
@@ -1370,6 +1380,9 @@ void launch_strip_grad(int dtype, hipStream_t s, const StripArgs& a, int nt, int
     else if (nt == 64) launch_strip_t<float, 64, 16, 256, 2, 16, true>(s, a, grid, nstrips);
     else launch_strip_t<float, 128, 16, 256, 2, 16, true>(s, a, grid, nstrips);
   }
+#else
+  leave_note("internal: the in-kernel likelihood-gradient strips exist in the experiments build only");
+#endif
 }
 
 int point_grad_blocks(int64_t len) { return int((len + k256 - 1) / k256); }
@@ -1477,12 +1490,14 @@ static void launch_kuf_f(hipStream_t s, const KernelParams& kp, const T* zs, int
 template <typename T>
 static void launch_kuf_t(hipStream_t s, const KernelParams& kp, const T* zs, int64_t M, int64_t Mp, const T* x, int64_t ldx,
                          int64_t off, int64_t len, T* Kuf) {
-  static const bool generic_knob = [] { const char* e = getenv("SVGP_KUF_GENERIC"); return e && e[0] == '1'; }();   // A/B: the round-3 path for d > 32
+#ifdef SVGP_EXPERIMENTS
+  static const bool generic_knob = exp_int("SVGP_KUF_GENERIC", 0) == 1;   // A/B: the round-3 path for d > 32
   if (kp.d > 32 && generic_knob) {
     hipLaunchKernelGGL(kuf_generic_kernel<T>, dim3((unsigned)((M + 255) / 256), (unsigned)((len + 15) / 16)), dim3(k256), 0, s, kp, zs, M, Mp, x, ldx,
                        off, len, Kuf);
     return;
   }
+#endif
   if (kp.family == KSE) launch_kuf_f<T, KSE>(s, kp, zs, M, Mp, x, ldx, off, len, Kuf);
   else if (kp.family == KM32) launch_kuf_f<T, KM32>(s, kp, zs, M, Mp, x, ldx, off, len, Kuf);
   else launch_kuf_f<T, KM52>(s, kp, zs, M, Mp, x, ldx, off, len, Kuf);

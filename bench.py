@@ -130,7 +130,7 @@ def cpu_baseline(p, family, lik, sample, n_full, M, force_sample=False):
 
 
 def lib_sha16():
-    """sha256 (first 16 hex digits) of the library this process loaded: profiles/round4/build.log lists the same hash for the .so
+    """sha256 (first 16 hex digits) of the library this process loaded: the build log (approximategps.jl_amd/csrc/build.log, copied to profiles/roundN/build.log by the evidence run) lists the same hash for the .so
     build.sh produced from the tree's sources."""
     import hashlib
     from approxgp import _ffi
@@ -418,7 +418,8 @@ def measure_host_step(ctx, n=16384, M=1024, d=8, reps=20):
     return {"workload": f"minibatch of {n} points, M={M}, d={d}, SE-ARD, Gaussian, f64; parameters from host memory every step, "
                         "gradients to host memory (pinned staging, reused host arrays)",
             "ms_step": step, "steps_per_s": 1e3 / step, "ms_model_update": float(np.median(tu)) * 1e3,
-            "ms_elbo_grad": float(np.median(tg)) * 1e3, "ms_device": float(np.median(td)), "pcie_bytes_per_step": 2 * 8 * (M * M + M * d + M)}
+            "ms_elbo_grad": float(np.median(tg)) * 1e3, "ms_device": float(np.median(td)), "pcie_bytes_per_step": 8 * (M * M + M * d + M) + 8 * (M * (M + 1) // 2 + M * d + M),
+            "pcie_note": "parameters up: dense M x M Lq as the C-ABI takes it; gradients down: Lq_bar as its packed lower triangle (round 5)"}
 
 
 def timing_on(ctx=None):

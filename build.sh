@@ -1,13 +1,15 @@
 #!/usr/bin/env bash
 # Builds libsvgp_mi355x.so for gfx950 in-tree (approximategps.jl_amd/csrc/).  hipcc cross-compiles without a GPU.
-# Leaves profiles/round4/build.log: the hipcc command lines, the compiler version and the sha256 of every source, object and of
-# the library, so that a reader can see the .so a GPU box loaded (bench.py prints its sha256 as `lib_sha16`) is this tree's.
+# Leaves approximategps.jl_amd/csrc/build.log (untracked; SVGP_BUILD_LOG overrides the path): the hipcc command lines, the compiler
+# version and the sha256 of every source, object and of the library, so that a reader can see the .so a GPU box loaded (bench.py prints
+# its sha256 as `lib_sha16`) is this tree's.  The evidence script of a round copies it into profiles/roundN/build.log - a plain build
+# (or an ablation build with SVGP_EXTRA_FLAGS) never touches tracked files.
 set -euo pipefail
 HERE="$(cd "$(dirname "$0")" && pwd)"
 SRC="$HERE/approximategps.jl_amd/csrc"
 OUT="$SRC/libsvgp_mi355x.so"
 FLAGS="-O3 -std=c++17 --offload-arch=gfx950 -fPIC -Wall -Wno-unused-function ${SVGP_EXTRA_FLAGS:-}"
-LOG="${SVGP_BUILD_LOG:-$HERE/profiles/round4/build.log}"
+LOG="${SVGP_BUILD_LOG:-$SRC/build.log}"
 mkdir -p "$(dirname "$LOG")"
 {
   echo "# build.sh: $(hipcc --version 2>/dev/null | grep -m1 -i 'HIP version' || echo 'hipcc version unknown')"

@@ -138,7 +138,10 @@ int32_t svgp_ctx_create(int32_t device_id, void* stream, svgp_ctx** out);
 int32_t svgp_ctx_destroy(svgp_ctx* ctx);
 /* text of the last error on ctx (owned by the library, valid until the next call on ctx) */
 const char* svgp_last_error(const svgp_ctx* ctx);
-/* writes the first SVGP_TIMING_V3_BYTES of the timing struct: the layout every ABI version shares */
+/* writes the first SVGP_TIMING_V3_BYTES of the timing struct: the layout every ABI version shares.
+ * NOTE for hosts compiled against the ABI-v4 header (56-byte struct): v4's svgp_last_timing also wrote ms_chol; since v5 it does NOT
+ * (a v3-compiled host had sized its buffer at 48 bytes), so a v4 host reading ms_chol after this call sees whatever its buffer held.
+ * The library cannot know the caller's struct size here: v4 hosts must move to svgp_last_timing_sized. */
 int32_t svgp_last_timing(const svgp_ctx* ctx, svgp_timing* out);
 /* (v5) writes the first min(out_bytes, size of svgp_timing) bytes: a host passes the size of the struct IT was compiled against, so the
  * struct can grow without the library ever writing past the caller's buffer */

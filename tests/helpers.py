@@ -1,4 +1,7 @@
 """Shared helpers for the parity tests: turn an oracle SVA (oracle/svgp_oracle.py) into the C-ABI objects."""
+import contextlib
+import os
+
 import numpy as np
 
 import svgp_oracle as o
@@ -20,6 +23,32 @@ def device_model(ctx, sva, **kw):
 
 def rel(a, b):
     return abs(a - b) / max(abs(b), 1e-300)
+
+
+@contextlib.contextmanager
+def context_with_env(**env):
+    """A fresh context created under the given environment: the library reads its settings ONCE, at svgp_ctx_create
+    (csrc/knobs.hpp) - SVGP_TIMING, SVGP_OVERLAP, SVGP_SEG_SPLIT in every build, the tuning / A-B knobs in the experiments build."""
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update({k: str(v) for k, v in env.items()})
+    try:
+        c = _ffi.Context(0)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    try:
+        yield c
+    finally:
+        c.close()
+
+
+def experiments_build() -> bool:
+    """True when the loaded library is the experiments build (tools/build_experiments.sh, SVGP_MI355X_LIB=...): it alone exports
+    svgp_debug_experiments and honours the tuning / A-B environment knobs."""
+    return hasattr(_ffi.load_library(), "svgp_debug_experiments")
 
 
 class GaussHermiteLikelihood:

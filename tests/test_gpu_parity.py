@@ -390,9 +390,24 @@ def test_one_shot_elbo_host_entry_point(ctx):
     assert rc == _ffi.INVALID_ARG and b"null" in ctx.lib.svgp_last_error(ctx.h)
 
 
-def test_half_width_strips_are_bitwise_identical():
-    """Small batches run as half-width strips (strip_plan); the per-point arithmetic must not depend on the width.
-    SVGP_TAIL is read once per process, so the two schedules run in two child processes."""
+def test_half_width_strips_are_bitwise_identical(ctx):
+    """Small batches run as half-width strips (strip_plan); the per-point arithmetic must not depend on the width: the marginals
+    of a 777-point window evaluated on its own (32- / 64-point strips) are bit for bit those of the same points inside a 40 000-point
+    batch (64- / 128-point strips).  In the experiments build SVGP_TAIL=0 / 1 (read once per process: two child processes) also
+    switches the half-width schedule off and on for the same batch."""
+    for dt in (np.float64, np.float32):
+        x, y, sva, s2 = o.synth_problem(77, 40000, 200, 3, dtype=dt)
+        m = device_model(ctx, sva, dtype=dt, sigma2=s2)
+        d = _ffi.DeviceData(ctx, x, y, dt)
+        mu_s, var_s = m.marginals(d, 100, 777)
+        assert ctx.timing().strip_launches == 1
+        mu_l, var_l = m.marginals(d, 100, 39900)
+        assert np.array_equal(mu_s, mu_l[:777]) and np.array_equal(var_s, var_l[:777])
+        m.free()
+        d.free()
+    from helpers import experiments_build
+    if not experiments_build():
+        return
     import os
     import subprocess
     import sys

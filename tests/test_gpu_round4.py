@@ -9,7 +9,7 @@ import pytest
 
 import svgp_oracle as o
 from approxgp import _ffi
-from helpers import GaussHermiteLikelihood, device_model, rel
+from helpers import GaussHermiteLikelihood, context_with_env, device_model, experiments_build, rel
 
 pytestmark = pytest.mark.gpu
 
@@ -51,26 +51,25 @@ def test_wide_inputs_on_the_mfma_pregeneration(ctx, dtype, tol, mtol, gtol, fami
 
 @pytest.mark.parametrize("dtype,vtol,gtol", [(np.float64, 1e-13, 1e-11), (np.float32, 2e-6, 2e-4)])
 @pytest.mark.parametrize("lik,qn", [(o.LIK_GAUSSIAN, 0), (o.LIK_BERNOULLI_LOGISTIC, 0), (o.LIK_POISSON_EXP, 0), (o.LIK_GAMMA_EXP, 7)])
-def test_point_gradient_kernel_equals_the_in_kernel_forms(ctx, dtype, vtol, gtol, lik, qn):
+def test_point_gradient_kernel_equals_the_in_kernel_forms(dtype, vtol, gtol, lik, qn):
     """Round 4 moved the likelihood gradients out of the value-and-gradient strips into point_grad_kernel (strip.hip, kPgPost).
     Per point it is the same arithmetic on the same moments; only the order of the per-block sums differs.  SVGP_GRAD_POST=0
-    selects the round-3 in-kernel build: both must agree to rounding in the compute dtype, on a batch spanning several strips and
-    a ragged end, with the oracle between them."""
+    (EXPERIMENTS build only: the product library no longer compiles the in-kernel forms) selects the round-3 in-kernel build: both
+    must agree to rounding in the compute dtype, on a batch spanning several strips and a ragged end, with the oracle between them."""
+    if not experiments_build():
+        pytest.skip("the in-kernel likelihood-gradient strips exist in the experiments build only (tools/build_experiments.sh)")
     N, M, d = 2900, 140, 5
     x, y, sva, s2 = o.synth_problem(5200, N, M, d, family=o.KERNEL_MATERN52, lik=lik, dtype=dtype)
-    model = device_model(ctx, sva, dtype=dtype, lik=lik, sigma2=s2, quadrature_n=qn)
-    data = _ffi.DeviceData(ctx, x, y, dtype)
-    old = os.environ.get("SVGP_GRAD_POST")
-    try:
-        os.environ["SVGP_GRAD_POST"] = "1"
-        v1, _, g1 = model.elbo_grad(data, 0, N, 2.0 * N)
-        os.environ["SVGP_GRAD_POST"] = "0"
-        v0, _, g0 = model.elbo_grad(data, 0, N, 2.0 * N)
-    finally:
-        if old is None:
-            os.environ.pop("SVGP_GRAD_POST", None)
-        else:
-            os.environ["SVGP_GRAD_POST"] = old
+    res = []
+    for post in ("1", "0"):
+        with context_with_env(SVGP_GRAD_POST=post) as c:
+            model = device_model(c, sva, dtype=dtype, lik=lik, sigma2=s2, quadrature_n=qn)
+            data = _ffi.DeviceData(c, x, y, dtype)
+            v, _, g = model.elbo_grad(data, 0, N, 2.0 * N)
+            res.append((v, g))
+            model.free()
+            data.free()
+    (v1, g1), (v0, g0) = res
     assert rel(v1, v0) < vtol
     for k in ("z", "m", "Lq", "inv_lengthscale"):
         a, b = np.asarray(g1[k], dtype=np.float64), np.asarray(g0[k], dtype=np.float64)
@@ -79,8 +78,6 @@ def test_point_gradient_kernel_equals_the_in_kernel_forms(ctx, dtype, vtol, gtol
         assert abs(g1[k] - g0[k]) <= gtol * max(abs(g0[k]), 1e-12) + (0 if dtype == np.float64 else 1e-6), k
     val_ref, _ = o.elbo_grad(sva, x, y, lik=lik, sigma2=s2, num_data=2.0 * N, quadrature_n=qn)
     assert rel(v1, val_ref) < (1e-8 if dtype == np.float64 else 1e-4)
-    model.free()
-    data.free()
 
 
 def test_host_evaluated_route_through_the_point_gradient_kernel(ctx):
@@ -144,17 +141,11 @@ def test_dimension_beyond_the_maximum_is_unsupported_everywhere(ctx):
     assert rc == _ffi.INVALID_ARG
 
 
-def _toggle(name, value):
-    old = os.environ.get(name)
-    os.environ[name] = value
-    return old
-
-
-def _restore(name, old):
-    if old is None:
-        os.environ.pop(name, None)
-    else:
-        os.environ[name] = old
+# The overlap settings are read once per context (csrc/knobs.hpp): every variant below is its own context on the same inputs.
+# SVGP_OVERLAP_MIN_PANELS / _HEAD / _HEAD_MIN_PANELS take effect in the experiments build only (the product build overlaps from
+# five panels on and never runs a segmented head); under the product library the small models simply evaluate serially in all
+# contexts and the comparison is trivially true for them - the larger ones still cross the two paths.
+_OV = dict(SVGP_OVERLAP_MIN_PANELS="2", SVGP_OVERLAP_HEAD="1", SVGP_OVERLAP_HEAD_MIN_PANELS="2")
 
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
@@ -162,76 +153,69 @@ def _restore(name, old):
                                       (777, 1500, 2, o.LIK_POISSON_EXP), (20000, 256, 16, o.LIK_GAUSSIAN), (64, 2048, 1, o.LIK_GAUSSIAN),
                                       # more than one round of strips: a segmented head beside the factorisation + the rest behind it
                                       (100000, 512, 8, o.LIK_GAUSSIAN), (70001, 650, 4, o.LIK_BERNOULLI_LOGISTIC), (150000, 300, 2, o.LIK_GAUSSIAN)])
-def test_strips_beside_the_factorisation_are_bitwise_the_serial_result(ctx, dtype, N, M, d, lik):
+def test_strips_beside_the_factorisation_are_bitwise_the_serial_result(dtype, N, M, d, lik):
     """a batch of at most one round of strips runs as segmented strips on a second stream, panel I behind the
     event of block row I of T, beside the Cholesky of Kuu (api.hip: SegRun).  Per strip the arithmetic is the
     one-launch kernel's, register for register: ELBO, expectation and the per-point marginals must be IDENTICAL bits with the
     overlap on and off, repeatedly (a race between the streams would show as a flaky difference), at several M / widths."""
     x, y, sva, s2 = o.synth_problem(6000 + M, N, M, d, lik=lik, dtype=dtype)
-    model = device_model(ctx, sva, dtype=dtype, lik=lik, sigma2=s2)
-    data = _ffi.DeviceData(ctx, x, y, dtype)
-    old = _toggle("SVGP_OVERLAP", "0")
-    oldp = _toggle("SVGP_OVERLAP_MIN_PANELS", "2")   # the product default (5: where it pays) would skip the small models here
-    oldh = _toggle("SVGP_OVERLAP_HEAD", "1")         # ... and the segmented head of a multi-round batch is off by default
-    oldhp = _toggle("SVGP_OVERLAP_HEAD_MIN_PANELS", "2")
-    olds = _toggle("SVGP_SEG_SPLIT", "0")            # small batches: the split closing launch sums the variance in another order (below)
-    try:
+    off = min(17, N - 1)                     # an offset window, ragged end
+    with context_with_env(SVGP_OVERLAP="0") as c0:
+        model = device_model(c0, sva, dtype=dtype, lik=lik, sigma2=s2)
+        data = _ffi.DeviceData(c0, x, y, dtype)
         v0, t0 = model.elbo(data, 0, N, 3.0 * N)
-        os.environ["SVGP_OVERLAP"] = "1"
+        w0 = model.elbo(data, off, N - off, 0.0)[0]
+        assert c0.timing().ms_overlap == 0.0
+        model.free(), data.free()
+    # small batches: the split closing launch sums the variance in another order (below): off here
+    with context_with_env(SVGP_OVERLAP="1", SVGP_SEG_SPLIT="0", **_OV) as c1:
+        model = device_model(c1, sva, dtype=dtype, lik=lik, sigma2=s2)
+        data = _ffi.DeviceData(c1, x, y, dtype)
         for rep in range(4):
             v1, t1 = model.elbo(data, 0, N, 3.0 * N)
             assert v1 == v0 and t1.expectation == t0.expectation and t1.kl == t0.kl, (rep, v1, v0)
-        tm = ctx.timing()
-        # the product default: phase 2 of a batch of fewer strips than workgroup slots in a closing launch of its own, several
-        # workgroups per strip - identical bits run to run, rounding-level agreement with the unsplit launch
-        os.environ["SVGP_SEG_SPLIT"] = "1"
+        tm = c1.timing()
+        assert model.elbo(data, off, N - off, 0.0)[0] == w0
+        model.free(), data.free()
+    # the product default: phase 2 of a batch of fewer strips than workgroup slots in a closing launch of its own, several
+    # workgroups per strip - identical bits run to run, rounding-level agreement with the unsplit launch
+    with context_with_env(SVGP_OVERLAP="1", SVGP_SEG_SPLIT="1", **_OV) as c2:
+        model = device_model(c2, sva, dtype=dtype, lik=lik, sigma2=s2)
+        data = _ffi.DeviceData(c2, x, y, dtype)
         vs = model.elbo(data, 0, N, 3.0 * N)[0]
         assert model.elbo(data, 0, N, 3.0 * N)[0] == vs
         assert rel(vs, v0) < (1e-13 if dtype == np.float64 else 1e-6), (vs, v0)
-        os.environ["SVGP_SEG_SPLIT"] = "0"
-        off = min(17, N - 1)                     # an offset window, ragged end
-        os.environ["SVGP_OVERLAP"] = "0"
-        w0 = model.elbo(data, off, N - off, 0.0)[0]
-        os.environ["SVGP_OVERLAP"] = "1"
-        assert model.elbo(data, off, N - off, 0.0)[0] == w0
-    finally:
-        _restore("SVGP_OVERLAP", old)
-        _restore("SVGP_OVERLAP_MIN_PANELS", oldp)
-        _restore("SVGP_OVERLAP_HEAD", oldh)
-        _restore("SVGP_OVERLAP_HEAD_MIN_PANELS", oldhp)
-        _restore("SVGP_SEG_SPLIT", olds)
+        model.free(), data.free()
     ref = o.elbo(sva, x, y, lik=lik, sigma2=s2, num_data=3.0 * N)
     assert rel(v0, ref) < (1e-8 if dtype == np.float64 else 1e-4)
-    if M >= 256:   # two panels at least: the path was really taken (one launch per panel + the pre-generation [+ the rest of the batch])
-        assert (M + 127) // 128 + 1 <= tm.strip_launches <= (M + 127) // 128 + 3, tm.strip_launches
-    model.free()
-    data.free()
+    nP = (M + 127) // 128
+    took_it = experiments_build() and M >= 256 or (N, M) in ((16384, 1024), (777, 1500), (64, 2048))   # product: >= 5 panels, one round
+    if took_it:   # the path was really taken (one launch per panel + the pre-generation [+ the rest of the batch])
+        assert nP + 1 <= tm.strip_launches <= nP + 3, tm.strip_launches
+        assert tm.ms_overlap > 0.0
 
 
 def test_overlapped_strips_report_a_non_positive_definite_kuu(ctx):
     """The strips beside the factorisation wait for events, not for values: a failed Cholesky (a negative jitter beyond the
     smallest eigenvalue) still records every row event, the strips run on garbage and the call returns SVGP_NOT_POSDEF with the
-    failing order - no waiter is left behind, and the context works afterwards."""
-    N, M, d = 5000, 512, 2
+    failing order - no waiter is left behind, and the context works afterwards.  (Six panels: overlapped in the product build too.)"""
+    N, M, d = 5000, 768, 2
     x, y, sva, s2 = o.synth_problem(6100, N, M, d)
     bad = o.SVA(sva.kernel, sva.z, sva.m, sva.Lq, jitter=-0.5)
-    old = _toggle("SVGP_OVERLAP", "1")
-    try:
-        model = device_model(ctx, bad, sigma2=s2)
-        data = _ffi.DeviceData(ctx, x, y, np.float64)
-        with pytest.raises(_ffi.PosDefException) as ei:
-            model.elbo(data, 0, N, float(N))
-        with pytest.raises(o.PosDefException) as ref:
-            o.posterior(bad)
-        assert ei.value.info == ref.value.info and 0 < ei.value.info <= 512
-        model.free()
-        good = device_model(ctx, sva, sigma2=s2)
-        v = good.elbo(data, 0, N, float(N))[0]
-        assert rel(v, o.elbo(sva, x, y, sigma2=s2, num_data=float(N))) < 1e-8
-        good.free()
-        data.free()
-    finally:
-        _restore("SVGP_OVERLAP", old)
+    model = device_model(ctx, bad, sigma2=s2)
+    data = _ffi.DeviceData(ctx, x, y, np.float64)
+    with pytest.raises(_ffi.PosDefException) as ei:
+        model.elbo(data, 0, N, float(N))
+    with pytest.raises(o.PosDefException) as ref:
+        o.posterior(bad)
+    assert ei.value.info == ref.value.info and 0 < ei.value.info <= M
+    model.free()
+    good = device_model(ctx, sva, sigma2=s2)
+    v = good.elbo(data, 0, N, float(N))[0]
+    assert ctx.timing().ms_overlap > 0.0
+    assert rel(v, o.elbo(sva, x, y, sigma2=s2, num_data=float(N))) < 1e-8
+    good.free()
+    data.free()
 
 
 def test_batches_of_many_rounds_keep_the_one_launch_path(ctx):
@@ -241,12 +225,8 @@ def test_batches_of_many_rounds_keep_the_one_launch_path(ctx):
     x, y, sva, s2 = o.synth_problem(6200, N, M, d)
     model = device_model(ctx, sva, sigma2=s2)
     data = _ffi.DeviceData(ctx, x, y, np.float64)
-    old = _toggle("SVGP_OVERLAP", "1")
-    try:
-        v = model.elbo(data, 0, N, float(N))[0]
-        assert ctx.timing().strip_launches <= 2 and ctx.timing().ms_overlap == 0.0
-    finally:
-        _restore("SVGP_OVERLAP", old)
+    v = model.elbo(data, 0, N, float(N))[0]
+    assert ctx.timing().strip_launches <= 2 and ctx.timing().ms_overlap == 0.0
     assert rel(v, o.elbo(sva, x, y, sigma2=s2, num_data=float(N))) < 1e-8
     model.free()
     data.free()
@@ -256,54 +236,70 @@ def test_batches_of_many_rounds_keep_the_one_launch_path(ctx):
 @pytest.mark.parametrize("N,M,clamp", [(3001, 200, False), (70001, 130, False), (1000, 64, True)])
 def test_uniform_weight_syrk_equals_the_weighted_one(ctx, dtype, gtol, N, M, clamp):
     """Gaussian likelihood: d E_i / d v_i = -1 / (2 sigma^2) for every point, so W = A diag(2 g_v) A' is w A A' and the SYRK runs its
-    unweighted loop (grad.hip: UW).  Against the per-point weighted SYRK (SVGP_SYRK_UNIFORM=0): same gradient to rounding, on
-    batches whose length is not a multiple of the 16-point k-step (the replicated columns of the last strip must not count), over
-    more than one gradient chunk, and with the clamping policy on a posterior with negative variances."""
+    unweighted loop (grad.hip: UW).  Against the per-point weighted SYRK: same gradient to rounding, on batches whose length is not a
+    multiple of the 16-point k-step (the replicated columns of the last strip must not count), over more than one gradient chunk, and
+    with the clamping policy on a posterior with negative variances.  The weighted SYRK is what the host-evaluated route runs
+    (svgp_elbo_grad_ext: the weights are the host's), so the comparison needs no knob: the host hands back exactly the Gaussian's
+    point gradients; in the experiments build SVGP_SYRK_UNIFORM=0 selects the weighted loop for the built-in likelihood as well."""
     x, y, sva, s2 = o.synth_problem(7000 + M, N, M, 3, dtype=dtype)
     if clamp:   # a small NEGATIVE jitter and a tiny cov(q): at the points next to an inducing input k - sum A^2 dips below zero and is
         # clamped (tests/test_gpu_parity.py::test_error_statuses builds its case the same way); their g_v is still -scale / (2 sigma^2)
         x = np.concatenate([np.asarray(sva.z), x[:, : N - M]], axis=1).astype(dtype)
         sva = o.SVA(o.Kernel(o.KERNEL_SE, 1.0, [6.0, 6.0, 6.0]), sva.z, np.zeros(M), 1e-3 * np.eye(M), jitter=-1e-3)
-    model = device_model(ctx, sva, dtype=dtype, sigma2=s2, neg_var_policy=_ffi.NEGVAR_CLAMP if clamp else _ffi.NEGVAR_ERROR)
+    pol = _ffi.NEGVAR_CLAMP if clamp else _ffi.NEGVAR_ERROR
+
+    def host_weights(model, data, off, n):
+        mu, var = model.marginals(data, off, n)
+        yb = np.asarray(y, dtype=np.float64)[off:off + n]
+        sum_e = float(np.sum(-0.5 * (np.log(2 * np.pi * s2) + ((yb - mu) ** 2 + var) / s2)))
+        return sum_e, (yb - mu) / s2, np.full(n, -0.5 / s2)
+
+    model = device_model(ctx, sva, dtype=dtype, sigma2=s2, neg_var_policy=pol)
     data = _ffi.DeviceData(ctx, x, y, dtype)
-    old = _toggle("SVGP_SYRK_UNIFORM", "0")
-    try:
-        v0, t0, g0 = model.elbo_grad(data, 0, N, 2.0 * N)
-        os.environ["SVGP_SYRK_UNIFORM"] = "1"
-        v1, t1, g1 = model.elbo_grad(data, 0, N, 2.0 * N)
-        w1, _, h1 = model.elbo_grad(data, 5, N - 9, 0.0)
-        os.environ["SVGP_SYRK_UNIFORM"] = "0"
-        w0, _, h0 = model.elbo_grad(data, 5, N - 9, 0.0)
-    finally:
-        _restore("SVGP_SYRK_UNIFORM", old)
-    assert v1 == v0 and w1 == w0          # the value does not depend on the SYRK at all
+    v1, t1, g1 = model.elbo_grad(data, 0, N, 2.0 * N)
+    w1, _, h1 = model.elbo_grad(data, 5, N - 9, 0.0)
+    v0, _, g0 = model.elbo_grad(data, 0, N, 2.0 * N, ext=host_weights(model, data, 0, N))
+    w0, _, h0 = model.elbo_grad(data, 5, N - 9, 0.0, ext=host_weights(model, data, 5, N - 9))
+    vt = 1e-12 if dtype == np.float64 else 2e-5   # (the host's sum E against the device's: another summation order)
+    assert rel(v1, v0) < vt and rel(w1, w0) < vt
     if clamp:
         assert t1.n_neg_var > 0
-    for a, b in ((g1, g0), (h1, h0)):
+    pairs = [(g1, g0), (h1, h0)]
+    model.free(), data.free()
+    if experiments_build():
+        with context_with_env(SVGP_SYRK_UNIFORM="0") as c:
+            model = device_model(c, sva, dtype=dtype, sigma2=s2, neg_var_policy=pol)
+            data = _ffi.DeviceData(c, x, y, dtype)
+            vk, _, gk = model.elbo_grad(data, 0, N, 2.0 * N)
+            assert vk == v1          # the value does not depend on the SYRK at all
+            pairs.append((g1, gk))
+            model.free(), data.free()
+    for a, b in pairs:
         for k in ("z", "m", "Lq", "inv_lengthscale"):
             p, q = np.asarray(a[k], dtype=np.float64), np.asarray(b[k], dtype=np.float64)
             assert np.abs(p - q).max() <= gtol * max(np.abs(q).max(), 1e-30), k
         assert abs(a["variance"] - b["variance"]) <= gtol * max(abs(b["variance"]), 1e-12) * 10
-    model.free()
-    data.free()
 
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
 @pytest.mark.parametrize("N,M,d,lik", [(8192, 1024, 8, o.LIK_GAUSSIAN), (3000, 700, 3, o.LIK_BERNOULLI_LOGISTIC), (16384, 640, 8, o.LIK_POISSON_EXP),
                                       (500, 1300, 2, o.LIK_GAUSSIAN)])
-def test_gradient_strips_beside_the_factorisation_are_bitwise_the_serial_result(ctx, dtype, N, M, d, lik):
+def test_gradient_strips_beside_the_factorisation_are_bitwise_the_serial_result(dtype, N, M, d, lik):
     """The training step's strips run their phase 1 beside the factorisation too (segmented, panel I behind the event of block row
     I of T) and their phase 3 behind the M-sized gradient prep (Linv, alpha, R) that the main stream computes meanwhile: value and
-    EVERY gradient block must be identical bits with SVGP_OVERLAP on and off, repeatedly."""
+    EVERY gradient block must be identical bits with SVGP_OVERLAP on and off, repeatedly.  (Five panels or more: overlapped in the
+    product build too.)"""
     x, y, sva, s2 = o.synth_problem(8000 + M, N, M, d, lik=lik, dtype=dtype)
-    model = device_model(ctx, sva, dtype=dtype, lik=lik, sigma2=s2)
-    data = _ffi.DeviceData(ctx, x, y, dtype)
-    old = _toggle("SVGP_OVERLAP", "0")
-    oldp = _toggle("SVGP_OVERLAP_MIN_PANELS", "2")
-    olds = _toggle("SVGP_SEG_SPLIT", "0")   # the split closing launch of small batches sums the variance in another order (test below)
-    try:
+    with context_with_env(SVGP_OVERLAP="0") as c0:
+        model = device_model(c0, sva, dtype=dtype, lik=lik, sigma2=s2)
+        data = _ffi.DeviceData(c0, x, y, dtype)
         v0, t0, g0 = model.elbo_grad(data, 0, N, 2.0 * N)
-        os.environ["SVGP_OVERLAP"] = "1"
+        f0 = model.elbo(data, 0, N, 2.0 * N)[0]
+        model.free(), data.free()
+    # (the split closing launch of small batches sums the variance in another order: off here, on below)
+    with context_with_env(SVGP_OVERLAP="1", SVGP_SEG_SPLIT="0", **_OV) as c1:
+        model = device_model(c1, sva, dtype=dtype, lik=lik, sigma2=s2)
+        data = _ffi.DeviceData(c1, x, y, dtype)
         for rep in range(3):
             v1, t1, g1 = model.elbo_grad(data, 0, N, 2.0 * N)
             assert v1 == v0, (rep, v1, v0)
@@ -311,10 +307,17 @@ def test_gradient_strips_beside_the_factorisation_are_bitwise_the_serial_result(
                 assert np.array_equal(np.asarray(g1[k]), np.asarray(g0[k])), (rep, k)
             for k in ("variance", "lik_sigma2", "mean_const"):
                 assert g1[k] == g0[k], (rep, k)
-        # Split closing launch (the default for batches of fewer strips than workgroup slots): S workgroups per strip share phase 3's
-        # output panels, the variance is summed per part and then over the parts - same operations, another association.  Run-to-run
-        # identical bits; against the unsplit launch: rounding-level agreement.
-        os.environ["SVGP_SEG_SPLIT"] = "1"
+        # the forward entry point between two gradient calls (shared scratch, shared events)
+        assert model.elbo(data, 0, N, 2.0 * N)[0] == f0
+        assert c1.timing().ms_overlap > 0.0
+        assert model.elbo_grad(data, 0, N, 2.0 * N)[0] == v0
+        model.free(), data.free()
+    # Split closing launch (the default for batches of fewer strips than workgroup slots): S workgroups per strip share phase 3's
+    # output panels, the variance is summed per part and then over the parts - same operations, another association.  Run-to-run
+    # identical bits; against the unsplit launch: rounding-level agreement.
+    with context_with_env(SVGP_OVERLAP="1", SVGP_SEG_SPLIT="1", **_OV) as c2:
+        model = device_model(c2, sva, dtype=dtype, lik=lik, sigma2=s2)
+        data = _ffi.DeviceData(c2, x, y, dtype)
         vs, _, gs = model.elbo_grad(data, 0, N, 2.0 * N)
         vs2, _, gs2 = model.elbo_grad(data, 0, N, 2.0 * N)
         assert vs2 == vs
@@ -324,19 +327,9 @@ def test_gradient_strips_beside_the_factorisation_are_bitwise_the_serial_result(
             a, b, c = np.asarray(gs[k], dtype=np.float64), np.asarray(g0[k], dtype=np.float64), np.asarray(gs2[k], dtype=np.float64)
             assert np.array_equal(a, c), k
             assert np.abs(a - b).max() <= gt * max(np.abs(b).max(), 1e-300), (k, np.abs(a - b).max(), np.abs(b).max())
-        os.environ["SVGP_SEG_SPLIT"] = "0"
-        # the forward entry point between two gradient calls (shared scratch, shared events)
-        f1 = model.elbo(data, 0, N, 2.0 * N)[0]
-        os.environ["SVGP_OVERLAP"] = "0"
-        assert model.elbo(data, 0, N, 2.0 * N)[0] == f1
-    finally:
-        _restore("SVGP_OVERLAP", old)
-        _restore("SVGP_OVERLAP_MIN_PANELS", oldp)
-        _restore("SVGP_SEG_SPLIT", olds)
+        model.free(), data.free()
     val_ref, g_ref = o.elbo_grad(sva, x, y, lik=lik, sigma2=s2, num_data=2.0 * N)
     assert rel(v0, val_ref) < (1e-8 if dtype == np.float64 else 1e-4)
-    model.free()
-    data.free()
 
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
@@ -377,11 +370,11 @@ def test_context_without_timing_events():
     (querying an event that was never recorded would be a sticky error)."""
     x, y, sva, s2 = o.synth_problem(5150, 3000, 700, 3, dtype=np.float64)
     ref_ctx = _ffi.Context(0)
-    old = _toggle("SVGP_TIMING", "0")
+    os.environ["SVGP_TIMING"] = "0"
     try:
         quiet = _ffi.Context(0)
     finally:
-        _restore("SVGP_TIMING", old)
+        os.environ.pop("SVGP_TIMING", None)
     out = []
     for c in (ref_ctx, quiet):
         model = device_model(c, sva, dtype=np.float64, sigma2=s2)

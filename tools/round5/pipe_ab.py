@@ -13,10 +13,11 @@ rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 settings = (sys.argv[3] if len(sys.argv) > 3 else "1:1:0,2:1:0,3:1:0,3:2:0,4:2:0").split(",")
 
 def make_ctx(setting):
-    lanes, streams, prio = setting.split(":")
+    lanes, streams, prio, mode = (setting.split(":") + ["1"])[:4]
     os.environ["SVGP_GRAD_PIPELINE"] = lanes; os.environ["SVGP_GRAD_PIPE_STREAMS"] = streams; os.environ["SVGP_GRAD_PIPE_PRIO"] = prio
+    os.environ["SVGP_GRAD_PIPE_MODE"] = mode
     c = _ffi.Context(0)
-    for k in ("SVGP_GRAD_PIPELINE", "SVGP_GRAD_PIPE_STREAMS", "SVGP_GRAD_PIPE_PRIO"): os.environ.pop(k)
+    for k in ("SVGP_GRAD_PIPELINE", "SVGP_GRAD_PIPE_STREAMS", "SVGP_GRAD_PIPE_PRIO", "SVGP_GRAD_PIPE_MODE"): os.environ.pop(k)
     return c
 
 for cfg in cfgs:
@@ -38,6 +39,6 @@ for cfg in cfgs:
             t0 = time.perf_counter(); r["model"].elbo_grad(data=r["data"], off=0, length=n, num_data=float(n)) if False else r["model"].elbo_grad(r["data"], 0, n, float(n)); r["ts"].append(time.perf_counter() - t0)
     for r in runs:
         ts = np.array(r["ts"]) * 1e3
-        print(f"{cfg} lanes:streams:prio {r['st']}: median {np.median(ts):.3f} ms  min {ts.min():.3f} ms  (x{np.median(ts) / np.median(np.array(ref['ts']) * 1e3):.3f} of {ref['st']})", flush=True)
+        print(f"{cfg} lanes:streams:prio[:mode] {r['st']}: median {np.median(ts):.3f} ms  min {ts.min():.3f} ms  (x{np.median(ts) / np.median(np.array(ref['ts']) * 1e3):.3f} of {ref['st']})", flush=True)
     for r in runs:
         r["model"].free(); r["data"].free(); r["ctx"].close()
