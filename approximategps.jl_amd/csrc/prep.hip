@@ -204,6 +204,14 @@ template <typename T>
 struct PivotTail;
 template <>
 struct PivotTail<double> {
+  // Round 5: 7 dependent stages instead of 13.  Rounds 3-4 refined r = 1/sqrt(d) with two Newton steps, formed sqrt(d) with a residual
+  // correction and divided t and sx by it with another (S0 .. S12).  The quotient t / sqrt(d) needs none of the intermediate values:
+  // with r0 = v_rsq_f64(d) (relative error eps ~ 2^-26) and e = 1 - d r0^2 (= -2 eps - eps^2, formed with one FMA from the rounded
+  // product d r0: absolute error 2^-53),  1 / sqrt(d) = r0 (1 - e)^(-1/2) = r0 (1 + e / 2 + 3 e^2 / 8 + O(e^3)), so
+  //   t / sqrt(d) = t r0 + (t r0) e (1/2 + 3/8 e)          (truncation 5/16 e^3 ~ 2^-77; rounding: within 1 ulp of the quotient)
+  // - the same accuracy class as before ("within 1 ulp of sqrt / divide"), half the dependent chain.  SVGP_POTF2_TAIL13=1 (build-time
+  // A/B) keeps the round-4 tail.
+#if defined(SVGP_POTF2_TAIL13) && SVGP_POTF2_TAIL13
   static constexpr int NST = 13;
   double t, sx, d, r, u, h, e, dj, rt, rs, c1, c2;
   template <int J, int S>
@@ -219,6 +227,20 @@ struct PivotTail<double> {
     if constexpr (S == 11) { c1 = fma(-rt, dj, t); c2 = fma(-rs, dj, sx); }
     if constexpr (S == 12) { row[J] = fma(c1, r, rt); x[J] = fma(c2, r, rs); }   // t / sqrt(d), sx / sqrt(d)
   }
+#else
+  static constexpr int NST = 7;
+  double t, sx, d, r, u, e, w, rt, rs;
+  template <int J, int S>
+  __device__ __forceinline__ void stage(double (&row)[16], double (&x)[16], int& bad) {
+    if constexpr (S == 0) { d = row_bcast<J>(t); if (!(d > 0.0) && !bad) bad = J + 1; }
+    if constexpr (S == 1) r = __builtin_amdgcn_rsq(d);                      // r0, ~26 bits
+    if constexpr (S == 2) { u = d * r; rt = t * r; rs = sx * r; }
+    if constexpr (S == 3) e = fma(-u, r, 1.0);                              // 1 - d r0^2
+    if constexpr (S == 4) w = fma(e, 0.375, 0.5);
+    if constexpr (S == 5) w = w * e;                                        // e / 2 + 3 e^2 / 8
+    if constexpr (S == 6) { row[J] = fma(rt, w, rt); x[J] = fma(rs, w, rs); }   // t / sqrt(d), sx / sqrt(d)
+  }
+#endif
 };
 template <>
 struct PivotTail<float> {
@@ -359,6 +381,44 @@ __device__ __forceinline__ void potf2_update_tile(T* __restrict__ sm, int p, int
 // when its factor is done (the round-2 static round-robin left wave 0 waiting 1-5k cycles at every step's barrier: the workers'
 // ~190 tile products per block at 600-950 cycles each exceed wave 0's 8 x 4k chain).  The inverse rows prefetch the operand
 // fragments of the next product before the MFMAs of the current one.
+// Round 5: the queue pop is pipelined - the atomic for the NEXT item is issued before the current item's work and its result read
+// after it (an LDS atomic with return + v_readfirstlane + the index decode sat in front of every ~600-cycle tile) - and the trailing
+// tiles are software-pipelined over two operand sets: the LDS reads of tile k + 1 are in flight during the MFMA chain of tile k.
+// (Each wave pops one index past the end; the counter is reset by the next step.)  SVGP_POTF2_QUEUE_V1=1 (build-time A/B): the round-3 loop.
+template <typename T>
+struct TrailOps {
+  T fa[4], fb[4];
+  typename Mfma16<T>::acc_t acc;
+  int ti, tj;
+};
+template <typename T>
+__device__ __forceinline__ void trail_load(TrailOps<T>& o, const T* __restrict__ sm, int p, int q, int lane) {
+  constexpr int LD = kNB + 1;
+  using M16 = Mfma16<T>;
+  int ti = 0;
+  while (q >= ti + 1) { q -= ti + 1; ++ti; }
+  o.ti = p + 1 + ti; o.tj = p + 1 + q;
+  const int l15 = lane & 15, g = lane >> 4, ob = 16 * p, bi = 16 * o.ti, bj = 16 * o.tj;
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    const int k = 4 * s + g;
+    o.fa[s] = -sm[(bi + l15) * LD + ob + k];
+    o.fb[s] = sm[(bj + l15) * LD + ob + k];
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) o.acc[r] = sm[(bi + M16::row(lane, r)) * LD + bj + l15];
+}
+template <typename T>
+__device__ __forceinline__ void trail_mma_store(TrailOps<T>& o, T* __restrict__ sm, int lane) {
+  constexpr int LD = kNB + 1;
+  using M16 = Mfma16<T>;
+  const int l15 = lane & 15, bi = 16 * o.ti, bj = 16 * o.tj;
+#pragma unroll
+  for (int s = 0; s < 4; ++s) o.acc = M16::mma(o.fa[s], o.fb[s], o.acc);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) sm[(bi + M16::row(lane, r)) * LD + bj + l15] = o.acc[r];
+}
+
 template <typename T>
 __device__ __forceinline__ void potf2_items(T* __restrict__ sm, T* __restrict__ dinv, int* __restrict__ queue, int p, int lane) {
   constexpr int NB = kNB, LD = NB + 1, NBLK = NB / 16, DL = 17;
@@ -367,45 +427,75 @@ __device__ __forceinline__ void potf2_items(T* __restrict__ sm, T* __restrict__ 
   const int l15 = lane & 15, g = lane >> 4, o = 16 * p;
   const bool last = (p + 1 == NBLK);
   const int n = NBLK - p - 1, ntr = n * (n + 1) / 2 - (last ? 0 : 1), nit = p + ntr;
+  auto inverse_tile = [&](int tj2) {   // inverse tile X[p, tj2]
+    T a0[4], b0[4], a1[4], b1[4];   // two operand sets with static names (a runtime-indexed pair lives in scratch memory)
+    auto ld = [&](int sb, T (&a)[4], T (&b)[4]) {
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) {
+        const int k = 4 * s4 + g;
+        a[s4] = sm[(o + l15) * LD + 16 * sb + k];
+        b[s4] = (sb == tj2) ? dinv[(tj2 * 16 + k) * DL + l15] : sm[(16 * tj2 + l15) * LD + 16 * sb + k];
+      }
+    };
+    acc_t acc = {0, 0, 0, 0};
+    ld(tj2, a0, b0);
+    for (int sb = tj2; sb < p; sb += 2) {
+      if (sb + 1 < p) ld(sb + 1, a1, b1);
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) acc = M16::mma(a0[s4], b0[s4], acc);
+      if (sb + 1 < p) {
+        if (sb + 2 < p) ld(sb + 2, a0, b0);
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) acc = M16::mma(a1[s4], b1[s4], acc);
+      }
+    }
+    acc_t x = {0, 0, 0, 0};
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) x = M16::mma(dinv[(p * 16 + l15) * DL + M16::row(lane, s4)], acc[s4], x);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) sm[(16 * tj2 + l15) * LD + o + M16::row(lane, r)] = -x[r];
+  };
+#if defined(SVGP_POTF2_QUEUE_V1) && SVGP_POTF2_QUEUE_V1
   for (;;) {
     int it = 0;
     if (lane == 0) it = atomicAdd(queue, 1);
     it = __builtin_amdgcn_readfirstlane(it);
     if (it >= nit) break;
-    if (it < p) {   // inverse tile X[p, tj2]
-      const int tj2 = it;
-      T a0[4], b0[4], a1[4], b1[4];   // two operand sets with static names (a runtime-indexed pair lives in scratch memory)
-      auto ld = [&](int sb, T (&a)[4], T (&b)[4]) {
-#pragma unroll
-        for (int s4 = 0; s4 < 4; ++s4) {
-          const int k = 4 * s4 + g;
-          a[s4] = sm[(o + l15) * LD + 16 * sb + k];
-          b[s4] = (sb == tj2) ? dinv[(tj2 * 16 + k) * DL + l15] : sm[(16 * tj2 + l15) * LD + 16 * sb + k];
-        }
-      };
-      acc_t acc = {0, 0, 0, 0};
-      ld(tj2, a0, b0);
-      for (int sb = tj2; sb < p; sb += 2) {
-        if (sb + 1 < p) ld(sb + 1, a1, b1);
-#pragma unroll
-        for (int s4 = 0; s4 < 4; ++s4) acc = M16::mma(a0[s4], b0[s4], acc);
-        if (sb + 1 < p) {
-          if (sb + 2 < p) ld(sb + 2, a0, b0);
-#pragma unroll
-          for (int s4 = 0; s4 < 4; ++s4) acc = M16::mma(a1[s4], b1[s4], acc);
-        }
-      }
-      acc_t x = {0, 0, 0, 0};
-#pragma unroll
-      for (int s4 = 0; s4 < 4; ++s4) x = M16::mma(dinv[(p * 16 + l15) * DL + M16::row(lane, s4)], acc[s4], x);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) sm[(16 * tj2 + l15) * LD + o + M16::row(lane, r)] = -x[r];
+    if (it < p) {
+      inverse_tile(it);
     } else {        // trailing tile number q of the lower triangle of the trailing block ((0, 0) is wave 0's unless last)
       int q = it - p + (last ? 0 : 1), ti = 0;
       while (q >= ti + 1) { q -= ti + 1; ++ti; }
       potf2_update_tile<T>(sm, p, p + 1 + ti, p + 1 + q, lane);
     }
   }
+#else
+  auto pop = [&]() { int v = 0; if (lane == 0) v = atomicAdd(queue, 1); return v; };   // lane 0 holds the index; read with readfirstlane LATER
+  const int qoff = last ? 0 : 1;   // trailing tile number = item - p + qoff ((0, 0) is wave 0's unless last)
+  int raw = pop();
+  int it = __builtin_amdgcn_readfirstlane(raw);
+  while (it < p && it < nit) {   // the rows of the block inverse (longest items, first in the queue)
+    raw = pop();
+    inverse_tile(it);
+    it = __builtin_amdgcn_readfirstlane(raw);
+  }
+  if (it >= nit) return;
+  raw = pop();
+  TrailOps<T> o0, o1;
+  trail_load(o0, sm, p, it - p + qoff, lane);
+  for (;;) {
+    int itn = __builtin_amdgcn_readfirstlane(raw);
+    bool more = itn < nit;
+    if (more) { raw = pop(); trail_load(o1, sm, p, itn - p + qoff, lane); }
+    trail_mma_store(o0, sm, lane);
+    if (!more) break;
+    itn = __builtin_amdgcn_readfirstlane(raw);
+    more = itn < nit;
+    if (more) { raw = pop(); trail_load(o0, sm, p, itn - p + qoff, lane); }
+    trail_mma_store(o1, sm, lane);
+    if (!more) break;
+  }
+#endif
 }
 
 template <typename T>
