@@ -205,6 +205,7 @@ KernelParams kparams(const svgp_model* m) {
 // info + the factorisation's hand-over counters and flags: 1 + 2 nP ints, rounded up to 256 bytes - a memset whose size is not a
 // multiple of 16 bytes becomes TWO fill kernels (aligned body + tail), ~5 us of every call's prologue
 inline size_t info_bytes(int64_t Mp) { return (sizeof(int) * size_t(1 + 2 * (Mp / 128)) + 255) / 256 * 256; }
+int ensure_overlap(svgp_ctx* ctx, size_t state_doubles);   // (below) second stream + the row / look-ahead events
 int enqueue_prep(svgp_ctx* ctx, svgp_model* m, bool overlap = false, const RowHook* hook = nullptr) {
   hipStream_t s = ctx->stream;
   const KernelParams kp = kparams(m);
@@ -220,9 +221,18 @@ int enqueue_prep(svgp_ctx* ctx, svgp_model* m, bool overlap = false, const RowHo
   }
   launch_kuu(m->dtype, s, kp, m->zs, m->M, m->Mp, m->desc.jitter, m->L);
   KCHECK(ctx, "kuu");
+  // a large Kuu (more panels than row events: M > 2048) factorises with the bulk trailing updates on the second stream, one panel
+  // behind the chain on this one (prep.hip: potrf_t look-ahead); the row events - unused at that size - are its eight event slots
+  PotrfLookahead la;
+  if (m->Mp / 128 > potrf_max_row_events()) {
+    const int rcl = ensure_overlap(ctx, 0);
+    if (rcl) return rcl;
+    la.s2 = ctx->stream2;
+    la.ev = ctx->ev_row;
+  }
   TREC(ctx, ctx->ev_chol[0], s);
   launch_potrf(m->dtype, s, m->L, m->T, m->Mp, m->info, reinterpret_cast<unsigned*>(m->info + 1), overlap ? ctx->ev_row : nullptr,
-               overlap ? hook : nullptr);   // T panels included
+               overlap ? hook : nullptr, la.s2 ? &la : nullptr);   // T panels included
   KCHECK(ctx, "potrf");
   TREC(ctx, ctx->ev_chol[1], s);
   if (overlap) {

@@ -42,8 +42,11 @@ void launch_kuu(int dtype, hipStream_t s, const KernelParams& kp, const void* zs
 // row hook: called on the host right after row_events[p] is recorded (p = block row of T that has just become final), so that the
 // caller can enqueue the work that waits for that event BEHIND the record and still AHEAD of the device (api.hip: SegRun)
 struct RowHook { void (*fn)(void* user, int row) = nullptr; void* user = nullptr; };
+// look-ahead for a large Kuu (Mp / 128 > potrf_max_row_events(); prep.hip: potrf_t): a second stream for the bulk trailing updates and
+// eight events (four "TRSM of panel p done" + four "bulk update of panel p done", rotated) - nullable: then everything runs on `s`
+struct PotrfLookahead { hipStream_t s2 = nullptr; hipEvent_t* ev = nullptr; };
 void launch_potrf(int dtype, hipStream_t s, void* A, void* T, int64_t Mp, int* info, unsigned* sync, hipEvent_t* row_events = nullptr,
-                  const RowHook* hook = nullptr);
+                  const RowHook* hook = nullptr, const PotrfLookahead* la = nullptr);
 int potrf_max_row_events();
 // U = Lq' (upper triangular, Mp x Mp col-major, zero padding); also mp[i] = m[i] padded with zeros.
 void launch_pack_q(int dtype, hipStream_t s, const void* Lq, const void* m, int64_t M, int64_t Mp, void* U, void* mp);

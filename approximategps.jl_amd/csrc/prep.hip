@@ -240,6 +240,10 @@ struct PivotTail<double> {
     if constexpr (S == 5) w = w * e;                                        // e / 2 + 3 e^2 / 8
     if constexpr (S == 6) { row[J] = fma(rt, w, rt); x[J] = fma(rs, w, rs); }   // t / sqrt(d), sx / sqrt(d)
   }
+  // (measured too, profiles/round5/potf2_ab.md: a 6-stage form - e (t r0 / 2 + e 3/8 t r0) as two FMAs on pre-scaled copies - with the
+  // k = J - 1 term landing on the pre-added sum of the bulk accumulators: one stage and one add less on the chain, three instructions more
+  // per column, and SLOWER (factor16 4.4k -> 4.8k cycles): from J = 3 on a column step is bound by the ISSUE of its 2 J DPP FMACs plus the
+  // tail's instructions, not by the chain's latency)
 #endif
 };
 template <>
@@ -299,6 +303,11 @@ __device__ __forceinline__ void factor16_step(T (&row)[16], T (&x)[16], T (&pt)[
   asm volatile("" : "+v"(pt[0]), "+v"(pt[1]), "+v"(ps[0]), "+v"(ps[1]));
 }
 
+// Round 5, measured and rejected (profiles/round5/potf2_ab.md): a SPLIT factor - lanes 0-31 running the L recurrence and lanes 32-63 the X
+// recurrence in the same instructions (one DPP FMAC per (J, k) instead of two; the pivot and each new column of L duplicated into the
+// upper half by v_permlane32_swap_b32).  Correct (same residuals), but SLOWER: factor16 4.4k -> 5.7k cycles f64, 3.7k -> 4.3k fp32.  The
+// column step is bound by the LATENCY of its dependent chain (~27 cycles per dependent f64 operation for a lone wave), not by the issue
+// cycles of the DPP FMACs, and the two duplications add two stages to every column.
 template <typename T>
 __device__ __forceinline__ int factor16(T* __restrict__ sm, T* __restrict__ dinv, int LD, int DL, int o, int p, int lane) {
   const int l15 = lane & 15;
@@ -365,13 +374,15 @@ __device__ __forceinline__ void potf2_update_tile(T* __restrict__ sm, int p, int
 #pragma unroll
   for (int s = 0; s < 4; ++s) {
     const int k = 4 * s + g;
-    fa[s] = -sm[(bi + l15) * LD + o + k];
+    fa[s] = sm[(bi + l15) * LD + o + k];
     fb[s] = sm[(bj + l15) * LD + o + k];
   }
 #pragma unroll
   for (int r = 0; r < 4; ++r) acc[r] = sm[(bi + M16::row(lane, r)) * LD + bj + l15];
+  // (round 5: the sign is applied HERE - negated at the load, every fragment read was waited for on the spot: three LDS round trips per
+  // tile instead of one)
 #pragma unroll
-  for (int s = 0; s < 4; ++s) acc = M16::mma(fa[s], fb[s], acc);
+  for (int s = 0; s < 4; ++s) acc = M16::mma(-fa[s], fb[s], acc);
 #pragma unroll
   for (int r = 0; r < 4; ++r) sm[(bi + M16::row(lane, r)) * LD + bj + l15] = acc[r];
 }
@@ -381,44 +392,9 @@ __device__ __forceinline__ void potf2_update_tile(T* __restrict__ sm, int p, int
 // when its factor is done (the round-2 static round-robin left wave 0 waiting 1-5k cycles at every step's barrier: the workers'
 // ~190 tile products per block at 600-950 cycles each exceed wave 0's 8 x 4k chain).  The inverse rows prefetch the operand
 // fragments of the next product before the MFMAs of the current one.
-// Round 5: the queue pop is pipelined - the atomic for the NEXT item is issued before the current item's work and its result read
-// after it (an LDS atomic with return + v_readfirstlane + the index decode sat in front of every ~600-cycle tile) - and the trailing
-// tiles are software-pipelined over two operand sets: the LDS reads of tile k + 1 are in flight during the MFMA chain of tile k.
-// (Each wave pops one index past the end; the counter is reset by the next step.)  SVGP_POTF2_QUEUE_V1=1 (build-time A/B): the round-3 loop.
-template <typename T>
-struct TrailOps {
-  T fa[4], fb[4];
-  typename Mfma16<T>::acc_t acc;
-  int ti, tj;
-};
-template <typename T>
-__device__ __forceinline__ void trail_load(TrailOps<T>& o, const T* __restrict__ sm, int p, int q, int lane) {
-  constexpr int LD = kNB + 1;
-  using M16 = Mfma16<T>;
-  int ti = 0;
-  while (q >= ti + 1) { q -= ti + 1; ++ti; }
-  o.ti = p + 1 + ti; o.tj = p + 1 + q;
-  const int l15 = lane & 15, g = lane >> 4, ob = 16 * p, bi = 16 * o.ti, bj = 16 * o.tj;
-#pragma unroll
-  for (int s = 0; s < 4; ++s) {
-    const int k = 4 * s + g;
-    o.fa[s] = -sm[(bi + l15) * LD + ob + k];
-    o.fb[s] = sm[(bj + l15) * LD + ob + k];
-  }
-#pragma unroll
-  for (int r = 0; r < 4; ++r) o.acc[r] = sm[(bi + M16::row(lane, r)) * LD + bj + l15];
-}
-template <typename T>
-__device__ __forceinline__ void trail_mma_store(TrailOps<T>& o, T* __restrict__ sm, int lane) {
-  constexpr int LD = kNB + 1;
-  using M16 = Mfma16<T>;
-  const int l15 = lane & 15, bi = 16 * o.ti, bj = 16 * o.tj;
-#pragma unroll
-  for (int s = 0; s < 4; ++s) o.acc = M16::mma(o.fa[s], o.fb[s], o.acc);
-#pragma unroll
-  for (int r = 0; r < 4; ++r) sm[(bi + M16::row(lane, r)) * LD + bj + l15] = o.acc[r];
-}
-
+// Round 5, measured and rejected (profiles/round5/potf2_ab.md): the queue pop pipelined (the atomic for the next item issued before the
+// current item's work) with the trailing tiles software-pipelined over two operand sets - fp32 unchanged, f64 items 8.5k -> 9.7k cycles in
+// block step 0 (two operand sets in a kernel already at 256 VGPRs + AGPRs).
 template <typename T>
 __device__ __forceinline__ void potf2_items(T* __restrict__ sm, T* __restrict__ dinv, int* __restrict__ queue, int p, int lane) {
   constexpr int NB = kNB, LD = NB + 1, NBLK = NB / 16, DL = 17;
@@ -455,7 +431,6 @@ __device__ __forceinline__ void potf2_items(T* __restrict__ sm, T* __restrict__ 
 #pragma unroll
     for (int r = 0; r < 4; ++r) sm[(16 * tj2 + l15) * LD + o + M16::row(lane, r)] = -x[r];
   };
-#if defined(SVGP_POTF2_QUEUE_V1) && SVGP_POTF2_QUEUE_V1
   for (;;) {
     int it = 0;
     if (lane == 0) it = atomicAdd(queue, 1);
@@ -469,33 +444,6 @@ __device__ __forceinline__ void potf2_items(T* __restrict__ sm, T* __restrict__ 
       potf2_update_tile<T>(sm, p, p + 1 + ti, p + 1 + q, lane);
     }
   }
-#else
-  auto pop = [&]() { int v = 0; if (lane == 0) v = atomicAdd(queue, 1); return v; };   // lane 0 holds the index; read with readfirstlane LATER
-  const int qoff = last ? 0 : 1;   // trailing tile number = item - p + qoff ((0, 0) is wave 0's unless last)
-  int raw = pop();
-  int it = __builtin_amdgcn_readfirstlane(raw);
-  while (it < p && it < nit) {   // the rows of the block inverse (longest items, first in the queue)
-    raw = pop();
-    inverse_tile(it);
-    it = __builtin_amdgcn_readfirstlane(raw);
-  }
-  if (it >= nit) return;
-  raw = pop();
-  TrailOps<T> o0, o1;
-  trail_load(o0, sm, p, it - p + qoff, lane);
-  for (;;) {
-    int itn = __builtin_amdgcn_readfirstlane(raw);
-    bool more = itn < nit;
-    if (more) { raw = pop(); trail_load(o1, sm, p, itn - p + qoff, lane); }
-    trail_mma_store(o0, sm, lane);
-    if (!more) break;
-    itn = __builtin_amdgcn_readfirstlane(raw);
-    more = itn < nit;
-    if (more) { raw = pop(); trail_load(o0, sm, p, itn - p + qoff, lane); }
-    trail_mma_store(o1, sm, lane);
-    if (!more) break;
-  }
-#endif
 }
 
 template <typename T>
@@ -653,7 +601,7 @@ __device__ __forceinline__ void tri_index(int b, int& i, int& j) {  // b -> (i >
 // and written per 4.2 MFLOP).
 template <typename T, int MODE, int NT, bool FUSE = false>
 __global__ void __launch_bounds__(k256, (FUSE && sizeof(T) == 8) ? 1 : 2) chol_tile_kernel(T* __restrict__ A, T* __restrict__ Tm, int64_t ld, int p, int n,
-                                                            int* __restrict__ info, unsigned* __restrict__ sync, int kb = 1) {
+                                                            int* __restrict__ info, unsigned* __restrict__ sync, int kb = 1, int skip = 0) {
   using G = TileGemm<T, NT, 16, k256>;
   using QRegs = typename G::QRegs;
   constexpr int NB = kNB, NCH = NB / NT;
@@ -696,8 +644,8 @@ __global__ void __launch_bounds__(k256, (FUSE && sizeof(T) == 8) ? 1 : 2) chol_t
   } else {                       // A[i, j] -= L[i, p - kb + 1 .. p] L[j, p - kb + 1 .. p]'
     int ti, tj;
     tri_index(tile, ti, tj);
-    i = p + 1 + ti;
-    j = p + 1 + tj;
+    i = p + 1 + skip + ti;   // skip = 1 (look-ahead, potrf_t): the trailing matrix WITHOUT its first block column, which the chain's
+    j = p + 1 + skip + tj;   // MODE_COL launch updates by itself
     P = A + int64_t(j) * NB + int64_t(p - kb + 1) * NB * ld;
   }
   const int kcol = (MODE == MODE_SYRK) ? p - kb + 1 : p;   // first block column of the contraction
@@ -855,7 +803,7 @@ __global__ void __launch_bounds__(k256, sizeof(T) == 8 ? 1 : 2) chol_chain_kerne
 // have not ended).
 template <typename T, bool FUSE>
 __global__ void __launch_bounds__(kThreads, 2) syrk128_kernel(T* __restrict__ A, T* __restrict__ Tm, int64_t ld, int p,
-                                                               int* __restrict__ info, int kb = 1) {
+                                                               int* __restrict__ info, int kb = 1, int skip = 0) {
   using G = TileGemm<T, kNB, 16>;
   using QRegs = typename G::QRegs;
   constexpr int NB = kNB;
@@ -865,7 +813,7 @@ __global__ void __launch_bounds__(kThreads, 2) syrk128_kernel(T* __restrict__ A,
   acc.zero();
   int ti, tj;
   tri_index(blockIdx.x, ti, tj);
-  const int i = p + 1 + ti, j = p + 1 + tj;
+  const int i = p + 1 + skip + ti, j = p + 1 + skip + tj;   // skip = 1: the look-ahead's bulk update (potrf_t)
   const T* P = A + int64_t(j) * NB + int64_t(p - kb + 1) * NB * ld;   // kb = 2: rank-256 update over block columns p - 1, p
   const T* Q = A + int64_t(i) * NB + int64_t(p - kb + 1) * NB * ld;
   const typename G::QOff qoff = G::q_offsets(ld);
@@ -1165,7 +1113,8 @@ void dbg(const char* name, hipStream_t s) {
 }
 
 template <typename T>
-void potrf_t(hipStream_t s, T* A, T* Tm, int64_t Mp, int* info, unsigned* sync, hipEvent_t* row_events, const RowHook* hook) {
+void potrf_t(hipStream_t s, T* A, T* Tm, int64_t Mp, int* info, unsigned* sync, hipEvent_t* row_events, const RowHook* hook,
+             const PotrfLookahead* la) {
   using G = TileGemm<T, kNB, 16>;
   const int nP = int(Mp / kNB);
   constexpr size_t lds_potf2 = potf2_lds_bytes<T>();
@@ -1252,6 +1201,51 @@ void potrf_t(hipStream_t s, T* A, T* Tm, int64_t Mp, int* info, unsigned* sync, 
     return;
   }
 #endif
+  // ---- two-stream look-ahead for a large Kuu (round 5, VERDICT r4 item 3: the variant round 4 wrote down and did not build) --------
+  // One-stream form per panel p: TRSM(p) -> ONE launch that updates the whole trailing matrix and, in the workgroup of tile (p+1, p+1),
+  // factors the next diagonal block (34 us fp32) -> TRSM(p+1) ...: a panel costs max(update, update of one tile + block factorisation)
+  // + TRSM + two launch gaps, and from the panel where the update is shorter than the block factorisation on (C4: the last 33 of 64) the
+  // chip idles behind one workgroup.  Here the chain - update of block column p+1 ALONE (MODE_COL) with the block factorisation fused
+  // into it, then TRSM(p+1) - runs on the main stream, and the bulk - the update of everything right of column p+1 with panel p, which
+  // nothing needs before the column update of panel p+1 - on the second (low-priority) stream, one panel behind:
+  //     main:   TRSM(p) . [wait bulk(p-1)] col(p)+potf2(p+1) . TRSM(p+1) . [wait bulk(p)] col(p+1)+potf2(p+2) ...
+  //     second: [wait TRSM(p)] bulk(p)                                   . [wait TRSM(p+1)] bulk(p+1) ...
+  // A panel costs max(bulk, chain).  Same arithmetic on every tile in the same order (each tile still receives its rank-128 updates
+  // panel by panel): the factor is bitwise the one-stream one.  Events rotate over four slots (a wait captures the record before it).
+  static const bool lookahead_on = exp_int("SVGP_CHOL_LOOKAHEAD", 1) != 0;   // (experiments build: A/B)
+  if (la && la->s2 && la->ev && lookahead_on && fuse_on && !t_inside) {
+    set_max_lds(reinterpret_cast<const void*>(chol_tile_kernel<T, MODE_COL, CNT, true>), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds_fused_s));
+    hipStream_t s2 = la->s2;
+    hipEvent_t* evT = la->ev;
+    hipEvent_t* evB = la->ev + 4;
+    potf2(0);
+    bool bulk_pending = false;
+    for (int p = 0; p < nP; ++p) {
+      const int n = nP - p - 1;
+      if (n == 0) break;
+      hipLaunchKernelGGL((chol_tile_kernel<T, MODE_TRSM, CNT>), dim3(n * NCH), dim3(k256), lds_tile, s, A, Tm, Mp, p, n, info, sync, 1, 0);
+      dbg("chol trsm (look-ahead)", s);
+      const int nb = n - 1, ntb = nb * (nb + 1) / 2;
+      const bool had_bulk = bulk_pending;
+      if (ntb > 0) {   // the bulk: tiles (i, j), i >= j >= p + 2, on the second stream behind this TRSM
+        (void)hipEventRecord(evT[p & 3], s);
+        (void)hipStreamWaitEvent(s2, evT[p & 3], 0);
+        if (ntb >= 256) hipLaunchKernelGGL((syrk128_kernel<T, false>), dim3(ntb), dim3(kThreads), G::LDS_BYTES, s2, A, Tm, Mp, p, info, 1, 1);
+        else hipLaunchKernelGGL((chol_tile_kernel<T, MODE_SYRK, CNT>), dim3(ntb * NCH), dim3(k256), lds_tile, s2, A, Tm, Mp, p, nb, info, sync, 1, 1);
+        dbg("chol bulk update (look-ahead)", s2);
+      }
+      // the chain: column p + 1 must have received the bulk update of panel p - 1 (it covered the columns >= p + 1)
+      if (had_bulk) (void)hipStreamWaitEvent(s, evB[(p - 1) & 3], 0);
+      hipLaunchKernelGGL((chol_tile_kernel<T, MODE_COL, CNT, true>), dim3(n * NCH), dim3(k256), lds_fused_s, s, A, Tm, Mp, p, n, info, sync, 1, 0);
+      dbg("chol column update + potf2 (look-ahead)", s);
+      bulk_pending = ntb > 0;
+      if (bulk_pending) (void)hipEventRecord(evB[p & 3], s2);
+    }
+    // (every bulk update was waited for by the column update of the next panel: the main stream holds the whole factorisation)
+    hipLaunchKernelGGL((chol_tile_kernel<T, MODE_TRSM, CNT>), dim3((nP * (nP - 1) / 2) * NCH), dim3(k256), lds_tile, s, A, Tm, Mp, -1, 0, info, sync, 1, 0);
+    dbg("T panels", s);
+    return;
+  }
   // one launch per panel (chol_chain_kernel) where the whole launch is resident at once.  MEASURED AND NOT ADOPTED
   // (profiles/round4/chol_chain.md): bitwise the same factor, but no faster - M = 1024 f64 0.558-0.561 ms of prep against 0.553-0.561,
   // fp32 0.580-0.588 against 0.552-0.560.  The kernel trace says why: the TRSM launch already starts the instant the fused
@@ -1282,7 +1276,7 @@ void potrf_t(hipStream_t s, T* A, T* Tm, int64_t Mp, int* info, unsigned* sync, 
     if (!trsm_done && n + nt_p > 0) {   // the panel below the diagonal (and the T panels of block row p)
       if (want_ev && ev_ext) {
         hipExtLaunchKernelGGL((chol_tile_kernel<T, MODE_TRSM, CNT>), dim3((n + nt_p) * NCH), dim3(k256), lds_tile, s, nullptr, row_events[p], 0,
-                              A, Tm, Mp, p, n, info, sync, 1);
+                              A, Tm, Mp, p, n, info, sync, 1, 0);
         ev_done = true;
       } else {
         hipLaunchKernelGGL((chol_tile_kernel<T, MODE_TRSM, CNT>), dim3((n + nt_p) * NCH), dim3(k256), lds_tile, s, A, Tm, Mp, p, n, info, sync);
@@ -1364,9 +1358,9 @@ void launch_kuu(int dtype, hipStream_t s, const KernelParams& kp, const void* zs
 // T must be zero above the diagonal on entry (the model's buffer is cleared once at creation): the factorisation writes the
 // lower triangles of the inverted diagonal blocks and the T panels below them only
 void launch_potrf(int dtype, hipStream_t s, void* A, void* T, int64_t Mp, int* info, unsigned* sync, hipEvent_t* row_events,
-                  const RowHook* hook) {
-  SVGP_DISPATCH(dtype, potrf_t<double>(s, (double*)A, (double*)T, Mp, info, sync, row_events, hook),
-                potrf_t<float>(s, (float*)A, (float*)T, Mp, info, sync, row_events, hook));
+                  const RowHook* hook, const PotrfLookahead* la) {
+  SVGP_DISPATCH(dtype, potrf_t<double>(s, (double*)A, (double*)T, Mp, info, sync, row_events, hook, la),
+                potrf_t<float>(s, (float*)A, (float*)T, Mp, info, sync, row_events, hook, la));
 }
 int potrf_max_row_events() { return 16; }   // block rows of T are final one by one only while they ride in the TRSM launches (nP <= 16)
 

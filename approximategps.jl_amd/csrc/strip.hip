@@ -919,11 +919,14 @@ template <typename T, int DREG, int FAMILY, int NBLK = 4>
 __global__ void __launch_bounds__(k256, 2) kuf_kernel(KernelParams kp, const T* __restrict__ zs, int64_t M, int64_t Mp,
                                                     const T* __restrict__ x, int64_t ldx, int64_t off, int64_t len,
                                                     T* __restrict__ K) {
-  constexpr int VEC = Vec16<T>::N, JB = 256, XLD = JB + 16, KS = DREG / 4, WROWS = 16 * NBLK;
+  // Points per block: 256, one staged point per thread.  The 64-feature build (round 5) takes 128: its f64 x image
+  // was 64 x 272 x 8 B = 139 KiB - ONE workgroup per CU, one wave per SIMD, every LDS read -> MFMA chain -> exp -> store serialised
+  // (Hd64: 0.91 TB/s) - and is 74 KiB now: two workgroups per CU.
+  constexpr int VEC = Vec16<T>::N, JB = (DREG == 64 ? 128 : 256), XLD = JB + 16, KS = DREG / 4, WROWS = 16 * NBLK;
   static_assert(NBLK % VEC == 0, "a lane stores VEC consecutive rows");
   using V = typename Vec16<T>::type;
   using acc_t = typename Mfma16<T>::acc_t;
-  static_assert(JB == k256, "one staged point per thread");
+  static_assert(JB <= k256, "at most one staged point per thread");
   __shared__ T xs[DREG * XLD];   // scaled inputs of the block, feature-major
   __shared__ T xn[JB];           // c0 + c1 |x|^2
   const int d = kp.d;
@@ -938,7 +941,7 @@ __global__ void __launch_bounds__(k256, 2) kuf_kernel(KernelParams kp, const T* 
   const T c1 = (FAMILY == KSE) ? T(-0.5) : T(1);
   const T c0 = (FAMILY == KSE) ? T(log(kp.variance)) : T(0);
   const T bscale = (FAMILY == KSE) ? T(1) : T(-2);
-  {
+  if (tid < JB) {
     int64_t g = j0 + tid;
     g = g < len ? g : len - 1;
     T s = T(0);
@@ -954,17 +957,19 @@ __global__ void __launch_bounds__(k256, 2) kuf_kernel(KernelParams kp, const T* 
 #pragma unroll
   for (int b = 0; b < NBLK; ++b) {
     const int64_t i = ibase + (b / VEC) * (16 * VEC) + c * VEC + (b % VEC);
+    // the row norm from the fragment values themselves: lane (c, kq) holds the features 4 q + kq of row c, the four kq groups meet
+    // by two xor-shuffles (round 4 re-read all d features per lane for it: 64 more loads per lane and block at d = 64)
     T s = T(0);
-    for (int f = 0; f < d; ++f) {
-      const T v = (i < Mp) ? zs[int64_t(f) * Mp + i] : T(0);
-      s = fma(v, v, s);
-    }
-    zn[b] = c1 * s;
 #pragma unroll
     for (int q = 0; q < KS; ++q) {
       const int f = 4 * q + kq;
-      zb[b][q] = (f < d && i < Mp) ? bscale * zs[int64_t(f) * Mp + i] : T(0);
+      const T v = (f < d && i < Mp) ? zs[int64_t(f) * Mp + i] : T(0);
+      zb[b][q] = bscale * v;
+      s = fma(v, v, s);
     }
+    s += __shfl_xor(s, 16);
+    s += __shfl_xor(s, 32);
+    zn[b] = c1 * s;
   }
   __syncthreads();
   if (ibase >= M) return;
@@ -1437,9 +1442,9 @@ static void launch_kuf_f(hipStream_t s, const KernelParams& kp, const T* zs, int
     const dim3 grid((unsigned)(((len + 255) / 256) * ((M + 255) / 256)));
 #define SVGP_KUF_LAUNCH(DREG) \
   hipLaunchKernelGGL((kuf_kernel<T, DREG, FAMILY>), grid, dim3(k256), 0, s, kp, zs, M, Mp, x, ldx, off, len, Kuf)
-    if (kp.d > 32) {   // 64 feature rows: VEC blocks of 16 rows per wave
+    if (kp.d > 32) {   // 64 feature rows: VEC blocks of 16 rows per wave, 128 points per block
       constexpr int NB64 = Vec16<T>::N, WGROWS = 64 * NB64;
-      const dim3 g64((unsigned)(((len + 255) / 256) * ((M + WGROWS - 1) / WGROWS)));
+      const dim3 g64((unsigned)(((len + 127) / 128) * ((M + WGROWS - 1) / WGROWS)));
       hipLaunchKernelGGL((kuf_kernel<T, 64, FAMILY, NB64>), g64, dim3(k256), 0, s, kp, zs, M, Mp, x, ldx, off, len, Kuf);
       return;
     }

@@ -233,7 +233,15 @@ typedef struct svgp_grads {
   void* Lq;
 } svgp_grads;
 /* On a context with a communicator: COLLECTIVE — value and gradient of the global ELBO on every rank (the batch size
- * is all-reduced on the device before the backward pass, the gradient by one grouped ncclAllReduce after it). */
+ * is all-reduced on the device before the backward pass, the gradient by one grouped ncclAllReduce after it).
+ * The VALUE this call returns and svgp_elbo's value of the same batch are the same quantity computed along two paths: svgp_elbo takes
+ * the posterior variance as k(x,x) - sum A^2 + sum (B'A)^2 (SVA:251, two column sums), the value-and-gradient strips have no B'A product
+ * and take it from the algebraically equal k_j' (R A)_j, R = Lk^-T (Lq Lq' - I).  In SVGP_F64 the two agree to ~1e-15 relative.  In
+ * SVGP_F32 they differ by rounding: measured |value_grad - value_elbo| / |value_elbo| = 2e-9 ... 3e-7 on the benchmark shapes (H32, C3, C5
+ * at full size) and on ill-conditioned posteriors with a marginal variance down to 4.5e-5 of the prior's (profiles/round5/f32_value_gap.log;
+ * both are within 1e-6 of the fp64 value there) - a host that logs both should expect agreement to ~1e-6 relative in fp32, not to the last
+ * bit (tests/test_gpu_round5.py asserts 2e-6).  The fp32 gradient blocks on those posteriors stay within 5e-5 (m, Lq) / 5e-4 (z, inverse
+ * lengthscales) of the fp64 gradient, relative to each block's largest entry. */
 int32_t svgp_elbo_grad(svgp_ctx* ctx, svgp_model* model, const svgp_data* data, int64_t batch_off, int64_t batch_len,
                        double num_data, double* elbo_out, svgp_terms* terms_out, svgp_grads* grads_out);
 /* the same two evaluations driven from one process over the members of a group: member i evaluates points
