@@ -221,10 +221,11 @@ int enqueue_prep(svgp_ctx* ctx, svgp_model* m, bool overlap = false, const RowHo
   }
   launch_kuu(m->dtype, s, kp, m->zs, m->M, m->Mp, m->desc.jitter, m->L);
   KCHECK(ctx, "kuu");
-  // a large Kuu (more panels than row events: M > 2048) factorises with the bulk trailing updates on the second stream, one panel
-  // behind the chain on this one (prep.hip: potrf_t look-ahead); the row events - unused at that size - are its eight event slots
+  // (experiments build, SVGP_CHOL_LOOKAHEAD=1: a large Kuu - more panels than row events, M > 2048 - factorises with the bulk trailing
+  // updates on the second stream, one panel behind the chain on this one; measured slower, prep.hip: potrf_t.  The row events - unused
+  // at that size - are its eight event slots)
   PotrfLookahead la;
-  if (m->Mp / 128 > potrf_max_row_events()) {
+  if (kExperiments && exp_int("SVGP_CHOL_LOOKAHEAD", 0) != 0 && m->Mp / 128 > potrf_max_row_events()) {
     const int rcl = ensure_overlap(ctx, 0);
     if (rcl) return rcl;
     la.s2 = ctx->stream2;

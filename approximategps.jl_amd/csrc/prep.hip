@@ -1201,7 +1201,8 @@ void potrf_t(hipStream_t s, T* A, T* Tm, int64_t Mp, int* info, unsigned* sync, 
     return;
   }
 #endif
-  // ---- two-stream look-ahead for a large Kuu (round 5, VERDICT r4 item 3: the variant round 4 wrote down and did not build) --------
+  // ---- two-stream look-ahead for a large Kuu (round 5, VERDICT r4 item 3: the variant round 4 wrote down and did not build; built now,
+  //      measured, not adopted - see the table below) ------------------------------------------------------------------------------
   // One-stream form per panel p: TRSM(p) -> ONE launch that updates the whole trailing matrix and, in the workgroup of tile (p+1, p+1),
   // factors the next diagonal block (34 us fp32) -> TRSM(p+1) ...: a panel costs max(update, update of one tile + block factorisation)
   // + TRSM + two launch gaps, and from the panel where the update is shorter than the block factorisation on (C4: the last 33 of 64) the
@@ -1212,7 +1213,16 @@ void potrf_t(hipStream_t s, T* A, T* Tm, int64_t Mp, int* info, unsigned* sync, 
   //     second: [wait TRSM(p)] bulk(p)                                   . [wait TRSM(p+1)] bulk(p+1) ...
   // A panel costs max(bulk, chain).  Same arithmetic on every tile in the same order (each tile still receives its rank-128 updates
   // panel by panel): the factor is bitwise the one-stream one.  Events rotate over four slots (a wait captures the record before it).
-  static const bool lookahead_on = exp_int("SVGP_CHOL_LOOKAHEAD", 1) != 0;   // (experiments build: A/B)
+  // MEASURED AND NOT ADOPTED (profiles/round5/chol_lookahead_ab.log; same process pair, ms per factorisation, look-ahead off / on):
+  //     fp32 M = 2304  0.89 / 1.02     4096  1.66 / 1.93     8192  4.66 / 5.02-5.06        f64 M = 2304  0.97 / 1.12     4096  2.05 / 2.26
+  // - bitwise the same factor, 8-15 % SLOWER: every panel now carries two cross-stream event dependencies (TRSM -> bulk, bulk -> next
+  // column update), each a barrier packet + a signal wait of several microseconds on BOTH queues, plus one more launch on the chain
+  // (column update + block factorisation instead of riding in the big update) - 63 panels x ~6 us at M = 8192 - and that is more than
+  // the idle time the look-ahead reclaims from the late panels.  The one-stream form (the workgroup of tile (p+1, p+1) goes straight on to
+  // the block factorisation while the other workgroups finish the trailing update) already IS a look-ahead with no synchronisation
+  // cost.  Experiments build only: SVGP_CHOL_LOOKAHEAD=1.
+#ifdef SVGP_EXPERIMENTS
+  static const bool lookahead_on = exp_int("SVGP_CHOL_LOOKAHEAD", 0) != 0;
   if (la && la->s2 && la->ev && lookahead_on && fuse_on && !t_inside) {
     set_max_lds(reinterpret_cast<const void*>(chol_tile_kernel<T, MODE_COL, CNT, true>), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds_fused_s));
     hipStream_t s2 = la->s2;
@@ -1246,6 +1256,9 @@ void potrf_t(hipStream_t s, T* A, T* Tm, int64_t Mp, int* info, unsigned* sync, 
     dbg("T panels", s);
     return;
   }
+#else
+  (void)la;
+#endif
   // one launch per panel (chol_chain_kernel) where the whole launch is resident at once.  MEASURED AND NOT ADOPTED
   // (profiles/round4/chol_chain.md): bitwise the same factor, but no faster - M = 1024 f64 0.558-0.561 ms of prep against 0.553-0.561,
   // fp32 0.580-0.588 against 0.552-0.560.  The kernel trace says why: the TRSM launch already starts the instant the fused

@@ -128,3 +128,34 @@ def test_operational_settings_are_read_at_context_creation():
     assert res["off"][0] == res["on"][0]
     assert res["off"][1] == 0.0 and res["on"][1] > 0.0          # each context kept the setting it was created with
     assert res["off"][2] > 0.0 and res["on"][2] > 0.0           # ... and its timing events
+
+
+@pytest.mark.parametrize("dtype,tol", [(np.float64, 1e-9), (np.float32, 2e-3)])
+def test_large_kuu_factorisation(ctx, dtype, tol):
+    """M = 2300 (18 panels: more than the 16 row events, so cholesky(Kuu) takes the large-Kuu path: 512-thread trailing updates with
+    the next block factorisation fused in, one T-panel launch at the end; in the experiments build with SVGP_CHOL_LOOKAHEAD=1 the
+    two-stream look-ahead that round 5 measured and rejected).  The factor must be LAPACK's to rounding, the ELBO the oracle's, and
+    repeated evaluations identical bits (a missing dependency would show as a run-to-run difference or a wrong tile)."""
+    N, M, d = 3000, 2300, 3
+    x, y, sva, s2 = o.synth_problem(8700, N, M, d, dtype=dtype)
+    model = device_model(ctx, sva, dtype=dtype, sigma2=s2)
+    data = _ffi.DeviceData(ctx, x, y, dtype)
+    vals = {model.elbo(data, 0, N, float(N))[0] for _ in range(6)}
+    assert len(vals) == 1, vals
+    Lk, alpha, B = model.posterior()
+    K = o.kuu(sva)
+    L = np.tril(np.asarray(Lk, dtype=np.float64))
+    back = np.linalg.norm(L @ L.T - K) / np.linalg.norm(K)
+    assert back < (5e-15 if dtype == np.float64 else 2e-6), back
+    Lref = np.linalg.cholesky(K)
+    assert np.abs(L - Lref).max() <= tol * np.abs(Lref).max()
+    assert rel(vals.pop(), o.elbo(sva, x, y, sigma2=s2, num_data=float(N))) < (1e-8 if dtype == np.float64 else 1e-4)
+    # a non-positive-definite Kuu is reported with LAPACK's info through these launches too
+    bad = device_model(ctx, o.SVA(sva.kernel, sva.z, sva.m, sva.Lq, jitter=-0.5), dtype=dtype, sigma2=s2)
+    with pytest.raises(_ffi.PosDefException) as ei:
+        bad.elbo(data, 0, N, float(N))
+    assert 0 < ei.value.info <= M
+    assert model.elbo(data, 0, N, float(N))[0] == model.elbo(data, 0, N, float(N))[0]
+    bad.free()
+    model.free()
+    data.free()
