@@ -343,6 +343,13 @@ struct TileGemm {
     return (wave % WC) * (NJ * 16) + j * 16 + (lane & 15);
   }
 
+  // Workgroup barriers a thread executes inside one call of the loops below - for kernels that keep PASSENGER waves at the loops'
+  // barriers (prep.hip: the 512-thread fused factorisation kernels, whose waves 4-7 only join the block factorisation afterwards):
+  // loop / loop_tri: the prologue's, one per step, the closing one; loop_tri_async(_w): the prologue's, one per step but the last, the
+  // closing one.  KEEP IN STEP WITH THE LOOPS (a miscount deadlocks those kernels; tests/test_gpu_round5.py runs them).
+  static constexpr int loop_barrier_count(int nsteps) { return nsteps <= 0 ? 0 : nsteps + 2; }
+  static constexpr int async_barrier_count(int nsteps) { return nsteps <= 0 ? 0 : nsteps + 1; }
+
   // --- the K loop -----------------------------------------------------------------------------------
   // P tile of step t is Pbase + t*BK*ldp (Pbase wave-uniform); QLoad::operator()(step, QRegs&) produces the
   // Q tile of a step.  Software pipeline, written so that the steady state issues (almost) nothing but

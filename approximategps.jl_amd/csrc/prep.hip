@@ -449,10 +449,14 @@ __device__ __forceinline__ void potf2_items(T* __restrict__ sm, T* __restrict__ 
 template <typename T>
 constexpr size_t potf2_lds_bytes() { return (size_t(kNB) * (kNB + 1) + 8 * 16 * 17) * sizeof(T); }
 
-template <typename T>
+// NW (round 5): waves of the workgroup that take part - 4 (256 threads: the round 1-4 shape) or 8 (512 threads).  Wave 0 runs the column
+// chain; with seven worker waves instead of three the block steps whose tiles outlast the chain (steps 0-2 and the last) become
+// chain-bound, the panel solves take one pass and the load / store phases have twice the loads in flight.
+template <typename T, int NW = 4>
 __device__ __forceinline__ void potf2_body(T* __restrict__ A, T* __restrict__ Tm, int64_t ld, int* __restrict__ info, int pbase,
                                               unsigned char* __restrict__ smem_raw) {
-  constexpr int NB = kNB, LD = NB + 1, NBLK = NB / 16, DL = 17;
+  constexpr int NB = kNB, LD = NB + 1, NBLK = NB / 16, DL = 17, NTH = 64 * NW;
+  static_assert((NB * NB) % (NTH * 16) == 0, "the load / store passes move 16 elements per thread");
   using M16 = Mfma16<T>;
   using acc_t = typename M16::acc_t;
   T* sm = reinterpret_cast<T*>(smem_raw);   // [128][129] row-major block; strictly-upper 16-blocks later hold X'
@@ -468,16 +472,16 @@ __device__ __forceinline__ void potf2_body(T* __restrict__ A, T* __restrict__ Tm
     // or skipping the 16-blocks above the diagonal with a predicate, are not faster (7.5k cycles of the f64 block's 88k either way:
     // one CU's share of the memory pipe)
     constexpr int U = 16;
-    for (int e0 = tid; e0 < NB * NB; e0 += k256 * U) {
+    for (int e0 = tid; e0 < NB * NB; e0 += NTH * U) {
       T v[U];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-        const int e = e0 + u * k256;
+        const int e = e0 + u * NTH;
         v[u] = A[(e % NB) + int64_t(e / NB) * ld];
       }
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-        const int e = e0 + u * k256;
+        const int e = e0 + u * NTH;
         sm[(e % NB) * LD + e / NB] = v[u];
       }
     }
@@ -500,7 +504,7 @@ __device__ __forceinline__ void potf2_body(T* __restrict__ A, T* __restrict__ Tm
       return;
     }
     // ---- panel: L[t, p] = A[t, p] inv(D_p)' ----
-    for (int t = p + 1 + wave; t < NBLK; t += 4) {
+    for (int t = p + 1 + wave; t < NBLK; t += NW) {
       acc_t acc = {0, 0, 0, 0};
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
@@ -522,7 +526,10 @@ __device__ __forceinline__ void potf2_body(T* __restrict__ A, T* __restrict__ Tm
       SVGP_STAMP(45 + 2 * p);
     }
     SVGP_STAMPW(64 + 4 * p);
-    potf2_items<T>(sm, dinv, &queue, p, lane);
+    // 512 threads: waves w and w + 4 share a SIMD (a workgroup's waves are dealt cyclically over the four), and f64 MFMA and VALU work
+    // never co-execute on one: with wave 4 pulling tiles beside it wave 0's column chain ran 5.2 k instead of 4.4 k cycles per 16 x 16
+    // factor (stamps, profiles/round5/potf2_ab.md).  Wave 4 therefore sits out the steps that carry a factor: six workers.
+    if (!(NW == 8 && wave == 4 && !last)) potf2_items<T>(sm, dinv, &queue, p, lane);
     SVGP_STAMPW(66 + 4 * p);
     __syncthreads();
     SVGP_STAMP(4 + 4 * p);
@@ -534,17 +541,17 @@ __device__ __forceinline__ void potf2_body(T* __restrict__ A, T* __restrict__ Tm
   SVGP_STAMP(40);
   {
     constexpr int U = 16;
-    for (int e0 = tid; e0 < NB * NB; e0 += k256 * U) {
+    for (int e0 = tid; e0 < NB * NB; e0 += NTH * U) {
       T lv[U], xv[U];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-        const int e = e0 + u * k256, r = e % NB, c = e / NB;
+        const int e = e0 + u * NTH, r = e % NB, c = e / NB;
         lv[u] = sm[r * LD + c];
         xv[u] = ((r >> 4) == (c >> 4)) ? dinv[((r >> 4) * 16 + (r & 15)) * DL + (c & 15)] : sm[c * LD + r];
       }
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-        const int e = e0 + u * k256, r = e % NB, c = e / NB;
+        const int e = e0 + u * NTH, r = e % NB, c = e / NB;
         if (r >= c) {   // Tm is zero above the diagonal on entry and stays so (launch_potrf's contract): nothing to store there
           A[r + int64_t(c) * ld] = lv[u];
           Tm[r + int64_t(c) * ld] = xv[u];
@@ -557,10 +564,10 @@ __device__ __forceinline__ void potf2_body(T* __restrict__ A, T* __restrict__ Tm
 
 
 template <typename T>
-__global__ void __launch_bounds__(k256) potf2_kernel(T* __restrict__ A, T* __restrict__ Tm, int64_t ld,
-                                                      int* __restrict__ info, int pbase) {
+__global__ void __launch_bounds__(kThreads, 2) potf2_kernel(T* __restrict__ A, T* __restrict__ Tm, int64_t ld,
+                                                             int* __restrict__ info, int pbase) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  potf2_body<T>(A, Tm, ld, info, pbase, smem_raw);
+  potf2_body<T, kThreads / 64>(A, Tm, ld, info, pbase, smem_raw);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -599,17 +606,28 @@ __device__ __forceinline__ void tri_index(int b, int& i, int& j) {  // b -> (i >
 // that rest then takes ONE update of rank 256 (kb = 2: the contraction runs over the two block columns p - 1, p) instead of two of
 // rank 128: half the read-modify-write traffic of the trailing matrix, which is what bounds these launches (a 128 x 128 tile read
 // and written per 4.2 MFLOP).
-template <typename T, int MODE, int NT, bool FUSE = false>
-__global__ void __launch_bounds__(k256, (FUSE && sizeof(T) == 8) ? 1 : 2) chol_tile_kernel(T* __restrict__ A, T* __restrict__ Tm, int64_t ld, int p, int n,
+// P8 (round 5, FUSE only): the kernel is launched with 512 threads.  Waves 0-3 are the 256-thread tile kernel unchanged (TileGemm
+// indexes by threadIdx.x < 256); waves 4-7 are PASSENGERS that only execute the tile loop's barriers (TileGemm::*_barrier_count: same
+// count by construction of the loops) and then join the block factorisation, which so has seven worker waves instead of three.
+// One workgroup per CU (the block's LDS image), so potrf_t takes this form only where the launch fits the chip in one round anyway.
+template <typename T, int MODE, int NT, bool FUSE = false, bool P8 = false>
+__global__ void __launch_bounds__(P8 ? kThreads : k256, P8 ? 2 : ((FUSE && sizeof(T) == 8) ? 1 : 2)) chol_tile_kernel(T* __restrict__ A, T* __restrict__ Tm, int64_t ld, int p, int n,
                                                             int* __restrict__ info, unsigned* __restrict__ sync, int kb = 1, int skip = 0) {
   using G = TileGemm<T, NT, 16, k256>;
   using QRegs = typename G::QRegs;
   constexpr int NB = kNB, NCH = NB / NT;
+  static_assert(!P8 || (FUSE && MODE == MODE_SYRK), "passenger waves exist for the fused trailing update only");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   T* smem = reinterpret_cast<T*>(smem_raw);
   typename G::Acc acc;
   acc.zero();
   const int chunk = blockIdx.x % NCH, tile = blockIdx.x / NCH;
+  const bool passenger = P8 && threadIdx.x >= k256;   // wave-uniform
+  if (passenger) {
+    const int nst = (MODE == MODE_SYRK ? kb : 1) * (NB / 16);
+    const int nbar = (SVGP_CHOL_TILE_ASYNC && G::kAsync) ? G::async_barrier_count(nst) : G::loop_barrier_count(nst);
+    for (int q = 0; q < nbar; ++q) __builtin_amdgcn_s_barrier();
+  } else {
   if (MODE == MODE_TRSM && (p < 0 || tile >= n)) {   // T[p, J] = -inv(L_pp) L[p, J]
     int J = tile - n;
     if (p < 0) {   // all block rows in one launch (large Kuu: potrf_t): tile -> (row I >= 1, column J < I)
@@ -674,6 +692,7 @@ __global__ void __launch_bounds__(k256, (FUSE && sizeof(T) == 8) ? 1 : 2) chol_t
         if (MODE == MODE_TRSM) *dst = acc.v[a][b][r];
         else *dst -= acc.v[a][b][r];
       }
+  }   // (!passenger)
   if constexpr (FUSE && (MODE == MODE_SYRK || MODE == MODE_COL)) {
     if (tile != 0) return;         // tile 0 = (p+1, p+1): the next diagonal block
     __shared__ int is_last;
@@ -683,7 +702,7 @@ __global__ void __launch_bounds__(k256, (FUSE && sizeof(T) == 8) ? 1 : 2) chol_t
     __syncthreads();
     if (!is_last) return;
     __threadfence();               // acquire: the other chunks' stores (other CUs, possibly other XCDs) before the loads below
-    potf2_body<T>(A + int64_t(p + 1) * NB * (ld + 1), Tm + int64_t(p + 1) * NB * (ld + 1), ld, info, (p + 1) * NB, smem_raw);
+    potf2_body<T, P8 ? 8 : 4>(A + int64_t(p + 1) * NB * (ld + 1), Tm + int64_t(p + 1) * NB * (ld + 1), ld, info, (p + 1) * NB, smem_raw);
   }
 }
 
@@ -830,8 +849,7 @@ __global__ void __launch_bounds__(kThreads, 2) syrk128_kernel(T* __restrict__ A,
     if (blockIdx.x != 0) return;
     __threadfence();               // the tile this workgroup just wrote is re-read below (through L2: drop stale L1 lines)
     __syncthreads();
-    if (threadIdx.x >= k256) return;
-    potf2_body<T>(A + int64_t(p + 1) * NB * (ld + 1), Tm + int64_t(p + 1) * NB * (ld + 1), ld, info, (p + 1) * NB, smem_raw);
+    potf2_body<T, kThreads / 64>(A + int64_t(p + 1) * NB * (ld + 1), Tm + int64_t(p + 1) * NB * (ld + 1), ld, info, (p + 1) * NB, smem_raw);
   }
 }
 
@@ -1130,8 +1148,18 @@ void potrf_t(hipStream_t s, T* A, T* Tm, int64_t Mp, int* info, unsigned* sync, 
   set_max_lds(reinterpret_cast<const void*>(chol_tile_kernel<T, MODE_TRSM, CNT>), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds_tile));
   set_max_lds(reinterpret_cast<const void*>(chol_tile_kernel<T, MODE_SYRK, CNT>), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds_tile));
   set_max_lds(reinterpret_cast<const void*>(chol_tile_kernel<T, MODE_SYRK, CNT, true>), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds_fused_s));
+  set_max_lds(reinterpret_cast<const void*>(chol_tile_kernel<T, MODE_SYRK, CNT, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds_fused_s));
+  // the 512-thread fused form (seven worker waves in the block factorisation) holds one workgroup per CU: taken where the launch fits
+  // the chip in one round that way (SVGP_POTF2_WAVES=4 in the experiments build: always the 256-thread form)
+  static const int ncus = [] {
+    hipDeviceProp_t prop;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
+    return prop.multiProcessorCount;
+  }();
+  static const bool p8_on = exp_int("SVGP_POTF2_WAVES", 8) == 8;
   auto potf2 = [&](int p) {
-    hipLaunchKernelGGL(potf2_kernel<T>, dim3(1), dim3(k256), lds_potf2, s, A + int64_t(p) * kNB * (Mp + 1), Tm + int64_t(p) * kNB * (Mp + 1), Mp,
+    hipLaunchKernelGGL(potf2_kernel<T>, dim3(1), dim3(kThreads), lds_potf2, s, A + int64_t(p) * kNB * (Mp + 1), Tm + int64_t(p) * kNB * (Mp + 1), Mp,
                        info, p * kNB);
     dbg("potf2", s);
   };
@@ -1315,7 +1343,10 @@ void potrf_t(hipStream_t s, T* A, T* Tm, int64_t Mp, int* info, unsigned* sync, 
     if (fused && large) {
       big_update(nt, p, 1);
     } else if (fused) {
-      hipLaunchKernelGGL((chol_tile_kernel<T, MODE_SYRK, CNT, true>), dim3(nt * NCH), dim3(k256), lds_fused_s, s, A, Tm, Mp, p, n, info, sync);
+      if (p8_on && nt * NCH <= ncus)
+        hipLaunchKernelGGL((chol_tile_kernel<T, MODE_SYRK, CNT, true, true>), dim3(nt * NCH), dim3(kThreads), lds_fused_s, s, A, Tm, Mp, p, n, info, sync);
+      else
+        hipLaunchKernelGGL((chol_tile_kernel<T, MODE_SYRK, CNT, true>), dim3(nt * NCH), dim3(k256), lds_fused_s, s, A, Tm, Mp, p, n, info, sync);
     } else {
       if (large) hipLaunchKernelGGL((syrk128_kernel<T, false>), dim3(nt), dim3(kThreads), G::LDS_BYTES, s, A, Tm, Mp, p, info);
       else hipLaunchKernelGGL((chol_tile_kernel<T, MODE_SYRK, CNT>), dim3(nt * NCH), dim3(k256), lds_tile, s, A, Tm, Mp, p, n, info, sync);
