@@ -9,7 +9,7 @@ from approxgp import _ffi
 ctx = _ffi.Context(0)
 out = []
 for dt in os.environ.get("POTF2_DTYPES", "f64,f32").split(","):   # the stamps printed below are those of the LAST dtype
-    p = bench.synth(3, 4096, 128, 8, 0, 0, dt)
+    p = bench.synth(3, 4096, int(os.environ.get("POTF2_M", "128")), 8, 0, 0, dt)   # POTF2_M=256: the stamps are those of the FUSED launch's block (the last one factored)
     desc, keep = _ffi.make_desc(p["np_dt"], 0, p["variance"], p["inv_l"], p["z"], p["m"], p["Lq"], p["jitter"], likelihood=0, lik_sigma2=p["sigma2"], neg_var_policy=_ffi.NEGVAR_CLAMP)
     model = _ffi.DeviceModel(ctx, desc, keep)
     data = _ffi.DeviceData(ctx, p["x"], p["y"], p["np_dt"])
