@@ -12,6 +12,11 @@
 
 #include <hip/hip_ext.h>
 #include <cstdlib>
+#include <algorithm>
+#include <cmath>
+#include <map>
+#include <mutex>
+#include <vector>
 
 namespace svgp {
 namespace {
@@ -822,7 +827,7 @@ __global__ void __launch_bounds__(k256, sizeof(T) == 8 ? 1 : 2) chol_chain_kerne
 // have not ended).
 template <typename T, bool FUSE>
 __global__ void __launch_bounds__(kThreads, 2) syrk128_kernel(T* __restrict__ A, T* __restrict__ Tm, int64_t ld, int p,
-                                                               int* __restrict__ info, int kb = 1, int skip = 0) {
+                                                               int* __restrict__ info, int kb = 1, int skip = 0, const int* __restrict__ perm = nullptr) {
   using G = TileGemm<T, kNB, 16>;
   using QRegs = typename G::QRegs;
   constexpr int NB = kNB;
@@ -831,7 +836,14 @@ __global__ void __launch_bounds__(kThreads, 2) syrk128_kernel(T* __restrict__ A,
   typename G::Acc acc;
   acc.zero();
   int ti, tj;
-  tri_index(blockIdx.x, ti, tj);
+  if (perm) {   // XCD-aware tile order (potrf_t: xcd_tile_order): workgroup b -> tile perm[b] (row << 16 | column), -1: no tile
+    const int code = perm[blockIdx.x];
+    if (code < 0) return;
+    ti = code >> 16;
+    tj = code & 0xffff;
+  } else {
+    tri_index(blockIdx.x, ti, tj);
+  }
   const int i = p + 1 + skip + ti, j = p + 1 + skip + tj;   // skip = 1: the look-ahead's bulk update (potrf_t)
   const T* P = A + int64_t(j) * NB + int64_t(p - kb + 1) * NB * ld;   // kb = 2: rank-256 update over block columns p - 1, p
   const T* Q = A + int64_t(i) * NB + int64_t(p - kb + 1) * NB * ld;
@@ -846,7 +858,7 @@ __global__ void __launch_bounds__(kThreads, 2) syrk128_kernel(T* __restrict__ A,
 #pragma unroll
       for (int b = 0; b < G::NJ; ++b) C[G::acc_col(b) + int64_t(G::acc_row(a, r)) * ld] -= acc.v[a][b][r];
   if constexpr (FUSE) {
-    if (blockIdx.x != 0) return;
+    if (ti != 0 || tj != 0) return;   // the owner of tile (p+1, p+1) - workgroup 0 in either tile order - goes on to factor it
     __threadfence();               // the tile this workgroup just wrote is re-read below (through L2: drop stale L1 lines)
     __syncthreads();
     potf2_body<T, kThreads / 64>(A + int64_t(p + 1) * NB * (ld + 1), Tm + int64_t(p + 1) * NB * (ld + 1), ld, info, (p + 1) * NB, smem_raw);
@@ -1130,6 +1142,62 @@ void dbg(const char* name, hipStream_t s) {
   if (e != hipSuccess) leave_note(std::string("SVGP_DEBUG_SYNC: ") + name + ": " + hipGetErrorString(e));   // -> svgp_last_error
 }
 
+// XCD-aware tile order of the large trailing update (round 5 experiment, SVGP_SYRK_XCD=1 in the experiments build).  The dispatcher deals
+// workgroups round-robin over the 8 XCDs (b and b + 8 share one; each XCD has its own 4 MiB L2).  In row-major triangle order every XCD
+// works on every 8th tile of every row, so each XCD streams the WHOLE panel L[:, p] (4 MB at 63 block rows, fp32) through its L2 for
+// both operands.  Here the triangle is cut into 8 x 8 super-tiles (16 operand blocks = 1 MB for 64 tiles), the super-tiles are dealt to
+// the XCDs (largest first, to the least loaded), and workgroup b = 8 k + x takes the k-th tile of XCD x's list; lists are padded
+// with -1 to the longest.  The super-tile of tile (0, 0) - whose workgroup carries the next block factorisation - comes first in its list.
+struct XcdOrder { int grid = 0; int* dev = nullptr; };
+const XcdOrder& xcd_tile_order(int n) {
+  static std::mutex mu;
+  static std::map<std::pair<int, int>, XcdOrder> cache;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  std::lock_guard<std::mutex> lk(mu);
+  auto it = cache.find({dev, n});
+  if (it != cache.end()) return it->second;
+  constexpr int S = 8, NX = 8;
+  const int G = (n + S - 1) / S;
+  struct Sup { int I, J, cnt; };
+  std::vector<Sup> sup;
+  for (int I = 0; I < G; ++I)
+    for (int J = 0; J <= I; ++J) {
+      int cnt = 0;
+      for (int ti = I * S; ti < std::min(n, (I + 1) * S); ++ti)
+        for (int tj = J * S; tj < std::min(n, (J + 1) * S); ++tj) cnt += (tj <= ti);
+      sup.push_back({I, J, cnt});
+    }
+  std::vector<int> order(sup.size());
+  for (size_t q = 0; q < order.size(); ++q) order[q] = int(q);
+  std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return sup[a].cnt > sup[b].cnt; });
+  std::vector<std::vector<int>> lists(NX);   // super-tile indices per XCD
+  std::vector<int> load(NX, 0);
+  for (int q : order) {
+    int x = 0;
+    for (int y = 1; y < NX; ++y) if (load[y] < load[x]) x = y;
+    if (sup[q].I == 0 && sup[q].J == 0) lists[x].insert(lists[x].begin(), q); else lists[x].push_back(q);
+    load[x] += sup[q].cnt;
+  }
+  const int L = *std::max_element(load.begin(), load.end());
+  std::vector<int> perm(size_t(NX) * L, -1);
+  for (int x = 0; x < NX; ++x) {
+    int k = 0;
+    for (int q : lists[x])
+      for (int ti = sup[q].I * S; ti < std::min(n, (sup[q].I + 1) * S); ++ti)
+        for (int tj = sup[q].J * S; tj < std::min(n, (sup[q].J + 1) * S); ++tj)
+          if (tj <= ti) perm[size_t(k++) * NX + x] = (ti << 16) | tj;
+  }
+  // workgroup 0 must own SOME tile; the fused kernel finds tile (0, 0) by its coordinates wherever it is dispatched
+  XcdOrder o;
+  o.grid = NX * L;
+  if (hipMalloc(&o.dev, perm.size() * sizeof(int)) != hipSuccess || hipMemcpy(o.dev, perm.data(), perm.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) {
+    o.dev = nullptr;
+    o.grid = 0;
+  }
+  return cache.emplace(std::make_pair(dev, n), o).first->second;
+}
+
 template <typename T>
 void potrf_t(hipStream_t s, T* A, T* Tm, int64_t Mp, int* info, unsigned* sync, hipEvent_t* row_events, const RowHook* hook,
              const PotrfLookahead* la) {
@@ -1198,6 +1266,15 @@ void potrf_t(hipStream_t s, T* A, T* Tm, int64_t Mp, int* info, unsigned* sync, 
       }
     }
 #endif
+    static const bool xcd_on = exp_int("SVGP_SYRK_XCD", 0) == 1;
+    if (xcd_on && kbb == 1) {
+      const int nrows = int((std::sqrt(8.0 * nt + 1.0) - 1.0) / 2.0 + 0.5);   // nt = nrows (nrows + 1) / 2
+      const XcdOrder& xo = xcd_tile_order(nrows);
+      if (xo.dev) {
+        hipLaunchKernelGGL((syrk128_kernel<T, true>), dim3(xo.grid), dim3(kThreads), lds_fused_l, s, A, Tm, Mp, pp, info, kbb, 0, xo.dev);
+        return;
+      }
+    }
     hipLaunchKernelGGL((syrk128_kernel<T, true>), dim3(nt), dim3(kThreads), lds_fused_l, s, A, Tm, Mp, pp, info, kbb);
   };
 #ifdef SVGP_EXPERIMENTS
