@@ -5,7 +5,8 @@
 // rejected variant of rounds 1-5 is a compile-time constant (its default) and the code only such a knob could reach is not compiled.
 //
 //   SVGP_TIMING, SVGP_OVERLAP, SVGP_SEG_SPLIT      per context (svgp_ctx_create)
-//   SVGP_DEBUG_SYNC, SVGP_OFFLOAD_MIN_WORK, SVGP_RCCL_LIB, SVGP_DISABLE_RCCL      per process
+//   SVGP_DEBUG_SYNC, SVGP_RCCL_LIB, SVGP_DISABLE_RCCL      per process (first use)
+//   SVGP_OFFLOAD_MIN_WORK      by svgp_offload_advice, a host-side advisory function outside every evaluation (hosts change it at run time)
 //
 // EXPERIMENTS build (tools/build_variant.sh experiments: -DSVGP_EXPERIMENTS, libsvgp_experiments.so): the same sources with every knob
 // read from the environment (per context where a test toggles it, else once per process) and the rejected variants compiled in; it
