@@ -8,7 +8,7 @@
 //   SVGP_DEBUG_SYNC, SVGP_RCCL_LIB, SVGP_DISABLE_RCCL      per process (first use)
 //   SVGP_OFFLOAD_MIN_WORK      by svgp_offload_advice, a host-side advisory function outside every evaluation (hosts change it at run time)
 //
-// EXPERIMENTS build (tools/build_variant.sh experiments: -DSVGP_EXPERIMENTS, libsvgp_experiments.so): the same sources with every knob
+// EXPERIMENTS build (tools/build_experiments.sh: -DSVGP_EXPERIMENTS, libsvgp_experiments.so): the same sources with every knob
 // read from the environment (per context where a test toggles it, else once per process) and the rejected variants compiled in; it
 // exports the extra symbol svgp_debug_experiments so that tools and tests can tell the two apart.  INTEGRATION.md lists both sets.
 #pragma once

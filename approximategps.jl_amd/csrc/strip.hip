@@ -1486,9 +1486,13 @@ static void launch_kuf_f(hipStream_t s, const KernelParams& kp, const T* zs, int
     const dim3 grid((unsigned)(npairs * nR < slots ? npairs * nR : slots));
     hipLaunchKernelGGL(kern, grid, dim3(512), lds, s, kp, zs, M, Mp, x, ldx, off, len, Kuf, int(rw), nR);
   };
+  // feature rows padded to 4 / 8 / 16 / 20 / 24 / 32 (round 5: 20 and 24 - at 16 < d <= 32 the kernel is bound by the f64 distance chain,
+  // KS = DREG / 4 MFMAs per 16 x 16 tile, plus the kernel function on the VALU, not by the stores: d = 17 ran eight MFMAs where five do)
   if (kp.d <= 4) launch(std::integral_constant<int, 4>{});
   else if (kp.d <= 8) launch(std::integral_constant<int, 8>{});
   else if (kp.d <= 16) launch(std::integral_constant<int, 16>{});
+  else if (kp.d <= 20) launch(std::integral_constant<int, 20>{});
+  else if (kp.d <= 24) launch(std::integral_constant<int, 24>{});
   else launch(std::integral_constant<int, 32>{});
 }
 
