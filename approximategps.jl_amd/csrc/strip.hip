@@ -1426,6 +1426,40 @@ void launch_final_reduce(hipStream_t s, const double* partial, const unsigned* n
   hipLaunchKernelGGL(final_reduce_kernel, dim3(1), dim3(k256), 0, s, partial, negcnt, n, chol_info, n_points, out, prep_scal);
 }
 
+// The column-owning Kuf kernel's launch for one padded feature count.
+template <typename T, int DREG, int FAMILY>
+static void launch_kuf_cols(hipStream_t s, const KernelParams& kp, const T* zs, int64_t M, int64_t Mp, const T* x, int64_t ldx,
+                            int64_t off, int64_t len, T* Kuf) {
+  // rows per workgroup: 8 KiB of a column where the z image ((DREG + 1) values per row) fits 72 KiB of LDS (two workgroups
+  // per CU), never less than 256 rows, never more than the (256-padded) matrix
+  static const int forced = env_int("SVGP_KUF_RW", 0);
+  // 36 KiB of z image per workgroup (four 512-thread workgroups per CU by LDS): 4 KiB column pieces for d <= 8.  The
+  // arithmetic needs the resident waves more than the stores need 8 KiB pieces (same box, H f64: RW 1024 4.88, RW 512
+  // 5.26, RW 256 4.95 TB/s; C4 f32: RW 2048 4.5, RW 1024 4.9 TB/s)
+  // (d > 8: 72 KiB, or the pieces shrink to 2 KiB: C3 4.0-4.15 vs 4.5-4.65 TB/s)
+  int64_t rw = int64_t((DREG > 8 ? 73728 : 36864) / ((DREG + 1) * sizeof(T))) / 256 * 256;
+  const int64_t cap = int64_t(8192 / sizeof(T)), mrows = (M + 255) / 256 * 256;
+  rw = rw > cap ? cap : rw;
+  if (forced > 0) rw = int64_t(forced) / 256 * 256;
+  rw = rw < 256 ? 256 : rw;
+  rw = rw > mrows ? mrows : rw;
+  const int nR = int((M + rw - 1) / rw);
+  const size_t lds = size_t(DREG + 1) * size_t(rw) * sizeof(T);
+  auto kern = kuf_cols_kernel<T, DREG, FAMILY>;
+  set_max_lds(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
+  const int64_t npairs = (len + 31) / 32;   // a workgroup's two halves take one 16-point group each per step
+  int per_cu = 0, dev = 0, cus = 256;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 512, lds) != hipSuccess || per_cu < 1) per_cu = 1;
+  (void)hipGetDevice(&dev);
+  (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+  static const int forced_wg = env_int("SVGP_KUF_WG_PER_CU", 0);
+  if (forced_wg > 0 && forced_wg < per_cu) per_cu = forced_wg;
+  int64_t slots = int64_t(cus) * per_cu / nR * nR;
+  slots = slots < nR ? nR : slots;
+  const dim3 grid((unsigned)(npairs * nR < slots ? npairs * nR : slots));
+  hipLaunchKernelGGL(kern, grid, dim3(512), lds, s, kp, zs, M, Mp, x, ldx, off, len, Kuf, int(rw), nR);
+}
+
 template <typename T, int FAMILY>
 static void launch_kuf_f(hipStream_t s, const KernelParams& kp, const T* zs, int64_t M, int64_t Mp, const T* x, int64_t ldx,
                          int64_t off, int64_t len, T* Kuf) {
@@ -1455,45 +1489,14 @@ static void launch_kuf_f(hipStream_t s, const KernelParams& kp, const T* zs, int
 #undef SVGP_KUF_LAUNCH
     return;
   }
-  // rows per workgroup: 8 KiB of a column where the z image ((DREG + 1) values per row) fits 72 KiB of LDS (two workgroups
-  // per CU), never less than 256 rows, never more than the (256-padded) matrix
-  auto launch = [&](auto dreg_c) {
-    constexpr int DREG = decltype(dreg_c)::value;
-    static const int forced = env_int("SVGP_KUF_RW", 0);
-    // 36 KiB of z image per workgroup (four 512-thread workgroups per CU by LDS): 4 KiB column pieces for d <= 8.  The
-    // arithmetic needs the resident waves more than the stores need 8 KiB pieces (same box, H f64: RW 1024 4.88, RW 512
-    // 5.26, RW 256 4.95 TB/s; C4 f32: RW 2048 4.5, RW 1024 4.9 TB/s)
-    // (d > 8: 72 KiB, or the pieces shrink to 2 KiB: C3 4.0-4.15 vs 4.5-4.65 TB/s)
-    int64_t rw = int64_t((DREG > 8 ? 73728 : 36864) / ((DREG + 1) * sizeof(T))) / 256 * 256;
-    const int64_t cap = int64_t(8192 / sizeof(T)), mrows = (M + 255) / 256 * 256;
-    rw = rw > cap ? cap : rw;
-    if (forced > 0) rw = int64_t(forced) / 256 * 256;
-    rw = rw < 256 ? 256 : rw;
-    rw = rw > mrows ? mrows : rw;
-    const int nR = int((M + rw - 1) / rw);
-    const size_t lds = size_t(DREG + 1) * size_t(rw) * sizeof(T);
-    auto kern = kuf_cols_kernel<T, DREG, FAMILY>;
-    set_max_lds(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
-    const int64_t npairs = (len + 31) / 32;   // a workgroup's two halves take one 16-point group each per step
-    int per_cu = 0, dev = 0, cus = 256;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 512, lds) != hipSuccess || per_cu < 1) per_cu = 1;
-    (void)hipGetDevice(&dev);
-    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    static const int forced_wg = env_int("SVGP_KUF_WG_PER_CU", 0);
-    if (forced_wg > 0 && forced_wg < per_cu) per_cu = forced_wg;
-    int64_t slots = int64_t(cus) * per_cu / nR * nR;
-    slots = slots < nR ? nR : slots;
-    const dim3 grid((unsigned)(npairs * nR < slots ? npairs * nR : slots));
-    hipLaunchKernelGGL(kern, grid, dim3(512), lds, s, kp, zs, M, Mp, x, ldx, off, len, Kuf, int(rw), nR);
-  };
   // feature rows padded to 4 / 8 / 16 / 20 / 24 / 32 (round 5: 20 and 24 - at 16 < d <= 32 the kernel is bound by the f64 distance chain,
   // KS = DREG / 4 MFMAs per 16 x 16 tile, plus the kernel function on the VALU, not by the stores: d = 17 ran eight MFMAs where five do)
-  if (kp.d <= 4) launch(std::integral_constant<int, 4>{});
-  else if (kp.d <= 8) launch(std::integral_constant<int, 8>{});
-  else if (kp.d <= 16) launch(std::integral_constant<int, 16>{});
-  else if (kp.d <= 20) launch(std::integral_constant<int, 20>{});
-  else if (kp.d <= 24) launch(std::integral_constant<int, 24>{});
-  else launch(std::integral_constant<int, 32>{});
+  if (kp.d <= 4) launch_kuf_cols<T, 4, FAMILY>(s, kp, zs, M, Mp, x, ldx, off, len, Kuf);
+  else if (kp.d <= 8) launch_kuf_cols<T, 8, FAMILY>(s, kp, zs, M, Mp, x, ldx, off, len, Kuf);
+  else if (kp.d <= 16) launch_kuf_cols<T, 16, FAMILY>(s, kp, zs, M, Mp, x, ldx, off, len, Kuf);
+  else if (kp.d <= 20) launch_kuf_cols<T, 20, FAMILY>(s, kp, zs, M, Mp, x, ldx, off, len, Kuf);
+  else if (kp.d <= 24) launch_kuf_cols<T, 24, FAMILY>(s, kp, zs, M, Mp, x, ldx, off, len, Kuf);
+  else launch_kuf_cols<T, 32, FAMILY>(s, kp, zs, M, Mp, x, ldx, off, len, Kuf);
 }
 
 template <typename T>
