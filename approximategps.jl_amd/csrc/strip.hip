@@ -1027,7 +1027,7 @@ __global__ void __launch_bounds__(k256, 2) kuf_kernel(KernelParams kp, const T* 
 // LDS allows) x 128 points; the -2z fragments and row norms of its RW rows sit in LDS (they no longer fit registers), the
 // loop order is 16-point group outside, 256-row chunk inside.
 // ---------------------------------------------------------------------------------------------
-template <typename T, int DREG, int FAMILY>
+template <typename T, int DREG, int FAMILY, int NBLK = 4>
 __global__ void __launch_bounds__(512, 2) kuf_cols_kernel(KernelParams kp, const T* __restrict__ zs, int64_t M, int64_t Mp,
                                                         const T* __restrict__ x, int64_t ldx, int64_t off, int64_t len,
                                                         T* __restrict__ K, int RW, int nR) {
@@ -1037,7 +1037,8 @@ __global__ void __launch_bounds__(512, 2) kuf_cols_kernel(KernelParams kp, const
   // half cover 256 rows per chunk.  The x fragments of a group come straight from global memory (prefetched one group
   // ahead) with the norms by wave shuffles, so the main loop has no barrier: with a staged x tile and two barriers per
   // 128 points, 49 % of the wave cycles were spent waiting (SQ_WAIT_ANY) behind whichever wave the store queue held back.
-  constexpr int VEC = Vec16<T>::N, NBLK = 4, KS = DREG / 4, NTH = 512;
+  constexpr int VEC = Vec16<T>::N, KS = DREG / 4, NTH = 512, WROWS = 16 * NBLK, CH = 4 * WROWS;   // a wave owns WROWS rows of a CH-row chunk
+  static_assert(NBLK % VEC == 0, "a lane stores VEC consecutive rows");
   using V = typename Vec16<T>::type;
   using acc_t = typename Mfma16<T>::acc_t;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -1051,7 +1052,7 @@ __global__ void __launch_bounds__(512, 2) kuf_cols_kernel(KernelParams kp, const
   const T c0 = (FAMILY == KSE) ? T(log(kp.variance)) : T(0);
   const T bscale = (FAMILY == KSE) ? T(1) : T(-2);
   const bool vec_ok = (M % VEC == 0);
-  const int nch = RW / 256;
+  const int nch = RW / CH;
   const int64_t r0 = int64_t(blockIdx.x % nR) * RW;
   for (int rl = tid; rl < RW; rl += NTH) {
     const int64_t i = r0 + rl;
@@ -1101,10 +1102,10 @@ __global__ void __launch_bounds__(512, 2) kuf_cols_kernel(KernelParams kp, const
     for (int r = 0; r < 4; ++r) {
       const int64_t j = jb + Mfma16<T>::row(lane, r);
       live[r] = j < len;
-      dst0[r] = K + (live[r] ? j : jb) * M + r0 + wave * 64 + c * VEC;
+      dst0[r] = K + (live[r] ? j : jb) * M + r0 + wave * WROWS + c * VEC;
     }
     for (int rc = 0; rc < nch; ++rc) {
-      const int rl0 = rc * 256 + wave * 64;
+      const int rl0 = rc * CH + wave * WROWS;
       const int64_t ibase = r0 + rl0;
       if (ibase >= M) break;   // wave-uniform
       acc_t acc[NBLK];
@@ -1124,7 +1125,7 @@ __global__ void __launch_bounds__(512, 2) kuf_cols_kernel(KernelParams kp, const
         for (int b = 0; b < NBLK; ++b) acc[b] = Mfma16<T>::mma(a[q], zb[b][q], acc[b]);
       // full tiles (16 live points, 64 rows inside M, vector-aligned columns): straight-line stores, no per-store masks or
       // branches (same box: 5.32 -> 5.45 TB/s at H); the ragged edges of the batch / of M take the guarded path
-      if (vec_ok && jb + 16 <= len && ibase + 64 <= M) {
+      if (vec_ok && jb + 16 <= len && ibase + WROWS <= M) {
 #pragma unroll
         for (int r = 0; r < 4; ++r)
 #pragma unroll
@@ -1135,7 +1136,7 @@ __global__ void __launch_bounds__(512, 2) kuf_cols_kernel(KernelParams kp, const
               const T v = acc[g * VEC + e][r];
               out[e] = (FAMILY == KSE) ? kexp(v < c0 ? v : c0) : kappa<T>(FAMILY, v > T(0) ? v : T(0), variance);
             }
-            *reinterpret_cast<V*>(dst0[r] + rc * 256 + g * (16 * VEC)) = out;
+            *reinterpret_cast<V*>(dst0[r] + rc * CH + g * (16 * VEC)) = out;
           }
         continue;
       }
@@ -1151,7 +1152,7 @@ __global__ void __launch_bounds__(512, 2) kuf_cols_kernel(KernelParams kp, const
             out[e] = (FAMILY == KSE) ? kexp(v < c0 ? v : c0) : kappa<T>(FAMILY, v > T(0) ? v : T(0), variance);
           }
           const int64_t i = ibase + g * (16 * VEC) + c * VEC;
-          T* dst = dst0[r] + rc * 256 + g * (16 * VEC);
+          T* dst = dst0[r] + rc * CH + g * (16 * VEC);
           if (vec_ok && i + VEC <= M) {
             *reinterpret_cast<V*>(dst) = out;
           } else {
@@ -1427,7 +1428,7 @@ void launch_final_reduce(hipStream_t s, const double* partial, const unsigned* n
 }
 
 // The column-owning Kuf kernel's launch for one padded feature count.
-template <typename T, int DREG, int FAMILY>
+template <typename T, int DREG, int FAMILY, int NBLK = 4>
 static void launch_kuf_cols(hipStream_t s, const KernelParams& kp, const T* zs, int64_t M, int64_t Mp, const T* x, int64_t ldx,
                             int64_t off, int64_t len, T* Kuf) {
   // rows per workgroup: 8 KiB of a column where the z image ((DREG + 1) values per row) fits 72 KiB of LDS (two workgroups
@@ -1445,7 +1446,7 @@ static void launch_kuf_cols(hipStream_t s, const KernelParams& kp, const T* zs, 
   rw = rw > mrows ? mrows : rw;
   const int nR = int((M + rw - 1) / rw);
   const size_t lds = size_t(DREG + 1) * size_t(rw) * sizeof(T);
-  auto kern = kuf_cols_kernel<T, DREG, FAMILY>;
+  auto kern = kuf_cols_kernel<T, DREG, FAMILY, NBLK>;
   set_max_lds(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
   const int64_t npairs = (len + 31) / 32;   // a workgroup's two halves take one 16-point group each per step
   int per_cu = 0, dev = 0, cus = 256;
@@ -1471,7 +1472,14 @@ static void launch_kuf_f(hipStream_t s, const KernelParams& kp, const T* zs, int
   // persistent structure (f64; f32 with d > 8) and the column fits one 8 KiB piece; the light f32 d <= 8 case is purely
   // store-bound in both and the block kernel's higher residency wins by a few per cent.
   static const int forced_v = env_int("SVGP_KUF_V1", -1);   // A/B knob: 1 = block kernel, 0 = column-owning kernel
-  const bool v1 = kp.d > 32 || (forced_v >= 0 ? forced_v != 0 : (size_t(M) * sizeof(T) > 8192 || (sizeof(T) == 4 && kp.d <= 8)));
+  // d > 32 (round 5): the column-owning kernel too wherever a column is one 8 KiB piece - its z image then takes 98 / 130 KiB of LDS
+  // in f64 (48 / 64 feature rows x 256 inducing rows: ONE 512-thread workgroup per CU, which its 200+ VGPRs allow anyway) and is built
+  // once per launch, where the block kernel re-reads 64 KiB of z and 64 KiB of x per 128 x 128 block of Kuf
+  static const int cols_wide = env_int("SVGP_KUF_COLS_WIDE", 1);   // experiments build, A/B: 0 = the block kernel for every d > 32
+  const bool one_piece = size_t(M) * sizeof(T) <= 8192;
+  // (same box, profiles/round5/kuf_wide_cols.log: Hd64 f64 1.35 -> 2.55 TB/s; fp32 d = 64 2.09 -> 1.98: fp32 keeps the block kernel)
+  const bool v1 = kp.d > 32 ? !(sizeof(T) == 8 && one_piece && cols_wide)
+                            : (forced_v >= 0 ? forced_v != 0 : (!one_piece || (sizeof(T) == 4 && kp.d <= 8)));
   if (v1) {
     const dim3 grid((unsigned)(((len + 255) / 256) * ((M + 255) / 256)));
 #define SVGP_KUF_LAUNCH(DREG) \
@@ -1489,14 +1497,32 @@ static void launch_kuf_f(hipStream_t s, const KernelParams& kp, const T* zs, int
 #undef SVGP_KUF_LAUNCH
     return;
   }
-  // feature rows padded to 4 / 8 / 16 / 20 / 24 / 32 (round 5: 20 and 24 - at 16 < d <= 32 the kernel is bound by the f64 distance chain,
+  // feature rows padded to 4 / 8 / 16 / 20 / 24 / 32 / 48 / 64 (round 5: 20 and 24 - at 16 < d <= 32 the kernel is bound by the f64 distance chain,
   // KS = DREG / 4 MFMAs per 16 x 16 tile, plus the kernel function on the VALU, not by the stores: d = 17 ran eight MFMAs where five do)
   if (kp.d <= 4) launch_kuf_cols<T, 4, FAMILY>(s, kp, zs, M, Mp, x, ldx, off, len, Kuf);
   else if (kp.d <= 8) launch_kuf_cols<T, 8, FAMILY>(s, kp, zs, M, Mp, x, ldx, off, len, Kuf);
   else if (kp.d <= 16) launch_kuf_cols<T, 16, FAMILY>(s, kp, zs, M, Mp, x, ldx, off, len, Kuf);
-  else if (kp.d <= 20) launch_kuf_cols<T, 20, FAMILY>(s, kp, zs, M, Mp, x, ldx, off, len, Kuf);
-  else if (kp.d <= 24) launch_kuf_cols<T, 24, FAMILY>(s, kp, zs, M, Mp, x, ldx, off, len, Kuf);
-  else launch_kuf_cols<T, 32, FAMILY>(s, kp, zs, M, Mp, x, ldx, off, len, Kuf);
+  else if (kp.d <= 32) {
+#ifdef SVGP_EXPERIMENTS
+    // A/B: two 16-row blocks per wave (128-row chunks) - 121-ish VGPRs instead of 139-169, i.e. two workgroups per CU
+    static const int nblk2 = exp_int("SVGP_KUF_NBLK2", 0);
+    if constexpr (sizeof(T) == 8) {
+      if (nblk2) {
+        if (kp.d <= 20) launch_kuf_cols<T, 20, FAMILY, 2>(s, kp, zs, M, Mp, x, ldx, off, len, Kuf);
+        else if (kp.d <= 24) launch_kuf_cols<T, 24, FAMILY, 2>(s, kp, zs, M, Mp, x, ldx, off, len, Kuf);
+        else launch_kuf_cols<T, 32, FAMILY, 2>(s, kp, zs, M, Mp, x, ldx, off, len, Kuf);
+        return;
+      }
+    }
+#endif
+    if (kp.d <= 20) launch_kuf_cols<T, 20, FAMILY>(s, kp, zs, M, Mp, x, ldx, off, len, Kuf);
+    else if (kp.d <= 24) launch_kuf_cols<T, 24, FAMILY>(s, kp, zs, M, Mp, x, ldx, off, len, Kuf);
+    else launch_kuf_cols<T, 32, FAMILY>(s, kp, zs, M, Mp, x, ldx, off, len, Kuf);
+  }
+  else if constexpr (sizeof(T) == 8) {
+    if (kp.d <= 48) launch_kuf_cols<T, 48, FAMILY>(s, kp, zs, M, Mp, x, ldx, off, len, Kuf);
+    else launch_kuf_cols<T, 64, FAMILY>(s, kp, zs, M, Mp, x, ldx, off, len, Kuf);
+  }
 }
 
 template <typename T>

@@ -159,3 +159,28 @@ def test_large_kuu_factorisation(ctx, dtype, tol):
     bad.free()
     model.free()
     data.free()
+
+
+@pytest.mark.parametrize("dtype,atol", [(np.float64, 1e-12), (np.float32, 3e-6)])
+@pytest.mark.parametrize("family", [o.KERNEL_SE, o.KERNEL_MATERN32, o.KERNEL_MATERN52])
+def test_kuf_assembly_at_every_padded_feature_count(ctx, dtype, atol, family):
+    """svgp_kuf = cov(f.prior, z, x) (SVA:216) for every padded feature count of the standalone assembly kernels (4, 8, 16, 20, 24, 32,
+    48, 64 feature rows: strip.hip, launch_kuf_f), each at its upper edge and one past the edge below it, on both kernel forms: the
+    column-owning kernel (a column of Kuf is at most 8 KiB: M = 150, one row chunk, and M = 600, three chunks with a ragged last one)
+    and the block kernel (M = 1100 f64 / 2100 fp32).  Ragged batch, window offset 3."""
+    rng = np.random.default_rng(77)
+    for d in (3, 5, 9, 16, 17, 20, 21, 24, 25, 32, 33, 48, 49, 64):
+        for M in (150, 600, 1100 if dtype == np.float64 else 2100):
+            if M > 600 and d not in (9, 24, 33, 64):
+                continue
+            N = 333
+            x, y, sva, s2 = o.synth_problem(5000 + 7 * d + M, N + 3, M, d, family=family, dtype=dtype)
+            model = device_model(ctx, sva, dtype=dtype, sigma2=s2)
+            data = _ffi.DeviceData(ctx, x, y, dtype)
+            K = model.kuf(data, 3, N)
+            ref = o.kernelmatrix(sva.kernel, sva.z, x[:, 3:])
+            assert K.shape == ref.shape, (d, M, K.shape, ref.shape)
+            err = np.abs(K - ref).max()
+            assert err <= atol * sva.kernel.variance, (d, M, err)
+            model.free()
+            data.free()
