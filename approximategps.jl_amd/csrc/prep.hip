@@ -844,19 +844,29 @@ __global__ void __launch_bounds__(kThreads, 2) syrk128_kernel(T* __restrict__ A,
   } else {
     tri_index(blockIdx.x, ti, tj);
   }
+  // (experiments build, timing probes of the big update - WRONG results: skip >> 8 = 1: no read-modify-write of C, 2: the k-loop twice,
+  //  3: the read-modify-write alone)
+  const int probe = kExperiments ? (skip >> 8) : 0;
+  skip &= 0xff;
   const int i = p + 1 + skip + ti, j = p + 1 + skip + tj;   // skip = 1: the look-ahead's bulk update (potrf_t)
   const T* P = A + int64_t(j) * NB + int64_t(p - kb + 1) * NB * ld;   // kb = 2: rank-256 update over block columns p - 1, p
   const T* Q = A + int64_t(i) * NB + int64_t(p - kb + 1) * NB * ld;
   const typename G::QOff qoff = G::q_offsets(ld);
   auto qload = [&](int t, QRegs& r) { G::load_q(r, Q + int64_t(t) * 16 * ld, qoff); };
-  G::loop(acc, P, ld, kb * (NB / 16), qload, smem);
+  if (probe != 3) G::loop(acc, P, ld, kb * (NB / 16), qload, smem);
+  if (probe == 2) {
+    __syncthreads();
+    G::loop(acc, P, ld, kb * (NB / 16), qload, smem);
+  }
   T* C = A + int64_t(i) * NB + int64_t(j) * NB * ld;
+  if (probe != 1 || (ti == 0 && tj == 0)) {
 #pragma unroll
-  for (int a = 0; a < G::MI; ++a)
+    for (int a = 0; a < G::MI; ++a)
 #pragma unroll
-    for (int r = 0; r < 4; ++r)
+      for (int r = 0; r < 4; ++r)
 #pragma unroll
-      for (int b = 0; b < G::NJ; ++b) C[G::acc_col(b) + int64_t(G::acc_row(a, r)) * ld] -= acc.v[a][b][r];
+        for (int b = 0; b < G::NJ; ++b) C[G::acc_col(b) + int64_t(G::acc_row(a, r)) * ld] -= acc.v[a][b][r];
+  }
   if constexpr (FUSE) {
     if (ti != 0 || tj != 0) return;   // the owner of tile (p+1, p+1) - workgroup 0 in either tile order - goes on to factor it
     __threadfence();               // the tile this workgroup just wrote is re-read below (through L2: drop stale L1 lines)
@@ -1275,7 +1285,8 @@ void potrf_t(hipStream_t s, T* A, T* Tm, int64_t Mp, int* info, unsigned* sync, 
         return;
       }
     }
-    hipLaunchKernelGGL((syrk128_kernel<T, true>), dim3(nt), dim3(kThreads), lds_fused_l, s, A, Tm, Mp, pp, info, kbb);
+    static const int probe = exp_int("SVGP_SYRK_PROBE", 0);   // experiments build: timing probes (wrong results)
+    hipLaunchKernelGGL((syrk128_kernel<T, true>), dim3(nt), dim3(kThreads), lds_fused_l, s, A, Tm, Mp, pp, info, kbb, probe << 8);
   };
 #ifdef SVGP_EXPERIMENTS
   static const bool two_level_on = exp_int("SVGP_CHOL_TWO_LEVEL", 0) == 1;
