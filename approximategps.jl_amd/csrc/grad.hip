@@ -390,8 +390,11 @@ __device__ __forceinline__ void kappa_and_d(T r2, T variance, T& k, T& dk) {
 //   rowpart[slice][0][i] += sum_j W_ij           rowpart[slice][1][i] += sum_j At_ji g_mu_j   (m_bar)
 //   rowpart[slice][2+f][i] += sum_j W_ij xs_fj    scalpart[slice][rb][0] += sum P_ij K_ij,  [1+f] += sum W_ij u_fij^2
 // Pt is point-major [n][Mp]; each thread owns KV rows i for the whole slice (scaled z in registers).
+#ifndef SVGP_KGRAD_MINW
+#define SVGP_KGRAD_MINW 2   // waves per SIMD the register allocation must leave room for (A/B builds: 1 = round 4, the 16-feature kernels at 320-336 VGPRs)
+#endif
 template <typename T, int DREG, int KV, int FAMILY>
-__global__ void __launch_bounds__(k256) kgrad_kernel(KernelParams kp, const T* __restrict__ zs, int64_t Mp,
+__global__ void __launch_bounds__(k256, SVGP_KGRAD_MINW) kgrad_kernel(KernelParams kp, const T* __restrict__ zs, int64_t Mp,
                                                      const T* __restrict__ x, int64_t ldx, int64_t xoff, int prescaled,
                                                      int64_t n, int64_t nvalid, const T* __restrict__ Pt,
                                                      const T* __restrict__ At, const T* __restrict__ gmu, const T* __restrict__ gv,
@@ -489,7 +492,9 @@ __global__ void __launch_bounds__(k256) kgrad_kernel(KernelParams kp, const T* _
       for (int u = 0; u < U; ++u) {
         const int c = c0w + 4 * u;
         if (!(c < JB && jb + c < j1)) break;   // wave-uniform
-        T r2[KV], uu[DREG][KV];
+        // (the differences z - x are formed again in the accumulation loop below instead of being kept: DREG x KV registers - the f64
+        //  d <= 16 kernel had 320-336 VGPRs, one wave per SIMD)
+        T r2[KV];
 #pragma unroll
         for (int e = 0; e < KV; ++e) r2[e] = T(0);
 #pragma unroll
@@ -497,8 +502,8 @@ __global__ void __launch_bounds__(k256) kgrad_kernel(KernelParams kp, const T* _
           const T xv = xt[c * DREG + f];
 #pragma unroll
           for (int e = 0; e < KV; ++e) {
-            uu[f][e] = z[f][e] - xv;
-            r2[e] = fma(uu[f][e], uu[f][e], r2[e]);
+            const T uf = z[f][e] - xv;
+            r2[e] = fma(uf, uf, r2[e]);
           }
         }
 #pragma unroll
@@ -514,8 +519,9 @@ __global__ void __launch_bounds__(k256) kgrad_kernel(KernelParams kp, const T* _
             else if (kmb) MBb[e] = fmaf(float(k), float(gmv[u]), MBb[e]);
 #pragma unroll
             for (int f = 0; f < DREG; ++f) {
-              Qb[f][e] = fmaf(Wf, float(xt[c * DREG + f]), Qb[f][e]);
-              ILb[f] = fmaf(Wf * float(uu[f][e]), float(uu[f][e]), ILb[f]);
+              const float xv = float(xt[c * DREG + f]), uf = float(z[f][e]) - xv;
+              Qb[f][e] = fmaf(Wf, xv, Qb[f][e]);
+              ILb[f] = fmaf(Wf * uf, uf, ILb[f]);
             }
             continue;
           }
@@ -526,8 +532,10 @@ __global__ void __launch_bounds__(k256) kgrad_kernel(KernelParams kp, const T* _
           else if (kmb) MB[e] += double(k) * double(gmv[u]);    // (Kuf g_mu)_i: the caller applies Lk^-1 (f64: A is not read at all)
 #pragma unroll
           for (int f = 0; f < DREG; ++f) {
-            Q[f][e] += W * double(xt[c * DREG + f]);
-            IL[f] += W * double(uu[f][e]) * double(uu[f][e]);
+            const T xv = xt[c * DREG + f];
+            const double uf = double(z[f][e] - xv);
+            Q[f][e] += W * double(xv);
+            IL[f] += W * uf * uf;
           }
         }
       }
@@ -635,9 +643,14 @@ __global__ void __launch_bounds__(k256) kgrad_wide_kernel(KernelParams kp, const
       gvs[threadIdx.x] = alpha ? T(2) * gv[g] : T(1);
     }
     __syncthreads();
-    B Rb = 0, MBb = 0, S1b = 0, Qb[FL], ILb[FL];
+    // fp32: per-block sums in fp32 (Rb ...), added to the fp64 totals once per staged block.  f64: the totals themselves are the
+    // accumulators (round 5: a second fp64 set and the kept differences uu[] put the kernel at 345-350 VGPRs - ONE wave per SIMD for a
+    // kernel of dependent f64 chains and global loads; the differences are recomputed in the second feature loop instead)
+    B Rb = 0, MBb = 0, S1b = 0, Qb[kF32 ? FL : 1], ILb[kF32 ? FL : 1];
+    if constexpr (kF32) {
 #pragma unroll
-    for (int f = 0; f < FL; ++f) Qb[f] = ILb[f] = 0;
+      for (int f = 0; f < FL; ++f) Qb[f] = ILb[f] = 0;
+    }
     for (int c0w = wave; c0w < JB && jb + c0w < j1; c0w += 4 * U) {
       T pv[U], av[U], gmv[U], gvv[U];
 #pragma unroll
@@ -655,12 +668,14 @@ __global__ void __launch_bounds__(k256) kgrad_wide_kernel(KernelParams kp, const
         const int c = c0w + 4 * u;
         if (!(c < JB && jb + c < j1)) break;   // wave-uniform
         const T* __restrict__ xc = xt + c * DL + FL * fg;
-        T uu[FL], r2 = T(0);
+        T r2a = T(0), r2b = T(0);   // two chains: a lone wave waits out every dependent f64 FMA
 #pragma unroll
-        for (int f = 0; f < FL; ++f) {
-          uu[f] = z[f] - xc[f];
-          r2 = fma(uu[f], uu[f], r2);
+        for (int f = 0; f < FL; f += 2) {
+          const T ua = z[f] - xc[f], ub = z[f + 1] - xc[f + 1];
+          r2a = fma(ua, ua, r2a);
+          r2b = fma(ub, ub, r2b);
         }
+        T r2 = r2a + r2b;
         r2 += __shfl_xor(r2, 1);
         if (LPR == 4) r2 += __shfl_xor(r2, 2);
         T k, dk;
@@ -675,14 +690,22 @@ __global__ void __launch_bounds__(k256) kgrad_wide_kernel(KernelParams kp, const
         }
 #pragma unroll
         for (int f = 0; f < FL; ++f) {
-          Qb[f] = fma(W, B(xc[f]), Qb[f]);
-          ILb[f] = fma(W * B(uu[f]), B(uu[f]), ILb[f]);
+          const T xv = xc[f], uf = z[f] - xv;
+          if constexpr (kF32) {
+            Qb[f] = fma(W, B(xv), Qb[f]);
+            ILb[f] = fma(W * B(uf), B(uf), ILb[f]);
+          } else {
+            Q[f] = fma(double(W), double(xv), Q[f]);
+            IL[f] = fma(double(W) * double(uf), double(uf), IL[f]);
+          }
         }
       }
     }
     S1 += double(S1b); R += double(Rb); MB += double(MBb);
+    if constexpr (kF32) {
 #pragma unroll
-    for (int f = 0; f < FL; ++f) { Q[f] += double(Qb[f]); IL[f] += double(ILb[f]); }
+      for (int f = 0; f < FL; ++f) { Q[f] += double(Qb[f]); IL[f] += double(ILb[f]); }
+    }
   }
   // combine the four waves (same rows) in a fixed order, then add into this (slice, row-block)'s partials
   constexpr int NV = 2 + FL;
@@ -720,6 +743,200 @@ __global__ void __launch_bounds__(k256) kgrad_wide_kernel(KernelParams kp, const
       __syncthreads();
     }
     if (threadIdx.x == 0) sp[q] += sred[0];
+  }
+}
+
+// ---- wide inputs, round 5: one WAVE per 16-feature group ------------------------------------------------------------------------
+// kgrad_wide_kernel gives a row to LPR adjacent lanes: a wave then covers 64 / LPR rows, its loads of P are 128-256 bytes each, and
+// its 345-350 VGPRs (f64, round 4; 244-254 since round 5) left one wave per SIMD.  Here a lane owns a ROW (64 rows per workgroup, every load of P a full 512 / 256-byte line per wave) and a
+// WAVE owns a group of 16 features: the NG = 2 / 4 feature groups of a point meet through LDS - each wave leaves the partial squared
+// distances of its PB points, one workgroup barrier, every wave adds the NG partials in the same order - and then every wave evaluates
+// the kernel function for itself and accumulates its own 16 feature sums.  With NG = 2 the other two waves take the other half of the
+// points.  Same interface, same partial-sum layout (rows per workgroup: 64), sums in a fixed order.
+template <typename T, int NG, int FAMILY>
+__global__ void __launch_bounds__(k256, 2) kgrad_wide2_kernel(KernelParams kp, const T* __restrict__ zs, int64_t Mp,
+                                                              const T* __restrict__ x, int64_t ldx, int64_t xoff, int prescaled,
+                                                              int64_t n, int64_t nvalid, const T* __restrict__ Pt,
+                                                              const T* __restrict__ At, const T* __restrict__ gmu, const T* __restrict__ gv,
+                                                              const T* __restrict__ alpha, int64_t slice_len,
+                                                              double* __restrict__ rowpart, double* __restrict__ scalpart, int kmb) {
+  constexpr int FL = 16, DL = FL * NG, PS = 4 / NG, PB = 4;
+  constexpr int JB = (sizeof(T) * DL == 512) ? 64 : 128;   // 32 KiB of staged inputs at most
+  constexpr int NBATCH = JB / (PS * PB);
+  constexpr bool kF32 = (sizeof(T) == 4);
+  using B = std::conditional_t<kF32, float, double>;   // per-staged-block accumulators (fp32 builds: <= 128 terms in fp32, then fp64 totals)
+  __shared__ __attribute__((aligned(16))) T xt[JB * DL];
+  __shared__ T gms[JB], gvs[JB];
+  __shared__ T part[2][4][PB][64];
+  const int d = kp.d;
+  const T* __restrict__ invl = static_cast<const T*>(kp.invl);
+  // (the wave index as a scalar: everything derived from it - feature group, point subset, the points' addresses - stays in SGPRs)
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(int(threadIdx.x >> 6)), g = wave % NG, ps = wave / NG;
+  const bool lead = (g == 0);
+  const int64_t i = int64_t(blockIdx.y) * 64 + lane;
+  const int64_t j0 = int64_t(blockIdx.x) * slice_len;
+  int64_t j1 = j0 + slice_len;
+  j1 = j1 < n ? j1 : n;
+  T z[FL];
+#pragma unroll
+  for (int f = 0; f < FL; ++f) z[f] = (FL * g + f < d) ? zs[int64_t(FL * g + f) * Mp + i] : T(0);
+  const T al = alpha ? alpha[i] : T(0);
+  double R = 0.0, MB = 0.0, S1 = 0.0, Q[FL], IL[FL];
+#pragma unroll
+  for (int f = 0; f < FL; ++f) Q[f] = IL[f] = 0.0;
+  const T variance = T(kp.variance);
+  const T* __restrict__ prow = Pt + i;
+  const T* __restrict__ arow = (At ? At : Pt) + i;
+  const int sf = threadIdx.x % DL, sc0 = threadIdx.x / DL;
+  const T* __restrict__ xrow = x + int64_t(sf < d ? sf : 0) * ldx + xoff;
+  const T sscale = (prescaled || sf >= d) ? T(1) : invl[sf];
+  for (int64_t jb = j0; jb < j1; jb += JB) {
+    __syncthreads();
+    // a thread stages ONE feature (256 is a multiple of DL) of every (256 / DL)-th point: one base pointer and one scale per thread (the
+    // generic e / DL, e % DL form left sixteen hoisted 64-bit addresses live across the whole kernel)
+    if (sf < d) {
+#pragma unroll 4
+      for (int c = sc0; c < JB; c += k256 / DL) {
+        int64_t gg = jb + c;
+        gg = gg < nvalid ? gg : nvalid - 1;
+        xt[c * DL + sf] = xrow[gg] * sscale;
+      }
+    } else {
+      for (int c = sc0; c < JB; c += k256 / DL) xt[c * DL + sf] = T(0);
+    }
+    if (threadIdx.x < JB) {
+      int64_t gg = jb + threadIdx.x;
+      gg = gg < j1 ? gg : j1 - 1;
+      gms[threadIdx.x] = gmu ? gmu[gg] : T(0);
+      gvs[threadIdx.x] = alpha ? T(2) * gv[gg] : T(1);
+    }
+    __syncthreads();
+    B Rb = 0, MBb = 0, S1b = 0, Qb[kF32 ? FL : 1], ILb[kF32 ? FL : 1];
+    if constexpr (kF32) {
+#pragma unroll
+      for (int f = 0; f < FL; ++f) Qb[f] = ILb[f] = 0;
+    }
+    // the P (and A) values of a batch are loaded one batch ahead
+    // (A is read only by the experiments build's SVGP_A_FROM_K=0 form: api.hip passes At = nullptr otherwise)
+    constexpr int PA = kExperiments ? PB : 1;
+    T pn[PB], an[PA];
+    const bool need_a = kExperiments && At && lead;   // (wave-uniform)
+    auto fetch = [&](int b) {
+#pragma unroll
+      for (int t = 0; t < PB; ++t) {
+        int64_t j = jb + (b * PS + ps) * PB + t;
+        j = j < j1 ? j : j1 - 1;
+        pn[t] = prow[j * Mp];
+        if constexpr (kExperiments) an[t] = need_a ? arow[j * Mp] : T(0);
+      }
+    };
+    fetch(0);
+#pragma unroll 1
+    for (int b = 0; b < NBATCH; ++b) {
+      const int cb = (b * PS + ps) * PB;
+      T pv[PB], av[PA];
+#pragma unroll
+      for (int t = 0; t < PB; ++t) {
+        pv[t] = pn[t];
+        if constexpr (kExperiments) av[t] = an[t];
+      }
+      if (b + 1 < NBATCH && jb + ((b + 1) * PS) * PB < j1) fetch(b + 1);   // (workgroup-uniform condition; a batch wholly past j1 reuses the last values, masked below)
+#pragma unroll
+      for (int t = 0; t < PB; ++t) {
+        const T* __restrict__ xc = xt + (cb + t) * DL + FL * g;
+        T ra = T(0), rb = T(0);   // two chains
+#pragma unroll
+        for (int f = 0; f < FL; f += 2) {
+          const T ua = z[f] - xc[f], ub = z[f + 1] - xc[f + 1];
+          ra = fma(ua, ua, ra);
+          rb = fma(ub, ub, rb);
+        }
+        part[b & 1][wave][t][lane] = ra + rb;
+        asm volatile("" ::: "memory");   // one point's 16 inputs in registers at a time (hoisted over the unrolled loop they cost 128 VGPRs in f64)
+      }
+      __syncthreads();   // (the buffer of batch b is rewritten by batch b + 2, behind the barrier of batch b + 1)
+#pragma unroll
+      for (int t = 0; t < PB; ++t) {
+        const int c = cb + t;
+        const bool ok = jb + c < j1;
+        T r2 = part[b & 1][ps * NG][t][lane];
+#pragma unroll
+        for (int q = 1; q < NG; ++q) r2 += part[b & 1][ps * NG + q][t][lane];
+        T k, dk;
+        kappa_and_d<T, FAMILY>(r2, variance, k, dk);
+        const T gm = gms[c];
+        const T p = ok ? fma(gvs[c], pv[t], al * gm) : T(0);   // alpha == nullptr: 1 * pv + 0
+        const B W = B(p) * B(dk);
+        if (lead) {
+          S1b = fma(B(p), B(k), S1b);
+          Rb += W;
+          if (kExperiments && At) MBb = fma(B(ok ? av[kExperiments ? t : 0] : T(0)), B(gm), MBb);
+          else if (kmb) MBb = fma(B(ok ? k : T(0)), B(gm), MBb);
+        }
+        const T* __restrict__ xc = xt + c * DL + FL * g;
+#pragma unroll
+        for (int f = 0; f < FL; ++f) {
+          const T xv = xc[f], uf = z[f] - xv;
+          if constexpr (kF32) {
+            Qb[f] = fma(W, B(xv), Qb[f]);
+            ILb[f] = fma(W * B(uf), B(uf), ILb[f]);
+          } else {
+            Q[f] = fma(double(W), double(xv), Q[f]);
+            IL[f] = fma(double(W) * double(uf), double(uf), IL[f]);
+          }
+        }
+        asm volatile("" ::: "memory");
+      }
+    }
+    S1 += double(S1b); R += double(Rb); MB += double(MBb);
+    if constexpr (kF32) {
+#pragma unroll
+      for (int f = 0; f < FL; ++f) { Q[f] += double(Qb[f]); IL[f] += double(ILb[f]); }
+    }
+  }
+  // closing sums: the PS waves of a feature group in a fixed order, then this (slice, row-block)'s partials
+  constexpr int NV = 2 + FL;
+  __shared__ double red[PS > 1 ? NG * 64 * NV : 1];   // the second wave's row sums of a feature group
+  __shared__ double sc[4 * (1 + FL)];                   // the waves' column sums
+  __syncthreads();
+  if (PS > 1 && ps == 1) {
+    double* rr = red + (g * 64 + lane) * NV;
+    rr[0] = R; rr[1] = MB;
+#pragma unroll
+    for (int f = 0; f < FL; ++f) rr[2 + f] = Q[f];
+  }
+  // the column sums over the 64 rows of the wave (butterfly: the same order in every lane), then over the PS waves
+  double cs[1 + FL];
+  cs[0] = S1;
+#pragma unroll
+  for (int f = 0; f < FL; ++f) cs[1 + f] = IL[f];
+#pragma unroll
+  for (int q = 0; q <= FL; ++q) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) cs[q] += __shfl_xor(cs[q], o);
+  }
+  if (lane == 0) {
+#pragma unroll
+    for (int q = 0; q <= FL; ++q) sc[wave * (1 + FL) + q] = cs[q];
+  }
+  __syncthreads();
+  double* rp = rowpart + int64_t(blockIdx.x) * (2 + DL) * Mp;
+  if (ps == 0) {
+    const double* rr = red + (g * 64 + lane) * NV;
+    if (lead) {
+      rp[i] += (PS > 1) ? R + rr[0] : R;
+      rp[Mp + i] += (PS > 1) ? MB + rr[1] : MB;
+    }
+#pragma unroll
+    for (int f = 0; f < FL; ++f) rp[int64_t(2 + FL * g + f) * Mp + i] += (PS > 1) ? Q[f] + rr[2 + f] : Q[f];
+    if (lane <= FL) {   // lane q of the group's first wave adds scalar q: q = 0 (sum P K) from the lead group only
+      double* sp = scalpart + (int64_t(blockIdx.x) * gridDim.y + blockIdx.y) * (1 + DL);
+      const int q = lane;
+      double v = sc[g * (1 + FL) + q];
+      if (PS > 1) v += sc[(NG + g) * (1 + FL) + q];
+      if (q == 0) { if (lead) sp[0] += v; }
+      else sp[FL * g + q] += v;
+    }
   }
 }
 
@@ -856,18 +1073,33 @@ void launch_kgrad_f(hipStream_t s, const KernelParams& kp, const T* zs, int64_t 
     dim3 grid((unsigned)nslices, (unsigned)(Mp / 128));
     hipLaunchKernelGGL((kgrad_kernel<T, 16, 2, FAMILY>), grid, dim3(k256), 0, s, kp, zs, Mp, x, ldx, xoff, prescaled, n, nvalid,
                        Pt, At, gmu, gv, alpha, slice_len, rowpart, scalpart, kmb);
-  } else if (kp.d <= 32) {   // two lanes per row, 16 features each (round 3: 32 slots in one thread)
-    dim3 grid((unsigned)nslices, (unsigned)(Mp / 32));
-    hipLaunchKernelGGL((kgrad_wide_kernel<T, 2, FAMILY>), grid, dim3(k256), 0, s, kp, zs, Mp, x, ldx, xoff, prescaled, n, nvalid,
-                       Pt, At, gmu, gv, alpha, slice_len, rowpart, scalpart, kmb);
-  } else if (sizeof(T) == 8) {   // 32 < d <= 64 (SVGP_MAX_D), f64: four lanes per row (round 3: 64 slots in one thread - it spilled by the hundred)
-    dim3 grid((unsigned)nslices, (unsigned)(Mp / 16));
-    hipLaunchKernelGGL((kgrad_wide_kernel<T, 4, FAMILY>), grid, dim3(k256), 0, s, kp, zs, Mp, x, ldx, xoff, prescaled, n, nvalid,
-                       Pt, At, gmu, gv, alpha, slice_len, rowpart, scalpart, kmb);
-  } else {   // fp32: the 64-slot thread still wins (H-sized value-and-gradient at d = 64: 73.6 ms against 98.5 with four lanes per row)
-    dim3 grid((unsigned)nslices, (unsigned)(Mp / 64));
-    hipLaunchKernelGGL((kgrad_kernel<T, 64, 1, FAMILY>), grid, dim3(k256), 0, s, kp, zs, Mp, x, ldx, xoff, prescaled, n, nvalid,
-                       Pt, At, gmu, gv, alpha, slice_len, rowpart, scalpart, kmb);
+  } else {
+    // 16 < d <= 64 (same box, H-sized value-and-gradient evaluations, ms; profiles/round5/kgrad_wide2_ab.log):
+    //                         round 4     LPR lanes per row, round-5 registers     a wave per feature group (kgrad_wide2_kernel)
+    //   f64  d = 32             97.3        86.2-87.3                                93.5-93.9
+    //   f64  d = 64            145          114.0-115.1                              114.3-116.7
+    //   fp32 d = 32             47.2        46.2-46.7                                45.8-45.9
+    //   fp32 d = 64             72.9        72.7-74.2 (the 64-slot thread)           63.5-64.1
+    // so: f64 keeps the lanes-per-row form, fp32 takes the wave-per-group form (experiments build: SVGP_KGRAD_WIDE2 = 0 / 1 forces one)
+    static const int wide2_knob = exp_int("SVGP_KGRAD_WIDE2", -1);
+    const bool wide2 = wide2_knob < 0 ? sizeof(T) == 4 : wide2_knob != 0;
+    if (wide2) {
+      dim3 grid((unsigned)nslices, (unsigned)(Mp / 64));
+      if (kp.d <= 32)
+        hipLaunchKernelGGL((kgrad_wide2_kernel<T, 2, FAMILY>), grid, dim3(k256), 0, s, kp, zs, Mp, x, ldx, xoff, prescaled, n, nvalid,
+                           Pt, At, gmu, gv, alpha, slice_len, rowpart, scalpart, kmb);
+      else
+        hipLaunchKernelGGL((kgrad_wide2_kernel<T, 4, FAMILY>), grid, dim3(k256), 0, s, kp, zs, Mp, x, ldx, xoff, prescaled, n, nvalid,
+                           Pt, At, gmu, gv, alpha, slice_len, rowpart, scalpart, kmb);
+    } else if (kp.d <= 32) {   // two lanes per row, 16 features each
+      dim3 grid((unsigned)nslices, (unsigned)(Mp / 32));
+      hipLaunchKernelGGL((kgrad_wide_kernel<T, 2, FAMILY>), grid, dim3(k256), 0, s, kp, zs, Mp, x, ldx, xoff, prescaled, n, nvalid,
+                         Pt, At, gmu, gv, alpha, slice_len, rowpart, scalpart, kmb);
+    } else {                   // four lanes per row
+      dim3 grid((unsigned)nslices, (unsigned)(Mp / 16));
+      hipLaunchKernelGGL((kgrad_wide_kernel<T, 4, FAMILY>), grid, dim3(k256), 0, s, kp, zs, Mp, x, ldx, xoff, prescaled, n, nvalid,
+                         Pt, At, gmu, gv, alpha, slice_len, rowpart, scalpart, kmb);
+    }
   }
 }
 
@@ -880,8 +1112,14 @@ void launch_kgrad_f(hipStream_t s, const KernelParams& kp, const T* zs, int64_t 
   } while (0)
 
 int grad_dreg(int d) { return d <= 8 ? 8 : (d <= 16 ? 16 : (d <= 32 ? 32 : 64)); }
-// workgroups along the rows, exactly launch_kgrad_f's grid: 128 rows (d <= 16), 32 (two lanes per row), 16 (f64, four lanes per row) or 64 (fp32, d > 32)
-int grad_rowblocks(int dtype, int d, int64_t Mp) { return int(d <= 16 ? Mp / 128 : (d <= 32 ? Mp / 32 : (dtype == 0 ? Mp / 16 : Mp / 64))); }
+// workgroups along the rows, exactly launch_kgrad_f's grid: 128 rows (d <= 16); wide inputs: 64 (fp32: a wave per feature group) or 32 / 16
+// (f64: two / four lanes per row)
+int grad_rowblocks(int dtype, int d, int64_t Mp) {
+  if (d <= 16) return int(Mp / 128);
+  const int knob = exp_int("SVGP_KGRAD_WIDE2", -1);
+  const bool wide2 = knob < 0 ? dtype != 0 : knob != 0;
+  return int(wide2 ? Mp / 64 : (d <= 32 ? Mp / 32 : Mp / 16));
+}
 
 void launch_set_f64(hipStream_t s, double* dst, double value) { hipLaunchKernelGGL(set_f64_kernel, dim3(1), dim3(1), 0, s, dst, value); }
 struct Vec64 { double v[64]; };
