@@ -1081,9 +1081,7 @@ void launch_kgrad_f(hipStream_t s, const KernelParams& kp, const T* zs, int64_t 
     //   fp32 d = 32             47.2        46.2-46.7                                45.8-45.9
     //   fp32 d = 64             72.9        72.7-74.2 (the 64-slot thread)           63.5-64.1
     // so: f64 keeps the lanes-per-row form, fp32 takes the wave-per-group form (experiments build: SVGP_KGRAD_WIDE2 = 0 / 1 forces one)
-    static const int wide2_knob = exp_int("SVGP_KGRAD_WIDE2", -1);
-    const bool wide2 = wide2_knob < 0 ? sizeof(T) == 4 : wide2_knob != 0;
-    if (wide2) {
+    auto wide2 = [&]() {
       dim3 grid((unsigned)nslices, (unsigned)(Mp / 64));
       if (kp.d <= 32)
         hipLaunchKernelGGL((kgrad_wide2_kernel<T, 2, FAMILY>), grid, dim3(k256), 0, s, kp, zs, Mp, x, ldx, xoff, prescaled, n, nvalid,
@@ -1091,14 +1089,26 @@ void launch_kgrad_f(hipStream_t s, const KernelParams& kp, const T* zs, int64_t 
       else
         hipLaunchKernelGGL((kgrad_wide2_kernel<T, 4, FAMILY>), grid, dim3(k256), 0, s, kp, zs, Mp, x, ldx, xoff, prescaled, n, nvalid,
                            Pt, At, gmu, gv, alpha, slice_len, rowpart, scalpart, kmb);
-    } else if (kp.d <= 32) {   // two lanes per row, 16 features each
-      dim3 grid((unsigned)nslices, (unsigned)(Mp / 32));
-      hipLaunchKernelGGL((kgrad_wide_kernel<T, 2, FAMILY>), grid, dim3(k256), 0, s, kp, zs, Mp, x, ldx, xoff, prescaled, n, nvalid,
-                         Pt, At, gmu, gv, alpha, slice_len, rowpart, scalpart, kmb);
-    } else {                   // four lanes per row
-      dim3 grid((unsigned)nslices, (unsigned)(Mp / 16));
-      hipLaunchKernelGGL((kgrad_wide_kernel<T, 4, FAMILY>), grid, dim3(k256), 0, s, kp, zs, Mp, x, ldx, xoff, prescaled, n, nvalid,
-                         Pt, At, gmu, gv, alpha, slice_len, rowpart, scalpart, kmb);
+    };
+    auto lanes_per_row = [&]() {
+      if (kp.d <= 32) {   // two lanes per row, 16 features each
+        dim3 grid((unsigned)nslices, (unsigned)(Mp / 32));
+        hipLaunchKernelGGL((kgrad_wide_kernel<T, 2, FAMILY>), grid, dim3(k256), 0, s, kp, zs, Mp, x, ldx, xoff, prescaled, n, nvalid,
+                           Pt, At, gmu, gv, alpha, slice_len, rowpart, scalpart, kmb);
+      } else {            // four lanes per row
+        dim3 grid((unsigned)nslices, (unsigned)(Mp / 16));
+        hipLaunchKernelGGL((kgrad_wide_kernel<T, 4, FAMILY>), grid, dim3(k256), 0, s, kp, zs, Mp, x, ldx, xoff, prescaled, n, nvalid,
+                           Pt, At, gmu, gv, alpha, slice_len, rowpart, scalpart, kmb);
+      }
+    };
+    if constexpr (kExperiments) {
+      static const int wide2_knob = exp_int("SVGP_KGRAD_WIDE2", -1);
+      if (wide2_knob < 0 ? sizeof(T) == 4 : wide2_knob != 0) wide2();
+      else lanes_per_row();
+    } else if constexpr (sizeof(T) == 4) {   // (the product build compiles only the form it takes)
+      wide2();
+    } else {
+      lanes_per_row();
     }
   }
 }
