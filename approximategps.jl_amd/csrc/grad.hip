@@ -390,6 +390,16 @@ __device__ __forceinline__ void kappa_and_d(T r2, T variance, T& k, T& dk) {
 //   rowpart[slice][0][i] += sum_j W_ij           rowpart[slice][1][i] += sum_j At_ji g_mu_j   (m_bar)
 //   rowpart[slice][2+f][i] += sum_j W_ij xs_fj    scalpart[slice][rb][0] += sum P_ij K_ij,  [1+f] += sum W_ij u_fij^2
 // Pt is point-major [n][Mp]; each thread owns KV rows i for the whole slice (scaled z in registers).
+// rows per lane of the 16-feature kernel (same box, H-sized value and gradient at d = 16, profiles/round5/kgrad_kv1_ab.log: f64 two rows
+// - 256 VGPRs with 111-143 spilled - 90.6-91.1 ms, one row 79.8-80.3; fp32 (C3) two rows 149.3-149.6 ms, one row 150.9)
+template <typename T> struct Kgrad16 { static constexpr int KV = sizeof(T) == 8 ? 1 : 2; };
+#ifndef SVGP_KGRAD8_KV_F64
+#define SVGP_KGRAD8_KV_F64 2
+#endif
+#ifndef SVGP_KGRAD8_KV_F32
+#define SVGP_KGRAD8_KV_F32 2
+#endif
+template <typename T> struct Kgrad8 { static constexpr int KV = sizeof(T) == 8 ? SVGP_KGRAD8_KV_F64 : SVGP_KGRAD8_KV_F32; };   // (A/B builds)
 #ifndef SVGP_KGRAD_MINW
 #define SVGP_KGRAD_MINW 2   // waves per SIMD the register allocation must leave room for (A/B builds: 1 = round 4, the 16-feature kernels at 320-336 VGPRs)
 #endif
@@ -1066,12 +1076,12 @@ void launch_kgrad_f(hipStream_t s, const KernelParams& kp, const T* zs, int64_t 
                     int prescaled, int64_t n, int64_t nvalid, const T* Pt, const T* At, const T* gmu, const T* gv, const T* alpha,
                     int64_t slice_len, int nslices, double* rowpart, double* scalpart, int kmb) {
   if (kp.d <= 8) {
-    dim3 grid((unsigned)nslices, (unsigned)(Mp / 128));
-    hipLaunchKernelGGL((kgrad_kernel<T, 8, 2, FAMILY>), grid, dim3(k256), 0, s, kp, zs, Mp, x, ldx, xoff, prescaled, n, nvalid, Pt,
+    dim3 grid((unsigned)nslices, (unsigned)(Mp / (64 * Kgrad8<T>::KV)));
+    hipLaunchKernelGGL((kgrad_kernel<T, 8, Kgrad8<T>::KV, FAMILY>), grid, dim3(k256), 0, s, kp, zs, Mp, x, ldx, xoff, prescaled, n, nvalid, Pt,
                        At, gmu, gv, alpha, slice_len, rowpart, scalpart, kmb);
   } else if (kp.d <= 16) {
-    dim3 grid((unsigned)nslices, (unsigned)(Mp / 128));
-    hipLaunchKernelGGL((kgrad_kernel<T, 16, 2, FAMILY>), grid, dim3(k256), 0, s, kp, zs, Mp, x, ldx, xoff, prescaled, n, nvalid,
+    dim3 grid((unsigned)nslices, (unsigned)(Mp / (64 * Kgrad16<T>::KV)));
+    hipLaunchKernelGGL((kgrad_kernel<T, 16, Kgrad16<T>::KV, FAMILY>), grid, dim3(k256), 0, s, kp, zs, Mp, x, ldx, xoff, prescaled, n, nvalid,
                        Pt, At, gmu, gv, alpha, slice_len, rowpart, scalpart, kmb);
   } else {
     // 16 < d <= 64 (same box, H-sized value-and-gradient evaluations, ms; profiles/round5/kgrad_wide2_ab.log):
@@ -1125,7 +1135,8 @@ int grad_dreg(int d) { return d <= 8 ? 8 : (d <= 16 ? 16 : (d <= 32 ? 32 : 64));
 // workgroups along the rows, exactly launch_kgrad_f's grid: 128 rows (d <= 16); wide inputs: 64 (fp32: a wave per feature group) or 32 / 16
 // (f64: two / four lanes per row)
 int grad_rowblocks(int dtype, int d, int64_t Mp) {
-  if (d <= 16) return int(Mp / 128);
+  if (d <= 8) return int(Mp / (64 * (dtype == 0 ? Kgrad8<double>::KV : Kgrad8<float>::KV)));
+  if (d <= 16) return int(Mp / (64 * (dtype == 0 ? Kgrad16<double>::KV : Kgrad16<float>::KV)));
   const int knob = exp_int("SVGP_KGRAD_WIDE2", -1);
   const bool wide2 = knob < 0 ? dtype != 0 : knob != 0;
   return int(wide2 ? Mp / 64 : (d <= 32 ? Mp / 32 : Mp / 16));

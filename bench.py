@@ -50,7 +50,7 @@ CONFIGS = {
     # wide inputs (round 4): the headline shape at d = 32 / 64, both precisions
     "Hd32": (1_000_000, 1024, 32, SE, GAUSS, "f64", 6), "Hd64": (1_000_000, 1024, 64, SE, GAUSS, "f64", 6),
     "H32d32": (1_000_000, 1024, 32, SE, GAUSS, "f32", 6), "H32d64": (1_000_000, 1024, 64, SE, GAUSS, "f32", 6),
-    "Hd17": (1_000_000, 1024, 17, SE, GAUSS, "f64", 6), "Hd24": (1_000_000, 1024, 24, SE, GAUSS, "f64", 6), "Hd48": (1_000_000, 1024, 48, SE, GAUSS, "f64", 6),
+    "Hd16": (1_000_000, 1024, 16, SE, GAUSS, "f64", 6), "Hd17": (1_000_000, 1024, 17, SE, GAUSS, "f64", 6), "Hd24": (1_000_000, 1024, 24, SE, GAUSS, "f64", 6), "Hd48": (1_000_000, 1024, 48, SE, GAUSS, "f64", 6),
     # minibatch shapes of the verdict's prep-overlap targets
     "MB16k": (16_384, 1024, 8, SE, GAUSS, "f64", 7), "MB4k": (4_096, 512, 8, SE, GAUSS, "f64", 7),
 }
