@@ -184,3 +184,23 @@ def test_kuf_assembly_at_every_padded_feature_count(ctx, dtype, atol, family):
             assert err <= atol * sva.kernel.variance, (d, M, err)
             model.free()
             data.free()
+
+
+@pytest.mark.parametrize("d", [9, 16])
+@pytest.mark.parametrize("family", [o.KERNEL_SE, o.KERNEL_MATERN52])
+@pytest.mark.parametrize("dtype,tol,gtol", [(np.float64, 1e-8, 1e-6), (np.float32, 1e-4, 3e-3)])
+def test_gradient_on_the_sixteen_feature_reduction_kernel(ctx, dtype, tol, gtol, family, d):
+    """8 < d <= 16 takes the 16-feature form of kgrad_kernel (grad.hip), since round 5 with ONE row per lane in f64 (two rows spilled
+    111-143 VGPRs) and two in fp32: value and every gradient block against the oracle's, M spanning several 64- / 128-row blocks with a
+    ragged last one, a ragged batch of several slices."""
+    N, M = 2311, 300
+    x, y, sva, s2 = o.synth_problem(5200 + d, N, M, d, family=family, dtype=dtype)
+    model = device_model(ctx, sva, dtype=dtype, sigma2=s2)
+    data = _ffi.DeviceData(ctx, x, y, dtype)
+    val_ref, g_ref = o.elbo_grad(sva, x, y, sigma2=s2, num_data=2.0 * N)
+    val, _, g = model.elbo_grad(data, 0, N, 2.0 * N)
+    assert rel(val, val_ref) < tol
+    for k in ("m", "Lq", "z", "inv_lengthscale"):
+        assert _blk(g[k], g_ref[k]) <= gtol, (k, _blk(g[k], g_ref[k]))
+    model.free()
+    data.free()
