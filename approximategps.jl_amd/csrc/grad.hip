@@ -1071,6 +1071,36 @@ __global__ void finish_kgrad_kernel(int d, int64_t M, int64_t Mp, const T* __res
   }
 }
 
+// the two forms of the wide-input reductions as function templates (NOT lambdas inside launch_kgrad_f: a lambda's body is instantiated
+// with its enclosing function whether it is called or not, and the product build would compile both kernel families for both dtypes)
+#define SVGP_KGRAD_ARGS                                                                                                          \
+  hipStream_t s, const KernelParams &kp, const T *zs, int64_t Mp, const T *x, int64_t ldx, int64_t xoff, int prescaled, int64_t n, \
+      int64_t nvalid, const T *Pt, const T *At, const T *gmu, const T *gv, const T *alpha, int64_t slice_len, int nslices,        \
+      double *rowpart, double *scalpart, int kmb
+template <typename T, int FAMILY>
+void launch_kgrad_groups(SVGP_KGRAD_ARGS) {   // a wave per 16-feature group
+  dim3 grid((unsigned)nslices, (unsigned)(Mp / 64));
+  if (kp.d <= 32)
+    hipLaunchKernelGGL((kgrad_wide2_kernel<T, 2, FAMILY>), grid, dim3(k256), 0, s, kp, zs, Mp, x, ldx, xoff, prescaled, n, nvalid,
+                       Pt, At, gmu, gv, alpha, slice_len, rowpart, scalpart, kmb);
+  else
+    hipLaunchKernelGGL((kgrad_wide2_kernel<T, 4, FAMILY>), grid, dim3(k256), 0, s, kp, zs, Mp, x, ldx, xoff, prescaled, n, nvalid,
+                       Pt, At, gmu, gv, alpha, slice_len, rowpart, scalpart, kmb);
+}
+template <typename T, int FAMILY>
+void launch_kgrad_lanes(SVGP_KGRAD_ARGS) {    // two / four lanes per row, 16 features each
+  if (kp.d <= 32) {
+    dim3 grid((unsigned)nslices, (unsigned)(Mp / 32));
+    hipLaunchKernelGGL((kgrad_wide_kernel<T, 2, FAMILY>), grid, dim3(k256), 0, s, kp, zs, Mp, x, ldx, xoff, prescaled, n, nvalid,
+                       Pt, At, gmu, gv, alpha, slice_len, rowpart, scalpart, kmb);
+  } else {
+    dim3 grid((unsigned)nslices, (unsigned)(Mp / 16));
+    hipLaunchKernelGGL((kgrad_wide_kernel<T, 4, FAMILY>), grid, dim3(k256), 0, s, kp, zs, Mp, x, ldx, xoff, prescaled, n, nvalid,
+                       Pt, At, gmu, gv, alpha, slice_len, rowpart, scalpart, kmb);
+  }
+}
+#undef SVGP_KGRAD_ARGS
+
 template <typename T, int FAMILY>
 void launch_kgrad_f(hipStream_t s, const KernelParams& kp, const T* zs, int64_t Mp, const T* x, int64_t ldx, int64_t xoff,
                     int prescaled, int64_t n, int64_t nvalid, const T* Pt, const T* At, const T* gmu, const T* gv, const T* alpha,
@@ -1091,35 +1121,17 @@ void launch_kgrad_f(hipStream_t s, const KernelParams& kp, const T* zs, int64_t 
     //   fp32 d = 32             47.2        46.2-46.7                                45.8-45.9
     //   fp32 d = 64             72.9        72.7-74.2 (the 64-slot thread)           63.5-64.1
     // so: f64 keeps the lanes-per-row form, fp32 takes the wave-per-group form (experiments build: SVGP_KGRAD_WIDE2 = 0 / 1 forces one)
-    auto wide2 = [&]() {
-      dim3 grid((unsigned)nslices, (unsigned)(Mp / 64));
-      if (kp.d <= 32)
-        hipLaunchKernelGGL((kgrad_wide2_kernel<T, 2, FAMILY>), grid, dim3(k256), 0, s, kp, zs, Mp, x, ldx, xoff, prescaled, n, nvalid,
-                           Pt, At, gmu, gv, alpha, slice_len, rowpart, scalpart, kmb);
-      else
-        hipLaunchKernelGGL((kgrad_wide2_kernel<T, 4, FAMILY>), grid, dim3(k256), 0, s, kp, zs, Mp, x, ldx, xoff, prescaled, n, nvalid,
-                           Pt, At, gmu, gv, alpha, slice_len, rowpart, scalpart, kmb);
-    };
-    auto lanes_per_row = [&]() {
-      if (kp.d <= 32) {   // two lanes per row, 16 features each
-        dim3 grid((unsigned)nslices, (unsigned)(Mp / 32));
-        hipLaunchKernelGGL((kgrad_wide_kernel<T, 2, FAMILY>), grid, dim3(k256), 0, s, kp, zs, Mp, x, ldx, xoff, prescaled, n, nvalid,
-                           Pt, At, gmu, gv, alpha, slice_len, rowpart, scalpart, kmb);
-      } else {            // four lanes per row
-        dim3 grid((unsigned)nslices, (unsigned)(Mp / 16));
-        hipLaunchKernelGGL((kgrad_wide_kernel<T, 4, FAMILY>), grid, dim3(k256), 0, s, kp, zs, Mp, x, ldx, xoff, prescaled, n, nvalid,
-                           Pt, At, gmu, gv, alpha, slice_len, rowpart, scalpart, kmb);
-      }
-    };
     if constexpr (kExperiments) {
       static const int wide2_knob = exp_int("SVGP_KGRAD_WIDE2", -1);
-      if (wide2_knob < 0 ? sizeof(T) == 4 : wide2_knob != 0) wide2();
-      else lanes_per_row();
+#define SVGP_KGRAD_PASS s, kp, zs, Mp, x, ldx, xoff, prescaled, n, nvalid, Pt, At, gmu, gv, alpha, slice_len, nslices, rowpart, scalpart, kmb
+      if (wide2_knob < 0 ? sizeof(T) == 4 : wide2_knob != 0) launch_kgrad_groups<T, FAMILY>(SVGP_KGRAD_PASS);
+      else launch_kgrad_lanes<T, FAMILY>(SVGP_KGRAD_PASS);
     } else if constexpr (sizeof(T) == 4) {   // (the product build compiles only the form it takes)
-      wide2();
+      launch_kgrad_groups<T, FAMILY>(SVGP_KGRAD_PASS);
     } else {
-      lanes_per_row();
+      launch_kgrad_lanes<T, FAMILY>(SVGP_KGRAD_PASS);
     }
+#undef SVGP_KGRAD_PASS
   }
 }
 

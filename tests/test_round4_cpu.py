@@ -194,6 +194,39 @@ def test_every_kernel_the_host_side_registers_has_device_code():
         assert not missing, (lib, missing[:5], len(missing))
 
 
+def test_no_product_kernel_runs_at_one_wave_per_simd_unnoticed():
+    """Round 5 found the kernel-gradient reductions of wide inputs at 345-350 VGPRs - ONE wave per SIMD - and their 16-feature f64 form
+    spilling 111-143 VGPRs: an H-sized value-and-gradient evaluation at d = 64 took 145 ms (116 now), at d = 16 90.8 (79.8).  Nothing had
+    looked at the register counts of kernels outside strip.hip.  For the built product library: a kernel that needs more than 256 VGPRs
+    + AGPRs (one wave per SIMD) or spills must be on the lists below, each entry with the reason it is acceptable."""
+    import re
+    from approxgp import _ffi
+    tools = ["/opt/rocm/lib/llvm/bin/llvm-readelf", "/opt/rocm/lib/llvm/bin/clang-offload-bundler", "/opt/rocm/lib/llvm/bin/llvm-objcopy"]
+    if not os.path.exists(_ffi.LIB_PATH) or "experiments" in os.path.basename(_ffi.LIB_PATH) or not all(os.path.exists(t) for t in tools):
+        import pytest
+        pytest.skip("needs the built product library and the ROCm llvm tools")
+    one_wave_ok = (
+        "expect_kernelI",        # per-point likelihood expectations (lgamma / Gauss-Hermite loops): 0.04-0.2 ms per evaluation
+        "point_grad_kernelI",    # their adjoint: 7-31 us per 65 536-point chunk
+        "chol_tile_kernelIdLi1ELi32ELb1ELb0E",   # the 256-thread fused update + block factorisation: <= 28 workgroups, latency-bound chain
+    )
+    spills_ok = (
+        "expect_kernelI", "kgrad_kernelIdLi16E", "kgrad_kernelIfLi16E",   # kgrad 16-feature forms: measured faster WITH the two-wave bound (kgrad_minw_ab.log)
+        "kuf_cols_kernelIdLi64E",                                           # 2-4 VGPRs in the prologue
+        "strip_kernelI",                                                      # checked kernel by kernel in the next test
+    )
+    offenders = []
+    for m in re.finditer(r"\.name:\s+(_Z\S+)(.*?)\.wavefront_size", _code_object_notes(_ffi.LIB_PATH), flags=re.S):
+        name, body = m.group(1), m.group(2)
+        g = lambda k: int((re.search(r"\." + k + r":\s+(\d+)", body) or [None, "0"])[1])
+        regs, spill = g("vgpr_count") + g("agpr_count"), g("vgpr_spill_count")
+        if regs > 256 and not any(t in name for t in one_wave_ok):
+            offenders.append((name[:90], "registers", regs))
+        if spill > 0 and not any(t in name for t in spills_ok):
+            offenders.append((name[:90], "spilled", spill))
+    assert not offenders, offenders
+
+
 def test_product_build_has_at_most_thirty_strip_kernels_and_none_that_spills():
     """the product build instantiates strip_kernel 30 times (5 shapes x {forward, value-and-gradient} x {d <= 16,
     wide inputs} + 5 x 2 segmented), none at occupancy 1 and none with spilled registers; the in-kernel likelihood-gradient forms
