@@ -204,3 +204,23 @@ def test_gradient_on_the_sixteen_feature_reduction_kernel(ctx, dtype, tol, gtol,
         assert _blk(g[k], g_ref[k]) <= gtol, (k, _blk(g[k], g_ref[k]))
     model.free()
     data.free()
+
+
+@pytest.mark.parametrize("dtype,tol,gtol", [(np.float64, 1e-8, 1e-6), (np.float32, 1e-4, 3e-3)])
+def test_wide_input_gradient_on_tiny_and_ragged_batches(ctx, dtype, tol, gtol):
+    """The wide-input kernel-gradient reductions (grad.hip: lanes per row in f64, a wave per 16-feature group in fp32) walk a batch in
+    groups of 4 points per wave and blocks of 64 / 128 points: batches of 1, 3, 5 and 131 points (shorter than a group, than a block,
+    one point past a block), d = 20 and 40, against the oracle."""
+    for N, d in ((1, 20), (3, 40), (5, 20), (131, 40)):
+        M = 70
+        x, y, sva, s2 = o.synth_problem(6100 + 10 * N + d, max(N, 2), M, d, family=o.KERNEL_MATERN32, dtype=dtype)
+        x, y = x[:, :N], y[:N]
+        model = device_model(ctx, sva, dtype=dtype, sigma2=s2)
+        data = _ffi.DeviceData(ctx, x, y, dtype)
+        val_ref, g_ref = o.elbo_grad(sva, x, y, sigma2=s2, num_data=9.0 * N)
+        val, _, g = model.elbo_grad(data, 0, N, 9.0 * N)
+        assert rel(val, val_ref) < tol, (N, d)
+        for k in ("m", "Lq", "z", "inv_lengthscale"):
+            assert _blk(g[k], g_ref[k]) <= gtol, (N, d, k, _blk(g[k], g_ref[k]))
+        model.free()
+        data.free()
