@@ -1,0 +1,7 @@
+#!/usr/bin/env bash
+cd "$GRAFT_REPO_ROOT"; O=gpurun_out/r5_ops; mkdir -p $O
+f() { grep -v "^RCCL\|^HIP\|^ROCm\|^Hostname\|^Librccl"; }
+for e in "SVGP_TIMING=0" "SVGP_NONE=0"; do
+  echo "== $e"
+  (export $e; timeout 1200 python -m pytest tests/test_gpu_parity.py tests/test_gpu_grad.py tests/test_gpu_round5.py -m gpu -q 2>&1 | f | tail -n 2)
+done 2>&1 | tee $O/operational_settings_pass2.log

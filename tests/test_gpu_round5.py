@@ -110,19 +110,23 @@ def test_operational_settings_are_read_at_context_creation():
     import os
     N, M, d = 8192, 1024, 4
     x, y, sva, s2 = o.synth_problem(8600, N, M, d)
-    with context_with_env(SVGP_OVERLAP="0") as c0, context_with_env(SVGP_OVERLAP="1") as c1:
+    with context_with_env(SVGP_OVERLAP="0", SVGP_TIMING="1") as c0, context_with_env(SVGP_OVERLAP="1", SVGP_TIMING="1") as c1:
         res = {}
         for name, c in (("off", c0), ("on", c1)):
             model = device_model(c, sva, sigma2=s2)
             data = _ffi.DeviceData(c, x, y, np.float64)
+            ambient = {k: os.environ.get(k) for k in ("SVGP_OVERLAP", "SVGP_TIMING")}   # (the suite itself may run under a setting)
             os.environ["SVGP_OVERLAP"] = "1" if name == "off" else "0"      # the opposite of what the context was created with
             os.environ["SVGP_TIMING"] = "0"
             try:
                 v = model.elbo(data, 0, N, float(N))[0]
                 t = c.timing()
             finally:
-                os.environ.pop("SVGP_OVERLAP")
-                os.environ.pop("SVGP_TIMING")
+                for k, v0 in ambient.items():
+                    if v0 is None:
+                        os.environ.pop(k, None)
+                    else:
+                        os.environ[k] = v0
             res[name] = (v, t.ms_overlap, t.ms_total)
             model.free(), data.free()
     assert res["off"][0] == res["on"][0]
