@@ -232,7 +232,7 @@ int enqueue_prep(svgp_ctx* ctx, svgp_model* m, bool overlap = false, const RowHo
     la.ev = ctx->ev_row;
   }
   TREC(ctx, ctx->ev_chol[0], s);
-  launch_potrf(m->dtype, s, m->L, m->T, m->Mp, m->info, reinterpret_cast<unsigned*>(m->info + 1), overlap ? ctx->ev_row : nullptr,
+  launch_potrf(m->dtype, s, m->L, m->T, m->Mp, m->info, reinterpret_cast<unsigned*>(m->info + 1), ctx->num_cus, overlap ? ctx->ev_row : nullptr,
                overlap ? hook : nullptr, la.s2 ? &la : nullptr);   // T panels included
   KCHECK(ctx, "potrf");
   TREC(ctx, ctx->ev_chol[1], s);
@@ -1366,7 +1366,13 @@ int grad_workspace(svgp_ctx* ctx, svgp_model* m, int64_t len, GradWs** out) {
   // and rejected: H 81.9 -> 85-87 ms - the operand re-reads come out of the Infinity Cache at no cost to the MFMA pipe.
   w->nslices = syrk_slices(ctx, m, int64_t(1) << 40);   // the buffer holds the count an unbounded chunk would take: a call's count never exceeds it
   w->rb = grad_rowblocks(m->dtype, m->d, Mp);
-  static const int kg_wg = exp_int("SVGP_KGRAD_WG_PER_CU", 2);   // tuning knob (experiments build)
+  // workgroups per CU of the kernel-gradient reductions (grad.hip: kgrad_mfma_kernel): as many as its registers and LDS admit - the kernel
+  // is a chain global load -> MFMA -> kernel function -> MFMA per 16-point tile and lives off the waves it can interleave (rocprofv3, us
+  // per 65 536-point chunk at M = 1024, 2 / 3 / 4 / 6 per CU: d = 8 f64 185 / 171 / 162 / 177, fp32 115 / 99 / 88 / 104; d = 64 f64, whose
+  // 72 KiB of LDS admit two, 512 / 671 / 549 / 598; profiles/round6/kgrad_wg_per_cu.log)
+  const int kg_dflt = grad_dreg(m->d) <= 16 ? 4 : (grad_dreg(m->d) <= 32 ? 3 : 2);
+  static const int kg_knob = exp_int("SVGP_KGRAD_WG_PER_CU", 0);   // tuning knob (experiments build)
+  const int kg_wg = kg_knob > 0 ? kg_knob : kg_dflt;
   int nu = (kg_wg * ctx->num_cus + w->rb - 1) / w->rb;
   w->ns_uf = nu < 1 ? 1 : (nu > 256 ? 256 : nu);
   w->ns_uu = 8;

@@ -122,6 +122,24 @@ __device__ __forceinline__ float kexp(float v) {
   const float e = __builtin_amdgcn_exp2f(hi);
   return fmaf(e, lo * 0.693147180559945309f, e);
 }
+// kexp_tab - exp(v), v <= 0, from a 64-entry table tab[j] = 2^(j/64) (LDS) + a degree-5 polynomial: v = (64 m + j) ln2 / 64 + r, |r| <= ln2 / 128: 2^m * tab[j] * (1 + r + ... + r^5 / 120) (truncation 3.5e-17): ~15 VALU
+// instructions and one LDS read against kexp's ~20 - the pre-generation is VALU-bound and f64 VALU blocks the MFMA pipe of the
+// partner workgroup too (s_memtime stamps: 140-158k of a forward strip's 2230k ticks).  Same box, three repetitions, H strip ms:
+// 33.44 / 33.41 / 33.57 with kexp, 33.35 / 33.33 / 33.27 with the table (C2 1.13 vs 1.13): -0.5 %, parity tests unchanged; 212 VGPRs either way
+__device__ __forceinline__ double kexp_tab(double v, const double* __restrict__ tab) {
+  const double nd = rint(v * 92.332482616893658);               // 64 / ln2
+  const int n = int(nd);
+  double r = fma(nd, -1.08304246932675596327e-02, v);           // ln2_hi / 64 (kexp's split, exact in binary)
+  r = fma(nd, -2.98158582698529328128e-12, r);                  // ln2_lo / 64
+  const double t = tab[n & 63];
+  double p = fma(r, 8.333333333333333e-03, 4.1666666666666664e-02);
+  p = fma(p, r, 1.6666666666666666e-01);
+  p = fma(p, r, 0.5);
+  p = fma(p, r, 1.0);
+  p *= r;                                                       // exp(r) - 1
+  return ldexp(fma(t, p, t), n >> 6);
+}
+
 __device__ __forceinline__ double ksqrt(double v) { return sqrt(v); }
 __device__ __forceinline__ float ksqrt(float v) { return __builtin_amdgcn_sqrtf(v); }   // v_sqrt_f32, 1 ulp
 
@@ -346,9 +364,16 @@ struct TileGemm {
   // Workgroup barriers a thread executes inside one call of the loops below - for kernels that keep PASSENGER waves at the loops'
   // barriers (prep.hip: the 512-thread fused factorisation kernels, whose waves 4-7 only join the block factorisation afterwards):
   // loop / loop_tri: the prologue's, one per step, the closing one; loop_tri_async(_w): the prologue's, one per step but the last, the
-  // closing one.  KEEP IN STEP WITH THE LOOPS (a miscount deadlocks those kernels; tests/test_gpu_round5.py runs them).
-  static constexpr int loop_barrier_count(int nsteps) { return nsteps <= 0 ? 0 : nsteps + 2; }
-  static constexpr int async_barrier_count(int nsteps) { return nsteps <= 0 ? 0 : nsteps + 1; }
+  // closing one.  KEEP IN STEP WITH THE LOOPS.  A miscount does NOT deadlock: passengers of a workgroup that does not go on to the
+  // block factorisation simply exit, and exited waves drop out of s_barrier; in the workgroup that does go on the passengers' barrier
+  // phases would shift into potf2_body's - a SILENT LDS race, caught only by the tests that check the factor
+  // itself (every ELBO parity case with 2 <= M / 128 <= 16 runs the 512-thread form; tests/test_gpu_round5.py::test_large_kuu_factorisation
+  // and tools/chol_check.py compare the factor).  The counts are spelled as prologue + per-step + closing so that an edit of a loop
+  // has one obvious line to change with it.
+  static constexpr int kLoopPrologueBarriers = 1, kLoopClosingBarriers = 1;   // loop_tri: store tile 0 | __syncthreads, ..., closing __syncthreads; one per step in step()
+  static constexpr int kAsyncPrologueBarriers = 1, kAsyncClosingBarriers = 1; // loop_tri_async_w: wait_barrier before the first fragments, closing __syncthreads; astep: one per step but the last
+  static constexpr int loop_barrier_count(int nsteps) { return nsteps <= 0 ? 0 : kLoopPrologueBarriers + nsteps + kLoopClosingBarriers; }
+  static constexpr int async_barrier_count(int nsteps) { return nsteps <= 0 ? 0 : kAsyncPrologueBarriers + (nsteps - 1) + kAsyncClosingBarriers; }
 
   // --- the K loop -----------------------------------------------------------------------------------
   // P tile of step t is Pbase + t*BK*ldp (Pbase wave-uniform); QLoad::operator()(step, QRegs&) produces the

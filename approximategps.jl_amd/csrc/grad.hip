@@ -950,6 +950,297 @@ __global__ void __launch_bounds__(k256, 2) kgrad_wide2_kernel(KernelParams kp, c
   }
 }
 
+// ---- the kernel-gradient reductions on the MFMA (round 6) ----------------------------------------------------
+// The three kernels above hold a row's feature sums in VALU registers: ~75 (d = 8) to ~450 (d = 64) VALU instructions per 64 entries
+// of W, no matrix instruction.  Here both data-sized contractions are MFMAs and the VALU is left the kernel function itself:
+//   (1) r2 tile (16 points x 16 inducing rows) = |x|^2 + |z|^2 - 2 x.z on the MFMA (accumulator preloaded with the norms, as the
+//       strips' pre-generation and kuf_cols_kernel do): D[point slot][inducing row];
+//   (2) VALU, 4 entries per lane: kernel function and its derivative, P = alpha g_mu' + 2 (R A) diag(g_v), W = P o dK/dr2, the row
+//       sums R_i = sum_j W_ij, (Kuf g_mu)_i, sum P o K;
+//   (3) Q (16 rows x 16 features) += W (16 rows x 4 points) X (4 points x 16 features): register r of the D tile of (1), as it
+//       stands, IS the A operand of a 16x16x4 MFMA whose four k-slots are the points {g + 4 r} (g = lane / 16) - W never moves
+//       between lanes - and the B operand is read from the staged x tile at those points.
+// The lengthscale sums IL_f = sum_ij W_ij (z_fi - x_fj)^2 are not accumulated entry by entry (4 d VALU instructions per entry):
+//     IL_f = sum_i (z_fi^2 R_i - 2 z_fi Q_fi) + sum_j x_fj^2 C_j,        C_j = sum_i W_ij  (over the workgroup's rows: linear, so
+// per-workgroup partials add up), C_j by a DPP butterfly over the 16 lanes of a row group.  d <= 8: the eight spare columns of the one
+// feature tile carry x_f^2 instead and give sum_j W_ij x_fj^2 directly.  The expansion cancels where |z - x| << |z|: relative error
+// eps (|z|^2 + |x|^2) / |z - x|^2 in units of the scaled inputs - the same exposure as the MFMA distances themselves - so both x and
+// z are taken RELATIVE TO A CENTRE c (the workgroup's first inducing row): distances and IL do not change, |z|, |x| become the spread of
+// the data instead of its distance from the origin, and the row sums leave as Q = Q' + c R (fp64).  (Found by the one-point,
+// one-inducing-point case of test_gradient_degenerate_shapes: z = x + 1e-3, where the fp32 build lost IL altogether.)
+// A wave owns 16 inducing rows for the whole slice of points (no cross-wave sums but the scalars), a workgroup 64 rows; the staged
+// tile is point-major with row stride DL + 16 bytes... (+6 / +4 elements): the r2 operand reads are conflict-free, and the pad columns
+// carry g_mu, 2 g_v and c1 |x|^2 of the point.  fp32: per staged block (128 points) sums in fp32 (MFMA accumulators included), totals fp64.
+// Same interface and partial-sum layout as kgrad_kernel; rows per workgroup: 64 for every d.
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, true);
+  return __hiloint2double(hi, lo);
+}
+// sum over the 16 lanes of a DPP row, left in every lane: quad_perm [1,0,3,2], [2,3,0,1], row_half_mirror, row_mirror
+template <typename T>
+__device__ __forceinline__ T row16_sum(T v) {
+  v += dpp_mov<0xB1>(v);
+  v += dpp_mov<0x4E>(v);
+  v += dpp_mov<0x141>(v);
+  v += dpp_mov<0x140>(v);
+  return v;
+}
+
+template <typename T, int FAMILY, int DL>
+__global__ void __launch_bounds__(k256, 2) kgrad_mfma_kernel(KernelParams kp, const T* __restrict__ zs, int64_t Mp,
+                                                             const T* __restrict__ x, int64_t ldx, int64_t xoff, int prescaled,
+                                                             int64_t n, int64_t nvalid, const T* __restrict__ Pt,
+                                                             const T* __restrict__ gmu, const T* __restrict__ gv,
+                                                             const T* __restrict__ alpha, int64_t slice_len,
+                                                             double* __restrict__ rowpart, double* __restrict__ scalpart, int kmb) {
+  using M16 = Mfma16<T>;
+  using acc_t = typename M16::acc_t;
+  constexpr bool kF64 = (sizeof(T) == 8);
+  constexpr bool SQ = (DL == 8);                    // x_f^2 in the spare columns 8..15 of the feature tile
+  constexpr int JB = 128, KS = DL / 4, CT = (DL + 15) / 16, NTILE = JB / 16;
+  constexpr int NQ = (CT <= 2) ? 2 : 1;             // independent accumulator sets of step (3) (a lone tile would be a chain of dependent MFMAs)
+  constexpr int XLD = DL + (kF64 ? 6 : 4);          // f64: 16 rows x two k-slots on 32 distinct 8-byte banks; fp32: 16 x 4 on 64 banks
+  constexpr int GM = DL, GV = DL + 1, XN = DL + 2;  // pad columns of a staged point
+  constexpr T c1 = (FAMILY == KSE) ? T(-0.5) : T(1);      // SE: the tile holds -r2 / 2, the argument of exp
+  constexpr T ascale = (FAMILY == KSE) ? T(1) : T(-2);
+  __shared__ __attribute__((aligned(16))) T xt[JB * XLD];
+  __shared__ double sred[4][2 + 16 * CT];
+  __shared__ T cz[DL];                              // the centre: scaled inducing row blockIdx.y * 64 (zeros beyond d)
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(int(threadIdx.x >> 6)), l15 = lane & 15, g = lane >> 4;
+  const int d = kp.d;
+  const T* __restrict__ invl = static_cast<const T*>(kp.invl);
+  const int64_t iw0 = int64_t(blockIdx.y) * 64 + wave * 16, i = iw0 + l15;   // this lane's inducing row (tile column / A-operand row)
+  if (int(threadIdx.x) < DL) cz[threadIdx.x] = (int(threadIdx.x) < d) ? zs[int64_t(threadIdx.x) * Mp + int64_t(blockIdx.y) * 64] : T(0);
+  __syncthreads();
+  const int64_t j0 = int64_t(blockIdx.x) * slice_len;
+  int64_t j1 = j0 + slice_len;
+  j1 = j1 < n ? j1 : n;
+  // z fragments of the wave's 16 rows (B operand of step (1): B[k = feature 4 q + g][col = row l15]) and c1 |z_i|^2
+  T za[KS], zn = T(0);
+#pragma unroll
+  for (int q = 0; q < KS; ++q) {
+    const int f = 4 * q + g;
+    const T v = (f < d) ? zs[int64_t(f) * Mp + i] - cz[f] : T(0);
+    za[q] = ascale * v;
+    zn = fma(v, v, zn);
+  }
+  zn += __shfl_xor(zn, 16);
+  zn += __shfl_xor(zn, 32);
+  zn *= c1;
+  const T al = alpha ? alpha[i] : T(0);
+  // the staged slot a lane reads as A operand of step (1): D row s of the tile is point g + 4 r for f64 (s = g + 4 r) and must be made
+  // the same point for fp32 (s = 4 g + r), so that the k-slots of step (3) are the points g + 4 r in both
+  const int slot_pt = kF64 ? l15 : ((l15 >> 2) + 4 * (l15 & 3));
+  const T* __restrict__ xa = xt + slot_pt * XLD + g;         // + (16 t) XLD + 4 q
+  const T* __restrict__ xb = xt + g * XLD + (SQ ? (l15 & 7) : l15);   // + (16 t + 4 r) XLD + 16 c
+  const T* __restrict__ prow = Pt + i;
+  // totals (fp64) and, fp32 builds, the staged block's sums
+  double Rd = 0.0, MBd = 0.0, S1d = 0.0, ILd[SQ ? 1 : CT], Qd[kF64 ? 1 : CT][kF64 ? 1 : 4];
+  acc_t Q[NQ][CT];
+  T Rl = T(0), MBl = T(0), S1l = T(0), ILx[SQ ? 1 : CT];
+#pragma unroll
+  for (int c = 0; c < CT; ++c) {
+    if constexpr (!SQ) { ILd[c] = 0.0; ILx[c] = T(0); }
+    if constexpr (!kF64) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) Qd[c][r] = 0.0;
+    }
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) Q[q][c] = acc_t{0, 0, 0, 0};
+  }
+  if constexpr (SQ) ILd[0] = 0.0;
+  (void)ILx;
+  for (int64_t jb = j0; jb < j1; jb += JB) {
+    __syncthreads();
+    // stage the block: scaled inputs point-major, (g_mu, 2 g_v) of the point (zeros beyond the slice: P = 0 there), then c1 |x|^2
+    for (int e = threadIdx.x; e < JB * DL; e += k256) {
+      const int c = e % JB, f = e / JB;
+      int64_t gg = jb + c;
+      gg = gg < nvalid ? gg : nvalid - 1;
+      T v = T(0);
+      if (f < d) v = (prescaled ? x[int64_t(f) * ldx + xoff + gg] : x[int64_t(f) * ldx + xoff + gg] * invl[f]) - cz[f];
+      xt[c * XLD + f] = v;
+    }
+    if (threadIdx.x < JB) {
+      const int64_t gg = jb + threadIdx.x;
+      const bool ok = gg < j1;
+      xt[threadIdx.x * XLD + GM] = (ok && gmu) ? gmu[gg] : T(0);
+      xt[threadIdx.x * XLD + GV] = ok ? (alpha ? T(2) * gv[gg] : T(1)) : T(0);
+    }
+    __syncthreads();
+    if (threadIdx.x < JB) {
+      const T* __restrict__ xp = xt + threadIdx.x * XLD;
+      T s = T(0);
+#pragma unroll
+      for (int f = 0; f < DL; ++f) s = fma(xp[f], xp[f], s);
+      xt[threadIdx.x * XLD + XN] = c1 * s;
+    }
+    __syncthreads();
+    // P of a tile is fetched one tile ahead (4 entries per lane: points g + 4 r of the tile, row i)
+    T pn[4];
+    auto fetch = [&](int t) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        int64_t j = jb + 16 * t + g + 4 * r;
+        j = j < j1 ? j : j1 - 1;
+        pn[r] = prow[j * Mp];
+      }
+    };
+    fetch(0);
+#pragma unroll 1
+    for (int t = 0; t < NTILE; ++t) {
+      if (jb + 16 * t >= j1) break;   // (workgroup-uniform)
+      T pv[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) pv[r] = pn[r];
+      if (t + 1 < NTILE) fetch(t + 1);   // (a tile wholly beyond j1 re-reads the last point: never used)
+      const T* __restrict__ xat = xa + (16 * t) * XLD;
+      const T* __restrict__ xbt = xb + (16 * t) * XLD;
+      // (1) the distance tile
+      acc_t a, a2 = {0, 0, 0, 0};
+      T gm[4], gv2[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const T* __restrict__ xp = xt + (16 * t + g + 4 * r) * XLD;
+        gm[r] = xp[GM];
+        gv2[r] = xp[GV];
+        a[r] = xp[XN] + zn;
+      }
+      if constexpr (KS >= 4) {   // two chains (even / odd feature slabs)
+#pragma unroll
+        for (int q = 0; q < KS; q += 2) {
+          a = M16::mma(xat[4 * q], za[q], a);
+          a2 = M16::mma(xat[4 * q + 4], za[q + 1], a2);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) a[r] += a2[r];
+      } else {
+#pragma unroll
+        for (int q = 0; q < KS; ++q) a = M16::mma(xat[4 * q], za[q], a);
+      }
+      // (2) kernel function, P, W
+      T w[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const T p = fma(gv2[r], pv[r], al * gm[r]);   // (alpha == nullptr: 1 * pv + 0; beyond the slice: 0)
+        if constexpr (FAMILY == KSE) {
+          // unit variance and without the factor -1/2 of dK/dr2: both are applied to the sums at the end (sum P o K = sum_i of the R_i here)
+          const T e = kexp(a[r] < T(0) ? a[r] : T(0));
+          w[r] = p * e;
+          if (kmb) MBl = fma(e, gm[r], MBl);
+        } else {
+          T k, dk;
+          kappa_and_d<T, FAMILY>(a[r] > T(0) ? a[r] : T(0), T(1), k, dk);
+          w[r] = p * dk;
+          S1l = fma(p, k, S1l);
+          if (kmb) MBl = fma(k, gm[r], MBl);
+        }
+        Rl += w[r];
+      }
+      // (3) the feature sums
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        [[maybe_unused]] T cs = T(0);
+        if constexpr (!SQ) cs = row16_sum(w[r]);
+#pragma unroll
+        for (int c = 0; c < CT; ++c) {
+          T xv = xbt[(4 * r) * XLD + 16 * c];
+          if constexpr (SQ) xv = (l15 & 8) ? xv * xv : xv;
+          else ILx[c] = fma(xv * xv, cs, ILx[c]);
+          Q[r % NQ][c] = M16::mma(w[r], xv, Q[r % NQ][c]);
+        }
+      }
+    }
+    if constexpr (!kF64) {   // the block's fp32 sums join the fp64 totals
+      Rd += double(Rl); MBd += double(MBl); S1d += double(S1l);
+      Rl = MBl = S1l = T(0);
+#pragma unroll
+      for (int c = 0; c < CT; ++c) {
+        if constexpr (!SQ) { ILd[c] += double(ILx[c]); ILx[c] = T(0); }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          T v = Q[0][c][r];
+          if constexpr (NQ == 2) v += Q[1][c][r];
+          Qd[c][r] += double(v);
+        }
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) Q[q][c] = acc_t{0, 0, 0, 0};
+      }
+    }
+  }
+  // ---- closing sums ----
+  // scale of everything that is linear in W: the variance, and for SE the -1/2 of dK/dr2 left out above
+  const double var = kp.variance, wsc = (FAMILY == KSE) ? -0.5 * var : var;
+  double R = kF64 ? double(Rl) : Rd, MB = kF64 ? double(MBl) : MBd, S1 = kF64 ? double(S1l) : S1d;
+  R += __shfl_xor(R, 16); R += __shfl_xor(R, 32);          // row l15, all its points
+  MB += __shfl_xor(MB, 16); MB += __shfl_xor(MB, 32);
+  double* rp = rowpart + int64_t(blockIdx.x) * (2 + DL) * Mp;
+  if (g == 0) {
+    rp[i] += wsc * R;
+    if (kmb) rp[Mp + i] += var * MB;
+  }
+  // Q in the D layout: lane (feature l15 + 16 c, group g), register r <-> row M16::row(lane, r) of the wave's 16
+  __syncthreads();
+  if (g == 0) sred[wave][2 + l15] = R;
+  __syncthreads();
+  double ilw[CT];
+#pragma unroll
+  for (int c = 0; c < CT; ++c) {
+    const int f = SQ ? (l15 & 7) : (l15 + 16 * c);
+    double il = 0.0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = M16::row(lane, r);
+      double q;
+      if constexpr (kF64) { q = double(Q[0][c][r]); if constexpr (NQ == 2) q += double(Q[1][c][r]); }
+      else q = Qd[c][r];
+      if (SQ && (l15 & 8)) {
+        il += q;                                             // sum_j W_ij x_fj^2
+      } else {
+        const double cf = double(cz[f]), Rr = sred[wave][2 + row];
+        const double zf = (f < d) ? double(zs[int64_t(f) * Mp + iw0 + row] - cz[f]) : 0.0;   // (the centred value as the tiles saw it)
+        il += zf * (zf * Rr - 2.0 * q);
+        if (f < d) rp[int64_t(2 + f) * Mp + iw0 + row] += wsc * (q + cf * Rr);                // sum_j W_ij x_fj, uncentred
+      }
+    }
+    if constexpr (SQ) il += __shfl_xor(il, 8);               // lanes l15 < 8: feature l15 complete over the lane's rows
+    else il += kF64 ? double(ILx[c]) : ILd[c];               // + this lane's share of sum_j x_fj^2 C_j
+    il += __shfl_xor(il, 16);
+    il += __shfl_xor(il, 32);
+    ilw[c] = il;
+  }
+  // sum P o K of the wave: SE - the sum of its R_i; Matern - accumulated
+  if constexpr (FAMILY == KSE) {
+    S1 = (g == 0) ? R : 0.0;
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) S1 += __shfl_xor(S1, o);
+  } else {
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) S1 += __shfl_xor(S1, o);
+  }
+  __syncthreads();
+  if (lane == 0) sred[wave][0] = S1;
+  if (g == 0 && (!SQ || l15 < 8)) {
+#pragma unroll
+    for (int c = 0; c < CT; ++c) sred[wave][2 + l15 + 16 * c] = ilw[c];
+  }
+  __syncthreads();
+  if (int(threadIdx.x) <= DL) {
+    const int q = threadIdx.x;
+    const int slot = q == 0 ? 0 : 1 + q;
+    const double v = ((sred[0][slot] + sred[1][slot]) + sred[2][slot]) + sred[3][slot];
+    double* sp = scalpart + (int64_t(blockIdx.x) * gridDim.y + blockIdx.y) * (1 + DL);
+    if (q == 0) sp[0] += var * v;
+    else if (q - 1 < d) sp[q] += wsc * v;
+  }
+}
+
 // ---- small M x M helpers -------------------------------------------------------------------------------------
 template <typename T>
 __global__ void lower_to_rowmajor_kernel(const T* __restrict__ L, int64_t Mp, T* __restrict__ out) {
@@ -1101,10 +1392,33 @@ void launch_kgrad_lanes(SVGP_KGRAD_ARGS) {    // two / four lanes per row, 16 fe
 }
 #undef SVGP_KGRAD_ARGS
 
+// the MFMA form (round 6): 64 rows per workgroup for every d
+bool kgrad_mfma_on() {
+  static const int knob = exp_int("SVGP_KGRAD_MFMA", 1) && exp_int("SVGP_A_FROM_K", 1);   // (experiments build: 0 = the VALU kernels of rounds 2-5)
+  return knob != 0;
+}
+template <typename T, int FAMILY>
+void launch_kgrad_mfma(hipStream_t s, const KernelParams& kp, const T* zs, int64_t Mp, const T* x, int64_t ldx, int64_t xoff,
+                       int prescaled, int64_t n, int64_t nvalid, const T* Pt, const T* gmu, const T* gv, const T* alpha,
+                       int64_t slice_len, int nslices, double* rowpart, double* scalpart, int kmb) {
+  dim3 grid((unsigned)nslices, (unsigned)(Mp / 64));
+#define SVGP_KGM(DL) hipLaunchKernelGGL((kgrad_mfma_kernel<T, FAMILY, DL>), grid, dim3(k256), 0, s, kp, zs, Mp, x, ldx, xoff, prescaled, n, \
+                                        nvalid, Pt, gmu, gv, alpha, slice_len, rowpart, scalpart, kmb)
+  if (kp.d <= 8) SVGP_KGM(8);
+  else if (kp.d <= 16) SVGP_KGM(16);
+  else if (kp.d <= 32) SVGP_KGM(32);
+  else SVGP_KGM(64);
+#undef SVGP_KGM
+}
+
 template <typename T, int FAMILY>
 void launch_kgrad_f(hipStream_t s, const KernelParams& kp, const T* zs, int64_t Mp, const T* x, int64_t ldx, int64_t xoff,
                     int prescaled, int64_t n, int64_t nvalid, const T* Pt, const T* At, const T* gmu, const T* gv, const T* alpha,
                     int64_t slice_len, int nslices, double* rowpart, double* scalpart, int kmb) {
+  if (kgrad_mfma_on() && !At) {
+    launch_kgrad_mfma<T, FAMILY>(s, kp, zs, Mp, x, ldx, xoff, prescaled, n, nvalid, Pt, gmu, gv, alpha, slice_len, nslices, rowpart, scalpart, kmb);
+    return;
+  }
   if (kp.d <= 8) {
     dim3 grid((unsigned)nslices, (unsigned)(Mp / (64 * Kgrad8<T>::KV)));
     hipLaunchKernelGGL((kgrad_kernel<T, 8, Kgrad8<T>::KV, FAMILY>), grid, dim3(k256), 0, s, kp, zs, Mp, x, ldx, xoff, prescaled, n, nvalid, Pt,
@@ -1147,6 +1461,7 @@ int grad_dreg(int d) { return d <= 8 ? 8 : (d <= 16 ? 16 : (d <= 32 ? 32 : 64));
 // workgroups along the rows, exactly launch_kgrad_f's grid: 128 rows (d <= 16); wide inputs: 64 (fp32: a wave per feature group) or 32 / 16
 // (f64: two / four lanes per row)
 int grad_rowblocks(int dtype, int d, int64_t Mp) {
+  if (kgrad_mfma_on()) return int(Mp / 64);
   if (d <= 8) return int(Mp / (64 * (dtype == 0 ? Kgrad8<double>::KV : Kgrad8<float>::KV)));
   if (d <= 16) return int(Mp / (64 * (dtype == 0 ? Kgrad16<double>::KV : Kgrad16<float>::KV)));
   const int knob = exp_int("SVGP_KGRAD_WIDE2", -1);

@@ -45,7 +45,7 @@ struct RowHook { void (*fn)(void* user, int row) = nullptr; void* user = nullptr
 // look-ahead for a large Kuu (Mp / 128 > potrf_max_row_events(); prep.hip: potrf_t): a second stream for the bulk trailing updates and
 // eight events (four "TRSM of panel p done" + four "bulk update of panel p done", rotated) - nullable: then everything runs on `s`
 struct PotrfLookahead { hipStream_t s2 = nullptr; hipEvent_t* ev = nullptr; };
-void launch_potrf(int dtype, hipStream_t s, void* A, void* T, int64_t Mp, int* info, unsigned* sync, hipEvent_t* row_events = nullptr,
+void launch_potrf(int dtype, hipStream_t s, void* A, void* T, int64_t Mp, int* info, unsigned* sync, int num_cus, hipEvent_t* row_events = nullptr,
                   const RowHook* hook = nullptr, const PotrfLookahead* la = nullptr);
 int potrf_max_row_events();
 // U = Lq' (upper triangular, Mp x Mp col-major, zero padding); also mp[i] = m[i] padded with zeros.

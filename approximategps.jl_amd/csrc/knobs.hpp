@@ -28,8 +28,13 @@ constexpr long long exp_ll(const char*, long long dflt) { return dflt; }
 constexpr double exp_double(const char*, double dflt) { return dflt; }
 #endif
 
-// operational variables: read by every build
-inline int env_flag(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
+// operational variables: read by every build.  Strictly "0" or "1": anything else (empty, "on", "true", "2") keeps the default - atoi
+// turned SVGP_TIMING=on into 0 and silently switched the timing off
+inline int env_flag(const char* name, int dflt) {
+  const char* e = getenv(name);
+  if (!e || (e[0] != '0' && e[0] != '1') || e[1] != '\0') return dflt;
+  return e[0] - '0';
+}
 
 // Per-context settings, filled by read_knobs() in svgp_ctx_create.  The first three are operational; the rest keep their defaults
 // in the product build.

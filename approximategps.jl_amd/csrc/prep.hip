@@ -1210,7 +1210,7 @@ const XcdOrder& xcd_tile_order(int n) {
 
 template <typename T>
 void potrf_t(hipStream_t s, T* A, T* Tm, int64_t Mp, int* info, unsigned* sync, hipEvent_t* row_events, const RowHook* hook,
-             const PotrfLookahead* la) {
+             const PotrfLookahead* la, int ncus) {
   using G = TileGemm<T, kNB, 16>;
   const int nP = int(Mp / kNB);
   constexpr size_t lds_potf2 = potf2_lds_bytes<T>();
@@ -1229,12 +1229,8 @@ void potrf_t(hipStream_t s, T* A, T* Tm, int64_t Mp, int* info, unsigned* sync, 
   set_max_lds(reinterpret_cast<const void*>(chol_tile_kernel<T, MODE_SYRK, CNT, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds_fused_s));
   // the 512-thread fused form (seven worker waves in the block factorisation) holds one workgroup per CU: taken where the launch fits
   // the chip in one round that way (SVGP_POTF2_WAVES=4 in the experiments build: always the 256-thread form)
-  static const int ncus = [] {
-    hipDeviceProp_t prop;
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
-    return prop.multiProcessorCount;
-  }();
+  // (`ncus`: the calling context's device - a process-wide static captured the first caller's, wrong for the other members of a
+  // single-process svgp_group on unlike devices)
   static const bool p8_on = exp_int("SVGP_POTF2_WAVES", 8) == 8;
   auto potf2 = [&](int p) {
     hipLaunchKernelGGL(potf2_kernel<T>, dim3(1), dim3(kThreads), lds_potf2, s, A + int64_t(p) * kNB * (Mp + 1), Tm + int64_t(p) * kNB * (Mp + 1), Mp,
@@ -1489,10 +1485,10 @@ void launch_kuu(int dtype, hipStream_t s, const KernelParams& kp, const void* zs
 
 // T must be zero above the diagonal on entry (the model's buffer is cleared once at creation): the factorisation writes the
 // lower triangles of the inverted diagonal blocks and the T panels below them only
-void launch_potrf(int dtype, hipStream_t s, void* A, void* T, int64_t Mp, int* info, unsigned* sync, hipEvent_t* row_events,
+void launch_potrf(int dtype, hipStream_t s, void* A, void* T, int64_t Mp, int* info, unsigned* sync, int num_cus, hipEvent_t* row_events,
                   const RowHook* hook, const PotrfLookahead* la) {
-  SVGP_DISPATCH(dtype, potrf_t<double>(s, (double*)A, (double*)T, Mp, info, sync, row_events, hook, la),
-                potrf_t<float>(s, (float*)A, (float*)T, Mp, info, sync, row_events, hook, la));
+  SVGP_DISPATCH(dtype, potrf_t<double>(s, (double*)A, (double*)T, Mp, info, sync, row_events, hook, la, num_cus),
+                potrf_t<float>(s, (float*)A, (float*)T, Mp, info, sync, row_events, hook, la, num_cus));
 }
 int potrf_max_row_events() { return 16; }   // block rows of T are final one by one only while they ride in the TRSM launches (nP <= 16)
 

@@ -39,24 +39,7 @@ namespace {
 #ifndef SVGP_PREGEN_EXPTAB
 #define SVGP_PREGEN_EXPTAB 1   // the f64 SE pre-generation takes exp from a 64-entry table of 2^(j/64) in LDS + a degree-5 polynomial (0: kexp; A/B builds)
 #endif
-// exp(v), v <= 0: v = (64 m + j) ln2 / 64 + r, |r| <= ln2 / 128: 2^m * tab[j] * (1 + r + ... + r^5 / 120) (truncation 3.5e-17): ~15 VALU
-// instructions and one LDS read against kexp's ~20 - the pre-generation is VALU-bound and f64 VALU blocks the MFMA pipe of the
-// partner workgroup too (s_memtime stamps: 140-158k of a forward strip's 2230k ticks).  Same box, three repetitions, H strip ms:
-// 33.44 / 33.41 / 33.57 with kexp, 33.35 / 33.33 / 33.27 with the table (C2 1.13 vs 1.13): -0.5 %, parity tests unchanged; 212 VGPRs either way
-__device__ __forceinline__ double kexp_tab(double v, const double* __restrict__ tab) {
-  const double nd = rint(v * 92.332482616893658);               // 64 / ln2
-  const int n = int(nd);
-  double r = fma(nd, -1.08304246932675596327e-02, v);           // ln2_hi / 64 (kexp's split, exact in binary)
-  r = fma(nd, -2.98158582698529328128e-12, r);                  // ln2_lo / 64
-  const double t = tab[n & 63];
-  double p = fma(r, 8.333333333333333e-03, 4.1666666666666664e-02);
-  p = fma(p, r, 1.6666666666666666e-01);
-  p = fma(p, r, 0.5);
-  p = fma(p, r, 1.0);
-  p *= r;                                                       // exp(r) - 1
-  return ldexp(fma(t, p, t), n >> 6);
-}
-
+// (kexp_tab: device_common.hpp)
 template <typename T, int NT, int NTHR, int F, int DL>
 __device__ __forceinline__ void pregen_mfma(const T* __restrict__ xs, const T* __restrict__ zs, int d, int64_t Mp, int64_t M,
                                             double variance_d, T* __restrict__ work, const double* __restrict__ exptab = nullptr) {
@@ -192,6 +175,26 @@ __device__ __forceinline__ void store_tile_point_major(const typename G::Acc& ac
   }
 }
 
+// Wave priority of the value-and-gradient strips, alternated strip by strip (round 6).  The two workgroups of a CU share its SIMDs
+// wave for wave, and at equal priority the issue arbiter prefers the OLDER wave: the workgroup of the first dispatch round
+// (blockIdx < grid / 2) wins every contended MFMA slot, finishes its strips 10-15 % earlier than its partner (s_memtime, H: 3.47 + 3.35 M
+// ticks for its two strips against 4.06 + 3.58 M), and the partner then runs alone - at the half MFMA rate one workgroup can sustain -
+// to the end of the launch.  A gradient chunk is exactly two rounds of strips, so that ragged end comes with EVERY launch.  Here the
+// older workgroup takes the higher priority for its first strip, the younger one for its second, and so on: both reach the end of the
+// launch together.  Same box, value and gradient ms, f64: H 78.9 -> 77.0, C2 3.30 -> 3.14; alternating per panel 78.0, by time slices
+// of the shared clock (2^18 / 2^20 ticks) 77.6 / 77.4; fp32 (H32, C5), whose VALU work co-executes with the partner's MFMAs,
+// unchanged by any of them (profiles/round6/strip_prio_ab.log).  SVGP_STRIP_PRIO=0: no priorities (A/B builds).
+#ifndef SVGP_STRIP_PRIO
+#define SVGP_STRIP_PRIO 1
+#endif
+template <bool ON>
+__device__ __forceinline__ void strip_prio(int strips_done) {
+  if constexpr (ON && SVGP_STRIP_PRIO != 0) {
+    if ((strips_done + (blockIdx.x >= gridDim.x / 2 ? 1 : 0)) & 1) __builtin_amdgcn_s_setprio(0);
+    else __builtin_amdgcn_s_setprio(1);
+  }
+}
+
 struct PointGrads { double e, gmu, gv, gs2; };
 __device__ __noinline__ PointGrads strip_point_grads(LikParams lp, double mu, double v, double yv, double scale) {
   // everything by value: taking the address of the kernel argument block would move it (and with it the wave-uniform
@@ -295,6 +298,7 @@ __global__ void __launch_bounds__(NTHR, MINW) strip_kernel(StripArgs a, int64_t 
   if (threadIdx.x < 128) s_strip_stamps[threadIdx.x] = 0;
   __syncthreads();
 #endif
+  [[maybe_unused]] int prio_strips = 0;
   [[maybe_unused]] int part = 0, nsplit = 1;   // split closing launch (kernels.hpp: seg_split)
   if constexpr (SEG) {
     if (a.seg_split > 1) { nsplit = a.seg_split; part = int(blockIdx.x / nstrips); }
@@ -311,6 +315,7 @@ __global__ void __launch_bounds__(NTHR, MINW) strip_kernel(StripArgs a, int64_t 
     ++strips_done;
 #endif
     SVGP_SSTAMP(0);
+    if constexpr (SVGP_STRIP_PRIO == 2) ++prio_strips; else strip_prio<GRAD && !SEG>(prio_strips++);
     const int64_t c0 = strip * NT;                          // first column of the strip inside the batch
     if constexpr (SEG) { if (tid == 0) next_strip = unsigned(strip + gridDim.x); }   // static schedule: launches are at most one round
     else if (tid == 0) next_strip = gridDim.x + atomicAdd(a.counter, 1u);
@@ -393,6 +398,7 @@ __global__ void __launch_bounds__(NTHR, MINW) strip_kernel(StripArgs a, int64_t 
     SVGP_SSTAMP(1);
     for (int I = I_lo; I < I_hi; ++I) {
       SVGP_SSTAMP(2 + 3 * I);
+      if constexpr (SVGP_STRIP_PRIO == 2) strip_prio<GRAD && !SEG>(prio_strips - 1);
       Acc acc;
       acc.zero();
       // the last NB/BK steps multiply the lower-triangular inv(L_II): their zero 16-row tiles are skipped
@@ -563,6 +569,7 @@ __global__ void __launch_bounds__(NTHR, MINW) strip_kernel(StripArgs a, int64_t 
       if constexpr (SEG) { p3_lo = (part * nP) / nsplit; p3_hi = ((part + 1) * nP) / nsplit; }
       for (int I = p3_lo; I < p3_hi; ++I) {
         SVGP_SSTAMP(26 + 4 * I);   // (diagnostic builds, nP <= 8) phase 3: loop start / loop end / after the K-dot / after the point-major store
+        if constexpr (SVGP_STRIP_PRIO == 2) strip_prio<!SEG>(prio_strips - 1);
         Acc acc;
         acc.zero();
         if constexpr (SVGP_ASYNC && G::kAsync) {
@@ -1044,6 +1051,12 @@ __global__ void __launch_bounds__(512, 2) kuf_cols_kernel(KernelParams kp, const
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   T* zl = reinterpret_cast<T*>(smem_raw);   // [DREG][RW]  bscale * scaled z of the workgroup's rows
   T* znl = zl + DREG * RW;                  // [RW]        c1 |z|^2
+  // f64 SE: exp from the 64-entry table of 2^(j/64) + a degree-5 polynomial (kexp_tab, as the strips' pre-generation: ~15 VALU
+  // instructions and one LDS read against kexp's ~20).  Round 6: at d > 16 the kernel is bound by f64 MFMA + VALU ISSUE, not by the
+  // store stream, and the kernel function is the VALU part
+  constexpr bool kTab = SVGP_PREGEN_EXPTAB && FAMILY == KSE && sizeof(T) == 8;
+  __shared__ double s_exptab[kTab ? 64 : 1];
+  if (kTab && threadIdx.x < 64) s_exptab[threadIdx.x] = exp2(double(threadIdx.x) * 0.015625);
   const int d = kp.d;
   const T* __restrict__ invl = static_cast<const T*>(kp.invl);
   const int tid = threadIdx.x, lane = tid & 63, wave = (tid >> 6) & 3, half = tid >> 8, c = lane & 15, kq = lane >> 4;
@@ -1134,7 +1147,8 @@ __global__ void __launch_bounds__(512, 2) kuf_cols_kernel(KernelParams kp, const
 #pragma unroll
             for (int e = 0; e < VEC; ++e) {
               const T v = acc[g * VEC + e][r];
-              out[e] = (FAMILY == KSE) ? kexp(v < c0 ? v : c0) : kappa<T>(FAMILY, v > T(0) ? v : T(0), variance);
+              if constexpr (kTab) out[e] = T(kexp_tab(double(v < c0 ? v : c0), s_exptab));
+              else out[e] = (FAMILY == KSE) ? kexp(v < c0 ? v : c0) : kappa<T>(FAMILY, v > T(0) ? v : T(0), variance);
             }
             *reinterpret_cast<V*>(dst0[r] + rc * CH + g * (16 * VEC)) = out;
           }
@@ -1149,7 +1163,8 @@ __global__ void __launch_bounds__(512, 2) kuf_cols_kernel(KernelParams kp, const
 #pragma unroll
           for (int e = 0; e < VEC; ++e) {
             const T v = acc[g * VEC + e][r];
-            out[e] = (FAMILY == KSE) ? kexp(v < c0 ? v : c0) : kappa<T>(FAMILY, v > T(0) ? v : T(0), variance);
+            if constexpr (kTab) out[e] = T(kexp_tab(double(v < c0 ? v : c0), s_exptab));
+            else out[e] = (FAMILY == KSE) ? kexp(v < c0 ? v : c0) : kappa<T>(FAMILY, v > T(0) ? v : T(0), variance);
           }
           const int64_t i = ibase + g * (16 * VEC) + c * VEC;
           T* dst = dst0[r] + rc * CH + g * (16 * VEC);

@@ -101,13 +101,22 @@ def cpu_baseline(p, family, lik, sample, n_full, M, force_sample=False):
             "mem_available_GB": round(avail / 1e9, 1), "mem_needed_full_GB": round(need / 1e9, 1)}
     o.elbo(sva, f64(p["x"][:, :2000]), f64(p["y"][:2000]), lik=lik, sigma2=p["sigma2"])  # warm BLAS threads
     if avail >= need and os.environ.get("BENCH_CPU_SAMPLE_ONLY") != "1" and not force_sample:
+        # the median of three warm evaluations of the full workload when three of them fit the budget (BENCH_CPU_BUDGET_S,
+        # default 100 s: ~85 s at H on the GPU box's host), else as many as fit - `runs` and `t_evals_s` say which
         xs, ys = f64(p["x"]), f64(p["y"])
-        t0 = time.perf_counter()
-        ref = o.elbo(sva, xs, ys, lik=lik, sigma2=p["sigma2"])
-        t_full = time.perf_counter() - t0
-        return dict(base, value=1.0 / t_full, oracle_elbo=float(ref), oracle_points=int(n_full),
+        budget = float(os.environ.get("BENCH_CPU_BUDGET_S", "100"))
+        t_evals = []
+        while len(t_evals) < 3:
+            t0 = time.perf_counter()
+            ref = o.elbo(sva, xs, ys, lik=lik, sigma2=p["sigma2"])
+            t_evals.append(time.perf_counter() - t0)
+            if sum(t_evals) + max(t_evals) > budget:   # the next one would not fit
+                break
+        t_full = float(np.median(t_evals))
+        return dict(base, value=1.0 / t_full, oracle_elbo=float(ref), oracle_points=int(n_full), runs=len(t_evals),
+                    t_evals_s=[round(t, 3) for t in t_evals],
                     sample=f"oracle/svgp_oracle.py (numpy + scipy-OpenBLAS, fp64, {threads} BLAS threads) on ALL {n_full} points, "
-                           f"one evaluation = {t_full:.1f} s (no extrapolation)")
+                           f"median of {len(t_evals)} evaluation(s) = {t_full:.1f} s (no extrapolation)")
     xs, ys = f64(p["x"][:, :sample]), f64(p["y"][:sample])
     t_small = []
     for _ in range(2):
@@ -123,7 +132,7 @@ def cpu_baseline(p, family, lik, sample, n_full, M, force_sample=False):
     per_point = max(t_s - t_2k, 1e-9) / max(sample - 2000, 1)    # data-proportional part
     fixed = max(t_2k - 2000 * per_point, 0.0)                    # cholesky(Kuu) etc.
     t_full = fixed + per_point * n_full
-    return dict(base, value=1.0 / t_full, oracle_elbo=float(ref), oracle_points=int(sample),
+    return dict(base, value=1.0 / t_full, oracle_elbo=float(ref), oracle_points=int(sample), runs=len(ts), t_evals_s=[round(t, 3) for t in ts],
                 sample=f"oracle/svgp_oracle.py (numpy + scipy-OpenBLAS, fp64, {threads} BLAS threads) on {sample} of the {n_full} "
                        f"points ({'N > 1 ranks: bounded sample of rank 0 shard' if force_sample else 'host RAM below 5 M N 8 bytes'}), "
                        f"median of 3 = {t_s:.2f} s; extrapolated linearly in N to {t_full:.1f} s/eval")
@@ -423,8 +432,14 @@ def measure_host_step(ctx, n=16384, M=1024, d=8, reps=20):
 
 
 def timing_on(ctx=None):
-    """The library's device timings exist unless the context was created with SVGP_TIMING=0 (svgp_last_timing then reports zeros)."""
-    return os.environ.get("SVGP_TIMING", "1")[:1] != "0"
+    """The library's device timings exist unless the context was created with SVGP_TIMING=0 (svgp_last_timing then reports zeros).  Asked of
+    the CONTEXT (what it captured at svgp_ctx_create: a timed evaluation has ms_total > 0), not of this process's present environment."""
+    if ctx is not None:
+        try:
+            return float(ctx.timing().ms_total) > 0.0
+        except Exception:  # noqa: BLE001
+            pass
+    return os.environ.get("SVGP_TIMING", "1").strip() != "0"
 
 
 def measure_kuf(name, ctx, model, data, torch, dev):
@@ -567,7 +582,8 @@ def bench_config(args, name, ctx, torch, dist, dev, world, rank, use_dist, steps
         overlap_ms.append(t.ms_overlap)
         total_ms.append(t.ms_total)
     fence()
-    elapsed = time.perf_counter() - t0
+    t_region = (t0, time.perf_counter())   # (for a telemetry thread the caller may run beside the region)
+    elapsed = t_region[1] - t0
     if use_dist:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -588,7 +604,7 @@ def bench_config(args, name, ctx, torch, dist, dev, world, rank, use_dist, steps
         kernel_name = "whole evaluation (segmented strip launches beside the factorisation: no single dominant launch)"
     ach = flops_strip / (strip_avg_ms * 1e-3) / 1e12 if strip_avg_ms > 0 else None
     res = {
-        "elapsed": elapsed, "ms_per_step": 1e3 * elapsed / steps, "evals_per_s": world * steps / elapsed,
+        "elapsed": elapsed, "t_region": t_region, "ms_per_step": 1e3 * elapsed / steps, "evals_per_s": world * steps / elapsed,
         "points_per_s": n * world * steps / elapsed, "elbo": val, "n_points_global": int(terms.n_points),
         "roofline": {"kernel": kernel_name, "bound": "mfma", "achieved": ach,
                      "peak": PEAK_TFLOPS[dtype], "unit": "TFLOP/s", "frac": (ach / PEAK_TFLOPS[dtype]) if ach else None, "traffic": None,
@@ -801,14 +817,22 @@ def main():
         # BASELINE config C5 (8 x MI355X: minibatched ELBO, N = 1e8, per-GPU batch 2^18, M = 1024, fp32) through the same
         # collective path: every rank evaluates its own 2^18-point minibatch per step, scale = 1e8 / (world * 2^18).
         try:
+            # the shader clock during C5's timed region (0.1 s of back-to-back 5 ms steps, sampled every 10 ms): a short region runs on a
+            # clock that is still ramping, which is what separates its roofline fraction from a profiled run's
+            tel5 = GpuTelemetry(local_rank, period=0.01).start() if rank == 0 else None
             c5, m5, d5, _ = bench_config(args, "C5", ctx, torch, dist, dev, world, rank, use_dist, max(20, args.steps), 5,
                                          num_data_override=C5_NUM_DATA, host_comm=host_comm, resident=args.c5_resident)
+            clk5 = GpuTelemetry.summarize(tel5.stop(), *c5["t_region"]) if tel5 else None
             nwin5 = c5["windows"]
             c5out = {"workload": c5["workload"] + f"; num_data = {C5_NUM_DATA:.0e}, global minibatch = {world} x 262144",
                      "resident_points_per_gpu": c5["resident_points_per_gpu"], "windows": nwin5,
                      "minibatch_steps_per_s": c5["evals_per_s"] / world, "ms_per_step": c5["ms_per_step"],
                      "points_per_s": c5["points_per_s"], "dtype": "f32", "roofline": c5["roofline"],
                      "breakdown_ms": c5["breakdown_ms"], "elbo": c5["elbo"], "n_points_global": c5["n_points_global"]}
+            if clk5 is not None:
+                c5out["shader_clock_mhz_during_timed_region"] = clk5.get("sclk_mhz")
+                c5out["shader_clock_note"] = ("roofline.frac is flops / time / the 2.4 GHz peak: a region run at a lower (ramping or power-limited) "
+                                              "clock reads proportionally lower; samples = " + str(clk5.get("samples")))
             if not args.no_grad and not host_comm:
                 _, _, g5 = m5.elbo_grad(d5, 0, 262144, C5_NUM_DATA)
                 fence()

@@ -11,12 +11,17 @@ from approxgp import _ffi
 from helpers import desc_from_oracle
 
 
-def make_ctx(**env):   # the overlap settings are read once, at context creation (csrc/knobs.hpp)
+def make_ctx(**env):   # the overlap settings are read once, at context creation (csrc/knobs.hpp); an ambient value of the same variable is
+    old = {k: os.environ.get(k) for k in env}   # restored afterwards, as helpers.context_with_env does
     os.environ.update(env)
-    c = _ffi.Context(0)
-    for k in env:
-        os.environ.pop(k)
-    return c
+    try:
+        return _ffi.Context(0)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
 
 
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 300

@@ -280,7 +280,11 @@ def test_gradient_more_than_1024_inducing_points_f64(ctx):
 
 
 # ---- likelihoods the ABI does not enumerate: host-evaluated on the device marginals (svgp_marginals / svgp_elbo_grad_ext) ----
-@pytest.mark.parametrize("dtype,vtol,gtol", [(np.float64, 1e-12, 1e-10), (np.float32, 1e-5, 5e-5)])   # fp32: the built-in gradient build takes v from k_j'(R A)_j, svgp_marginals from sum C^2 - sum A^2
+# fp32: the built-in gradient build takes v from k_j'(R A)_j, svgp_marginals from sum C^2 - sum A^2; and either fp32 gradient is itself 1e-4 ... 3e-4
+# of the block's scale away from the fp64 evaluation of the same fp32 inputs (profiles/round6/kgrad_ab.log: both the VALU and the MFMA form of the
+# kernel-gradient reductions), so two fp32 evaluations whose point gradients differ in the last bits are compared at 2e-4 (5e-5 until round 6: passed
+# by the round-5 reductions with 3.9e-5, not by the MFMA form with 6.2e-5 on the Centered case)
+@pytest.mark.parametrize("dtype,vtol,gtol", [(np.float64, 1e-12, 1e-10), (np.float32, 1e-5, 2e-4)])
 @pytest.mark.parametrize("centered", [False, True])
 def test_host_evaluated_likelihood_equals_builtin(ctx, dtype, vtol, gtol, centered):
     """The split path must reproduce the fused one when the host evaluates a likelihood the library also has: marginals ->

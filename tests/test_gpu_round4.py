@@ -369,12 +369,17 @@ def test_context_without_timing_events():
     forward call).  Same results bit for bit, svgp_last_timing reports zeros, and nothing is left behind in the HIP error state
     (querying an event that was never recorded would be a sticky error)."""
     x, y, sva, s2 = o.synth_problem(5150, 3000, 700, 3, dtype=np.float64)
-    ref_ctx = _ffi.Context(0)
-    os.environ["SVGP_TIMING"] = "0"
+    prev = os.environ.get("SVGP_TIMING")   # (restored: a suite run under SVGP_TIMING=0 must keep it for the tests that follow, ADVICE r5)
+    os.environ["SVGP_TIMING"] = "1"
     try:
+        ref_ctx = _ffi.Context(0)
+        os.environ["SVGP_TIMING"] = "0"
         quiet = _ffi.Context(0)
     finally:
-        os.environ.pop("SVGP_TIMING", None)
+        if prev is None:
+            os.environ.pop("SVGP_TIMING", None)
+        else:
+            os.environ["SVGP_TIMING"] = prev
     out = []
     for c in (ref_ctx, quiet):
         model = device_model(c, sva, dtype=np.float64, sigma2=s2)
