@@ -1619,17 +1619,14 @@ int grad_enqueue_impl(svgp_ctx* ctx, svgp_model* m, const svgp_data* data, int64
   // Who evaluates the likelihood gradients (strip.hip: kPgPost): round 4 - a small kernel behind the strips, for both likelihood
   // routes; SVGP_GRAD_POST=0 keeps the round-3 in-kernel forms (A/B).  In-kernel fp32 builds also form A g_mu per strip (`apart`).
   const bool post = gop.on || ctx->kn.grad_post;   // always in the product build; the segmented strips exist in the post form only
-  // A g_mu (the data part of m_bar): in-kernel fp32 - per strip inside the strip kernel, so that kgrad streams P only; otherwise
-  // kgrad, which evaluates the kernel anyway, sums Kuf g_mu and the tail applies Lk^-1 (one gemv with the explicit inverse): A is
-  // then read by the SYRK only (round 3, f64: 0.32 -> 0.2 ms per 65 536-point chunk at M = 1024); SVGP_A_FROM_K=0: kgrad reads A
-  // beside P.  (Round-2 three-way A/B, ms: H 97.8 -> 95.4 with the kgrad prefetch alone, 99.0 with the in-strip form; H32 53.6 ->
-  // 53.0 -> 52.35; C5 16.25 -> 16.2 -> 15.9; C3 208.3 -> 217.2 -> 209.6.)
-  static const int afk_knob = exp_int("SVGP_A_FROM_K", 1);   // A/B knob (experiments build)
+  // A g_mu (the data part of m_bar): in-kernel fp32 (experiments build, SVGP_GRAD_POST=0) - per strip inside the strip kernel;
+  // otherwise kgrad, which evaluates the kernel anyway, sums Kuf g_mu and the tail applies Lk^-1 (one gemv with the explicit
+  // inverse): A is then read by the SYRK only (round 3, f64: 0.32 -> 0.2 ms per 65 536-point chunk at M = 1024).
   // the SYRK's weights 2 g_v are uniform over the points for the built-in Gaussian likelihood (grad.hip: UW) unless a variance was
   // negative and clamped (then that point's g_v differs... it does not: dE/dv = -1 / (2 sigma^2) whatever v) - so: Gaussian, built in
   const bool uniform_w = m->desc.likelihood == SVGP_LIK_GAUSSIAN && !gc.ext_gmu && m->gh_n == 0 && ctx->kn.syrk_uniform;   // (knob: experiments build)
   const bool a_in_strips = (dt == SVGP_F32) && !post;
-  const bool a_from_k = !a_in_strips && afk_knob;
+  const bool a_from_k = !a_in_strips;
   // the strips' arguments for the chunk [c0, c0 + clen) (scratch / moment pointers: read after the ensure_scratch of the caller)
   auto strip_args = [&](int64_t c0, int64_t clen, LikParams& lpc) -> StripArgs {
     StripArgs a{};
@@ -1815,8 +1812,8 @@ int grad_enqueue_impl(svgp_ctx* ctx, svgp_model* m, const svgp_data* data, int64
     }
     int64_t ksl = ((clen + w->ns_uf - 1) / w->ns_uf + 127) / 128 * 128;
     if (a_in_strips) launch_apart_reduce(sk, w->apart, int(nstrips), Mp, w->rp_uf + Mp);   // slot 1 of slice 0 of rp_uf
-    launch_kgrad(dt, sk, kp, m->zs, Mp, data->x, data->ldx, off + c0, 0, clen, clen, L.Pt, (a_in_strips || a_from_k) ? nullptr : L.At,
-                 L.gmu, L.gv, w->alpha, ksl, w->ns_uf, w->rp_uf, w->sp_uf, a_from_k ? 1 : 0);
+    launch_kgrad(dt, sk, kp, m->zs, Mp, data->x, data->ldx, off + c0, 0, clen, clen, L.Pt, L.gmu, L.gv, w->alpha, ksl, w->ns_uf,
+                 w->rp_uf, w->sp_uf, a_from_k ? 1 : 0);
     KCHECK(ctx, "kgrad uf");
     if (kg_overlap) HIPC(ctx, hipEventRecord(ctx->ev_join, sk));
     if (trail) HIPC(ctx, hipEventRecord(L.ev_done, sk));
@@ -1875,7 +1872,7 @@ int grad_enqueue_impl(svgp_ctx* ctx, svgp_model* m, const svgp_data* data, int64
   // the Kuu part: the ns_uu slices must cover all M columns (a fixed slice of 128 covered only 1024 of them: the kernel-
   // parameter and z gradients were wrong for M > 1024 until tests/test_gpu_grad.py::test_gradient_large_m_float32_strips)
   const int64_t uu_sl = ((M + w->ns_uu - 1) / w->ns_uu + 127) / 128 * 128;
-  launch_kgrad(dt, s, kp, m->zs, Mp, m->zs, Mp, 0, 1, M, M, w->H, nullptr, nullptr, nullptr, nullptr, uu_sl, w->ns_uu, w->rp_uu, w->sp_uu);
+  launch_kgrad(dt, s, kp, m->zs, Mp, m->zs, Mp, 0, 1, M, M, w->H, nullptr, nullptr, nullptr, uu_sl, w->ns_uu, w->rp_uu, w->sp_uu);
   launch_finish_kgrad(dt, s, m->d, M, Mp, m->zs, w->invl_d, w->rp_uf, w->ns_uf, w->rp_uu, w->ns_uu, w->sp_uf, w->ns_uf * w->rb,
                       w->sp_uu, w->ns_uu * w->rb, m->mp, klw, m->desc.layout_z, m->desc.variance, w->zbar, centered ? nullptr : w->mbar,
                       w->scal_out, w->kred, w->avec);

@@ -3,14 +3,14 @@
 // that are NOT the strip kernel's phase 3.  Hand-derived adjoint of the forward path (oracle/svgp_oracle.py: elbo_grad is
 // the same derivation; api.hip: grad_enqueue is the schedule).  With A = Lk \ Kuf, B the whitened factor, W = A diag(2 g_v) A':
 //   data-sized     W (SYRK over the points, split-K slices)                         gemm_pm_kernel
-//                  kernel-parameter / inducing-input reductions of P o dK           kgrad_kernel
+//                  kernel-parameter / inducing-input reductions of P o dK           kgrad_mfma_kernel
 //                  (P = alpha g_mu' + 2 (R A) diag(g_v) is formed there from the strips' UNSCALED R A: the strips take the
 //                  variance from the same product, so their phase 2 is gone - 4 GEMM units per point in all: trsm 1 + R A 2 + W 1)
 //   M-sized        Linv = Lk^-1 by recursive doubling (round 3)                     linv_init / linv_step kernels
 //                  alpha = Linv' m~,  R = Linv' (B B' - I)                          linv_t_gemv, gemm_pm (M x M x M form)
 //                  Lq_bar = tril(W B) - dKL/dB,  Lk_bar = -tril(alpha a' + R W)     gemm_pm, finish_mm2
 //                  Kuu_bar = sym(Linv' Phi(Lk' Lk_bar) Linv)                        gemm_pm x 3, phi, symmetrize
-//                  their Kuu part of the kernel-parameter gradients                 kgrad_kernel (uu), kgrad_reduce, finish_kgrad
+//                  their Kuu part of the kernel-parameter gradients                 kgrad_mfma_kernel (uu), kgrad_reduce, finish_kgrad
 // Round 2 applied Lk^-T by blocked substitution (four chains of nP panels, 0.18 ms each at M = 1024 whatever the batch);
 // with the explicit inverse every M-sized step is a GEMM over the whole chip.
 #include <cstdlib>
@@ -386,573 +386,15 @@ __device__ __forceinline__ void kappa_and_d(T r2, T variance, T& k, T& dk) {
   }
 }
 
-// Row-wise reductions of W = Pt o dK/dr^2 against the points of a slice:
-//   rowpart[slice][0][i] += sum_j W_ij           rowpart[slice][1][i] += sum_j At_ji g_mu_j   (m_bar)
+// Row-wise reductions of W = Pt o dK/dr^2 against the points of a slice (the interface of launch_kgrad):
+//   rowpart[slice][0][i] += sum_j W_ij           rowpart[slice][1][i] += sum_j K_ij g_mu_j   (m_bar: the caller applies Lk^-1)
 //   rowpart[slice][2+f][i] += sum_j W_ij xs_fj    scalpart[slice][rb][0] += sum P_ij K_ij,  [1+f] += sum W_ij u_fij^2
-// Pt is point-major [n][Mp]; each thread owns KV rows i for the whole slice (scaled z in registers).
-// rows per lane of the 16-feature kernel (same box, H-sized value and gradient at d = 16, profiles/round5/kgrad_kv1_ab.log: f64 two rows
-// - 256 VGPRs with 111-143 spilled - 90.6-91.1 ms, one row 79.8-80.3; fp32 (C3) two rows 149.3-149.6 ms, one row 150.9)
-template <typename T> struct Kgrad16 { static constexpr int KV = sizeof(T) == 8 ? 1 : 2; };
-#ifndef SVGP_KGRAD8_KV_F64
-#define SVGP_KGRAD8_KV_F64 2
-#endif
-#ifndef SVGP_KGRAD8_KV_F32
-#define SVGP_KGRAD8_KV_F32 2
-#endif
-template <typename T> struct Kgrad8 { static constexpr int KV = sizeof(T) == 8 ? SVGP_KGRAD8_KV_F64 : SVGP_KGRAD8_KV_F32; };   // (A/B builds)
-#ifndef SVGP_KGRAD_MINW
-#define SVGP_KGRAD_MINW 2   // waves per SIMD the register allocation must leave room for (A/B builds: 1 = round 4, the 16-feature kernels at 320-336 VGPRs)
-#endif
-template <typename T, int DREG, int KV, int FAMILY>
-__global__ void __launch_bounds__(k256, SVGP_KGRAD_MINW) kgrad_kernel(KernelParams kp, const T* __restrict__ zs, int64_t Mp,
-                                                     const T* __restrict__ x, int64_t ldx, int64_t xoff, int prescaled,
-                                                     int64_t n, int64_t nvalid, const T* __restrict__ Pt,
-                                                     const T* __restrict__ At, const T* __restrict__ gmu, const T* __restrict__ gv,
-                                                     const T* __restrict__ alpha, int64_t slice_len,
-                                                     double* __restrict__ rowpart, double* __restrict__ scalpart, int kmb) {
-  constexpr int JB = 128;
-  __shared__ T xt[JB * DREG];
-  __shared__ T gms[JB], gvs[JB];   // g_mu and 2 g_v of the staged points (1 where P is given as it is): staged with x, read as broadcasts
-  __shared__ double red[64 * KV * (2 + DREG)];
-  __shared__ double sred[k256];
-  const int d = kp.d;
-  const T* __restrict__ invl = static_cast<const T*>(kp.invl);
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int64_t i = (int64_t(blockIdx.y) * 64 + lane) * KV;
-  const int64_t j0 = int64_t(blockIdx.x) * slice_len;
-  int64_t j1 = j0 + slice_len;
-  j1 = j1 < n ? j1 : n;
-  T z[DREG][KV];
-#pragma unroll
-  for (int f = 0; f < DREG; ++f)
-#pragma unroll
-    for (int e = 0; e < KV; ++e) z[f][e] = (f < d) ? zs[int64_t(f) * Mp + i + e] : T(0);
-  // data part (round 3): Pt holds the strips' UNSCALED product R A; P_ij = alpha_i g_mu_j + 2 g_v_j (R A)_ij is formed here, by
-  // its one consumer (the strips learn g_v only after their last panel).  Kuu part (alpha == nullptr): Pt is the matrix itself.
-  T al[KV];
-#pragma unroll
-  for (int e = 0; e < KV; ++e) al[e] = alpha ? alpha[i + e] : T(0);
-  double R[KV], MB[KV], Q[DREG][KV], IL[DREG], S1 = 0.0;
-#pragma unroll
-  for (int e = 0; e < KV; ++e) R[e] = MB[e] = 0.0;
-#pragma unroll
-  for (int f = 0; f < DREG; ++f) {
-    IL[f] = 0.0;
-#pragma unroll
-    for (int e = 0; e < KV; ++e) Q[f][e] = 0.0;
-  }
-  const T variance = T(kp.variance);
-  for (int64_t jb = j0; jb < j1; jb += JB) {
-    __syncthreads();
-    for (int e = threadIdx.x; e < JB * DREG; e += k256) {
-      const int c = e / DREG, f = e % DREG;
-      int64_t g = jb + c;
-      g = g < nvalid ? g : nvalid - 1;
-      T v = T(0);
-      if (f < d) v = prescaled ? x[int64_t(f) * ldx + xoff + g] : x[int64_t(f) * ldx + xoff + g] * invl[f];
-      xt[e] = v;
-    }
-    if (threadIdx.x < JB) {
-      int64_t g = jb + threadIdx.x;
-      g = g < j1 ? g : j1 - 1;
-      gms[threadIdx.x] = gmu ? gmu[g] : T(0);
-      gvs[threadIdx.x] = alpha ? T(2) * gv[g] : T(1);
-    }
-    __syncthreads();
-    // U points of this wave in flight at a time: the kernel streams P (and A) once from HBM with ONE 1 KiB load per point
-    // and wave, and with a single load outstanding per wave it ran at the memory latency (350 us per 65 536-point chunk in
-    // f64 AND in fp32: 5-6 ms of a value-and-gradient evaluation)
-#ifndef SVGP_KGRAD_U
-#define SVGP_KGRAD_U 4
-#endif
-#ifndef SVGP_KGRAD_F32_BLOCKS
-#define SVGP_KGRAD_F32_BLOCKS 1   // 0: fp64 accumulation of every entry in the fp32 builds too (A/B builds)
-#endif
-    constexpr int U = SVGP_KGRAD_U;
-    // fp32 builds: the 32 points a wave takes of a staged block are summed in fp32 and the block sums added to the fp64 totals
-    // (the per-entry fp64 conversions and FMAs - half the fp32 rate - were most of this VALU-bound kernel: 0.216 ms per 65 536-point
-    // chunk at M = 1024 for 0.27 GB read; a 32-term fp32 sum adds ~3e-7 relative to the one-rounding error of the kernel entries
-    // themselves, which the fp32 gradient tolerances are built on)
-    constexpr bool kBlockF32 = (sizeof(T) == 4) && SVGP_KGRAD_F32_BLOCKS;
-    float Rb[KV], MBb[KV], Qb[DREG][KV], ILb[DREG], S1b = 0.0f;
-#pragma unroll
-    for (int e = 0; e < KV; ++e) Rb[e] = MBb[e] = 0.0f;
-#pragma unroll
-    for (int f = 0; f < DREG; ++f) {
-      ILb[f] = 0.0f;
-#pragma unroll
-      for (int e = 0; e < KV; ++e) Qb[f][e] = 0.0f;
-    }
-    for (int c0w = wave; c0w < JB && jb + c0w < j1; c0w += 4 * U) {
-      T pv[U][KV], av[U][KV], gmv[U], gvv[U];
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const int c = c0w + 4 * u;
-        const bool ok = c < JB && jb + c < j1;
-        const int64_t j = ok ? jb + c : jb + c0w;
-#pragma unroll
-        for (int e = 0; e < KV; ++e) {
-          pv[u][e] = Pt[j * Mp + i + e];
-          av[u][e] = At ? At[j * Mp + i + e] : T(0);
-        }
-        gmv[u] = gms[ok ? c : c0w];
-        gvv[u] = gvs[ok ? c : c0w];
-      }
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const int c = c0w + 4 * u;
-        if (!(c < JB && jb + c < j1)) break;   // wave-uniform
-        // (the differences z - x are formed again in the accumulation loop below instead of being kept: DREG x KV registers - the f64
-        //  d <= 16 kernel had 320-336 VGPRs, one wave per SIMD)
-        T r2[KV];
-#pragma unroll
-        for (int e = 0; e < KV; ++e) r2[e] = T(0);
-#pragma unroll
-        for (int f = 0; f < DREG; ++f) {
-          const T xv = xt[c * DREG + f];
-#pragma unroll
-          for (int e = 0; e < KV; ++e) {
-            const T uf = z[f][e] - xv;
-            r2[e] = fma(uf, uf, r2[e]);
-          }
-        }
-#pragma unroll
-        for (int e = 0; e < KV; ++e) {
-          T k, dk;
-          kappa_and_d<T, FAMILY>(r2[e], variance, k, dk);
-          const T p = fma(gvv[u], pv[u][e], al[e] * gmv[u]);   // alpha == nullptr: 1 * pv + 0
-          if constexpr (kBlockF32) {
-            const float Wf = float(p) * float(dk);
-            S1b = fmaf(float(p), float(k), S1b);
-            Rb[e] += Wf;
-            if (At) MBb[e] = fmaf(float(av[u][e]), float(gmv[u]), MBb[e]);
-            else if (kmb) MBb[e] = fmaf(float(k), float(gmv[u]), MBb[e]);
-#pragma unroll
-            for (int f = 0; f < DREG; ++f) {
-              const float xv = float(xt[c * DREG + f]), uf = float(z[f][e]) - xv;
-              Qb[f][e] = fmaf(Wf, xv, Qb[f][e]);
-              ILb[f] = fmaf(Wf * uf, uf, ILb[f]);
-            }
-            continue;
-          }
-          const double W = double(p) * double(dk);
-          S1 += double(p) * double(k);
-          R[e] += W;
-          if (At) MB[e] += double(av[u][e]) * double(gmv[u]);   // (A g_mu)_i from A
-          else if (kmb) MB[e] += double(k) * double(gmv[u]);    // (Kuf g_mu)_i: the caller applies Lk^-1 (f64: A is not read at all)
-#pragma unroll
-          for (int f = 0; f < DREG; ++f) {
-            const T xv = xt[c * DREG + f];
-            const double uf = double(z[f][e] - xv);
-            Q[f][e] += W * double(xv);
-            IL[f] += W * uf * uf;
-          }
-        }
-      }
-    }
-    if constexpr (kBlockF32) {
-      S1 += double(S1b);
-#pragma unroll
-      for (int e = 0; e < KV; ++e) {
-        R[e] += double(Rb[e]);
-        MB[e] += double(MBb[e]);
-      }
-#pragma unroll
-      for (int f = 0; f < DREG; ++f) {
-        IL[f] += double(ILb[f]);
-#pragma unroll
-        for (int e = 0; e < KV; ++e) Q[f][e] += double(Qb[f][e]);
-      }
-    }
-  }
-  // combine the four waves (same rows) in a fixed order, then add into this (slice, row-block)'s partials
-  constexpr int NV = KV * (2 + DREG);
-  for (int w = 0; w < 4; ++w) {
-    __syncthreads();
-    if (wave == w) {
-      double* rr = red + lane * NV;
-#pragma unroll
-      for (int e = 0; e < KV; ++e) {
-        rr[e] = (w ? rr[e] : 0.0) + R[e];
-        rr[KV + e] = (w ? rr[KV + e] : 0.0) + MB[e];
-#pragma unroll
-        for (int f = 0; f < DREG; ++f) rr[(2 + f) * KV + e] = (w ? rr[(2 + f) * KV + e] : 0.0) + Q[f][e];
-      }
-    }
-  }
-  __syncthreads();
-  double* rp = rowpart + int64_t(blockIdx.x) * (2 + DREG) * Mp;
-  for (int t = threadIdx.x; t < 64 * NV; t += k256) {
-    const int ln = t / NV, q = (t % NV) / KV, e = t % KV;
-    rp[int64_t(q) * Mp + (int64_t(blockIdx.y) * 64 + ln) * KV + e] += red[t];
-  }
-  double* sp = scalpart + (int64_t(blockIdx.x) * gridDim.y + blockIdx.y) * (1 + DREG);
-  for (int q = 0; q <= DREG; ++q) {
-    __syncthreads();
-    sred[threadIdx.x] = (q == 0) ? S1 : IL[q - 1];
-    __syncthreads();
-    for (int w = k256 / 2; w > 0; w >>= 1) {
-      if (int(threadIdx.x) < w) sred[threadIdx.x] += sred[threadIdx.x + w];
-      __syncthreads();
-    }
-    if (threadIdx.x == 0) sp[q] += sred[0];
-  }
-}
-
-// ---- wide inputs: 16 < d <= 64 (round 4) ------------------------------------------------------------------------------------
-// kgrad_kernel keeps a row's d feature slots (z, Q, IL) in the registers of ONE thread: 32 slots still fit, 64 spill by the hundred
-// (an H-sized value-and-gradient evaluation at d = 64 took 590 ms against 78 at d = 8).  Here LPR = 2 / 4 adjacent lanes share a
-// row, 16 features each: the squared distance is completed by LPR - 1 xor-shuffles per (row, point), every lane evaluates the
-// kernel function for itself (no broadcast to wait for) and accumulates only its own features' sums; the row-level sums (R, the
-// m_bar column, sum P K) are kept by the first lane of the group.  Same interface, same partial-sum layout, same fixed-order
-// reductions as kgrad_kernel (rows per workgroup: 64 / LPR).
-template <typename T, int LPR, int FAMILY>
-__global__ void __launch_bounds__(k256) kgrad_wide_kernel(KernelParams kp, const T* __restrict__ zs, int64_t Mp,
-                                                          const T* __restrict__ x, int64_t ldx, int64_t xoff, int prescaled,
-                                                          int64_t n, int64_t nvalid, const T* __restrict__ Pt,
-                                                          const T* __restrict__ At, const T* __restrict__ gmu, const T* __restrict__ gv,
-                                                          const T* __restrict__ alpha, int64_t slice_len,
-                                                          double* __restrict__ rowpart, double* __restrict__ scalpart, int kmb) {
-  constexpr int JB = 128, FL = 16, DL = FL * LPR, RPW = 64 / LPR, U = 4;
-  constexpr bool kF32 = (sizeof(T) == 4);
-  using B = std::conditional_t<kF32, float, double>;   // per-staged-block accumulators (fp32 builds: 32 terms in fp32, then fp64 totals)
-  __shared__ T xt[JB * DL];
-  __shared__ T gms[JB], gvs[JB];
-  __shared__ double red[64 * (2 + FL)];
-  __shared__ double sred[k256];
-  const int d = kp.d;
-  const T* __restrict__ invl = static_cast<const T*>(kp.invl);
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, rowl = lane / LPR, fg = lane % LPR;
-  const bool lead = (fg == 0);
-  const int64_t i = int64_t(blockIdx.y) * RPW + rowl;
-  const int64_t j0 = int64_t(blockIdx.x) * slice_len;
-  int64_t j1 = j0 + slice_len;
-  j1 = j1 < n ? j1 : n;
-  T z[FL];
-#pragma unroll
-  for (int f = 0; f < FL; ++f) z[f] = (FL * fg + f < d) ? zs[int64_t(FL * fg + f) * Mp + i] : T(0);
-  const T al = alpha ? alpha[i] : T(0);
-  double R = 0.0, MB = 0.0, S1 = 0.0, Q[FL], IL[FL];
-#pragma unroll
-  for (int f = 0; f < FL; ++f) Q[f] = IL[f] = 0.0;
-  const T variance = T(kp.variance);
-  for (int64_t jb = j0; jb < j1; jb += JB) {
-    __syncthreads();
-    for (int e = threadIdx.x; e < JB * DL; e += k256) {
-      const int c = e / DL, f = e % DL;
-      int64_t g = jb + c;
-      g = g < nvalid ? g : nvalid - 1;
-      T v = T(0);
-      if (f < d) v = prescaled ? x[int64_t(f) * ldx + xoff + g] : x[int64_t(f) * ldx + xoff + g] * invl[f];
-      xt[e] = v;
-    }
-    if (threadIdx.x < JB) {
-      int64_t g = jb + threadIdx.x;
-      g = g < j1 ? g : j1 - 1;
-      gms[threadIdx.x] = gmu ? gmu[g] : T(0);
-      gvs[threadIdx.x] = alpha ? T(2) * gv[g] : T(1);
-    }
-    __syncthreads();
-    // fp32: per-block sums in fp32 (Rb ...), added to the fp64 totals once per staged block.  f64: the totals themselves are the
-    // accumulators (round 5: a second fp64 set and the kept differences uu[] put the kernel at 345-350 VGPRs - ONE wave per SIMD for a
-    // kernel of dependent f64 chains and global loads; the differences are recomputed in the second feature loop instead)
-    B Rb = 0, MBb = 0, S1b = 0, Qb[kF32 ? FL : 1], ILb[kF32 ? FL : 1];
-    if constexpr (kF32) {
-#pragma unroll
-      for (int f = 0; f < FL; ++f) Qb[f] = ILb[f] = 0;
-    }
-    for (int c0w = wave; c0w < JB && jb + c0w < j1; c0w += 4 * U) {
-      T pv[U], av[U], gmv[U], gvv[U];
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const int c = c0w + 4 * u;
-        const bool ok = c < JB && jb + c < j1;
-        const int64_t j = ok ? jb + c : jb + c0w;
-        pv[u] = Pt[j * Mp + i];
-        av[u] = At ? At[j * Mp + i] : T(0);
-        gmv[u] = gms[ok ? c : c0w];
-        gvv[u] = gvs[ok ? c : c0w];
-      }
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const int c = c0w + 4 * u;
-        if (!(c < JB && jb + c < j1)) break;   // wave-uniform
-        const T* __restrict__ xc = xt + c * DL + FL * fg;
-        T r2a = T(0), r2b = T(0);   // two chains: a lone wave waits out every dependent f64 FMA
-#pragma unroll
-        for (int f = 0; f < FL; f += 2) {
-          const T ua = z[f] - xc[f], ub = z[f + 1] - xc[f + 1];
-          r2a = fma(ua, ua, r2a);
-          r2b = fma(ub, ub, r2b);
-        }
-        T r2 = r2a + r2b;
-        r2 += __shfl_xor(r2, 1);
-        if (LPR == 4) r2 += __shfl_xor(r2, 2);
-        T k, dk;
-        kappa_and_d<T, FAMILY>(r2, variance, k, dk);
-        const T p = fma(gvv[u], pv[u], al * gmv[u]);   // alpha == nullptr: 1 * pv + 0
-        const B W = B(p) * B(dk);
-        if (lead) {
-          S1b = fma(B(p), B(k), S1b);
-          Rb += W;
-          if (At) MBb = fma(B(av[u]), B(gmv[u]), MBb);
-          else if (kmb) MBb = fma(B(k), B(gmv[u]), MBb);
-        }
-#pragma unroll
-        for (int f = 0; f < FL; ++f) {
-          const T xv = xc[f], uf = z[f] - xv;
-          if constexpr (kF32) {
-            Qb[f] = fma(W, B(xv), Qb[f]);
-            ILb[f] = fma(W * B(uf), B(uf), ILb[f]);
-          } else {
-            Q[f] = fma(double(W), double(xv), Q[f]);
-            IL[f] = fma(double(W) * double(uf), double(uf), IL[f]);
-          }
-        }
-      }
-    }
-    S1 += double(S1b); R += double(Rb); MB += double(MBb);
-    if constexpr (kF32) {
-#pragma unroll
-      for (int f = 0; f < FL; ++f) { Q[f] += double(Qb[f]); IL[f] += double(ILb[f]); }
-    }
-  }
-  // combine the four waves (same rows) in a fixed order, then add into this (slice, row-block)'s partials
-  constexpr int NV = 2 + FL;
-  for (int w = 0; w < 4; ++w) {
-    __syncthreads();
-    if (wave == w) {
-      double* rr = red + lane * NV;
-      rr[0] = (w ? rr[0] : 0.0) + R;
-      rr[1] = (w ? rr[1] : 0.0) + MB;
-#pragma unroll
-      for (int f = 0; f < FL; ++f) rr[2 + f] = (w ? rr[2 + f] : 0.0) + Q[f];
-    }
-  }
-  __syncthreads();
-  double* rp = rowpart + int64_t(blockIdx.x) * (2 + DL) * Mp;
-  for (int t = threadIdx.x; t < 64 * NV; t += k256) {
-    const int ln = t / NV, q = t % NV, rl = ln / LPR, g = ln % LPR;
-    const int64_t row = int64_t(blockIdx.y) * RPW + rl;
-    if (q < 2) { if (g == 0) rp[int64_t(q) * Mp + row] += red[t]; }
-    else rp[int64_t(2 + FL * g + (q - 2)) * Mp + row] += red[t];
-  }
-  double* sp = scalpart + (int64_t(blockIdx.x) * gridDim.y + blockIdx.y) * (1 + DL);
-  for (int q = 0; q <= DL; ++q) {
-    __syncthreads();
-    double v = 0.0;
-    if (q == 0) v = S1;
-    else if ((q - 1) / FL == fg) {
-#pragma unroll
-      for (int f = 0; f < FL; ++f) v = ((q - 1) % FL == f) ? IL[f] : v;
-    }
-    sred[threadIdx.x] = v;
-    __syncthreads();
-    for (int w = k256 / 2; w > 0; w >>= 1) {
-      if (int(threadIdx.x) < w) sred[threadIdx.x] += sred[threadIdx.x + w];
-      __syncthreads();
-    }
-    if (threadIdx.x == 0) sp[q] += sred[0];
-  }
-}
-
-// ---- wide inputs, round 5: one WAVE per 16-feature group ------------------------------------------------------------------------
-// kgrad_wide_kernel gives a row to LPR adjacent lanes: a wave then covers 64 / LPR rows, its loads of P are 128-256 bytes each, and
-// its 345-350 VGPRs (f64, round 4; 244-254 since round 5) left one wave per SIMD.  Here a lane owns a ROW (64 rows per workgroup, every load of P a full 512 / 256-byte line per wave) and a
-// WAVE owns a group of 16 features: the NG = 2 / 4 feature groups of a point meet through LDS - each wave leaves the partial squared
-// distances of its PB points, one workgroup barrier, every wave adds the NG partials in the same order - and then every wave evaluates
-// the kernel function for itself and accumulates its own 16 feature sums.  With NG = 2 the other two waves take the other half of the
-// points.  Same interface, same partial-sum layout (rows per workgroup: 64), sums in a fixed order.
-template <typename T, int NG, int FAMILY>
-__global__ void __launch_bounds__(k256, 2) kgrad_wide2_kernel(KernelParams kp, const T* __restrict__ zs, int64_t Mp,
-                                                              const T* __restrict__ x, int64_t ldx, int64_t xoff, int prescaled,
-                                                              int64_t n, int64_t nvalid, const T* __restrict__ Pt,
-                                                              const T* __restrict__ At, const T* __restrict__ gmu, const T* __restrict__ gv,
-                                                              const T* __restrict__ alpha, int64_t slice_len,
-                                                              double* __restrict__ rowpart, double* __restrict__ scalpart, int kmb) {
-  constexpr int FL = 16, DL = FL * NG, PS = 4 / NG, PB = 4;
-  constexpr int JB = (sizeof(T) * DL == 512) ? 64 : 128;   // 32 KiB of staged inputs at most
-  constexpr int NBATCH = JB / (PS * PB);
-  constexpr bool kF32 = (sizeof(T) == 4);
-  using B = std::conditional_t<kF32, float, double>;   // per-staged-block accumulators (fp32 builds: <= 128 terms in fp32, then fp64 totals)
-  __shared__ __attribute__((aligned(16))) T xt[JB * DL];
-  __shared__ T gms[JB], gvs[JB];
-  __shared__ T part[2][4][PB][64];
-  const int d = kp.d;
-  const T* __restrict__ invl = static_cast<const T*>(kp.invl);
-  // (the wave index as a scalar: everything derived from it - feature group, point subset, the points' addresses - stays in SGPRs)
-  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(int(threadIdx.x >> 6)), g = wave % NG, ps = wave / NG;
-  const bool lead = (g == 0);
-  const int64_t i = int64_t(blockIdx.y) * 64 + lane;
-  const int64_t j0 = int64_t(blockIdx.x) * slice_len;
-  int64_t j1 = j0 + slice_len;
-  j1 = j1 < n ? j1 : n;
-  T z[FL];
-#pragma unroll
-  for (int f = 0; f < FL; ++f) z[f] = (FL * g + f < d) ? zs[int64_t(FL * g + f) * Mp + i] : T(0);
-  const T al = alpha ? alpha[i] : T(0);
-  double R = 0.0, MB = 0.0, S1 = 0.0, Q[FL], IL[FL];
-#pragma unroll
-  for (int f = 0; f < FL; ++f) Q[f] = IL[f] = 0.0;
-  const T variance = T(kp.variance);
-  const T* __restrict__ prow = Pt + i;
-  const T* __restrict__ arow = (At ? At : Pt) + i;
-  const int sf = threadIdx.x % DL, sc0 = threadIdx.x / DL;
-  const T* __restrict__ xrow = x + int64_t(sf < d ? sf : 0) * ldx + xoff;
-  const T sscale = (prescaled || sf >= d) ? T(1) : invl[sf];
-  for (int64_t jb = j0; jb < j1; jb += JB) {
-    __syncthreads();
-    // a thread stages ONE feature (256 is a multiple of DL) of every (256 / DL)-th point: one base pointer and one scale per thread (the
-    // generic e / DL, e % DL form left sixteen hoisted 64-bit addresses live across the whole kernel)
-    if (sf < d) {
-#pragma unroll 4
-      for (int c = sc0; c < JB; c += k256 / DL) {
-        int64_t gg = jb + c;
-        gg = gg < nvalid ? gg : nvalid - 1;
-        xt[c * DL + sf] = xrow[gg] * sscale;
-      }
-    } else {
-      for (int c = sc0; c < JB; c += k256 / DL) xt[c * DL + sf] = T(0);
-    }
-    if (threadIdx.x < JB) {
-      int64_t gg = jb + threadIdx.x;
-      gg = gg < j1 ? gg : j1 - 1;
-      gms[threadIdx.x] = gmu ? gmu[gg] : T(0);
-      gvs[threadIdx.x] = alpha ? T(2) * gv[gg] : T(1);
-    }
-    __syncthreads();
-    B Rb = 0, MBb = 0, S1b = 0, Qb[kF32 ? FL : 1], ILb[kF32 ? FL : 1];
-    if constexpr (kF32) {
-#pragma unroll
-      for (int f = 0; f < FL; ++f) Qb[f] = ILb[f] = 0;
-    }
-    // the P (and A) values of a batch are loaded one batch ahead
-    // (A is read only by the experiments build's SVGP_A_FROM_K=0 form: api.hip passes At = nullptr otherwise)
-    constexpr int PA = kExperiments ? PB : 1;
-    T pn[PB], an[PA];
-    const bool need_a = kExperiments && At && lead;   // (wave-uniform)
-    auto fetch = [&](int b) {
-#pragma unroll
-      for (int t = 0; t < PB; ++t) {
-        int64_t j = jb + (b * PS + ps) * PB + t;
-        j = j < j1 ? j : j1 - 1;
-        pn[t] = prow[j * Mp];
-        if constexpr (kExperiments) an[t] = need_a ? arow[j * Mp] : T(0);
-      }
-    };
-    fetch(0);
-#pragma unroll 1
-    for (int b = 0; b < NBATCH; ++b) {
-      const int cb = (b * PS + ps) * PB;
-      T pv[PB], av[PA];
-#pragma unroll
-      for (int t = 0; t < PB; ++t) {
-        pv[t] = pn[t];
-        if constexpr (kExperiments) av[t] = an[t];
-      }
-      if (b + 1 < NBATCH && jb + ((b + 1) * PS) * PB < j1) fetch(b + 1);   // (workgroup-uniform condition; a batch wholly past j1 reuses the last values, masked below)
-#pragma unroll
-      for (int t = 0; t < PB; ++t) {
-        const T* __restrict__ xc = xt + (cb + t) * DL + FL * g;
-        T ra = T(0), rb = T(0);   // two chains
-#pragma unroll
-        for (int f = 0; f < FL; f += 2) {
-          const T ua = z[f] - xc[f], ub = z[f + 1] - xc[f + 1];
-          ra = fma(ua, ua, ra);
-          rb = fma(ub, ub, rb);
-        }
-        part[b & 1][wave][t][lane] = ra + rb;
-        asm volatile("" ::: "memory");   // one point's 16 inputs in registers at a time (hoisted over the unrolled loop they cost 128 VGPRs in f64)
-      }
-      __syncthreads();   // (the buffer of batch b is rewritten by batch b + 2, behind the barrier of batch b + 1)
-#pragma unroll
-      for (int t = 0; t < PB; ++t) {
-        const int c = cb + t;
-        const bool ok = jb + c < j1;
-        T r2 = part[b & 1][ps * NG][t][lane];
-#pragma unroll
-        for (int q = 1; q < NG; ++q) r2 += part[b & 1][ps * NG + q][t][lane];
-        T k, dk;
-        kappa_and_d<T, FAMILY>(r2, variance, k, dk);
-        const T gm = gms[c];
-        const T p = ok ? fma(gvs[c], pv[t], al * gm) : T(0);   // alpha == nullptr: 1 * pv + 0
-        const B W = B(p) * B(dk);
-        if (lead) {
-          S1b = fma(B(p), B(k), S1b);
-          Rb += W;
-          if (kExperiments && At) MBb = fma(B(ok ? av[kExperiments ? t : 0] : T(0)), B(gm), MBb);
-          else if (kmb) MBb = fma(B(ok ? k : T(0)), B(gm), MBb);
-        }
-        const T* __restrict__ xc = xt + c * DL + FL * g;
-#pragma unroll
-        for (int f = 0; f < FL; ++f) {
-          const T xv = xc[f], uf = z[f] - xv;
-          if constexpr (kF32) {
-            Qb[f] = fma(W, B(xv), Qb[f]);
-            ILb[f] = fma(W * B(uf), B(uf), ILb[f]);
-          } else {
-            Q[f] = fma(double(W), double(xv), Q[f]);
-            IL[f] = fma(double(W) * double(uf), double(uf), IL[f]);
-          }
-        }
-        asm volatile("" ::: "memory");
-      }
-    }
-    S1 += double(S1b); R += double(Rb); MB += double(MBb);
-    if constexpr (kF32) {
-#pragma unroll
-      for (int f = 0; f < FL; ++f) { Q[f] += double(Qb[f]); IL[f] += double(ILb[f]); }
-    }
-  }
-  // closing sums: the PS waves of a feature group in a fixed order, then this (slice, row-block)'s partials
-  constexpr int NV = 2 + FL;
-  __shared__ double red[PS > 1 ? NG * 64 * NV : 1];   // the second wave's row sums of a feature group
-  __shared__ double sc[4 * (1 + FL)];                   // the waves' column sums
-  __syncthreads();
-  if (PS > 1 && ps == 1) {
-    double* rr = red + (g * 64 + lane) * NV;
-    rr[0] = R; rr[1] = MB;
-#pragma unroll
-    for (int f = 0; f < FL; ++f) rr[2 + f] = Q[f];
-  }
-  // the column sums over the 64 rows of the wave (butterfly: the same order in every lane), then over the PS waves
-  double cs[1 + FL];
-  cs[0] = S1;
-#pragma unroll
-  for (int f = 0; f < FL; ++f) cs[1 + f] = IL[f];
-#pragma unroll
-  for (int q = 0; q <= FL; ++q) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) cs[q] += __shfl_xor(cs[q], o);
-  }
-  if (lane == 0) {
-#pragma unroll
-    for (int q = 0; q <= FL; ++q) sc[wave * (1 + FL) + q] = cs[q];
-  }
-  __syncthreads();
-  double* rp = rowpart + int64_t(blockIdx.x) * (2 + DL) * Mp;
-  if (ps == 0) {
-    const double* rr = red + (g * 64 + lane) * NV;
-    if (lead) {
-      rp[i] += (PS > 1) ? R + rr[0] : R;
-      rp[Mp + i] += (PS > 1) ? MB + rr[1] : MB;
-    }
-#pragma unroll
-    for (int f = 0; f < FL; ++f) rp[int64_t(2 + FL * g + f) * Mp + i] += (PS > 1) ? Q[f] + rr[2 + f] : Q[f];
-    if (lane <= FL) {   // lane q of the group's first wave adds scalar q: q = 0 (sum P K) from the lead group only
-      double* sp = scalpart + (int64_t(blockIdx.x) * gridDim.y + blockIdx.y) * (1 + DL);
-      const int q = lane;
-      double v = sc[g * (1 + FL) + q];
-      if (PS > 1) v += sc[(NG + g) * (1 + FL) + q];
-      if (q == 0) { if (lead) sp[0] += v; }
-      else sp[FL * g + q] += v;
-    }
-  }
-}
-
+// Pt is point-major [n][Mp].  Rounds 2-5 computed them on the VALU - a lane owned one or two rows with all d feature slots in
+// registers (kgrad_kernel), two / four lanes a row (kgrad_wide_kernel), a wave a 16-feature group (kgrad_wide2_kernel): 75 (d = 8)
+// to 450 (d = 64) VALU instructions per 64 entries, 219 us per 65 536-point chunk at d = 8 and 2.9 ms at d = 64 (M = 1024, f64).
+// Those kernels left the tree in round 6 (profiles/round6/kgrad_valu_kernels_removed.patch).
 // ---- the kernel-gradient reductions on the MFMA (round 6) ----------------------------------------------------
-// The three kernels above hold a row's feature sums in VALU registers: ~75 (d = 8) to ~450 (d = 64) VALU instructions per 64 entries
-// of W, no matrix instruction.  Here both data-sized contractions are MFMAs and the VALU is left the kernel function itself:
+// Both data-sized contractions are MFMAs and the VALU is left the kernel function itself:
 //   (1) r2 tile (16 points x 16 inducing rows) = |x|^2 + |z|^2 - 2 x.z on the MFMA (accumulator preloaded with the norms, as the
 //       strips' pre-generation and kuf_cols_kernel do): D[point slot][inducing row];
 //   (2) VALU, 4 entries per lane: kernel function and its derivative, P = alpha g_mu' + 2 (R A) diag(g_v), W = P o dK/dr2, the row
@@ -971,7 +413,7 @@ __global__ void __launch_bounds__(k256, 2) kgrad_wide2_kernel(KernelParams kp, c
 // A wave owns 16 inducing rows for the whole slice of points (no cross-wave sums but the scalars), a workgroup 64 rows; the staged
 // tile is point-major with row stride DL + 16 bytes... (+6 / +4 elements): the r2 operand reads are conflict-free, and the pad columns
 // carry g_mu, 2 g_v and c1 |x|^2 of the point.  fp32: per staged block (128 points) sums in fp32 (MFMA accumulators included), totals fp64.
-// Same interface and partial-sum layout as kgrad_kernel; rows per workgroup: 64 for every d.
+// Rows per workgroup: 64 for every d.
 template <int CTRL>
 __device__ __forceinline__ float dpp_mov(float v) {
   return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
@@ -1362,45 +804,11 @@ __global__ void finish_kgrad_kernel(int d, int64_t M, int64_t Mp, const T* __res
   }
 }
 
-// the two forms of the wide-input reductions as function templates (NOT lambdas inside launch_kgrad_f: a lambda's body is instantiated
-// with its enclosing function whether it is called or not, and the product build would compile both kernel families for both dtypes)
-#define SVGP_KGRAD_ARGS                                                                                                          \
-  hipStream_t s, const KernelParams &kp, const T *zs, int64_t Mp, const T *x, int64_t ldx, int64_t xoff, int prescaled, int64_t n, \
-      int64_t nvalid, const T *Pt, const T *At, const T *gmu, const T *gv, const T *alpha, int64_t slice_len, int nslices,        \
-      double *rowpart, double *scalpart, int kmb
+// 64 rows per workgroup for every d
 template <typename T, int FAMILY>
-void launch_kgrad_groups(SVGP_KGRAD_ARGS) {   // a wave per 16-feature group
-  dim3 grid((unsigned)nslices, (unsigned)(Mp / 64));
-  if (kp.d <= 32)
-    hipLaunchKernelGGL((kgrad_wide2_kernel<T, 2, FAMILY>), grid, dim3(k256), 0, s, kp, zs, Mp, x, ldx, xoff, prescaled, n, nvalid,
-                       Pt, At, gmu, gv, alpha, slice_len, rowpart, scalpart, kmb);
-  else
-    hipLaunchKernelGGL((kgrad_wide2_kernel<T, 4, FAMILY>), grid, dim3(k256), 0, s, kp, zs, Mp, x, ldx, xoff, prescaled, n, nvalid,
-                       Pt, At, gmu, gv, alpha, slice_len, rowpart, scalpart, kmb);
-}
-template <typename T, int FAMILY>
-void launch_kgrad_lanes(SVGP_KGRAD_ARGS) {    // two / four lanes per row, 16 features each
-  if (kp.d <= 32) {
-    dim3 grid((unsigned)nslices, (unsigned)(Mp / 32));
-    hipLaunchKernelGGL((kgrad_wide_kernel<T, 2, FAMILY>), grid, dim3(k256), 0, s, kp, zs, Mp, x, ldx, xoff, prescaled, n, nvalid,
-                       Pt, At, gmu, gv, alpha, slice_len, rowpart, scalpart, kmb);
-  } else {
-    dim3 grid((unsigned)nslices, (unsigned)(Mp / 16));
-    hipLaunchKernelGGL((kgrad_wide_kernel<T, 4, FAMILY>), grid, dim3(k256), 0, s, kp, zs, Mp, x, ldx, xoff, prescaled, n, nvalid,
-                       Pt, At, gmu, gv, alpha, slice_len, rowpart, scalpart, kmb);
-  }
-}
-#undef SVGP_KGRAD_ARGS
-
-// the MFMA form (round 6): 64 rows per workgroup for every d
-bool kgrad_mfma_on() {
-  static const int knob = exp_int("SVGP_KGRAD_MFMA", 1) && exp_int("SVGP_A_FROM_K", 1);   // (experiments build: 0 = the VALU kernels of rounds 2-5)
-  return knob != 0;
-}
-template <typename T, int FAMILY>
-void launch_kgrad_mfma(hipStream_t s, const KernelParams& kp, const T* zs, int64_t Mp, const T* x, int64_t ldx, int64_t xoff,
-                       int prescaled, int64_t n, int64_t nvalid, const T* Pt, const T* gmu, const T* gv, const T* alpha,
-                       int64_t slice_len, int nslices, double* rowpart, double* scalpart, int kmb) {
+void launch_kgrad_f(hipStream_t s, const KernelParams& kp, const T* zs, int64_t Mp, const T* x, int64_t ldx, int64_t xoff,
+                    int prescaled, int64_t n, int64_t nvalid, const T* Pt, const T* gmu, const T* gv, const T* alpha,
+                    int64_t slice_len, int nslices, double* rowpart, double* scalpart, int kmb) {
   dim3 grid((unsigned)nslices, (unsigned)(Mp / 64));
 #define SVGP_KGM(DL) hipLaunchKernelGGL((kgrad_mfma_kernel<T, FAMILY, DL>), grid, dim3(k256), 0, s, kp, zs, Mp, x, ldx, xoff, prescaled, n, \
                                         nvalid, Pt, gmu, gv, alpha, slice_len, rowpart, scalpart, kmb)
@@ -1409,44 +817,6 @@ void launch_kgrad_mfma(hipStream_t s, const KernelParams& kp, const T* zs, int64
   else if (kp.d <= 32) SVGP_KGM(32);
   else SVGP_KGM(64);
 #undef SVGP_KGM
-}
-
-template <typename T, int FAMILY>
-void launch_kgrad_f(hipStream_t s, const KernelParams& kp, const T* zs, int64_t Mp, const T* x, int64_t ldx, int64_t xoff,
-                    int prescaled, int64_t n, int64_t nvalid, const T* Pt, const T* At, const T* gmu, const T* gv, const T* alpha,
-                    int64_t slice_len, int nslices, double* rowpart, double* scalpart, int kmb) {
-  if (kgrad_mfma_on() && !At) {
-    launch_kgrad_mfma<T, FAMILY>(s, kp, zs, Mp, x, ldx, xoff, prescaled, n, nvalid, Pt, gmu, gv, alpha, slice_len, nslices, rowpart, scalpart, kmb);
-    return;
-  }
-  if (kp.d <= 8) {
-    dim3 grid((unsigned)nslices, (unsigned)(Mp / (64 * Kgrad8<T>::KV)));
-    hipLaunchKernelGGL((kgrad_kernel<T, 8, Kgrad8<T>::KV, FAMILY>), grid, dim3(k256), 0, s, kp, zs, Mp, x, ldx, xoff, prescaled, n, nvalid, Pt,
-                       At, gmu, gv, alpha, slice_len, rowpart, scalpart, kmb);
-  } else if (kp.d <= 16) {
-    dim3 grid((unsigned)nslices, (unsigned)(Mp / (64 * Kgrad16<T>::KV)));
-    hipLaunchKernelGGL((kgrad_kernel<T, 16, Kgrad16<T>::KV, FAMILY>), grid, dim3(k256), 0, s, kp, zs, Mp, x, ldx, xoff, prescaled, n, nvalid,
-                       Pt, At, gmu, gv, alpha, slice_len, rowpart, scalpart, kmb);
-  } else {
-    // 16 < d <= 64 (same box, H-sized value-and-gradient evaluations, ms; profiles/round5/kgrad_wide2_ab.log):
-    //                         round 4     LPR lanes per row, round-5 registers     a wave per feature group (kgrad_wide2_kernel)
-    //   f64  d = 32             97.3        86.2-87.3                                93.5-93.9
-    //   f64  d = 64            145          114.0-115.1                              114.3-116.7
-    //   fp32 d = 32             47.2        46.2-46.7                                45.8-45.9
-    //   fp32 d = 64             72.9        72.7-74.2 (the 64-slot thread)           63.5-64.1
-    // so: f64 keeps the lanes-per-row form, fp32 takes the wave-per-group form (experiments build: SVGP_KGRAD_WIDE2 = 0 / 1 forces one)
-    if constexpr (kExperiments) {
-      static const int wide2_knob = exp_int("SVGP_KGRAD_WIDE2", -1);
-#define SVGP_KGRAD_PASS s, kp, zs, Mp, x, ldx, xoff, prescaled, n, nvalid, Pt, At, gmu, gv, alpha, slice_len, nslices, rowpart, scalpart, kmb
-      if (wide2_knob < 0 ? sizeof(T) == 4 : wide2_knob != 0) launch_kgrad_groups<T, FAMILY>(SVGP_KGRAD_PASS);
-      else launch_kgrad_lanes<T, FAMILY>(SVGP_KGRAD_PASS);
-    } else if constexpr (sizeof(T) == 4) {   // (the product build compiles only the form it takes)
-      launch_kgrad_groups<T, FAMILY>(SVGP_KGRAD_PASS);
-    } else {
-      launch_kgrad_lanes<T, FAMILY>(SVGP_KGRAD_PASS);
-    }
-#undef SVGP_KGRAD_PASS
-  }
 }
 
 }  // namespace
@@ -1458,15 +828,10 @@ void launch_kgrad_f(hipStream_t s, const KernelParams& kp, const T* zs, int64_t 
   } while (0)
 
 int grad_dreg(int d) { return d <= 8 ? 8 : (d <= 16 ? 16 : (d <= 32 ? 32 : 64)); }
-// workgroups along the rows, exactly launch_kgrad_f's grid: 128 rows (d <= 16); wide inputs: 64 (fp32: a wave per feature group) or 32 / 16
-// (f64: two / four lanes per row)
+// workgroups along the rows of the kernel-gradient reductions: launch_kgrad_f's grid
 int grad_rowblocks(int dtype, int d, int64_t Mp) {
-  if (kgrad_mfma_on()) return int(Mp / 64);
-  if (d <= 8) return int(Mp / (64 * (dtype == 0 ? Kgrad8<double>::KV : Kgrad8<float>::KV)));
-  if (d <= 16) return int(Mp / (64 * (dtype == 0 ? Kgrad16<double>::KV : Kgrad16<float>::KV)));
-  const int knob = exp_int("SVGP_KGRAD_WIDE2", -1);
-  const bool wide2 = knob < 0 ? dtype != 0 : knob != 0;
-  return int(wide2 ? Mp / 64 : (d <= 32 ? Mp / 32 : Mp / 16));
+  (void)dtype; (void)d;
+  return int(Mp / 64);
 }
 
 void launch_set_f64(hipStream_t s, double* dst, double value) { hipLaunchKernelGGL(set_f64_kernel, dim3(1), dim3(1), 0, s, dst, value); }
@@ -1596,17 +961,17 @@ void launch_syrk_uniform(int dtype, hipStream_t s, const void* At, double w, dou
 }
 
 void launch_kgrad(int dtype, hipStream_t s, const KernelParams& kp, const void* zs, int64_t Mp, const void* x, int64_t ldx,
-                  int64_t xoff, int prescaled, int64_t n, int64_t nvalid, const void* Pt, const void* At, const void* gmu,
+                  int64_t xoff, int prescaled, int64_t n, int64_t nvalid, const void* Pt, const void* gmu,
                   const void* gv, const void* alpha, int64_t slice_len, int nslices, double* rowpart, double* scalpart, int kmb) {
   GD(dtype, T, {
     if (kp.family == KSE)
-      launch_kgrad_f<T, KSE>(s, kp, (const T*)zs, Mp, (const T*)x, ldx, xoff, prescaled, n, nvalid, (const T*)Pt, (const T*)At,
+      launch_kgrad_f<T, KSE>(s, kp, (const T*)zs, Mp, (const T*)x, ldx, xoff, prescaled, n, nvalid, (const T*)Pt,
                              (const T*)gmu, (const T*)gv, (const T*)alpha, slice_len, nslices, rowpart, scalpart, kmb);
     else if (kp.family == KM32)
-      launch_kgrad_f<T, KM32>(s, kp, (const T*)zs, Mp, (const T*)x, ldx, xoff, prescaled, n, nvalid, (const T*)Pt, (const T*)At,
+      launch_kgrad_f<T, KM32>(s, kp, (const T*)zs, Mp, (const T*)x, ldx, xoff, prescaled, n, nvalid, (const T*)Pt,
                               (const T*)gmu, (const T*)gv, (const T*)alpha, slice_len, nslices, rowpart, scalpart, kmb);
     else
-      launch_kgrad_f<T, KM52>(s, kp, (const T*)zs, Mp, (const T*)x, ldx, xoff, prescaled, n, nvalid, (const T*)Pt, (const T*)At,
+      launch_kgrad_f<T, KM52>(s, kp, (const T*)zs, Mp, (const T*)x, ldx, xoff, prescaled, n, nvalid, (const T*)Pt,
                               (const T*)gmu, (const T*)gv, (const T*)alpha, slice_len, nslices, rowpart, scalpart, kmb);
   });
 }

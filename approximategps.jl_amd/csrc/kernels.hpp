@@ -195,9 +195,9 @@ void launch_linv(int dtype, hipStream_t s, const void* L, const void* Tm, int64_
 void launch_linv_t_gemv(int dtype, hipStream_t s, const void* LinvRM, const void* v, int64_t Mp, void* out, double* part, int notrans = 0,
                         int vec_f64 = 0);
 // data part: Pt = the strips' unscaled R A, P_ij = alpha_i gmu_j + 2 gv_j Pt_ji formed inside (alpha != nullptr); Kuu part: Pt is
-// the matrix itself (alpha = gmu = gv = nullptr); At: (A g_mu) row sums beside it (f64 builds), else nullptr
+// the matrix itself (alpha = gmu = gv = nullptr); kmb: also the row sums (Kuf g_mu)_i into slot 1 (the caller applies Lk^-1: A g_mu)
 void launch_kgrad(int dtype, hipStream_t s, const KernelParams& kp, const void* zs, int64_t Mp, const void* x, int64_t ldx,
-                  int64_t xoff, int prescaled, int64_t n, int64_t nvalid, const void* Pt, const void* At, const void* gmu,
+                  int64_t xoff, int prescaled, int64_t n, int64_t nvalid, const void* Pt, const void* gmu,
                   const void* gv, const void* alpha, int64_t slice_len, int nslices, double* rowpart, double* scalpart, int kmb = 0);
 // fused gradient path: sums of the per-strip partials, W = A diag(2 g_v) A' from its split-K lower tiles, (A g_mu), and the
 // assembly of Lq_bar / Lk_bar from G1 = 2 W Lq, G2 = 2 R W and the rank-one term alpha (A g_mu)'

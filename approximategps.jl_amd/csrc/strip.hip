@@ -1051,10 +1051,12 @@ __global__ void __launch_bounds__(512, 2) kuf_cols_kernel(KernelParams kp, const
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   T* zl = reinterpret_cast<T*>(smem_raw);   // [DREG][RW]  bscale * scaled z of the workgroup's rows
   T* znl = zl + DREG * RW;                  // [RW]        c1 |z|^2
-  // f64 SE: exp from the 64-entry table of 2^(j/64) + a degree-5 polynomial (kexp_tab, as the strips' pre-generation: ~15 VALU
-  // instructions and one LDS read against kexp's ~20).  Round 6: at d > 16 the kernel is bound by f64 MFMA + VALU ISSUE, not by the
-  // store stream, and the kernel function is the VALU part
-  constexpr bool kTab = SVGP_PREGEN_EXPTAB && FAMILY == KSE && sizeof(T) == 8;
+  // f64 SE, d > 32: exp from the 64-entry table of 2^(j/64) + a degree-5 polynomial (kexp_tab, as the strips' pre-generation: ~15 VALU
+  // instructions and one LDS read against kexp's ~20).  Round 6, same box, TB/s with kexp -> with the table:
+  // d = 8 5.06 -> 5.02, d = 17 4.14 -> 4.19, d = 32 3.46 -> 3.42, d = 64 2.51 -> 2.59 (profiles/round6/kuf_exptab_ab.log) - the five
+  // instructions are ~4 % of a d = 64 tile, whose 16 f64 MFMAs per 256 entries (256 of ~390 issue cycles per 64 entries; f64 MFMA and
+  // VALU do not co-execute) are what bounds it: 3.2 TB/s at 100 % issue
+  constexpr bool kTab = SVGP_PREGEN_EXPTAB && FAMILY == KSE && sizeof(T) == 8 && DREG > 32;
   __shared__ double s_exptab[kTab ? 64 : 1];
   if (kTab && threadIdx.x < 64) s_exptab[threadIdx.x] = exp2(double(threadIdx.x) * 0.015625);
   const int d = kp.d;

@@ -1,10 +1,12 @@
-"""A/B of the kernel-gradient reductions: the VALU kernels of rounds 2-5 (SVGP_KGRAD_MFMA=0) against the MFMA form (round 6), on the
+"""(Ran at commit 4434fb5, the last one that holds both forms - the VALU kernels left the tree right after it:
+profiles/round6/kgrad_valu_kernels_removed.patch; from the repo root: python profiles/round6/scripts/kgrad_ab.py ...)
+A/B of the kernel-gradient reductions: the VALU kernels of rounds 2-5 (SVGP_KGRAD_MFMA=0) against the MFMA form (round 6), on the
 EXPERIMENTS library (the knob is read once per process, so every leg is its own process).  For each bench configuration given:
 value-and-gradient time (best of 3) and the gradient blocks' largest difference between the two legs relative to the block's scale.
 usage: python tools/round6/kgrad_ab.py H Hd16 Hd32 Hd64 H32 H32d64 C3 C5   (leg mode: --leg <0|1> <cfg> <out.npz>)"""
 import os, subprocess, sys, time
 R = os.path.dirname(os.path.abspath(__file__))
-ROOT = os.path.join(R, "..", "..")
+ROOT = os.path.join(R, "..", "..", "..")
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "approximategps.jl_amd"))
 import numpy as np
 
