@@ -128,7 +128,20 @@ class ShardedELBO:
         if self.in_library:
             val, _, g = self.model.elbo_grad(self.data, off, length, self.num_data)
             return val, g
-        val, _, g = self.model.elbo_grad(self.data, off, length, shard=(self.num_data / n_global, 1.0 / world))
+        # The host-side mirror of the library's protocol (csrc/api.hip: grad_handshake): the gradient all-reduce is sized by the model,
+        # so a rank whose evaluation raised cannot simply enter it.  Every rank first enters ONE fixed-size all-reduce of its failure
+        # flag; if any rank failed, all of them leave here - the failing rank with its own exception, the others with RuntimeError -
+        # and nobody enters the gradient all-reduce.
+        err, val, g = None, 0.0, None
+        try:
+            val, _, g = self.model.elbo_grad(self.data, off, length, shard=(self.num_data / n_global, 1.0 / world))
+        except Exception as e:   # noqa: BLE001 - re-raised after the flag's all-reduce
+            err = e
+        nfail = allreduce_failure_flag(err is not None, self.group, self.device)
+        if err is not None:
+            raise err
+        if nfail > 0:
+            raise RuntimeError("a rank failed before the gradient all-reduce (it was skipped on every rank)")
         return allreduce_value_and_gradient(val, g, self.group, self.device)
 
 
@@ -142,3 +155,14 @@ def allreduce_partials5(vec, group=None, device=None):
     if dist.is_available() and dist.is_initialized():
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
     return t.cpu().numpy()
+
+
+def allreduce_failure_flag(failed: bool, group=None, device=None) -> float:
+    """Number of ranks that failed locally: one fixed-size all-reduce every rank can enter whatever state it is in."""
+    import torch
+    import torch.distributed as dist
+
+    t = torch.tensor([1.0 if failed else 0.0], dtype=torch.float64, device=device if device is not None else "cpu")
+    if dist.is_available() and dist.is_initialized():
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    return float(t.item())

@@ -205,7 +205,7 @@ KernelParams kparams(const svgp_model* m) {
 // info + the factorisation's hand-over counters and flags: 1 + 2 nP ints, rounded up to 256 bytes - a memset whose size is not a
 // multiple of 16 bytes becomes TWO fill kernels (aligned body + tail), ~5 us of every call's prologue
 inline size_t info_bytes(int64_t Mp) { return (sizeof(int) * size_t(1 + 2 * (Mp / 128)) + 255) / 256 * 256; }
-int ensure_overlap(svgp_ctx* ctx, size_t state_doubles);   // (below) second stream + the row / look-ahead events
+int ensure_overlap(svgp_ctx* ctx, size_t state_doubles); int ensure_overlap(svgp_ctx* ctx, size_t state_doubles);   // (below) second stream + the row events
 int enqueue_prep(svgp_ctx* ctx, svgp_model* m, bool overlap = false, const RowHook* hook = nullptr) {
   hipStream_t s = ctx->stream;
   const KernelParams kp = kparams(m);
@@ -221,19 +221,9 @@ int enqueue_prep(svgp_ctx* ctx, svgp_model* m, bool overlap = false, const RowHo
   }
   launch_kuu(m->dtype, s, kp, m->zs, m->M, m->Mp, m->desc.jitter, m->L);
   KCHECK(ctx, "kuu");
-  // (experiments build, SVGP_CHOL_LOOKAHEAD=1: a large Kuu - more panels than row events, M > 2048 - factorises with the bulk trailing
-  // updates on the second stream, one panel behind the chain on this one; measured slower, prep.hip: potrf_t.  The row events - unused
-  // at that size - are its eight event slots)
-  PotrfLookahead la;
-  if (kExperiments && exp_int("SVGP_CHOL_LOOKAHEAD", 0) != 0 && m->Mp / 128 > potrf_max_row_events()) {
-    const int rcl = ensure_overlap(ctx, 0);
-    if (rcl) return rcl;
-    la.s2 = ctx->stream2;
-    la.ev = ctx->ev_row;
-  }
   TREC(ctx, ctx->ev_chol[0], s);
   launch_potrf(m->dtype, s, m->L, m->T, m->Mp, m->info, reinterpret_cast<unsigned*>(m->info + 1), ctx->num_cus, overlap ? ctx->ev_row : nullptr,
-               overlap ? hook : nullptr, la.s2 ? &la : nullptr);   // T panels included
+               overlap ? hook : nullptr);   // T panels included
   KCHECK(ctx, "potrf");
   TREC(ctx, ctx->ev_chol[1], s);
   if (overlap) {
@@ -522,9 +512,9 @@ struct SegRun {
   svgp_model* m = nullptr;
   StripArgs a{};
   OverlapPlan op;
-  bool grad = false, ckpt = false;
+  bool grad = false;
   int split = 1;   // forward: phase 2 in a closing launch of its own, `split` workgroups per strip (small batches; kernels.hpp: seg_split)
-  int nP = 0, ck[3] = {0, 0, 0}, ck_prev = 0, rc = SVGP_OK;
+  int nP = 0, rc = SVGP_OK;
   size_t wb1 = 0;
   int64_t head = 0;
   std::function<int()>* pre = nullptr;   // work for the second stream ahead of the pre-generation (the gradient's chain-independent prep)
@@ -548,13 +538,6 @@ int seg_enqueue_row(SegRun& r, int row) {
   HIPC(ctx, hipStreamWaitEvent(s2, ctx->ev_row[I], 0));
   a.seg_lo = I; a.seg_hi = I + 1;
   a.seg_flags = (I > 0 ? kSegLoad : 0) | ((r.grad || r.split > 1 || I + 1 < nP) ? kSegStore : kSegPhase2);
-  a.seg_p2_lo = a.seg_p2_hi = 0;
-  if (r.ckpt) {
-    a.seg_flags |= kSegP2;
-    if (I + 1 == r.ck[0] || I + 1 == r.ck[1] || I + 1 == r.ck[2]) {
-      if (I + 1 > r.ck_prev) { a.seg_p2_lo = r.ck_prev; a.seg_p2_hi = I + 1; r.ck_prev = I + 1; }
-    }
-  }
   launch_strip_seg(dt, s2, a, r.op.nt, r.op.grid, r.op.nstrips, r.grad);
   KCHECK(ctx, "strip (segmented: panel)");
   if (I == 0) TREC(ctx, ctx->ev_ov[1], s2);
@@ -579,11 +562,10 @@ int seg_prepare_forward(svgp_ctx* ctx, svgp_model* m, const void* x, int64_t ldx
   const int64_t head = op.head_points < len ? op.head_points : len;
   // the segmented strips' scratch is per STRIP and lives beside the main launch's per-workgroup scratch (a segmented head runs
   // concurrently with the rest of its batch): its own buffer
-  // ... twice: the A strips, then the parked phase-2 accumulator tiles (checkpointed phase 2: strip.hip kSegP2)
-  const size_t wb1 = strip_work_bytes(m->dtype, m->Mp, op.nt, int(op.nstrips)), wb = 2 * wb1;
-  // Checkpointed phase 2: bitwise-tested, MEASURED, default OFF (profiles/round4/overlap.md): the factorisation slows by what the
-  // strips' extra work beside it occupies (16 384 / 1024 f64: prep 0.60 -> 0.78 ms, rest 0.38 -> 0.23: 1.046 -> 1.06-1.07 ms; M = 2048
-  // 1.94 -> 2.11).  The chain is latency-bound and every CU a strip launch holds delays it.  SVGP_OVERLAP_P2CKPT=1 (experiments build) enables it.
+  const size_t wb1 = strip_work_bytes(m->dtype, m->Mp, op.nt, int(op.nstrips)), wb = wb1;
+  // (A checkpointed phase 2 beside the factorisation - bitwise-tested, measured in round 4, profiles/round4/overlap.md: the factorisation
+  // slows by what the strips' extra work beside it occupies, 16 384 / 1024 f64 1.046 -> 1.06-1.07 ms, M = 2048 1.94 -> 2.11 - left the
+  // tree in round 6.)
   if (wb > ctx->work_seg_bytes) {
     if (ctx->work_seg) (void)hipFree(ctx->work_seg);
     ctx->work_seg = nullptr;
@@ -601,17 +583,14 @@ int seg_prepare_forward(svgp_ctx* ctx, svgp_model* m, const void* x, int64_t ldx
     if (rc) return rc;
   }
   r.ctx = ctx; r.m = m; r.op = op; r.grad = false; r.nP = nP; r.wb1 = wb1; r.head = head;
-  r.ckpt = ctx->kn.overlap_p2ckpt && nP >= 4;   // experiments build only
-  r.ck[0] = nP / 2; r.ck[1] = (3 * nP) / 4; r.ck[2] = nP;   // phase-2 checkpoints: after panels ck[.] - 1
   // A small batch (fewer strips than workgroup slots; not a segmented head): phase 2 - one panel C_J after the other inside a strip's
   // workgroup - is latency-bound on the few CUs it reaches, and its panels are independent: a closing launch with S workgroups per strip
-  r.split = (r.ckpt || head < len) ? 1 : seg_split_factor(ctx, nP, op.nstrips);
+  r.split = (head < len) ? 1 : seg_split_factor(ctx, nP, op.nstrips);
   StripArgs& a = r.a;
   a.T = m->T; a.U = m->U; a.zs = m->zs; a.mp = m->mp; a.x = x; a.work = ctx->work_seg; a.counter = ctx->counter2;
   a.mom_mu = ctx->mom; a.mom_var = ctx->mom + ctx->mom_cap;
   a.ldx = ldx; a.off = off; a.len = head; a.Mp = m->Mp; a.M = m->M; a.kp = kparams(m); a.mean_const = m->desc.mean_const;
   a.seg_state = ctx->seg_state;
-  a.seg_cacc = static_cast<char*>(ctx->work_seg) + wb1;
   return SVGP_OK;
 }
 
@@ -628,7 +607,6 @@ int seg_finish_forward(svgp_ctx* ctx, svgp_model* m, const void* x, int64_t ldx,
     if (rcs) return rcs;
     a.seg_lo = a.seg_hi = r.nP;
     a.seg_flags = kSegLoad | kSegPhase2;
-    a.seg_p2_lo = a.seg_p2_hi = 0;
     launch_strip_seg(m->dtype, s2, a, r.op.nt, int(r.op.nstrips) * r.split, r.op.nstrips, false);
     KCHECK(ctx, "strip (segmented: split phase 2)");
     ++launches;
@@ -941,6 +919,8 @@ int32_t svgp_ctx_destroy(svgp_ctx* c) {
   if (c->comm) (void)svgp_ctx_detach_comm(c);
   if (c->d_res) (void)hipFree(c->d_res);
   if (c->d_coll) (void)hipFree(c->d_coll);
+  if (c->h_open) (void)hipHostFree(c->h_open);
+  if (c->ev_open) (void)hipEventDestroy(c->ev_open);
   if (c->counter) (void)hipFree(c->counter);
   if (c->counter2) (void)hipFree(c->counter2);
   if (c->work2) (void)hipFree(c->work2);
@@ -1396,7 +1376,7 @@ int grad_workspace(svgp_ctx* ctx, svgp_model* m, int64_t len, GradWs** out) {
       {&w->W2, mm}, {&w->Rcm, mm}, {&w->G1p, mm}, {&w->alpha, size_t(Mp) * es}, {(void**)&w->avec, size_t(Mp) * 8},
       {(void**)&w->gemv_part, size_t(Mp / 128) * size_t(Mp) * 8},
       {&w->zero_blk, w->zero_b},
-      {(void**)&w->partial5, size_t(w->part5_strips) * 5 * 8}, {(void**)&w->apart, size_t(w->part5_strips) * size_t(Mp) * 8}, {(void**)&w->invl_d, size_t(m->d) * 8},
+      {(void**)&w->partial5, size_t(w->part5_strips) * 5 * 8}, {(void**)&w->invl_d, size_t(m->d) * 8},
       {(void**)&w->kred, (size_t(2 + dreg) * size_t(Mp) + size_t(1 + dreg)) * 8}};
   for (auto& r : req) {
     if (hipMalloc(r.p, r.b) != hipSuccess) {
@@ -1616,28 +1596,22 @@ int grad_enqueue_impl(svgp_ctx* ctx, svgp_model* m, const svgp_data* data, int64
     HIPC(ctx, hipMemcpyAsync(ctx->ext_g, gc.ext_gmu, size_t(len) * 8, hipMemcpyHostToDevice, s));
     HIPC(ctx, hipMemcpyAsync(ctx->ext_g + ctx->ext_cap, gc.ext_gv, size_t(len) * 8, hipMemcpyHostToDevice, s));
   }
-  // Who evaluates the likelihood gradients (strip.hip: kPgPost): round 4 - a small kernel behind the strips, for both likelihood
-  // routes; SVGP_GRAD_POST=0 keeps the round-3 in-kernel forms (A/B).  In-kernel fp32 builds also form A g_mu per strip (`apart`).
-  const bool post = gop.on || ctx->kn.grad_post;   // always in the product build; the segmented strips exist in the post form only
-  // A g_mu (the data part of m_bar): in-kernel fp32 (experiments build, SVGP_GRAD_POST=0) - per strip inside the strip kernel;
-  // otherwise kgrad, which evaluates the kernel anyway, sums Kuf g_mu and the tail applies Lk^-1 (one gemv with the explicit
-  // inverse): A is then read by the SYRK only (round 3, f64: 0.32 -> 0.2 ms per 65 536-point chunk at M = 1024).
+  // The likelihood gradients come from point_grad_kernel behind the strips (both likelihood routes); A g_mu (the data part of m_bar): the
+  // kernel-gradient reductions, which evaluate the kernel anyway, sum Kuf g_mu and the tail applies Lk^-1 (one gemv with the explicit
+  // inverse), so A is read by the SYRK only (round 3, f64: 0.32 -> 0.2 ms per 65 536-point chunk at M = 1024).
   // the SYRK's weights 2 g_v are uniform over the points for the built-in Gaussian likelihood (grad.hip: UW) unless a variance was
   // negative and clamped (then that point's g_v differs... it does not: dE/dv = -1 / (2 sigma^2) whatever v) - so: Gaussian, built in
   const bool uniform_w = m->desc.likelihood == SVGP_LIK_GAUSSIAN && !gc.ext_gmu && m->gh_n == 0 && ctx->kn.syrk_uniform;   // (knob: experiments build)
-  const bool a_in_strips = (dt == SVGP_F32) && !post;
-  const bool a_from_k = !a_in_strips;
   // the strips' arguments for the chunk [c0, c0 + clen) (scratch / moment pointers: read after the ensure_scratch of the caller)
   auto strip_args = [&](int64_t c0, int64_t clen, LikParams& lpc) -> StripArgs {
     StripArgs a{};
     a.T = m->T; a.U = m->U; a.zs = m->zs; a.mp = m->mp; a.x = data->x; a.work = ctx->work; a.counter = ctx->counter;
     a.At_out = w->At; a.ldx = data->ldx; a.off = off + c0; a.len = clen; a.Mp = Mp; a.M = M; a.kp = kp;
     a.mean_const = m->desc.mean_const;
-    a.mom_mu = ctx->mom; a.mom_var = ctx->mom + ctx->mom_cap;   // post: the strips' (mu, v), read by launch_point_grads
-    a.R = w->Rcm; a.alpha = w->alpha; a.Pt_out = w->Pt; a.gmu_out = w->gmu; a.gv_out = w->gv; a.y = data->y;
+    a.mom_mu = ctx->mom; a.mom_var = ctx->mom + ctx->mom_cap;   // the strips' (mu, v), read by launch_point_grads
+    a.R = w->Rcm; a.alpha = w->alpha; a.Pt_out = w->Pt;
     lpc = lp;
-    if (gc.ext_gmu) { lpc.lik = kLikExternal; lpc.gh_x = ctx->ext_g + c0; lpc.gh_w = ctx->ext_g + ctx->ext_cap + c0; a.y = nullptr; }
-    a.part5 = w->partial5; a.apart = a_in_strips ? w->apart : nullptr; a.lp = lpc; a.scale = scale; a.n_global_dev = n_global_dev; a.num_data = gc.num_data;
+    if (gc.ext_gmu) { lpc.lik = kLikExternal; lpc.gh_x = ctx->ext_g + c0; lpc.gh_w = ctx->ext_g + ctx->ext_cap + c0; }   // (launch_point_grads' arguments)
     return a;
   };
   // The M-sized work of the adjoint that does NOT depend on the factorisation: the cleared accumulators, the inverse lengthscales for
@@ -1716,10 +1690,10 @@ int grad_enqueue_impl(svgp_ctx* ctx, svgp_model* m, const svgp_data* data, int64
   }
   rc = ensure_scratch(ctx, wb_max, size_t(nc));
   if (rc) return rc;
-  // chunk pipeline (ensure_pipe): needs the post form of the point gradients (the in-kernel forms write per-strip partials the lanes do not hold)
+  // chunk pipeline (ensure_pipe; experiments build)
   static const int kg_overlap = exp_int("SVGP_KGRAD_OVERLAP", 0);   // experiments build
   const PipeCfg pc = pipe_cfg(ctx);
-  const bool pipe_any = !gop.on && post && !kg_overlap && nchunks >= 2 && pc.lanes >= 2;
+  const bool pipe_any = !gop.on && !kg_overlap && nchunks >= 2 && pc.lanes >= 2;
   const bool pipe = pipe_any && ctx->kn.pipe_mode != 2;   // mode 1: strips(k + 1) on a pipeline stream beside the consumers of chunk k
   const bool trail = pipe_any && ctx->kn.pipe_mode == 2;  // mode 2: everything on the main stream but kgrad(k), which trails on a pipeline stream beside SYRK(k) and strips(k + 1)
   ctx->pipelined = pipe_any;
@@ -1752,7 +1726,7 @@ int grad_enqueue_impl(svgp_ctx* ctx, svgp_model* m, const svgp_data* data, int64
     StripArgs a = gop.on ? gseg.a : strip_args(c0, clen, lpc);
     if (gop.on) lpc = lpc_seg;
     if (!gop.on) {
-      a.At_out = L.At; a.Pt_out = L.Pt; a.gmu_out = L.gmu; a.gv_out = L.gv; a.part5 = L.partial5;
+      a.At_out = L.At; a.Pt_out = L.Pt;
       if (pipe && pq == 1) { a.work = ctx->pwork; a.counter = ctx->pcounter; a.mom_mu = ctx->pmom; a.mom_var = ctx->pmom + ctx->pmom_cap; }
     }
     if (gop.on) {   // (single chunk) the segments are on the second stream already; the closing launch (phase 2 + 3) waits for R and alpha,
@@ -1781,15 +1755,12 @@ int grad_enqueue_impl(svgp_ctx* ctx, svgp_model* m, const svgp_data* data, int64
       HIPC(ctx, hipStreamWaitEvent(s, ctx->ev_join, 0));
     } else {
       HIPC(ctx, hipMemsetAsync(a.counter, 0, sizeof(unsigned), ss));
-      launch_strip_grad(dt, ss, a, nt, grid, nstrips, post);
+      launch_strip_grad(dt, ss, a, nt, grid, nstrips);
       KCHECK(ctx, "strip (value and gradient)");
     }
-    int n5 = int(nstrips);   // rows of partial5: per strip (in-kernel forms) or per 256-point block (post)
-    if (post) {
-      launch_point_grads(dt, ss, lpc, a.mom_mu, a.mom_var, a.y, off + c0, clen, scale, n_global_dev, gc.num_data, L.gmu, L.gv, L.partial5);
-      KCHECK(ctx, "point gradients");
-      n5 = point_grad_blocks(clen);
-    }
+    launch_point_grads(dt, ss, lpc, a.mom_mu, a.mom_var, gc.ext_gmu ? nullptr : data->y, off + c0, clen, scale, n_global_dev, gc.num_data, L.gmu, L.gv, L.partial5);
+    KCHECK(ctx, "point gradients");
+    const int n5 = point_grad_blocks(clen);   // rows of partial5: one per 256-point block
     if (pipe) {   // the consumers of this chunk: on the main stream, behind the chunk's strips
       HIPC(ctx, hipEventRecord(L.ev_strips, ss));
       HIPC(ctx, hipStreamWaitEvent(s, L.ev_strips, 0));
@@ -1811,9 +1782,8 @@ int grad_enqueue_impl(svgp_ctx* ctx, svgp_model* m, const svgp_data* data, int64
       HIPC(ctx, hipStreamWaitEvent(sk, ctx->ev_fork, 0));
     }
     int64_t ksl = ((clen + w->ns_uf - 1) / w->ns_uf + 127) / 128 * 128;
-    if (a_in_strips) launch_apart_reduce(sk, w->apart, int(nstrips), Mp, w->rp_uf + Mp);   // slot 1 of slice 0 of rp_uf
     launch_kgrad(dt, sk, kp, m->zs, Mp, data->x, data->ldx, off + c0, 0, clen, clen, L.Pt, L.gmu, L.gv, w->alpha, ksl, w->ns_uf,
-                 w->rp_uf, w->sp_uf, a_from_k ? 1 : 0);
+                 w->rp_uf, w->sp_uf, 1);
     KCHECK(ctx, "kgrad uf");
     if (kg_overlap) HIPC(ctx, hipEventRecord(ctx->ev_join, sk));
     if (trail) HIPC(ctx, hipEventRecord(L.ev_done, sk));
@@ -1843,8 +1813,8 @@ int grad_enqueue_impl(svgp_ctx* ctx, svgp_model* m, const svgp_data* data, int64
   gemm_mm(ctx, w, dt, s, w->W2, m->U, Mp, w->G1p, kMmYLow);   // (W B)[r][c] = sum_i W[i][r] B[i][c]; B[i][c] = 0 for i < c
   gemm_mm(ctx, w, dt, s, w->Rcm, w->W2, Mp, w->G2);           // (R W)[r][c] = sum_i R[r][i] W[i][c]
   launch_avec(s, w->rp_uf, w->ns_uf, int64_t(2 + dreg) * Mp, Mp, w->avec);
-  if (a_from_k)   // avec holds Kuf g_mu: A g_mu = Lk^-1 (Kuf g_mu)
-    launch_linv_t_gemv(dt, s, w->LinvCM, w->avec, Mp, w->avec, w->gemv_part, 1, 1);   // avec is fp64 in both builds
+  // avec holds Kuf g_mu: A g_mu = Lk^-1 (Kuf g_mu)
+  launch_linv_t_gemv(dt, s, w->LinvCM, w->avec, Mp, w->avec, w->gemv_part, 1, 1);   // avec is fp64 in both builds
   launch_finish_mm2(dt, s, w->G1p, w->G2, w->alpha, w->avec, Mp, M, centered ? m->B : m->Lq_raw, centered ? Mp : M, klw, w->Lqbar,
                     centered ? w->BbarRM : nullptr, w->LbarRM);
   KCHECK(ctx, "Lq_bar / Lk_bar");
@@ -1883,54 +1853,51 @@ int grad_enqueue_impl(svgp_ctx* ctx, svgp_model* m, const svgp_data* data, int64
   return SVGP_OK;
 }
 
-// Opening all-reduce of a collective value-and-gradient call: the global batch size, summed over the ranks ON THE DEVICE (the
-// strips' phase 3 reads num_data / n_global there).  Asynchronous since round 3: the two values travel as kernel arguments,
-// the 16-byte ncclAllReduce is enqueued behind them, nothing is read back - round 2 synchronised the host twice here to learn
-// of failed peers before enqueueing, which every 5 ms C5 step paid for.  A peer that cannot evaluate now joins BOTH
-// collectives with zero buffers and the failure flag (grad_fail_collective), so the others find out in the closing
-// all-reduce (sums[7]) instead.
-int grad_handshake(svgp_ctx* ctx, GradCall& gc, int64_t len) {
+// Opening all-reduce of a collective value-and-gradient call: {global batch size, failure flag}, summed over the ranks ON THE DEVICE
+// (the strips' phase 3 reads num_data / n_global there).  Asynchronous since round 3: the two values travel as kernel arguments, the
+// 16-byte ncclAllReduce is enqueued behind them.  Round 6: it is the ONE collective of the call whose size does not
+// depend on the model, so EVERY rank enters it - also one that cannot evaluate at all (NULL model, bad arguments, no memory for the
+// gradient workspace): that rank sends {0, 1}, returns its own error and joins nothing else.  The reduced flag comes back through a
+// pinned host word behind an event (grad_peers_failed); a healthy rank reads it after it has enqueued its backward pass - by then the
+// 16 bytes have long arrived, so the wait costs nothing - and, if any peer failed, SKIPS the closing gradient all-reduce and returns
+// SVGP_RCCL_ERROR.  No rank is left inside a collective a peer will never enter, and nothing is aborted.  (Rounds 2-5: the failing rank
+// had to match the closing all-reduce with M^2-sized zeros, and without a model - the element counts unknown - it aborted its
+// communicator, which does not wake the peers: a documented hang.)
+int grad_handshake(svgp_ctx* ctx, GradCall& gc, int64_t len, bool failed) {
   if (hipSetDevice(ctx->device) != hipSuccess) return fail(ctx, SVGP_HIP_ERROR, "hipSetDevice failed");
-  launch_set2_f64(ctx->stream, ctx->d_coll, double(len), 0.0);
+  if (!ctx->h_open && hipHostMalloc(reinterpret_cast<void**>(&ctx->h_open), 64, hipHostMallocDefault) != hipSuccess) {
+    ctx->h_open = nullptr;
+    return fail(ctx, SVGP_OOM, "hipHostMalloc failed for the opening all-reduce's flag");
+  }
+  if (!ctx->ev_open && hipEventCreateWithFlags(&ctx->ev_open, hipEventDisableTiming) != hipSuccess) {
+    ctx->ev_open = nullptr;
+    return fail(ctx, SVGP_HIP_ERROR, "hipEventCreate failed");
+  }
+  launch_set2_f64(ctx->stream, ctx->d_coll, failed ? 0.0 : double(len), failed ? 1.0 : 0.0);
   if (hipGetLastError() != hipSuccess) return fail(ctx, SVGP_HIP_ERROR, "launch failed in the opening all-reduce");
   const int rc = comm_allreduce(ctx, ctx->d_coll, 2, SVGP_F64);
   if (rc != SVGP_OK) return rc;
+  *ctx->h_open = -1.0;
+  if (hipMemcpyAsync(ctx->h_open, ctx->d_coll + 1, sizeof(double), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+      hipEventRecord(ctx->ev_open, ctx->stream) != hipSuccess)
+    return fail(ctx, SVGP_HIP_ERROR, "read-back of the opening all-reduce's flag failed");
   gc.n_global_dev = ctx->d_coll;
   return SVGP_OK;
 }
+// number of ranks that entered the opening all-reduce with the failure flag (blocks until that all-reduce has completed); < 0: unknown
+double grad_peers_failed(svgp_ctx* ctx) {
+  if (!ctx->ev_open || hipEventSynchronize(ctx->ev_open) != hipSuccess) return -1.0;
+  return *ctx->h_open;
+}
 
-// A rank of a collective svgp_elbo_grad / svgp_elbo_grad_ext that failed BEFORE anything could be enqueued (argument checks,
-// workspace allocation): it still has to match its peers' two collectives or they wait for it forever.  With a valid model
-// the element counts are known (they depend on M and d only, identical on every rank), so it joins with zero gradient
-// blocks and the failure flag set (its peers return SVGP_RCCL_ERROR).  Without a model, or if even these M^2-sized zeros
-// cannot be allocated, the communicator is aborted: that case is FATAL for the job (ncclCommAbort on one rank does not
-// wake the others; include/svgp_mi355x.h says so).
-int grad_fail_collective(svgp_ctx* ctx, const svgp_model* m, int pre_rc) {
+// A rank of a collective svgp_elbo_grad / svgp_elbo_grad_ext that failed BEFORE anything could be enqueued (argument checks, NULL model,
+// workspace allocation): it enters the opening all-reduce with the failure flag - its peers then skip the closing one and return
+// SVGP_RCCL_ERROR - and returns its own error.  Only if even that 16-byte collective cannot be issued is the communicator aborted.
+int grad_fail_collective(svgp_ctx* ctx, int pre_rc) {
   const std::string keep = ctx->err;
-  auto give_up = [&]() {
-    comm_abort(ctx);
-    ctx->err = keep;
-    return pre_rc;
-  };
-  if (!m || m->M < 1 || m->d < 1 || hipSetDevice(ctx->device) != hipSuccess) return give_up();
-  const size_t es = m->es, M = size_t(m->M), nz = M * size_t(m->d), nsum = size_t(8 + 1 + grad_dreg(m->d));
-  const size_t ncoll = nz + M + M * (M + 1) / 2;   // {z_bar | m_bar | packed tril(Lq_bar)}: exactly grad_collective's count
-  DevBuf blocks, sums;
-  if (blocks.alloc(ncoll * es) != hipSuccess || sums.alloc(nsum * 8) != hipSuccess) return give_up();
-  hipStream_t s = ctx->stream;
-  if (hipMemsetAsync(blocks.p, 0, ncoll * es, s) != hipSuccess || hipMemsetAsync(sums.p, 0, nsum * 8, s) != hipSuccess)
-    return give_up();
-  launch_set2_f64(s, ctx->d_coll, 0.0, 1.0);
-  launch_set_f64(s, static_cast<double*>(sums.p) + 7, 1.0);
-  int rc = comm_allreduce(ctx, ctx->d_coll, 2, SVGP_F64);
-  if (rc == SVGP_OK) rc = comm_group_start(ctx);
-  if (rc == SVGP_OK) {
-    rc = comm_allreduce(ctx, blocks.p, ncoll, m->dtype);   // the same counts as grad_collective
-    if (rc == SVGP_OK) rc = comm_allreduce(ctx, sums.p, nsum, SVGP_F64);
-    const int rce = comm_group_end(ctx);
-    if (rc == SVGP_OK) rc = rce;
-  }
-  if (rc != SVGP_OK || hipStreamSynchronize(s) != hipSuccess) return give_up();   // the buffers die with this scope
+  GradCall gc;
+  if (grad_handshake(ctx, gc, 0, true) != SVGP_OK) comm_abort(ctx);
+  else (void)hipStreamSynchronize(ctx->stream);
   ctx->err = keep;
   return pre_rc;
 }
@@ -2096,15 +2063,24 @@ int elbo_grad_impl(svgp_ctx* ctx, svgp_model* m, const svgp_data* data, int64_t 
   if (rc == SVGP_OK && (!(scale > 0.0) || !(klw >= 0.0))) rc = fail(ctx, SVGP_INVALID_ARG, "scale must be positive and kl_weight non-negative");
   if (rc == SVGP_OK && hipSetDevice(ctx->device) != hipSuccess) rc = fail(ctx, SVGP_HIP_ERROR, "hipSetDevice failed");
   if (rc == SVGP_OK) rc = grad_workspace(ctx, m, len, &gc.w);
-  if (rc != SVGP_OK) return (ctx && gc.collective) ? grad_fail_collective(ctx, m, rc) : rc;
+  if (rc != SVGP_OK) return (ctx && gc.collective) ? grad_fail_collective(ctx, rc) : rc;
   if (gc.collective) {
-    rc = grad_handshake(ctx, gc, len);
+    rc = grad_handshake(ctx, gc, len, false);
     if (rc != SVGP_OK) {   // the opening all-reduce itself could not be issued: nothing sane can follow on this communicator
       comm_abort(ctx);
       return rc;
     }
   }
   rc = grad_enqueue(ctx, m, data, off, len, gc);
+  if (gc.collective) {
+    const double nfail = grad_peers_failed(ctx);
+    if (nfail != 0.0) {   // a peer failed before its backward pass (or the flag could not be read): it will not enter the closing all-reduce
+      (void)hipStreamSynchronize(ctx->stream);
+      if (ctx->overlapped && ctx->stream2) (void)hipStreamSynchronize(ctx->stream2);
+      if (nfail < 0.0) { comm_abort(ctx); return rc != SVGP_OK ? rc : fail(ctx, SVGP_RCCL_ERROR, "the opening all-reduce of svgp_elbo_grad did not complete"); }
+      return rc != SVGP_OK ? rc : fail(ctx, SVGP_RCCL_ERROR, "a peer rank failed before its backward pass (opening all-reduce of svgp_elbo_grad): the gradient all-reduce was skipped on every rank");
+    }
+  }
   rc = grad_collective(ctx, m, gc, rc);
   if (rc) return rc;
   return grad_finish(ctx, m, gc, elbo_out, terms_out, g);
@@ -2181,7 +2157,7 @@ extern "C" int32_t svgp_elbo_grad_ext(svgp_ctx* ctx, svgp_model* m, const svgp_d
   if (!ctx) return SVGP_INVALID_ARG;
   if (!g_mu || !g_v) {
     const int rc = fail(ctx, SVGP_INVALID_ARG, "null point gradients");
-    return ctx->comm ? grad_fail_collective(ctx, m, rc) : rc;   // keep the peers' collectives matched: they return SVGP_RCCL_ERROR
+    return ctx->comm ? grad_fail_collective(ctx, rc) : rc;   // the peers learn it from the opening all-reduce: they return SVGP_RCCL_ERROR
   }
   const double scale = len >= 1 ? (num_data > 0 ? num_data : double(len)) / double(len) : 1.0;
   return elbo_grad_impl(ctx, m, data, off, len, scale, 1.0, num_data, true, elbo_out, terms_out, g, g_mu, g_v, sum_e);

@@ -58,6 +58,8 @@ struct svgp_ctx {
   void* comm = nullptr;        // ncclComm_t
   int world = 1, rank = 0;
   bool comm_owned_by_group = false;
+  double* h_open = nullptr;    // pinned host word: the reduced failure flag of svgp_elbo_grad's opening all-reduce (api.hip: grad_handshake)
+  hipEvent_t ev_open = nullptr;   // ... recorded behind its copy
   double* d_coll = nullptr;    // [8] the all-reduced vector {sum E, n_points, n_neg_var, chol flag, failure flag, ...}
 };
 
@@ -79,7 +81,7 @@ struct GradWs {
   void* zero_blk = nullptr;
   size_t zero_b = 0;
   double *rp_uf = nullptr, *sp_uf = nullptr, *rp_uu = nullptr, *sp_uu = nullptr, *partial5 = nullptr, *sums = nullptr,
-         *invl_d = nullptr, *scal_out = nullptr, *avec = nullptr, *apart = nullptr, *kred = nullptr, *gemv_part = nullptr;
+         *invl_d = nullptr, *scal_out = nullptr, *avec = nullptr, *kred = nullptr, *gemv_part = nullptr;
   int64_t part5_strips = 0;
   size_t rp_uf_b = 0, sp_uf_b = 0, rp_uu_b = 0, sp_uu_b = 0, g_b = 0;
   // chunk pipeline: buffer sets ("lanes") of the per-chunk arrays; lane 0 is {At, Pt, gmu, gv, partial5} above, the others are

@@ -7,6 +7,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <type_traits>
+
+#include "diag.hpp"
 #include <stdint.h>
 
 #include <mutex>
@@ -220,10 +222,10 @@ struct TileGemm {
     return r;
   }
   static __device__ __forceinline__ void load_p(PRegs& r, const T* __restrict__ src, const POff& off) {
-#if defined(SVGP_ABLATE) && (SVGP_ABLATE & 1)
-    (void)src; (void)off; asm volatile("" : "+v"(r.v[0]));  // diagnostic build: skip the P-tile loads
-    return;
-#endif
+    if constexpr (diag::ablate<1>) {   // diagnostic build: skip the P-tile loads
+      asm volatile("" : "+v"(r.v[0]));
+      return;
+    }
     const char* base = reinterpret_cast<const char*>(src);
 #pragma unroll
     for (int p = 0; p < P_PASSES; ++p) r.v[p] = *reinterpret_cast<const V*>(base + off.o[p]);
@@ -272,19 +274,16 @@ struct TileGemm {
 #endif
   }
   static __device__ __forceinline__ void dma_p(const T* __restrict__ src, const DOff& off, T* __restrict__ Ps) {
-#if defined(SVGP_ABLATE) && (SVGP_ABLATE & 1)
-    (void)src; (void)off; (void)Ps;
-    return;
-#endif
+    if constexpr (diag::ablate<1>) return;
     const int wv = __builtin_amdgcn_readfirstlane(int(threadIdx.x >> 6));
 #pragma unroll
     for (int q = 0; q < D_ROWS; ++q) glds16(src, off.o[q], Ps + (wv + q * NW) * PLD);
   }
   static __device__ __forceinline__ void load_q(QRegs& r, const T* __restrict__ src, const QOff& off) {
-#if defined(SVGP_ABLATE) && (SVGP_ABLATE & 2)
-    (void)src; (void)off; asm volatile("" : "+v"(r.v[0]));  // diagnostic build: skip the Q-tile loads
-    return;
-#endif
+    if constexpr (diag::ablate<2>) {   // diagnostic build: skip the Q-tile loads
+      asm volatile("" : "+v"(r.v[0]));
+      return;
+    }
     const char* base = reinterpret_cast<const char*>(src);
     if (Q_PARTIAL && int(threadIdx.x) >= BK * Q_TPR) return;
 #pragma unroll
@@ -567,14 +566,14 @@ struct TileGemm {
   static __device__ __forceinline__ void dma_tile(const T* __restrict__ psrc, const T* __restrict__ qsrc, const AOff& off,
                                                   T* __restrict__ Pb, T* __restrict__ Qb) {
     const int wv = __builtin_amdgcn_readfirstlane(int(threadIdx.x >> 6));
-#if !(defined(SVGP_ABLATE) && (SVGP_ABLATE & 1))   // diagnostic builds: bit 1 no P-tile DMA, bit 2 no Q-tile DMA (timing only)
+    if constexpr (!diag::ablate<1>) {   // (diagnostic builds: bit 1 no P-tile DMA, bit 2 no Q-tile DMA - timing only)
 #pragma unroll
-    for (int q = 0; q < DP; ++q) glds16(psrc, off.p[q], Pb + (wv + q * NW) * (kPairP ? PPP : PLD));
-#endif
-#if !(defined(SVGP_ABLATE) && (SVGP_ABLATE & 2))
+      for (int q = 0; q < DP; ++q) glds16(psrc, off.p[q], Pb + (wv + q * NW) * (kPairP ? PPP : PLD));
+    }
+    if constexpr (!diag::ablate<2>) {
 #pragma unroll
-    for (int q = 0; q < DQ; ++q) glds16(qsrc, off.q[q], Qb + (wv + q * NW) * QPP);
-#endif
+      for (int q = 0; q < DQ; ++q) glds16(qsrc, off.q[q], Qb + (wv + q * NW) * QPP);
+    }
   }
   static __device__ __forceinline__ void dma_w(const T* __restrict__ wsrc, T* __restrict__ Wb) {
     const uint32_t l = uint32_t(uintptr_t((__attribute__((address_space(3))) T*)(Wb)));

@@ -48,21 +48,6 @@ __global__ void __launch_bounds__(320) sum5_kernel(const double* __restrict__ pa
   if (lane == 0) out[q] += s;
 }
 
-// out[i] += sum over strips of apart[strip][i]: thread (row, group g of 4) sums strips g, g + 4, ... in order, the four groups
-// are combined in a fixed order
-__global__ void __launch_bounds__(k256) apart_reduce_kernel(const double* __restrict__ apart, int nstrips, int64_t Mp,
-                                                            double* __restrict__ out) {
-  __shared__ double sh[4][64];
-  const int rl = threadIdx.x & 63, g = threadIdx.x >> 6;
-  const int64_t i = int64_t(blockIdx.x) * 64 + rl;
-  double s = 0.0;
-  if (i < Mp)
-    for (int st = g; st < nstrips; st += 4) s += apart[int64_t(st) * Mp + i];
-  sh[g][rl] = s;
-  __syncthreads();
-  if (g == 0 && i < Mp) out[i] += ((sh[0][rl] + sh[1][rl]) + sh[2][rl]) + sh[3][rl];
-}
-
 // ---- M x M helpers of the fused gradient path (svgp_elbo_grad, api.hip: grad_enqueue) ---------------------------------
 // out (row-major, FULL symmetric) = sum over slices of the lower triangle of G (row-major; only entries c <= r are read, also
 // inside the diagonal tiles, so the result is exactly symmetric), minus `eye` on the diagonal.  One 32 x 32 tile of the lower
@@ -853,10 +838,6 @@ void launch_grad_status(hipStream_t s, double* sums, const int* chol_info, doubl
 
 void launch_sum5(hipStream_t s, const double* partial, int nblocks, double* sums) {
   hipLaunchKernelGGL(sum5_kernel, dim3(1), dim3(320), 0, s, partial, nblocks, sums);
-}
-
-void launch_apart_reduce(hipStream_t s, const double* apart, int nstrips, int64_t Mp, double* out) {
-  hipLaunchKernelGGL(apart_reduce_kernel, dim3((unsigned)((Mp + 63) / 64)), dim3(k256), 0, s, apart, nstrips, Mp, out);
 }
 
 void launch_sym_from_lower(int dtype, hipStream_t s, const void* G, int nslices, int64_t Mp, double eye, void* out) {

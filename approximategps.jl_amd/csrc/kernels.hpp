@@ -42,11 +42,8 @@ void launch_kuu(int dtype, hipStream_t s, const KernelParams& kp, const void* zs
 // row hook: called on the host right after row_events[p] is recorded (p = block row of T that has just become final), so that the
 // caller can enqueue the work that waits for that event BEHIND the record and still AHEAD of the device (api.hip: SegRun)
 struct RowHook { void (*fn)(void* user, int row) = nullptr; void* user = nullptr; };
-// look-ahead for a large Kuu (Mp / 128 > potrf_max_row_events(); prep.hip: potrf_t): a second stream for the bulk trailing updates and
-// eight events (four "TRSM of panel p done" + four "bulk update of panel p done", rotated) - nullable: then everything runs on `s`
-struct PotrfLookahead { hipStream_t s2 = nullptr; hipEvent_t* ev = nullptr; };
 void launch_potrf(int dtype, hipStream_t s, void* A, void* T, int64_t Mp, int* info, unsigned* sync, int num_cus, hipEvent_t* row_events = nullptr,
-                  const RowHook* hook = nullptr, const PotrfLookahead* la = nullptr);
+                  const RowHook* hook = nullptr);
 int potrf_max_row_events();
 // U = Lq' (upper triangular, Mp x Mp col-major, zero padding); also mp[i] = m[i] padded with zeros.
 void launch_pack_q(int dtype, hipStream_t s, const void* Lq, const void* m, int64_t M, int64_t Mp, void* U, void* mp);
@@ -69,7 +66,7 @@ void launch_shift_vec(int dtype, hipStream_t s, const void* m, double shift, int
 void launch_extract_lower(int dtype, hipStream_t s, const void* A, int64_t Mp, int64_t M, void* out);
 
 // ---- strip.hip -------------------------------------------------------------------------------
-enum : int { kSegPregen = 1, kSegPhase2 = 2, kSegLoad = 4, kSegStore = 8, kSegP2 = 16 };   // StripArgs::seg_flags
+enum : int { kSegPregen = 1, kSegPhase2 = 2, kSegLoad = 4, kSegStore = 8 };   // StripArgs::seg_flags
 struct StripArgs {
   const void* T;     // Mp x Mp col-major: block rows of inv(L_II) * [-L_I,<I | I]
   const void* U;     // Mp x Mp col-major: B' (upper triangular)
@@ -93,24 +90,12 @@ struct StripArgs {
   const void* R;        // Mp x Mp col-major: Lk^-T (Lq Lq' - I)
   const void* alpha;    // [Mp] Lk^-T m
   void* Pt_out;         // point-major [n][Mp]: the UNSCALED product R A (P = alpha g_mu' + 2 (R A) diag(g_v) is formed by kgrad)
-  void* gmu_out;        // [n] g_mu = scale dE/dmu (compute dtype), also read by kgrad
-  void* gv_out;         // [n] g_v
-  const void* y;        // observations of the batch (index off + i)
-  double* part5;        // [nstrips][5] per-strip {E, sum g_mu, sum g_v, dE/dsigma2, n_neg}
-  double* apart;        // [nstrips][Mp] per-strip A g_mu (the data part of m_bar), reduced over strips in a fixed order
-  LikParams lp;
-  double scale;               // num_data / n_batch ...
-  const double* n_global_dev; // ... or, data-parallel, num_data / *n_global_dev (0 -> 1)
-  double num_data;
+  // (the likelihood gradients g_mu, g_v and the per-block sums come from launch_point_grads, which reads mom_mu / mom_var)
   // ---- segmented forward strips (launch_strip_seg): one launch covers the phase-1 panels [seg_lo, seg_hi) of every strip ----
   int seg_flags;              // kSegPregen 1: generate the Kuf block first; kSegPhase2 2: phase 2 + moments after the panels;
                               // kSegLoad 4 / kSegStore 8: restore / save the threads' fp64 column sums in seg_state
   int seg_lo, seg_hi;
   double* seg_state;          // [nstrips][256][2 NJ]; `work` then holds ONE scratch strip PER STRIP (nstrips x Mp x NT)
-  // kSegP2 (forward): checkpointed phase 2 - this launch advances the accumulators of the panels J < seg_p2_hi over the k-blocks
-  // [max(J, seg_p2_lo), seg_p2_hi) and parks them in seg_cacc (nstrips x Mp x NT elements, register layout); seg_p2_hi == Mp / 128 closes
-  int seg_p2_lo, seg_p2_hi;
-  void* seg_cacc;
   // Split closing launch (segmented strips of a SMALL batch: fewer strips than workgroup slots).  The output panels of phase 3 (value and
   // gradient: dense) and of phase 2 (forward: C_J = sum_{I >= J} U[J, I] A_I) are independent, so the closing launch runs seg_split
   // workgroups per strip - workgroup (strip, part) = blockIdx (part * nstrips + strip) takes the panels [part nP / S, (part + 1) nP / S)
@@ -141,7 +126,7 @@ size_t strip_seg_state_doubles(int dtype, int nt);
 // unscaled), gmu_out, gv_out, part5.  `work` must hold TWO scratch strips per workgroup (2 x strip_work_bytes).
 // post = true (round 4): the strips leave their moments in mom_mu / mom_var (like launch_strip) and write no gmu / gv / part5 -
 // launch_point_grads, next on the stream, produces those from the moments.  post = false: the round-3 in-kernel forms.
-void launch_strip_grad(int dtype, hipStream_t s, const StripArgs& a, int nt, int grid, int64_t nstrips, bool post);
+void launch_strip_grad(int dtype, hipStream_t s, const StripArgs& a, int nt, int grid, int64_t nstrips);
 // marginals, expected log-likelihood and d E / d (mu, v) (x scale) of the points [off, off + len) of y from their moments: gmu_out /
 // gv_out (compute dtype, [len]) and part5[point_grad_blocks(len)][5] = per-block {E, sum g_mu, sum g_v, dE/dsigma2, n_neg}
 int point_grad_blocks(int64_t len);
@@ -202,8 +187,6 @@ void launch_kgrad(int dtype, hipStream_t s, const KernelParams& kp, const void* 
 // fused gradient path: sums of the per-strip partials, W = A diag(2 g_v) A' from its split-K lower tiles, (A g_mu), and the
 // assembly of Lq_bar / Lk_bar from G1 = 2 W Lq, G2 = 2 R W and the rank-one term alpha (A g_mu)'
 void launch_sum5(hipStream_t s, const double* partial, int nblocks, double* sums);
-// out[i] += sum over strips of apart[strip][i]  (fixed order)
-void launch_apart_reduce(hipStream_t s, const double* apart, int nstrips, int64_t Mp, double* out);
 void launch_sym_from_lower(int dtype, hipStream_t s, const void* G, int nslices, int64_t Mp, double eye, void* out);
 void launch_avec(hipStream_t s, const double* rp_uf, int ns, int64_t stride, int64_t Mp, double* avec);
 void launch_finish_mm2(int dtype, hipStream_t s, const void* G1, const void* G2, const void* alpha, const double* avec, int64_t Mp,

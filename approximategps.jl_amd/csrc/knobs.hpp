@@ -46,9 +46,7 @@ struct Knobs {
   int overlap_min_panels = 5;        // SVGP_OVERLAP_MIN_PANELS
   int overlap_head = 0;              // SVGP_OVERLAP_HEAD: segmented head of multi-round batches (measured: no gain)
   int overlap_head_min_panels = 4;   // SVGP_OVERLAP_HEAD_MIN_PANELS
-  int overlap_p2ckpt = 0;            // SVGP_OVERLAP_P2CKPT: checkpointed phase 2 (measured: slower)
   int overlap_dry = 0;               // SVGP_OVERLAP_DRY: enqueue the segments without the prep (timing experiments)
-  int grad_post = 1;                 // SVGP_GRAD_POST: 0 = the round-3 in-kernel likelihood gradients
   int syrk_uniform = 1;              // SVGP_SYRK_UNIFORM: 0 = the weighted SYRK for the Gaussian likelihood too
   int pipe_lanes = 1, pipe_streams = 1, pipe_prio = 0, pipe_mode = 1;   // SVGP_GRAD_PIPELINE / _PIPE_STREAMS / _PIPE_PRIO / _PIPE_MODE (round 5: measured, rejected)
 };
@@ -61,9 +59,7 @@ inline void read_knobs(Knobs& k) {
   k.overlap_min_panels = exp_int("SVGP_OVERLAP_MIN_PANELS", 5);
   k.overlap_head = exp_int("SVGP_OVERLAP_HEAD", 0) == 1;
   k.overlap_head_min_panels = exp_int("SVGP_OVERLAP_HEAD_MIN_PANELS", 4);
-  k.overlap_p2ckpt = exp_int("SVGP_OVERLAP_P2CKPT", 0) == 1;
   k.overlap_dry = exp_int("SVGP_OVERLAP_DRY", 0);
-  k.grad_post = exp_int("SVGP_GRAD_POST", 1) != 0;
   k.syrk_uniform = exp_int("SVGP_SYRK_UNIFORM", 1) != 0;
   k.pipe_lanes = exp_int("SVGP_GRAD_PIPELINE", 1);
   k.pipe_lanes = k.pipe_lanes < 2 ? 1 : (k.pipe_lanes > 4 ? 4 : k.pipe_lanes);

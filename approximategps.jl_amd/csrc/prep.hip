@@ -6,6 +6,7 @@
 //   U   = Lq'                           (SVA:183-184, B = Lq for NonCentered)
 //   KL scalars                          (SVA:364-373)
 // Everything is padded to Mp = ceil(M/128)*128 with an identity block so no kernel needs edge tiles.
+#define SVGP_DIAG_TU_PREP
 #include "device_common.hpp"
 #include "kernels.hpp"
 #include "knobs.hpp"
@@ -119,17 +120,7 @@ __device__ __forceinline__ float krsqrt(float d) {
   return r;
 }
 
-#ifdef SVGP_POTF2_STAMPS   // diagnostic build (tools/build_ablate.sh stamps): s_memtime at the phase boundaries of potf2
-__device__ unsigned long long g_potf2_stamps[128];
-#define SVGP_STAMP(i) do { if (threadIdx.x == 0) g_potf2_stamps[i] = clock64(); } while (0)
-#define SVGP_STAMPW(i) do { if (threadIdx.x == 64) g_potf2_stamps[i] = clock64(); } while (0)   // a worker wave
-extern "C" int svgp_debug_potf2_stamps(unsigned long long* out) {
-  return int(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_potf2_stamps), sizeof(g_potf2_stamps)));
-}
-#else
-#define SVGP_STAMP(i)
-#define SVGP_STAMPW(i)
-#endif
+// (s_memtime stamps of the diagnostic build: SVGP_STAMP / SVGP_STAMPW, diag.hpp)
 
 // wave 0's part of a block step: factor the 16x16 diagonal block at offset o (already updated) and invert it.
 // 16x16 Cholesky AND its inverse in registers, left-looking: lane l15 (every 16-lane row of the wave redundantly) owns row
@@ -617,7 +608,7 @@ __device__ __forceinline__ void tri_index(int b, int& i, int& j) {  // b -> (i >
 // One workgroup per CU (the block's LDS image), so potrf_t takes this form only where the launch fits the chip in one round anyway.
 template <typename T, int MODE, int NT, bool FUSE = false, bool P8 = false>
 __global__ void __launch_bounds__(P8 ? kThreads : k256, P8 ? 2 : ((FUSE && sizeof(T) == 8) ? 1 : 2)) chol_tile_kernel(T* __restrict__ A, T* __restrict__ Tm, int64_t ld, int p, int n,
-                                                            int* __restrict__ info, unsigned* __restrict__ sync, int kb = 1, int skip = 0) {
+                                                            int* __restrict__ info, unsigned* __restrict__ sync, int kb = 1) {
   using G = TileGemm<T, NT, 16, k256>;
   using QRegs = typename G::QRegs;
   constexpr int NB = kNB, NCH = NB / NT;
@@ -667,8 +658,8 @@ __global__ void __launch_bounds__(P8 ? kThreads : k256, P8 ? 2 : ((FUSE && sizeo
   } else {                       // A[i, j] -= L[i, p - kb + 1 .. p] L[j, p - kb + 1 .. p]'
     int ti, tj;
     tri_index(tile, ti, tj);
-    i = p + 1 + skip + ti;   // skip = 1 (look-ahead, potrf_t): the trailing matrix WITHOUT its first block column, which the chain's
-    j = p + 1 + skip + tj;   // MODE_COL launch updates by itself
+    i = p + 1 + ti;
+    j = p + 1 + tj;
     P = A + int64_t(j) * NB + int64_t(p - kb + 1) * NB * ld;
   }
   const int kcol = (MODE == MODE_SYRK) ? p - kb + 1 : p;   // first block column of the contraction
@@ -711,115 +702,6 @@ __global__ void __launch_bounds__(P8 ? kThreads : k256, P8 ? 2 : ((FUSE && sizeo
   }
 }
 
-// Round 4, one launch per panel of a small Kuu (the factorisation chain is what a minibatch step waits for).
-// Launch p of the chain =  trailing update of panel p  +  factorisation of block (q, q), q = p + 1  +  the TRSM of panel q  +  the
-// T panels of block row q.  The round-3 form needed two launches for this (update + factorisation; TRSM + T panels) and paid the
-// launch boundary between them (~8 us of the ~54 us a panel costs at M = 1024) for a dependency that is much narrower than "the whole
-// previous launch": the TRSM of rows [c NT, (c + 1) NT) of tile (i, q) reads exactly the rows the SAME workgroup has just updated, plus
-// inv(L_qq).  So every workgroup that updated a chunk of block column q keeps going: it waits for flag[q] (set by the workgroup that
-// factored block (q, q), the last arriver of tile 0's chunks as in the round-3 fused kernel) and runs its own rows' TRSM; q * NCH
-// further workgroups of the launch wait for the same flag and write the T panels.
-//   Residency: waiting workgroups hold a CU slot, so the launch must fit the chip at once - potrf_t checks (nt + q) NCH against the
-// slots (one workgroup per CU for f64: potf2's LDS image) and falls back to the two-launch form otherwise.  The only thing anybody
-// waits for is the factorisation, whose workgroup is one of blockIdx 0 .. NCH - 1 (dispatched first) and waits for nothing but those
-// NCH workgroups: no cycle.  A wait that outlasts 0.2 s (never seen; a guard against a wedged box, not a protocol step) gives up
-// and reports through info.  NOT ADOPTED (see potrf_t): correct and bitwise equal to the two-launch form, but no faster.
-// sync layout (unsigned words): [p] hand-over counter of tile (p + 1, p + 1)  |  [nP + q] flag: block (q, q) factored and stored.
-#ifdef SVGP_EXPERIMENTS
-template <typename T, int NT>
-__global__ void __launch_bounds__(k256, sizeof(T) == 8 ? 1 : 2) chol_chain_kernel(T* __restrict__ A, T* __restrict__ Tm, int64_t ld, int p, int n,
-                                                                                   int nP, int* __restrict__ info, unsigned* __restrict__ sync) {
-  using G = TileGemm<T, NT, 16, k256>;
-  using QRegs = typename G::QRegs;
-  constexpr int NB = kNB, NCH = NB / NT;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  T* smem = reinterpret_cast<T*>(smem_raw);
-  const int chunk = blockIdx.x % NCH, tile = blockIdx.x / NCH;
-  const int nt = n * (n + 1) / 2, q = p + 1;
-  unsigned* flag = sync + nP + q;
-  int ti = 0, tj = 0;
-  if (tile < nt) {   // ---- trailing update: A[i, j] -= L[i, p] L[j, p]' ----
-    tri_index(tile, ti, tj);
-    const int i = q + ti, j = q + tj;
-    typename G::Acc acc;
-    acc.zero();
-    const T* P = A + int64_t(j) * NB + int64_t(p) * NB * ld;
-    const T* Q = A + int64_t(i) * NB + int64_t(p) * NB * ld + chunk * NT;
-    const typename G::QOff qoff = G::q_offsets(ld);
-    auto qload = [&](int t, QRegs& r) { G::load_q(r, Q + int64_t(t) * 16 * ld, qoff); };
-    G::loop(acc, P, ld, NB / 16, qload, smem);
-    T* C = A + int64_t(i) * NB + int64_t(j) * NB * ld + chunk * NT;
-#pragma unroll
-    for (int a = 0; a < G::MI; ++a)
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-#pragma unroll
-        for (int b = 0; b < G::NJ; ++b) {
-          T* dst = C + G::acc_col(b) + int64_t(G::acc_row(a, r)) * ld;
-          *dst -= acc.v[a][b][r];
-        }
-    if (tj != 0) return;           // not a tile of block column q: nothing more to do here
-    if (ti == 0) {                 // tile (q, q): hand over to the factorisation as in chol_tile_kernel<FUSE>
-      __shared__ int is_last;
-      __threadfence();
-      __syncthreads();
-      if (threadIdx.x == 0) is_last = (__hip_atomic_fetch_add(&sync[p], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == unsigned(NCH - 1));
-      __syncthreads();
-      if (!is_last) return;
-      __threadfence();
-      potf2_body<T>(A + int64_t(q) * NB * (ld + 1), Tm + int64_t(q) * NB * (ld + 1), ld, info, q * NB, smem_raw);
-      __threadfence();             // release: L_qq and inv(L_qq) device-wide before the flag (also on the failure returns of potf2_body)
-      __syncthreads();
-      if (threadIdx.x == 0) __hip_atomic_store(flag, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-      return;
-    }
-  }
-  // ---- wait for block (q, q) ----
-  if (threadIdx.x == 0) {
-    const uint64_t t0 = wall_clock64();   // 100 MHz
-    // relaxed polls (an acquire here would invalidate caches a hundred times a microsecond across the chip); ONE acquire fence below
-    while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
-      __builtin_amdgcn_s_sleep(16);
-      if (wall_clock64() - t0 > 20000000ull) {
-        atomicCAS(info, 0, 0x7ffffffe);
-        break;
-      }
-    }
-  }
-  __syncthreads();
-  __threadfence();                 // acquire: the factorisation's stores (another CU, possibly another XCD) before the loads below
-  typename G::Acc acc;
-  acc.zero();
-  const T* P = Tm + int64_t(q) * NB * (ld + 1);   // inv(L_qq)
-  if (tile >= nt) {   // T[q, J] = -inv(L_qq) L[q, J]
-    const int J = tile - nt;
-    const T* Q = A + int64_t(q) * NB + (int64_t(J) * NB + chunk * NT) * ld;
-    auto qload = [&](int t, QRegs& r) { G::load_q_trans(r, Q + int64_t(t) * 16, ld); };
-    G::loop(acc, P, ld, NB / 16, qload, smem);
-    T* C = Tm + int64_t(q) * NB + (int64_t(J) * NB + chunk * NT) * ld;
-#pragma unroll
-    for (int a = 0; a < G::MI; ++a)
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-#pragma unroll
-        for (int b = 0; b < G::NJ; ++b) C[G::acc_row(a, r) + int64_t(G::acc_col(b)) * ld] = -acc.v[a][b][r];
-    return;
-  }
-  // L[i, q] = A[i, q] inv(L_qq)' on the rows this workgroup has just updated
-  const int i = q + ti;
-  T* C = A + int64_t(i) * NB + int64_t(q) * NB * ld + chunk * NT;
-  const typename G::QOff qoff = G::q_offsets(ld);
-  auto qload = [&](int t, QRegs& r) { G::load_q(r, C + int64_t(t) * 16 * ld, qoff); };
-  G::loop(acc, P, ld, NB / 16, qload, smem);
-#pragma unroll
-  for (int a = 0; a < G::MI; ++a)
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-#pragma unroll
-      for (int b = 0; b < G::NJ; ++b) C[G::acc_col(b) + int64_t(G::acc_row(a, r)) * ld] = acc.v[a][b][r];
-}
-#endif   // SVGP_EXPERIMENTS
-
 // The large-grid form of the trailing update (trailing matrices of >= 256 tiles fill the chip by themselves): whole
 // 128 x 128 tiles on 512-thread workgroups, A[i, j] -= L[i, p] L[j, p]' computed transposed so that stores run along columns
 // of A (half the operand traffic of the chunked form).  FUSE: workgroup 0 owns tile (p+1, p+1) and factors it right after its
@@ -827,7 +709,7 @@ __global__ void __launch_bounds__(k256, sizeof(T) == 8 ? 1 : 2) chol_chain_kerne
 // have not ended).
 template <typename T, bool FUSE>
 __global__ void __launch_bounds__(kThreads, 2) syrk128_kernel(T* __restrict__ A, T* __restrict__ Tm, int64_t ld, int p,
-                                                               int* __restrict__ info, int kb = 1, int skip = 0, const int* __restrict__ perm = nullptr) {
+                                                               int* __restrict__ info, int kb = 1) {
   using G = TileGemm<T, kNB, 16>;
   using QRegs = typename G::QRegs;
   constexpr int NB = kNB;
@@ -836,69 +718,13 @@ __global__ void __launch_bounds__(kThreads, 2) syrk128_kernel(T* __restrict__ A,
   typename G::Acc acc;
   acc.zero();
   int ti, tj;
-  if (perm) {   // XCD-aware tile order (potrf_t: xcd_tile_order): workgroup b -> tile perm[b] (row << 16 | column), -1: no tile
-    const int code = perm[blockIdx.x];
-    if (code < 0) return;
-    ti = code >> 16;
-    tj = code & 0xffff;
-  } else {
-    tri_index(blockIdx.x, ti, tj);
-  }
-  // (experiments build, timing probes of the big update - WRONG results: skip >> 8 = 1: no read-modify-write of C, 2: the k-loop twice,
-  //  3: the read-modify-write alone)
-  const int probe = kExperiments ? (skip >> 8) : 0;
-  skip &= 0xff;
-  const int i = p + 1 + skip + ti, j = p + 1 + skip + tj;   // skip = 1: the look-ahead's bulk update (potrf_t)
+  tri_index(blockIdx.x, ti, tj);
+  const int i = p + 1 + ti, j = p + 1 + tj;
   const T* P = A + int64_t(j) * NB + int64_t(p - kb + 1) * NB * ld;   // kb = 2: rank-256 update over block columns p - 1, p
   const T* Q = A + int64_t(i) * NB + int64_t(p - kb + 1) * NB * ld;
   const typename G::QOff qoff = G::q_offsets(ld);
   auto qload = [&](int t, QRegs& r) { G::load_q(r, Q + int64_t(t) * 16 * ld, qoff); };
-  if (probe != 3) G::loop(acc, P, ld, kb * (NB / 16), qload, smem);
-  if (probe == 2) {
-    __syncthreads();
-    G::loop(acc, P, ld, kb * (NB / 16), qload, smem);
-  }
-  T* C = A + int64_t(i) * NB + int64_t(j) * NB * ld;
-  if (probe != 1 || (ti == 0 && tj == 0)) {
-#pragma unroll
-    for (int a = 0; a < G::MI; ++a)
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-#pragma unroll
-        for (int b = 0; b < G::NJ; ++b) C[G::acc_col(b) + int64_t(G::acc_row(a, r)) * ld] -= acc.v[a][b][r];
-  }
-  if constexpr (FUSE) {
-    if (ti != 0 || tj != 0) return;   // the owner of tile (p+1, p+1) - workgroup 0 in either tile order - goes on to factor it
-    __threadfence();               // the tile this workgroup just wrote is re-read below (through L2: drop stale L1 lines)
-    __syncthreads();
-    potf2_body<T, kThreads / 64>(A + int64_t(p + 1) * NB * (ld + 1), Tm + int64_t(p + 1) * NB * (ld + 1), ld, info, (p + 1) * NB, smem_raw);
-  }
-}
-
-// The same update on the fully asynchronous three-buffer LDS-DMA loop of the strips (round 4; fp32, whose 128-column tiles take it
-// on 256 threads: a wave owns 64 x 64).  Why: the big launches sat at MFMA busy 0.37, and it is the OPERAND stream that bounds
-// them, not the read-modify-write of C - a rank-256 update (two-level blocking, same operand bytes per flop) bought nothing by
-// itself (M = 8192: 5.05 vs 4.92 ms).  The register-staged two-buffer loop waits for every operand tile at a __syncthreads(); here
-// a tile has two whole steps to land.  P and Q are both k-major views of the panel L[:, kcol..] (leading dimension ld): the Q
-// operand's 512-byte k-rows travel in pairs like the fp32 strips'.
-#ifdef SVGP_EXPERIMENTS
-template <typename T, bool FUSE>
-__global__ void __launch_bounds__(k256, 2) syrk128_async_kernel(T* __restrict__ A, T* __restrict__ Tm, int64_t ld, int p,
-                                                                 int* __restrict__ info, int kb) {
-  using G = TileGemm<T, kNB, 16, k256>;
-  static_assert(G::kAsync, "tile shape without an asynchronous loop");
-  constexpr int NB = kNB;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  T* smem = reinterpret_cast<T*>(smem_raw);
-  typename G::Acc acc;
-  acc.zero();
-  int ti, tj;
-  tri_index(blockIdx.x, ti, tj);
-  const int i = p + 1 + ti, j = p + 1 + tj;
-  const T* P = A + int64_t(j) * NB + int64_t(p - kb + 1) * NB * ld;
-  const T* Q = A + int64_t(i) * NB + int64_t(p - kb + 1) * NB * ld;
-  auto qsrc = [&](int t) { return Q + int64_t(t) * 16 * ld; };
-  G::template loop_tri_async<0>(acc, P, ld, kb * (NB / 16), qsrc, smem, ld);
+  G::loop(acc, P, ld, kb * (NB / 16), qload, smem);
   T* C = A + int64_t(i) * NB + int64_t(j) * NB * ld;
 #pragma unroll
   for (int a = 0; a < G::MI; ++a)
@@ -907,13 +733,12 @@ __global__ void __launch_bounds__(k256, 2) syrk128_async_kernel(T* __restrict__ 
 #pragma unroll
       for (int b = 0; b < G::NJ; ++b) C[G::acc_col(b) + int64_t(G::acc_row(a, r)) * ld] -= acc.v[a][b][r];
   if constexpr (FUSE) {
-    if (blockIdx.x != 0) return;
+    if (blockIdx.x != 0) return;   // the owner of tile (p+1, p+1) goes on to factor it
     __threadfence();               // the tile this workgroup just wrote is re-read below (through L2: drop stale L1 lines)
     __syncthreads();
-    potf2_body<T>(A + int64_t(p + 1) * NB * (ld + 1), Tm + int64_t(p + 1) * NB * (ld + 1), ld, info, (p + 1) * NB, smem_raw);
+    potf2_body<T, kThreads / 64>(A + int64_t(p + 1) * NB * (ld + 1), Tm + int64_t(p + 1) * NB * (ld + 1), ld, info, (p + 1) * NB, smem_raw);
   }
 }
-#endif   // SVGP_EXPERIMENTS
 
 // ------------------------------------------------------------------------------------------------
 template <typename T>
@@ -1152,65 +977,8 @@ void dbg(const char* name, hipStream_t s) {
   if (e != hipSuccess) leave_note(std::string("SVGP_DEBUG_SYNC: ") + name + ": " + hipGetErrorString(e));   // -> svgp_last_error
 }
 
-// XCD-aware tile order of the large trailing update (round 5 experiment, SVGP_SYRK_XCD=1 in the experiments build).  The dispatcher deals
-// workgroups round-robin over the 8 XCDs (b and b + 8 share one; each XCD has its own 4 MiB L2).  In row-major triangle order every XCD
-// works on every 8th tile of every row, so each XCD streams the WHOLE panel L[:, p] (4 MB at 63 block rows, fp32) through its L2 for
-// both operands.  Here the triangle is cut into 8 x 8 super-tiles (16 operand blocks = 1 MB for 64 tiles), the super-tiles are dealt to
-// the XCDs (largest first, to the least loaded), and workgroup b = 8 k + x takes the k-th tile of XCD x's list; lists are padded
-// with -1 to the longest.  The super-tile of tile (0, 0) - whose workgroup carries the next block factorisation - comes first in its list.
-struct XcdOrder { int grid = 0; int* dev = nullptr; };
-const XcdOrder& xcd_tile_order(int n) {
-  static std::mutex mu;
-  static std::map<std::pair<int, int>, XcdOrder> cache;
-  int dev = 0;
-  (void)hipGetDevice(&dev);
-  std::lock_guard<std::mutex> lk(mu);
-  auto it = cache.find({dev, n});
-  if (it != cache.end()) return it->second;
-  constexpr int S = 8, NX = 8;
-  const int G = (n + S - 1) / S;
-  struct Sup { int I, J, cnt; };
-  std::vector<Sup> sup;
-  for (int I = 0; I < G; ++I)
-    for (int J = 0; J <= I; ++J) {
-      int cnt = 0;
-      for (int ti = I * S; ti < std::min(n, (I + 1) * S); ++ti)
-        for (int tj = J * S; tj < std::min(n, (J + 1) * S); ++tj) cnt += (tj <= ti);
-      sup.push_back({I, J, cnt});
-    }
-  std::vector<int> order(sup.size());
-  for (size_t q = 0; q < order.size(); ++q) order[q] = int(q);
-  std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return sup[a].cnt > sup[b].cnt; });
-  std::vector<std::vector<int>> lists(NX);   // super-tile indices per XCD
-  std::vector<int> load(NX, 0);
-  for (int q : order) {
-    int x = 0;
-    for (int y = 1; y < NX; ++y) if (load[y] < load[x]) x = y;
-    if (sup[q].I == 0 && sup[q].J == 0) lists[x].insert(lists[x].begin(), q); else lists[x].push_back(q);
-    load[x] += sup[q].cnt;
-  }
-  const int L = *std::max_element(load.begin(), load.end());
-  std::vector<int> perm(size_t(NX) * L, -1);
-  for (int x = 0; x < NX; ++x) {
-    int k = 0;
-    for (int q : lists[x])
-      for (int ti = sup[q].I * S; ti < std::min(n, (sup[q].I + 1) * S); ++ti)
-        for (int tj = sup[q].J * S; tj < std::min(n, (sup[q].J + 1) * S); ++tj)
-          if (tj <= ti) perm[size_t(k++) * NX + x] = (ti << 16) | tj;
-  }
-  // workgroup 0 must own SOME tile; the fused kernel finds tile (0, 0) by its coordinates wherever it is dispatched
-  XcdOrder o;
-  o.grid = NX * L;
-  if (hipMalloc(&o.dev, perm.size() * sizeof(int)) != hipSuccess || hipMemcpy(o.dev, perm.data(), perm.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) {
-    o.dev = nullptr;
-    o.grid = 0;
-  }
-  return cache.emplace(std::make_pair(dev, n), o).first->second;
-}
-
 template <typename T>
-void potrf_t(hipStream_t s, T* A, T* Tm, int64_t Mp, int* info, unsigned* sync, hipEvent_t* row_events, const RowHook* hook,
-             const PotrfLookahead* la, int ncus) {
+void potrf_t(hipStream_t s, T* A, T* Tm, int64_t Mp, int* info, unsigned* sync, hipEvent_t* row_events, const RowHook* hook, int ncus) {
   using G = TileGemm<T, kNB, 16>;
   const int nP = int(Mp / kNB);
   constexpr size_t lds_potf2 = potf2_lds_bytes<T>();
@@ -1245,44 +1013,13 @@ void potrf_t(hipStream_t s, T* A, T* Tm, int64_t Mp, int* info, unsigned* sync, 
   // Per outer panel (block columns a, b = a + 1):  TRSM(a);  update of block column b alone + factorisation of (b, b) in the same
   // launch;  TRSM(b);  ONE rank-256 update of everything right of b (+ the factorisation of the next diagonal block in it).
   // The trailing matrix is read and written once per 256 columns instead of once per 128.
-  // MEASURED AND NOT ADOPTED (profiles/round4/chol_two_level.md; fp32, ms per factorisation, same box, two repetitions):
-  //     M       one-level (round 3)   two-level   one-level + async update   two-level + async update
-  //   8192          4.89                5.00            4.73                       4.83
-  //   4224          1.88                1.97            1.95                       2.02
-  //   2304          0.976               1.02            0.977                      1.02
-  // The rank-256 update is no faster per flop than two of rank 128 (it is the OPERAND stream and the 64-byte pieces of the C
-  // tile's read-modify-write that bound a 128 x 128 x K tile, and K only amortises the second), while the column-b step puts a
-  // second block factorisation per 256 columns on the serial chain.  Where the 4.9 ms go at M = 8192: ~3.0 ms in the 32 big
-  // updates that are longer than the block factorisation fused into them, ~1.3 ms in the 32 panels where the factorisation (34 us)
-  // is the longer one, ~1.2 ms in 64 TRSM launches + gaps.  Reaching the 3.3 ms the verdict asked for needs the chain
-  // (factorisation + TRSM of the next panel) OFF the bulk update's stream - a two-stream lookahead with the bulk one panel
-  // behind - which was not built.  Both forms stay as A/B knobs (SVGP_CHOL_TWO_LEVEL=1, SVGP_CHOL_ASYNC=1), default off.
-  // (experiments build only: SVGP_CHOL_TWO_LEVEL=1, SVGP_CHOL_ASYNC=1, SVGP_CHOL_CHAIN=1; the product build compiles none of them)
-  // the big fused update: the 512-thread two-buffer kernel (experiments build: fp32 on the asynchronous loop, 256 threads)
+  // Round 4 (profiles/round4/chol_two_level.md; fp32, ms per factorisation, same box): M = 8192 one-level 4.89, two-level 5.00; 4224 1.88 /
+  // 1.97; 2304 0.976 / 1.02 - with the 128 x 128-tile update the rank-256 form is no faster per flop than two of rank 128 (it is the
+  // OPERAND stream and the C tile's read-modify-write that bound a 128 x 128 x K tile, and K only amortises the second), while the
+  // column-b step puts a second launch per 256 columns on the serial chain.  Experiments build: SVGP_CHOL_TWO_LEVEL=1.
+  // the big fused update: whole 128 x 128 tiles on 512 threads (kbb = 2: rank-256, the two-level form)
   auto big_update = [&](int nt, int pp, int kbb) {
-#ifdef SVGP_EXPERIMENTS
-    static const bool async_on = exp_int("SVGP_CHOL_ASYNC", 0) == 1;   // A/B knob
-    if constexpr (sizeof(T) == 4) {
-      if (async_on) {
-        using GA = TileGemm<T, kNB, 16, k256>;
-        constexpr size_t lds_a = GA::ASYNC_LDS_BYTES > lds_potf2 ? GA::ASYNC_LDS_BYTES : lds_potf2;
-        set_max_lds(reinterpret_cast<const void*>(syrk128_async_kernel<T, true>), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds_a));
-        hipLaunchKernelGGL((syrk128_async_kernel<T, true>), dim3(nt), dim3(k256), lds_a, s, A, Tm, Mp, pp, info, kbb);
-        return;
-      }
-    }
-#endif
-    static const bool xcd_on = exp_int("SVGP_SYRK_XCD", 0) == 1;
-    if (xcd_on && kbb == 1) {
-      const int nrows = int((std::sqrt(8.0 * nt + 1.0) - 1.0) / 2.0 + 0.5);   // nt = nrows (nrows + 1) / 2
-      const XcdOrder& xo = xcd_tile_order(nrows);
-      if (xo.dev) {
-        hipLaunchKernelGGL((syrk128_kernel<T, true>), dim3(xo.grid), dim3(kThreads), lds_fused_l, s, A, Tm, Mp, pp, info, kbb, 0, xo.dev);
-        return;
-      }
-    }
-    static const int probe = exp_int("SVGP_SYRK_PROBE", 0);   // experiments build: timing probes (wrong results)
-    hipLaunchKernelGGL((syrk128_kernel<T, true>), dim3(nt), dim3(kThreads), lds_fused_l, s, A, Tm, Mp, pp, info, kbb, probe << 8);
+    hipLaunchKernelGGL((syrk128_kernel<T, true>), dim3(nt), dim3(kThreads), lds_fused_l, s, A, Tm, Mp, pp, info, kbb);
   };
 #ifdef SVGP_EXPERIMENTS
   static const bool two_level_on = exp_int("SVGP_CHOL_TWO_LEVEL", 0) == 1;
@@ -1313,80 +1050,12 @@ void potrf_t(hipStream_t s, T* A, T* Tm, int64_t Mp, int* info, unsigned* sync, 
     return;
   }
 #endif
-  // ---- two-stream look-ahead for a large Kuu (round 5, VERDICT r4 item 3: the variant round 4 wrote down and did not build; built now,
-  //      measured, not adopted - see the table below) ------------------------------------------------------------------------------
-  // One-stream form per panel p: TRSM(p) -> ONE launch that updates the whole trailing matrix and, in the workgroup of tile (p+1, p+1),
-  // factors the next diagonal block (34 us fp32) -> TRSM(p+1) ...: a panel costs max(update, update of one tile + block factorisation)
-  // + TRSM + two launch gaps, and from the panel where the update is shorter than the block factorisation on (C4: the last 33 of 64) the
-  // chip idles behind one workgroup.  Here the chain - update of block column p+1 ALONE (MODE_COL) with the block factorisation fused
-  // into it, then TRSM(p+1) - runs on the main stream, and the bulk - the update of everything right of column p+1 with panel p, which
-  // nothing needs before the column update of panel p+1 - on the second (low-priority) stream, one panel behind:
-  //     main:   TRSM(p) . [wait bulk(p-1)] col(p)+potf2(p+1) . TRSM(p+1) . [wait bulk(p)] col(p+1)+potf2(p+2) ...
-  //     second: [wait TRSM(p)] bulk(p)                                   . [wait TRSM(p+1)] bulk(p+1) ...
-  // A panel costs max(bulk, chain).  Same arithmetic on every tile in the same order (each tile still receives its rank-128 updates
-  // panel by panel): the factor is bitwise the one-stream one.  Events rotate over four slots (a wait captures the record before it).
-  // MEASURED AND NOT ADOPTED (profiles/round5/chol_lookahead_ab.log; same process pair, ms per factorisation, look-ahead off / on):
-  //     fp32 M = 2304  0.89 / 1.02     4096  1.66 / 1.93     8192  4.66 / 5.02-5.06        f64 M = 2304  0.97 / 1.12     4096  2.05 / 2.26
-  // - bitwise the same factor, 8-15 % SLOWER: every panel now carries two cross-stream event dependencies (TRSM -> bulk, bulk -> next
-  // column update), each a barrier packet + a signal wait of several microseconds on BOTH queues, plus one more launch on the chain
-  // (column update + block factorisation instead of riding in the big update) - 63 panels x ~6 us at M = 8192 - and that is more than
-  // the idle time the look-ahead reclaims from the late panels.  The one-stream form (the workgroup of tile (p+1, p+1) goes straight on to
-  // the block factorisation while the other workgroups finish the trailing update) already IS a look-ahead with no synchronisation
-  // cost.  Experiments build only: SVGP_CHOL_LOOKAHEAD=1.
-#ifdef SVGP_EXPERIMENTS
-  static const bool lookahead_on = exp_int("SVGP_CHOL_LOOKAHEAD", 0) != 0;
-  if (la && la->s2 && la->ev && lookahead_on && fuse_on && !t_inside) {
-    set_max_lds(reinterpret_cast<const void*>(chol_tile_kernel<T, MODE_COL, CNT, true>), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds_fused_s));
-    hipStream_t s2 = la->s2;
-    hipEvent_t* evT = la->ev;
-    hipEvent_t* evB = la->ev + 4;
-    potf2(0);
-    bool bulk_pending = false;
-    for (int p = 0; p < nP; ++p) {
-      const int n = nP - p - 1;
-      if (n == 0) break;
-      hipLaunchKernelGGL((chol_tile_kernel<T, MODE_TRSM, CNT>), dim3(n * NCH), dim3(k256), lds_tile, s, A, Tm, Mp, p, n, info, sync, 1, 0);
-      dbg("chol trsm (look-ahead)", s);
-      const int nb = n - 1, ntb = nb * (nb + 1) / 2;
-      const bool had_bulk = bulk_pending;
-      if (ntb > 0) {   // the bulk: tiles (i, j), i >= j >= p + 2, on the second stream behind this TRSM
-        (void)hipEventRecord(evT[p & 3], s);
-        (void)hipStreamWaitEvent(s2, evT[p & 3], 0);
-        if (ntb >= 256) hipLaunchKernelGGL((syrk128_kernel<T, false>), dim3(ntb), dim3(kThreads), G::LDS_BYTES, s2, A, Tm, Mp, p, info, 1, 1);
-        else hipLaunchKernelGGL((chol_tile_kernel<T, MODE_SYRK, CNT>), dim3(ntb * NCH), dim3(k256), lds_tile, s2, A, Tm, Mp, p, nb, info, sync, 1, 1);
-        dbg("chol bulk update (look-ahead)", s2);
-      }
-      // the chain: column p + 1 must have received the bulk update of panel p - 1 (it covered the columns >= p + 1)
-      if (had_bulk) (void)hipStreamWaitEvent(s, evB[(p - 1) & 3], 0);
-      hipLaunchKernelGGL((chol_tile_kernel<T, MODE_COL, CNT, true>), dim3(n * NCH), dim3(k256), lds_fused_s, s, A, Tm, Mp, p, n, info, sync, 1, 0);
-      dbg("chol column update + potf2 (look-ahead)", s);
-      bulk_pending = ntb > 0;
-      if (bulk_pending) (void)hipEventRecord(evB[p & 3], s2);
-    }
-    // (every bulk update was waited for by the column update of the next panel: the main stream holds the whole factorisation)
-    hipLaunchKernelGGL((chol_tile_kernel<T, MODE_TRSM, CNT>), dim3((nP * (nP - 1) / 2) * NCH), dim3(k256), lds_tile, s, A, Tm, Mp, -1, 0, info, sync, 1, 0);
-    dbg("T panels", s);
-    return;
-  }
-#else
-  (void)la;
-#endif
-  // one launch per panel (chol_chain_kernel) where the whole launch is resident at once.  MEASURED AND NOT ADOPTED
-  // (profiles/round4/chol_chain.md): bitwise the same factor, but no faster - M = 1024 f64 0.558-0.561 ms of prep against 0.553-0.561,
-  // fp32 0.580-0.588 against 0.552-0.560.  The kernel trace says why: the TRSM launch already starts the instant the fused
-  // update + factorisation launch ends (0.0 us between them), so the flag hand-over (57 us per chain launch against 46.4 + 8.8)
-  // replaces a boundary that cost nothing; the 5.4 us gap sits in front of every update launch in either form.  A/B knob, default off.
-#ifdef SVGP_EXPERIMENTS
-  static const bool chain_on = exp_int("SVGP_CHOL_CHAIN", 0) == 1;
-  static const int chain_slots = [] {
-    hipDeviceProp_t prop;
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
-    return prop.multiProcessorCount * (sizeof(T) == 8 ? 1 : 2);
-  }();
-  set_max_lds(reinterpret_cast<const void*>(chol_chain_kernel<T, CNT>), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds_fused_s));
-#endif
-  bool trsm_done = false;   // panel p's TRSM and T panels rode in the previous chain launch
+  // Measured and rejected forms of this schedule, no longer in the tree (profiles/round6/removed_variants.patch): a two-stream look-ahead
+  // with the bulk update one panel behind the chain (round 5: bitwise the same factor, 8-15 % slower - two cross-stream dependencies
+  // per panel cost more than the idle time they reclaim; profiles/round5/chol_lookahead_ab.log), one launch per panel with a flag
+  // hand-over (round 4, chol_chain_kernel: no faster - the TRSM launch already starts the instant the fused launch ends;
+  // profiles/round4/chol_chain.md), the big update on the asynchronous three-buffer loop (round 4) and in an XCD-aware tile order
+  // (round 5: no gain, profiles/round5/syrk_xcd_ab.log).
   potf2(0);
   for (int p = 0; p < nP; ++p) {
     const int n = nP - p - 1, nt_p = t_inside ? p : 0;
@@ -1398,10 +1067,10 @@ void potrf_t(hipStream_t s, T* A, T* Tm, int64_t Mp, int* info, unsigned* sync, 
     static const bool ev_ext = exp_int("SVGP_ROW_EVENT_EXT", 1) != 0;   // (experiments build)
     const bool want_ev = row_events && t_inside;
     bool ev_done = false;
-    if (!trsm_done && n + nt_p > 0) {   // the panel below the diagonal (and the T panels of block row p)
+    if (n + nt_p > 0) {   // the panel below the diagonal (and the T panels of block row p)
       if (want_ev && ev_ext) {
         hipExtLaunchKernelGGL((chol_tile_kernel<T, MODE_TRSM, CNT>), dim3((n + nt_p) * NCH), dim3(k256), lds_tile, s, nullptr, row_events[p], 0,
-                              A, Tm, Mp, p, n, info, sync, 1, 0);
+                              A, Tm, Mp, p, n, info, sync, 1);
         ev_done = true;
       } else {
         hipLaunchKernelGGL((chol_tile_kernel<T, MODE_TRSM, CNT>), dim3((n + nt_p) * NCH), dim3(k256), lds_tile, s, A, Tm, Mp, p, n, info, sync);
@@ -1417,13 +1086,6 @@ void potrf_t(hipStream_t s, T* A, T* Tm, int64_t Mp, int* info, unsigned* sync, 
     const bool large = nt >= 256;   // a trailing matrix that fills the chip by itself: full 128 x 128 tiles (half the operand traffic)
     // the fused f64 form of the large grid would cost the second resident workgroup (potf2's LDS image of an f64 block is 146 KiB)
     const bool fused = fuse_on && !(large && sizeof(T) == 8);
-    trsm_done = false;
-#ifdef SVGP_EXPERIMENTS
-    if (fused && !large && chain_on && t_inside && (nt + p + 1) * NCH <= chain_slots) {
-      hipLaunchKernelGGL((chol_chain_kernel<T, CNT>), dim3((nt + p + 1) * NCH), dim3(k256), lds_fused_s, s, A, Tm, Mp, p, n, nP, info, sync);
-      trsm_done = true;
-    } else
-#endif
     if (fused && large) {
       big_update(nt, p, 1);
     } else if (fused) {
@@ -1486,9 +1148,9 @@ void launch_kuu(int dtype, hipStream_t s, const KernelParams& kp, const void* zs
 // T must be zero above the diagonal on entry (the model's buffer is cleared once at creation): the factorisation writes the
 // lower triangles of the inverted diagonal blocks and the T panels below them only
 void launch_potrf(int dtype, hipStream_t s, void* A, void* T, int64_t Mp, int* info, unsigned* sync, int num_cus, hipEvent_t* row_events,
-                  const RowHook* hook, const PotrfLookahead* la) {
-  SVGP_DISPATCH(dtype, potrf_t<double>(s, (double*)A, (double*)T, Mp, info, sync, row_events, hook, la, num_cus),
-                potrf_t<float>(s, (float*)A, (float*)T, Mp, info, sync, row_events, hook, la, num_cus));
+                  const RowHook* hook) {
+  SVGP_DISPATCH(dtype, potrf_t<double>(s, (double*)A, (double*)T, Mp, info, sync, row_events, hook, num_cus),
+                potrf_t<float>(s, (float*)A, (float*)T, Mp, info, sync, row_events, hook, num_cus));
 }
 int potrf_max_row_events() { return 16; }   // block rows of T are final one by one only while they ride in the TRSM launches (nP <= 16)
 

@@ -12,6 +12,7 @@
 //   epilogue: v = k(x,x) - Σ A² + Σ C² + 1e-18 (SVA:251, :354), expected log-likelihood per point
 //      (GPLikelihoods), deterministic per-strip sum.
 // Roofline: MFMA-bound (2 Mp² flops per point); algorithmic HBM bytes are only x, y.
+#define SVGP_DIAG_TU_STRIP
 #include "device_common.hpp"
 #include "kernels.hpp"
 #include "knobs.hpp"
@@ -122,22 +123,7 @@ __device__ __forceinline__ void pregen_mfma(const T* __restrict__ xs, const T* _
   }
 }
 
-#ifdef SVGP_STRIP_STAMPS   // diagnostic build (tools/build_ablate.sh stripstamps): s_memtime at the phase boundaries of one strip
-__device__ unsigned long long g_strip_stamps[128];
-__shared__ unsigned long long s_strip_stamps[128];   // accumulated in LDS (a global read-modify-write per stamp costs ~2k cycles)
-#define SVGP_SSTAMP(i) do { if (stamping && threadIdx.x == 0) s_strip_stamps[i] += clock64(); } while (0)   // sums over strips
-extern "C" int svgp_debug_strip_stamps(unsigned long long* out) {
-  return int(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_strip_stamps), sizeof(g_strip_stamps)));
-}
-// per-workgroup timeline of the LAST launch: for workgroups 0, 37, 74, ... (16 of them) the clock at the start of each of its first
-// 10 strips, at its end (slot 10), and its XCC id (slot 11): first-strip cost, lockstep, spread over the chip
-__device__ unsigned long long g_wg_times[16][12];
-extern "C" int svgp_debug_wg_times(unsigned long long* out) {
-  return int(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wg_times), sizeof(g_wg_times)));
-}
-#else
-#define SVGP_SSTAMP(i)
-#endif
+// (s_memtime stamps of the diagnostic build: SVGP_SSTAMP*, diag.hpp; timing-only ablations: diag::ablate<BIT>)
 
 // d E[log p] / d (mu, v) of one point for the value-and-gradient strips.  Not inlined: lgamma / exp / log1p and the
 // Gauss-Hermite loop must not take part in the register allocation of the MFMA loops around the call (146 spilled VGPRs
@@ -217,15 +203,12 @@ __device__ __noinline__ PointGrads strip_point_grads(LikParams lp, double mu, do
 // Outputs: A and R A point-major (for the products contracted over points: the SYRK W = A diag(2 g_v) A' and the
 // kernel-gradient reductions, which form P = Kuf_bar = alpha g_mu' + 2 (R A) diag(g_v) themselves), g_mu, g_v, and five
 // per-strip sums.
-// PG (value-and-gradient builds): who turns the strip's (mu, v) into likelihood gradients.
-//   kPgPost (round 4, the default): nobody in here - the strip leaves its moments in mom_mu / mom_var exactly like a forward strip and
-//            point_grad_kernel evaluates SVA:354-355 and their adjoint afterwards (as expect_kernel does for the forward path).
-//            Since phase 3 moved in FRONT of the likelihood gradients nothing in the strip consumes g_mu / g_v (the fp32 `apart`
-//            row sums excepted), and the non-inlined call was all that separated the f64 kernel (256 VGPRs + 72 spilled, 336 B of
-//            scratch) from the spill-free shape of the host-evaluated build: one kernel now serves both.
-//   kPgBuiltin / kPgExternal: the round-3 in-kernel forms (strip_point_grads / two loads of the host's point gradients), kept
-//            for the fp32 `apart` path and as A/B builds (SVGP_GRAD_POST=0).
-enum : int { kPgBuiltin = 0, kPgExternal = 1, kPgPost = 2 };
+// The likelihood gradients are NOT evaluated in here (round 4): a value-and-gradient strip leaves its moments in mom_mu / mom_var exactly
+// like a forward strip and point_grad_kernel evaluates SVA:354-355 and their adjoint afterwards (as expect_kernel does for the forward
+// path) - for the built-in likelihoods and for the host-evaluated ones alike.  Since phase 3 moved in FRONT of the likelihood gradients
+// nothing in the strip consumes g_mu / g_v, and the non-inlined call was all that separated the f64 kernel (256 VGPRs + 72 spilled) from a
+// spill-free shape.  The round-3 in-kernel forms (and the fp32 per-strip row sums A g_mu that went with them) left the tree in round 6:
+// profiles/round6/removed_variants.patch.
 // BIGD (round 4): the instantiation for 16 < d <= 64.  A separate kernel, not a branch: with the 32- / 64-feature pre-generation
 // bodies inside, the register allocation of the WHOLE kernel changed (the headline f64 kernel went from 0 to 335 spilled VGPRs) -
 // so the d <= 16 kernels stay bit for bit what they were and the wide-input kernels hold only the wide bodies.
@@ -238,10 +221,8 @@ enum : int { kPgBuiltin = 0, kPgExternal = 1, kPgPost = 2 };
 // so that the arithmetic - and the result, bit for bit - is that of the one-launch kernel.  No spinning, no flags: a launch that
 // is waiting occupies nothing, so the factorisation's own launches always find the chip (VERDICT r3 item 2 asked for flag-gated
 // persistent strips; those hold every CU while they wait - DESIGN section 3 "prep beside the strips").
-template <typename T, int NT, int BK, int NTHR, int MINW = 2, int PAD = 16, bool GRAD = false, int PG = kPgBuiltin, bool BIGD = false, bool SEG = false>
+template <typename T, int NT, int BK, int NTHR, int MINW = 2, int PAD = 16, bool GRAD = false, bool BIGD = false, bool SEG = false>
 __global__ void __launch_bounds__(NTHR, MINW) strip_kernel(StripArgs a, int64_t nstrips) {
-  static_assert(!(SEG && GRAD) || PG == kPgPost, "segmented value-and-gradient strips leave their moments to point_grad_kernel");
-  constexpr bool EXT = (PG == kPgExternal);
   using G = TileGemm<T, NT, BK, NTHR, PAD>;
   using Acc = typename G::Acc;
   using QRegs = typename G::QRegs;
@@ -292,12 +273,7 @@ __global__ void __launch_bounds__(NTHR, MINW) strip_kernel(StripArgs a, int64_t 
 #else
   const double* exptab = nullptr;
 #endif
-  __shared__ T s_gmu[(GRAD && PG != kPgPost) ? NT : 1], s_gv[(GRAD && PG != kPgPost) ? NT : 1];   // the strip's likelihood gradients (fp32 `apart` row sums)
-#ifdef SVGP_STRIP_STAMPS
-  int strips_done = 0;
-  if (threadIdx.x < 128) s_strip_stamps[threadIdx.x] = 0;
-  __syncthreads();
-#endif
+  SVGP_SSTAMP_KERNEL_BEGIN();
   [[maybe_unused]] int prio_strips = 0;
   [[maybe_unused]] int part = 0, nsplit = 1;   // split closing launch (kernels.hpp: seg_split)
   if constexpr (SEG) {
@@ -308,12 +284,7 @@ __global__ void __launch_bounds__(NTHR, MINW) strip_kernel(StripArgs a, int64_t 
       work = static_cast<T*>(a.work) + strip * Mp * NT;
       workK = GRAD ? static_cast<T*>(a.work) + (nstrips + strip) * Mp * NT : work;   // GRAD: the Kuf strips behind the A strips
     }
-#ifdef SVGP_STRIP_STAMPS
-    const bool stamping = (blockIdx.x == 37 && strips_done >= 1);   // every strip of one workgroup but its first
-    if (stamping && threadIdx.x == 0) s_strip_stamps[127] += 1;
-    if (threadIdx.x == 0 && blockIdx.x % 37 == 0 && blockIdx.x / 37 < 16 && strips_done < 10) g_wg_times[blockIdx.x / 37][strips_done] = clock64();
-    ++strips_done;
-#endif
+    SVGP_SSTAMP_STRIP_BEGIN();
     SVGP_SSTAMP(0);
     if constexpr (SVGP_STRIP_PRIO == 2) ++prio_strips; else strip_prio<GRAD && !SEG>(prio_strips++);
     const int64_t c0 = strip * NT;                          // first column of the strip inside the batch
@@ -423,98 +394,33 @@ __global__ void __launch_bounds__(NTHR, MINW) strip_kernel(StripArgs a, int64_t 
           for (int j = 0; j < NJ; ++j) {
             const T val = acc.v[i][j][r];
             const int col = G::acc_col(j);
-#if !(defined(SVGP_ABLATE) && (SVGP_ABLATE & 4))
-            work[int64_t(row) * NT + col] = val;
-#endif
+            if constexpr (!diag::ablate<4>) work[int64_t(row) * NT + col] = val;
             if (a.A_out) static_cast<T*>(a.A_out)[int64_t(row) * a.lda + c0 + col] = val;
             if constexpr (!GRAD) {
               if (a.At_out) static_cast<T*>(a.At_out)[(c0 + col) * Mp + row] = val;
             }
-#if !(defined(SVGP_ABLATE) && (SVGP_ABLATE & 16))
-            const double dv = double(val);
-            if constexpr (!GRAD) sA[j] = fma(dv, dv, sA[j]);
-            sM[j] = fma(dv, mr, sM[j]);
-#else
-            sA[j] += double(val) + mr;
-#endif
+            if constexpr (!diag::ablate<16>) {
+              const double dv = double(val);
+              if constexpr (!GRAD) sA[j] = fma(dv, dv, sA[j]);
+              sM[j] = fma(dv, mr, sM[j]);
+            } else {
+              sA[j] += double(val) + mr;
+            }
           }
         }
       }
-#if !(defined(SVGP_ABLATE) && (SVGP_ABLATE & 32))   // timing-only builds: bit 32 no point-major A, 64 no point-major R A, 128 no K-dot
-      if constexpr (GRAD) store_tile_point_major<G, T, NT, NTHR>(acc, smem, static_cast<T*>(a.At_out), c0, Mp, I * NB);
-#endif
+      if constexpr (GRAD && !diag::ablate<32>) store_tile_point_major<G, T, NT, NTHR>(acc, smem, static_cast<T*>(a.At_out), c0, Mp, I * NB);
       __syncthreads();  // scratch rows of panel I visible to the whole workgroup
       SVGP_SSTAMP(4 + 3 * I);
     }
 
     // ---------------- phase 2: C = B' A  (forward builds; the value-and-gradient build gets the variance from phase 3) --------
-    [[maybe_unused]] bool p2_complete = false;
     if constexpr (SEG) {
       if (a.seg_flags & kSegStore) {
         double* __restrict__ st = a.seg_state + (strip * NTHR + tid) * (2 * NJ);
 #pragma unroll
         for (int j = 0; j < NJ; ++j) { st[j] = sA[j]; st[NJ + j] = sM[j]; }
       }
-      // Checkpointed phase 2 (forward builds, kSegP2): every C_J = sum_{I >= J} U[J, I] A_I needs the LAST panel of A, so a phase 2
-      // that starts behind phase 1 leaves all of it behind the factorisation.  But the contraction runs over ascending I, and
-      // splitting a K loop into two invocations changes no arithmetic: at a checkpoint launch (after panel p2_hi - 1) every panel
-      // J < p2_hi advances its accumulator over the k-blocks [max(J, p2_lo), p2_hi) - resuming from the tile it parked in `seg_cacc`
-      // at the previous checkpoint, in the threads' own register layout - and parks it again; the closing launch finishes all of
-      // them.  Same operations on every accumulator in the same order: bitwise the one-launch result.  Three checkpoints
-      // (nP / 2, 3 nP / 4, nP): 20 tile transfers per strip instead of 64 for one per panel.
-#ifdef SVGP_EXPERIMENTS   // (measured, not adopted: SVGP_OVERLAP_P2CKPT=1 - the product build's segmented kernels do not carry it)
-      if constexpr (!GRAD) {
-        const int p2_lo = a.seg_p2_lo, p2_hi = a.seg_p2_hi;
-        if ((a.seg_flags & kSegP2) && p2_hi > p2_lo) {
-          constexpr int PT = MI * NJ * 4;   // accumulator values per thread and tile
-          using acc_t = typename G::acc_t;
-          T* __restrict__ cacc = static_cast<T*>(a.seg_cacc) + strip * Mp * NT;
-          const bool last = (p2_hi == nP);
-          for (int J = 0; J < p2_hi; ++J) {
-            Acc acc;
-            T* __restrict__ ct = cacc + (int64_t(J) * NTHR + tid) * PT;
-            const int kb0 = J > p2_lo ? J : p2_lo;   // first k-block of panel J in this launch
-            if (J < p2_lo) {
-#pragma unroll
-              for (int i = 0; i < MI; ++i)
-#pragma unroll
-                for (int j = 0; j < NJ; ++j) acc.v[i][j] = *reinterpret_cast<const acc_t*>(ct + (i * NJ + j) * 4);
-            } else {
-              acc.zero();
-            }
-            const int nst = (p2_hi - kb0) * (NB / BK);
-            const T* Pb = U + int64_t(J) * NB + int64_t(kb0) * NB * Mp;
-            const T* wq = work + int64_t(kb0) * NB * NT;
-            if constexpr (SVGP_ASYNC && G::kAsync) {
-              auto qsrc = [&](int t) { return wq + int64_t(t) * BK * NT; };
-              if (kb0 == J) G::template loop_tri_async<(SVGP_TRI & 2) ? -1 : 0>(acc, Pb, Mp, nst, qsrc, smem);
-              else G::template loop_tri_async<0>(acc, Pb, Mp, nst, qsrc, smem);
-            } else {
-              auto qload = [&](int t, QRegs& r) { G::load_q(r, wq + int64_t(t) * BK * NT, qoff); };
-              if (kb0 == J) G::template loop_tri<(BK == 16 && (SVGP_TRI & 2)) ? -1 : 0>(acc, Pb, Mp, nst, qload, smem);
-              else G::template loop_tri<0>(acc, Pb, Mp, nst, qload, smem);
-            }
-            if (!last) {
-#pragma unroll
-              for (int i = 0; i < MI; ++i)
-#pragma unroll
-                for (int j = 0; j < NJ; ++j) *reinterpret_cast<acc_t*>(ct + (i * NJ + j) * 4) = acc.v[i][j];
-            } else {   // C_J is complete: its column sums, panels in ascending order as in the one-launch kernel
-#pragma unroll
-              for (int i = 0; i < MI; ++i)
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-#pragma unroll
-                  for (int j = 0; j < NJ; ++j) {
-                    const double dv = double(acc.v[i][j][r]);
-                    sC[j] = fma(dv, dv, sC[j]);
-                  }
-            }
-          }
-          p2_complete = last;
-        }
-      }
-#endif
       if (!(a.seg_flags & kSegPhase2)) {   // this launch ends here for the strip; phase 2 (GRAD: phase 3) and the moments come with a later one
         strip = next_strip;
         __syncthreads();
@@ -522,9 +428,10 @@ __global__ void __launch_bounds__(NTHR, MINW) strip_kernel(StripArgs a, int64_t 
       }
     }
     if constexpr (!GRAD)
-    // (segmented builds: the checkpoints may have covered phase 2; a split closing launch deals the panels round-robin - C_J costs
-    // nP - J block products - to the strip's nsplit workgroups)
-    for (int J = (SEG && p2_complete) ? nP : (SEG ? part : 0); J < nP; J += (SEG ? nsplit : 1)) {
+    // (segmented builds: a split closing launch deals the panels round-robin - C_J costs nP - J block products - to the strip's nsplit
+    // workgroups.  A checkpointed phase 2 beside the factorisation was built in round 4, measured slower and left the tree in round 6:
+    // profiles/round6/removed_variants.patch)
+    for (int J = SEG ? part : 0; J < nP; J += (SEG ? nsplit : 1)) {
       SVGP_SSTAMP(60 + 2 * J);
       Acc acc;
       acc.zero();
@@ -580,25 +487,22 @@ __global__ void __launch_bounds__(NTHR, MINW) strip_kernel(StripArgs a, int64_t 
           G::template loop_tri<0>(acc, Rm + int64_t(I) * NB, Mp, nP * (NB / BK), qload, smem);
         }
         SVGP_SSTAMP(27 + 4 * I);
-#if !(defined(SVGP_ABLATE) && (SVGP_ABLATE & 128))
+        if constexpr (!diag::ablate<128>) {
 #pragma unroll
-        for (int i = 0; i < MI; ++i)
+          for (int i = 0; i < MI; ++i)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int64_t row = int64_t(I) * NB + G::acc_row(i, r);
+            for (int r = 0; r < 4; ++r) {
+              const int64_t row = int64_t(I) * NB + G::acc_row(i, r);
 #pragma unroll
-            for (int j = 0; j < NJ; ++j) sC[j] = fma(double(acc.v[i][j][r]), double(workK[row * NT + G::acc_col(j)]), sC[j]);
-          }
-#else
+              for (int j = 0; j < NJ; ++j) sC[j] = fma(double(acc.v[i][j][r]), double(workK[row * NT + G::acc_col(j)]), sC[j]);
+            }
+        } else {
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) sC[j] += double(acc.v[0][j][0]);
-#endif
+          for (int j = 0; j < NJ; ++j) sC[j] += double(acc.v[0][j][0]);
+        }
         SVGP_SSTAMP(28 + 4 * I);
-#if !(defined(SVGP_ABLATE) && (SVGP_ABLATE & 64))
-        store_tile_point_major<G, T, NT, NTHR>(acc, smem, Pt, c0, Mp, I * NB);
-#else
-        if (acc.v[0][0][0] == T(12345.678)) Pt[c0] = acc.v[0][0][0];   // keep the accumulators live
-#endif
+        if constexpr (!diag::ablate<64>) store_tile_point_major<G, T, NT, NTHR>(acc, smem, Pt, c0, Mp, I * NB);
+        else if (acc.v[0][0][0] == T(12345.678)) Pt[c0] = acc.v[0][0][0];   // keep the accumulators live
         SVGP_SSTAMP(29 + 4 * I);
       }
     }
@@ -621,7 +525,7 @@ __global__ void __launch_bounds__(NTHR, MINW) strip_kernel(StripArgs a, int64_t 
       }
     }
     __syncthreads();
-    if constexpr (!GRAD || PG == kPgPost) {
+    {
       bool split_done = false;
       if constexpr (SEG) {
         if (nsplit > 1) {   // this part's column sums -> seg_part; the last part of the strip to arrive adds them in part order
@@ -676,101 +580,12 @@ __global__ void __launch_bounds__(NTHR, MINW) strip_kernel(StripArgs a, int64_t 
       }
       __syncthreads();
       }
-    } else {
-      // ---- marginals + d E[log p] / d (mu, v) of the strip's points (SVA:354-355 and their adjoint), one thread per point
-      double e5[5] = {0, 0, 0, 0, 0};   // E, sum g_mu, sum g_v, dE/dsigma2, n_neg
-      double gm = 0.0, gvv = 0.0;
-      if (tid < NT && c0 + tid < a.len) {
-        double qa = 0, qm = 0, qc = 0;
-#pragma unroll
-        for (int w = 0; w < G::WR; ++w) {
-          qa += red[(0 * G::WR + w) * NT + tid];
-          qm += red[(1 * G::WR + w) * NT + tid];
-          qc += red[(2 * G::WR + w) * NT + tid];
-        }
-        const double mu = a.mean_const + qm;
-        double v = a.kp.variance + qc + kDefaultSigma2;   // qc = k_j' (R A)_.j  (= sum C^2 - sum A^2; qa is not accumulated in this build)
-        const double scale = a.n_global_dev ? (a.num_data > 0.0 ? a.num_data / *a.n_global_dev : 1.0) : a.scale;
-        bool bad = v < 0.0;
-        if (bad) {
-          e5[4] = 1.0;
-          if (a.lp.clamp_neg_var) { v = 0.0; bad = false; }
-        }
-        if constexpr (EXT) {   // svgp_elbo_grad_ext: the host evaluated the likelihood on svgp_marginals; its point gradients
-          if (!bad) {          // come in through gh_x / gh_w (kernels.hpp kLikExternal), E is the host's
-            e5[1] = gm = a.lp.gh_x[c0 + tid] * scale;
-            e5[2] = gvv = a.lp.gh_w[c0 + tid] * scale;
-          }
-        } else if (!bad) {
-          const double yv = double(static_cast<const T*>(a.y)[a.off + c0 + tid]);
-          const PointGrads pg = strip_point_grads(a.lp, mu, v, yv, scale);
-          e5[0] = pg.e; e5[1] = gm = pg.gmu; e5[2] = gvv = pg.gv; e5[3] = pg.gs2;
-        }
-        static_cast<T*>(a.gmu_out)[c0 + tid] = T(gm);
-        static_cast<T*>(a.gv_out)[c0 + tid] = T(gvv);
-      }
-      __syncthreads();   // every read of red[] done
-      if (tid < NT) {
-        s_gmu[tid] = T(gm);
-        s_gv[tid] = T(gvv);
-#pragma unroll
-        for (int q = 0; q < 5; ++q) red[q * NT + tid] = e5[q];
-      }
-      __syncthreads();
-      if (tid < 5) {   // fixed order: bitwise reproducible
-        double sacc = 0.0;
-        for (int c = 0; c < NT; ++c) sacc += red[tid * NT + c];
-        a.part5[strip * 5 + tid] = sacc;
-      }
-      __syncthreads();   // staging free again
-      // a = A g_mu of this strip (the data part of m_bar; A still in the scratch strip): a wave per row, lanes along the
-      // points (coalesced), fixed-order shuffle tree; written per strip and reduced over strips in a fixed order afterwards, so
-      // the kernel-gradient kernel no longer has to stream A from HBM beside P just for these row sums
-      if (a.apart) {   // fp32 only (api.hip): in f64 these VALU cycles are stolen from the MFMA pipe and cost more than they save
-        constexpr int RU = 8, CL = NT / 64 > 0 ? NT / 64 : 1;   // rows in flight per wave (one row at a time ran at the L2 latency)
-        const int wv = tid >> 6, lc = NT >= 64 ? lane : lane % NT;
-        double* __restrict__ ap = a.apart + strip * Mp;
-        double gl[CL];
-#pragma unroll
-        for (int q = 0; q < CL; ++q) gl[q] = (NT >= 64 || lane < NT) ? double(s_gmu[q * 64 + lc]) : 0.0;
-        for (int64_t r0 = int64_t(wv) * RU; r0 < Mp; r0 += int64_t(NTHR / 64) * RU) {   // Mp is a multiple of 128: whole groups
-          T av[RU][CL];
-#pragma unroll
-          for (int u = 0; u < RU; ++u)
-#pragma unroll
-            for (int q = 0; q < CL; ++q) av[u][q] = work[(r0 + u) * NT + q * 64 + lc];
-          double acc1[RU];
-#pragma unroll
-          for (int u = 0; u < RU; ++u) {
-            acc1[u] = 0.0;
-#pragma unroll
-            for (int q = 0; q < CL; ++q) acc1[u] = fma(double(av[u][q]), gl[q], acc1[u]);
-          }
-#pragma unroll
-          for (int w = 32; w > 0; w >>= 1)
-#pragma unroll
-            for (int u = 0; u < RU; ++u) acc1[u] += __shfl_xor(acc1[u], w);
-          if (lane < RU) {
-            double v = acc1[0];
-#pragma unroll
-            for (int u = 1; u < RU; ++u) v = (lane == u) ? acc1[u] : v;
-            ap[r0 + lane] = v;
-          }
-        }
-      }
     }
     strip = next_strip;
     __syncthreads();
     SVGP_SSTAMP(101);
   }
-#ifdef SVGP_STRIP_STAMPS
-  if (blockIdx.x == 37 && threadIdx.x < 128) g_strip_stamps[threadIdx.x] = s_strip_stamps[threadIdx.x];
-  if (threadIdx.x == 0 && blockIdx.x % 37 == 0 && blockIdx.x / 37 < 16) {
-    g_wg_times[blockIdx.x / 37][10] = clock64();
-    g_wg_times[blockIdx.x / 37][11] = (unsigned long long)(__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) & 0xf) | ((unsigned long long)strips_done << 8);   // HW_REG_XCC_ID
-    for (int q = strips_done; q < 10; ++q) g_wg_times[blockIdx.x / 37][q] = 0;
-  }
-#endif
+  SVGP_SSTAMP_KERNEL_END();
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1204,7 +1019,7 @@ __global__ void __launch_bounds__(k256) kuf_generic_kernel(KernelParams kp, cons
   }
 }
 
-template <typename T, int NT, int BK, int NTHR, int MINW = 2, int PAD = 16, bool GRAD = false, int PG = kPgBuiltin, bool BIGD = false, bool SEG = false>
+template <typename T, int NT, int BK, int NTHR, int MINW = 2, int PAD = 16, bool GRAD = false, bool BIGD = false, bool SEG = false>
 void launch_strip_t(hipStream_t s, const StripArgs& a, int grid, int64_t nstrips) {
   using G = TileGemm<T, NT, BK, NTHR, PAD>;
   // the strip's x image (<= 64 feature rows: SVGP_MAX_D) aliases the staging buffers
@@ -1212,18 +1027,18 @@ void launch_strip_t(hipStream_t s, const StripArgs& a, int grid, int64_t nstrips
   static_assert(G::LDS_BYTES >= size_t(64) * NT * sizeof(T) && (!(SVGP_ASYNC && G::kAsync) || G::ASYNC_LDS_BYTES >= size_t(64) * NT * sizeof(T)),
                 "x image must fit the staging buffers");
   static_assert(G::LDS_BYTES >= size_t(5) * NT * sizeof(double), "the five per-strip sums reuse the staging buffers");
-  auto kern = strip_kernel<T, NT, BK, NTHR, MINW, PAD, GRAD, PG, BIGD, SEG>;
+  auto kern = strip_kernel<T, NT, BK, NTHR, MINW, PAD, GRAD, BIGD, SEG>;
   set_max_lds(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
   hipLaunchKernelGGL(kern, dim3(grid), dim3(NTHR), lds, s, a, nstrips);
 }
 
 // the product shapes (256 threads): d <= 16 -> the round-3 kernel, 16 < d <= 64 -> its wide-input twin (SVGP_PREGEN_MFMA_BIGD=0:
 // the scalar per-feature generation inside the d <= 16 kernel, as round 3 - A/B knob)
-template <typename T, int NT, bool GRAD, int PG>
+template <typename T, int NT, bool GRAD>
 void launch_strip_d(hipStream_t s, const StripArgs& a, int grid, int64_t nstrips) {
   static const bool bigd_on = exp_int("SVGP_PREGEN_MFMA_BIGD", 1) != 0;   // experiments build: A/B
-  if (a.kp.d > 16 && bigd_on) launch_strip_t<T, NT, 16, 256, 2, 16, GRAD, PG, true>(s, a, grid, nstrips);
-  else launch_strip_t<T, NT, 16, 256, 2, 16, GRAD, PG, false>(s, a, grid, nstrips);
+  if (a.kp.d > 16 && bigd_on) launch_strip_t<T, NT, 16, 256, 2, 16, GRAD, true>(s, a, grid, nstrips);
+  else launch_strip_t<T, NT, 16, 256, 2, 16, GRAD, false>(s, a, grid, nstrips);
 }
 
 }  // namespace
@@ -1315,14 +1130,14 @@ StripPlan strip_plan_single(int dtype, int64_t Mp, int64_t len, int num_cus) {
 void launch_strip(int dtype, hipStream_t s, const StripArgs& a, int nt, int grid, int64_t nstrips) {
   static const bool bk32 = env_int("SVGP_STRIP_BK", 16) == 32;
   if (nt == 32 && dtype == 0) {
-    launch_strip_d<double, 32, false, kPgBuiltin>(s, a, grid, nstrips);
+    launch_strip_d<double, 32, false>(s, a, grid, nstrips);
   } else if (nt == 32) {
-    launch_strip_d<float, 32, false, kPgBuiltin>(s, a, grid, nstrips);
+    launch_strip_d<float, 32, false>(s, a, grid, nstrips);
   } else if (nt == 64) {
-    if (dtype == 0) launch_strip_d<double, 64, false, kPgBuiltin>(s, a, grid, nstrips);
-    else launch_strip_d<float, 64, false, kPgBuiltin>(s, a, grid, nstrips);   // BK = 32 measured identical
+    if (dtype == 0) launch_strip_d<double, 64, false>(s, a, grid, nstrips);
+    else launch_strip_d<float, 64, false>(s, a, grid, nstrips);   // BK = 32 measured identical
   } else if (dtype == 1 && env_int("SVGP_F32_THREADS", 256) == 256) {
-    launch_strip_d<float, 128, false, kPgBuiltin>(s, a, grid, nstrips);
+    launch_strip_d<float, 128, false>(s, a, grid, nstrips);
   }
 #ifdef SVGP_EXPERIMENTS   // the 512-thread, 128-point builds (SVGP_STRIP_NT=128 / SVGP_F32_THREADS=512): measured and rejected, round 1-3
   else if (dtype == 0) {
@@ -1346,22 +1161,22 @@ void launch_strip(int dtype, hipStream_t s, const StripArgs& a, int nt, int grid
 void launch_strip_seg(int dtype, hipStream_t s, const StripArgs& a, int nt, int grid, int64_t nstrips, bool grad) {
   if (grad) {
     if (dtype == 0) {
-      if (nt == 32) launch_strip_t<double, 32, 16, 256, 2, 16, true, kPgPost, false, true>(s, a, grid, nstrips);
-      else launch_strip_t<double, 64, 16, 256, 2, 16, true, kPgPost, false, true>(s, a, grid, nstrips);
+      if (nt == 32) launch_strip_t<double, 32, 16, 256, 2, 16, true, false, true>(s, a, grid, nstrips);
+      else launch_strip_t<double, 64, 16, 256, 2, 16, true, false, true>(s, a, grid, nstrips);
     } else {
-      if (nt == 32) launch_strip_t<float, 32, 16, 256, 2, 16, true, kPgPost, false, true>(s, a, grid, nstrips);
-      else if (nt == 64) launch_strip_t<float, 64, 16, 256, 2, 16, true, kPgPost, false, true>(s, a, grid, nstrips);
-      else launch_strip_t<float, 128, 16, 256, 2, 16, true, kPgPost, false, true>(s, a, grid, nstrips);
+      if (nt == 32) launch_strip_t<float, 32, 16, 256, 2, 16, true, false, true>(s, a, grid, nstrips);
+      else if (nt == 64) launch_strip_t<float, 64, 16, 256, 2, 16, true, false, true>(s, a, grid, nstrips);
+      else launch_strip_t<float, 128, 16, 256, 2, 16, true, false, true>(s, a, grid, nstrips);
     }
     return;
   }
   if (dtype == 0) {
-    if (nt == 32) launch_strip_t<double, 32, 16, 256, 2, 16, false, kPgBuiltin, false, true>(s, a, grid, nstrips);
-    else launch_strip_t<double, 64, 16, 256, 2, 16, false, kPgBuiltin, false, true>(s, a, grid, nstrips);
+    if (nt == 32) launch_strip_t<double, 32, 16, 256, 2, 16, false, false, true>(s, a, grid, nstrips);
+    else launch_strip_t<double, 64, 16, 256, 2, 16, false, false, true>(s, a, grid, nstrips);
   } else {
-    if (nt == 32) launch_strip_t<float, 32, 16, 256, 2, 16, false, kPgBuiltin, false, true>(s, a, grid, nstrips);
-    else if (nt == 64) launch_strip_t<float, 64, 16, 256, 2, 16, false, kPgBuiltin, false, true>(s, a, grid, nstrips);
-    else launch_strip_t<float, 128, 16, 256, 2, 16, false, kPgBuiltin, false, true>(s, a, grid, nstrips);
+    if (nt == 32) launch_strip_t<float, 32, 16, 256, 2, 16, false, false, true>(s, a, grid, nstrips);
+    else if (nt == 64) launch_strip_t<float, 64, 16, 256, 2, 16, false, false, true>(s, a, grid, nstrips);
+    else launch_strip_t<float, 128, 16, 256, 2, 16, false, false, true>(s, a, grid, nstrips);
   }
 }
 // doubles of state per strip a segmented launch saves / restores (kernels.hpp: StripArgs::seg_state)
@@ -1371,41 +1186,16 @@ size_t strip_seg_state_doubles(int dtype, int nt) {
   return size_t(256) * 2 * nj;
 }
 
-void launch_strip_grad(int dtype, hipStream_t s, const StripArgs& a, int nt, int grid, int64_t nstrips, bool post) {
-  if (post) {   // the strips leave (mu, v); launch_point_grads follows (both likelihood routes, one instantiation per shape)
-    if (dtype == 0) {
-      if (nt == 32) launch_strip_d<double, 32, true, kPgPost>(s, a, grid, nstrips);
-      else launch_strip_d<double, 64, true, kPgPost>(s, a, grid, nstrips);
-    } else {
-      if (nt == 32) launch_strip_d<float, 32, true, kPgPost>(s, a, grid, nstrips);
-      else if (nt == 64) launch_strip_d<float, 64, true, kPgPost>(s, a, grid, nstrips);
-      else launch_strip_d<float, 128, true, kPgPost>(s, a, grid, nstrips);
-    }
-    return;
-  }
-#ifdef SVGP_EXPERIMENTS   // the round-3 in-kernel likelihood-gradient forms (SVGP_GRAD_POST=0): five of them spill at occupancy 1
-  if (a.lp.lik == kLikExternal) {   // the host-evaluated-likelihood build: a separate instantiation, so the enumerated one
-    if (dtype == 0) {               // is bit for bit the kernel it was (its register allocation is that sensitive)
-      if (nt == 32) launch_strip_t<double, 32, 16, 256, 2, 16, true, kPgExternal>(s, a, grid, nstrips);
-      else launch_strip_t<double, 64, 16, 256, 2, 16, true, kPgExternal>(s, a, grid, nstrips);
-    } else {
-      if (nt == 32) launch_strip_t<float, 32, 16, 256, 2, 16, true, kPgExternal>(s, a, grid, nstrips);
-      else if (nt == 64) launch_strip_t<float, 64, 16, 256, 2, 16, true, kPgExternal>(s, a, grid, nstrips);
-      else launch_strip_t<float, 128, 16, 256, 2, 16, true, kPgExternal>(s, a, grid, nstrips);
-    }
-    return;
-  }
+void launch_strip_grad(int dtype, hipStream_t s, const StripArgs& a, int nt, int grid, int64_t nstrips) {
+  // the strips leave (mu, v); launch_point_grads follows (both likelihood routes, one instantiation per shape)
   if (dtype == 0) {
-    if (nt == 32) launch_strip_t<double, 32, 16, 256, 2, 16, true>(s, a, grid, nstrips);
-    else launch_strip_t<double, 64, 16, 256, 2, 16, true>(s, a, grid, nstrips);
+    if (nt == 32) launch_strip_d<double, 32, true>(s, a, grid, nstrips);
+    else launch_strip_d<double, 64, true>(s, a, grid, nstrips);
   } else {
-    if (nt == 32) launch_strip_t<float, 32, 16, 256, 2, 16, true>(s, a, grid, nstrips);
-    else if (nt == 64) launch_strip_t<float, 64, 16, 256, 2, 16, true>(s, a, grid, nstrips);
-    else launch_strip_t<float, 128, 16, 256, 2, 16, true>(s, a, grid, nstrips);
+    if (nt == 32) launch_strip_d<float, 32, true>(s, a, grid, nstrips);
+    else if (nt == 64) launch_strip_d<float, 64, true>(s, a, grid, nstrips);
+    else launch_strip_d<float, 128, true>(s, a, grid, nstrips);
   }
-#else
-  leave_note("internal: the in-kernel likelihood-gradient strips exist in the experiments build only");
-#endif
 }
 
 int point_grad_blocks(int64_t len) { return int((len + k256 - 1) / k256); }

@@ -156,14 +156,17 @@ int32_t svgp_last_timing_sized(const svgp_ctx* ctx, void* out, int64_t out_bytes
  *
  * One process per GPU: rank 0 calls svgp_comm_unique_id, the host transports the 128 bytes to every rank
  * (MPI / torch.distributed / Distributed.jl), every rank calls svgp_ctx_attach_comm on its own context
- * (collective: ncclCommInitRank).  A rank that fails locally (bad arguments, allocation failure, HIP error) still enters
- * every collective of the call - with zero contributions and a failure flag - so its peers return SVGP_RCCL_ERROR
- * instead of waiting for it; svgp_elbo_host does so too when it fails before it reaches svgp_elbo.  The exceptions are
- * FATAL for the job: a rank that was handed a NULL model (the element counts of the gradient all-reduce are unknown to it)
- * or that cannot even allocate the zero contributions aborts its communicator (ncclCommAbort), which does NOT wake its
- * peers - they stay inside the collective and the process group has to be torn down from outside.  The one-process
- * group calls (svgp_group_elbo / svgp_group_elbo_grad) validate every member before anything is enqueued and return the
- * first member's error without touching the communicator. */
+ * (collective: ncclCommInitRank).  No rank can leave its peers inside a collective:
+ *   svgp_elbo / svgp_elbo_host: ONE fixed-size all-reduce (8 doubles); a rank that fails locally - bad arguments, NULL model,
+ *     allocation failure, HIP error - enters it with zero contributions and the failure flag; its peers return SVGP_RCCL_ERROR.
+ *   svgp_elbo_grad / svgp_elbo_grad_ext: an opening fixed-size all-reduce {batch size, failure flag} every rank enters, whatever
+ *     state it is in - a rank that cannot evaluate (also one handed a NULL model) sends the flag, returns its own error and joins
+ *     nothing else; every other rank reads the reduced flag before the closing gradient all-reduce (whose size depends on M and d),
+ *     skips it and returns SVGP_RCCL_ERROR.  A rank that fails later, inside its backward pass, enters the closing all-reduce with
+ *     its failure flag.  The communicator stays usable after either kind of failure.
+ * ncclCommAbort is left for the case that a collective itself cannot be issued (an RCCL error).  The one-process group calls
+ * (svgp_group_elbo / svgp_group_elbo_grad) validate every member before anything is enqueued and return the first member's
+ * error without touching the communicator. */
 #define SVGP_COMM_ID_BYTES 128
 int32_t svgp_comm_unique_id(void* id_out /* SVGP_COMM_ID_BYTES */);
 int32_t svgp_ctx_attach_comm(svgp_ctx* ctx, const void* id, int32_t world_size, int32_t rank);

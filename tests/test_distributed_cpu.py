@@ -121,6 +121,13 @@ def _failing_worker(rank, world, port, out):
         def prior_kl(self):
             return 0.75, 0.0
 
+        def elbo_grad(self, data, off, length, shard=None):
+            #  the gradient step: rank 1 cannot even size its gradient blocks (the "NULL model" case of the library)
+            if rank == 1:
+                raise ValueError("no model on this rank")
+            g = dict(variance=0.1, lik_sigma2=0.2, mean_const=0.3, inv_lengthscale=np.ones(2), z=np.ones((2, 3)), m=np.ones(3), Lq=np.eye(3))
+            return -3.0, None, g
+
     sh = ShardedELBO(Model(), None, 1000.0)
     try:
         sh.step(0, 10)
@@ -129,6 +136,20 @@ def _failing_worker(rank, world, port, out):
         res = "own:" + str(e)
     except RuntimeError as e:
         res = "peer:" + str(e)
+    try:
+        sh.step_grad(0, 10, 20, world)
+        res += "|grad:no exception"
+    except ValueError as e:
+        res += "|grad own:" + str(e)
+    except RuntimeError as e:
+        res += "|grad peer:" + str(e)
+    # and the group is still usable afterwards: a healthy step on both ranks
+    class Healthy(Model):
+        def elbo_grad(self, data, off, length, shard=None):
+            g = dict(variance=0.1, lik_sigma2=0.2, mean_const=0.3, inv_lengthscale=np.ones(2), z=np.ones((2, 3)), m=np.ones(3), Lq=np.eye(3))
+            return -3.0, None, g
+    v, g = ShardedELBO(Healthy(), None, 1000.0).step_grad(0, 10, 20, world)
+    res += f"|after:{v:.1f}:{float(g['variance']):.1f}"
     with open(f"{out}.{rank}", "w") as f:
         f.write(res)
     dist.destroy_process_group()
@@ -140,8 +161,11 @@ def test_failing_rank_does_not_hang_the_others(tmp_path):
         port = s.getsockname()[1]
     out = str(tmp_path / "fail")
     mp.spawn(_failing_worker, args=(2, port, out), nprocs=2, join=True)
-    assert open(out + ".0").read().startswith("peer:a rank failed")
-    assert open(out + ".1").read().startswith("own:negative variance")
+    r0, r1 = open(out + ".0").read().split("|"), open(out + ".1").read().split("|")
+    assert r0[0].startswith("peer:a rank failed") and r1[0].startswith("own:negative variance")
+    # the gradient step (its all-reduce is sized by the model): the failing rank's own error, RuntimeError on its peer, no hang
+    assert r0[1].startswith("grad peer:a rank failed before the gradient all-reduce") and r1[1].startswith("grad own:no model on this rank")
+    assert r0[2] == r1[2] == "after:-6.0:0.2"   # the process group survived: the next step sums the two ranks
 
 
 def test_synthetic_shards_share_the_model():

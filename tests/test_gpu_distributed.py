@@ -116,6 +116,15 @@ def test_library_collective_world_of_one(centered):
         model.elbo_grad(data, 2900, 500, 0.0)
     g2 = model.elbo_grad(data, 100, 1500, 9000.0)
     assert abs(g2[0] - lv) <= 1e-12 * abs(lv)
+    # (round 6) a rank handed NO model: it cannot size the gradient all-reduce, so it takes part in the opening
+    # fixed-size all-reduce only (with the failure flag) and returns its own error; rounds 2-5 aborted the communicator here
+    import ctypes as C
+    out_, terms_, grads_ = C.c_double(), _ffi.Terms(), _ffi.Grads()
+    rc_null = ctx.lib.svgp_elbo_grad(ctx.h, None, data.h, 100, 1500, 9000.0, C.byref(out_), C.byref(terms_), C.byref(grads_))
+    assert rc_null == _ffi.INVALID_ARG
+    g3 = model.elbo_grad(data, 100, 1500, 9000.0)              # ... and the communicator is still usable
+    assert abs(g3[0] - lv) <= 1e-12 * abs(lv)
+    assert model.elbo(data, 100, 1500, 9000.0)[0] == val
     # status travels in the reduced vector: a non-PD Kuu is reported collectively
     bad = device_model(ctx, o.SVA(sva.kernel, sva.z, sva.m, sva.Lq, jitter=-1.0, centered=sva.centered, mean_const=sva.mean_const))
     with pytest.raises(_ffi.PosDefException):

@@ -137,8 +137,7 @@ def test_operational_settings_are_read_at_context_creation():
 @pytest.mark.parametrize("dtype,tol", [(np.float64, 1e-9), (np.float32, 2e-3)])
 def test_large_kuu_factorisation(ctx, dtype, tol):
     """M = 2300 (18 panels: more than the 16 row events, so cholesky(Kuu) takes the large-Kuu path: 512-thread trailing updates with
-    the next block factorisation fused in, one T-panel launch at the end; in the experiments build with SVGP_CHOL_LOOKAHEAD=1 the
-    two-stream look-ahead that round 5 measured and rejected).  The factor must be LAPACK's to rounding, the ELBO the oracle's, and
+    the next block factorisation fused in, one T-panel launch at the end).  The factor must be LAPACK's to rounding, the ELBO the oracle's, and
     repeated evaluations identical bits (a missing dependency would show as a run-to-run difference or a wrong tile)."""
     N, M, d = 3000, 2300, 3
     x, y, sva, s2 = o.synth_problem(8700, N, M, d, dtype=dtype)
