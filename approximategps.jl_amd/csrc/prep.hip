@@ -740,6 +740,109 @@ __global__ void __launch_bounds__(kThreads, 2) syrk128_kernel(T* __restrict__ A,
   }
 }
 
+// Rank-256 trailing update on 256 x 256 tiles (round 6; fp32: the C4 regime).  The 128 x 128 x 128 tiles of
+// syrk128_kernel move 61 KB per MFLOP across the L2 <-> fabric boundary (two 64 KiB operand panels and 64 KiB of C read and written per
+// 4.2 MFLOP) and run at 0.45 of the MFMA rate inside a round at ~4.6 TB/s - bandwidth-bound (profiles/round5/c4_chol_bulk.md).  Here a
+// 512-thread workgroup owns a 256 x 256 tile of the trailing matrix and contracts over TWO panels (block columns p - 1, p: the two-level
+// schedule of potrf_t): 512 KiB of operands + 512 KiB of C per 33.5 MFLOP = 30 KB per MFLOP.  A wave holds 128 x 64 of the tile
+// (8 x 4 MFMA tiles: 128 accumulator VGPRs); the operand k-rows (256 consecutive floats of a column of L: 1 KiB) travel global ->
+// registers -> LDS through two buffers, one barrier per 16-deep step; row stride 272 floats = 16 banks: the four k-rows of a fragment read
+// sit on disjoint banks.  D rows are the C rows (contiguous in memory): a lane reads-modifies-writes float4 pieces.
+// Tile (ti >= tj) in units of 256 rows from block row p + 1; diagonal tiles skip their upper-right quadrant.  FUSE: the workgroup of
+// tile (0, 0) factors the next diagonal block (potf2_body, 8 waves) as syrk128_kernel's does.
+template <bool FUSE>
+__global__ void __launch_bounds__(kThreads, 2) syrk256_kernel(float* __restrict__ A, float* __restrict__ Tm, int64_t ld, int p,
+                                                               int* __restrict__ info) {
+  using M16 = Mfma16<float>;
+  using acc_t = M16::acc_t;
+  using V4 = float __attribute__((ext_vector_type(4)));
+  constexpr int NB = kNB, TS = 256, BK = 16, LDS_LD = TS + 16, KTOT = 2 * NB, NSTEP = KTOT / BK;
+  constexpr int TILE = BK * LDS_LD;            // floats per operand tile in LDS
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  float* smem = reinterpret_cast<float*>(smem_raw);   // [2 buffers][Q tile | P tile]
+  int ti, tj;
+  tri_index(blockIdx.x, ti, tj);
+  const int64_t i0 = int64_t(p + 1 + 2 * ti) * NB, j0 = int64_t(p + 1 + 2 * tj) * NB, kc0 = int64_t(p - 1) * NB;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, g = lane >> 4;
+  const int wr = wave >> 2, wc = wave & 3;     // wave grid 2 x 4: rows wr * 128, columns wc * 64
+  const bool idle = (ti == tj) && wr == 0 && wc >= 2;   // upper-right quadrant of a diagonal tile: never read afterwards
+  const float* __restrict__ Qg = A + i0 + kc0 * ld;   // element (k, r) at Qg[k * ld + r]: rows of C
+  const float* __restrict__ Pg = A + j0 + kc0 * ld;   // element (k, c) at Pg[k * ld + c]: columns of C
+  // staging: thread t moves k-rows t / 64 and t / 64 + 8 of each operand tile, 4 floats at column (t % 64) * 4
+  const int srow = tid >> 6, scol = (tid & 63) * 4;
+  V4 sq[2], sp[2];
+  auto gload = [&](int step) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int64_t k = int64_t(step) * BK + srow + 8 * h;
+      sq[h] = *reinterpret_cast<const V4*>(Qg + k * ld + scol);
+      sp[h] = *reinterpret_cast<const V4*>(Pg + k * ld + scol);
+    }
+  };
+  auto sstore = [&](int buf) {
+    float* q = smem + buf * 2 * TILE;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      *reinterpret_cast<V4*>(q + (srow + 8 * h) * LDS_LD + scol) = sq[h];
+      *reinterpret_cast<V4*>(q + TILE + (srow + 8 * h) * LDS_LD + scol) = sp[h];
+    }
+  };
+  acc_t acc[8][4];
+#pragma unroll
+  for (int a = 0; a < 8; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = acc_t{0, 0, 0, 0};
+  gload(0);
+  sstore(0);
+  __syncthreads();
+  const float* fa0 = smem + g * LDS_LD + wr * 128 + l15;          // A operand (D rows = C rows): Q tile
+  const float* fb0 = smem + TILE + g * LDS_LD + wc * 64 + l15;    // B operand (D columns = C columns): P tile
+#pragma unroll 1
+  for (int step = 0; step < NSTEP; ++step) {
+    const int buf = step & 1;
+    if (step + 1 < NSTEP) gload(step + 1);
+    if (!idle) {
+      const float* fa = fa0 + buf * 2 * TILE;
+      const float* fb = fb0 + buf * 2 * TILE;
+#pragma unroll
+      for (int ks = 0; ks < BK / 4; ++ks) {
+        float av[8], bv[4];
+#pragma unroll
+        for (int a = 0; a < 8; ++a) av[a] = fa[ks * 4 * LDS_LD + a * 16];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) bv[b] = fb[ks * 4 * LDS_LD + b * 16];
+#pragma unroll
+        for (int a = 0; a < 8; ++a)
+#pragma unroll
+          for (int b = 0; b < 4; ++b) acc[a][b] = M16::mma(av[a], bv[b], acc[a][b]);
+      }
+    }
+    if (step + 1 < NSTEP) sstore(buf ^ 1);   // (last read in step - 1, behind that step's barrier)
+    __syncthreads();
+  }
+  if (!idle) {
+    // C[r][c] at A[(i0 + r) + (j0 + c) * ld]; D tile (a, b): rows wr * 128 + a * 16 + 4 g + q, column wc * 64 + b * 16 + l15
+    float* __restrict__ Cw = A + i0 + wr * 128 + 4 * g + (j0 + wc * 64 + l15) * ld;
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+      for (int a = 0; a < 8; ++a) {
+        V4* dst = reinterpret_cast<V4*>(Cw + a * 16 + int64_t(b) * 16 * ld);
+        V4 c = *dst;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) c[q] -= acc[a][b][q];
+        *dst = c;
+      }
+  }
+  if constexpr (FUSE) {
+    if (blockIdx.x != 0) return;   // the owner of tile (0, 0), which holds block (p + 1, p + 1), goes on to factor it
+    __threadfence();               // the block this workgroup just wrote is re-read below (through L2: drop stale L1 lines)
+    __syncthreads();
+    potf2_body<float, kThreads / 64>(A + int64_t(p + 1) * NB * (ld + 1), Tm + int64_t(p + 1) * NB * (ld + 1), ld, info, (p + 1) * NB, smem_raw);
+  }
+}
+constexpr size_t kSyrk256LdsBytes = size_t(2) * 2 * 16 * (256 + 16) * sizeof(float);
+
 // ------------------------------------------------------------------------------------------------
 template <typename T>
 __global__ void pack_q_kernel(const T* __restrict__ Lq, int64_t ldq, const T* __restrict__ m, int64_t M, int64_t Mp,
@@ -1009,47 +1112,24 @@ void potrf_t(hipStream_t s, T* A, T* Tm, int64_t Mp, int* info, unsigned* sync, 
   // saves the 25 us of a launch of their own); from 17 panels on they would lengthen 60-odd serial launches instead (C4: +0.33 ms
   // in the TRSM launches against the 0.15 ms of one launch over all 2016 tiles at the end), so a large Kuu keeps the one launch.
   const bool t_inside = nP <= 16;
-  // ---- two-level blocking (round 4): 256-wide outer panels for a large Kuu -------------------------------
+  // ---- two-level blocking for a large fp32 Kuu (round 4 schedule, round 6 kernel) -----------------------------------------------------
   // Per outer panel (block columns a, b = a + 1):  TRSM(a);  update of block column b alone + factorisation of (b, b) in the same
-  // launch;  TRSM(b);  ONE rank-256 update of everything right of b (+ the factorisation of the next diagonal block in it).
-  // The trailing matrix is read and written once per 256 columns instead of once per 128.
-  // Round 4 (profiles/round4/chol_two_level.md; fp32, ms per factorisation, same box): M = 8192 one-level 4.89, two-level 5.00; 4224 1.88 /
-  // 1.97; 2304 0.976 / 1.02 - with the 128 x 128-tile update the rank-256 form is no faster per flop than two of rank 128 (it is the
-  // OPERAND stream and the C tile's read-modify-write that bound a 128 x 128 x K tile, and K only amortises the second), while the
-  // column-b step puts a second launch per 256 columns on the serial chain.  Experiments build: SVGP_CHOL_TWO_LEVEL=1.
+  // launch;  TRSM(b);  ONE rank-256 update of everything right of b on 256 x 256 tiles (syrk256_kernel: half the bytes per flop of the
+  // 128 x 128 x 128 tiles) with the factorisation of the next diagonal block fused in.  Taken pair by pair while the rank-256 launch
+  // beats the two rank-128 launches it replaces (it runs one workgroup per CU: whole rounds of `ncus` tiles); the rest of the matrix
+  // takes the one-level steps.  Round 4 built this schedule on the 128 x 128 tiles (kb = 2) and found it no faster than one level
+  // (M = 8192 4.89 / 5.00 ms, profiles/round4/chol_two_level.md): K only amortises the C tile's read-modify-write, not the operand stream.
+  // Round 6, with the 256 x 256 tiles (profiles/round6/c4_chol_256.md; same box, fp32, ms per factorisation, one level / two levels):
+  // M = 8192 4.57 / 4.73, 6144 2.74 / 2.87, 4096 1.59 / 1.59 - NOT ADOPTED.  A tile takes 100-110 us for its 57 us of MFMA work (0.55 of the
+  // rate: the 512 KiB read-modify-write of C is not hidden behind anything with one 202-VGPR workgroup per CU, ~30 us at the ~18 GB/s
+  // a CU draws across the fabric), a launch is whole rounds of 256 tiles (496 tiles: 200 us), and the column step puts a 40-44 us launch
+  // (its fused block factorisation is no longer hidden inside a big update) on the chain of every pair: 262 us for the first pair against
+  // ~300 us one-level, break-even from the fifth pair on, a loss where the cost rule's optimistic 62 us per round still took them.
+  // Experiments build: SVGP_CHOL_TWO_LEVEL=1 (tests/test_gpu_round6.py runs it).
   // the big fused update: whole 128 x 128 tiles on 512 threads (kbb = 2: rank-256, the two-level form)
   auto big_update = [&](int nt, int pp, int kbb) {
     hipLaunchKernelGGL((syrk128_kernel<T, true>), dim3(nt), dim3(kThreads), lds_fused_l, s, A, Tm, Mp, pp, info, kbb);
   };
-#ifdef SVGP_EXPERIMENTS
-  static const bool two_level_on = exp_int("SVGP_CHOL_TWO_LEVEL", 0) == 1;
-  set_max_lds(reinterpret_cast<const void*>(chol_tile_kernel<T, MODE_COL, CNT, true>), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds_fused_s));
-  if (two_level_on && fuse_on && !t_inside && sizeof(T) == 4) {
-    potf2(0);
-    for (int a = 0; a < nP; a += 2) {
-      const int b = a + 1, na = nP - a - 1;
-      if (na > 0) {
-        hipLaunchKernelGGL((chol_tile_kernel<T, MODE_TRSM, CNT>), dim3(na * NCH), dim3(k256), lds_tile, s, A, Tm, Mp, a, na, info, sync, 1);
-        dbg("chol trsm (a)", s);
-      }
-      if (b >= nP) break;
-      // block column b: A[i, b] -= L[i, a] L[b, a]' for i >= b, then the workgroup that completes tile (b, b) factors it
-      hipLaunchKernelGGL((chol_tile_kernel<T, MODE_COL, CNT, true>), dim3(na * NCH), dim3(k256), lds_fused_s, s, A, Tm, Mp, a, na, info, sync, 1);
-      dbg("chol column update + potf2 (b)", s);
-      const int nb = nP - b - 1;
-      if (nb == 0) break;
-      hipLaunchKernelGGL((chol_tile_kernel<T, MODE_TRSM, CNT>), dim3(nb * NCH), dim3(k256), lds_tile, s, A, Tm, Mp, b, nb, info, sync, 1);
-      dbg("chol trsm (b)", s);
-      const int nt = nb * (nb + 1) / 2;
-      if (nt >= 256) big_update(nt, b, 2);
-      else hipLaunchKernelGGL((chol_tile_kernel<T, MODE_SYRK, CNT, true>), dim3(nt * NCH), dim3(k256), lds_fused_s, s, A, Tm, Mp, b, nb, info, sync, 2);
-      dbg("chol rank-256 update + potf2 (next a)", s);
-    }
-    hipLaunchKernelGGL((chol_tile_kernel<T, MODE_TRSM, CNT>), dim3((nP * (nP - 1) / 2) * NCH), dim3(k256), lds_tile, s, A, Tm, Mp, -1, 0, info, sync, 1);
-    dbg("T panels", s);
-    return;
-  }
-#endif
   // Measured and rejected forms of this schedule, no longer in the tree (profiles/round6/removed_variants.patch): a two-stream look-ahead
   // with the bulk update one panel behind the chain (round 5: bitwise the same factor, 8-15 % slower - two cross-stream dependencies
   // per panel cost more than the idle time they reclaim; profiles/round5/chol_lookahead_ab.log), one launch per panel with a flag
@@ -1057,7 +1137,7 @@ void potrf_t(hipStream_t s, T* A, T* Tm, int64_t Mp, int* info, unsigned* sync, 
   // profiles/round4/chol_chain.md), the big update on the asynchronous three-buffer loop (round 4) and in an XCD-aware tile order
   // (round 5: no gain, profiles/round5/syrk_xcd_ab.log).
   potf2(0);
-  for (int p = 0; p < nP; ++p) {
+  auto step1 = [&](int p) {   // one-level panel step p: TRSM (+ T panels), trailing update with the next block factorisation
     const int n = nP - p - 1, nt_p = t_inside ? p : 0;
     // block row p of T (inv(L_pp) from the block factorisation, T[p, J < p] from the TRSM launch) is final behind that launch: the
     // strips' phase 1 of panel p may start (api.hip: SegRun - the row hook below enqueues the waiter on its own stream).  The event
@@ -1081,7 +1161,7 @@ void potrf_t(hipStream_t s, T* A, T* Tm, int64_t Mp, int* info, unsigned* sync, 
       if (!ev_done) (void)hipEventRecord(row_events[p], s);
       if (hook && hook->fn) hook->fn(hook->user, p);   // the waiters of this row are enqueued now, not after the whole chain (host time)
     }
-    if (n == 0) break;
+    if (n == 0) return;
     const int nt = n * (n + 1) / 2;
     const bool large = nt >= 256;   // a trailing matrix that fills the chip by itself: full 128 x 128 tiles (half the operand traffic)
     // the fused f64 form of the large grid would cost the second resident workgroup (potf2's LDS image of an f64 block is 146 KiB)
@@ -1099,7 +1179,38 @@ void potrf_t(hipStream_t s, T* A, T* Tm, int64_t Mp, int* info, unsigned* sync, 
       potf2(p + 1);
     }
     dbg("chol syrk", s);
+  };
+  int p = 0;
+  if constexpr (sizeof(T) == 4 && kExperiments) {   // MEASURED AND NOT ADOPTED (below): the product build takes the one-level steps throughout
+    // (read per call: tests and A/B runs change them inside one process)
+    const int two_level = exp_int("SVGP_CHOL_TWO_LEVEL", 0);         // 1 = two-level pairs where the cost rule takes them
+    const double t256_us = exp_double("SVGP_CHOL_T256_US", 105.0);   // a round of 256 x 256 x 256 tiles (one per CU): measured 100-110 us
+    const double t128_us = exp_double("SVGP_CHOL_T128_US", 15.3);    // a round of 128 x 128 x 128 tiles (profiles/round5/c4_syrk_occupancy.log)
+    if (two_level && fuse_on && !t_inside && ncus > 0) {
+      set_max_lds(reinterpret_cast<const void*>(chol_tile_kernel<T, MODE_COL, CNT, true>), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds_fused_s));
+      constexpr size_t lds256 = kSyrk256LdsBytes > lds_potf2 ? kSyrk256LdsBytes : lds_potf2;
+      set_max_lds(reinterpret_cast<const void*>(syrk256_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds256));
+      while (p + 2 < nP) {
+        const int a = p, b = a + 1, na = nP - a - 1, nb = nP - b - 1;
+        if (nb % 2 != 0) { step1(p++); continue; }   // (256-row tiles from block row a + 2 on: an even number of block rows)
+        const int n2 = nb / 2, t256 = n2 * (n2 + 1) / 2;
+        const double cost256 = double((t256 + ncus - 1) / ncus) * t256_us + 15.0;   // + the column launch the pair adds to the chain
+        const double cost128 = (double(na) * (na + 1) / 2 + double(nb) * (nb + 1) / 2) * t128_us / double(ncus);
+        if (cost256 >= cost128) { step1(p++); continue; }
+        hipLaunchKernelGGL((chol_tile_kernel<T, MODE_TRSM, CNT>), dim3(na * NCH), dim3(k256), lds_tile, s, A, Tm, Mp, a, na, info, sync, 1);
+        dbg("chol trsm (a)", s);
+        // block column b: A[i, b] -= L[i, a] L[b, a]' for i >= b, then the workgroup that completes tile (b, b) factors it
+        hipLaunchKernelGGL((chol_tile_kernel<T, MODE_COL, CNT, true>), dim3(na * NCH), dim3(k256), lds_fused_s, s, A, Tm, Mp, a, na, info, sync, 1);
+        dbg("chol column update + potf2 (b)", s);
+        hipLaunchKernelGGL((chol_tile_kernel<T, MODE_TRSM, CNT>), dim3(nb * NCH), dim3(k256), lds_tile, s, A, Tm, Mp, b, nb, info, sync, 1);
+        dbg("chol trsm (b)", s);
+        hipLaunchKernelGGL(syrk256_kernel<true>, dim3(t256), dim3(kThreads), lds256, s, reinterpret_cast<float*>(A), reinterpret_cast<float*>(Tm), Mp, b, info);
+        dbg("chol rank-256 update + potf2 (next a)", s);
+        p += 2;
+      }
+    }
   }
+  for (; p < nP; ++p) step1(p);
   if (!t_inside) {
     hipLaunchKernelGGL((chol_tile_kernel<T, MODE_TRSM, CNT>), dim3((nP * (nP - 1) / 2) * NCH), dim3(k256), lds_tile, s, A, Tm, Mp, -1, 0, info, sync);
     dbg("T panels", s);

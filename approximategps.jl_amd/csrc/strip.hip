@@ -286,7 +286,7 @@ __global__ void __launch_bounds__(NTHR, MINW) strip_kernel(StripArgs a, int64_t 
     }
     SVGP_SSTAMP_STRIP_BEGIN();
     SVGP_SSTAMP(0);
-    if constexpr (SVGP_STRIP_PRIO == 2) ++prio_strips; else strip_prio<GRAD && !SEG>(prio_strips++);
+    strip_prio<GRAD && !SEG>(prio_strips++);
     const int64_t c0 = strip * NT;                          // first column of the strip inside the batch
     if constexpr (SEG) { if (tid == 0) next_strip = unsigned(strip + gridDim.x); }   // static schedule: launches are at most one round
     else if (tid == 0) next_strip = gridDim.x + atomicAdd(a.counter, 1u);
@@ -369,7 +369,6 @@ __global__ void __launch_bounds__(NTHR, MINW) strip_kernel(StripArgs a, int64_t 
     SVGP_SSTAMP(1);
     for (int I = I_lo; I < I_hi; ++I) {
       SVGP_SSTAMP(2 + 3 * I);
-      if constexpr (SVGP_STRIP_PRIO == 2) strip_prio<GRAD && !SEG>(prio_strips - 1);
       Acc acc;
       acc.zero();
       // the last NB/BK steps multiply the lower-triangular inv(L_II): their zero 16-row tiles are skipped
@@ -476,7 +475,6 @@ __global__ void __launch_bounds__(NTHR, MINW) strip_kernel(StripArgs a, int64_t 
       if constexpr (SEG) { p3_lo = (part * nP) / nsplit; p3_hi = ((part + 1) * nP) / nsplit; }
       for (int I = p3_lo; I < p3_hi; ++I) {
         SVGP_SSTAMP(26 + 4 * I);   // (diagnostic builds, nP <= 8) phase 3: loop start / loop end / after the K-dot / after the point-major store
-        if constexpr (SVGP_STRIP_PRIO == 2) strip_prio<!SEG>(prio_strips - 1);
         Acc acc;
         acc.zero();
         if constexpr (SVGP_ASYNC && G::kAsync) {
