@@ -1503,7 +1503,8 @@ struct GradCall {
 // (half the k-steps).  One workgroup pair per tile is 72 (128) workgroups at M = 1024 for 256 CUs, so the product is split
 // along K into slices whose partials land in `scratch` ([ns][Mp][Mp], the SYRK's slice buffer when it is idle) and are summed
 // in a fixed order.  The result OVERWRITES `out` (no pre-zeroing: round 2 spent a memset per product on it).
-void gemm_mm(svgp_ctx* ctx, GradWs* w, int dt, hipStream_t s, const void* Xt, const void* Yt, int64_t Mp, void* out, int flags = 0) {
+void gemm_mm(svgp_ctx* ctx, GradWs* w, int dt, hipStream_t s, const void* Xt, const void* Yt, int64_t Mp, void* out, int flags = 0,
+             void* scratch = nullptr) {   // scratch: [min(nP, nslices)][Mp][Mp] instead of the SYRK's slice buffer
   const int nP = int(Mp / 128), ntiles = (flags & kMmFull) ? nP * nP : nP * (nP + 1) / 2;
   int ns = (2 * ctx->num_cus) / (ntiles * (dt == SVGP_F64 ? 2 : 1));   // fill the workgroup slots once (f64: two 128 x 64 halves per tile)
   if (ns > nP) ns = nP;                         // at least 8 k-steps of 16 per slice
@@ -1514,8 +1515,9 @@ void gemm_mm(svgp_ctx* ctx, GradWs* w, int dt, hipStream_t s, const void* Xt, co
     return;
   }
   const int64_t sl = ((Mp + ns - 1) / ns + 15) / 16 * 16;
-  launch_gemm_pm(dt, s, Xt, Yt, nullptr, 1.0, Mp, Mp, sl, ns, w->G1, 1, flags);
-  launch_sum_slices_lower(dt, s, w->G1, ns, Mp, out, (flags & kMmFull) ? 1 : 0, 1);
+  void* sc = scratch ? scratch : w->G1;
+  launch_gemm_pm(dt, s, Xt, Yt, nullptr, 1.0, Mp, Mp, sl, ns, sc, 1, flags);
+  launch_sum_slices_lower(dt, s, sc, ns, Mp, out, (flags & kMmFull) ? 1 : 0, 1);
 }
 
 int grad_enqueue_impl(svgp_ctx* ctx, svgp_model* m, const svgp_data* data, int64_t off, int64_t len, GradCall& gc);
@@ -1602,6 +1604,20 @@ int grad_enqueue_impl(svgp_ctx* ctx, svgp_model* m, const svgp_data* data, int64
   // the SYRK's weights 2 g_v are uniform over the points for the built-in Gaussian likelihood (grad.hip: UW) unless a variance was
   // negative and clamped (then that point's g_v differs... it does not: dE/dv = -1 / (2 sigma^2) whatever v) - so: Gaussian, built in
   const bool uniform_w = m->desc.likelihood == SVGP_LIK_GAUSSIAN && !gc.ext_gmu && m->gh_n == 0 && ctx->kn.syrk_uniform;   // (knob: experiments build)
+  // Round 6: strips beside the factorisation + uniform weights = the SYRK needs nothing but A, which phase 1 has
+  // written by the time the chain ends - so it goes on the second stream right behind the last phase-1 segment, BESIDE the M-sized prep
+  // of phase 3 on the main stream (Lk^-1 by recursive doubling, R, alpha: ~230 us of small launches at M = 1024), instead of behind
+  // phase 3 and the kernel-gradient reductions.  Same kernel, same slices, same single overwrite of the slice buffer: bitwise the
+  // serial result.  The one M x M product that runs meanwhile (R) takes a split-K scratch of its own.  Measured (same box, update +
+  // value and gradient, ms): 16 384 points M = 1024 f64 2.72 -> 2.67, fp32 1.94 -> 1.88; 4 096 points 1.87 -> 1.81 - the SYRK's 504
+  // workgroups and the prep's small launches slow each other, so only a quarter of the 230 us comes back (profiles/round6/minibatch_trace.md).
+  static const int early_knob = exp_int("SVGP_SYRK_EARLY", 1);   // (experiments build: 0 = the SYRK behind phase 3, as rounds 3-5)
+  const bool syrk_early = gop.on && uniform_w && early_knob != 0;
+  if (syrk_early && !w->Gmm) {
+    const size_t gmm_b = size_t(std::min<int64_t>(Mp / 128, w->nslices)) * size_t(Mp) * size_t(Mp) * m->es;
+    if (hipMalloc(&w->Gmm, gmm_b) != hipSuccess) { w->Gmm = nullptr; return fail(ctx, SVGP_OOM, "hipMalloc failed for the gradient workspace"); }
+    w->all.push_back(w->Gmm);
+  }
   // the strips' arguments for the chunk [c0, c0 + clen) (scratch / moment pointers: read after the ensure_scratch of the caller)
   auto strip_args = [&](int64_t c0, int64_t clen, LikParams& lpc) -> StripArgs {
     StripArgs a{};
@@ -1668,7 +1684,7 @@ int grad_enqueue_impl(svgp_ctx* ctx, svgp_model* m, const svgp_data* data, int64
   launch_linv(dt, s, m->L, m->T, Mp, w->LinvRM, w->LinvCM, w->H);
   // M-sized operands of the strips' phase 3:  R = Lk^-T (B B' - I)  (column-major: the P operand of the GEMM); then, for the
   // kernel-gradient reductions behind the strips, alpha = Lk^-T m~ (no strip reads it: it follows ev_R)
-  gemm_mm(ctx, w, dt, s, w->tmp, w->LinvRM, Mp, w->Rcm, kMmFull | kMmYLow); // out[c][r] = sum_k S[k][c] Linv[k][r] = R[r][c]: R column-major
+  gemm_mm(ctx, w, dt, s, w->tmp, w->LinvRM, Mp, w->Rcm, kMmFull | kMmYLow, syrk_early ? w->Gmm : nullptr); // out[c][r] = sum_k S[k][c] Linv[k][r] = R[r][c]: R column-major
   KCHECK(ctx, "grad prep");
   if (gop.on) HIPC(ctx, hipEventRecord(ctx->ev_R, s));   // R is final: the segmented strips' closing launch (phase 3) may run
   launch_linv_t_gemv(dt, s, w->LinvRM, m->mp, Mp, w->alpha, w->gemv_part);
@@ -1746,6 +1762,12 @@ int grad_enqueue_impl(svgp_ctx* ctx, svgp_model* m, const svgp_data* data, int64
         if (rc) return rc;
         cgrid = int(nstrips) * S;
       }
+      if (syrk_early) {   // W = w A A' behind the last phase-1 segment, beside the main stream's Lk^-1 / R / alpha
+        const int64_t n16 = (clen + 15) / 16 * 16, sl_e = ((ncp + ns_syrk - 1) / ns_syrk + 15) / 16 * 16;
+        if (n16 > clen) HIPC(ctx, hipMemsetAsync(static_cast<char*>(L.At) + size_t(clen) * size_t(Mp) * es, 0, size_t(n16 - clen) * size_t(Mp) * es, s2));
+        launch_syrk_uniform(dt, s2, L.At, -0.5 / lp.sigma2, scale, n_global_dev, gc.num_data, 2.0, Mp, n16, sl_e, ns_syrk, w->G1, 1);
+        KCHECK(ctx, "syrk (beside the prep of phase 3)");
+      }
       HIPC(ctx, hipStreamWaitEvent(s2, ctx->ev_R, 0));
       a.seg_lo = a.seg_hi = nPn;
       a.seg_flags = kSegLoad | kSegPhase2;
@@ -1790,7 +1812,9 @@ int grad_enqueue_impl(svgp_ctx* ctx, svgp_model* m, const svgp_data* data, int64
     launch_sum5(s, L.partial5, n5, w->sums);
     int64_t sl = ((ncp + ns_syrk - 1) / ns_syrk + 15) / 16 * 16;   // as even as the 16-point k-step allows
     // W (+)= A diag(2 g_v) A' (lower tiles, split-K slices): the first chunk overwrites, so the slice buffer needs no zeroing
-    if (uniform_w) {
+    if (syrk_early) {
+      // (already on the second stream, joined above)
+    } else if (uniform_w) {
       // g_v is the same for every point (Gaussian: -scale / (2 sigma^2)): the unweighted loop, the weight applied to the accumulators.
       // Columns of the chunk's last strip beyond its last point hold the replicated last point: zero them up to the k-step boundary
       const int64_t n16 = (clen + 15) / 16 * 16;

@@ -72,6 +72,7 @@ struct GradWs {
   void *Lqp = nullptr, *G1 = nullptr, *G2 = nullptr, *LkRM = nullptr, *LbarRM = nullptr, *Phi = nullptr,
        *tmp = nullptr, *H = nullptr, *BbarRM = nullptr, *rbar = nullptr;
   void *LinvRM = nullptr, *LinvCM = nullptr;   // Lk^-1 in both storage orders (launch_linv): every Lk^-T . of the tail is a GEMM with it
+  void* Gmm = nullptr;   // split-K scratch of the M x M products that run BESIDE an early SYRK (api.hip: syrk_early), allocated on first use
   void *W2 = nullptr, *Rcm = nullptr, *G1p = nullptr, *alpha = nullptr;   // W = A diag(2 g_v) A', R = Lk^-T (Lq Lq' - I), 2 W Lq, Lk^-T m
   // the user-layout gradient blocks {z_bar (M d) | m_bar (M) | Lq_bar (M^2)}: ONE allocation, contiguous for the model's M, so
   // that the data-parallel sum is one ncclAllReduce and the read-back one copy; zbar / mbar / Lqbar point into it (set per call)

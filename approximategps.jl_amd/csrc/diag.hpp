@@ -3,7 +3,8 @@
 // diag::ablate<BIT> is false (the `if constexpr` around it folds away) and the stamp macros expand to nothing.
 //   tools/build_ablate.sh strip N       -DSVGP_ABLATE=N       timing-only ablations of the strip kernels - WRONG results by construction:
 //                                                             bit 1 no P-tile loads / DMA, 2 no Q-tile loads / DMA, 4 no scratch stores of A,
-//                                                             16 cheap column sums, 32 no point-major A, 64 no point-major R A, 128 no K-dot
+//                                                             16 cheap column sums, 32 no point-major A, 64 no point-major R A, 128 no K-dot,
+//                                                             256 the value-and-gradient strips overwrite Kuf by A in place (one scratch strip)
 //   tools/build_ablate.sh stripstamps x -DSVGP_STRIP_STAMPS   s_memtime stamps at the phase boundaries of a strip (tools/strip_stamps*.py)
 //   tools/build_ablate.sh stamps x      -DSVGP_POTF2_STAMPS   s_memtime stamps inside the block factorisation (tools/potf2_time.py)
 // A translation unit that owns stamp storage defines SVGP_DIAG_TU_STRIP / SVGP_DIAG_TU_PREP before including this file.

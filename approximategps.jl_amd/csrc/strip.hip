@@ -258,7 +258,7 @@ __global__ void __launch_bounds__(NTHR, MINW) strip_kernel(StripArgs a, int64_t 
   T* __restrict__ work = static_cast<T*>(a.work) + int64_t(blockIdx.x) * Mp * NT;   // SEG: re-pointed per strip below
   // GRAD: the generated Kuf block keeps a scratch strip of its own (the A strip goes beside it instead of overwriting it panel by
   // panel): phase 3's epilogue needs K again for the variance (see below).  Forward builds: one strip, K overwritten in place.
-  T* __restrict__ workK = GRAD ? static_cast<T*>(a.work) + (int64_t(gridDim.x) + blockIdx.x) * Mp * NT : work;   // not const: SEG re-points it
+  T* __restrict__ workK = (GRAD && !diag::ablate<256>) ? static_cast<T*>(a.work) + (int64_t(gridDim.x) + blockIdx.x) * Mp * NT : work;   // not const: SEG re-points it
   const int tid = threadIdx.x, lane = tid & 63;
   const typename G::QOff qoff = G::q_offsets(NT);           // per-thread byte offsets inside a scratch-strip tile
 
