@@ -819,7 +819,12 @@ def main():
         try:
             # the shader clock during C5's timed region (0.1 s of back-to-back 5 ms steps, sampled every 10 ms): a short region runs on a
             # clock that is still ramping, which is what separates its roofline fraction from a profiled run's
-            tel5 = GpuTelemetry(local_rank, period=0.01).start() if rank == 0 else None
+            try:
+                pr5 = torch.cuda.get_device_properties(local_rank)
+                pci5 = f"{pr5.pci_domain_id:04x}:{pr5.pci_bus_id:02x}:{pr5.pci_device_id:02x}.0"
+            except Exception:  # noqa: BLE001
+                pci5 = None
+            tel5 = GpuTelemetry(local_rank, period=0.01, pci_bus_id=pci5).start() if rank == 0 else None
             c5, m5, d5, _ = bench_config(args, "C5", ctx, torch, dist, dev, world, rank, use_dist, max(20, args.steps), 5,
                                          num_data_override=C5_NUM_DATA, host_comm=host_comm, resident=args.c5_resident)
             clk5 = GpuTelemetry.summarize(tel5.stop(), *c5["t_region"]) if tel5 else None
@@ -831,6 +836,7 @@ def main():
                      "breakdown_ms": c5["breakdown_ms"], "elbo": c5["elbo"], "n_points_global": c5["n_points_global"]}
             if clk5 is not None:
                 c5out["shader_clock_mhz_during_timed_region"] = clk5.get("sclk_mhz")
+                c5out["shader_clock_source"] = {"card": tel5.card, "matched_by_pci_bus_id": tel5.card_matched_by_pci}
                 c5out["shader_clock_note"] = ("roofline.frac is flops / time / the 2.4 GHz peak: a region run at a lower (ramping or power-limited) "
                                               "clock reads proportionally lower; samples = " + str(clk5.get("samples")))
             if not args.no_grad and not host_comm:
