@@ -1737,7 +1737,7 @@ int grad_enqueue_impl(svgp_ctx* ctx, svgp_model* m, const svgp_data* data, int64
       if (kc >= pc.lanes) HIPC(ctx, hipStreamWaitEvent(ss, L.ev_done, 0));   // the lane's previous chunk has been consumed
     }
     if (trail && kc >= pc.lanes) HIPC(ctx, hipStreamWaitEvent(s, L.ev_done, 0));   // the reductions of the lane's previous chunk have read P / g
-    HIPC(ctx, hipMemsetAsync(L.gmu, 0, 2 * size_t(w->nc) * es, ss));   // g_mu | g_v, w->nc apart (the SYRK reads g_v over the padded chunk)
+    // (g_mu | g_v, w->nc apart: the weighted SYRK reads g_v over the chunk padded to 128 points - launch_point_grads writes that padding)
     LikParams lpc{};
     StripArgs a = gop.on ? gseg.a : strip_args(c0, clen, lpc);
     if (gop.on) lpc = lpc_seg;
@@ -1776,11 +1776,13 @@ int grad_enqueue_impl(svgp_ctx* ctx, svgp_model* m, const svgp_data* data, int64
       HIPC(ctx, hipEventRecord(ctx->ev_join, s2));
       HIPC(ctx, hipStreamWaitEvent(s, ctx->ev_join, 0));
     } else {
-      HIPC(ctx, hipMemsetAsync(a.counter, 0, sizeof(unsigned), ss));
+      // the head of the strips' queue: zeroed here for the first chunk, by the previous chunk's launch_point_grads for the others
+      if (kc == 0 || pipe_any) HIPC(ctx, hipMemsetAsync(a.counter, 0, sizeof(unsigned), ss));
       launch_strip_grad(dt, ss, a, nt, grid, nstrips);
       KCHECK(ctx, "strip (value and gradient)");
     }
-    launch_point_grads(dt, ss, lpc, a.mom_mu, a.mom_var, gc.ext_gmu ? nullptr : data->y, off + c0, clen, scale, n_global_dev, gc.num_data, L.gmu, L.gv, L.partial5);
+    launch_point_grads(dt, ss, lpc, a.mom_mu, a.mom_var, gc.ext_gmu ? nullptr : data->y, off + c0, clen, scale, n_global_dev, gc.num_data, L.gmu, L.gv, L.partial5,
+                       (!gop.on && !pipe_any) ? a.counter : nullptr, ncp);
     KCHECK(ctx, "point gradients");
     const int n5 = point_grad_blocks(clen);   // rows of partial5: one per 256-point block
     if (pipe) {   // the consumers of this chunk: on the main stream, behind the chunk's strips

@@ -132,7 +132,7 @@ void launch_strip_grad(int dtype, hipStream_t s, const StripArgs& a, int nt, int
 int point_grad_blocks(int64_t len);
 void launch_point_grads(int dtype, hipStream_t s, const LikParams& lp, const double* mom_mu, const double* mom_var, const void* y,
                         int64_t off, int64_t len, double scale, const double* n_global_dev, double num_data, void* gmu_out,
-                        void* gv_out, double* part5);
+                        void* gv_out, double* part5, unsigned* strip_queue = nullptr, int64_t pad_to = 0);
 // marginals + expected log-likelihood of every point (SVA:354-355): per-block sums into partial/negcnt
 int expect_blocks(int64_t len);
 void launch_expect(int dtype, hipStream_t s, const LikParams& lp, const double* mom_mu, const double* mom_var,

@@ -641,9 +641,13 @@ __global__ void __launch_bounds__(k256) point_grad_kernel(LikParams lp, const do
                                                           const double* __restrict__ mom_var, const T* __restrict__ y, int64_t off,
                                                           int64_t len, double scale_host, const double* __restrict__ n_global_dev,
                                                           double num_data, T* __restrict__ gmu_out, T* __restrict__ gv_out,
-                                                          double* __restrict__ part5) {
+                                                          double* __restrict__ part5, unsigned* __restrict__ strip_queue, int64_t pad_to) {
   __shared__ double sh[5][k256];
   const int64_t i = int64_t(blockIdx.x) * k256 + threadIdx.x;
+  // (round 6: two fills per gradient chunk - the head of the strips' queue and the padding of g_mu | g_v - ride in this launch, which
+  // follows the chunk's strips on their stream: 32 launches less per H-sized evaluation)
+  if (strip_queue && blockIdx.x == 0 && threadIdx.x == 0) *strip_queue = 0u;
+  if (i >= len && i < pad_to) { gmu_out[i] = T(0); gv_out[i] = T(0); }
   double e5[5] = {0, 0, 0, 0, 0};
   if (i < len) {
     const double scale = n_global_dev ? (num_data > 0.0 ? num_data / *n_global_dev : 1.0) : scale_host;
@@ -1200,14 +1204,16 @@ int point_grad_blocks(int64_t len) { return int((len + k256 - 1) / k256); }
 
 void launch_point_grads(int dtype, hipStream_t s, const LikParams& lp, const double* mom_mu, const double* mom_var, const void* y,
                         int64_t off, int64_t len, double scale, const double* n_global_dev, double num_data, void* gmu_out,
-                        void* gv_out, double* part5) {
+                        void* gv_out, double* part5, unsigned* strip_queue, int64_t pad_to) {
+  // strip_queue (nullable): zeroed for the NEXT launch of the strips; pad_to: g_mu, g_v of the points [len, pad_to) are written as zeros
+  // (pad_to <= the 256-point blocks of the launch: the weighted SYRK reads g_v over the chunk padded to 128 points)
   const int nb = point_grad_blocks(len);
   if (dtype == 0)
     hipLaunchKernelGGL(point_grad_kernel<double>, dim3(nb), dim3(k256), 0, s, lp, mom_mu, mom_var, (const double*)y, off, len, scale,
-                       n_global_dev, num_data, (double*)gmu_out, (double*)gv_out, part5);
+                       n_global_dev, num_data, (double*)gmu_out, (double*)gv_out, part5, strip_queue, pad_to);
   else
     hipLaunchKernelGGL(point_grad_kernel<float>, dim3(nb), dim3(k256), 0, s, lp, mom_mu, mom_var, (const float*)y, off, len, scale,
-                       n_global_dev, num_data, (float*)gmu_out, (float*)gv_out, part5);
+                       n_global_dev, num_data, (float*)gmu_out, (float*)gv_out, part5, strip_queue, pad_to);
 }
 
 int expect_blocks(int64_t len) {
