@@ -19,3 +19,5 @@ python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | f | tail -n 3 | tee $O
 # the driver's N > 1 launch form, on this one-GPU box with one rank
 (timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 1 --steps 5 --warmup 2 --no-cpu-baseline --no-c5 2>&1 | f | tail -n 1 | cut -c1-300) | tee $O/bench_torchrun_n1.log
 cp approximategps.jl_amd/csrc/build.log $O/build.log 2>/dev/null
+# soak runs on the final library (create / evaluate / free loop; strips beside / behind the factorisation)
+(timeout 200 python tests/soak.py 60 2>&1 | tail -n 3; timeout 300 python tests/soak_overlap.py 200 2>&1 | tail -n 2) | tee $O/soak.log
