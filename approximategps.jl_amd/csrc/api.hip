@@ -1806,7 +1806,7 @@ int grad_enqueue_impl(svgp_ctx* ctx, svgp_model* m, const svgp_data* data, int64
       HIPC(ctx, hipStreamWaitEvent(sk, ctx->ev_fork, 0));
     }
     int64_t ksl = ((clen + w->ns_uf - 1) / w->ns_uf + 127) / 128 * 128;
-    launch_kgrad(dt, sk, kp, m->zs, Mp, data->x, data->ldx, off + c0, 0, clen, clen, L.Pt, L.gmu, L.gv, w->alpha, ksl, w->ns_uf,
+    launch_kgrad(dt, sk, kp, m->zs, Mp, M, data->x, data->ldx, off + c0, 0, clen, clen, L.Pt, L.gmu, L.gv, w->alpha, ksl, w->ns_uf,
                  w->rp_uf, w->sp_uf, 1);
     KCHECK(ctx, "kgrad uf");
     if (kg_overlap) HIPC(ctx, hipEventRecord(ctx->ev_join, sk));
@@ -1868,7 +1868,7 @@ int grad_enqueue_impl(svgp_ctx* ctx, svgp_model* m, const svgp_data* data, int64
   // the Kuu part: the ns_uu slices must cover all M columns (a fixed slice of 128 covered only 1024 of them: the kernel-
   // parameter and z gradients were wrong for M > 1024 until tests/test_gpu_grad.py::test_gradient_large_m_float32_strips)
   const int64_t uu_sl = ((M + w->ns_uu - 1) / w->ns_uu + 127) / 128 * 128;
-  launch_kgrad(dt, s, kp, m->zs, Mp, m->zs, Mp, 0, 1, M, M, w->H, nullptr, nullptr, nullptr, uu_sl, w->ns_uu, w->rp_uu, w->sp_uu);
+  launch_kgrad(dt, s, kp, m->zs, Mp, M, m->zs, Mp, 0, 1, M, M, w->H, nullptr, nullptr, nullptr, uu_sl, w->ns_uu, w->rp_uu, w->sp_uu);
   launch_finish_kgrad(dt, s, m->d, M, Mp, m->zs, w->invl_d, w->rp_uf, w->ns_uf, w->rp_uu, w->ns_uu, w->sp_uf, w->ns_uf * w->rb,
                       w->sp_uu, w->ns_uu * w->rb, m->mp, klw, m->desc.layout_z, m->desc.variance, w->zbar, centered ? nullptr : w->mbar,
                       w->scal_out, w->kred, w->avec);

@@ -392,9 +392,15 @@ __device__ __forceinline__ void kappa_and_d(T r2, T variance, T& k, T& dk) {
 // per-workgroup partials add up), C_j by a DPP butterfly over the 16 lanes of a row group.  d <= 8: the eight spare columns of the one
 // feature tile carry x_f^2 instead and give sum_j W_ij x_fj^2 directly.  The expansion cancels where |z - x| << |z|: relative error
 // eps (|z|^2 + |x|^2) / |z - x|^2 in units of the scaled inputs - the same exposure as the MFMA distances themselves - so both x and
-// z are taken RELATIVE TO A CENTRE c (the workgroup's first inducing row): distances and IL do not change, |z|, |x| become the spread of
-// the data instead of its distance from the origin, and the row sums leave as Q = Q' + c R (fp64).  (Found by the one-point,
-// one-inducing-point case of test_gradient_degenerate_shapes: z = x + 1e-3, where the fp32 build lost IL altogether.)
+// z are taken RELATIVE TO A CENTRE c: distances and IL do not change, |z|, |x| become the spread of the data instead of its distance
+// from the origin, and the row sums leave as Q = Q' + c R (fp64).  (Found by the one-point, one-inducing-point case of
+// test_gradient_degenerate_shapes: z = x + 1e-3, where the fp32 build lost IL altogether.)  The centre of a feature is the MIDDLE OF THE
+// RANGE of the workgroup's 64 inducing rows (the valid ones).  What is left of the cancellation in IL_f is (|z_fi - c_f| / lengthscale)^2
+// times the fp32 rounding of the accumulated sums: with many inducing points per lengthscale (d = 1, M >= 128 over 8 lengthscales) that was
+// 10-45 x the error of the entry-by-entry VALU sums of rounds 2-5 on the fp32 lengthscale gradient (profiles/round6/fuzz_grad.md).  So for
+// d <= 4 the SPARE FEATURE SLOTS of the one feature tile carry the same feature about further centres - 8 / d centres per feature, evenly
+// spaced over the rows' range - and every inducing row takes IL_f and sum_j W_ij x_fj from the slot whose centre is nearest to it:
+// |z_fi - c| <= range / (2 * 8 / d), at no cost in the loop (the MFMAs of the slots were issued anyway, on zeros).
 // A wave owns 16 inducing rows for the whole slice of points (no cross-wave sums but the scalars), a workgroup 64 rows; the staged
 // tile is point-major with row stride DL + 16 bytes... (+6 / +4 elements): the r2 operand reads are conflict-free, and the pad columns
 // carry g_mu, 2 g_v and c1 |x|^2 of the point.  fp32: per staged block (128 points) sums in fp32 (MFMA accumulators included), totals fp64.
@@ -425,7 +431,7 @@ __global__ void __launch_bounds__(k256, 2) kgrad_mfma_kernel(KernelParams kp, co
                                                              int64_t n, int64_t nvalid, const T* __restrict__ Pt,
                                                              const T* __restrict__ gmu, const T* __restrict__ gv,
                                                              const T* __restrict__ alpha, int64_t slice_len,
-                                                             double* __restrict__ rowpart, double* __restrict__ scalpart, int kmb) {
+                                                             double* __restrict__ rowpart, double* __restrict__ scalpart, int kmb, int64_t M) {
   using M16 = Mfma16<T>;
   using acc_t = typename M16::acc_t;
   constexpr bool kF64 = (sizeof(T) == 8);
@@ -438,12 +444,40 @@ __global__ void __launch_bounds__(k256, 2) kgrad_mfma_kernel(KernelParams kp, co
   constexpr T ascale = (FAMILY == KSE) ? T(1) : T(-2);
   __shared__ __attribute__((aligned(16))) T xt[JB * XLD];
   __shared__ double sred[4][2 + 16 * CT];
-  __shared__ T cz[DL];                              // the centre: scaled inducing row blockIdx.y * 64 (zeros beyond d)
+  __shared__ T cz[DL];                              // the centre of a feature slot (zeros for the unused ones)
+  __shared__ T flo[SQ ? 8 : 1], finv[SQ ? 8 : 1];   // SQ: low end of a feature's range over the workgroup's rows, centres per unit length
+  __shared__ int sfeat[SQ ? 8 : 1];                 // SQ: the feature a slot carries (d: none)
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(int(threadIdx.x >> 6)), l15 = lane & 15, g = lane >> 4;
   const int d = kp.d;
   const T* __restrict__ invl = static_cast<const T*>(kp.invl);
   const int64_t iw0 = int64_t(blockIdx.y) * 64 + wave * 16, i = iw0 + l15;   // this lane's inducing row (tile column / A-operand row)
-  if (int(threadIdx.x) < DL) cz[threadIdx.x] = (int(threadIdx.x) < d) ? zs[int64_t(threadIdx.x) * Mp + int64_t(blockIdx.y) * 64] : T(0);
+  // SQ: slot s = k d + f < nslot carries feature f about its centre number k (k = 0: the one the distances use - the middle position)
+  const int nrep = SQ ? 8 / d : 1, nslot = SQ ? nrep * d : d;
+  auto slot_pos = [&](int k) { return (k + nrep / 2) % nrep; };   // position of centre k along the range
+  if (int(threadIdx.x) < DL) cz[threadIdx.x] = T(0);
+  if (SQ && int(threadIdx.x) < 8) sfeat[threadIdx.x] = int(threadIdx.x) < nslot ? int(threadIdx.x) % d : d;
+  __syncthreads();
+  for (int f = wave; f < d; f += 4) {   // range of feature f over the valid rows of the workgroup (a wave per feature, a lane per row)
+    const int64_t ri = int64_t(blockIdx.y) * 64 + lane;
+    const T v = ri < M ? zs[int64_t(f) * Mp + ri] : T(0);
+    T lo = ri < M ? v : T(INFINITY), hi = ri < M ? v : T(-INFINITY);
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      lo = fmin(lo, __shfl_xor(lo, o));
+      hi = fmax(hi, __shfl_xor(hi, o));
+    }
+    if (!(lo <= hi)) lo = hi = T(0);   // padding rows only
+    if constexpr (SQ) {
+      const T step = (hi - lo) / T(nrep);
+      if (lane < nrep) cz[lane * d + f] = lo + (T(slot_pos(lane)) + T(0.5)) * step;
+      if (lane == 0) {
+        flo[f] = lo;
+        finv[f] = hi > lo ? T(nrep) / (hi - lo) : T(0);
+      }
+    } else {
+      if (lane == 0) cz[f] = T(0.5) * (lo + hi);
+    }
+  }
   __syncthreads();
   const int64_t j0 = int64_t(blockIdx.x) * slice_len;
   int64_t j1 = j0 + slice_len;
@@ -487,12 +521,13 @@ __global__ void __launch_bounds__(k256, 2) kgrad_mfma_kernel(KernelParams kp, co
     __syncthreads();
     // stage the block: scaled inputs point-major, (g_mu, 2 g_v) of the point (zeros beyond the slice: P = 0 there), then c1 |x|^2
     for (int e = threadIdx.x; e < JB * DL; e += k256) {
-      const int c = e % JB, f = e / JB;
+      const int c = e % JB, sl = e / JB;                    // point, feature slot
+      const int f = SQ ? sfeat[sl] : sl;                    // the slot's feature (d: none)
       int64_t gg = jb + c;
       gg = gg < nvalid ? gg : nvalid - 1;
       T v = T(0);
-      if (f < d) v = (prescaled ? x[int64_t(f) * ldx + xoff + gg] : x[int64_t(f) * ldx + xoff + gg] * invl[f]) - cz[f];
-      xt[c * XLD + f] = v;
+      if (f < d) v = (prescaled ? x[int64_t(f) * ldx + xoff + gg] : x[int64_t(f) * ldx + xoff + gg] * invl[f]) - cz[sl];
+      xt[c * XLD + sl] = v;
     }
     if (threadIdx.x < JB) {
       const int64_t gg = jb + threadIdx.x;
@@ -505,7 +540,10 @@ __global__ void __launch_bounds__(k256, 2) kgrad_mfma_kernel(KernelParams kp, co
       const T* __restrict__ xp = xt + threadIdx.x * XLD;
       T s = T(0);
 #pragma unroll
-      for (int f = 0; f < DL; ++f) s = fma(xp[f], xp[f], s);
+      for (int f = 0; f < DL; ++f) {
+        const T v = (!SQ || f < d) ? xp[f] : T(0);   // (SQ: slots d .. 7 repeat features about other centres)
+        s = fma(v, v, s);
+      }
       xt[threadIdx.x * XLD + XN] = c1 * s;
     }
     __syncthreads();
@@ -619,7 +657,9 @@ __global__ void __launch_bounds__(k256, 2) kgrad_mfma_kernel(KernelParams kp, co
   double ilw[CT];
 #pragma unroll
   for (int c = 0; c < CT; ++c) {
-    const int f = SQ ? (l15 & 7) : (l15 + 16 * c);
+    const int sl = SQ ? (l15 & 7) : (l15 + 16 * c);                                // this lane's feature slot
+    const int f = SQ ? sfeat[sl] : sl;
+    [[maybe_unused]] const int pos = SQ ? slot_pos(sl / d) : 0;
     double il = 0.0;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -627,13 +667,22 @@ __global__ void __launch_bounds__(k256, 2) kgrad_mfma_kernel(KernelParams kp, co
       double q;
       if constexpr (kF64) { q = double(Q[0][c][r]); if constexpr (NQ == 2) q += double(Q[1][c][r]); }
       else q = Qd[c][r];
+      const T zrow = (f < d) ? zs[int64_t(f) * Mp + iw0 + row] : T(0);
+      bool sel = f < d;
+      if constexpr (SQ) {   // the row takes feature f from the slot whose centre is nearest to it
+        if (sel) {
+          int prow = int((zrow - flo[f]) * finv[f]);
+          prow = prow < 0 ? 0 : (prow > nrep - 1 ? nrep - 1 : prow);
+          sel = prow == pos;
+        }
+      }
       if (SQ && (l15 & 8)) {
-        il += q;                                             // sum_j W_ij x_fj^2
-      } else {
-        const double cf = double(cz[f]), Rr = sred[wave][2 + row];
-        const double zf = (f < d) ? double(zs[int64_t(f) * Mp + iw0 + row] - cz[f]) : 0.0;   // (the centred value as the tiles saw it)
+        il += sel ? q : 0.0;                                 // sum_j W_ij x_fj^2 (about the slot's centre)
+      } else if (sel) {
+        const double cf = double(cz[sl]), Rr = sred[wave][2 + row];
+        const double zf = double(zrow - cz[sl]);             // (the centred value as the tiles saw it)
         il += zf * (zf * Rr - 2.0 * q);
-        if (f < d) rp[int64_t(2 + f) * Mp + iw0 + row] += wsc * (q + cf * Rr);                // sum_j W_ij x_fj, uncentred
+        rp[int64_t(2 + f) * Mp + iw0 + row] += wsc * (q + cf * Rr);                           // sum_j W_ij x_fj, uncentred
       }
     }
     if constexpr (SQ) il += __shfl_xor(il, 8);               // lanes l15 < 8: feature l15 complete over the lane's rows
@@ -661,7 +710,11 @@ __global__ void __launch_bounds__(k256, 2) kgrad_mfma_kernel(KernelParams kp, co
   if (int(threadIdx.x) <= DL) {
     const int q = threadIdx.x;
     const int slot = q == 0 ? 0 : 1 + q;
-    const double v = ((sred[0][slot] + sred[1][slot]) + sred[2][slot]) + sred[3][slot];
+    double v = ((sred[0][slot] + sred[1][slot]) + sred[2][slot]) + sred[3][slot];
+    if constexpr (SQ) {   // feature q - 1: its further slots
+      if (q >= 1 && q - 1 < d)
+        for (int k = 1; k < nrep; ++k) v += ((sred[0][slot + k * d] + sred[1][slot + k * d]) + sred[2][slot + k * d]) + sred[3][slot + k * d];
+    }
     double* sp = scalpart + (int64_t(blockIdx.x) * gridDim.y + blockIdx.y) * (1 + DL);
     if (q == 0) sp[0] += var * v;
     else if (q - 1 < d) sp[q] += wsc * v;
@@ -793,10 +846,10 @@ __global__ void finish_kgrad_kernel(int d, int64_t M, int64_t Mp, const T* __res
 template <typename T, int FAMILY>
 void launch_kgrad_f(hipStream_t s, const KernelParams& kp, const T* zs, int64_t Mp, const T* x, int64_t ldx, int64_t xoff,
                     int prescaled, int64_t n, int64_t nvalid, const T* Pt, const T* gmu, const T* gv, const T* alpha,
-                    int64_t slice_len, int nslices, double* rowpart, double* scalpart, int kmb) {
+                    int64_t slice_len, int nslices, double* rowpart, double* scalpart, int kmb, int64_t M) {
   dim3 grid((unsigned)nslices, (unsigned)(Mp / 64));
 #define SVGP_KGM(DL) hipLaunchKernelGGL((kgrad_mfma_kernel<T, FAMILY, DL>), grid, dim3(k256), 0, s, kp, zs, Mp, x, ldx, xoff, prescaled, n, \
-                                        nvalid, Pt, gmu, gv, alpha, slice_len, rowpart, scalpart, kmb)
+                                        nvalid, Pt, gmu, gv, alpha, slice_len, rowpart, scalpart, kmb, M)
   if (kp.d <= 8) SVGP_KGM(8);
   else if (kp.d <= 16) SVGP_KGM(16);
   else if (kp.d <= 32) SVGP_KGM(32);
@@ -941,19 +994,19 @@ void launch_syrk_uniform(int dtype, hipStream_t s, const void* At, double w, dou
   });
 }
 
-void launch_kgrad(int dtype, hipStream_t s, const KernelParams& kp, const void* zs, int64_t Mp, const void* x, int64_t ldx,
+void launch_kgrad(int dtype, hipStream_t s, const KernelParams& kp, const void* zs, int64_t Mp, int64_t M, const void* x, int64_t ldx,
                   int64_t xoff, int prescaled, int64_t n, int64_t nvalid, const void* Pt, const void* gmu,
                   const void* gv, const void* alpha, int64_t slice_len, int nslices, double* rowpart, double* scalpart, int kmb) {
   GD(dtype, T, {
     if (kp.family == KSE)
       launch_kgrad_f<T, KSE>(s, kp, (const T*)zs, Mp, (const T*)x, ldx, xoff, prescaled, n, nvalid, (const T*)Pt,
-                             (const T*)gmu, (const T*)gv, (const T*)alpha, slice_len, nslices, rowpart, scalpart, kmb);
+                             (const T*)gmu, (const T*)gv, (const T*)alpha, slice_len, nslices, rowpart, scalpart, kmb, M);
     else if (kp.family == KM32)
       launch_kgrad_f<T, KM32>(s, kp, (const T*)zs, Mp, (const T*)x, ldx, xoff, prescaled, n, nvalid, (const T*)Pt,
-                              (const T*)gmu, (const T*)gv, (const T*)alpha, slice_len, nslices, rowpart, scalpart, kmb);
+                              (const T*)gmu, (const T*)gv, (const T*)alpha, slice_len, nslices, rowpart, scalpart, kmb, M);
     else
       launch_kgrad_f<T, KM52>(s, kp, (const T*)zs, Mp, (const T*)x, ldx, xoff, prescaled, n, nvalid, (const T*)Pt,
-                              (const T*)gmu, (const T*)gv, (const T*)alpha, slice_len, nslices, rowpart, scalpart, kmb);
+                              (const T*)gmu, (const T*)gv, (const T*)alpha, slice_len, nslices, rowpart, scalpart, kmb, M);
   });
 }
 

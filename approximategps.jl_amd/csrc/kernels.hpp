@@ -181,7 +181,7 @@ void launch_linv_t_gemv(int dtype, hipStream_t s, const void* LinvRM, const void
                         int vec_f64 = 0);
 // data part: Pt = the strips' unscaled R A, P_ij = alpha_i gmu_j + 2 gv_j Pt_ji formed inside (alpha != nullptr); Kuu part: Pt is
 // the matrix itself (alpha = gmu = gv = nullptr); kmb: also the row sums (Kuf g_mu)_i into slot 1 (the caller applies Lk^-1: A g_mu)
-void launch_kgrad(int dtype, hipStream_t s, const KernelParams& kp, const void* zs, int64_t Mp, const void* x, int64_t ldx,
+void launch_kgrad(int dtype, hipStream_t s, const KernelParams& kp, const void* zs, int64_t Mp, int64_t M, const void* x, int64_t ldx,
                   int64_t xoff, int prescaled, int64_t n, int64_t nvalid, const void* Pt, const void* gmu,
                   const void* gv, const void* alpha, int64_t slice_len, int nslices, double* rowpart, double* scalpart, int kmb = 0);
 // fused gradient path: sums of the per-strip partials, W = A diag(2 g_v) A' from its split-K lower tiles, (A g_mu), and the

@@ -68,3 +68,49 @@ def test_rank256_trailing_update_forced_at_every_pair():
                 os.environ.pop(k, None)
             else:
                 os.environ[k] = v
+
+
+# (points, inducing points, d, family, likelihood, seed): cases a randomised sweep (tests/fuzz_grad.py, seed 6) found, where the fp32
+# lengthscale gradient of the first MFMA form of the kernel-gradient reductions was 5e-3 ... 7e-2 away from the oracle against 1.5e-4 ... 1.5e-3
+# for the entry-by-entry VALU sums of rounds 2-5: many inducing points per lengthscale, so |z - centre|^2 / lengthscale^2 multiplied the
+# fp32 rounding of the accumulated sums in IL = sum z^2 R - 2 z Q + sum x^2 W.  With 8 / d centres per feature in the spare slots of the
+# feature tile (grad.hip) they are 2e-4 ... 4e-3 (profiles/round6/fuzz_grad.md).
+DENSE_INDUCING_FP32 = [
+    (127, 129, 1, o.KERNEL_MATERN52, o.LIK_GAUSSIAN, 927227814, 2e-3),
+    (33, 200, 1, o.KERNEL_MATERN52, o.LIK_GAUSSIAN, 536005819, 3e-3),
+    (65, 640, 1, o.KERNEL_MATERN32, o.LIK_GAUSSIAN, 191970586, 4e-3),
+    (2049, 511, 1, o.KERNEL_MATERN32, o.LIK_GAUSSIAN, 827967779, 3e-3),
+]
+
+
+@pytest.mark.parametrize("N,M,d,family,lik,seed,tol", DENSE_INDUCING_FP32)
+def test_fp32_lengthscale_gradient_with_many_inducing_points_per_lengthscale(ctx, N, M, d, family, lik, seed, tol):
+    x, y, sva, s2 = o.synth_problem(seed, N, M, d, family=family, lik=lik, dtype=np.float32)
+    sva.mean_const = 0.1
+    _, g_ref = o.elbo_grad(sva, x, y, lik=lik, sigma2=s2, num_data=2.5 * N)
+    model = device_model(ctx, sva, dtype=np.float32, lik=lik, sigma2=s2)
+    data = _ffi.DeviceData(ctx, x, y, np.float32)
+    _, _, g = model.elbo_grad(data, 0, N, 2.5 * N)
+    model.free()
+    data.free()
+    assert abs(g["inv_lengthscale"][0] - g_ref["inv_lengthscale"][0]) <= tol * abs(g_ref["inv_lengthscale"][0])
+
+
+@pytest.mark.parametrize("d", [1, 2, 3, 4, 5, 8])
+@pytest.mark.parametrize("dtype,tol", [(np.float64, 1e-9), (np.float32, 5e-3)])
+def test_every_centre_count_of_the_feature_slots(ctx, d, dtype, tol):
+    """8 / d centres per feature (8, 4, 2, 2, 1, 1 at d = 1, 2, 3, 4, 5, 8), several row blocks, a ragged last block of inducing rows and a
+    batch that is not a multiple of the 128-point stage: every gradient block against the oracle."""
+    N, M = 1301, 200
+    x, y, sva, s2 = o.synth_problem(4000 + d, N, M, d, family=o.KERNEL_SE, dtype=dtype)
+    _, g_ref = o.elbo_grad(sva, x, y, sigma2=s2, num_data=float(N))
+    model = device_model(ctx, sva, dtype=dtype, sigma2=s2)
+    data = _ffi.DeviceData(ctx, x, y, dtype)
+    _, _, g = model.elbo_grad(data, 0, N, float(N))
+    model.free()
+    data.free()
+    gz = g["z"].reshape(g_ref["z"].shape, order="F") if d > 1 else g["z"]
+    zr = g_ref["z"] if d > 1 else g_ref["z"][0]
+    for a, b in ((gz, zr), (g["inv_lengthscale"], g_ref["inv_lengthscale"]), ([g["variance"]], [g_ref["variance"]]), (g["m"], g_ref["m"])):
+        a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+        assert np.abs(a - b).max() <= tol * np.abs(b).max(), (d, np.abs(a - b).max(), np.abs(b).max())
