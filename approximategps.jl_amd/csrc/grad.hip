@@ -596,12 +596,12 @@ __global__ void __launch_bounds__(k256, 2) kgrad_mfma_kernel(KernelParams kp, co
         const T p = fma(gv2[r], pv[r], al * gm[r]);   // (alpha == nullptr: 1 * pv + 0; beyond the slice: 0)
         if constexpr (FAMILY == KSE) {
           // unit variance and without the factor -1/2 of dK/dr2: both are applied to the sums at the end (sum P o K = sum_i of the R_i here)
-          const T e = kexp(a[r] < T(0) ? a[r] : T(0));
+          const T e = kexp(a[r] > T(0) ? T(0) : a[r]);
           w[r] = p * e;
           if (kmb) MBl = fma(e, gm[r], MBl);
         } else {
           T k, dk;
-          kappa_and_d<T, FAMILY>(a[r] > T(0) ? a[r] : T(0), T(1), k, dk);
+          kappa_and_d<T, FAMILY>(a[r] < T(0) ? T(0) : a[r], T(1), k, dk);
           w[r] = p * dk;
           S1l = fma(p, k, S1l);
           if (kmb) MBl = fma(k, gm[r], MBl);

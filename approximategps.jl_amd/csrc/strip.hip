@@ -115,8 +115,8 @@ __device__ __forceinline__ void pregen_mfma(const T* __restrict__ xs, const T* _
         const int64_t k = k0 + M16::row(lane, r);
         const T v = acc[r];
         T out;
-        if constexpr (SVGP_PREGEN_EXPTAB && F == KSE && sizeof(T) == 8) out = T(kexp_tab(double(v < c0 ? v : c0), exptab));
-        else out = (F == KSE) ? kexp(v < c0 ? v : c0) : kappa<T>(F, v > T(0) ? v : T(0), variance);
+        if constexpr (SVGP_PREGEN_EXPTAB && F == KSE && sizeof(T) == 8) out = T(kexp_tab(double(v > c0 ? c0 : v), exptab));
+        else out = (F == KSE) ? kexp(v > c0 ? c0 : v) : kappa<T>(F, v < T(0) ? T(0) : v, variance);
         work[k * NT + jt * 16 + l15] = (k < M) ? out : T(0);
       }
     }
@@ -825,7 +825,7 @@ __global__ void __launch_bounds__(k256, 2) kuf_kernel(KernelParams kp, const T* 
 #pragma unroll
         for (int e = 0; e < VEC; ++e) {
           const T v = acc[g * VEC + e][r];
-          out[e] = (FAMILY == KSE) ? kexp(v < c0 ? v : c0) : kappa<T>(FAMILY, v > T(0) ? v : T(0), variance);
+          out[e] = (FAMILY == KSE) ? kexp(v > c0 ? c0 : v) : kappa<T>(FAMILY, v < T(0) ? T(0) : v, variance);
         }
         const int64_t i = ibase + g * (16 * VEC) + c * VEC;
         T* dst = K + j * M + i;
@@ -966,8 +966,8 @@ __global__ void __launch_bounds__(512, 2) kuf_cols_kernel(KernelParams kp, const
 #pragma unroll
             for (int e = 0; e < VEC; ++e) {
               const T v = acc[g * VEC + e][r];
-              if constexpr (kTab) out[e] = T(kexp_tab(double(v < c0 ? v : c0), s_exptab));
-              else out[e] = (FAMILY == KSE) ? kexp(v < c0 ? v : c0) : kappa<T>(FAMILY, v > T(0) ? v : T(0), variance);
+              if constexpr (kTab) out[e] = T(kexp_tab(double(v > c0 ? c0 : v), s_exptab));
+              else out[e] = (FAMILY == KSE) ? kexp(v > c0 ? c0 : v) : kappa<T>(FAMILY, v < T(0) ? T(0) : v, variance);
             }
             *reinterpret_cast<V*>(dst0[r] + rc * CH + g * (16 * VEC)) = out;
           }
@@ -982,8 +982,8 @@ __global__ void __launch_bounds__(512, 2) kuf_cols_kernel(KernelParams kp, const
 #pragma unroll
           for (int e = 0; e < VEC; ++e) {
             const T v = acc[g * VEC + e][r];
-            if constexpr (kTab) out[e] = T(kexp_tab(double(v < c0 ? v : c0), s_exptab));
-            else out[e] = (FAMILY == KSE) ? kexp(v < c0 ? v : c0) : kappa<T>(FAMILY, v > T(0) ? v : T(0), variance);
+            if constexpr (kTab) out[e] = T(kexp_tab(double(v > c0 ? c0 : v), s_exptab));
+            else out[e] = (FAMILY == KSE) ? kexp(v > c0 ? c0 : v) : kappa<T>(FAMILY, v < T(0) ? T(0) : v, variance);
           }
           const int64_t i = ibase + g * (16 * VEC) + c * VEC;
           T* dst = dst0[r] + rc * CH + g * (16 * VEC);

@@ -114,3 +114,31 @@ def test_every_centre_count_of_the_feature_slots(ctx, d, dtype, tol):
     for a, b in ((gz, zr), (g["inv_lengthscale"], g_ref["inv_lengthscale"]), ([g["variance"]], [g_ref["variance"]]), (g["m"], g_ref["m"])):
         a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
         assert np.abs(a - b).max() <= tol * np.abs(b).max(), (d, np.abs(a - b).max(), np.abs(b).max())
+
+
+@pytest.mark.parametrize("family", [o.KERNEL_SE, o.KERNEL_MATERN32, o.KERNEL_MATERN52])
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_a_nan_coordinate_reaches_the_results(ctx, dtype, family):
+    """x with one NaN coordinate: the reference's arithmetic gives NaN marginals for that point and a NaN ELBO.  The clamps of the
+    MFMA distance tiles (min(v, c0) for SE, max(r2, 0) for Matern) used to return the clamp value for a NaN - a FINITE value for hostile
+    data (found by tests/fuzz_errors.py); they now let it through.  The other points are untouched, bit for bit."""
+    N, M, d, bad = 700, 90, 3, 333
+    x, y, sva, s2 = o.synth_problem(6100 + family, N, M, d, family=family, dtype=dtype)
+    xb = x.copy()
+    xb[1, bad] = np.nan
+    model = device_model(ctx, sva, dtype=dtype, sigma2=s2)
+    clean, dirty = _ffi.DeviceData(ctx, x, y, dtype), _ffi.DeviceData(ctx, xb, y, dtype)
+    mu0, v0 = model.marginals(clean)
+    mu1, v1 = model.marginals(dirty)
+    assert np.isnan(mu1[bad]) and np.isnan(v1[bad])
+    keep = np.arange(N) != bad
+    assert np.array_equal(mu0[keep], mu1[keep]) and np.array_equal(v0[keep], v1[keep])
+    assert not np.isfinite(model.elbo(dirty, 0, N, float(N))[0])
+    val, _, g = model.elbo_grad(dirty, 0, N, float(N))
+    assert not np.isfinite(val) and not np.isfinite(g["inv_lengthscale"]).any() and not np.isfinite(np.asarray(g["m"])).any()
+    K = model.kuf(dirty)
+    assert np.isnan(K[:, bad]).all() and np.isfinite(K[:, keep]).all()
+    # a window without the point is the clean result
+    assert model.elbo(dirty, 0, bad, float(N))[0] == model.elbo(clean, 0, bad, float(N))[0]
+    for h in (model, clean, dirty):
+        h.free()
