@@ -1,6 +1,6 @@
 """Randomised parity sweep of svgp_elbo / svgp_elbo_grad against the oracle (round 6: the kernel-gradient reductions are new).
 
-    python tests/fuzz_grad.py [--seconds 420] [--seed 6]
+    python tests/fuzz_grad.py [--seconds 420] [--seed 6] [--large]
 
 Draws (points, inducing points, input dimension, kernel family, likelihood, quadrature, parametrisation, dtype, window) at random -
 ragged and degenerate shapes included - and compares value and every gradient block with oracle/svgp_oracle.py.  Tolerances are the
@@ -26,6 +26,17 @@ from helpers import device_model, rel  # noqa: E402
 LIKS = [o.LIK_GAUSSIAN, o.LIK_GAUSSIAN, o.LIK_BERNOULLI_LOGISTIC, o.LIK_POISSON_EXP, o.LIK_EXPONENTIAL_EXP, o.LIK_GAMMA_EXP,
         o.LIK_BERNOULLI_NORMCDF]
 FAMS = [o.KERNEL_SE, o.KERNEL_MATERN32, o.KERNEL_MATERN52]
+
+
+def draw_large(rng):
+    """Shapes of the multi-launch plans: several gradient chunks (N > 65 536 / its fp32 and M-dependent equivalents), ragged tails of
+    half-width strips, six and more factorisation panels (strips beside the factorisation), windows that start inside a chunk."""
+    M = int(rng.choice([640, 1000, 1024, 1100, 1536, 2048]))
+    N = int(rng.choice([20000, 40000, 65536, 65537, 70001, 100000]))   # (the oracle holds a dozen M x N fp64 arrays: <= 1.6 GB each)
+    off = int(rng.integers(0, N // 2))
+    return dict(N=N, M=M, d=int(rng.choice([1, 3, 8, 9, 16, 20, 33])), family=int(rng.choice(FAMS)), lik=int(rng.choice(LIKS)),
+                qn=int(rng.choice([0, 0, 7])), centered=bool(rng.random() < 0.2), dtype=np.float32 if rng.random() < 0.4 else np.float64,
+                window=bool(rng.random() < 0.4), off=off, nb=int(rng.integers(1, N - off + 1)), seed=int(rng.integers(1, 1 << 30)))
 
 
 def draw(rng):
@@ -54,8 +65,8 @@ def run_case(ctx, c):
         sva = o.SVA(sva.kernel, sva.z, tame * (sva.m + 0.3), 0.7 * tame * sva.Lq, jitter=jit, mean_const=0.15, centered=True)
     off, nb = 0, N
     if c["window"] and N > 4:
-        off = N // 3
-        nb = max(1, N // 2)
+        off = c.get("off", N // 3)
+        nb = c.get("nb", max(1, N // 2))
     xs, ys = (x[:, off:off + nb] if x.ndim == 2 else x[off:off + nb]), y[off:off + nb]
     val_ref, g_ref = o.elbo_grad(sva, xs, ys, lik=lik, sigma2=s2, num_data=2.5 * N, quadrature_n=c["qn"])
     model = device_model(ctx, sva, dtype=dtype, lik=lik, sigma2=s2, quadrature_n=c["qn"])
@@ -83,12 +94,13 @@ def main():
     ap.add_argument("--seconds", type=float, default=420.0)
     ap.add_argument("--seed", type=int, default=6)
     ap.add_argument("--max-cases", type=int, default=100000)
+    ap.add_argument("--large", action="store_true", help="M 640 ... 2500, N 20 000 ... 150 000 (seconds per case: the oracle)")
     args = ap.parse_args()
     rng = np.random.default_rng(args.seed)
     ctx = _ffi.Context(0)
     t0, n, bad, worst = time.time(), 0, [], {}
     while time.time() - t0 < args.seconds and n < args.max_cases:
-        c = draw(rng)
+        c = draw_large(rng) if args.large else draw(rng)
         f64 = c["dtype"] == np.float64
         vtol, gtol = (1e-8, 1e-6) if f64 else (1e-4, 5e-3)
         tag = {k: (v.__name__ if k == "dtype" else v) for k, v in c.items()}
