@@ -4,7 +4,7 @@ shard form, host-evaluated likelihood), svgp_marginals, svgp_predict, free - eve
 grown for one shape and reused for another, the prepared flag of a model across updates, the second stream's scratch between a large and
 a small batch, pinned staging reused across models.  (tests/fuzz_grad.py / fuzz_forward.py create and free one model per case.)
 
-    python tests/fuzz_stateful.py [--seconds 300] [--seed 26]
+    python tests/fuzz_stateful.py [--seconds 300] [--seed 26] [--slots 4] [--comm]
 
 A script for the GPU box, not a pytest file; the oracle is the checker.  Exit code 1 when a result is outside its tolerance."""
 import argparse
@@ -147,9 +147,13 @@ def main():
     ap.add_argument("--seconds", type=float, default=300.0)
     ap.add_argument("--seed", type=int, default=26)
     ap.add_argument("--slots", type=int, default=4)
+    ap.add_argument("--comm", action="store_true", help="attach an RCCL communicator of ONE rank: every evaluation takes the collective forms "
+                    "(opening all-reduce with the failure flag, device-resident batch size, grouped gradient all-reduce)")
     args = ap.parse_args()
     rng = np.random.default_rng(args.seed)
     ctx = _ffi.Context(0)
+    if args.comm:
+        ctx.attach_comm(_ffi.comm_unique_id(), 1, 0)
     slots, t0, n, bad, worst = [], time.time(), 0, [], {}
     while time.time() - t0 < args.seconds:
         r = rng.random()
