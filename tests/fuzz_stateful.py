@@ -109,6 +109,7 @@ def step(rng, s):
     xs = s.x[:, off:off + nb] if s.x.ndim == 2 else s.x[off:off + nb]
     ys = s.y[off:off + nb]
     op = str(rng.choice(["elbo", "grad", "grad", "shard", "ext", "marginals", "predict"]))
+    s.last_window = (off, nb)
     nd = float(rng.choice([0.0, 3.0 * s.N]))
     kw = dict(lik=s.lik, sigma2=s.s2, num_data=nd if nd else None)
     if op == "elbo":
@@ -183,7 +184,7 @@ def main():
         for k, v in errs.items():
             key = (op, k, "f64" if f64 else "f32")
             worst[key] = max(worst.get(key, 0.0), v)
-        print("OP", n, op, s.tag(), "FAIL" if fails else "ok", {k: f"{v:.1e}" for k, v in (fails or errs).items()}, flush=True)
+        print("OP", n, op, s.tag(), "window", s.last_window, "FAIL" if fails else "ok", {k: f"{v:.1e}" for k, v in (fails or errs).items()}, flush=True)
         if fails:
             bad.append((n, op, s.tag(), fails))
         n += 1
