@@ -206,7 +206,10 @@ int32_t svgp_model_free(svgp_ctx* ctx, svgp_model* model);
 /* ---- elbo(sva, lfx, y; num_data, quadrature)  replaces SVA:340-360 (and :307-317, :276-280) --- */
 /* evaluates points [batch_off, batch_off + batch_len) of `data`; num_data <= 0 means batch_len.
  * On a context with a communicator: COLLECTIVE — every rank passes its own shard's batch and gets the global
- * ELBO = (sum over all ranks' points) * num_data / n_global - KL; terms_out->n_points = n_global. */
+ * ELBO = (sum over all ranks' points) * num_data / n_global - KL; terms_out->n_points = n_global.
+ * Non-finite numbers are NOT an error, as in the reference: a NaN coordinate of x gives NaN marginals for that point (and only that
+ * point) and a NaN ELBO, an infinite y an infinite ELBO, a zero on the diagonal of Lq KL = +Inf - the status is SVGP_OK and the numbers say
+ * it; a NaN in z or in a kernel parameter makes Kuu NaN and cholesky(Kuu) reports SVGP_NOT_POSDEF as LAPACK does (tests/fuzz_errors.py). */
 int32_t svgp_elbo(svgp_ctx* ctx, svgp_model* model, const svgp_data* data, int64_t batch_off,
                   int64_t batch_len, double num_data, double* elbo_out, svgp_terms* terms_out);
 /* data-parallel shard: only Σ_i E[log p(y_i|f_i)] over the shard's points (no scale, no KL), so that
