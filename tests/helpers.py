@@ -45,6 +45,13 @@ def context_with_env(**env):
         c.close()
 
 
+def ambient_on(name: str) -> bool:
+    """The ambient value of an operational 0 / 1 setting (default 1): what a context created WITHOUT context_with_env carries.  The
+    suite also runs under SVGP_OVERLAP=0, SVGP_SEG_SPLIT=0, SVGP_TIMING=0 (profiles/round6/gputest_settings.log); assertions about the
+    timing record or about the overlapped path being taken on such a context ask this first."""
+    return os.environ.get(name, "1") != "0"
+
+
 def experiments_build() -> bool:
     """True when the loaded library is the experiments build (tools/build_experiments.sh, SVGP_MI355X_LIB=...): it alone exports
     svgp_debug_experiments and honours the tuning / A-B environment knobs."""
