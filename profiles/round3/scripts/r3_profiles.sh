@@ -4,4 +4,4 @@ cd $GRAFT_REPO_ROOT
 for C in H C2 C4 C5; do bash tools/run_profile.sh ${C}_r3 $C > gpurun_out/prof_${C}_r3.log 2>&1; tail -1 gpurun_out/prof_${C}_r3.log | cut -c1-200; done
 bash tools/run_profile.sh Hgrad_r3 H grad > gpurun_out/prof_Hgrad_r3.log 2>&1
 bash tools/run_profile.sh C5grad_r3 C5 grad > gpurun_out/prof_C5grad_r3.log 2>&1
-python tools/small_time.py > gpurun_out/r3/small_time.log 2>&1; tail -2 gpurun_out/r3/small_time.log
+python tests/small_time.py > gpurun_out/r3/small_time.log 2>&1; tail -2 gpurun_out/r3/small_time.log

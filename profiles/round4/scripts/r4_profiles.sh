@@ -16,5 +16,5 @@ timeout 600 python tools/overlap_time.py f64 2>&1 | grep "n=" | tee $O/overlap_f
 timeout 600 python tools/overlap_time.py f32 2>&1 | grep "n=" | tee $O/overlap_f32.log
 timeout 600 python tools/overlap_grad_time.py f64 2>&1 | grep "n=" | tee $O/overlap_grad_f64.log
 timeout 600 python tools/overlap_grad_time.py f32 2>&1 | grep "n=" | tee $O/overlap_grad_f32.log
-timeout 900 python tools/small_time.py > $O/small_time.log 2>&1; cp gpurun_out/small_problems.md $O/ 2>/dev/null; tail -3 $O/small_time.log
+timeout 900 python tests/small_time.py > $O/small_time.log 2>&1; cp gpurun_out/small_problems.md $O/ 2>/dev/null; tail -3 $O/small_time.log
 timeout 900 python bench.py > $O/bench_H_final.json 2> $O/bench_H_final.err; cut -c1-300 $O/bench_H_final.json

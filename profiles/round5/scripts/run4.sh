@@ -12,7 +12,7 @@ done
 done
 for v in p_base p_both; do
   SVGP_MI355X_LIB=$L/libsvgp_$v.so python tools/prep_time.py 2>&1 | grep -v "^RCCL\|^HIP\|^ROCm\|^Hostname\|^Librccl" >> gpurun_out/r5/potf2_ab.log
-  SVGP_MI355X_LIB=$L/libsvgp_$v.so python tools/round5/chol_accuracy.py 2>&1 | grep -v "^RCCL\|^HIP\|^ROCm\|^Hostname\|^Librccl" >> gpurun_out/r5/potf2_ab.log
+  SVGP_MI355X_LIB=$L/libsvgp_$v.so python tests/chol_accuracy.py 2>&1 | grep -v "^RCCL\|^HIP\|^ROCm\|^Hostname\|^Librccl" >> gpurun_out/r5/potf2_ab.log
   SVGP_MI355X_LIB=$L/libsvgp_$v.so python tools/chol_check.py 2>&1 | grep -v "^RCCL\|^HIP\|^ROCm\|^Hostname\|^Librccl" | tail -n 3 >> gpurun_out/r5/potf2_ab.log
 done
 grep -v "^  block" gpurun_out/r5/potf2_ab.log

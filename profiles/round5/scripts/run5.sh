@@ -13,6 +13,6 @@ done
 for v in p_tail7 p_r5d; do
   SVGP_MI355X_LIB=$L/libsvgp_$v.so python tools/prep_time.py 2>&1 | grep -v "^RCCL\|^HIP\|^ROCm\|^Hostname\|^Librccl" >> gpurun_out/r5/potf2_ab3.log
 done
-SVGP_MI355X_LIB=$L/libsvgp_p_r5d.so python tools/round5/chol_accuracy.py 2>&1 | grep -v "^RCCL\|^HIP\|^ROCm\|^Hostname\|^Librccl" >> gpurun_out/r5/potf2_ab3.log
+SVGP_MI355X_LIB=$L/libsvgp_p_r5d.so python tests/chol_accuracy.py 2>&1 | grep -v "^RCCL\|^HIP\|^ROCm\|^Hostname\|^Librccl" >> gpurun_out/r5/potf2_ab3.log
 SVGP_MI355X_LIB=$L/libsvgp_p_r5d.so python tools/chol_check.py 2>&1 | grep -v "^RCCL\|^HIP\|^ROCm\|^Hostname\|^Librccl" >> gpurun_out/r5/potf2_ab3.log
 grep -v "^  block [1-6]" gpurun_out/r5/potf2_ab3.log | cut -c1-260

@@ -1,6 +1,6 @@
 """Two-level blocked Cholesky (large Kuu, fp32) against the one-level loop: same process (separate model builds per knob via
 subprocess is not needed: the knob is read once per process, so this script is run once per setting), prints ms_chol and the ELBO /
-posterior checks.  usage: SVGP_CHOL_TWO_LEVEL=0|1 python tools/chol2_check.py"""
+posterior checks.  usage: SVGP_CHOL_TWO_LEVEL=0|1 python tests/chol2_check.py"""
 import os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

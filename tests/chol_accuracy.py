@@ -3,7 +3,7 @@
 SVGP_MI355X_LIB (A/B builds of the block factorisation must not move these)."""
 import os, sys
 R = os.path.dirname(os.path.abspath(__file__))
-for p in ("approximategps.jl_amd", "oracle", "tests"): sys.path.insert(0, os.path.join(R, "..", "..", p))
+for p in ("approximategps.jl_amd", "oracle", "tests"): sys.path.insert(0, os.path.join(R, "..", p))
 import numpy as np, svgp_oracle as o
 from approxgp import _ffi
 from helpers import device_model

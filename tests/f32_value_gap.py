@@ -5,7 +5,7 @@ fp64 oracle where it is affordable, for the bench configurations (reduced N) and
 1e-6 of the prior's: q(u) close to the exact posterior of a low-noise problem)."""
 import os, sys
 R = os.path.dirname(os.path.abspath(__file__))
-for p in ("approximategps.jl_amd", "oracle", "tests"): sys.path.insert(0, os.path.join(R, "..", "..", p))
+for p in ("approximategps.jl_amd", "oracle", "tests"): sys.path.insert(0, os.path.join(R, "..", p))
 import numpy as np, svgp_oracle as o
 from approxgp import _ffi
 from helpers import device_model

@@ -10,7 +10,7 @@ For each (resident N, batch, M, d): wall time per call of
 Writes a markdown table + JSON to gpurun_out/small_problems.{md,json}."""
 import ctypes as C, json, os, sys, time
 R = os.path.dirname(os.path.abspath(__file__))
-sys.path.insert(0, os.path.join(R, "..")); sys.path.insert(0, os.path.join(R, "..", "approximategps.jl_amd")); sys.path.insert(0, os.path.join(R, "..", "oracle"))
+sys.path.insert(0, os.path.join(R, "..")); sys.path.insert(0, os.path.join(R, "..", "approximategps.jl_amd")); sys.path.insert(0, os.path.join(R, "..", "oracle"))  # (R = tests/)
 import numpy as np
 import torch  # noqa: F401  (HIP runtime load order)
 import svgp_oracle as o
