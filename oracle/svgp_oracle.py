@@ -297,8 +297,14 @@ def marginals(post: Posterior, x: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
 # expected log-likelihood  [dep GPLikelihoods 0.4]; call site SVA:355
 # ----------------------------------------------------------------------------
 def gausshermite(n: int) -> Tuple[np.ndarray, np.ndarray]:
-    """[dep] FastGaussQuadrature.gausshermite(n): physicists' weight exp(-x^2)."""
-    return np.polynomial.hermite.hermgauss(n)
+    """[dep] FastGaussQuadrature.gausshermite(n): physicists' weight exp(-x^2).  numpy's Golub-Welsch rule up to n = 200; above that its
+    companion-matrix scaling overflows (n >= ~370 raises), so scipy.special.roots_hermite (asymptotic initial values + Newton) takes over -
+    the two agree to 1e-13 in the nodes and 1e-11 relative in the weights where both work (tests/test_abi_cpu.py)."""
+    if n <= 200:
+        return np.polynomial.hermite.hermgauss(n)
+    from scipy.special import roots_hermite
+
+    return roots_hermite(n)
 
 
 def loglik(lik: int, f: np.ndarray, y: np.ndarray, sigma2: float = 1.0) -> np.ndarray:

@@ -35,6 +35,27 @@ def test_gausshermite_matches_numpy():
         x2, w2 = np.polynomial.hermite.hermgauss(n)
         np.testing.assert_allclose(xs, x2, atol=1e-13)
         np.testing.assert_allclose(ws, w2, rtol=1e-11)
+    # the largest orders the C-ABI takes (quadrature_n <= 512), against scipy's rule (numpy's overflows from n ~ 370) and the moments of
+    # exp(-x^2); the oracle's gausshermite switches to scipy above 200 and must agree with numpy where both work
+    from scipy.special import roots_hermite
+
+    for n in (150, 200, 370, 512):
+        xs, ws = approxgp.gausshermite(n)
+        order = np.argsort(xs)
+        xs, ws = np.asarray(xs)[order], np.asarray(ws)[order]
+        xr, wr = roots_hermite(n)
+        np.testing.assert_allclose(xs, xr, atol=5e-13)
+        big = wr > 1e-300
+        np.testing.assert_allclose(ws[big], wr[big], rtol=1e-10)
+        for k, mom in ((0, 1.0), (2, 0.5), (4, 0.75), (6, 1.875)):
+            assert abs((ws * xs**k).sum() / np.sqrt(np.pi) - mom) < 1e-13 * max(1.0, mom), (n, k)
+    import svgp_oracle as o
+
+    x1, w1 = o.gausshermite(200)
+    x2, w2 = roots_hermite(200)
+    np.testing.assert_allclose(x1, x2, atol=5e-13)
+    np.testing.assert_allclose(w1[w2 > 1e-300], w2[w2 > 1e-300], rtol=1e-10)
+    assert len(o.gausshermite(512)[0]) == 512
     with pytest.raises(ValueError):
         approxgp.gausshermite(0)
 
