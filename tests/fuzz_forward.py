@@ -2,7 +2,7 @@
 svgp_predict_cross_cov, svgp_kuf, svgp_posterior, svgp_prior_kl - shapes, kernel family, parametrisation, dtype and batch window drawn
 at random (ragged and degenerate ones included), as tests/fuzz_grad.py does for value and gradient.
 
-    python tests/fuzz_forward.py [--seconds 300] [--seed 16]
+    python tests/fuzz_forward.py [--seconds 300] [--seed 16] [--large]
 
 Errors are max |device - oracle| over an array divided by max(|oracle|, floor); tolerances: fp64 1e-7 (alpha and the Centered B carry
 cond(Lk)); fp32 3e-3, and 2e-2 for alpha = Lk^-T m and the means that are k' alpha (eps * cond(Lk): with 500 inducing points in one or
@@ -32,6 +32,12 @@ def draw(rng):
                 N=int(rng.choice([1, 2, 15, 16, 17, 31, 33, 63, 64, 65, 127, 129, 500, 1000, 1023, 1025, 2049])),
                 family=int(rng.choice(FAMS)), centered=bool(rng.random() < 0.3),
                 dtype=np.float32 if rng.random() < 0.4 else np.float64, seed=int(rng.integers(1, 1 << 30)))
+
+
+def draw_large(rng):
+    c = draw(rng)
+    c.update(M=int(rng.choice([1000, 1024, 1536, 2048, 3000])), N=int(rng.choice([5000, 20000, 65537])), d=int(rng.choice([1, 3, 8, 16, 33, 64])))
+    return c
 
 
 def err(a, b, floor=1e-6):
@@ -81,12 +87,13 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=300.0)
     ap.add_argument("--seed", type=int, default=16)
+    ap.add_argument("--large", action="store_true", help="M 1000 ... 3000, N 5000 ... 65 537")
     args = ap.parse_args()
     rng = np.random.default_rng(args.seed)
     ctx = _ffi.Context(0)
     t0, n, bad, worst = time.time(), 0, [], {}
     while time.time() - t0 < args.seconds:
-        c = draw(rng)
+        c = draw_large(rng) if args.large else draw(rng)
         f64 = c["dtype"] == np.float64
         tol = 1e-7 if f64 else 3e-3
         tag = {k: (v.__name__ if k == "dtype" else v) for k, v in c.items()}
